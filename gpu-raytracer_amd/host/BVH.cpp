@@ -1,0 +1,369 @@
+#include "BVH.h"
+#include "Mesh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+// ---------------------------------------------------------------------------------------------
+// SAH builder
+// ---------------------------------------------------------------------------------------------
+
+SAHBuilder::SAHBuilder(BVH2 & bvh, size_t primitive_count) : bvh(bvh) {
+	for (int d = 0; d < 3; d++) {
+		sorted[d].resize(primitive_count);
+		for (size_t i = 0; i < primitive_count; i++) sorted[d][i] = int(i);
+	}
+	sweep_cost   .resize(primitive_count);
+	partition_tmp.resize(primitive_count);
+	goes_left    .resize(primitive_count);
+	bvh.nodes.reserve(2 * primitive_count);
+}
+
+// Monotone float -> unsigned key (the reference radix-sorts on it, Core/Sort.h:133-140),
+// so -0.0 orders before +0.0 and the sort is stable on equal keys.
+static inline unsigned float_sort_key(float x) {
+	unsigned u; memcpy(&u, &x, 4);
+	unsigned mask = unsigned(-int(u >> 31)) | 0x80000000u;
+	return u ^ mask;
+}
+
+namespace {
+struct Split {
+	int   index = -1;     // first primitive (position in the sorted list) of the right side
+	int   axis  = -1;
+	float cost  = INFINITY;
+	AABB  left  = AABB::create_empty();
+	AABB  right = AABB::create_empty();
+};
+
+struct BuildContext {
+	SAHBuilder & b;
+	const std::vector<AABB> & prim_aabb;
+
+	// Evaluate every object split along every axis (reference: BVHPartitions.cpp:6-54).
+	// '<=' keeps the LAST best candidate, i.e. later axes and smaller indices win ties.
+	Split find_split(int first, int count) const {
+		Split s;
+		float * partial = b.sweep_cost.data();
+		for (int axis = 0; axis < 3; axis++) {
+			const int * order = b.sorted[axis].data();
+			AABB grow_l = AABB::create_empty();
+			for (int i = 1; i < count; i++) {
+				grow_l.expand(prim_aabb[order[first + i - 1]]);
+				partial[i] = grow_l.surface_area() * float(i);
+			}
+			AABB grow_r = AABB::create_empty();
+			for (int i = count - 1; i > 0; i--) {
+				grow_r.expand(prim_aabb[order[first + i]]);
+				float c = partial[i] + grow_r.surface_area() * float(count - i);
+				if (c <= s.cost) {
+					s.cost  = c;
+					s.index = first + i;
+					s.axis  = axis;
+					s.right = grow_r;
+				}
+			}
+		}
+		const int * order = b.sorted[s.axis].data();
+		for (int i = first; i < s.index; i++) s.left.expand(prim_aabb[order[i]]);
+		return s;
+	}
+
+	void build_node(int node_index, int first, int count) {
+		if (count == 1) { // always split down to one primitive per leaf (SAHBuilder.cpp:15-24)
+			BVHNode2 & leaf = b.bvh.nodes[node_index];
+			leaf.first = first;
+			leaf.count = 1;
+			return;
+		}
+		Split s = find_split(first, count);
+
+		const int * split_order = b.sorted[s.axis].data();
+		for (int i = first;   i < s.index;       i++) b.goes_left[split_order[i]] = 1;
+		for (int i = s.index; i < first + count; i++) b.goes_left[split_order[i]] = 0;
+
+		// Stable partition of the other two orderings so that they stay sorted per side.
+		int n_left = s.index - first;
+		for (int axis = 0; axis < 3; axis++) {
+			if (axis == s.axis) continue;
+			int * order = b.sorted[axis].data() + first;
+			int * tmp = b.partition_tmp.data();
+			int l = 0, r = n_left;
+			for (int i = 0; i < count; i++) {
+				int id = order[i];
+				if (b.goes_left[id]) tmp[l++] = id; else tmp[r++] = id;
+			}
+			memcpy(order, tmp, size_t(count) * sizeof(int));
+		}
+
+		int child = int(b.bvh.nodes.size());
+		b.bvh.nodes.emplace_back();
+		b.bvh.nodes.emplace_back();
+		memset(&b.bvh.nodes[child], 0, 2 * sizeof(BVHNode2));
+		b.bvh.nodes[child    ].aabb = s.left;
+		b.bvh.nodes[child + 1].aabb = s.right;
+
+		BVHNode2 & node = b.bvh.nodes[node_index];
+		node.left  = child;
+		node.count = 0;
+		node.axis  = unsigned(s.axis);
+
+		build_node(child,     first,          n_left);
+		build_node(child + 1, first + n_left, count - n_left);
+	}
+};
+}
+
+static void build_from_bounds(SAHBuilder & b, const std::vector<AABB> & prim_aabb, const std::vector<Vector3> & prim_center) {
+	size_t n = prim_aabb.size();
+	b.bvh.indices.clear();
+	b.bvh.nodes.clear();
+	b.bvh.nodes.reserve(std::max<size_t>(2 * n, 2));
+	b.bvh.nodes.resize(2); // root + one dummy so that sibling pairs stay 64-byte aligned
+	memset(b.bvh.nodes.data(), 0, 2 * sizeof(BVHNode2));
+
+	AABB root = AABB::create_empty();
+	for (size_t i = 0; i < n; i++) root.expand(prim_aabb[i]);
+	b.bvh.nodes[0].aabb = root;
+
+	// The index lists keep their previous order as the starting permutation (a per-frame
+	// TLAS rebuild re-sorts the last frame's order), then get stably sorted by centroid.
+	for (int axis = 0; axis < 3; axis++) {
+		std::stable_sort(b.sorted[axis].begin(), b.sorted[axis].end(), [&](int l, int r) {
+			return float_sort_key(prim_center[l][axis]) < float_sort_key(prim_center[r][axis]);
+		});
+	}
+
+	BuildContext ctx { b, prim_aabb };
+	ctx.build_node(0, 0, int(n));
+
+	b.bvh.indices = b.sorted[0];
+}
+
+void SAHBuilder::build(const std::vector<Triangle> & triangles) {
+	std::vector<AABB>    bounds(triangles.size());
+	std::vector<Vector3> centers(triangles.size());
+	for (size_t i = 0; i < triangles.size(); i++) {
+		bounds [i] = triangles[i].get_aabb();
+		centers[i] = triangles[i].get_center();
+	}
+	build_from_bounds(*this, bounds, centers);
+}
+
+void SAHBuilder::build(const std::vector<Mesh> & meshes) {
+	std::vector<AABB>    bounds(meshes.size());
+	std::vector<Vector3> centers(meshes.size());
+	for (size_t i = 0; i < meshes.size(); i++) {
+		bounds [i] = meshes[i].get_aabb();
+		centers[i] = meshes[i].get_center();
+	}
+	build_from_bounds(*this, bounds, centers);
+}
+
+BVH2 BVH::create_from_triangles(const std::vector<Triangle> & triangles) {
+	BVH2 bvh;
+	SAHBuilder(bvh, triangles.size()).build(triangles);
+	return bvh;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BVH2 -> BVH8 (CWBVH)
+// ---------------------------------------------------------------------------------------------
+
+void BVH8Converter::convert() {
+	bvh8.indices.clear();
+	bvh8.indices.reserve(bvh2.indices.size());
+	bvh8.nodes.clear();
+	bvh8.nodes.reserve(bvh2.nodes.size());
+	bvh8.nodes.emplace_back();
+	memset(&bvh8.nodes[0], 0, sizeof(BVHNode8));
+
+	table.assign(bvh2.nodes.size() * 7, Decision { LEAF, char(INVALID), char(INVALID), 0.0f });
+
+	fill_cost_table(0); // bottom-up dynamic programme (BVH8Converter.cpp:24-115)
+	emit_node(0, 0);    // top-down collapse          (BVH8Converter.cpp:223-335)
+}
+
+// table[n*7 + i] = cheapest way to represent the subtree of n as a forest of at most i+1
+// roots; i == 0 decides between "one leaf" (<= 3 triangles) and "one wide inner node".
+int BVH8Converter::fill_cost_table(int node_index) {
+	const BVHNode2 & node = bvh2.nodes[node_index];
+	Decision * row = &table[size_t(node_index) * 7];
+
+	if (node.is_leaf()) {
+		if (node.count != 1) {
+			fprintf(stderr, "ERROR: BVH8 conversion needs exactly one primitive per BVH2 leaf\n");
+			abort();
+		}
+		float cost_leaf = node.aabb.surface_area() * float(node.count);
+		for (int i = 0; i < 7; i++) { row[i].kind = LEAF; row[i].cost = cost_leaf; }
+		return int(node.count);
+	}
+
+	int num_primitives = fill_cost_table(node.left) + fill_cost_table(node.left + 1);
+	const Decision * row_l = &table[size_t(node.left)     * 7];
+	const Decision * row_r = &table[size_t(node.left + 1) * 7];
+
+	{
+		float cost_leaf = num_primitives <= 3 ? float(num_primitives) * node.aabb.surface_area() : INFINITY;
+
+		float cost_distribute = INFINITY;
+		char  take_l = char(INVALID), take_r = char(INVALID);
+		for (int k = 0; k < 7; k++) {
+			float c = row_l[k].cost + row_r[6 - k].cost;
+			if (c < cost_distribute) { cost_distribute = c; take_l = char(k); take_r = char(6 - k); }
+		}
+		float cost_internal = cost_distribute + node.aabb.surface_area();
+
+		if (cost_leaf < cost_internal) { row[0].kind = LEAF;     row[0].cost = cost_leaf; }
+		else                           { row[0].kind = INTERNAL; row[0].cost = cost_internal; }
+		row[0].take_left  = take_l;
+		row[0].take_right = take_r;
+	}
+
+	for (int i = 1; i < 7; i++) {
+		float cost_distribute = row[i - 1].cost;
+		char  take_l = char(INVALID), take_r = char(INVALID);
+		for (int k = 0; k < i; k++) {
+			float c = row_l[k].cost + row_r[i - k - 1].cost;
+			if (c < cost_distribute) { cost_distribute = c; take_l = char(k); take_r = char(i - k - 1); }
+		}
+		row[i].cost = cost_distribute;
+		if (take_l != char(INVALID)) {
+			row[i].kind = DISTRIBUTE;
+			row[i].take_left  = take_l;
+			row[i].take_right = take_r;
+		} else {
+			row[i] = row[i - 1];
+		}
+	}
+	return num_primitives;
+}
+
+void BVH8Converter::gather_children(int node_index, int budget, int children[8], int & child_count) {
+	const BVHNode2 & node = bvh2.nodes[node_index];
+	if (node.is_leaf()) { children[child_count++] = node_index; return; }
+
+	int take_l = table[size_t(node_index) * 7 + budget].take_left;
+	int take_r = table[size_t(node_index) * 7 + budget].take_right;
+
+	if (table[size_t(node.left) * 7 + take_l].kind == DISTRIBUTE) gather_children(node.left, take_l, children, child_count);
+	else children[child_count++] = node.left;
+
+	if (table[size_t(node.left + 1) * 7 + take_r].kind == DISTRIBUTE) gather_children(node.left + 1, take_r, children, child_count);
+	else children[child_count++] = node.left + 1;
+}
+
+// Greedy assignment of children to the 8 octant slots: slot s is entered first by rays
+// whose direction signs are s, so a child should sit in the slot whose diagonal points
+// towards it (BVH8Converter.cpp:146-205). Strict '<' => first minimum in (child, slot) order.
+void BVH8Converter::assign_octant_slots(int node_index, int children[8], int child_count) {
+	Vector3 p = bvh2.nodes[node_index].aabb.get_center();
+
+	float cost[8][8] = { };
+	for (int c = 0; c < child_count; c++) {
+		Vector3 offset = bvh2.nodes[children[c]].aabb.get_center() - p;
+		for (int s = 0; s < 8; s++) {
+			Vector3 diagonal((s & 4) ? -1.0f : +1.0f, (s & 2) ? -1.0f : +1.0f, (s & 1) ? -1.0f : +1.0f);
+			cost[c][s] = Vector3::dot(offset, diagonal);
+		}
+	}
+
+	int  slot_of_child[8] = { INVALID, INVALID, INVALID, INVALID, INVALID, INVALID, INVALID, INVALID };
+	bool slot_taken[8] = { };
+	while (true) {
+		float best = INFINITY;
+		int best_slot = INVALID, best_child = INVALID;
+		for (int c = 0; c < child_count; c++) {
+			if (slot_of_child[c] != INVALID) continue;
+			for (int s = 0; s < 8; s++) {
+				if (!slot_taken[s] && cost[c][s] < best) { best = cost[c][s]; best_slot = s; best_child = c; }
+			}
+		}
+		if (best_slot == INVALID) break;
+		slot_taken[best_slot] = true;
+		slot_of_child[best_child] = best_slot;
+	}
+
+	int unordered[8];
+	for (int i = 0; i < 8; i++) { unordered[i] = children[i]; children[i] = INVALID; }
+	for (int c = 0; c < child_count; c++) children[slot_of_child[c]] = unordered[c];
+}
+
+int BVH8Converter::emit_leaf_indices(int node_index) {
+	const BVHNode2 & node = bvh2.nodes[node_index];
+	if (node.is_leaf()) {
+		for (unsigned i = 0; i < node.count; i++) bvh8.indices.push_back(bvh2.indices[node.first + i]);
+		return int(node.count);
+	}
+	return emit_leaf_indices(node.left) + emit_leaf_indices(node.left + 1);
+}
+
+void BVH8Converter::emit_node(int out_index, int bvh2_index) {
+	const AABB & aabb = bvh2.nodes[bvh2_index].aabb;
+
+	BVHNode8 node;
+	memset(&node, 0, sizeof(node));
+	node.p = aabb.min;
+
+	// Grid scale per axis: smallest power of two e with (max-min)/e <= 255, stored as its
+	// 8-bit float exponent (BVH8Converter.cpp:229-253).
+	constexpr float denom = 1.0f / float((1 << 8) - 1);
+	Vector3 e(
+		exp2f(ceilf(log2f((aabb.max.x - aabb.min.x) * denom))),
+		exp2f(ceilf(log2f((aabb.max.y - aabb.min.y) * denom))),
+		exp2f(ceilf(log2f((aabb.max.z - aabb.min.z) * denom))));
+	Vector3 one_over_e(1.0f / e.x, 1.0f / e.y, 1.0f / e.z);
+	for (int d = 0; d < 3; d++) {
+		unsigned bits; float v = e[d]; memcpy(&bits, &v, 4);
+		node.e[d] = byte(bits >> 23);
+	}
+
+	int child_count = 0;
+	int children[8] = { INVALID, INVALID, INVALID, INVALID, INVALID, INVALID, INVALID, INVALID };
+	gather_children(bvh2_index, 0, children, child_count);
+	assign_octant_slots(bvh2_index, children, child_count);
+
+	node.imask = 0;
+	node.base_index_triangle = unsigned(bvh8.indices.size());
+	node.base_index_child    = unsigned(bvh8.nodes.size());
+
+	int num_internal = 0, num_triangles = 0;
+	for (int i = 0; i < 8; i++) {
+		int child = children[i];
+		if (child == INVALID) continue;
+		const AABB & cb = bvh2.nodes[child].aabb;
+
+		node.quantized_min_x[i] = byte(floorf((cb.min.x - node.p.x) * one_over_e.x));
+		node.quantized_min_y[i] = byte(floorf((cb.min.y - node.p.y) * one_over_e.y));
+		node.quantized_min_z[i] = byte(floorf((cb.min.z - node.p.z) * one_over_e.z));
+		node.quantized_max_x[i] = byte(ceilf ((cb.max.x - node.p.x) * one_over_e.x));
+		node.quantized_max_y[i] = byte(ceilf ((cb.max.y - node.p.y) * one_over_e.y));
+		node.quantized_max_z[i] = byte(ceilf ((cb.max.z - node.p.z) * one_over_e.z));
+
+		if (table[size_t(child) * 7].kind == LEAF) {
+			int triangle_count = emit_leaf_indices(child);
+			for (int j = 0; j < triangle_count; j++) node.meta[i] |= byte(1 << (j + 5)); // unary count
+			node.meta[i] |= byte(num_triangles);                                          // offset from base
+			num_triangles += triangle_count;
+		} else {
+			node.meta[i] = byte((i + 24) | 0x20);
+			node.imask |= byte(1 << i);
+			num_internal++;
+		}
+	}
+
+	for (int i = 0; i < num_internal; i++) {
+		bvh8.nodes.emplace_back();
+		memset(&bvh8.nodes.back(), 0, sizeof(BVHNode8));
+	}
+	bvh8.nodes[out_index] = node;
+
+	int next = 0;
+	for (int i = 0; i < 8; i++) {
+		if (children[i] == INVALID) continue;
+		if (node.imask & (1 << i)) emit_node(int(node.base_index_child) + next++, children[i]);
+	}
+}

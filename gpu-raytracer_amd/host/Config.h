@@ -1,0 +1,68 @@
+// Global render settings, same field names as the reference so callers that
+// poke `gpu_config.num_bounces` / `cpu_config.bvh_type` keep working
+// (reference: Src/Config.h:7-64, Src/CUDA/Common.h:18-67).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/gpu_raytracer_amd.h"
+
+enum struct ReconstructionFilter : int { BOX = RT_FILTER_BOX, TENT = RT_FILTER_TENT, GAUSSIAN = RT_FILTER_GAUSSIAN };
+
+enum struct AOVType : int {
+	RADIANCE = RT_AOV_RADIANCE,
+	RADIANCE_DIRECT = RT_AOV_RADIANCE_DIRECT,
+	RADIANCE_INDIRECT = RT_AOV_RADIANCE_INDIRECT,
+	ALBEDO = RT_AOV_ALBEDO,
+	NORMAL = RT_AOV_NORMAL,
+	POSITION = RT_AOV_POSITION,
+	COUNT = RT_AOV_COUNT
+};
+
+// Mirrors the reference GPUConfig field for field; converted to the C-ABI's
+// rt_gpu_config by Integrator::update.
+struct GPUConfig {
+	ReconstructionFilter reconstruction_filter = ReconstructionFilter::GAUSSIAN;
+	unsigned aov_mask = 0;
+
+	int num_bounces = 10;
+
+	bool enable_mipmapping                   = true;
+	bool enable_next_event_estimation        = true;
+	bool enable_multiple_importance_sampling = true;
+	bool enable_russian_roulette             = true;
+	bool enable_svgf                         = false;
+	bool enable_spatial_variance             = true;
+	bool enable_taa                          = true;
+
+	float alpha_colour = 0.1f;
+	float alpha_moment = 0.1f;
+	int   num_atrous_iterations = 6;
+	float sigma_z =  4.0f;
+	float sigma_n = 16.0f;
+	float sigma_l = 10.0f;
+};
+
+enum struct BVHType { BVH, SBVH, BVH4, BVH8 };
+enum struct MipmapFilterType { BOX, LANCZOS, KAISER };
+
+struct CPUConfig {
+	int initial_width  = 900;
+	int initial_height = 600;
+
+	std::vector<std::string> scene_filenames;
+	std::string              sky_filename;
+
+	int         output_sample_index = INVALID_SAMPLE;
+	std::string output_filename     = "render.ppm";
+
+	bool enable_scene_update = false;
+
+	MipmapFilterType mipmap_filter = MipmapFilterType::BOX;
+	BVHType bvh_type = BVHType::BVH8;
+
+	static constexpr int INVALID_SAMPLE = -1;
+};
+
+extern GPUConfig gpu_config;
+extern CPUConfig cpu_config;

@@ -1,0 +1,293 @@
+#include "Integrator.h"
+
+#include <stdexcept>
+
+Integrator::Integrator(Scene & scene, int device_ordinal) : scene(scene) {
+	if (device_ordinal >= 0) {
+		int status = rt_create(device_ordinal, &ctx);
+		if (status != RT_OK) {
+			std::string message = rt_last_error(nullptr);
+			throw std::runtime_error("rt_create(" + std::to_string(device_ordinal) + ") failed: " + message);
+		}
+	}
+}
+
+Integrator::~Integrator() {
+	if (ctx) rt_destroy(ctx);
+}
+
+void Integrator::check(int status) const {
+	if (status != RT_OK) throw std::runtime_error(std::string("device layer error: ") + rt_last_error(ctx));
+}
+
+void Integrator::require_device() const {
+	if (!ctx) throw std::runtime_error("this Integrator was created without a device (host-only baking); rendering needs the HIP device layer");
+}
+
+void Integrator::gpu_init(int width, int height) {
+	resize_init(width, height);
+	init_materials();
+	init_geometry();
+	init_sky();
+	init_rng();
+
+	// reference: Integrator::cuda_init (Integrator.h:203-223)
+	scene.camera.update(0.0f);
+	scene.update(0.0f);
+	scene.has_diffuse = scene.has_plastic = scene.has_dielectric = scene.has_conductor = scene.has_lights = false;
+	invalidated_scene = invalidated_sky = invalidated_materials = invalidated_mediums = invalidated_gpu_config = invalidated_aovs = true;
+}
+
+void Integrator::gpu_free() {
+	resize_free();
+}
+
+void Integrator::init_materials() {
+	scene.asset_manager.wait_until_loaded();
+
+	if (ctx) {
+		const std::vector<Texture> & textures = scene.asset_manager.textures;
+		std::vector<rt_texture_desc> descs(textures.size());
+		for (size_t i = 0; i < textures.size(); i++) {
+			descs[i].texels     = textures[i].texels.data();
+			descs[i].width      = textures[i].width;
+			descs[i].height     = textures[i].height;
+			descs[i].mip_levels = textures[i].mip_levels();
+		}
+		check(rt_upload_textures(ctx, descs.data(), descs.size()));
+	}
+}
+
+// Concatenates all BLASes into one node array / one triangle array
+// (reference: Integrator::init_geometry, Integrator.cpp:101-283):
+//   * triangles are stored permuted by the BLAS `indices`, as pre-subtracted edges
+//   * node slots [0, 2*mesh_count) are reserved for the per-frame TLAS
+//   * each BLAS' child / triangle base offsets are rebased into the shared arrays
+void Integrator::init_geometry() {
+	scene.asset_manager.wait_until_loaded();
+	for (Mesh & mesh : scene.meshes) mesh.calc_aabb(scene);
+
+	const std::vector<MeshData> & mesh_datas = scene.asset_manager.mesh_datas;
+	size_t mesh_data_count = mesh_datas.size();
+	size_t mesh_count = scene.meshes.size();
+
+	mesh_data_bvh_offsets     .resize(mesh_data_count);
+	mesh_data_triangle_offsets.resize(mesh_data_count);
+	mesh_data_index_offsets   .resize(mesh_data_count);
+
+	bool use_bvh8 = cpu_config.bvh_type == BVHType::BVH8;
+
+	size_t node_total     = 2 * mesh_count;
+	size_t triangle_total = 0;
+	size_t index_total    = 0;
+	for (size_t m = 0; m < mesh_data_count; m++) {
+		mesh_data_bvh_offsets     [m] = int(node_total);
+		mesh_data_triangle_offsets[m] = int(triangle_total);
+		mesh_data_index_offsets   [m] = int(index_total);
+		node_total     += use_bvh8 ? mesh_datas[m].bvh8.nodes.size()   : mesh_datas[m].bvh2.nodes.size();
+		triangle_total += mesh_datas[m].triangles.size();
+		index_total    += use_bvh8 ? mesh_datas[m].bvh8.indices.size() : mesh_datas[m].bvh2.indices.size();
+	}
+
+	aggregated_triangles.assign(index_total, DeviceTriangle());
+	reverse_indices.assign(triangle_total, 0);
+	for (size_t m = 0; m < mesh_data_count; m++) {
+		const MeshData & md = mesh_datas[m];
+		const std::vector<int> & order = use_bvh8 ? md.bvh8.indices : md.bvh2.indices;
+		for (size_t i = 0; i < order.size(); i++) {
+			const Triangle & t = md.triangles[order[i]];
+			DeviceTriangle & d = aggregated_triangles[mesh_data_index_offsets[m] + i];
+			d.position_0       = t.position_0;
+			d.position_edge_1  = t.position_1 - t.position_0;
+			d.position_edge_2  = t.position_2 - t.position_0;
+			d.normal_0         = t.normal_0;
+			d.normal_edge_1    = t.normal_1 - t.normal_0;
+			d.normal_edge_2    = t.normal_2 - t.normal_0;
+			d.tex_coord_0      = t.tex_coord_0;
+			d.tex_coord_edge_1 = t.tex_coord_1 - t.tex_coord_0;
+			d.tex_coord_edge_2 = t.tex_coord_2 - t.tex_coord_0;
+			reverse_indices[mesh_data_triangle_offsets[m] + order[i]] = mesh_data_index_offsets[m] + int(i);
+		}
+	}
+
+	mesh_bvh_root_indices.assign(mesh_count, 0);
+	mesh_material_ids    .assign(mesh_count, 0);
+	mesh_transforms      .assign(mesh_count, Matrix3x4());
+	mesh_transforms_inv  .assign(mesh_count, Matrix3x4());
+	mesh_transforms_prev .assign(mesh_count, Matrix3x4());
+
+	tlas_raw.indices.resize(mesh_count);
+	tlas_raw.nodes  .resize(mesh_count * 2);
+	tlas_builder = std::make_unique<SAHBuilder>(tlas_raw, mesh_count);
+	tlas_converter = std::make_unique<BVH8Converter>(tlas, tlas_raw);
+
+	if (use_bvh8) {
+		aggregated_bvh_nodes_8.assign(node_total, BVHNode8());
+		memset(aggregated_bvh_nodes_8.data(), 0, node_total * sizeof(BVHNode8));
+		for (size_t m = 0; m < mesh_data_count; m++) {
+			const std::vector<BVHNode8> & nodes = mesh_datas[m].bvh8.nodes;
+			BVHNode8 * dst = aggregated_bvh_nodes_8.data() + mesh_data_bvh_offsets[m];
+			for (size_t n = 0; n < nodes.size(); n++) {
+				dst[n] = nodes[n];
+				dst[n].base_index_triangle += unsigned(mesh_data_index_offsets[m]);
+				dst[n].base_index_child    += unsigned(mesh_data_bvh_offsets[m]);
+			}
+		}
+		if (ctx) check(rt_upload_geometry(ctx, aggregated_triangles.data(), aggregated_triangles.size(), aggregated_bvh_nodes_8.data(), aggregated_bvh_nodes_8.size()));
+	} else {
+		aggregated_bvh_nodes_2.assign(node_total, BVHNode2());
+		memset(aggregated_bvh_nodes_2.data(), 0, node_total * sizeof(BVHNode2));
+		for (size_t m = 0; m < mesh_data_count; m++) {
+			const std::vector<BVHNode2> & nodes = mesh_datas[m].bvh2.nodes;
+			BVHNode2 * dst = aggregated_bvh_nodes_2.data() + mesh_data_bvh_offsets[m];
+			for (size_t n = 0; n < nodes.size(); n++) {
+				dst[n] = nodes[n];
+				if (dst[n].is_leaf()) dst[n].first += mesh_data_index_offsets[m];
+				else                  dst[n].left  += mesh_data_bvh_offsets[m];
+			}
+		}
+		if (ctx) check(rt_upload_geometry_bvh2(ctx, aggregated_triangles.data(), aggregated_triangles.size(), aggregated_bvh_nodes_2.data(), aggregated_bvh_nodes_2.size()));
+	}
+	if (ctx) check(rt_set_bvh_type(ctx, use_bvh8 ? 8 : 2));
+}
+
+void Integrator::init_sky() {
+	if (ctx) check(rt_set_sky(ctx, &scene.sky.data[0].x, scene.sky.width, scene.sky.height, scene.sky.scale));
+}
+
+void Integrator::init_rng() {
+	pmj_samples = PMJ::generate();
+	blue_noise  = BlueNoise::load();
+	if (ctx) check(rt_upload_rng(ctx, pmj_samples.data(), blue_noise.data()));
+}
+
+// Per-frame TLAS over the mesh AABBs; every per-instance table is written in TLAS
+// leaf order, which is what `mesh_id` means on the device (reference: Integrator.cpp:399-430).
+void Integrator::build_tlas() {
+	tlas_builder->build(scene.meshes);
+
+	size_t mesh_count = scene.meshes.size();
+	bool use_bvh8 = cpu_config.bvh_type == BVHType::BVH8;
+	const std::vector<int> * leaf_order;
+	if (use_bvh8) {
+		tlas_converter->convert();
+		memcpy(aggregated_bvh_nodes_8.data(), tlas.nodes.data(), tlas.nodes.size() * sizeof(BVHNode8));
+		if (ctx) check(rt_upload_tlas(ctx, tlas.nodes.data(), tlas.nodes.size()));
+		leaf_order = &tlas.indices;
+	} else {
+		memcpy(aggregated_bvh_nodes_2.data(), tlas_raw.nodes.data(), tlas_raw.nodes.size() * sizeof(BVHNode2));
+		if (ctx) check(rt_upload_tlas_bvh2(ctx, tlas_raw.nodes.data(), tlas_raw.nodes.size()));
+		tlas.indices = tlas_raw.indices;
+		leaf_order = &tlas_raw.indices;
+	}
+
+	for (size_t i = 0; i < mesh_count; i++) {
+		const Mesh & mesh = scene.meshes[(*leaf_order)[i]];
+		mesh_bvh_root_indices[i] = mesh_data_bvh_offsets[mesh.mesh_data_handle.handle] | (int(mesh.has_identity_transform()) << 31);
+		mesh_material_ids[i] = mesh.material_handle.handle;
+		memcpy(mesh_transforms     [i].cells, mesh.transform     .cells, sizeof(Matrix3x4));
+		memcpy(mesh_transforms_inv [i].cells, mesh.transform_inv .cells, sizeof(Matrix3x4));
+		memcpy(mesh_transforms_prev[i].cells, mesh.transform_prev.cells, sizeof(Matrix3x4));
+	}
+	if (ctx) check(rt_upload_instances(ctx, mesh_bvh_root_indices.data(), mesh_material_ids.data(),
+		mesh_transforms[0].cells, mesh_transforms_inv[0].cells, mesh_transforms_prev[0].cells, mesh_count));
+}
+
+rt_gpu_config Integrator::make_device_config() const {
+	rt_gpu_config c = { };
+	c.reconstruction_filter               = int(gpu_config.reconstruction_filter);
+	c.aov_mask                            = gpu_config.aov_mask;
+	c.num_bounces                         = gpu_config.num_bounces;
+	c.enable_mipmapping                   = gpu_config.enable_mipmapping;
+	c.enable_next_event_estimation        = gpu_config.enable_next_event_estimation;
+	c.enable_multiple_importance_sampling = gpu_config.enable_multiple_importance_sampling;
+	c.enable_russian_roulette             = gpu_config.enable_russian_roulette;
+	c.enable_svgf                         = gpu_config.enable_svgf;
+	c.enable_spatial_variance             = gpu_config.enable_spatial_variance;
+	c.enable_taa                          = gpu_config.enable_taa;
+	c.alpha_colour                        = gpu_config.alpha_colour;
+	c.alpha_moment                        = gpu_config.alpha_moment;
+	c.num_atrous_iterations               = gpu_config.num_atrous_iterations;
+	c.sigma_z                             = gpu_config.sigma_z;
+	c.sigma_n                             = gpu_config.sigma_n;
+	c.sigma_l                             = gpu_config.sigma_l;
+	return c;
+}
+
+// reference: Integrator::update (Integrator.cpp:432-528)
+void Integrator::update(float delta) {
+	if (invalidated_gpu_config && gpu_config.enable_svgf && scene.camera.aperture_radius > 0.0f) {
+		fprintf(stderr, "WARNING: SVGF and DoF cannot simultaneously be enabled!\n");
+		scene.camera.aperture_radius = 0.0f;
+		invalidated_camera = true;
+	}
+
+	if (cpu_config.enable_scene_update) {
+		scene.update(delta);
+		invalidated_scene = true;
+	} else if (gpu_config.enable_svgf || invalidated_scene) {
+		scene.camera.update(0.0f);
+		scene.update(0.0f);
+	}
+
+	if (invalidated_scene) {
+		invalidated_scene = false;
+		build_tlas();
+	}
+
+	scene.camera.update(delta);
+
+	if (scene.camera.moved || invalidated_camera) {
+		const Camera & c = scene.camera;
+		memcpy(device_camera.position,           &c.position.x,                   12);
+		memcpy(device_camera.bottom_left_corner, &c.bottom_left_corner_rotated.x, 12);
+		memcpy(device_camera.x_axis,             &c.x_axis_rotated.x,             12);
+		memcpy(device_camera.y_axis,             &c.y_axis_rotated.x,             12);
+		device_camera.pixel_spread_angle = c.pixel_spread_angle;
+		device_camera.aperture_radius    = c.aperture_radius;
+		device_camera.focal_distance     = c.focal_distance;
+		if (ctx) check(rt_set_camera(ctx, &device_camera));
+
+		if (!gpu_config.enable_svgf) sample_index = 0;
+		invalidated_camera = false;
+	}
+
+	if (invalidated_aovs) {
+		invalidated_aovs = false;
+		invalidated_gpu_config = true; // the device (re)allocates AOV buffers from aov_mask
+	}
+
+	if (invalidated_gpu_config) {
+		invalidated_gpu_config = false;
+		sample_index = 0;
+		rt_gpu_config c = make_device_config();
+		if (ctx) check(rt_set_config(ctx, &c));
+	} else if (scene.camera.moved && !gpu_config.enable_svgf) {
+		sample_index = 0;
+	} else {
+		sample_index++;
+	}
+	scene.camera.moved = false;
+}
+
+void Integrator::set_pixel_query(int x, int y) {
+	if (x < 0 || y < 0 || x >= screen_width || y >= screen_height) return;
+	y = screen_height - y; // window coordinates are top-down
+	pixel_query.pixel_index = x + y * screen_pitch;
+	pixel_query.mesh_id     = INVALID;
+	pixel_query.triangle_id = INVALID;
+}
+
+std::vector<float> Integrator::read_aov(AOVType type, bool accumulated) {
+	require_device();
+	std::vector<float> image(size_t(screen_pitch) * screen_height * 4);
+	check(rt_read_aov(ctx, int(type), image.data(), accumulated ? 1 : 0));
+	return image;
+}
+
+std::vector<float> Integrator::read_framebuffer() {
+	require_device();
+	std::vector<float> image(size_t(screen_pitch) * screen_height * 4);
+	check(rt_read_framebuffer(ctx, image.data()));
+	return image;
+}

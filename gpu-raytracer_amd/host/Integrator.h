@@ -1,0 +1,126 @@
+// Host side of the hot path: turns a Scene into the flat device data formats and
+// drives the device layer through the C ABI (include/gpu_raytracer_amd.h).
+// Same role, member names and invalidation protocol as the reference's
+// `struct Integrator` (Src/Renderer/Integrators/Integrator.h:56-296, Integrator.cpp):
+//   cuda_init/cuda_free  -> gpu_init/gpu_free   (cuda_* kept as aliases)
+//   resize_init/resize_free, update(delta), render(), invalidated_* flags,
+//   sample_index, aov_enable/aov_disable/aov_is_enabled, set_pixel_query.
+// GL interop, ImGui and NVRTC hot-reload have no counterpart (headless).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "Scene.h"
+#include "PMJ.h"
+
+struct DeviceTriangle { // CUDA/Raytracing/Triangle.h:4-11, Integrator.h:139-151
+	Vector3 position_0, position_edge_1, position_edge_2;
+	Vector3 normal_0,   normal_edge_1,   normal_edge_2;
+	Vector2 tex_coord_0, tex_coord_edge_1, tex_coord_edge_2;
+};
+static_assert(sizeof(DeviceTriangle) == 96, "device triangle is 6 x float4");
+
+struct Matrix3x4 { float cells[12]; };
+
+union alignas(16) DeviceMaterial { // CUDA/Material.h:21-39
+	struct { Vector3 emission; } light;
+	struct { Vector3 diffuse; int texture_id; } diffuse;
+	struct { Vector3 diffuse; int texture_id; float linear_roughness; } plastic;
+	struct { int medium_id; float ior; float linear_roughness; } dielectric;
+	struct { Vector3 eta; float linear_roughness; Vector3 k; } conductor;
+	float raw[8];
+	DeviceMaterial() { for (float & f : raw) f = 0.0f; }
+};
+static_assert(sizeof(DeviceMaterial) == 32, "device material is 2 x float4");
+
+struct alignas(16) DeviceMedium { Vector3 sigma_a; float g; Vector3 sigma_s; float pad = 0.0f; };
+static_assert(sizeof(DeviceMedium) == 32, "device medium is 2 x float4");
+
+struct PixelQuery { int pixel_index, mesh_id, triangle_id; };
+
+struct Integrator {
+	Scene & scene;
+	rt_context * ctx = nullptr; // null = host-only baking (tests, CPU oracle); render() then throws
+
+	bool invalidated_scene      = true;
+	bool invalidated_sky        = true;
+	bool invalidated_materials  = true;
+	bool invalidated_mediums    = true;
+	bool invalidated_camera     = true;
+	bool invalidated_gpu_config = true;
+	bool invalidated_aovs       = true;
+
+	int screen_width = 0, screen_height = 0, screen_pitch = 0;
+	int pixel_count = 0;
+	int sample_index = 0;
+
+	// Multi-GPU: scan-order pixel range rendered by this integrator (default: all)
+	int pixel_range_offset = 0, pixel_range_count = -1;
+
+	PixelQuery pixel_query = { INVALID, INVALID, INVALID };
+
+	// ---- host staging of everything the device consumes (filled by init_* / build_tlas) ----
+	std::vector<DeviceTriangle> aggregated_triangles;
+	std::vector<BVHNode8>       aggregated_bvh_nodes_8;   // slots [0, 2*meshes) = TLAS
+	std::vector<BVHNode2>       aggregated_bvh_nodes_2;   // same layout, binary BVH
+	std::vector<int>            reverse_indices;          // original triangle -> position in aggregated_triangles
+	std::vector<int>            mesh_data_bvh_offsets;
+	std::vector<int>            mesh_data_triangle_offsets;
+	std::vector<int>            mesh_data_index_offsets;
+
+	std::vector<int>       mesh_bvh_root_indices;   // TLAS order; MSB = identity transform
+	std::vector<int>       mesh_material_ids;
+	std::vector<Matrix3x4> mesh_transforms, mesh_transforms_inv, mesh_transforms_prev;
+
+	std::vector<unsigned char>  material_types;
+	std::vector<DeviceMaterial> materials;
+	std::vector<DeviceMedium>   media;
+
+	BVH2 tlas_raw;
+	BVH8 tlas;                                   // tlas.indices[i] = scene mesh index of TLAS leaf i
+	std::unique_ptr<SAHBuilder>    tlas_builder;
+	std::unique_ptr<BVH8Converter> tlas_converter;
+
+	std::vector<float>         pmj_samples;
+	std::vector<unsigned char> blue_noise;
+
+	rt_camera device_camera = { };
+
+	explicit Integrator(Scene & scene, int device_ordinal = 0);
+	virtual ~Integrator();
+
+	virtual void gpu_init(int screen_width, int screen_height);
+	virtual void gpu_free();
+	void cuda_init(unsigned /*frame_buffer_handle*/, int w, int h) { gpu_init(w, h); }
+	void cuda_free() { gpu_free(); }
+
+	void init_materials();
+	void init_geometry();
+	void init_sky();
+	void init_rng();
+
+	virtual void resize_free() = 0;
+	virtual void resize_init(int width, int height) = 0;
+
+	void aov_enable (AOVType t) { gpu_config.aov_mask |=  (1u << int(t)); invalidated_aovs = true; }
+	void aov_disable(AOVType t) { gpu_config.aov_mask &= ~(1u << int(t)); invalidated_aovs = true; }
+	bool aov_is_enabled(AOVType t) const { return gpu_config.aov_mask & (1u << int(t)); }
+
+	void build_tlas();
+
+	virtual void update(float delta);
+	virtual void render() = 0;
+
+	void set_pixel_query(int x, int y);
+	void set_pixel_range(int offset, int count) { pixel_range_offset = offset; pixel_range_count = count; if (ctx) check(rt_set_pixel_range(ctx, offset, count)); }
+
+	// Reads an AOV accumulator (pitch*height float4) back to the host.
+	std::vector<float> read_aov(AOVType type, bool accumulated = true);
+	std::vector<float> read_framebuffer();
+
+	rt_gpu_config make_device_config() const;
+
+protected:
+	void check(int status) const; // throws std::runtime_error with rt_last_error on failure
+	void require_device() const;
+};

@@ -1,0 +1,52 @@
+// Geometry containers: MeshData = triangles + BLAS, Mesh = one placed instance
+// (reference: Src/Renderer/MeshData.h, Mesh.h, Mesh.cpp).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "BVH.h"
+#include "Material.h"
+
+struct MeshData {
+	std::vector<Triangle> triangles;
+	BVH2 bvh2; // binary SAH BVH, one triangle per leaf
+	BVH8 bvh8; // its CWBVH collapse
+};
+
+struct Scene;
+
+struct Mesh {
+	std::string name;
+
+	AABB aabb_untransformed;
+	AABB aabb;
+
+	Handle<MeshData> mesh_data_handle;
+
+	Vector3    position;
+	Quaternion rotation;
+	float      scale = 1.0f;
+
+	Handle<Material> material_handle;
+
+	Matrix4 transform;
+	Matrix4 transform_inv;
+	Matrix4 transform_prev;
+
+	struct {
+		float weight = 0.0f;
+		int first_triangle_index = 0;
+		int triangle_count = 0;
+	} light;
+
+	Mesh(std::string name, Handle<MeshData> mesh_data_handle, Handle<Material> material_handle)
+		: name(std::move(name)), mesh_data_handle(mesh_data_handle), material_handle(material_handle) { }
+
+	void calc_aabb(const Scene & scene);
+	void update();
+	bool has_identity_transform() const;
+
+	Vector3 get_center() const { return aabb.get_center(); }
+	AABB    get_aabb()   const { return aabb; }
+};

@@ -1,0 +1,255 @@
+#include "Scene.h"
+#include "Parser.h"
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <thread>
+
+GPUConfig gpu_config;
+CPUConfig cpu_config;
+
+// ---- Mesh -------------------------------------------------------------------------------------
+
+void Mesh::calc_aabb(const Scene & scene) {
+	const MeshData & mesh_data = scene.asset_manager.get_mesh_data(mesh_data_handle);
+	aabb_untransformed = AABB::create_empty();
+	for (const Triangle & t : mesh_data.triangles) aabb_untransformed.expand(t.get_aabb());
+}
+
+// T*R*S and its inverse S^-1 * R^-1 * T^-1 (reference: Renderer/Mesh.cpp:16-34)
+void Mesh::update() {
+	transform_prev = transform;
+	transform =
+		Matrix4::create_translation(position) *
+		Matrix4::create_rotation(rotation) *
+		Matrix4::create_scale(scale);
+	transform_inv =
+		Matrix4::create_scale(1.0f / scale) *
+		Matrix4::create_rotation(Quaternion::conjugate(rotation)) *
+		Matrix4::create_translation(-position);
+
+	aabb = AABB::transform(aabb_untransformed, transform);
+	aabb.fix_if_needed();
+}
+
+bool Mesh::has_identity_transform() const {
+	constexpr float eps = 1e-6f;
+	return
+		Math::approx_equal(scale, 1.0f, eps) &&
+		Math::approx_equal(position.x, 0.0f, eps) && Math::approx_equal(position.y, 0.0f, eps) && Math::approx_equal(position.z, 0.0f, eps) &&
+		Math::approx_equal(rotation.x, 0.0f, eps) && Math::approx_equal(rotation.y, 0.0f, eps) && Math::approx_equal(rotation.z, 0.0f, eps) &&
+		(Math::approx_equal(rotation.w, 1.0f, eps) || Math::approx_equal(rotation.w, -1.0f, eps)); // quaternion double cover
+}
+
+// ---- AssetManager -----------------------------------------------------------------------------
+
+AssetManager::AssetManager() {
+	Material default_material;
+	default_material.name    = "Default";
+	default_material.diffuse = Vector3(1.0f, 0.0f, 1.0f);
+	add_material(std::move(default_material));
+
+	Medium default_medium;
+	default_medium.name = "Default";
+	add_medium(std::move(default_medium));
+}
+
+Handle<MeshData> AssetManager::add_mesh_data(const std::string & filename, FallbackLoader loader) {
+	auto it = mesh_data_cache.find(filename);
+	if (it != mesh_data_cache.end()) return it->second;
+
+	Handle<MeshData> handle { int(mesh_datas.size()) };
+	mesh_datas.emplace_back();
+	mesh_data_cache[filename] = handle;
+	pending_meshes.push_back({ handle.handle, filename, std::move(loader) });
+	return handle;
+}
+
+static void build_blas(MeshData & mesh_data) {
+	if (mesh_data.triangles.empty()) {
+		// An empty mesh is replaced by one dummy triangle (reference: AssetManager.cpp:64-78)
+		mesh_data.triangles.push_back(Triangle(
+			Vector3(-1.0f, -1.0f, 0.0f), Vector3(0.0f, +1.0f, 0.0f), Vector3(+1.0f, -1.0f, 0.0f),
+			Vector3(0.0f, 0.0f, 1.0f), Vector3(0.0f, 0.0f, 1.0f), Vector3(0.0f, 0.0f, 1.0f),
+			Vector2(0.0f, 1.0f), Vector2(0.5f, 0.0f), Vector2(1.0f, 1.0f)));
+	}
+	mesh_data.bvh2 = BVH::create_from_triangles(mesh_data.triangles);
+	BVH8Converter(mesh_data.bvh8, mesh_data.bvh2).convert();
+}
+
+Handle<MeshData> AssetManager::add_mesh_data(std::vector<Triangle> triangles) {
+	Handle<MeshData> handle { int(mesh_datas.size()) };
+	mesh_datas.emplace_back();
+	mesh_datas.back().triangles = std::move(triangles);
+	pending_meshes.push_back({ handle.handle, std::string(), nullptr });
+	return handle;
+}
+
+Handle<Material> AssetManager::add_material(Material material) {
+	Handle<Material> handle { int(materials.size()) };
+	materials.emplace_back(std::move(material));
+	return handle;
+}
+
+Handle<Medium> AssetManager::add_medium(Medium medium) {
+	Handle<Medium> handle { int(media.size()) };
+	media.emplace_back(std::move(medium));
+	return handle;
+}
+
+Handle<Texture> AssetManager::add_texture(const std::string & filename, const std::string & name) {
+	auto it = texture_cache.find(filename);
+	if (it != texture_cache.end()) return it->second;
+
+	Handle<Texture> handle { int(textures.size()) };
+	textures.emplace_back();
+	textures.back().name = name;
+	texture_cache[filename] = handle;
+	pending_textures.push_back({ handle.handle, filename });
+	return handle;
+}
+
+void AssetManager::wait_until_loaded() {
+	if (assets_loaded) return;
+
+	unsigned worker_count = std::max(1u, std::thread::hardware_concurrency());
+	auto t0 = std::chrono::steady_clock::now();
+	{
+		std::atomic<size_t> next { 0 };
+		auto work = [&]() {
+			while (true) {
+				size_t i = next.fetch_add(1);
+				if (i >= pending_meshes.size()) break;
+				PendingMesh & job = pending_meshes[i];
+				MeshData & mesh_data = mesh_datas[job.handle];
+				if (job.loader) mesh_data.triangles = job.loader(job.filename);
+				build_blas(mesh_data);
+			}
+		};
+		std::vector<std::thread> workers;
+		for (unsigned w = 1; w < worker_count; w++) workers.emplace_back(work);
+		work();
+		for (std::thread & t : workers) t.join();
+	}
+	bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	{
+		std::atomic<size_t> next { 0 };
+		auto work = [&]() {
+			while (true) {
+				size_t i = next.fetch_add(1);
+				if (i >= pending_textures.size()) break;
+				PendingTexture & job = pending_textures[i];
+				Texture & texture = textures[job.handle];
+				if (!TextureLoader::load(job.filename, &texture)) {
+					fprintf(stderr, "WARNING: Failed to load Texture '%s'!\n", job.filename.c_str());
+					// 1x1 pink fallback (reference: AssetManager.cpp:157-169)
+					texture.width = texture.height = 1;
+					texture.texels = { 255, 0, 255, 255 };
+					texture.mip_offsets = { 0 };
+				}
+			}
+		};
+		std::vector<std::thread> workers;
+		for (unsigned w = 1; w < worker_count; w++) workers.emplace_back(work);
+		work();
+		for (std::thread & t : workers) t.join();
+	}
+	pending_meshes.clear();
+	pending_textures.clear();
+	mesh_data_cache.clear();
+	texture_cache.clear();
+	assets_loaded = true;
+}
+
+// ---- Sky --------------------------------------------------------------------------------------
+
+// Radiance RGBE (.hdr) reader: "#?RADIANCE" header, -Y h +X w, flat or new-style RLE scanlines.
+void Sky::load(const std::string & filename) {
+	auto fallback = [this]() { width = height = 1; data = { Vector4(1.0f, 1.0f, 1.0f, 0.0f) }; };
+	if (filename.empty()) { fallback(); return; }
+
+	FILE * f = fopen(filename.c_str(), "rb");
+	if (!f) {
+		fprintf(stderr, "WARNING: unable to load hdr Sky from file '%s', using a constant white sky\n", filename.c_str());
+		fallback();
+		return;
+	}
+	char line[256];
+	bool have_size = false;
+	while (fgets(line, sizeof(line), f)) {
+		if (sscanf(line, "-Y %d +X %d", &height, &width) == 2) { have_size = true; break; }
+	}
+	if (!have_size || width <= 0 || height <= 0) { fclose(f); fallback(); return; }
+
+	data.resize(size_t(width) * height);
+	std::vector<unsigned char> scan(size_t(width) * 4);
+	for (int y = 0; y < height; y++) {
+		unsigned char head[4];
+		if (fread(head, 1, 4, f) != 4) break;
+		bool rle = head[0] == 2 && head[1] == 2 && !(head[2] & 0x80) && ((head[2] << 8) | head[3]) == width && width >= 8 && width < 32768;
+		if (rle) {
+			for (int c = 0; c < 4; c++) {
+				int x = 0;
+				while (x < width) {
+					int count = fgetc(f);
+					if (count > 128) { int v = fgetc(f); count -= 128; while (count-- > 0 && x < width) scan[size_t(x++) * 4 + c] = (unsigned char)v; }
+					else             { while (count-- > 0 && x < width) scan[size_t(x++) * 4 + c] = (unsigned char)fgetc(f); }
+				}
+			}
+		} else {
+			memcpy(scan.data(), head, 4);
+			if (fread(scan.data() + 4, 1, size_t(width - 1) * 4, f) != size_t(width - 1) * 4) break;
+		}
+		for (int x = 0; x < width; x++) {
+			const unsigned char * p = &scan[size_t(x) * 4];
+			float s = p[3] ? ldexpf(1.0f, int(p[3]) - (128 + 8)) : 0.0f;
+			data[size_t(x) + size_t(y) * width] = Vector4(p[0] * s, p[1] * s, p[2] * s, 0.0f);
+		}
+	}
+	fclose(f);
+}
+
+// ---- Scene ------------------------------------------------------------------------------------
+
+static std::string file_extension(const std::string & filename) {
+	size_t dot = filename.find_last_of('.');
+	return dot == std::string::npos ? std::string() : filename.substr(dot + 1);
+}
+
+Scene::Scene() : camera(Math::deg_to_rad(85.0f)) {
+	for (const std::string & scene_filename : cpu_config.scene_filenames) {
+		std::string ext = file_extension(scene_filename);
+		if (ext == "obj") {
+			add_mesh(scene_filename, asset_manager.add_mesh_data(scene_filename, OBJLoader::load));
+		} else if (ext == "xml") {
+			MitsubaLoader::load(scene_filename, *this);
+		} else {
+			throw ParseError("'" + scene_filename + "': file format is not supported (expected .xml or .obj)");
+		}
+	}
+	sky.load(cpu_config.sky_filename);
+}
+
+Mesh & Scene::add_mesh(std::string name, Handle<MeshData> mesh_data_handle, Handle<Material> material_handle) {
+	meshes.emplace_back(std::move(name), mesh_data_handle, material_handle);
+	return meshes.back();
+}
+
+void Scene::check_materials() {
+	has_diffuse = has_plastic = has_dielectric = has_conductor = has_lights = false;
+	for (const Material & material : asset_manager.materials) {
+		switch (material.type) {
+			case Material::Type::DIFFUSE:    has_diffuse    = true; break;
+			case Material::Type::PLASTIC:    has_plastic    = true; break;
+			case Material::Type::DIELECTRIC: has_dielectric = true; break;
+			case Material::Type::CONDUCTOR:  has_conductor  = true; break;
+			case Material::Type::LIGHT:      has_lights    |= material.is_light(); break;
+		}
+	}
+}
+
+void Scene::update(float delta) {
+	(void)delta;
+	for (Mesh & mesh : meshes) mesh.update();
+}

@@ -1,0 +1,218 @@
+// Texture files -> linear-light RGBA8 mip chains.
+// Pipeline as in the reference (Src/Assets/TextureLoader.cpp:129-206): decode to 8-bit RGBA,
+// sRGB -> linear in float, build each mip by box-filtering the previous level
+// (Src/Math/Mipmap.cpp:72-152), quantise back to 8 bits by truncation. The reference then
+// BC1-compresses power-of-two textures for the texture unit; CDNA has none, so the RGBA8
+// levels are what the shade kernel filters.
+// Decoders: TGA (types 2/3/10/11, 8/24/32 bpp, either origin) and binary PPM (P6) -- the
+// formats the BASELINE scenes use; stb_image is not linked.
+#include "Scene.h"
+#include "Parser.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+bool read_file(const std::string & filename, std::vector<unsigned char> & bytes) {
+	FILE * f = fopen(filename.c_str(), "rb");
+	if (!f) return false;
+	fseek(f, 0, SEEK_END);
+	long size = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	bytes.resize(size_t(size));
+	bool ok = fread(bytes.data(), 1, size_t(size), f) == size_t(size);
+	fclose(f);
+	return ok;
+}
+
+bool decode_tga(const std::vector<unsigned char> & file, int & width, int & height, std::vector<unsigned char> & rgba) {
+	if (file.size() < 18) return false;
+	int id_length  = file[0];
+	int cmap_type  = file[1];
+	int image_type = file[2];
+	width  = file[12] | (file[13] << 8);
+	height = file[14] | (file[15] << 8);
+	int bpp        = file[16];
+	int descriptor = file[17];
+	if (cmap_type != 0 || width <= 0 || height <= 0) return false;
+	bool rle  = image_type == 10 || image_type == 11;
+	bool grey = image_type == 3  || image_type == 11;
+	if (!(image_type == 2 || image_type == 3 || rle)) return false;
+	int bytes_pp = bpp / 8;
+	if (!((grey && bytes_pp == 1) || (!grey && (bytes_pp == 3 || bytes_pp == 4)))) return false;
+
+	size_t pixel_count = size_t(width) * height;
+	std::vector<unsigned char> raw(pixel_count * bytes_pp);
+	size_t pos = 18 + size_t(id_length);
+	if (!rle) {
+		if (file.size() < pos + raw.size()) return false;
+		memcpy(raw.data(), file.data() + pos, raw.size());
+	} else {
+		size_t out = 0;
+		while (out < pixel_count) {
+			if (pos >= file.size()) return false;
+			int header = file[pos++];
+			int count = (header & 0x7f) + 1;
+			if (header & 0x80) {
+				if (pos + bytes_pp > file.size()) return false;
+				for (int i = 0; i < count && out < pixel_count; i++, out++) memcpy(&raw[out * bytes_pp], &file[pos], bytes_pp);
+				pos += bytes_pp;
+			} else {
+				if (pos + size_t(count) * bytes_pp > file.size()) return false;
+				for (int i = 0; i < count && out < pixel_count; i++, out++, pos += bytes_pp) memcpy(&raw[out * bytes_pp], &file[pos], bytes_pp);
+			}
+		}
+	}
+
+	bool top_down   = (descriptor & 0x20) != 0;
+	bool right_left = (descriptor & 0x10) != 0;
+	rgba.resize(pixel_count * 4);
+	for (int y = 0; y < height; y++) {
+		int src_y = top_down ? y : height - 1 - y; // row 0 of the output is the top of the image
+		for (int x = 0; x < width; x++) {
+			int src_x = right_left ? width - 1 - x : x;
+			const unsigned char * s = &raw[(size_t(src_y) * width + src_x) * bytes_pp];
+			unsigned char * d = &rgba[(size_t(y) * width + x) * 4];
+			if (grey) { d[0] = d[1] = d[2] = s[0]; d[3] = 255; }
+			else      { d[0] = s[2]; d[1] = s[1]; d[2] = s[0]; d[3] = bytes_pp == 4 ? s[3] : 255; } // BGR(A) on disk
+		}
+	}
+	return true;
+}
+
+bool decode_ppm(const std::vector<unsigned char> & file, int & width, int & height, std::vector<unsigned char> & rgba) {
+	if (file.size() < 2 || file[0] != 'P' || file[1] != '6') return false;
+	size_t pos = 2;
+	auto next_int = [&](int & out) {
+		while (pos < file.size()) {
+			if (file[pos] == '#') { while (pos < file.size() && file[pos] != '\n') pos++; }
+			else if (file[pos] == ' ' || file[pos] == '\n' || file[pos] == '\r' || file[pos] == '\t') pos++;
+			else break;
+		}
+		if (pos >= file.size() || !is_digit(char(file[pos]))) return false;
+		out = 0;
+		while (pos < file.size() && is_digit(char(file[pos]))) out = out * 10 + (file[pos++] - '0');
+		return true;
+	};
+	int maxval = 0;
+	if (!next_int(width) || !next_int(height) || !next_int(maxval) || maxval != 255) return false;
+	pos++; // single whitespace after maxval
+	size_t pixel_count = size_t(width) * height;
+	if (file.size() < pos + pixel_count * 3) return false;
+	rgba.resize(pixel_count * 4);
+	for (size_t i = 0; i < pixel_count; i++) {
+		rgba[4 * i + 0] = file[pos + 3 * i + 0];
+		rgba[4 * i + 1] = file[pos + 3 * i + 1];
+		rgba[4 * i + 2] = file[pos + 3 * i + 2];
+		rgba[4 * i + 3] = 255;
+	}
+	return true;
+}
+
+// Separable box filter with the window construction of the reference mip generator: the
+// kernel is the box function integrated over each source texel (32 sub-samples).
+void downsample_box(int w_src, int h_src, int w_dst, int h_dst, const Vector4 * src, Vector4 * dst, std::vector<Vector4> & temp) {
+	auto make_kernel = [](int n_src, int n_dst, std::vector<float> & kernel, float & filter_width, float & inv_scale) {
+		float scale = float(n_dst) / float(n_src);
+		inv_scale = 1.0f / scale;
+		filter_width = 0.5f * inv_scale;
+		int window = int(ceilf(filter_width * 2.0f)) + 1;
+		kernel.assign(window, 0.0f);
+		float sum = 0.0f;
+		for (int i = 0; i < window; i++) {
+			float x = float(i - window / 2);
+			float acc = 0.0f, sample = 0.5f;
+			for (int s = 0; s < 32; s++, sample += 1.0f) {
+				float p = (x + sample * (1.0f / 32.0f)) * scale;
+				acc += fabsf(p) <= 0.5f ? 1.0f : 0.0f;
+			}
+			kernel[i] = acc * (1.0f / 32.0f);
+			sum += kernel[i];
+		}
+		for (float & k : kernel) k /= sum;
+	};
+	std::vector<float> kx, ky;
+	float fwx, fwy, isx, isy;
+	make_kernel(w_src, w_dst, kx, fwx, isx);
+	make_kernel(h_src, h_dst, ky, fwy, isy);
+
+	temp.resize(size_t(w_dst) * h_src);
+	for (int y = 0; y < h_src; y++) {
+		for (int x = 0; x < w_dst; x++) {
+			int left = int(floorf((float(x) + 0.5f) * isx - fwx));
+			Vector4 sum;
+			for (size_t i = 0; i < kx.size(); i++) {
+				const Vector4 & t = src[Math::clamp(left + int(i), 0, w_src - 1) + size_t(y) * w_src];
+				sum.x += kx[i] * t.x; sum.y += kx[i] * t.y; sum.z += kx[i] * t.z; sum.w += kx[i] * t.w;
+			}
+			temp[size_t(x) * h_src + y] = sum;
+		}
+	}
+	for (int x = 0; x < w_dst; x++) {
+		for (int y = 0; y < h_dst; y++) {
+			int top = int(floorf((float(y) + 0.5f) * isy - fwy));
+			Vector4 sum;
+			for (size_t i = 0; i < ky.size(); i++) {
+				const Vector4 & t = temp[size_t(x) * h_src + Math::clamp(top + int(i), 0, h_src - 1)];
+				sum.x += ky[i] * t.x; sum.y += ky[i] * t.y; sum.z += ky[i] * t.z; sum.w += ky[i] * t.w;
+			}
+			dst[x + size_t(y) * w_dst] = sum;
+		}
+	}
+}
+
+unsigned char quantise(float v) { return (unsigned char)(Math::clamp(v * 255.0f, 0.0f, 255.0f)); }
+
+} // namespace
+
+bool TextureLoader::load(const std::string & filename, Texture * texture) {
+	std::vector<unsigned char> file, rgba8;
+	if (!read_file(filename, file)) return false;
+
+	int width = 0, height = 0;
+	if (!decode_tga(file, width, height, rgba8) && !decode_ppm(file, width, height, rgba8)) return false;
+
+	// Mip level sizes: halve each dimension down to 1 (reference mip_count, TextureLoader.cpp:108-127)
+	std::vector<std::pair<int, int>> level_size;
+	size_t total = 0;
+	for (int w = width, h = height;;) {
+		level_size.emplace_back(w, h);
+		total += size_t(w) * h;
+		if (!gpu_config.enable_mipmapping || (w == 1 && h == 1)) break;
+		if (w > 1) w /= 2;
+		if (h > 1) h /= 2;
+	}
+
+	std::vector<Vector4> linear(total);
+	for (size_t i = 0; i < size_t(width) * height; i++) {
+		linear[i] = Vector4(
+			Math::gamma_to_linear(float(rgba8[4 * i + 0]) / 255.0f),
+			Math::gamma_to_linear(float(rgba8[4 * i + 1]) / 255.0f),
+			Math::gamma_to_linear(float(rgba8[4 * i + 2]) / 255.0f),
+			Math::gamma_to_linear(float(rgba8[4 * i + 3]) / 255.0f));
+	}
+
+	texture->width  = width;
+	texture->height = height;
+	texture->mip_offsets.clear();
+	size_t offset = 0;
+	std::vector<Vector4> temp;
+	for (size_t l = 0; l < level_size.size(); l++) {
+		texture->mip_offsets.push_back(offset);
+		if (l + 1 < level_size.size()) {
+			size_t next = offset + size_t(level_size[l].first) * level_size[l].second;
+			downsample_box(level_size[l].first, level_size[l].second, level_size[l + 1].first, level_size[l + 1].second, &linear[offset], &linear[next], temp);
+			offset = next;
+		}
+	}
+
+	texture->texels.resize(total * 4);
+	for (size_t i = 0; i < total; i++) {
+		texture->texels[4 * i + 0] = quantise(linear[i].x);
+		texture->texels[4 * i + 1] = quantise(linear[i].y);
+		texture->texels[4 * i + 2] = quantise(linear[i].z);
+		texture->texels[4 * i + 3] = quantise(linear[i].w);
+	}
+	return true;
+}

@@ -1,0 +1,268 @@
+// Flat C entry points over the C++ host classes, for ctypes (tests, bench.py) and for
+// host applications written in C. Nothing here touches the GPU directly: the device is
+// reached only through the Pathtracer, i.e. through include/gpu_raytracer_amd.h.
+#include "Pathtracer.h"
+
+#include <cstring>
+#include <string>
+
+static thread_local std::string g_host_error;
+
+#define GRT_TRY   try {
+#define GRT_CATCH(ret) } catch (const std::exception & e) { g_host_error = e.what(); return ret; } catch (...) { g_host_error = "unknown C++ exception"; return ret; }
+
+extern "C" {
+
+const char * grt_last_error() { return g_host_error.c_str(); }
+
+// key/value access to the two global config structs (reference: Src/Config.h)
+int grt_config_set(const char * key, double value) {
+	std::string k(key);
+	if      (k == "num_bounces")                         gpu_config.num_bounces = int(value);
+	else if (k == "reconstruction_filter")               gpu_config.reconstruction_filter = ReconstructionFilter(int(value));
+	else if (k == "enable_mipmapping")                   gpu_config.enable_mipmapping = value != 0;
+	else if (k == "enable_next_event_estimation")        gpu_config.enable_next_event_estimation = value != 0;
+	else if (k == "enable_multiple_importance_sampling") gpu_config.enable_multiple_importance_sampling = value != 0;
+	else if (k == "enable_russian_roulette")             gpu_config.enable_russian_roulette = value != 0;
+	else if (k == "enable_svgf")                         gpu_config.enable_svgf = value != 0;
+	else if (k == "enable_spatial_variance")             gpu_config.enable_spatial_variance = value != 0;
+	else if (k == "enable_taa")                          gpu_config.enable_taa = value != 0;
+	else if (k == "alpha_colour")                        gpu_config.alpha_colour = float(value);
+	else if (k == "alpha_moment")                        gpu_config.alpha_moment = float(value);
+	else if (k == "num_atrous_iterations")               gpu_config.num_atrous_iterations = int(value);
+	else if (k == "sigma_z")                             gpu_config.sigma_z = float(value);
+	else if (k == "sigma_n")                             gpu_config.sigma_n = float(value);
+	else if (k == "sigma_l")                             gpu_config.sigma_l = float(value);
+	else if (k == "aov_mask")                            gpu_config.aov_mask = unsigned(value);
+	else if (k == "bvh_type")                            cpu_config.bvh_type = int(value) == 2 ? BVHType::BVH : BVHType::BVH8;
+	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
+	else if (k == "initial_height")                      cpu_config.initial_height = int(value);
+	else { g_host_error = "unknown config key '" + k + "'"; return -1; }
+	return 0;
+}
+
+double grt_config_get(const char * key) {
+	std::string k(key);
+	if (k == "num_bounces")    return gpu_config.num_bounces;
+	if (k == "initial_width")  return cpu_config.initial_width;
+	if (k == "initial_height") return cpu_config.initial_height;
+	if (k == "aov_mask")       return gpu_config.aov_mask;
+	if (k == "enable_svgf")    return gpu_config.enable_svgf;
+	return -1.0;
+}
+
+void grt_config_reset() { gpu_config = GPUConfig(); cpu_config = CPUConfig(); }
+
+// Loads one scene file (.xml / .obj); sky_filename may be NULL/"" for the constant sky.
+void * grt_scene_load(const char * filename, const char * sky_filename) {
+	GRT_TRY
+		cpu_config.scene_filenames = { std::string(filename) };
+		cpu_config.sky_filename = sky_filename ? sky_filename : "";
+		return new Scene();
+	GRT_CATCH(nullptr)
+}
+void grt_scene_free(void * scene) { delete (Scene *)scene; }
+
+int grt_scene_mesh_count(void * scene)     { return int(((Scene *)scene)->meshes.size()); }
+int grt_scene_material_count(void * scene) { return int(((Scene *)scene)->asset_manager.materials.size()); }
+int grt_scene_texture_count(void * scene)  { return int(((Scene *)scene)->asset_manager.textures.size()); }
+double grt_scene_bvh_build_ms(void * scene) { return ((Scene *)scene)->asset_manager.bvh_build_ms; }
+
+void grt_scene_set_sky_scale(void * scene, float scale) { ((Scene *)scene)->sky.scale = scale; }
+
+// position xyz, rotation quaternion xyzw, fov in radians (<= 0 keeps the current one)
+void grt_scene_set_camera(void * scene, const float * position, const float * rotation, float fov) {
+	Camera & c = ((Scene *)scene)->camera;
+	c.position = Vector3(position[0], position[1], position[2]);
+	c.rotation = Quaternion(rotation[0], rotation[1], rotation[2], rotation[3]);
+	if (fov > 0.0f) c.set_fov(fov);
+	c.moved = true;
+}
+void grt_scene_get_camera(void * scene, float * position, float * rotation, float * fov) {
+	const Camera & c = ((Scene *)scene)->camera;
+	position[0] = c.position.x; position[1] = c.position.y; position[2] = c.position.z;
+	rotation[0] = c.rotation.x; rotation[1] = c.rotation.y; rotation[2] = c.rotation.z; rotation[3] = c.rotation.w;
+	*fov = c.fov;
+}
+
+// Overrides one material (used by the "odd materials -> roughplastic" Sponza variant)
+int grt_scene_set_material(void * scene, int index, int type, const float * diffuse, float linear_roughness) {
+	Scene * s = (Scene *)scene;
+	if (index < 0 || index >= int(s->asset_manager.materials.size())) { g_host_error = "material index out of range"; return -1; }
+	Material & m = s->asset_manager.materials[index];
+	m.type = Material::Type(type);
+	if (diffuse) m.diffuse = Vector3(diffuse[0], diffuse[1], diffuse[2]);
+	m.linear_roughness = linear_roughness;
+	return 0;
+}
+int grt_scene_material_type(void * scene, int index) { return int(((Scene *)scene)->asset_manager.materials[index].type); }
+
+// Triangles / BLAS of one MeshData, for the builder parity tests
+int grt_scene_mesh_data_count(void * scene) { return int(((Scene *)scene)->asset_manager.mesh_datas.size()); }
+int grt_scene_wait_until_loaded(void * scene) {
+	GRT_TRY
+		((Scene *)scene)->asset_manager.wait_until_loaded();
+		return 0;
+	GRT_CATCH(-1)
+}
+const void * grt_mesh_data_array(void * scene, int mesh_data, const char * name, size_t * bytes) {
+	Scene * s = (Scene *)scene;
+	const MeshData & md = s->asset_manager.mesh_datas[mesh_data];
+	std::string n(name);
+#define RET(vec) { *bytes = (vec).size() * sizeof((vec)[0]); return (vec).data(); }
+	if (n == "triangles")    RET(md.triangles)
+	if (n == "bvh2_nodes")   RET(md.bvh2.nodes)
+	if (n == "bvh2_indices") RET(md.bvh2.indices)
+	if (n == "bvh8_nodes")   RET(md.bvh8.nodes)
+	if (n == "bvh8_indices") RET(md.bvh8.indices)
+	*bytes = 0;
+	return nullptr;
+}
+
+// device_ordinal < 0: host-only baking (no GPU needed)
+void * grt_pathtracer_create(void * scene, int width, int height, int device_ordinal) {
+	GRT_TRY
+		return new Pathtracer(width, height, *(Scene *)scene, device_ordinal);
+	GRT_CATCH(nullptr)
+}
+void grt_pathtracer_free(void * pt) { delete (Pathtracer *)pt; }
+
+int grt_pathtracer_update(void * pt, float delta) {
+	GRT_TRY
+		((Pathtracer *)pt)->update(delta);
+		return 0;
+	GRT_CATCH(-1)
+}
+int grt_pathtracer_render(void * pt) {
+	GRT_TRY
+		((Pathtracer *)pt)->render();
+		return 0;
+	GRT_CATCH(-1)
+}
+int grt_pathtracer_resize(void * pt, int width, int height) {
+	GRT_TRY
+		Pathtracer * p = (Pathtracer *)pt;
+		p->resize_free();
+		p->resize_init(width, height);
+		return 0;
+	GRT_CATCH(-1)
+}
+int grt_pathtracer_set_pixel_range(void * pt, int offset, int count) {
+	GRT_TRY
+		((Pathtracer *)pt)->set_pixel_range(offset, count);
+		return 0;
+	GRT_CATCH(-1)
+}
+int  grt_pathtracer_sample_index(void * pt) { return ((Pathtracer *)pt)->sample_index; }
+int  grt_pathtracer_screen_pitch(void * pt) { return ((Pathtracer *)pt)->screen_pitch; }
+void grt_pathtracer_invalidate(void * pt, const char * what) {
+	Pathtracer * p = (Pathtracer *)pt;
+	std::string w(what);
+	if (w == "scene")      p->invalidated_scene = true;
+	if (w == "sky")        p->invalidated_sky = true;
+	if (w == "materials")  p->invalidated_materials = true;
+	if (w == "mediums")    p->invalidated_mediums = true;
+	if (w == "camera")     p->invalidated_camera = true;
+	if (w == "gpu_config") p->invalidated_gpu_config = true;
+	if (w == "aovs")       p->invalidated_aovs = true;
+}
+void grt_pathtracer_aov_enable(void * pt, int aov, int enable) {
+	if (enable) ((Pathtracer *)pt)->aov_enable(AOVType(aov)); else ((Pathtracer *)pt)->aov_disable(AOVType(aov));
+}
+void * grt_pathtracer_context(void * pt) { return ((Pathtracer *)pt)->ctx; }
+float  grt_pathtracer_lights_total_weight(void * pt) { return ((Pathtracer *)pt)->lights_total_weight; }
+
+int grt_pathtracer_read_aov(void * pt, int aov, int accumulated, float * dst) {
+	GRT_TRY
+		std::vector<float> image = ((Pathtracer *)pt)->read_aov(AOVType(aov), accumulated != 0);
+		memcpy(dst, image.data(), image.size() * sizeof(float));
+		return 0;
+	GRT_CATCH(-1)
+}
+int grt_pathtracer_read_framebuffer(void * pt, float * dst) {
+	GRT_TRY
+		std::vector<float> image = ((Pathtracer *)pt)->read_framebuffer();
+		memcpy(dst, image.data(), image.size() * sizeof(float));
+		return 0;
+	GRT_CATCH(-1)
+}
+
+// Host staging arrays by name (what the device was / would be given), read-only views.
+const void * grt_pathtracer_array(void * pt, const char * name, size_t * bytes) {
+	Pathtracer * p = (Pathtracer *)pt;
+	std::string n(name);
+	if (n == "triangles")             RET(p->aggregated_triangles)
+	if (n == "bvh8_nodes")            RET(p->aggregated_bvh_nodes_8)
+	if (n == "bvh2_nodes")            RET(p->aggregated_bvh_nodes_2)
+	if (n == "reverse_indices")       RET(p->reverse_indices)
+	if (n == "mesh_bvh_root_indices") RET(p->mesh_bvh_root_indices)
+	if (n == "mesh_material_ids")     RET(p->mesh_material_ids)
+	if (n == "mesh_transforms")       RET(p->mesh_transforms)
+	if (n == "mesh_transforms_inv")   RET(p->mesh_transforms_inv)
+	if (n == "mesh_transforms_prev")  RET(p->mesh_transforms_prev)
+	if (n == "material_types")        RET(p->material_types)
+	if (n == "materials")             RET(p->materials)
+	if (n == "media")                 RET(p->media)
+	if (n == "tlas_indices")          RET(p->tlas.indices)
+	if (n == "tlas_nodes")            RET(p->tlas.nodes)
+	if (n == "tlas_raw_nodes")        RET(p->tlas_raw.nodes)
+	if (n == "pmj_samples")           RET(p->pmj_samples)
+	if (n == "blue_noise")            RET(p->blue_noise)
+	if (n == "light_triangle_indices")                RET(p->light_triangle_indices)
+	if (n == "light_triangle_cumulative_probability") RET(p->light_triangle_cumulative_probability)
+	if (n == "light_mesh_cumulative_probability")     RET(p->light_mesh_cumulative_probability)
+	if (n == "light_mesh_triangle_span")              RET(p->light_mesh_triangle_span)
+	if (n == "light_mesh_transform_indices")          RET(p->light_mesh_transform_indices)
+	if (n == "sky")                   RET(p->scene.sky.data)
+	if (n == "camera") { *bytes = sizeof(rt_camera); return &p->device_camera; }
+	*bytes = 0;
+	return nullptr;
+#undef RET
+}
+void grt_pathtracer_sky_size(void * pt, int * w, int * h, float * scale) {
+	Pathtracer * p = (Pathtracer *)pt;
+	*w = p->scene.sky.width; *h = p->scene.sky.height; *scale = p->scene.sky.scale;
+}
+// Texture table views
+int grt_pathtracer_texture(void * pt, int index, const unsigned char ** texels, int * width, int * height, int * mip_levels) {
+	Pathtracer * p = (Pathtracer *)pt;
+	const std::vector<Texture> & t = p->scene.asset_manager.textures;
+	if (index < 0 || index >= int(t.size())) return -1;
+	*texels = t[index].texels.data(); *width = t[index].width; *height = t[index].height; *mip_levels = t[index].mip_levels();
+	return 0;
+}
+void grt_pathtracer_device_config(void * pt, rt_gpu_config * out) { *out = ((Pathtracer *)pt)->make_device_config(); }
+int  grt_pathtracer_counters(void * pt, rt_counters * out) {
+	GRT_TRY
+		*out = ((Pathtracer *)pt)->counters();
+		return 0;
+	GRT_CATCH(-1)
+}
+
+// Stand-alone builders for the parity tests against oracle/_ref
+// tris24: n x 24 floats (Triangle layout). Returns a MeshData* to query with grt_built_*.
+void * grt_build_blas(const float * tris24, int n) {
+	GRT_TRY
+		MeshData * md = new MeshData();
+		md->triangles.resize(n);
+		memcpy((void *)md->triangles.data(), tris24, size_t(n) * sizeof(Triangle));
+		md->bvh2 = BVH::create_from_triangles(md->triangles);
+		BVH8Converter(md->bvh8, md->bvh2).convert();
+		return md;
+	GRT_CATCH(nullptr)
+}
+const void * grt_built_array(void * mesh_data, const char * name, size_t * bytes) {
+	const MeshData & md = *(MeshData *)mesh_data;
+	std::string n(name);
+#define RET(vec) { *bytes = (vec).size() * sizeof((vec)[0]); return (vec).data(); }
+	if (n == "bvh2_nodes")   RET(md.bvh2.nodes)
+	if (n == "bvh2_indices") RET(md.bvh2.indices)
+	if (n == "bvh8_nodes")   RET(md.bvh8.nodes)
+	if (n == "bvh8_indices") RET(md.bvh8.indices)
+#undef RET
+	*bytes = 0;
+	return nullptr;
+}
+void grt_built_free(void * mesh_data) { delete (MeshData *)mesh_data; }
+
+} // extern "C"

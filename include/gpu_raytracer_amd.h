@@ -1,0 +1,222 @@
+/*
+ * gpu_raytracer_amd.h -- C ABI of the MI355X-native wavefront path tracer device layer.
+ *
+ * This is the drop-in boundary for the hot path of jan-van-bergen/GPU-Raytracer
+ * (ray-generate -> BVH8/CWBVH trace -> sort -> shade/NEE -> shadow trace ->
+ * accumulate | SVGF/TAA).  The reference has no FFI: its host class `Integrator`
+ * talks to the device code by *name* -- 23 `extern "C" __global__` kernels found
+ * with cuModuleGetFunction (Src/Renderer/Integrators/Pathtracer.cpp:79-101) and
+ * ~55 `__device__` globals found with cuModuleGetGlobal (`get_global("...")`,
+ * Integrator.cpp / Pathtracer.cpp).  Every entry point below replaces one group of
+ * those by-name bindings; the comment on each one cites what it replaces.
+ *
+ * Conventions: plain pointers and sizes only (no C++/torch types); one opaque
+ * context per GPU; every function returns RT_OK (0) or a negative rt_status and
+ * records a message retrievable with rt_last_error(); host pointers unless the
+ * name says `_device`; all work is enqueued on the context's HIP stream and is
+ * complete when the call returns only where stated ("synchronous").
+ */
+#ifndef GPU_RAYTRACER_AMD_H
+#define GPU_RAYTRACER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants shared with the reference (Src/CUDA/Common.h) -------------------- */
+#define RT_MAX_BOUNCES                  128   /* Common.h:75  MAX_BOUNCES            */
+#define RT_BATCH_SIZE                   (1080 * 720) /* Common.h:71 BATCH_SIZE       */
+#define RT_PMJ_NUM_SEQUENCES            64    /* Common.h:79                         */
+#define RT_PMJ_NUM_SAMPLES_PER_SEQUENCE 4096  /* Common.h:80                         */
+#define RT_BLUE_NOISE_NUM_TEXTURES      16    /* Common.h:82                         */
+#define RT_BLUE_NOISE_TEXTURE_DIM       128   /* Common.h:83                         */
+#define RT_MAX_ATROUS_ITERATIONS        10    /* Common.h:99                         */
+#define RT_LUT_DIELECTRIC_DIM           16    /* Common.h:87-89 (ior, roughness, cos)*/
+#define RT_LUT_CONDUCTOR_DIM            32    /* Common.h:94-95                      */
+#define RT_INVALID                      (-1)
+
+typedef enum rt_status {
+	RT_OK                 =  0,
+	RT_ERROR_INVALID_ARG  = -1,
+	RT_ERROR_NO_DEVICE    = -2,   /* no HIP device / hipSetDevice failed               */
+	RT_ERROR_HIP          = -3,   /* a HIP runtime call failed (message has the detail)*/
+	RT_ERROR_NOT_READY    = -4,   /* render before the scene/tables were uploaded      */
+	RT_ERROR_OUT_OF_RANGE = -5
+} rt_status;
+
+/* AOVType, Common.h:28-37 */
+typedef enum rt_aov_type {
+	RT_AOV_RADIANCE = 0, RT_AOV_RADIANCE_DIRECT, RT_AOV_RADIANCE_INDIRECT,
+	RT_AOV_ALBEDO, RT_AOV_NORMAL, RT_AOV_POSITION, RT_AOV_COUNT
+} rt_aov_type;
+
+/* ReconstructionFilter, Common.h:21-25 */
+typedef enum rt_filter { RT_FILTER_BOX = 0, RT_FILTER_TENT, RT_FILTER_GAUSSIAN } rt_filter;
+
+/* MaterialType, CUDA/Material.h:13-19 (one byte per material on the device) */
+typedef enum rt_material_type {
+	RT_MATERIAL_LIGHT = 0, RT_MATERIAL_DIFFUSE, RT_MATERIAL_PLASTIC, RT_MATERIAL_DIELECTRIC, RT_MATERIAL_CONDUCTOR
+} rt_material_type;
+
+/* GPUConfig, Common.h:39-67 -- replaces the `config` device constant (Integrator.cpp:521). */
+typedef struct rt_gpu_config {
+	int32_t  reconstruction_filter;            /* rt_filter                               */
+	uint32_t aov_mask;                         /* bit i = AOV i enabled                   */
+	int32_t  num_bounces;
+	int32_t  enable_mipmapping;
+	int32_t  enable_next_event_estimation;
+	int32_t  enable_multiple_importance_sampling;
+	int32_t  enable_russian_roulette;
+	int32_t  enable_svgf;
+	int32_t  enable_spatial_variance;
+	int32_t  enable_taa;
+	float    alpha_colour;
+	float    alpha_moment;
+	int32_t  num_atrous_iterations;
+	float    sigma_z;
+	float    sigma_n;
+	float    sigma_l;
+} rt_gpu_config;
+
+/* Camera, CUDA/Camera.h:10-18 -- replaces the `camera` constant (Integrator.cpp:454-481). */
+typedef struct rt_camera {
+	float position[3];
+	float bottom_left_corner[3];
+	float x_axis[3];
+	float y_axis[3];
+	float pixel_spread_angle;
+	float aperture_radius;
+	float focal_distance;
+} rt_camera;
+
+/* One mip-mapped RGBA8 texture in LINEAR light, i.e. what the reference hands to
+ * cuMipmappedArray before optional BC1 compression (Assets/TextureLoader.cpp:145-206).
+ * CDNA compute parts have no texture units, so wrap addressing and bi/tri-linear
+ * filtering are done in the shade kernel on these texels.                             */
+typedef struct rt_texture_desc {
+	const uint8_t * texels;      /* all mip levels back to back, level 0 first, 4 B/texel */
+	int32_t         width, height; /* level 0 size; level l is max(w>>l,1) x max(h>>l,1)  */
+	int32_t         mip_levels;
+} rt_texture_desc;
+
+/* Per-stage counters of the last rt_render_sample, replaces the read-back of
+ * `buffer_sizes` (Pathtracer.cpp:845-847) and the CUDAEventPool timings.              */
+typedef struct rt_counters {
+	int32_t trace     [RT_MAX_BOUNCES];        /* rays traced per bounce (closest hit)    */
+	int32_t shadow    [RT_MAX_BOUNCES];        /* shadow rays traced per bounce           */
+	int32_t diffuse   [RT_MAX_BOUNCES];
+	int32_t plastic   [RT_MAX_BOUNCES];
+	int32_t dielectric[RT_MAX_BOUNCES];
+	int32_t conductor [RT_MAX_BOUNCES];
+	float   ms_generate, ms_trace, ms_sort, ms_shade, ms_shadow, ms_post; /* HIP-event sums */
+	float   ms_total;
+} rt_counters;
+
+typedef struct rt_context rt_context;
+
+/* ---- lifetime: replaces CUDAContext::init / Integrator::cuda_init / cuda_free --------
+ * (Device/CUDAContext.cpp:21, Pathtracer.cpp:9-41, Integrator.h:203-229)                */
+int          rt_create (int device_ordinal, rt_context ** out_ctx);
+void         rt_destroy(rt_context * ctx);
+const char * rt_last_error(const rt_context * ctx);      /* ctx may be NULL: last global error */
+const char * rt_version(void);
+
+/* ---- scene upload ------------------------------------------------------------------- */
+/* Replaces globals `triangles` and `bvh8_nodes` (Integrator.cpp:153-154,268-269).
+ * triangles: triangle_count x 96 B in the device layout CUDA/Raytracing/Triangle.h:4-11
+ * (position_0, edge_1, edge_2, normal_0, n_edge_1, n_edge_2, uv_0, uv_edge_1, uv_edge_2),
+ * already permuted by the BLAS indices.  bvh8_nodes: node_count x 80 B CWBVH nodes
+ * (BVH/BVH.h:61-80); slots [0, 2*mesh_count) are reserved for the TLAS.                 */
+int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle_count,
+                       const void * bvh8_nodes, size_t node_count);
+/* Replaces the per-frame TLAS memcpy into the front of `bvh8_nodes` (Integrator.cpp:404-409). */
+int rt_upload_tlas(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count);
+/* Replaces `bvh2_nodes` (Integrator.cpp:205-206): binary SAH BVH, 32 B nodes, for
+ * rt_set_bvh_type(ctx, 2) (BASELINE config #1).  TLAS occupies the first slots likewise. */
+int rt_upload_geometry_bvh2(rt_context * ctx, const void * triangles, size_t triangle_count,
+                            const void * bvh2_nodes, size_t node_count);
+int rt_upload_tlas_bvh2(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count);
+int rt_set_bvh_type(rt_context * ctx, int bvh_width /* 2 or 8 */);
+/* Replaces mesh_bvh_root_indices / mesh_material_ids / mesh_transforms{,_inv,_prev}
+ * (Integrator.cpp:412-429). Index = TLAS-order mesh id. Matrices are 12 floats, row-major
+ * 3x4.  MSB of root_indices[i] = "identity transform" (Integrator.cpp:415).              */
+int rt_upload_instances(rt_context * ctx, const int32_t * root_indices, const int32_t * material_ids,
+                        const float * transforms, const float * transforms_inv, const float * transforms_prev,
+                        size_t mesh_count);
+/* Replaces material_types / materials (Pathtracer.cpp:545-589): types = 1 B each,
+ * materials = 32 B each in the union layout of CUDA/Material.h:21-39.                    */
+int rt_upload_materials(rt_context * ctx, const uint8_t * types, const void * materials, size_t count);
+/* Replaces `media` (Pathtracer.cpp:681-697): 32 B each {sigma_a.xyz, g, sigma_s.xyz, pad}. */
+int rt_upload_media(rt_context * ctx, const void * media, size_t count);
+/* Replaces `textures` (Integrator.cpp:33-98). */
+int rt_upload_textures(rt_context * ctx, const rt_texture_desc * descs, size_t count);
+/* Replaces light_* globals and lights_total_weight (Pathtracer.cpp:455-534).             */
+int rt_upload_lights(rt_context * ctx,
+                     const int32_t * light_triangle_indices, const float * light_triangle_cumulative_probability, size_t light_triangle_count,
+                     const float * light_mesh_cumulative_probability, const int32_t * light_mesh_triangle_span /* 2 per mesh */,
+                     const int32_t * light_mesh_transform_indices, size_t light_mesh_count,
+                     float lights_total_weight);
+/* Replaces pmj_samples / blue_noise_textures (Integrator.cpp:298-304):
+ * pmj = 64*4096 float2, blue_noise = 16*128*128 uchar2.                                   */
+int rt_upload_rng(rt_context * ctx, const float * pmj_samples, const uint8_t * blue_noise);
+/* Replaces sky_texture / sky_scale (Integrator.cpp:285-296): equirect float4 image.       */
+int rt_set_sky(rt_context * ctx, const float * rgba, int width, int height, float scale);
+
+/* ---- per-frame state ------------------------------------------------------------------ */
+/* Replaces resize_init/resize_free: screen_width/pitch/height, AOV buffers, SVGF buffers
+ * (Pathtracer.cpp:255-301,316-357). pitch = round_up(width, 32).                          */
+int rt_resize(rt_context * ctx, int width, int height);
+int rt_set_camera(rt_context * ctx, const rt_camera * camera);
+/* Replaces `svgf_data` (Pathtracer.cpp:707-717): two row-major 4x4 matrices.              */
+int rt_set_svgf_matrices(rt_context * ctx, const float * view_projection, const float * view_projection_prev);
+int rt_set_config(rt_context * ctx, const rt_gpu_config * config);
+/* Multi-GPU tile split: this context only renders pixels [offset, offset+count) of the
+ * scan-order frame (the reference's kernel_generate(sample, pixel_offset, pixel_count),
+ * Pathtracer.cu:122-131). Default = whole frame.                                          */
+int rt_set_pixel_range(rt_context * ctx, int pixel_offset, int pixel_count);
+
+/* ---- render: replaces Pathtracer::render (Pathtracer.cpp:738-855) ---------------------- */
+/* One sample for this context's pixel range: generate, (trace, sort, shade*, shadow) x
+ * bounces, then accumulate or SVGF/TAA.  Asynchronous; rt_synchronize or a read waits.    */
+int rt_render_sample(rt_context * ctx, int sample_index);
+int rt_synchronize(rt_context * ctx);
+/* Counters of the most recent completed rt_render_sample (synchronous).                    */
+int rt_get_counters(rt_context * ctx, rt_counters * out);
+
+/* ---- results ----------------------------------------------------------------------------*/
+/* Replaces get_aov(type).accumulator read-back (Main.cpp:226-249). Copies pitch*height
+ * float4 to dst (host). accumulated=0 reads the per-frame framebuffer instead.             */
+int rt_read_aov(rt_context * ctx, int aov_type, float * dst, int accumulated);
+/* The final image (`accumulator` surface, Pathtracer.cu:24): pitch*height float4.          */
+int rt_read_framebuffer(rt_context * ctx, float * dst);
+/* Device pointer of the final image for zero-copy consumers (RCCL gather).                 */
+int rt_framebuffer_device_ptr(rt_context * ctx, void ** out_ptr, size_t * out_bytes);
+int rt_screen_pitch(rt_context * ctx);
+
+/* ---- kernel-level entry points (parity tests and micro-benchmarks) ----------------------*/
+/* kernel_trace_bvh8 / kernel_trace_shadow_bvh8 on caller-supplied rays (SoA host arrays).
+ * hits: ray_count x uint4 {mesh_id, triangle_id, t bits, u16|v16<<16} (Buffers.h:25-32).
+ * Synchronous. `repeat` > 1 re-runs the kernel for timing; out_ms = mean kernel ms.        */
+int rt_trace_rays(rt_context * ctx, const float * ox, const float * oy, const float * oz,
+                  const float * dx, const float * dy, const float * dz, size_t ray_count,
+                  uint32_t * hits, int repeat, float * out_ms);
+int rt_trace_shadow_rays(rt_context * ctx, const float * ox, const float * oy, const float * oz,
+                         const float * dx, const float * dy, const float * dz, const float * max_distance,
+                         size_t ray_count, uint8_t * occluded, int repeat, float * out_ms);
+/* kernel_generate only: writes the primary rays of pixels [offset, offset+count).          */
+int rt_generate_rays(rt_context * ctx, int sample_index, int pixel_offset, int pixel_count,
+                     float * ox, float * oy, float * oz, float * dx, float * dy, float * dz,
+                     uint32_t * pixel_index_and_flags);
+/* random<Dim>() (CUDA/Sampling.h:44-84) for `count` (pixel_index) values: out = float2 each. */
+int rt_random_samples(rt_context * ctx, int dimension, const uint32_t * pixel_indices, size_t count,
+                      uint32_t bounce, uint32_t sample_index, float * out_xy);
+/* Streaming-read bandwidth probe used as the measured HBM roofline (GB/s).                 */
+int rt_measure_stream_bandwidth(rt_context * ctx, size_t bytes, int repeat, float * out_gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPU_RAYTRACER_AMD_H */
