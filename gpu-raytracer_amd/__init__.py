@@ -1,0 +1,435 @@
+"""ctypes front-end of the MI355X-native path tracer.
+
+Two in-tree shared libraries are loaded from this directory:
+
+* ``csrc/libgrt_device.so`` -- HIP kernels + the C ABI of ``include/gpu_raytracer_amd.h``
+* ``host/libgrt_host.so``   -- C++ host classes (Scene, Mitsuba/OBJ loaders, BVH builders,
+  Integrator/Pathtracer mirroring the reference's API) plus a flat C shim
+
+Nothing here computes anything: it only marshals numpy arrays into those libraries.  The
+libraries must have been built (``python __graft_entry__.py`` or ``make -C gpu-raytracer_amd``);
+there is no Python or CPU fallback for the device path.
+"""
+import ctypes
+import os
+import tarfile
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+ASSET_DIR = os.path.join(REPO_ROOT, "assets")
+DEVICE_LIB_PATH = os.path.join(_HERE, "csrc", "libgrt_device.so")
+HOST_LIB_PATH = os.path.join(_HERE, "host", "libgrt_host.so")
+
+RT_MAX_BOUNCES = 128
+RT_BATCH_SIZE = 1080 * 720
+AOV_RADIANCE, AOV_RADIANCE_DIRECT, AOV_RADIANCE_INDIRECT, AOV_ALBEDO, AOV_NORMAL, AOV_POSITION, AOV_COUNT = range(7)
+MATERIAL_LIGHT, MATERIAL_DIFFUSE, MATERIAL_PLASTIC, MATERIAL_DIELECTRIC, MATERIAL_CONDUCTOR = range(5)
+FILTER_BOX, FILTER_TENT, FILTER_GAUSSIAN = range(3)
+
+
+class GPUConfig(ctypes.Structure):  # rt_gpu_config
+    _fields_ = [("reconstruction_filter", c_int32), ("aov_mask", c_uint32), ("num_bounces", c_int32),
+                ("enable_mipmapping", c_int32), ("enable_next_event_estimation", c_int32),
+                ("enable_multiple_importance_sampling", c_int32), ("enable_russian_roulette", c_int32),
+                ("enable_svgf", c_int32), ("enable_spatial_variance", c_int32), ("enable_taa", c_int32),
+                ("alpha_colour", c_float), ("alpha_moment", c_float), ("num_atrous_iterations", c_int32),
+                ("sigma_z", c_float), ("sigma_n", c_float), ("sigma_l", c_float)]
+
+
+class Camera(ctypes.Structure):  # rt_camera
+    _fields_ = [("position", c_float * 3), ("bottom_left_corner", c_float * 3), ("x_axis", c_float * 3),
+                ("y_axis", c_float * 3), ("pixel_spread_angle", c_float), ("aperture_radius", c_float),
+                ("focal_distance", c_float)]
+
+
+class Counters(ctypes.Structure):  # rt_counters
+    _fields_ = [("trace", c_int32 * RT_MAX_BOUNCES), ("shadow", c_int32 * RT_MAX_BOUNCES),
+                ("diffuse", c_int32 * RT_MAX_BOUNCES), ("plastic", c_int32 * RT_MAX_BOUNCES),
+                ("dielectric", c_int32 * RT_MAX_BOUNCES), ("conductor", c_int32 * RT_MAX_BOUNCES),
+                ("ms_generate", c_float), ("ms_trace", c_float), ("ms_sort", c_float), ("ms_shade", c_float),
+                ("ms_shadow", c_float), ("ms_post", c_float), ("ms_total", c_float)]
+
+
+class DeviceLibraryMissing(RuntimeError):
+    pass
+
+
+_device = None
+_host = None
+
+
+def device_lib():
+    """The C-ABI library. Raises loudly when it has not been built: there is no fallback."""
+    global _device
+    if _device is None:
+        if not os.path.exists(DEVICE_LIB_PATH):
+            raise DeviceLibraryMissing("%s is missing -- run `python __graft_entry__.py` (build()) first" % DEVICE_LIB_PATH)
+        lib = ctypes.CDLL(DEVICE_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        lib.rt_last_error.restype = c_char_p
+        lib.rt_last_error.argtypes = [c_void_p]
+        lib.rt_version.restype = c_char_p
+        lib.rt_create.argtypes = [c_int, POINTER(c_void_p)]
+        lib.rt_destroy.argtypes = [c_void_p]
+        fp, u32p, u8p = POINTER(c_float), POINTER(c_uint32), POINTER(c_uint8)
+        lib.rt_trace_rays.argtypes = [c_void_p] + [c_void_p] * 6 + [c_size_t, c_void_p, c_int, POINTER(c_float)]
+        lib.rt_trace_shadow_rays.argtypes = [c_void_p] + [c_void_p] * 7 + [c_size_t, c_void_p, c_int, POINTER(c_float)]
+        lib.rt_generate_rays.argtypes = [c_void_p, c_int, c_int, c_int] + [c_void_p] * 7
+        lib.rt_random_samples.argtypes = [c_void_p, c_int, c_void_p, c_size_t, c_uint32, c_uint32, c_void_p]
+        lib.rt_measure_stream_bandwidth.argtypes = [c_void_p, c_size_t, c_int, POINTER(c_float)]
+        lib.rt_set_profiling.argtypes = [c_void_p, c_int]
+        lib.rt_get_counters.argtypes = [c_void_p, POINTER(Counters)]
+        lib.rt_render_sample.argtypes = [c_void_p, c_int]
+        lib.rt_synchronize.argtypes = [c_void_p]
+        lib.rt_set_pixel_range.argtypes = [c_void_p, c_int, c_int]
+        lib.rt_read_framebuffer.argtypes = [c_void_p, c_void_p]
+        lib.rt_read_aov.argtypes = [c_void_p, c_int, c_void_p, c_int]
+        lib.rt_framebuffer_device_ptr.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]
+        lib.rt_screen_pitch.argtypes = [c_void_p]
+        lib.rt_read_luts.argtypes = [c_void_p] + [c_void_p] * 6
+        lib.rt_set_config.argtypes = [c_void_p, POINTER(GPUConfig)]
+        _device = lib
+    return _device
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        device_lib()  # libgrt_host.so links against it
+        if not os.path.exists(HOST_LIB_PATH):
+            raise DeviceLibraryMissing("%s is missing -- run `python __graft_entry__.py` (build()) first" % HOST_LIB_PATH)
+        os.environ.setdefault("GRT_ASSET_DIR", ASSET_DIR)
+        lib = ctypes.CDLL(HOST_LIB_PATH)
+        lib.grt_last_error.restype = c_char_p
+        lib.grt_config_set.argtypes = [c_char_p, c_double]
+        lib.grt_config_get.argtypes = [c_char_p]
+        lib.grt_config_get.restype = c_double
+        lib.grt_scene_load.restype = c_void_p
+        lib.grt_scene_load.argtypes = [c_char_p, c_char_p]
+        lib.grt_scene_free.argtypes = [c_void_p]
+        for name in ("grt_scene_mesh_count", "grt_scene_material_count", "grt_scene_texture_count", "grt_scene_mesh_data_count", "grt_scene_wait_until_loaded"):
+            getattr(lib, name).argtypes = [c_void_p]
+        lib.grt_scene_bvh_build_ms.argtypes = [c_void_p]
+        lib.grt_scene_bvh_build_ms.restype = c_double
+        lib.grt_scene_set_sky_scale.argtypes = [c_void_p, c_float]
+        lib.grt_scene_set_camera.argtypes = [c_void_p, POINTER(c_float), POINTER(c_float), c_float]
+        lib.grt_scene_get_camera.argtypes = [c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_float)]
+        lib.grt_scene_set_material.argtypes = [c_void_p, c_int, c_int, POINTER(c_float), c_float]
+        lib.grt_scene_material_type.argtypes = [c_void_p, c_int]
+        lib.grt_mesh_data_array.restype = c_void_p
+        lib.grt_mesh_data_array.argtypes = [c_void_p, c_int, c_char_p, POINTER(c_size_t)]
+        lib.grt_pathtracer_create.restype = c_void_p
+        lib.grt_pathtracer_create.argtypes = [c_void_p, c_int, c_int, c_int]
+        lib.grt_pathtracer_free.argtypes = [c_void_p]
+        lib.grt_pathtracer_update.argtypes = [c_void_p, c_float]
+        lib.grt_pathtracer_render.argtypes = [c_void_p]
+        lib.grt_pathtracer_resize.argtypes = [c_void_p, c_int, c_int]
+        lib.grt_pathtracer_set_pixel_range.argtypes = [c_void_p, c_int, c_int]
+        lib.grt_pathtracer_sample_index.argtypes = [c_void_p]
+        lib.grt_pathtracer_screen_pitch.argtypes = [c_void_p]
+        lib.grt_pathtracer_invalidate.argtypes = [c_void_p, c_char_p]
+        lib.grt_pathtracer_aov_enable.argtypes = [c_void_p, c_int, c_int]
+        lib.grt_pathtracer_context.restype = c_void_p
+        lib.grt_pathtracer_context.argtypes = [c_void_p]
+        lib.grt_pathtracer_lights_total_weight.restype = c_float
+        lib.grt_pathtracer_lights_total_weight.argtypes = [c_void_p]
+        lib.grt_pathtracer_read_aov.argtypes = [c_void_p, c_int, c_int, c_void_p]
+        lib.grt_pathtracer_read_framebuffer.argtypes = [c_void_p, c_void_p]
+        lib.grt_pathtracer_array.restype = c_void_p
+        lib.grt_pathtracer_array.argtypes = [c_void_p, c_char_p, POINTER(c_size_t)]
+        lib.grt_pathtracer_sky_size.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_float)]
+        lib.grt_pathtracer_texture.argtypes = [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_int)]
+        lib.grt_pathtracer_device_config.argtypes = [c_void_p, POINTER(GPUConfig)]
+        lib.grt_pathtracer_counters.argtypes = [c_void_p, POINTER(Counters)]
+        lib.grt_build_blas.restype = c_void_p
+        lib.grt_build_blas.argtypes = [c_void_p, c_int]
+        lib.grt_built_array.restype = c_void_p
+        lib.grt_built_array.argtypes = [c_void_p, c_char_p, POINTER(c_size_t)]
+        lib.grt_built_free.argtypes = [c_void_p]
+        _host = lib
+    return _host
+
+
+def _host_check(status):
+    if status != 0:
+        raise RuntimeError(host_lib().grt_last_error().decode())
+
+
+def _view(ptr, nbytes, dtype):
+    if not ptr or nbytes == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (ctypes.c_char * nbytes).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).copy()
+
+
+# ---- scenes ---------------------------------------------------------------------------------------
+
+def scene_path(name):
+    """Path of a bundled scene's xml; archives under assets/scenes are unpacked on first use.
+
+    'cornellbox' and 'sponza' are the geometry of the reference's Data/cornellbox and
+    Data/Sponza (Crytek Sponza), packed because /root/reference does not exist on the GPU box.
+    """
+    cache = os.path.join(ASSET_DIR, "_cache")
+    table = {"cornellbox": ("cornellbox.tar.xz", "cornellbox/scene.xml"), "sponza": ("sponza_geometry.tar.xz", "Sponza/scene.xml")}
+    if name not in table:
+        raise KeyError("unknown bundled scene %r" % name)
+    archive, xml = table[name]
+    target = os.path.join(cache, xml)
+    if not os.path.exists(target):
+        os.makedirs(cache, exist_ok=True)
+        with tarfile.open(os.path.join(ASSET_DIR, "scenes", archive)) as tar:
+            tar.extractall(cache)
+    return target
+
+
+def config_reset():
+    host_lib().grt_config_reset()
+
+
+def config_set(**kwargs):
+    lib = host_lib()
+    for key, value in kwargs.items():
+        if lib.grt_config_set(key.encode(), float(value)) != 0:
+            raise KeyError(lib.grt_last_error().decode())
+
+
+def config_get(key):
+    return host_lib().grt_config_get(key.encode())
+
+
+class Scene:
+    """reference: Src/Renderer/Scene.h -- loads one .xml/.obj scene file."""
+
+    def __init__(self, filename, sky=None):
+        lib = host_lib()
+        self.handle = lib.grt_scene_load(os.fsencode(filename), os.fsencode(sky) if sky else b"")
+        if not self.handle:
+            raise RuntimeError("scene load failed: " + lib.grt_last_error().decode())
+
+    def close(self):
+        if self.handle:
+            host_lib().grt_scene_free(self.handle)
+            self.handle = None
+
+    def wait_until_loaded(self):
+        _host_check(host_lib().grt_scene_wait_until_loaded(self.handle))
+
+    @property
+    def mesh_count(self):
+        return host_lib().grt_scene_mesh_count(self.handle)
+
+    @property
+    def material_count(self):
+        return host_lib().grt_scene_material_count(self.handle)
+
+    @property
+    def mesh_data_count(self):
+        return host_lib().grt_scene_mesh_data_count(self.handle)
+
+    @property
+    def bvh_build_ms(self):
+        return host_lib().grt_scene_bvh_build_ms(self.handle)
+
+    def mesh_data_array(self, index, name, dtype):
+        n = c_size_t()
+        ptr = host_lib().grt_mesh_data_array(self.handle, index, name.encode(), byref(n))
+        return _view(ptr, n.value, dtype)
+
+    def set_camera(self, position, rotation, fov=-1.0):
+        pos = (c_float * 3)(*position)
+        rot = (c_float * 4)(*rotation)
+        host_lib().grt_scene_set_camera(self.handle, pos, rot, float(fov))
+
+    def get_camera(self):
+        pos, rot, fov = (c_float * 3)(), (c_float * 4)(), c_float()
+        host_lib().grt_scene_get_camera(self.handle, pos, rot, byref(fov))
+        return list(pos), list(rot), fov.value
+
+    def set_sky_scale(self, scale):
+        host_lib().grt_scene_set_sky_scale(self.handle, float(scale))
+
+    def set_material(self, index, mtype, diffuse=None, linear_roughness=0.5):
+        d = (c_float * 3)(*diffuse) if diffuse is not None else None
+        _host_check(host_lib().grt_scene_set_material(self.handle, index, mtype, d, float(linear_roughness)))
+
+    def material_type(self, index):
+        return host_lib().grt_scene_material_type(self.handle, index)
+
+
+_ARRAY_DTYPES = {
+    "triangles": np.float32, "bvh8_nodes": np.uint8, "bvh2_nodes": np.uint8, "reverse_indices": np.int32,
+    "mesh_bvh_root_indices": np.int32, "mesh_material_ids": np.int32, "mesh_transforms": np.float32,
+    "mesh_transforms_inv": np.float32, "mesh_transforms_prev": np.float32, "material_types": np.uint8,
+    "materials": np.float32, "media": np.float32, "tlas_indices": np.int32, "tlas_nodes": np.uint8,
+    "tlas_raw_nodes": np.uint8, "pmj_samples": np.float32, "blue_noise": np.uint8,
+    "light_triangle_indices": np.int32, "light_triangle_cumulative_probability": np.float32,
+    "light_mesh_cumulative_probability": np.float32, "light_mesh_triangle_span": np.int32,
+    "light_mesh_transform_indices": np.int32, "sky": np.float32, "camera": np.uint8,
+}
+
+
+class Pathtracer:
+    """reference: Src/Renderer/Integrators/Pathtracer.h -- update()/render() protocol.
+
+    device < 0 creates a host-only integrator that bakes the device data formats but cannot
+    render (used by the CPU tests and the oracle).
+    """
+
+    def __init__(self, scene, width, height, device=0):
+        lib = host_lib()
+        self.scene = scene
+        self.handle = lib.grt_pathtracer_create(scene.handle, width, height, device)
+        if not self.handle:
+            raise RuntimeError("Pathtracer creation failed: " + lib.grt_last_error().decode())
+        self.width, self.height = width, height
+
+    def close(self):
+        if self.handle:
+            host_lib().grt_pathtracer_free(self.handle)
+            self.handle = None
+
+    @property
+    def ctx(self):
+        return host_lib().grt_pathtracer_context(self.handle)
+
+    @property
+    def sample_index(self):
+        return host_lib().grt_pathtracer_sample_index(self.handle)
+
+    @property
+    def pitch(self):
+        return host_lib().grt_pathtracer_screen_pitch(self.handle)
+
+    @property
+    def lights_total_weight(self):
+        return host_lib().grt_pathtracer_lights_total_weight(self.handle)
+
+    def update(self, delta=0.0):
+        _host_check(host_lib().grt_pathtracer_update(self.handle, float(delta)))
+
+    def render(self):
+        _host_check(host_lib().grt_pathtracer_render(self.handle))
+
+    def invalidate(self, what):
+        host_lib().grt_pathtracer_invalidate(self.handle, what.encode())
+
+    def aov_enable(self, aov, enable=True):
+        host_lib().grt_pathtracer_aov_enable(self.handle, aov, 1 if enable else 0)
+
+    def set_pixel_range(self, offset, count):
+        _host_check(host_lib().grt_pathtracer_set_pixel_range(self.handle, offset, count))
+
+    def array(self, name):
+        n = c_size_t()
+        ptr = host_lib().grt_pathtracer_array(self.handle, name.encode(), byref(n))
+        return _view(ptr, n.value, _ARRAY_DTYPES[name])
+
+    def camera(self):
+        cam = Camera()
+        raw = self.array("camera")
+        ctypes.memmove(byref(cam), raw.ctypes.data, ctypes.sizeof(cam))
+        return cam
+
+    def device_config(self):
+        cfg = GPUConfig()
+        host_lib().grt_pathtracer_device_config(self.handle, byref(cfg))
+        return cfg
+
+    def sky(self):
+        w, h, s = c_int(), c_int(), c_float()
+        host_lib().grt_pathtracer_sky_size(self.handle, byref(w), byref(h), byref(s))
+        return self.array("sky"), w.value, h.value, s.value
+
+    def textures(self):
+        out = []
+        i = 0
+        while True:
+            texels, w, h, levels = c_void_p(), c_int(), c_int(), c_int()
+            if host_lib().grt_pathtracer_texture(self.handle, i, byref(texels), byref(w), byref(h), byref(levels)) != 0:
+                break
+            count = 0
+            for l in range(levels.value):
+                count += max(w.value >> l, 1) * max(h.value >> l, 1)
+            out.append((_view(texels.value, count * 4, np.uint8), w.value, h.value, levels.value))
+            i += 1
+        return out
+
+    def read_framebuffer(self):
+        image = np.zeros((self.height, self.pitch, 4), np.float32)
+        _host_check(host_lib().grt_pathtracer_read_framebuffer(self.handle, image.ctypes.data))
+        return image
+
+    def read_aov(self, aov, accumulated=True):
+        image = np.zeros((self.height, self.pitch, 4), np.float32)
+        _host_check(host_lib().grt_pathtracer_read_aov(self.handle, aov, 1 if accumulated else 0, image.ctypes.data))
+        return image
+
+    def counters(self):
+        c = Counters()
+        _host_check(host_lib().grt_pathtracer_counters(self.handle, byref(c)))
+        return c
+
+
+# ---- kernel-level entry points of the C ABI -----------------------------------------------------------
+
+def _dev_check(ctx, status):
+    if status != 0:
+        raise RuntimeError("device layer: " + device_lib().rt_last_error(ctx).decode())
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def trace_rays(ctx, origin, direction, repeat=1):
+    """rt_trace_rays: origin/direction are (3, N) float32 SoA. Returns (hits uint32[N,4], mean kernel ms)."""
+    o, d = _f32(origin), _f32(direction)
+    n = o.shape[1]
+    hits = np.zeros((n, 4), np.uint32)
+    ms = c_float()
+    _dev_check(ctx, device_lib().rt_trace_rays(ctx, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data, d[0].ctypes.data, d[1].ctypes.data, d[2].ctypes.data, n, hits.ctypes.data, repeat, byref(ms)))
+    return hits, ms.value
+
+
+def trace_shadow_rays(ctx, origin, direction, max_distance, repeat=1):
+    o, d, m = _f32(origin), _f32(direction), _f32(max_distance)
+    n = o.shape[1]
+    occluded = np.zeros(n, np.uint8)
+    ms = c_float()
+    _dev_check(ctx, device_lib().rt_trace_shadow_rays(ctx, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data, d[0].ctypes.data, d[1].ctypes.data, d[2].ctypes.data, m.ctypes.data, n, occluded.ctypes.data, repeat, byref(ms)))
+    return occluded, ms.value
+
+
+def generate_rays(ctx, sample_index, pixel_offset, pixel_count):
+    o = np.zeros((3, pixel_count), np.float32)
+    d = np.zeros((3, pixel_count), np.float32)
+    px = np.zeros(pixel_count, np.uint32)
+    _dev_check(ctx, device_lib().rt_generate_rays(ctx, sample_index, pixel_offset, pixel_count, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data, d[0].ctypes.data, d[1].ctypes.data, d[2].ctypes.data, px.ctypes.data))
+    return o, d, px
+
+
+def random_samples(ctx, dimension, pixel_indices, bounce, sample_index):
+    px = np.ascontiguousarray(pixel_indices, dtype=np.uint32)
+    out = np.zeros((px.size, 2), np.float32)
+    _dev_check(ctx, device_lib().rt_random_samples(ctx, dimension, px.ctypes.data, px.size, bounce, sample_index, out.ctypes.data))
+    return out
+
+
+def measure_stream_bandwidth(ctx, nbytes=1 << 30, repeat=5):
+    gbps = c_float()
+    _dev_check(ctx, device_lib().rt_measure_stream_bandwidth(ctx, nbytes, repeat, byref(gbps)))
+    return gbps.value
+
+
+def read_luts(ctx):
+    shapes = [4096, 4096, 256, 256, 1024, 32]
+    arrays = [np.zeros(s, np.float32) for s in shapes]
+    _dev_check(ctx, device_lib().rt_read_luts(ctx, *[a.ctypes.data for a in arrays]))
+    return arrays
+
+
+def set_profiling(ctx, enable):
+    _dev_check(ctx, device_lib().rt_set_profiling(ctx, 1 if enable else 0))

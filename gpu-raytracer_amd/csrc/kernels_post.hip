@@ -1,0 +1,562 @@
+// kernels_post.hip -- image-space kernels: accumulate, SVGF (reproject / variance / a-trous /
+// finalize), TAA, plus the Kulla-Conty LUT integration kernels and a bandwidth probe.
+//
+// Replaces kernel_accumulate (CUDA/Pathtracer.cu:775-796), the six kernels of
+// CUDA/SVGF/{SVGF,TAA}.h and the four LUT kernels of CUDA/KullaConty.h:83-240.
+// All of these stream pitch x height float4 images: HBM-bandwidth bound, so each thread
+// handles one pixel with 16-byte loads/stores and consecutive lanes touch consecutive
+// pixels (256 B per wave per access). CUDA surfaces become plain pitched arrays; reads the
+// reference does with cudaBoundaryModeClamp are clamped index computations.
+#include "rt_shading.h"
+
+#define RT_POST_BLOCK_X 64
+#define RT_POST_BLOCK_Y 4
+
+RT_DEV f4 ld4(const float4 * p, int i) { return mk4(p[i]); }
+RT_DEV void st4(float4 * p, int i, f4 v) { p[i] = to_float4(v); }
+
+// ---- accumulate ---------------------------------------------------------------------------------
+
+RT_DEV f4 aov_accumulate(const RtParams & p, int aov, int pixel_index, float n) { // AOV.h:35-46
+	const RtAOV & a = p.aovs[aov];
+	if (!a.framebuffer) return mk4(0.0f);
+	f4 fb = mk4(a.framebuffer[pixel_index]);
+	f4 acc;
+	if (n > 0.0f) { acc = mk4(a.accumulator[pixel_index]); acc = acc + (fb - acc) / n; }
+	else acc = fb;
+	a.accumulator[pixel_index] = to_float4(acc);
+	return acc;
+}
+
+__global__ void __launch_bounds__(256) kernel_accumulate(RtParams p, float frames_accumulated, int pixel_offset, int pixel_count) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pixel_count; i += gridDim.x * blockDim.x) {
+		int idx = i + pixel_offset;
+		int x = idx % p.screen_width, y = idx / p.screen_width;
+		int pixel_index = x + y * p.screen_pitch;
+
+		f4 colour = aov_accumulate(p, RT_AOV_RADIANCE, pixel_index, frames_accumulated);
+		aov_accumulate(p, RT_AOV_ALBEDO,   pixel_index, frames_accumulated);
+		aov_accumulate(p, RT_AOV_NORMAL,   pixel_index, frames_accumulated);
+		aov_accumulate(p, RT_AOV_POSITION, pixel_index, frames_accumulated);
+
+		if (!isfinite(colour.x + colour.y + colour.z)) colour = mk4(1000.0f, 0.0f, 1000.0f, 1.0f); // NaN guard, Pathtracer.cu:790-793
+		p.final_image[pixel_index] = to_float4(colour);
+	}
+}
+
+// ---- SVGF ----------------------------------------------------------------------------------------
+
+#define RT_SVGF_EPSILON 1e-8f
+#define RT_FEEDBACK_ITERATION 1
+
+RT_DEV f3 oct_decode_normal(f2 f) {
+	f = mk2(f.x * 2.0f - 1.0f, f.y * 2.0f - 1.0f);
+	f3 n = mk3(f.x, f.y, 1.0f - fabsf(f.x) - fabsf(f.y));
+	float t = saturate(-n.z);
+	n.x += n.x >= 0.0f ? -t : t;
+	n.y += n.y >= 0.0f ? -t : t;
+	return normalize(n);
+}
+RT_DEV f3 rgb_to_ycocg(f3 c) { return mk3(0.25f * c.x + 0.5f * c.y + 0.25f * c.z, 0.5f * c.x - 0.5f * c.z, -0.25f * c.x + 0.5f * c.y - 0.25f * c.z); }
+RT_DEV f3 ycocg_to_rgb(f3 c) { return mk3(saturate(c.x + c.y - c.z), saturate(c.x + c.z), saturate(c.x - c.y - c.z)); }
+RT_DEV float mitchell_netravali(float x) {
+	const float B = 1.0f / 3.0f, C = 1.0f / 3.0f;
+	x = fabsf(x);
+	float x2 = x * x, x3 = x2 * x;
+	if (x < 1.0f) return (1.0f / 6.0f) * ((12.0f - 9.0f * B - 6.0f * C) * x3 + (-18.0f + 12.0f * B + 6.0f * C) * x2 + (6.0f - 2.0f * B));
+	if (x < 2.0f) return (1.0f / 6.0f) * ((-B - 6.0f * C) * x3 + (6.0f * B + 30.0f * C) * x2 + (-12.0f * B - 48.0f * C) * x + (8.0f * B + 24.0f * C));
+	return 0.0f;
+}
+
+RT_DEV bool is_tap_consistent(const RtParams & p, int x, int y, f3 normal, float depth) {
+	if (x < 0 || x >= p.screen_width)  return false;
+	if (y < 0 || y >= p.screen_height) return false;
+	float4 prev = p.history_normal_and_depth[x + y * p.screen_pitch];
+	f3 prev_normal = oct_decode_normal(mk2(prev.x, prev.y));
+	return dot(normal, prev_normal) > 0.95f && fabsf(depth - prev.z) < 2.0f;
+}
+
+RT_DEV f2 edge_stopping_weights(const RtParams & p, int delta_x, int delta_y, f2 center_depth_gradient, float center_depth, float depth,
+		f3 center_normal, f3 normal, float cl_direct, float cl_indirect, float l_direct, float l_indirect, float denom_direct, float denom_indirect) {
+	float d = center_depth_gradient.x * float(delta_x) + center_depth_gradient.y * float(delta_y);
+	float ln_w_z = fabsf(center_depth - depth) / (p.config.sigma_z * fabsf(d) + RT_SVGF_EPSILON);
+	float w_n = powf(fmaxf(0.0f, dot(center_normal, normal)), p.config.sigma_n);
+	float w_l_direct   = w_n * expf(-fabsf(cl_direct   - l_direct)   * denom_direct   - ln_w_z);
+	float w_l_indirect = w_n * expf(-fabsf(cl_indirect - l_indirect) * denom_indirect - ln_w_z);
+	return mk2(w_l_direct, w_l_indirect);
+}
+
+__global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p) {
+	int x = blockIdx.x * blockDim.x + threadIdx.x;
+	int y = blockIdx.y * blockDim.y + threadIdx.y;
+	if (x >= p.screen_width || y >= p.screen_height) return;
+	int pixel_index = x + y * p.screen_pitch;
+
+	float4 * fb_direct = p.aovs[RT_AOV_RADIANCE_DIRECT].framebuffer, * fb_indirect = p.aovs[RT_AOV_RADIANCE_INDIRECT].framebuffer;
+	f4 direct = ld4(fb_direct, pixel_index), indirect = ld4(fb_indirect, pixel_index);
+
+	f4 moment;
+	moment.x = luminance(direct.x, direct.y, direct.z);
+	moment.y = luminance(indirect.x, indirect.y, indirect.z);
+	moment.z = moment.x * moment.x;
+	moment.w = moment.y * moment.y;
+
+	float4 normal_and_depth = p.gbuffer_normal_and_depth[pixel_index];
+	float2 screen_position_prev = p.gbuffer_screen_position_prev[pixel_index];
+
+	f3 normal = oct_decode_normal(mk2(normal_and_depth.x, normal_and_depth.y));
+	float depth = normal_and_depth.z, depth_prev = normal_and_depth.w;
+	if (depth == 0.0f) return; // sky
+
+	float s_prev = (0.5f + 0.5f * screen_position_prev.x) * float(p.screen_width);
+	float t_prev = (0.5f + 0.5f * screen_position_prev.y) * float(p.screen_height);
+	int x_prev = int(s_prev - 0.5f);
+	int y_prev = int(t_prev - 0.5f);
+
+	float fs = s_prev - floorf(s_prev), ft = t_prev - floorf(t_prev);
+	float w0 = (1.0f - fs) * (1.0f - ft), w1 = fs * (1.0f - ft), w2 = (1.0f - fs) * ft;
+	float w3 = 1.0f - w0 - w1 - w2;
+	float weights[4] = { w0, w1, w2, w3 };
+	float consistent_weights_sum = 0.0f;
+
+	#pragma unroll
+	for (int j = 0; j < 2; j++) {
+		#pragma unroll
+		for (int i = 0; i < 2; i++) {
+			int tap = i + j * 2;
+			if (is_tap_consistent(p, x_prev + i, y_prev + j, normal, depth_prev)) consistent_weights_sum += weights[tap];
+			else weights[tap] = 0.0f;
+		}
+	}
+
+	f4 prev_direct = mk4(0.0f), prev_indirect = mk4(0.0f), prev_moment = mk4(0.0f);
+	if (consistent_weights_sum > 0.0f) {
+		#pragma unroll
+		for (int j = 0; j < 2; j++) {
+			#pragma unroll
+			for (int i = 0; i < 2; i++) {
+				int tap = i + j * 2;
+				if (weights[tap] != 0.0f) {
+					int tap_index = (x_prev + i) + (y_prev + j) * p.screen_pitch;
+					prev_direct   += weights[tap] * ld4(p.history_direct,   tap_index);
+					prev_indirect += weights[tap] * ld4(p.history_indirect, tap_index);
+					prev_moment   += weights[tap] * ld4(p.history_moment,   tap_index);
+				}
+			}
+		}
+	} else {
+		for (int j = -1; j <= 1; j++) for (int i = -1; i <= 1; i++) {
+			int tap_x = x_prev + i, tap_y = y_prev + j;
+			if (is_tap_consistent(p, tap_x, tap_y, normal, depth_prev)) {
+				int tap_index = tap_x + tap_y * p.screen_pitch;
+				prev_direct   += ld4(p.history_direct,   tap_index);
+				prev_indirect += ld4(p.history_indirect, tap_index);
+				prev_moment   += ld4(p.history_moment,   tap_index);
+				consistent_weights_sum += 1.0f;
+			}
+		}
+	}
+
+	if (consistent_weights_sum > 0.0f) {
+		prev_direct   = prev_direct   / consistent_weights_sum;
+		prev_indirect = prev_indirect / consistent_weights_sum;
+		prev_moment   = prev_moment   / consistent_weights_sum;
+
+		int history = ++p.history_length[pixel_index];
+		float inv_history = 1.0f / float(history);
+		float alpha_colour = fmaxf(p.config.alpha_colour, inv_history);
+		float alpha_moment = fmaxf(p.config.alpha_moment, inv_history);
+
+		direct   = lerp_ref(prev_direct,   direct,   alpha_colour);
+		indirect = lerp_ref(prev_indirect, indirect, alpha_colour);
+		moment   = lerp_ref(prev_moment,   moment,   alpha_moment);
+
+		if (history >= 4 || !p.config.enable_spatial_variance) {
+			direct.w   = fmaxf(0.0f, moment.z - moment.x * moment.x);
+			indirect.w = fmaxf(0.0f, moment.w - moment.y * moment.y);
+		}
+	} else {
+		p.history_length[pixel_index] = 0;
+		direct.w = 1.0f;
+		indirect.w = 1.0f;
+	}
+	st4(fb_direct, pixel_index, direct);
+	st4(fb_indirect, pixel_index, indirect);
+	st4(p.frame_buffer_moment, pixel_index, moment);
+}
+
+__global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out) {
+	int x = blockIdx.x * blockDim.x + threadIdx.x;
+	int y = blockIdx.y * blockDim.y + threadIdx.y;
+	if (x >= p.screen_pitch || y >= p.screen_height) return; // pitch, as in the reference (SVGF.h:293)
+	int pixel_index = x + y * p.screen_pitch;
+
+	int history = p.history_length[pixel_index];
+	if (history >= 4) { d_out[pixel_index] = d_in[pixel_index]; i_out[pixel_index] = i_in[pixel_index]; return; }
+
+	float luminance_denom = 1.0f / p.config.sigma_l;
+	f4 cd = ld4(d_in, pixel_index), ci = ld4(i_in, pixel_index);
+	float cl_d = luminance(cd.x, cd.y, cd.z), cl_i = luminance(ci.x, ci.y, ci.z);
+
+	float4 cnd = p.gbuffer_normal_and_depth[pixel_index];
+	f3 center_normal = oct_decode_normal(mk2(cnd.x, cnd.y));
+	float center_depth = cnd.z;
+	int xr = min(x + 1, p.screen_pitch - 1), yd = min(y + 1, p.screen_height - 1);
+	f2 grad = mk2(p.gbuffer_normal_and_depth[xr + y * p.screen_pitch].z - center_depth,
+	              p.gbuffer_normal_and_depth[x + yd * p.screen_pitch].z - center_depth);
+
+	if (center_depth == 0.0f) { st4(d_out, pixel_index, cd); st4(i_out, pixel_index, ci); return; }
+
+	float sw_d = 1.0f, sw_i = 1.0f;
+	f4 sc_d = cd, sc_i = ci;
+	f4 sum_moment = mk4(0.0f);
+	const int radius = 3;
+	for (int j = -radius; j <= radius; j++) {
+		int tap_y = y + j;
+		if (tap_y < 0 || tap_y >= p.screen_height) continue;
+		for (int i = -radius; i <= radius; i++) {
+			int tap_x = x + i;
+			if (tap_x < 0 || tap_x >= p.screen_width) continue;
+			if (i == 0 && j == 0) continue;
+			int tap_index = tap_x + tap_y * p.screen_pitch;
+			f4 td = ld4(d_in, tap_index), ti = ld4(i_in, tap_index), moment = ld4(p.frame_buffer_moment, tap_index);
+			float l_d = luminance(td.x, td.y, td.z), l_i = luminance(ti.x, ti.y, ti.z);
+			float4 nd = p.gbuffer_normal_and_depth[tap_index];
+			f3 normal = oct_decode_normal(mk2(nd.x, nd.y));
+			f2 w = edge_stopping_weights(p, i, j, grad, center_depth, nd.z, center_normal, normal, cl_d, cl_i, l_d, l_i, luminance_denom, luminance_denom);
+			sw_d += w.x; sw_i += w.y;
+			sc_d += w.x * td;
+			sc_i += w.y * ti;
+			sum_moment += moment * mk4(w.x, w.y, w.x, w.y);
+		}
+	}
+	sw_d = fmaxf(sw_d, 1e-6f); sw_i = fmaxf(sw_i, 1e-6f);
+	sc_d = sc_d / sw_d; sc_i = sc_i / sw_i;
+	sum_moment = mk4(sum_moment.x / sw_d, sum_moment.y / sw_i, sum_moment.z / sw_d, sum_moment.w / sw_i);
+	sc_d.w = fmaxf(0.0f, sum_moment.z - sum_moment.x * sum_moment.x);
+	sc_i.w = fmaxf(0.0f, sum_moment.w - sum_moment.y * sum_moment.y);
+	st4(d_out, pixel_index, sc_d);
+	st4(i_out, pixel_index, sc_i);
+}
+
+__global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, int step_size) {
+	int x = blockIdx.x * blockDim.x + threadIdx.x;
+	int y = blockIdx.y * blockDim.y + threadIdx.y;
+	if (x >= p.screen_width || y >= p.screen_height) return;
+	int pixel_index = x + y * p.screen_pitch;
+
+	float vb_d = 0.0f, vb_i = 0.0f;
+	#pragma unroll
+	for (int j = -1; j <= 1; j++) {
+		int tap_y = min(max(y + j, 0), p.screen_height - 1);
+		#pragma unroll
+		for (int i = -1; i <= 1; i++) {
+			int tap_x = min(max(x + i, 0), p.screen_width - 1);
+			float kernel_weight = scalbnf(0.25f, -(abs(i) + abs(j)));
+			vb_d += d_in[tap_x + tap_y * p.screen_pitch].w * kernel_weight;
+			vb_i += i_in[tap_x + tap_y * p.screen_pitch].w * kernel_weight;
+		}
+	}
+	float denom_d = 1.0f / sqrtf(p.config.sigma_l * p.config.sigma_l * fmaxf(0.0f, vb_d) + RT_SVGF_EPSILON);
+	float denom_i = 1.0f / sqrtf(p.config.sigma_l * p.config.sigma_l * fmaxf(0.0f, vb_i) + RT_SVGF_EPSILON);
+
+	f4 cd = ld4(d_in, pixel_index), ci = ld4(i_in, pixel_index);
+	float cl_d = luminance(cd.x, cd.y, cd.z), cl_i = luminance(ci.x, ci.y, ci.z);
+
+	float4 cnd = p.gbuffer_normal_and_depth[pixel_index];
+	f3 center_normal = oct_decode_normal(mk2(cnd.x, cnd.y));
+	float center_depth = cnd.z;
+	if (center_depth == 0.0f) return; // sky: outputs intentionally not written (SVGF.h:462)
+
+	int xr = min(x + 1, p.screen_pitch - 1), yd = min(y + 1, p.screen_height - 1);
+	f2 grad = mk2(p.gbuffer_normal_and_depth[xr + y * p.screen_pitch].z - center_depth,
+	              p.gbuffer_normal_and_depth[x + yd * p.screen_pitch].z - center_depth);
+
+	float sw_d = 1.0f, sw_i = 1.0f;
+	f4 sc_d = cd, sc_i = ci;
+	for (int j = -1; j <= 1; j++) {
+		int tap_y = y + j * step_size;
+		if (tap_y < 0 || tap_y >= p.screen_height) continue;
+		for (int i = -1; i <= 1; i++) {
+			int tap_x = x + i * step_size;
+			if (tap_x < 0 || tap_x >= p.screen_width) continue;
+			if (i == 0 && j == 0) continue;
+			int tap_index = tap_x + tap_y * p.screen_pitch;
+			f4 td = ld4(d_in, tap_index), ti = ld4(i_in, tap_index);
+			float l_d = luminance(td.x, td.y, td.z), l_i = luminance(ti.x, ti.y, ti.z);
+			float4 nd = p.gbuffer_normal_and_depth[tap_index];
+			f3 normal = oct_decode_normal(mk2(nd.x, nd.y));
+			f2 w = edge_stopping_weights(p, i * step_size, j * step_size, grad, center_depth, nd.z, center_normal, normal, cl_d, cl_i, l_d, l_i, denom_d, denom_i);
+			sw_d += w.x; sw_i += w.y;
+			sc_d += mk4(w.x, w.x, w.x, w.x * w.x) * td;
+			sc_i += mk4(w.y, w.y, w.y, w.y * w.y) * ti;
+		}
+	}
+	float inv_d = 1.0f / sw_d, inv_i = 1.0f / sw_i;
+	sc_d *= inv_d; sc_i *= inv_i;
+	sc_d.w *= inv_d; sc_i.w *= inv_i;
+	st4(d_out, pixel_index, sc_d);
+	st4(i_out, pixel_index, sc_i);
+	if (step_size == (1 << RT_FEEDBACK_ITERATION)) { st4(p.history_direct, pixel_index, sc_d); st4(p.history_indirect, pixel_index, sc_i); }
+}
+
+__global__ void __launch_bounds__(256) kernel_svgf_finalize(RtParams p, const float4 * colour_direct, const float4 * colour_indirect) {
+	int x = blockIdx.x * blockDim.x + threadIdx.x;
+	int y = blockIdx.y * blockDim.y + threadIdx.y;
+	if (x >= p.screen_width || y >= p.screen_height) return;
+	int pixel_index = x + y * p.screen_pitch;
+
+	f4 direct = ld4(colour_direct, pixel_index), indirect = ld4(colour_indirect, pixel_index);
+	f4 colour = (direct + indirect) * aov_get(p, RT_AOV_ALBEDO, pixel_index);
+	st4(p.final_image, pixel_index, colour);
+
+	if (p.config.enable_taa) {
+		colour = colour / (1.0f + luminance(colour.x, colour.y, colour.z));
+		colour.x = safe_sqrt(colour.x); colour.y = safe_sqrt(colour.y); colour.z = safe_sqrt(colour.z);
+		st4(p.taa_frame_curr, pixel_index, colour);
+	}
+	float4 moment = p.frame_buffer_moment[pixel_index];
+	float4 normal_and_depth = p.gbuffer_normal_and_depth[pixel_index];
+	if (p.config.num_atrous_iterations <= RT_FEEDBACK_ITERATION) { st4(p.history_direct, pixel_index, direct); st4(p.history_indirect, pixel_index, indirect); }
+	p.history_moment[pixel_index] = moment;
+	p.history_normal_and_depth[pixel_index] = normal_and_depth;
+
+	p.gbuffer_normal_and_depth[pixel_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	p.gbuffer_mesh_id_and_triangle_id[pixel_index] = make_int2(0, 0);
+	if (!p.config.enable_taa) p.gbuffer_screen_position_prev[pixel_index] = make_float2(0.0f, 0.0f);
+}
+
+RT_DEV f3 clamp3(f3 v, f3 lo, f3 hi) { return mk3(clampf(v.x, lo.x, hi.x), clampf(v.y, lo.y, hi.y), clampf(v.z, lo.z, hi.z)); }
+
+// Reads final_image-independent inputs (taa_frame_curr / taa_frame_prev), writes taa_scratch;
+// kernel_taa_finalize then moves it into final_image. (The reference writes the `accumulator`
+// surface in place, which is safe there for the same reason: kernel_taa never reads it.)
+__global__ void __launch_bounds__(256) kernel_taa(RtParams p, int sample_index) {
+	int x = blockIdx.x * blockDim.x + threadIdx.x;
+	int y = blockIdx.y * blockDim.y + threadIdx.y;
+	if (x >= p.screen_width || y >= p.screen_height) return;
+	int pixel_index = x + y * p.screen_pitch;
+
+	f4 colour = ld4(p.taa_frame_curr, pixel_index);
+	if (sample_index == 0) { st4(p.final_image, pixel_index, colour); return; }
+
+	float2 sp = p.gbuffer_screen_position_prev[pixel_index];
+	float s_prev = (0.5f + 0.5f * sp.x) * float(p.screen_width);
+	float t_prev = (0.5f + 0.5f * sp.y) * float(p.screen_height);
+	int x_prev = int(s_prev + 0.5f), y_prev = int(t_prev + 0.5f);
+
+	float sum_weight = 0.0f;
+	f4 sum = mk4(0.0f);
+	for (int j = y_prev - 2; j < y_prev + 2; j++) {
+		if (j < 0 || j >= p.screen_height) continue;
+		for (int i = x_prev - 2; i < x_prev + 2; i++) {
+			if (i < 0 || i >= p.screen_width) continue;
+			float weight = mitchell_netravali(float(i) + 0.5f - s_prev) * mitchell_netravali(float(j) + 0.5f - t_prev);
+			sum_weight += weight;
+			sum += weight * ld4(p.taa_frame_prev, i + j * p.screen_pitch);
+		}
+	}
+	if (sum_weight > 0.0f) {
+		f3 colour_curr = rgb_to_ycocg(mk3(colour));
+		f3 colour_prev = rgb_to_ycocg(mk3(sum / sum_weight));
+		f3 avg = colour_curr, var = colour_curr * colour_curr;
+		int pitch = p.screen_pitch;
+		#define RT_TAA_TAP(offset) { f3 c = rgb_to_ycocg(mk3(ld4(p.taa_frame_curr, pixel_index + (offset)))); avg += c; var += c * c; }
+		if (x >= 1) {
+			if (y >= 1) RT_TAA_TAP(-pitch - 1)
+			RT_TAA_TAP(-1)
+			if (y < p.screen_height - 1) RT_TAA_TAP(pitch - 1)
+		}
+		if (y >= 1) RT_TAA_TAP(-pitch)
+		if (y < p.screen_height - 1) RT_TAA_TAP(pitch)
+		if (x < p.screen_width - 1) {
+			if (y >= 1) RT_TAA_TAP(1 - pitch)
+			RT_TAA_TAP(1)
+			if (y < p.screen_height - 1) RT_TAA_TAP(1 + pitch)
+		}
+		#undef RT_TAA_TAP
+		avg *= 1.0f / 9.0f; var *= 1.0f / 9.0f;
+		f3 sigma2 = var - avg * avg;
+		f3 sigma = mk3(safe_sqrt(sigma2.x), safe_sqrt(sigma2.y), safe_sqrt(sigma2.z));
+		colour_prev = clamp3(colour_prev, avg - 1.25f * sigma, avg + 1.25f * sigma);
+		f3 integrated = ycocg_to_rgb(lerp_ref(colour_prev, colour_curr, 0.1f));
+		colour.x = integrated.x; colour.y = integrated.y; colour.z = integrated.z;
+	}
+	st4(p.final_image, pixel_index, colour);
+}
+
+__global__ void __launch_bounds__(256) kernel_taa_finalize(RtParams p) {
+	int x = blockIdx.x * blockDim.x + threadIdx.x;
+	int y = blockIdx.y * blockDim.y + threadIdx.y;
+	if (x >= p.screen_width || y >= p.screen_height) return;
+	int pixel_index = x + y * p.screen_pitch;
+
+	f4 colour = ld4(p.final_image, pixel_index);
+	st4(p.taa_frame_prev, pixel_index, colour);
+	colour = colour * colour;
+	colour = colour / (1.0f - luminance(colour.x, colour.y, colour.z));
+	st4(p.final_image, pixel_index, colour);
+	p.gbuffer_screen_position_prev[pixel_index] = make_float2(0.0f, 0.0f);
+}
+
+// Launch order of Pathtracer::render (Pathtracer.cpp:798-838)
+void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream) {
+	dim3 block(RT_POST_BLOCK_X, RT_POST_BLOCK_Y);
+	dim3 grid((p.screen_pitch + block.x - 1) / block.x, (p.screen_height + block.y - 1) / block.y);
+
+	hipLaunchKernelGGL(kernel_svgf_reproject, grid, block, 0, stream, p);
+
+	float4 * direct_in    = p.aovs[RT_AOV_RADIANCE_DIRECT].framebuffer;
+	float4 * indirect_in  = p.aovs[RT_AOV_RADIANCE_INDIRECT].framebuffer;
+	float4 * direct_out   = p.aovs[RT_AOV_RADIANCE_DIRECT].accumulator;
+	float4 * indirect_out = p.aovs[RT_AOV_RADIANCE_INDIRECT].accumulator;
+
+	if (p.config.enable_spatial_variance) {
+		hipLaunchKernelGGL(kernel_svgf_variance, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out);
+		float4 * t = direct_in; direct_in = direct_out; direct_out = t;
+		t = indirect_in; indirect_in = indirect_out; indirect_out = t;
+	}
+	for (int i = 0; i < p.config.num_atrous_iterations; i++) {
+		hipLaunchKernelGGL(kernel_svgf_atrous, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out, 1 << i);
+		float4 * t = direct_in; direct_in = direct_out; direct_out = t;
+		t = indirect_in; indirect_in = indirect_out; indirect_out = t;
+	}
+	hipLaunchKernelGGL(kernel_svgf_finalize, grid, block, 0, stream, p, direct_in, indirect_in);
+
+	if (p.config.enable_taa) {
+		hipLaunchKernelGGL(kernel_taa, grid, block, 0, stream, p, sample_index);
+		hipLaunchKernelGGL(kernel_taa_finalize, grid, block, 0, stream, p);
+	}
+}
+
+void rt_launch_accumulate(const RtParams & p, float frames_accumulated, int pixel_offset, int pixel_count, hipStream_t stream) {
+	int blocks = (pixel_count + 255) / 256;
+	if (blocks > 4096) blocks = 4096;
+	if (blocks < 1) blocks = 1;
+	hipLaunchKernelGGL(kernel_accumulate, dim3(blocks), dim3(256), 0, stream, p, frames_accumulated, pixel_offset, pixel_count);
+}
+
+// ---- Kulla-Conty LUT integration (KullaConty.h:83-240) -------------------------------------------------------
+// One thread per LUT cell, NUM_SAMPLES Monte-Carlo samples each, online average.
+
+#define RT_LUT_NUM_SAMPLES 100000
+
+__global__ void kernel_integrate_dielectric(RtParams p, int entering_material, float * lut_directional_albedo) {
+	int thread_index = blockIdx.x * blockDim.x + threadIdx.x;
+	if (thread_index >= 16 * 16 * 16) return;
+	int i = thread_index % 16, r = (thread_index / 16) % 16, c = (thread_index / 256) % 16;
+
+	float ior = remap((float(i) + 0.5f) / 16.0f, 0.0f, 1.0f, RT_LUT_DIELECTRIC_MIN_IOR, RT_LUT_DIELECTRIC_MAX_IOR);
+	float eta = entering_material ? 1.0f / ior : ior;
+	float linear_roughness = (float(r) + 0.5f) / 16.0f;
+	float cos_theta = (float(c) + 0.5f) / 16.0f;
+	float sin_theta = safe_sqrt(1.0f - square(cos_theta));
+	f3 omega_i = mk3(sin_theta, 0.0f, cos_theta);
+
+	float ax = roughness_to_alpha(linear_roughness), ay = ax;
+	float avg = 0.0f;
+	for (int s = 0; s < RT_LUT_NUM_SAMPLES; s++) {
+		float rand_fresnel = random_sample(p, DIM_BSDF_0, unsigned(thread_index), 0, unsigned(s)).y;
+		f2    rand_brdf    = random_sample(p, DIM_BSDF_1, unsigned(thread_index), 0, unsigned(s));
+
+		f3 omega_m = sample_visible_normals_ggx(omega_i, ax, ay, rand_brdf.x, rand_brdf.y);
+		float F = fresnel_dielectric(abs_dot(omega_i, omega_m), eta);
+		bool reflected = rand_fresnel < F;
+		f3 omega_o = reflected ? reflect_direction(omega_i, omega_m) : refract_direction(omega_i, omega_m, eta);
+
+		float weight = 0.0f;
+		if (!(reflected ^ (omega_o.z >= 0.0f))) {
+			float D  = ggx_D(omega_m, ax, ay);
+			float G1 = ggx_G1(omega_i, ax, ay);
+			float G2 = ggx_G2(omega_o, omega_i, omega_m, ax, ay);
+			float i_dot_m = abs_dot(omega_i, omega_m);
+			float o_dot_m = abs_dot(omega_o, omega_m);
+			float pdf = reflected ? F * G1 * D / (4.0f * omega_i.z)
+			                      : (1.0f - F) * G1 * D * i_dot_m * o_dot_m / (omega_i.z * square(eta * i_dot_m + o_dot_m));
+			weight = pdf_is_valid(pdf) ? G2 / G1 : 0.0f;
+		}
+		avg = avg + (weight - avg) / float(s + 1);
+	}
+	lut_directional_albedo[thread_index] = avg;
+}
+
+__global__ void kernel_average_dielectric(const float * lut_directional_albedo, float * lut_albedo) {
+	int thread_index = blockIdx.x * blockDim.x + threadIdx.x;
+	if (thread_index >= 16 * 16) return;
+	int i = thread_index % 16, r = (thread_index / 16) % 16;
+	float avg = 0.0f;
+	for (int c = 0; c < 16; c++) {
+		float cos_theta = (float(c) + 0.5f) / 16.0f;
+		float sample = lut_directional_albedo[i + r * 16 + c * 256] * cos_theta;
+		avg = avg + (sample - avg) / float(c + 1);
+	}
+	lut_albedo[thread_index] = 2.0f * avg;
+}
+
+__global__ void kernel_integrate_conductor(RtParams p, float * lut_directional_albedo) {
+	int thread_index = blockIdx.x * blockDim.x + threadIdx.x;
+	if (thread_index >= 32 * 32) return;
+	int r = thread_index % 32, c = (thread_index / 32) % 32;
+	float linear_roughness = (float(r) + 0.5f) / 32.0f;
+	float cos_theta = (float(c) + 0.5f) / 32.0f;
+	float sin_theta = safe_sqrt(1.0f - square(cos_theta));
+	f3 omega_i = mk3(sin_theta, 0.0f, cos_theta);
+	float ax = roughness_to_alpha(linear_roughness), ay = ax;
+
+	float avg = 0.0f;
+	for (int s = 0; s < RT_LUT_NUM_SAMPLES; s++) {
+		f2 rand_brdf = random_sample(p, DIM_BSDF_0, unsigned(thread_index), 0, unsigned(s));
+		f3 omega_m = sample_visible_normals_ggx(omega_i, ax, ay, rand_brdf.x, rand_brdf.y);
+		f3 omega_o = reflect_direction(omega_i, omega_m);
+		float weight = 0.0f;
+		if (!(dot(omega_o, omega_m) <= 0.0f || omega_o.z <= 0.0f)) {
+			float D  = ggx_D(omega_m, ax, ay);
+			float G1 = ggx_G1(omega_i, ax, ay);
+			float G2 = ggx_G2(omega_o, omega_i, omega_m, ax, ay);
+			float pdf = G1 * D / (4.0f * omega_i.z);
+			weight = pdf_is_valid(pdf) ? G2 / G1 : 0.0f;
+		}
+		avg = avg + (weight - avg) / float(s + 1);
+	}
+	lut_directional_albedo[thread_index] = avg;
+}
+
+__global__ void kernel_average_conductor(const float * lut_directional_albedo, float * lut_albedo) {
+	int thread_index = blockIdx.x * blockDim.x + threadIdx.x;
+	if (thread_index >= 32) return;
+	int r = thread_index;
+	float avg = 0.0f;
+	for (int c = 0; c < 32; c++) {
+		float cos_theta = (float(c) + 0.5f) / 32.0f;
+		float sample = lut_directional_albedo[r + c * 32] * cos_theta;
+		avg = avg + (sample - avg) / float(c + 1);
+	}
+	lut_albedo[thread_index] = 2.0f * avg;
+}
+
+void rt_launch_integrate_luts(const RtParams & p, float * dielectric_dir_enter, float * dielectric_dir_leave, float * dielectric_enter, float * dielectric_leave,
+                              float * conductor_dir, float * conductor, hipStream_t stream) {
+	// 64-thread blocks: 4096 cells -> 64 workgroups, so the long sample loops spread over many CUs
+	hipLaunchKernelGGL(kernel_integrate_dielectric, dim3(4096 / 64), dim3(64), 0, stream, p, 1, dielectric_dir_enter);
+	hipLaunchKernelGGL(kernel_integrate_dielectric, dim3(4096 / 64), dim3(64), 0, stream, p, 0, dielectric_dir_leave);
+	hipLaunchKernelGGL(kernel_average_dielectric, dim3(1), dim3(256), 0, stream, dielectric_dir_enter, dielectric_enter);
+	hipLaunchKernelGGL(kernel_average_dielectric, dim3(1), dim3(256), 0, stream, dielectric_dir_leave, dielectric_leave);
+	hipLaunchKernelGGL(kernel_integrate_conductor, dim3(1024 / 64), dim3(64), 0, stream, p, conductor_dir);
+	hipLaunchKernelGGL(kernel_average_conductor, dim3(1), dim3(64), 0, stream, conductor_dir, conductor);
+}
+
+// ---- streaming-read probe: the measured HBM roofline the trace kernel is priced against --------------------
+
+__global__ void __launch_bounds__(256) kernel_stream_read(const float4 * __restrict__ src, size_t count, float * sink) {
+	float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	size_t stride = size_t(gridDim.x) * blockDim.x;
+	for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride) {
+		float4 v = src[i];
+		acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+	}
+	if (acc.x + acc.y + acc.z + acc.w == 123456.789f) *sink = acc.x; // never true: keeps the loads alive
+}
+
+void rt_launch_stream_read(const float4 * src, size_t count, float * sink, hipStream_t stream) {
+	hipLaunchKernelGGL(kernel_stream_read, dim3(256 * 8), dim3(256), 0, stream, src, count, sink);
+}

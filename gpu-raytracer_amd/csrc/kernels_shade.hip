@@ -1,0 +1,823 @@
+// kernels_shade.hip -- ray generation, the per-bounce "sort" dispatch kernel and the four
+// material kernels with next-event estimation.
+//
+// Replaces kernel_generate, kernel_sort and kernel_material_{diffuse,plastic,dielectric,
+// conductor} of the reference (CUDA/Pathtracer.cu:122-139,199-463,465-773, CUDA/Camera.h:20-62,
+// CUDA/BSDF.h).  Differences that are design, not behaviour:
+//   * every queue append (next ray, shadow ray, material queue) is ONE returning atomic per
+//     64-lane wave (wave_aggregated_append) instead of one per thread;
+//   * kernels are grid-stride loops over a fixed grid sized to the machine, so that the deep,
+//     nearly empty bounces do not launch ~3000 idle workgroups;
+//   * albedo / sky / LUT fetches go through the software texture unit in rt_shading.h.
+#include "rt_shading.h"
+
+#define RT_SHADE_BLOCK 256
+
+struct HitInfo { float t, u, v; int mesh_id, triangle_id; };
+
+RT_DEV HitInfo unpack_hit(uint4 h) { // Buffers.h:34-48
+	HitInfo r;
+	r.mesh_id = int(h.x); r.triangle_id = int(h.y);
+	r.t = __uint_as_float(h.z);
+	r.u = float(h.w & 0xffffu) / 65535.0f;
+	r.v = float(h.w >> 16)     / 65535.0f;
+	return r;
+}
+
+// ---- kernel_generate ----------------------------------------------------------------------------
+
+RT_DEV void camera_generate_ray(const RtParams & p, int pixel_index, int sample_index, int x, int y, f3 & origin, f3 & direction) {
+	f2 rand_filter   = random_sample(p, DIM_FILTER,   unsigned(pixel_index), 0, unsigned(sample_index));
+	f2 rand_aperture = random_sample(p, DIM_APERTURE, unsigned(pixel_index), 0, unsigned(sample_index));
+
+	f2 jitter;
+	if (p.config.enable_svgf) {
+		const float taa_halton_x[4] = { 0.3f, 0.7f, 0.2f, 0.8f };
+		const float taa_halton_y[4] = { 0.2f, 0.8f, 0.7f, 0.3f };
+		jitter.x = taa_halton_x[sample_index & 3];
+		jitter.y = taa_halton_y[sample_index & 3];
+	} else if (p.config.reconstruction_filter == RT_FILTER_BOX) {
+		jitter = rand_filter;
+	} else if (p.config.reconstruction_filter == RT_FILTER_TENT) {
+		jitter.x = sample_tent(rand_filter.x);
+		jitter.y = sample_tent(rand_filter.y);
+	} else {
+		f2 g = sample_gaussian(rand_filter.x, rand_filter.y);
+		jitter.x = 0.5f + 0.5f * g.x;
+		jitter.y = 0.5f + 0.5f * g.y;
+	}
+	float x_jittered = float(x) + jitter.x;
+	float y_jittered = float(y) + jitter.y;
+
+	f3 blc = mk3(p.camera.bottom_left_corner[0], p.camera.bottom_left_corner[1], p.camera.bottom_left_corner[2]);
+	f3 xa  = mk3(p.camera.x_axis[0], p.camera.x_axis[1], p.camera.x_axis[2]);
+	f3 ya  = mk3(p.camera.y_axis[0], p.camera.y_axis[1], p.camera.y_axis[2]);
+
+	f3 focal_point = p.camera.focal_distance * normalize(blc + x_jittered * xa + y_jittered * ya);
+	f2 lens_point  = p.camera.aperture_radius * sample_disk(rand_aperture.x, rand_aperture.y);
+
+	f3 offset = xa * lens_point.x + ya * lens_point.y;
+	direction = normalize(focal_point - offset);
+	origin = mk3(p.camera.position[0], p.camera.position[1], p.camera.position[2]) + offset;
+}
+
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate(RtParams p, int sample_index, int pixel_offset, int pixel_count) {
+	if (blockIdx.x == 0 && threadIdx.x == 0) p.sizes->trace[0] = pixel_count; // BufferSizes::reset (Pathtracer.h:143)
+	for (int index = blockIdx.x * blockDim.x + threadIdx.x; index < pixel_count; index += gridDim.x * blockDim.x) {
+		int index_offset = index + pixel_offset;
+		int x = index_offset % p.screen_width;
+		int y = index_offset / p.screen_width;
+		int pixel_index = x + y * p.screen_pitch;
+
+		f3 origin, direction;
+		camera_generate_ray(p, pixel_index, sample_index, x, y, origin, direction);
+
+		store3(p.trace[0].origin,    index, origin);
+		store3(p.trace[0].direction, index, direction);
+		p.trace[0].pixel_index_and_flags[index] = unsigned(pixel_index);
+	}
+}
+
+__global__ void kernel_random(RtParams p, int dimension, const unsigned * pixel_indices, int count, unsigned bounce, unsigned sample_index, float2 * out) {
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= count) return;
+	f2 r = random_sample(p, dimension, pixel_indices[i], bounce, sample_index);
+	out[i] = make_float2(r.x, r.y);
+}
+
+// ---- kernel_sort -----------------------------------------------------------------------------------
+
+// Returns true if the path terminates (Pathtracer.cu:199-218)
+RT_DEV bool russian_roulette(const RtParams & p, int pixel_index, int bounce, int sample_index, f3 & throughput) {
+	if (bounce == p.config.num_bounces - 1) return true;
+	if (p.config.enable_russian_roulette && bounce > 0) {
+		f3 t = throughput;
+		if (p.config.enable_svgf) t *= mk3(aov_get(p, RT_AOV_ALBEDO, pixel_index));
+		float survival_probability = saturate(fmaxf(fmaxf(t.x, t.y), t.z));
+		float r = random_sample(p, DIM_RUSSIAN_ROULETTE, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index)).x;
+		if (r > survival_probability) return true;
+		throughput /= survival_probability;
+	}
+	return false;
+}
+
+RT_DEV void add_radiance(const RtParams & p, int bounce, int pixel_index, f3 illumination, f3 bounce0_value) {
+	if (bounce == 0) {
+		aov_set(p, RT_AOV_ALBEDO,          pixel_index, mk4(1.0f));
+		aov_set(p, RT_AOV_RADIANCE,        pixel_index, mk4(bounce0_value));
+		aov_set(p, RT_AOV_RADIANCE_DIRECT, pixel_index, mk4(bounce0_value));
+	} else if (bounce == 1) {
+		aov_add(p, RT_AOV_RADIANCE,        pixel_index, mk4(illumination));
+		aov_add(p, RT_AOV_RADIANCE_DIRECT, pixel_index, mk4(illumination));
+	} else {
+		aov_add(p, RT_AOV_RADIANCE,          pixel_index, mk4(illumination));
+		aov_add(p, RT_AOV_RADIANCE_INDIRECT, pixel_index, mk4(illumination));
+	}
+}
+
+struct TriangleFull {
+	f3 position_0, position_edge_1, position_edge_2;
+	f3 normal_0, normal_edge_1, normal_edge_2;
+	f2 tex_coord_0, tex_coord_edge_1, tex_coord_edge_2;
+};
+RT_DEV void triangle_get_positions(const RtParams & p, int index, f3 & p0, f3 & e1, f3 & e2) {
+	const float4 * t = p.triangles + size_t(index) * 6;
+	float4 a = t[0], b = t[1], c = t[2];
+	p0 = mk3(a.x, a.y, a.z); e1 = mk3(a.w, b.x, b.y); e2 = mk3(b.z, b.w, c.x);
+}
+RT_DEV TriangleFull triangle_get_full(const RtParams & p, int index) {
+	const float4 * t = p.triangles + size_t(index) * 6;
+	float4 a = t[0], b = t[1], c = t[2], d = t[3], e = t[4], f = t[5];
+	TriangleFull r;
+	r.position_0 = mk3(a.x, a.y, a.z); r.position_edge_1 = mk3(a.w, b.x, b.y); r.position_edge_2 = mk3(b.z, b.w, c.x);
+	r.normal_0 = mk3(c.y, c.z, c.w); r.normal_edge_1 = mk3(d.x, d.y, d.z); r.normal_edge_2 = mk3(d.w, e.x, e.y);
+	r.tex_coord_0 = mk2(e.z, e.w); r.tex_coord_edge_1 = mk2(f.x, f.y); r.tex_coord_edge_2 = mk2(f.z, f.w);
+	return r;
+}
+RT_DEV f3 barycentric(float u, float v, f3 base, f3 e1, f3 e2) { return base + u * e1 + v * e2; }
+RT_DEV f2 barycentric(float u, float v, f2 base, f2 e1, f2 e2) { return base + u * e1 + v * e2; }
+
+RT_DEV f3 m_position(const float4 * m, f3 v) {
+	float4 r0 = m[0], r1 = m[1], r2 = m[2];
+	return mk3(r0.x * v.x + r0.y * v.y + r0.z * v.z + r0.w, r1.x * v.x + r1.y * v.y + r1.z * v.z + r1.w, r2.x * v.x + r2.y * v.y + r2.z * v.z + r2.w);
+}
+RT_DEV f3 m_direction(const float4 * m, f3 v) {
+	float4 r0 = m[0], r1 = m[1], r2 = m[2];
+	return mk3(r0.x * v.x + r0.y * v.y + r0.z * v.z, r1.x * v.x + r1.y * v.y + r1.z * v.z, r2.x * v.x + r2.y * v.y + r2.z * v.z);
+}
+
+// SVGF g-buffers (CUDA/SVGF/SVGF.h:61-84)
+RT_DEV f2 oct_encode_normal(f3 n) {
+	n /= (fabsf(n.x) + fabsf(n.y) + fabsf(n.z));
+	if (n.z < 0.0f) {
+		n.x = (1.0f - fabsf(n.y)) * (n.x >= 0.0f ? +1.0f : -1.0f);
+		n.y = (1.0f - fabsf(n.x)) * (n.y >= 0.0f ? +1.0f : -1.0f);
+	}
+	return mk2(0.5f + 0.5f * n.x, 0.5f + 0.5f * n.y);
+}
+RT_DEV f4 mat4_mul(const float * m, f4 v) {
+	return mk4(
+		m[ 0] * v.x + m[ 1] * v.y + m[ 2] * v.z + m[ 3] * v.w,
+		m[ 4] * v.x + m[ 5] * v.y + m[ 6] * v.z + m[ 7] * v.w,
+		m[ 8] * v.x + m[ 9] * v.y + m[10] * v.z + m[11] * v.w,
+		m[12] * v.x + m[13] * v.y + m[14] * v.z + m[15] * v.w);
+}
+RT_DEV void svgf_set_gbuffers(const RtParams & p, int x, int y, const HitInfo & hit, f3 hit_point, f3 normal, f3 hit_point_prev) {
+	f4 u_curr = mat4_mul(p.view_projection,      mk4(hit_point.x, hit_point.y, hit_point.z, 1.0f));
+	f4 u_prev = mat4_mul(p.view_projection_prev, mk4(hit_point_prev.x, hit_point_prev.y, hit_point_prev.z, 1.0f));
+	f2 oct = oct_encode_normal(normal);
+	int idx = x + y * p.screen_pitch;
+	p.gbuffer_normal_and_depth[idx] = make_float4(oct.x, oct.y, u_curr.z, u_prev.z);
+	p.gbuffer_mesh_id_and_triangle_id[idx] = make_int2(hit.mesh_id, hit.triangle_id);
+	p.gbuffer_screen_position_prev[idx] = make_float2(u_prev.x / u_prev.w, u_prev.y / u_prev.w);
+}
+
+RT_DEV void material_queue_append(const RtParams & p, int slot, int * counter, int bounce, f3 ray_direction, int medium_id, float cone_angle, float cone_width, uint4 hit, int pixel_index, f3 throughput) {
+	int index_out = wave_aggregated_append(counter);
+	const RtMaterialBuffer & q = p.material[slot];
+	store3(q.direction, index_out, ray_direction);
+	if (medium_id != RT_INVALID) q.medium[index_out] = medium_id;
+	if (bounce > 0 && p.config.enable_mipmapping) { q.cone_angle[index_out] = cone_angle; q.cone_width[index_out] = cone_width; }
+	q.hits[index_out] = hit;
+	unsigned flags = unsigned(medium_id != RT_INVALID) << 30;
+	q.pixel_index_and_flags[index_out] = unsigned(pixel_index) | flags;
+	if (bounce > 0) store3(q.throughput, index_out, throughput);
+}
+
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_sort(RtParams p, int bounce, int sample_index) {
+	const int ray_count = p.sizes->trace[bounce];
+	const RtTraceBuffer & in  = p.trace[bounce & 1];
+	const RtTraceBuffer & out = p.trace[(bounce + 1) & 1];
+
+	for (int index = blockIdx.x * blockDim.x + threadIdx.x; index < ray_count; index += gridDim.x * blockDim.x) {
+		f3 ray_direction = load3(in.direction, index);
+		uint4 packed_hit = in.hits[index];
+		HitInfo hit = unpack_hit(packed_hit);
+
+		float ray_cone_angle = 0.0f, ray_cone_width = 0.0f;
+		if (bounce > 0 && p.config.enable_mipmapping) { ray_cone_angle = in.cone_angle[index]; ray_cone_width = in.cone_width[index]; }
+
+		unsigned pixel_index_and_flags = in.pixel_index_and_flags[index];
+		int pixel_index = int(pixel_index_and_flags & ~RT_FLAGS_ALL);
+		int x = pixel_index % p.screen_pitch;
+		int y = pixel_index / p.screen_pitch;
+
+		bool allow_nee     = pixel_index_and_flags & RT_FLAG_ALLOW_NEE;
+		bool inside_medium = pixel_index_and_flags & RT_FLAG_INSIDE_MEDIUM;
+
+		f3 throughput = bounce == 0 ? mk3(1.0f) : load3(in.throughput, index);
+
+		int medium_id = RT_INVALID;
+		if (inside_medium) {
+			medium_id = in.medium[index];
+			HomogeneousMedium medium = medium_as_homogeneous(p, medium_id);
+			bool medium_can_scatter = (medium.sigma_s.x + medium.sigma_s.y + medium.sigma_s.z) > 0.0f;
+			if (medium_can_scatter) {
+				f2 rand_scatter = random_sample(p, DIM_BSDF_0, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+				f2 rand_phase   = random_sample(p, DIM_BSDF_1, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+				f3 sigma_t = medium.sigma_a + medium.sigma_s;
+
+				float throughput_sum = throughput.x + throughput.y + throughput.z;
+				f3 wavelength_pdf = throughput / throughput_sum;
+
+				float sigma_t_used;
+				if      (rand_scatter.x * throughput_sum < throughput.x)                sigma_t_used = sigma_t.x;
+				else if (rand_scatter.x * throughput_sum < throughput.x + throughput.y) sigma_t_used = sigma_t.y;
+				else                                                                   sigma_t_used = sigma_t.z;
+
+				float scatter_distance = sample_exp(sigma_t_used, rand_scatter.y);
+				f3 transmittance = beer_lambert(sigma_t, fminf(scatter_distance, hit.t));
+
+				if (scatter_distance < hit.t) {
+					f3 pdf = wavelength_pdf * sigma_t * transmittance;
+					throughput *= medium.sigma_s * transmittance / (pdf.x + pdf.y + pdf.z);
+					if (russian_roulette(p, pixel_index, bounce, sample_index, throughput)) continue;
+
+					f3 direction_out = sample_henyey_greenstein(-ray_direction, medium.g, rand_phase.x, rand_phase.y);
+					f3 origin_out = load3(in.origin, index) + scatter_distance * ray_direction;
+
+					int index_out = wave_aggregated_append(&p.sizes->trace[bounce + 1]);
+					store3(out.origin,    index_out, origin_out);
+					store3(out.direction, index_out, direction_out);
+					out.medium[index_out] = medium_id;
+					if (p.config.enable_mipmapping) {
+						if (bounce == 0) { ray_cone_angle = p.camera.pixel_spread_angle; ray_cone_width = p.camera.pixel_spread_angle * scatter_distance; }
+						out.cone_angle[index_out] = ray_cone_angle;
+						out.cone_width[index_out] = ray_cone_width;
+					}
+					out.pixel_index_and_flags[index_out] = unsigned(pixel_index) | RT_FLAG_INSIDE_MEDIUM;
+					store3(out.throughput, index_out, throughput);
+					continue;
+				} else {
+					f3 pdf = wavelength_pdf * transmittance;
+					throughput *= transmittance / (pdf.x + pdf.y + pdf.z);
+				}
+			} else {
+				throughput *= beer_lambert(medium.sigma_a, hit.t);
+			}
+		}
+
+		if (hit.triangle_id == RT_INVALID) { // miss: sky
+			f3 illumination = throughput * sample_sky(p, ray_direction);
+			add_radiance(p, bounce, pixel_index, illumination, illumination);
+			continue;
+		}
+
+		int material_id = p.mesh_material_ids[hit.mesh_id];
+		int material_type = p.material_types[material_id];
+
+		if (material_type == RT_MATERIAL_LIGHT) {
+			f3 p0, e1, e2;
+			triangle_get_positions(p, hit.triangle_id, p0, e1, e2);
+			f3 light_point = barycentric(hit.u, hit.v, p0, e1, e2);
+			f3 light_point_prev = light_point;
+			f3 light_geometric_normal = cross(e1, e2);
+
+			const float4 * world = p.mesh_transforms + size_t(hit.mesh_id) * 3;
+			light_point = m_position(world, light_point);
+			light_geometric_normal = normalize(m_direction(world, light_geometric_normal));
+
+			if (bounce == 0 && p.config.enable_svgf) {
+				light_point_prev = m_position(p.mesh_transforms_prev + size_t(hit.mesh_id) * 3, light_point_prev);
+				svgf_set_gbuffers(p, x, y, hit, light_point, light_geometric_normal, light_point_prev);
+			}
+
+			f3 emission = mk3(p.materials[2 * material_id]);
+
+			bool count_light = p.config.enable_next_event_estimation ? !allow_nee : true;
+			if (count_light) {
+				add_radiance(p, bounce, pixel_index, throughput * emission, emission);
+				continue;
+			}
+			if (p.config.enable_multiple_importance_sampling) {
+				float cos_theta_light = abs_dot(ray_direction, light_geometric_normal);
+				float distance_to_light_squared = hit.t * hit.t;
+				float brdf_pdf = in.last_pdf[index];
+				float light_power = luminance(emission.x, emission.y, emission.z);
+				float light_pdf = light_power * distance_to_light_squared / (cos_theta_light * p.lights_total_weight);
+				if (!pdf_is_valid(light_pdf)) continue;
+				float mis_weight = power_heuristic(brdf_pdf, light_pdf);
+				f3 illumination = throughput * emission * mis_weight;
+				aov_add(p, RT_AOV_RADIANCE, pixel_index, mk4(illumination));
+				if (bounce == 1) aov_add(p, RT_AOV_RADIANCE_DIRECT,   pixel_index, mk4(illumination));
+				else             aov_add(p, RT_AOV_RADIANCE_INDIRECT, pixel_index, mk4(illumination));
+			}
+			continue;
+		}
+
+		if (russian_roulette(p, pixel_index, bounce, sample_index, throughput)) continue;
+
+		switch (material_type) {
+			case RT_MATERIAL_DIFFUSE:    material_queue_append(p, 0, &p.sizes->diffuse   [bounce], bounce, ray_direction, medium_id, ray_cone_angle, ray_cone_width, packed_hit, pixel_index, throughput); break;
+			case RT_MATERIAL_PLASTIC:    material_queue_append(p, 1, &p.sizes->plastic   [bounce], bounce, ray_direction, medium_id, ray_cone_angle, ray_cone_width, packed_hit, pixel_index, throughput); break;
+			case RT_MATERIAL_DIELECTRIC: material_queue_append(p, 2, &p.sizes->dielectric[bounce], bounce, ray_direction, medium_id, ray_cone_angle, ray_cone_width, packed_hit, pixel_index, throughput); break;
+			case RT_MATERIAL_CONDUCTOR:  material_queue_append(p, 3, &p.sizes->conductor [bounce], bounce, ray_direction, medium_id, ray_cone_angle, ray_cone_width, packed_hit, pixel_index, throughput); break;
+		}
+	}
+}
+
+// ---- BSDFs (CUDA/BSDF.h) ----------------------------------------------------------------------------------
+
+struct TextureLOD { f2 gradient_1, gradient_2; float lod; };
+
+RT_DEV f3 sample_albedo(const RtParams & p, int bounce, f3 diffuse, int texture_id, f2 tex_coord, const TextureLOD & lod) { // RayCone.h:19-29
+	if (texture_id == RT_INVALID) return diffuse;
+	const RtTexture tex = p.textures[texture_id];
+	if (p.config.enable_mipmapping) {
+		if (bounce == 0) return diffuse * mk3(texture_get_grad(tex, tex_coord.x, tex_coord.y, lod.gradient_1, lod.gradient_2));
+		return diffuse * mk3(texture_get_lod(tex, tex_coord.x, tex_coord.y, lod.lod + tex.lod_bias));
+	}
+	return diffuse * mk3(texture_get(tex, tex_coord.x, tex_coord.y));
+}
+
+struct BSDFCommon {
+	int pixel_index, bounce, sample_index;
+	f3 tangent, bitangent, normal, omega_i;
+};
+
+struct BSDFDiffuse : BSDFCommon {
+	static constexpr bool HAS_ALBEDO = true;
+	f3 diffuse; int texture_id; f3 albedo;
+	RT_DEV void init(const RtParams & p, bool, int material_id) { float4 m = p.materials[2 * material_id]; diffuse = mk3(m.x, m.y, m.z); texture_id = __float_as_int(m.w); }
+	RT_DEV void calc_albedo(const RtParams & p, f3 & throughput, f2 tex_coord, const TextureLOD & lod) {
+		albedo = sample_albedo(p, bounce, diffuse, texture_id, tex_coord, lod);
+		if (bounce == 0) aov_set(p, RT_AOV_ALBEDO, pixel_index, mk4(albedo));
+		if (!(p.config.enable_svgf && bounce == 0)) throughput *= albedo;
+	}
+	RT_DEV bool eval(const RtParams &, f3, float cos_theta_o, f3 & bsdf, float & pdf) const {
+		if (cos_theta_o <= 0.0f) return false;
+		bsdf = mk3(cos_theta_o * RT_ONE_OVER_PI);
+		pdf  = cos_theta_o * RT_ONE_OVER_PI;
+		return pdf_is_valid(pdf);
+	}
+	RT_DEV bool sample(const RtParams & p, f3 &, int &, f3 & direction_out, float & pdf) const {
+		f2 r = random_sample(p, DIM_BSDF_0, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+		f3 omega_o = sample_cosine_weighted_direction(r.x, r.y);
+		direction_out = local_to_world(omega_o, tangent, bitangent, normal);
+		pdf = omega_o.z * RT_ONE_OVER_PI;
+		return pdf_is_valid(pdf);
+	}
+	RT_DEV bool has_texture() const { return texture_id != RT_INVALID; }
+	RT_DEV bool allow_nee() const { return true; }
+};
+
+struct BSDFPlastic : BSDFCommon {
+	static constexpr bool HAS_ALBEDO = true;
+	static constexpr float IOR = 1.5f;
+	static constexpr float ETA = 1.0f / IOR;
+	f3 diffuse; int texture_id; float linear_roughness; f3 albedo;
+	RT_DEV void init(const RtParams & p, bool, int material_id) {
+		float4 m = p.materials[2 * material_id]; diffuse = mk3(m.x, m.y, m.z); texture_id = __float_as_int(m.w);
+		linear_roughness = p.materials[2 * material_id + 1].x;
+	}
+	RT_DEV void calc_albedo(const RtParams & p, f3 &, f2 tex_coord, const TextureLOD & lod) {
+		albedo = sample_albedo(p, bounce, diffuse, texture_id, tex_coord, lod);
+		if (bounce == 0) aov_set(p, RT_AOV_ALBEDO, pixel_index, mk4(albedo));
+	}
+	RT_DEV f3 diffuse_lobe(float F_i, float F_o, float cos_o) const {
+		float F_avg = average_fresnel(IOR);
+		float internal_scattering_factor = 1.0f - (1.0f - F_avg) * square(ETA);
+		return ETA * ETA * (1.0f - F_i) * (1.0f - F_o) * albedo * RT_ONE_OVER_PI / (1.0f - albedo * internal_scattering_factor) * cos_o;
+	}
+	RT_DEV bool eval(const RtParams &, f3 to_light, float cos_theta_o, f3 & bsdf, float & pdf) const {
+		if (cos_theta_o <= 0.0f) return false;
+		f3 omega_o = world_to_local(to_light, tangent, bitangent, normal);
+		f3 omega_m = normalize(omega_i + omega_o);
+		float ax = roughness_to_alpha(linear_roughness), ay = ax;
+		float F  = fresnel_dielectric(dot(omega_i, omega_m), ETA);
+		float D  = ggx_D(omega_m, ax, ay);
+		float G1 = ggx_G1(omega_i, ax, ay);
+		float G2 = ggx_G2(omega_o, omega_i, omega_m, ax, ay);
+		f3 brdf_specular = mk3(F * G2 * D / (4.0f * omega_i.z));
+		float F_i = fresnel_dielectric(omega_i.z, ETA);
+		float F_o = fresnel_dielectric(omega_o.z, ETA);
+		f3 brdf_diffuse = diffuse_lobe(F_i, F_o, omega_o.z);
+		float pdf_specular = G1 * D / (4.0f * omega_i.z);
+		float pdf_diffuse  = omega_o.z * RT_ONE_OVER_PI;
+		pdf  = lerp_ref(pdf_diffuse, pdf_specular, F_i);
+		bsdf = brdf_specular + brdf_diffuse;
+		return pdf_is_valid(pdf);
+	}
+	RT_DEV bool sample(const RtParams & p, f3 & throughput, int &, f3 & direction_out, float & pdf) const {
+		float rand_fresnel = random_sample(p, DIM_BSDF_0, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index)).x;
+		f2    rand_brdf    = random_sample(p, DIM_BSDF_1, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+		float F_i = fresnel_dielectric(omega_i.z, ETA);
+		float ax = roughness_to_alpha(linear_roughness), ay = ax;
+		f3 omega_m, omega_o;
+		if (rand_fresnel < F_i) {
+			omega_m = sample_visible_normals_ggx(omega_i, ax, ay, rand_brdf.x, rand_brdf.y);
+			omega_o = reflect_direction(omega_i, omega_m);
+		} else {
+			omega_o = sample_cosine_weighted_direction(rand_brdf.x, rand_brdf.y);
+			omega_m = normalize(omega_i + omega_o);
+		}
+		if (omega_m.z < 0.0f) return false;
+		float F  = fresnel_dielectric(dot(omega_i, omega_m), ETA);
+		float D  = ggx_D(omega_m, ax, ay);
+		float G1 = ggx_G1(omega_i, ax, ay);
+		float G2 = ggx_G2(omega_o, omega_i, omega_m, ax, ay);
+		f3 brdf_specular = mk3(F * G2 * D / (4.0f * omega_i.z));
+		float F_o = fresnel_dielectric(omega_o.z, ETA);
+		f3 brdf_diffuse = diffuse_lobe(F_i, F_o, omega_o.z);
+		float pdf_specular = G1 * D / (4.0f * omega_i.z);
+		float pdf_diffuse  = omega_o.z * RT_ONE_OVER_PI;
+		pdf = lerp_ref(pdf_diffuse, pdf_specular, F_i);
+		throughput *= (brdf_specular + brdf_diffuse) / pdf;
+		direction_out = local_to_world(omega_o, tangent, bitangent, normal);
+		return pdf_is_valid(pdf);
+	}
+	RT_DEV bool has_texture() const { return texture_id != RT_INVALID; }
+	RT_DEV bool allow_nee() const { return true; }
+};
+
+struct BSDFDielectric : BSDFCommon {
+	static constexpr bool HAS_ALBEDO = false;
+	int medium_id_material; float ior, linear_roughness, eta;
+	RT_DEV void init(const RtParams & p, bool entering_material, int material_id) {
+		float4 m = p.materials[2 * material_id];
+		medium_id_material = __float_as_int(m.x); ior = m.y; linear_roughness = m.z;
+		eta = entering_material ? 1.0f / ior : ior;
+	}
+	RT_DEV void calc_albedo(const RtParams &, f3 &, f2, const TextureLOD &) { }
+
+	struct Lobes { float bsdf_single, bsdf_multi, pdf_single, pdf_multi; };
+	RT_DEV Lobes lobes(const RtParams & p, bool reflected, bool entering_material, f3 omega_o, f3 omega_m, float F, float E_i, float ratio, float E_avg_enter, float E_avg_leave) const {
+		float ax = roughness_to_alpha(linear_roughness), ay = ax;
+		float D  = ggx_D(omega_m, ax, ay);
+		float G1 = ggx_G1(omega_i, ax, ay);
+		float G2 = ggx_G2(omega_o, omega_i, omega_m, ax, ay);
+		float i_dot_m = abs_dot(omega_i, omega_m);
+		float o_dot_m = abs_dot(omega_o, omega_m);
+		Lobes l;
+		if (reflected) {
+			l.bsdf_single = F * G2 * D / (4.0f * omega_i.z);
+			l.pdf_single  = F * G1 * D / (4.0f * omega_i.z);
+			float E_o   = dielectric_directional_albedo(p, ior, linear_roughness, omega_o.z, entering_material);
+			float E_avg = entering_material ? E_avg_enter : E_avg_leave;
+			l.bsdf_multi = (1.0f - ratio) * fabsf(omega_o.z) * kulla_conty_multiscatter_lobe(E_i, E_o, E_avg);
+			l.pdf_multi  = (1.0f - ratio) * fabsf(omega_o.z) * RT_ONE_OVER_PI;
+		} else {
+			l.bsdf_single = (1.0f - F) * G2 * D * i_dot_m * o_dot_m / (omega_i.z * square(eta * i_dot_m + o_dot_m) * square(eta));
+			l.pdf_single  = (1.0f - F) * G1 * D * i_dot_m * o_dot_m / (omega_i.z * square(eta * i_dot_m + o_dot_m));
+			float E_o   = dielectric_directional_albedo(p, ior, linear_roughness, omega_o.z, !entering_material);
+			float E_avg = entering_material ? E_avg_leave : E_avg_enter; // inverted on purpose (BSDF.h:281)
+			l.bsdf_multi = ratio * fabsf(omega_o.z) * kulla_conty_multiscatter_lobe(E_i, E_o, E_avg);
+			l.pdf_multi  = ratio * fabsf(omega_o.z) * RT_ONE_OVER_PI;
+		}
+		return l;
+	}
+	RT_DEV void common(const RtParams & p, bool & entering_material, float & E_i, float & ratio, float & E_avg_enter, float & E_avg_leave) const {
+		entering_material = eta < 1.0f;
+		E_i = dielectric_directional_albedo(p, ior, linear_roughness, omega_i.z, entering_material);
+		float F_avg = average_fresnel(ior);
+		if (!entering_material) F_avg = 1.0f - (1.0f - F_avg) / square(ior);
+		E_avg_enter = dielectric_albedo(p, ior, linear_roughness, true);
+		E_avg_leave = dielectric_albedo(p, ior, linear_roughness, false);
+		float x = kulla_conty_dielectric_reciprocity_factor(E_avg_enter, E_avg_leave);
+		ratio = (entering_material ? x : (1.0f - x)) * (1.0f - F_avg);
+	}
+	RT_DEV bool eval(const RtParams & p, f3 to_light, float, f3 & bsdf, float & pdf) const {
+		f3 omega_o = world_to_local(to_light, tangent, bitangent, normal);
+		bool reflected = omega_o.z >= 0.0f;
+		f3 omega_m = reflected ? normalize(omega_i + omega_o) : normalize(eta * omega_i + omega_o);
+		omega_m *= sign_of(omega_m.z);
+		float F = fresnel_dielectric(abs_dot(omega_i, omega_m), eta);
+		bool entering_material; float E_i, ratio, E_avg_enter, E_avg_leave;
+		common(p, entering_material, E_i, ratio, E_avg_enter, E_avg_leave);
+		Lobes l = lobes(p, reflected, entering_material, omega_o, omega_m, F, E_i, ratio, E_avg_enter, E_avg_leave);
+		bsdf = mk3(l.bsdf_single + l.bsdf_multi);
+		pdf = lerp_ref(l.pdf_multi, l.pdf_single, E_i);
+		return pdf_is_valid(pdf);
+	}
+	RT_DEV bool sample(const RtParams & p, f3 & throughput, int & medium_id, f3 & direction_out, float & pdf) const {
+		f2 r0 = random_sample(p, DIM_BSDF_0, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+		f2 r1 = random_sample(p, DIM_BSDF_1, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+		float ax = roughness_to_alpha(linear_roughness), ay = ax;
+		bool entering_material; float E_i, ratio, E_avg_enter, E_avg_leave;
+		common(p, entering_material, E_i, ratio, E_avg_enter, E_avg_leave);
+
+		float F; bool reflected; f3 omega_m, omega_o;
+		if (r0.x < E_i) {
+			omega_m = sample_visible_normals_ggx(omega_i, ax, ay, r1.x, r1.y);
+			F = fresnel_dielectric(abs_dot(omega_i, omega_m), eta);
+			reflected = r0.y < F;
+			omega_o = reflected ? reflect_direction(omega_i, omega_m) : refract_direction(omega_i, omega_m, eta);
+		} else {
+			omega_o = sample_cosine_weighted_direction(r1.x, r1.y);
+			reflected = r0.y > ratio;
+			if (reflected) {
+				omega_m = normalize(omega_i + omega_o);
+			} else {
+				omega_o = -omega_o;
+				omega_m = normalize(eta * omega_i + omega_o);
+			}
+			omega_m *= sign_of(omega_m.z);
+			F = fresnel_dielectric(abs_dot(omega_i, omega_m), eta);
+		}
+		if (reflected ^ (omega_o.z >= 0.0f)) return false;
+
+		Lobes l = lobes(p, reflected, entering_material, omega_o, omega_m, F, E_i, ratio, E_avg_enter, E_avg_leave);
+		if (!reflected) medium_id = entering_material ? medium_id_material : RT_INVALID;
+		pdf = lerp_ref(l.pdf_multi, l.pdf_single, E_i);
+		throughput *= (l.bsdf_single + l.bsdf_multi) / pdf;
+		direction_out = local_to_world(omega_o, tangent, bitangent, normal);
+		return pdf_is_valid(pdf);
+	}
+	RT_DEV bool has_texture() const { return false; }
+	RT_DEV bool allow_nee() const { return linear_roughness >= RT_ROUGHNESS_CUTOFF; }
+};
+
+struct BSDFConductor : BSDFCommon {
+	static constexpr bool HAS_ALBEDO = false;
+	f3 eta3, k3; float linear_roughness;
+	RT_DEV void init(const RtParams & p, bool, int material_id) {
+		float4 a = p.materials[2 * material_id], b = p.materials[2 * material_id + 1];
+		eta3 = mk3(a.x, a.y, a.z); linear_roughness = a.w; k3 = mk3(b.x, b.y, b.z);
+	}
+	RT_DEV void calc_albedo(const RtParams &, f3 &, f2, const TextureLOD &) { }
+	RT_DEV void lobes(const RtParams & p, f3 omega_o, f3 omega_m, float o_dot_m, float E_i, f3 & brdf, float & pdf) const {
+		float ax = roughness_to_alpha(linear_roughness), ay = ax;
+		f3    F  = fresnel_conductor(o_dot_m, eta3, k3);
+		float D  = ggx_D(omega_m, ax, ay);
+		float G1 = ggx_G1(omega_i, ax, ay);
+		float G2 = ggx_G2(omega_o, omega_i, omega_m, ax, ay);
+		f3    brdf_single = F * G2 * D / (4.0f * omega_i.z);
+		float pdf_single  =     G1 * D / (4.0f * omega_i.z);
+		float E_o   = conductor_directional_albedo(p, linear_roughness, omega_o.z);
+		float E_avg = conductor_albedo(p, linear_roughness);
+		f3 F_avg = average_fresnel(eta3, k3);
+		f3 F_ms  = fresnel_multiscatter(F_avg, E_avg);
+		f3    brdf_multi = F_ms * kulla_conty_multiscatter_lobe(E_i, E_o, E_avg) * omega_o.z;
+		float pdf_multi  = omega_o.z * RT_ONE_OVER_PI;
+		brdf = brdf_single + brdf_multi;
+		pdf = lerp_ref(pdf_multi, pdf_single, E_i);
+	}
+	RT_DEV bool eval(const RtParams & p, f3 to_light, float cos_theta_o, f3 & bsdf, float & pdf) const {
+		if (cos_theta_o <= 0.0f) return false;
+		f3 omega_o = world_to_local(to_light, tangent, bitangent, normal);
+		f3 omega_m = normalize(omega_o + omega_i);
+		float o_dot_m = dot(omega_o, omega_m);
+		if (o_dot_m <= 0.0f) return false;
+		float E_i = conductor_directional_albedo(p, linear_roughness, omega_i.z);
+		lobes(p, omega_o, omega_m, o_dot_m, E_i, bsdf, pdf);
+		return pdf_is_valid(pdf);
+	}
+	RT_DEV bool sample(const RtParams & p, f3 & throughput, int &, f3 & direction_out, float & pdf) const {
+		f2 r0 = random_sample(p, DIM_BSDF_0, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+		f2 r1 = random_sample(p, DIM_BSDF_1, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+		float ax = roughness_to_alpha(linear_roughness), ay = ax;
+		float E_i = conductor_directional_albedo(p, linear_roughness, omega_i.z);
+		f3 omega_m, omega_o;
+		if (r0.x < E_i) {
+			omega_m = sample_visible_normals_ggx(omega_i, ax, ay, r1.x, r1.y);
+			omega_o = reflect_direction(omega_i, omega_m);
+		} else {
+			omega_o = sample_cosine_weighted_direction(r1.x, r1.y);
+			omega_m = normalize(omega_i + omega_o);
+		}
+		float o_dot_m = dot(omega_o, omega_m);
+		if (o_dot_m <= 0.0f || omega_o.z < 0.0f) return false;
+		f3 brdf;
+		lobes(p, omega_o, omega_m, o_dot_m, E_i, brdf, pdf);
+		throughput *= brdf / pdf;
+		direction_out = local_to_world(omega_o, tangent, bitangent, normal);
+		return pdf_is_valid(pdf);
+	}
+	RT_DEV bool has_texture() const { return false; }
+	RT_DEV bool allow_nee() const { return linear_roughness >= RT_ROUGHNESS_CUTOFF; }
+};
+
+// ---- next event estimation (Pathtracer.cu:465-555) ----------------------------------------------------------
+
+RT_DEV int sample_light(const RtParams & p, float u1, float u2, int & transform_id) { // Sampling.h:180-190
+	int light_mesh_id = binary_search(p.light_mesh_cumulative_probability, 0, p.light_mesh_count - 1, u1);
+	transform_id = p.light_mesh_transform_indices[light_mesh_id];
+	int2 span = p.light_mesh_triangle_span[light_mesh_id];
+	int light_triangle_id = binary_search(p.light_triangle_cumulative_probability, span.x, span.y, u2);
+	return p.light_triangle_indices[light_triangle_id];
+}
+
+template<typename BSDF>
+RT_DEV void next_event_estimation(const RtParams & p, int pixel_index, int bounce, int sample_index, const BSDF & bsdf, f3 hit_point, f3 normal, f3 geometric_normal, f3 throughput) {
+	f2 rand_light    = random_sample(p, DIM_NEE_LIGHT,    unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+	f2 rand_triangle = random_sample(p, DIM_NEE_TRIANGLE, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+
+	int light_mesh_id;
+	int light_triangle_id = sample_light(p, rand_light.x, rand_light.y, light_mesh_id);
+	f2 light_uv = sample_triangle(rand_triangle.x, rand_triangle.y);
+
+	f3 p0, e1, e2;
+	triangle_get_positions(p, light_triangle_id, p0, e1, e2);
+	f3 light_point = barycentric(light_uv.x, light_uv.y, p0, e1, e2);
+	f3 light_geometric_normal = cross(e1, e2);
+
+	const float4 * light_world = p.mesh_transforms + size_t(light_mesh_id) * 3;
+	light_point = m_position(light_world, light_point);
+	light_geometric_normal = normalize(m_direction(light_world, light_geometric_normal));
+
+	hit_point   = ray_origin_epsilon_offset(hit_point,   light_point - hit_point, geometric_normal);
+	light_point = ray_origin_epsilon_offset(light_point, hit_point - light_point, light_geometric_normal);
+
+	f3 to_light = light_point - hit_point;
+	float distance_to_light = length(to_light);
+	to_light /= distance_to_light;
+
+	float cos_theta_light = abs_dot(to_light, light_geometric_normal);
+	float cos_theta_hit = dot(to_light, normal);
+
+	int light_material_id = p.mesh_material_ids[light_mesh_id];
+	f3 emission = mk3(p.materials[2 * light_material_id]);
+
+	f3 bsdf_value; float bsdf_pdf;
+	if (!bsdf.eval(p, to_light, cos_theta_hit, bsdf_value, bsdf_pdf)) return;
+
+	float light_power = luminance(emission.x, emission.y, emission.z);
+	float light_pdf   = light_power * square(distance_to_light) / (cos_theta_light * p.lights_total_weight);
+	if (!pdf_is_valid(light_pdf)) return;
+
+	float mis_weight = p.config.enable_multiple_importance_sampling ? power_heuristic(light_pdf, bsdf_pdf) : 1.0f;
+	f3 illumination = throughput * bsdf_value * emission * mis_weight / light_pdf;
+
+	int shadow_ray_index = wave_aggregated_append(&p.sizes->shadow[bounce]);
+	store3(p.shadow.origin,    shadow_ray_index, hit_point);
+	store3(p.shadow.direction, shadow_ray_index, to_light);
+	p.shadow.max_distance[shadow_ray_index] = distance_to_light;
+	p.shadow.illumination_and_pixel_index[shadow_ray_index] = make_float4(illumination.x, illumination.y, illumination.z, __int_as_float(pixel_index));
+}
+
+// ---- shade_material<BSDF> (Pathtracer.cu:557-757) -------------------------------------------------------------
+
+RT_DEV float triangle_get_lod(float double_area_world_inv, f2 te1, f2 te2) {
+	float area_texel = fabsf(te1.x * te2.y - te2.x * te1.y);
+	return sqrtf(area_texel * double_area_world_inv);
+}
+RT_DEV float triangle_get_curvature(f3 pe1, f3 pe2, f3 ne1, f3 ne2) {
+	f3 ne0 = ne1 - ne2;
+	f3 pe0 = pe1 - pe2;
+	float k_01 = dot(ne1, pe1) / dot(pe1, pe1);
+	float k_02 = dot(ne2, pe2) / dot(pe2, pe2);
+	float k_12 = dot(ne0, pe0) / dot(pe0, pe0);
+	return (k_01 + k_02 + k_12) * (1.0f / 3.0f);
+}
+RT_DEV void ray_cone_get_ellipse_axes(f3 ray_direction, f3 geometric_normal, float cone_width, f3 & axis_1, f3 & axis_2) {
+	f3 h_1 = ray_direction - dot(geometric_normal, ray_direction) * geometric_normal;
+	f3 h_2 = cross(geometric_normal, h_1);
+	axis_1 = cone_width / fmaxf(0.0001f, length(h_1 - dot(ray_direction, h_1) * ray_direction)) * h_1;
+	axis_2 = cone_width / fmaxf(0.0001f, length(h_2 - dot(ray_direction, h_2) * ray_direction)) * h_2;
+}
+RT_DEV f2 ray_cone_ellipse_axis_to_gradient(const TriangleFull & tri, float double_area_inv, f3 geometric_normal, f3 hit_point, f2 hit_tex_coord, f3 ellipse_axis) {
+	f3 e_p = hit_point + ellipse_axis - tri.position_0;
+	float u = dot(geometric_normal, cross(e_p, tri.position_edge_2)) * double_area_inv;
+	float v = dot(geometric_normal, cross(tri.position_edge_1, e_p)) * double_area_inv;
+	return barycentric(u, v, tri.tex_coord_0, tri.tex_coord_edge_1, tri.tex_coord_edge_2) - hit_tex_coord;
+}
+RT_DEV float ray_cone_get_lod(f3 ray_direction, f3 geometric_normal, float cone_width) { return fabsf(cone_width / dot(ray_direction, geometric_normal)); }
+
+template<typename BSDF, int SLOT>
+RT_DEV void shade_material(const RtParams & p, int bounce, int sample_index, int buffer_size) {
+	const RtMaterialBuffer & q = p.material[SLOT];
+	const RtTraceBuffer & out = p.trace[(bounce + 1) & 1];
+
+	for (int index = blockIdx.x * blockDim.x + threadIdx.x; index < buffer_size; index += gridDim.x * blockDim.x) {
+		f3 ray_direction = load3(q.direction, index);
+		HitInfo hit = unpack_hit(q.hits[index]);
+
+		unsigned pixel_index_and_flags = q.pixel_index_and_flags[index];
+		int pixel_index = int(pixel_index_and_flags & ~RT_FLAGS_ALL);
+		bool inside_medium = pixel_index_and_flags & RT_FLAG_INSIDE_MEDIUM;
+		int medium_id = inside_medium ? q.medium[index] : RT_INVALID;
+
+		f3 throughput = bounce == 0 ? mk3(1.0f) : load3(q.throughput, index);
+
+		TriangleFull tri = triangle_get_full(p, hit.triangle_id);
+		f3 hit_point = barycentric(hit.u, hit.v, tri.position_0, tri.position_edge_1, tri.position_edge_2);
+		f3 normal    = barycentric(hit.u, hit.v, tri.normal_0,   tri.normal_edge_1,   tri.normal_edge_2);
+		f2 tex_coord = barycentric(hit.u, hit.v, tri.tex_coord_0, tri.tex_coord_edge_1, tri.tex_coord_edge_2);
+		f3 hit_point_local = hit_point;
+
+		const float4 * world = p.mesh_transforms + size_t(hit.mesh_id) * 3;
+		hit_point = m_position(world, hit_point);
+		normal = normalize(m_direction(world, normal));
+
+		float4 world_row_0 = world[0];
+		float mesh_scale_inv = 1.0f / length(mk3(world_row_0.x, world_row_0.y, world_row_0.z));
+
+		float cone_angle = 0.0f, cone_width = 0.0f, curvature = 0.0f;
+		if (p.config.enable_mipmapping) {
+			if (bounce == 0) { cone_angle = p.camera.pixel_spread_angle; cone_width = cone_angle * hit.t; }
+			else             { cone_angle = q.cone_angle[index]; cone_width = q.cone_width[index] + cone_angle * hit.t; }
+			curvature = triangle_get_curvature(tri.position_edge_1, tri.position_edge_2, tri.normal_edge_1, tri.normal_edge_2) * mesh_scale_inv;
+		}
+
+		tri.position_edge_1 = m_direction(world, tri.position_edge_1);
+		tri.position_edge_2 = m_direction(world, tri.position_edge_2);
+
+		f3 geometric_normal = cross(tri.position_edge_1, tri.position_edge_2);
+		float triangle_double_area_inv = 1.0f / length(geometric_normal);
+		geometric_normal *= triangle_double_area_inv;
+
+		bool entering_material = dot(ray_direction, geometric_normal) < 0.0f;
+		if (!entering_material) { normal = -normal; curvature = -curvature; }
+
+		f3 tangent, bitangent;
+		orthonormal_basis(normal, tangent, bitangent);
+		f3 omega_i = world_to_local(-ray_direction, tangent, bitangent, normal);
+		if (omega_i.z <= 0.0f) continue;
+
+		int material_id = p.mesh_material_ids[hit.mesh_id];
+
+		BSDF bsdf;
+		bsdf.pixel_index = pixel_index; bsdf.bounce = bounce; bsdf.sample_index = sample_index;
+		bsdf.tangent = tangent; bsdf.bitangent = bitangent; bsdf.normal = normal; bsdf.omega_i = omega_i;
+		bsdf.init(p, entering_material, material_id);
+
+		if (BSDF::HAS_ALBEDO) {
+			TextureLOD lod = { mk2(0.0f, 0.0f), mk2(0.0f, 0.0f), 0.0f };
+			if (p.config.enable_mipmapping && bsdf.has_texture()) {
+				if (bounce == 0) {
+					f3 axis_1, axis_2;
+					ray_cone_get_ellipse_axes(ray_direction, geometric_normal, cone_width, axis_1, axis_2);
+					lod.gradient_1 = ray_cone_ellipse_axis_to_gradient(tri, triangle_double_area_inv, geometric_normal, hit_point, tex_coord, axis_1);
+					lod.gradient_2 = ray_cone_ellipse_axis_to_gradient(tri, triangle_double_area_inv, geometric_normal, hit_point, tex_coord, axis_2);
+				} else {
+					float lod_triangle = triangle_get_lod(triangle_double_area_inv, tri.tex_coord_edge_1, tri.tex_coord_edge_2);
+					float lod_ray_cone = ray_cone_get_lod(ray_direction, geometric_normal, cone_width);
+					lod.lod = log2f(lod_triangle * lod_ray_cone);
+				}
+			}
+			bsdf.calc_albedo(p, throughput, tex_coord, lod);
+		} else if (bounce == 0) {
+			aov_set(p, RT_AOV_ALBEDO, pixel_index, mk4(1.0f));
+		}
+
+		if (bounce == 0) {
+			aov_set(p, RT_AOV_NORMAL,   pixel_index, mk4(normal));
+			aov_set(p, RT_AOV_POSITION, pixel_index, mk4(hit_point));
+		}
+
+		if (p.config.enable_mipmapping) cone_angle -= 2.0f * curvature * fabsf(cone_width) / dot(normal, ray_direction);
+
+		if (bounce == 0 && p.config.enable_svgf) {
+			f3 hit_point_prev = m_position(p.mesh_transforms_prev + size_t(hit.mesh_id) * 3, hit_point_local);
+			int x = pixel_index % p.screen_pitch, y = pixel_index / p.screen_pitch;
+			svgf_set_gbuffers(p, x, y, hit, hit_point, normal, hit_point_prev);
+		}
+
+		if (p.config.enable_next_event_estimation && p.lights_total_weight > 0.0f && bsdf.allow_nee()) {
+			next_event_estimation(p, pixel_index, bounce, sample_index, bsdf, hit_point, normal, geometric_normal, throughput);
+		}
+
+		f3 direction_out; float pdf;
+		if (!bsdf.sample(p, throughput, medium_id, direction_out, pdf)) continue;
+
+		f3 origin_out = ray_origin_epsilon_offset(hit_point, direction_out, geometric_normal);
+
+		int index_out = wave_aggregated_append(&p.sizes->trace[bounce + 1]);
+		store3(out.origin,    index_out, origin_out);
+		store3(out.direction, index_out, direction_out);
+		if (medium_id != RT_INVALID) out.medium[index_out] = medium_id;
+		if (p.config.enable_mipmapping) { out.cone_angle[index_out] = cone_angle; out.cone_width[index_out] = cone_width; }
+
+		bool allow_nee = bsdf.allow_nee();
+		unsigned flags = 0;
+		if (allow_nee)               flags |= RT_FLAG_ALLOW_NEE;
+		if (medium_id != RT_INVALID) flags |= RT_FLAG_INSIDE_MEDIUM;
+		out.pixel_index_and_flags[index_out] = unsigned(pixel_index) | flags;
+		store3(out.throughput, index_out, throughput);
+		if (allow_nee) out.last_pdf[index_out] = pdf;
+	}
+}
+
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_diffuse(RtParams p, int bounce, int sample_index)    { shade_material<BSDFDiffuse,    0>(p, bounce, sample_index, p.sizes->diffuse   [bounce]); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_plastic(RtParams p, int bounce, int sample_index)    { shade_material<BSDFPlastic,    1>(p, bounce, sample_index, p.sizes->plastic   [bounce]); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_dielectric(RtParams p, int bounce, int sample_index) { shade_material<BSDFDielectric, 2>(p, bounce, sample_index, p.sizes->dielectric[bounce]); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_conductor(RtParams p, int bounce, int sample_index)  { shade_material<BSDFConductor,  3>(p, bounce, sample_index, p.sizes->conductor [bounce]); }
+
+// ---- launchers ---------------------------------------------------------------------------------------------------
+
+static int streaming_grid(int work_items) {
+	// cap at ~8 workgroups per CU and grid-stride the rest (cdna_hip_programming.md G11)
+	int blocks = (work_items + RT_SHADE_BLOCK - 1) / RT_SHADE_BLOCK;
+	if (blocks < 1) blocks = 1;
+	if (blocks > 2048) blocks = 2048;
+	return blocks;
+}
+
+void rt_launch_generate(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, hipStream_t stream) {
+	hipLaunchKernelGGL(kernel_generate, dim3(streaming_grid(pixel_count)), dim3(RT_SHADE_BLOCK), 0, stream, p, sample_index, pixel_offset, pixel_count);
+}
+void rt_launch_sort(const RtParams & p, int bounce, int sample_index, hipStream_t stream) {
+	hipLaunchKernelGGL(kernel_sort, dim3(streaming_grid(RT_BATCH_SIZE)), dim3(RT_SHADE_BLOCK), 0, stream, p, bounce, sample_index);
+}
+void rt_launch_material(const RtParams & p, int material_slot, int bounce, int sample_index, hipStream_t stream) {
+	dim3 grid(streaming_grid(RT_BATCH_SIZE)), block(RT_SHADE_BLOCK);
+	switch (material_slot) {
+		case 0: hipLaunchKernelGGL(kernel_material_diffuse,    grid, block, 0, stream, p, bounce, sample_index); break;
+		case 1: hipLaunchKernelGGL(kernel_material_plastic,    grid, block, 0, stream, p, bounce, sample_index); break;
+		case 2: hipLaunchKernelGGL(kernel_material_dielectric, grid, block, 0, stream, p, bounce, sample_index); break;
+		case 3: hipLaunchKernelGGL(kernel_material_conductor,  grid, block, 0, stream, p, bounce, sample_index); break;
+	}
+}
+void rt_launch_random(const RtParams & p, int dimension, const unsigned * pixel_indices, int count, unsigned bounce, unsigned sample_index, float2 * out, hipStream_t stream) {
+	hipLaunchKernelGGL(kernel_random, dim3((count + 255) / 256), dim3(256), 0, stream, p, dimension, pixel_indices, count, bounce, sample_index, out);
+}

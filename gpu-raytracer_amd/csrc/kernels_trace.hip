@@ -1,0 +1,402 @@
+// kernels_trace.hip -- BVH8 (CWBVH) closest-hit and any-hit traversal for gfx950.
+//
+// Replaces kernel_trace_bvh8 / kernel_trace_shadow_bvh8 of the reference
+// (CUDA/Pathtracer.cu:149-196, CUDA/Raytracing/BVH8.h:29-444).  Same algorithm per ray --
+// octant-ordered traversal of 80-byte compressed 8-wide nodes, TLAS -> BLAS instancing with
+// un-normalised object-space rays, Moeller-Trumbore on pre-subtracted edges -- re-designed
+// for CDNA4:
+//   * persistent 64-lane waves pull rays with ONE wave-aggregated atomic per refill
+//     (ballot + mbcnt prefix rank) instead of one atomicAdd per lane;
+//   * the traversal stack lives in LDS, striped [entry][lane] so that a ds_write_b64 /
+//     ds_read_b64 of any mix of per-lane depths is bank-conflict free (entry stride is 512 B,
+//     a multiple of the 256 B bank row); only entries beyond RT_LDS_STACK spill to scratch;
+//   * the reciprocal ray direction is computed once per ray (and per BLAS entry) so the
+//     node test is 6 fma + min3/max3 per child; child bytes are unpacked with
+//     v_cvt_f32_ubyte0..3;
+//   * the dynamic-fetch heuristic of Ylitie et al. (section 4.4) is re-expressed for 64
+//     lanes: a wave goes back to fetch rays once it has lost RT_N_W lane-iterations.
+// Triangle postponing (BVH8.h:200,234-240) is intentionally absent: every ray visits nodes
+// and triangles in exactly the order of the sequential algorithm, which keeps hits
+// bit-identical to the CPU oracle even when two triangles tie in t.
+#include "rt_math.h"
+
+#define RT_LDS_STACK   12   // stack entries per lane kept in LDS
+#define RT_STACK_SIZE  32   // total entries per lane (reference: BVH_STACK_SIZE, Common.h:103)
+#define RT_TRACE_BLOCK 256  // 4 waves per workgroup
+#define RT_N_D 8            // dynamic fetch: tolerated idle lanes per iteration (N_d = 4 of 32 in the reference)
+#define RT_N_W 32           // dynamic fetch: lost lane-iterations before refilling  (N_w = 16 of 32)
+
+struct Ray3 { f3 origin, direction; };
+
+RT_DEV unsigned msb(unsigned x) { return 31u - unsigned(__clz(int(x))); }
+RT_DEV unsigned extract_byte(unsigned x, unsigned i) { return (x >> (i * 8)) & 0xffu; }
+RT_DEV unsigned sign_extend_s8x4(unsigned x) { return ((x >> 7) & 0x01010101u) * 0xffu; }
+
+RT_DEV unsigned ray_get_octant_inv4(f3 d) {
+	return (d.x < 0.0f ? 0u : 0x04040404u) | (d.y < 0.0f ? 0u : 0x02020202u) | (d.z < 0.0f ? 0u : 0x01010101u);
+}
+
+RT_DEV f3 reciprocal(f3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+
+RT_DEV f3 transform_position(const float4 * m, f3 p) {
+	float4 r0 = m[0], r1 = m[1], r2 = m[2];
+	return mk3(
+		__builtin_fmaf(r0.x, p.x, __builtin_fmaf(r0.y, p.y, __builtin_fmaf(r0.z, p.z, r0.w))),
+		__builtin_fmaf(r1.x, p.x, __builtin_fmaf(r1.y, p.y, __builtin_fmaf(r1.z, p.z, r1.w))),
+		__builtin_fmaf(r2.x, p.x, __builtin_fmaf(r2.y, p.y, __builtin_fmaf(r2.z, p.z, r2.w))));
+}
+RT_DEV f3 transform_direction(const float4 * m, f3 d) {
+	float4 r0 = m[0], r1 = m[1], r2 = m[2];
+	return mk3(
+		__builtin_fmaf(r0.x, d.x, __builtin_fmaf(r0.y, d.y, r0.z * d.z)),
+		__builtin_fmaf(r1.x, d.x, __builtin_fmaf(r1.y, d.y, r1.z * d.z)),
+		__builtin_fmaf(r2.x, d.x, __builtin_fmaf(r2.y, d.y, r2.z * d.z)));
+}
+
+// 8 slab tests against the quantised child boxes of one node; returns the hit mask
+// (bits 24..31: inner children in octant order, bits 0..23: triangles / TLAS leaves).
+RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_inv4, float max_distance,
+                                    float4 n0, float4 n1, float4 n2, float4 n3, float4 n4) {
+	f3 p = mk3(n0.x, n0.y, n0.z);
+	unsigned e_imask = __float_as_uint(n0.w);
+
+	f3 adjusted_dir_inv = mk3(
+		__uint_as_float(extract_byte(e_imask, 0) << 23) * inv_dir.x,
+		__uint_as_float(extract_byte(e_imask, 1) << 23) * inv_dir.y,
+		__uint_as_float(extract_byte(e_imask, 2) << 23) * inv_dir.z);
+	f3 adjusted_origin = (p - ray.origin) * inv_dir;
+
+	bool neg_x = ray.direction.x < 0.0f, neg_y = ray.direction.y < 0.0f, neg_z = ray.direction.z < 0.0f;
+
+	unsigned hit_mask = 0;
+	#pragma unroll
+	for (int i = 0; i < 2; i++) {
+		unsigned meta4 = __float_as_uint(i == 0 ? n1.z : n1.w);
+
+		unsigned is_inner4   = (meta4 & (meta4 << 1)) & 0x10101010u;
+		unsigned inner_mask4 = sign_extend_s8x4(is_inner4 << 3);
+		unsigned bit_index4  = (meta4 ^ (oct_inv4 & inner_mask4)) & 0x1f1f1f1fu;
+		unsigned child_bits4 = (meta4 >> 5) & 0x07070707u;
+
+		unsigned q_lo_x = __float_as_uint(i == 0 ? n2.x : n2.y), q_hi_x = __float_as_uint(i == 0 ? n2.z : n2.w);
+		unsigned q_lo_y = __float_as_uint(i == 0 ? n3.x : n3.y), q_hi_y = __float_as_uint(i == 0 ? n3.z : n3.w);
+		unsigned q_lo_z = __float_as_uint(i == 0 ? n4.x : n4.y), q_hi_z = __float_as_uint(i == 0 ? n4.z : n4.w);
+
+		unsigned x_min = neg_x ? q_hi_x : q_lo_x, x_max = neg_x ? q_lo_x : q_hi_x;
+		unsigned y_min = neg_y ? q_hi_y : q_lo_y, y_max = neg_y ? q_lo_y : q_hi_y;
+		unsigned z_min = neg_z ? q_hi_z : q_lo_z, z_max = neg_z ? q_lo_z : q_hi_z;
+
+		#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			float tx0 = __builtin_fmaf(float(extract_byte(x_min, j)), adjusted_dir_inv.x, adjusted_origin.x);
+			float ty0 = __builtin_fmaf(float(extract_byte(y_min, j)), adjusted_dir_inv.y, adjusted_origin.y);
+			float tz0 = __builtin_fmaf(float(extract_byte(z_min, j)), adjusted_dir_inv.z, adjusted_origin.z);
+			float tx1 = __builtin_fmaf(float(extract_byte(x_max, j)), adjusted_dir_inv.x, adjusted_origin.x);
+			float ty1 = __builtin_fmaf(float(extract_byte(y_max, j)), adjusted_dir_inv.y, adjusted_origin.y);
+			float tz1 = __builtin_fmaf(float(extract_byte(z_max, j)), adjusted_dir_inv.z, adjusted_origin.z);
+
+			float tmin = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, 0.0f));
+			float tmax = fminf(fminf(tx1, ty1), fminf(tz1, max_distance));
+
+			if (tmin < tmax) {
+				unsigned child_bits = extract_byte(child_bits4, j);
+				unsigned bit_index  = extract_byte(bit_index4,  j);
+				hit_mask |= child_bits << bit_index;
+			}
+		}
+	}
+	return hit_mask;
+}
+
+struct HitRecord { float t, u, v; int mesh_id, triangle_id; };
+
+template<bool SHADOW>
+RT_DEV bool triangle_test(const float4 * __restrict__ triangles, int mesh_id, int triangle_id, const Ray3 & ray, float max_distance, HitRecord & hit) {
+	const float4 * tri = triangles + size_t(triangle_id) * 6;
+	float4 part_0 = tri[0], part_1 = tri[1], part_2 = tri[2]; // 48 B: position_0, edge_1, edge_2 (+3 unused floats)
+	f3 p0 = mk3(part_0.x, part_0.y, part_0.z);
+	f3 e1 = mk3(part_0.w, part_1.x, part_1.y);
+	f3 e2 = mk3(part_1.z, part_1.w, part_2.x);
+
+	f3 h = cross_fma(ray.direction, e2);
+	float a = dot_fma(e1, h);
+	float f = 1.0f / a;
+	f3 s = ray.origin - p0;
+	float u = f * dot_fma(s, h);
+	if (u >= 0.0f && u <= 1.0f) {
+		f3 q = cross_fma(s, e1);
+		float v = f * dot_fma(ray.direction, q);
+		if (v >= 0.0f && u + v <= 1.0f) {
+			float t = f * dot_fma(e2, q);
+			if (SHADOW) {
+				if (t > 0.0f && t < max_distance) return true;
+			} else if (t > 0.0f && t < hit.t) {
+				hit.t = t; hit.u = u; hit.v = v;
+				hit.mesh_id = mesh_id;
+				hit.triangle_id = triangle_id;
+			}
+		}
+	}
+	return false;
+}
+
+// Per-lane stack: first RT_LDS_STACK entries in LDS, the rest in scratch.
+struct TraversalStack {
+	uint2 * lds;                                   // &shared[wave][0][lane]
+	uint2 spill[RT_STACK_SIZE - RT_LDS_STACK];
+	int size;
+
+	RT_DEV void push(uint2 item) {
+		if (size < RT_LDS_STACK) lds[size * RT_WAVE_SIZE] = item;
+		else                     spill[size - RT_LDS_STACK] = item;
+		size++;
+	}
+	RT_DEV uint2 pop() {
+		size--;
+		if (size < RT_LDS_STACK) return lds[size * RT_WAVE_SIZE];
+		return spill[size - RT_LDS_STACK];
+	}
+};
+
+// The common traversal engine. RaySource supplies rays and consumes results so that the same
+// code serves the wavefront queues and the stand-alone entry points.
+template<bool SHADOW, typename Source>
+RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_count, int * rays_retired) {
+	__shared__ uint2 shared_stack[(RT_TRACE_BLOCK / RT_WAVE_SIZE) * RT_LDS_STACK * RT_WAVE_SIZE];
+
+	const float4 * __restrict__ nodes     = p.bvh8_nodes;
+	const float4 * __restrict__ triangles = p.triangles;
+
+	unsigned lane = threadIdx.x & (RT_WAVE_SIZE - 1);
+	unsigned wave = threadIdx.x / RT_WAVE_SIZE;
+
+	TraversalStack stack;
+	stack.lds  = shared_stack + wave * (RT_LDS_STACK * RT_WAVE_SIZE) + lane;
+	stack.size = 0;
+
+	uint2 current_group = make_uint2(0, 0);
+
+	int  ray_index = 0;
+	Ray3 ray, ray_untransformed;
+	f3   inv_dir;
+	unsigned oct_inv4 = 0;
+	float max_distance = 0.0f;
+	HitRecord hit;
+	int  tlas_stack_size = RT_INVALID;
+	int  mesh_id = 0;
+	bool mesh_has_identity_transform = true;
+
+	while (true) {
+		bool inactive = stack.size == 0 && current_group.y == 0;
+
+		if (inactive) {
+			// wave-aggregated ray fetch
+			unsigned long long want = __ballot(1);
+			unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(want >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(want), 0u));
+			int leader = __ffsll((long long)want) - 1;
+			int base = 0;
+			if (rank == 0) base = atomicAdd(rays_retired, __popcll(want));
+			base = __shfl(base, leader);
+			ray_index = base + int(rank);
+			if (ray_index >= ray_count) return;
+
+			src.load(ray_index, ray, max_distance);
+			ray_untransformed = ray;
+			inv_dir  = reciprocal(ray.direction);
+			oct_inv4 = ray_get_octant_inv4(ray.direction);
+
+			current_group = make_uint2(0, 0x80000000u);
+			hit.t = RT_INFINITY; hit.u = 0.0f; hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
+			tlas_stack_size = RT_INVALID;
+		}
+
+		int iterations_lost = 0;
+		do {
+			uint2 triangle_group;
+
+			if (current_group.y & 0xff000000u) {
+				unsigned hits_imask = current_group.y;
+				unsigned child_index_offset = msb(hits_imask);
+				unsigned child_index_base   = current_group.x;
+
+				current_group.y &= ~(1u << child_index_offset);
+				if (current_group.y & 0xff000000u) stack.push(current_group);
+
+				unsigned slot_index     = (child_index_offset - 24) ^ (oct_inv4 & 0xffu);
+				unsigned relative_index = __popc(hits_imask & ~(0xffffffffu << slot_index));
+				unsigned child_node_index = child_index_base + relative_index;
+
+				const float4 * node = nodes + size_t(child_node_index) * 5;
+				float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
+
+				unsigned hitmask = bvh8_node_intersect(ray, inv_dir, oct_inv4, SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
+				unsigned imask = extract_byte(__float_as_uint(n0.w), 3);
+
+				current_group .x = __float_as_uint(n1.x);
+				triangle_group.x = __float_as_uint(n1.y);
+				current_group .y = (hitmask & 0xff000000u) | imask;
+				triangle_group.y = (hitmask & 0x00ffffffu);
+			} else {
+				triangle_group = current_group;
+				current_group  = make_uint2(0, 0);
+			}
+
+			bool occluded = false;
+			while (triangle_group.y != 0) {
+				if (tlas_stack_size == RT_INVALID) {
+					int mesh_offset = int(msb(triangle_group.y));
+					triangle_group.y &= ~(1u << mesh_offset);
+					mesh_id = int(triangle_group.x) + mesh_offset;
+
+					if (triangle_group.y != 0)         stack.push(triangle_group);
+					if (current_group.y & 0xff000000u) stack.push(current_group);
+					tlas_stack_size = stack.size;
+
+					unsigned root = unsigned(p.mesh_bvh_root_indices[mesh_id]);
+					mesh_has_identity_transform = (root >> 31) != 0;
+					if (!mesh_has_identity_transform) {
+						const float4 * m = p.mesh_transforms_inv + size_t(mesh_id) * 3;
+						ray.origin    = transform_position (m, ray.origin);
+						ray.direction = transform_direction(m, ray.direction);
+						inv_dir  = reciprocal(ray.direction);
+						oct_inv4 = ray_get_octant_inv4(ray.direction);
+					}
+					current_group = make_uint2(root & 0x7fffffffu, 0x80000000u);
+					break;
+				} else {
+					int triangle_index = int(msb(triangle_group.y));
+					triangle_group.y &= ~(1u << triangle_index);
+					if (triangle_test<SHADOW>(triangles, mesh_id, int(triangle_group.x) + triangle_index, ray, max_distance, hit)) {
+						occluded = true;
+						break;
+					}
+				}
+			}
+
+			if (SHADOW && occluded) {
+				src.finish(ray_index, hit, true);
+				stack.size = 0;
+				current_group.y = 0;
+				break;
+			}
+
+			if ((current_group.y & 0xff000000u) == 0) {
+				if (stack.size == 0) {
+					src.finish(ray_index, hit, false);
+					current_group.y = 0;
+					break;
+				}
+				if (stack.size == tlas_stack_size) {
+					tlas_stack_size = RT_INVALID;
+					if (!mesh_has_identity_transform) {
+						ray = ray_untransformed;
+						inv_dir  = reciprocal(ray.direction);
+						oct_inv4 = ray_get_octant_inv4(ray.direction);
+					}
+				}
+				current_group = stack.pop();
+			}
+
+			iterations_lost += RT_WAVE_SIZE - __popcll(__ballot(1)) - RT_N_D;
+		} while (iterations_lost < RT_N_W);
+	}
+}
+
+RT_DEV uint4 pack_hit(const HitRecord & h) { // Buffers.h:25-32
+	unsigned uv = unsigned(int(h.u * 65535.0f)) | (unsigned(int(h.v * 65535.0f)) << 16);
+	return make_uint4(unsigned(h.mesh_id), unsigned(h.triangle_id), __float_as_uint(h.t), uv);
+}
+
+// ---- ray sources ------------------------------------------------------------------------------
+
+struct ClosestHitSource {
+	RtVec3SoA origin, direction;
+	uint4 * hits;
+	RT_DEV void load(int i, Ray3 & ray, float & max_distance) const { ray.origin = load3(origin, i); ray.direction = load3(direction, i); max_distance = RT_INFINITY; }
+	RT_DEV void finish(int i, const HitRecord & hit, bool) const { hits[i] = pack_hit(hit); }
+};
+
+// Wavefront shadow rays: a MISS adds the pre-computed illumination to the AOVs
+// (the lambda of kernel_trace_shadow_bvh8, Pathtracer.cu:183-196).
+struct ShadowQueueSource {
+	RtShadowBuffer buffer;
+	RtAOV radiance, direct, indirect;
+	int bounce;
+	RT_DEV void load(int i, Ray3 & ray, float & max_distance) const { ray.origin = load3(buffer.origin, i); ray.direction = load3(buffer.direction, i); max_distance = buffer.max_distance[i]; }
+	RT_DEV void finish(int i, const HitRecord &, bool occluded) const {
+		if (occluded) return;
+		float4 ip = buffer.illumination_and_pixel_index[i];
+		int pixel_index = __float_as_int(ip.w);
+		float4 value = make_float4(ip.x, ip.y, ip.z, 0.0f);
+		if (radiance.framebuffer) { float4 c = radiance.framebuffer[pixel_index]; radiance.framebuffer[pixel_index] = make_float4(c.x + value.x, c.y + value.y, c.z + value.z, c.w + value.w); }
+		if (bounce == 0) {
+			if (direct.framebuffer) direct.framebuffer[pixel_index] = value;
+		} else if (indirect.framebuffer) {
+			float4 c = indirect.framebuffer[pixel_index];
+			indirect.framebuffer[pixel_index] = make_float4(c.x + value.x, c.y + value.y, c.z + value.z, c.w + value.w);
+		}
+	}
+};
+
+struct ShadowExplicitSource {
+	RtVec3SoA origin, direction;
+	const float * max_dist;
+	uint8_t * occluded_out;
+	RT_DEV void load(int i, Ray3 & ray, float & max_distance) const { ray.origin = load3(origin, i); ray.direction = load3(direction, i); max_distance = max_dist[i]; }
+	RT_DEV void finish(int i, const HitRecord &, bool occluded) const { occluded_out[i] = occluded ? 1 : 0; }
+};
+
+// ---- kernels ---------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(RT_TRACE_BLOCK) kernel_trace_bvh8(RtParams p, int bounce) {
+	ClosestHitSource src { p.trace[bounce & 1].origin, p.trace[bounce & 1].direction, p.trace[bounce & 1].hits };
+	bvh8_trace_persistent<false>(p, src, p.sizes->trace[bounce], &p.sizes->rays_retired[bounce]);
+}
+
+__global__ void __launch_bounds__(RT_TRACE_BLOCK) kernel_trace_shadow_bvh8(RtParams p, int bounce) {
+	ShadowQueueSource src { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT], bounce };
+	bvh8_trace_persistent<true>(p, src, p.sizes->shadow[bounce], &p.sizes->rays_retired_shadow[bounce]);
+}
+
+__global__ void __launch_bounds__(RT_TRACE_BLOCK) kernel_trace_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {
+	ClosestHitSource src { origin, direction, hits };
+	bvh8_trace_persistent<false>(p, src, ray_count, retired);
+}
+
+__global__ void __launch_bounds__(RT_TRACE_BLOCK) kernel_trace_shadow_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, const float * max_distance, uint8_t * occluded, int ray_count, int * retired) {
+	ShadowExplicitSource src { origin, direction, max_distance, occluded };
+	bvh8_trace_persistent<true>(p, src, ray_count, retired);
+}
+
+// Persistent grid: enough workgroups to fill every CU to the occupancy the kernel reaches,
+// a multiple of 8 so that all XCDs get the same share (block b runs on XCD b % 8).
+static int trace_grid_size(const void * kernel) {
+	static int cached_cus = 0;
+	if (!cached_cus) {
+		int device = 0;
+		hipGetDevice(&device);
+		hipDeviceGetAttribute(&cached_cus, hipDeviceAttributeMultiprocessorCount, device);
+		if (cached_cus <= 0) cached_cus = 256;
+	}
+	int blocks_per_cu = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, RT_TRACE_BLOCK, 0) != hipSuccess || blocks_per_cu <= 0) blocks_per_cu = 2;
+	if (blocks_per_cu > 8) blocks_per_cu = 8;
+	return cached_cus * blocks_per_cu;
+}
+
+void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream) {
+	static int grid = trace_grid_size((const void *)kernel_trace_bvh8);
+	hipLaunchKernelGGL(kernel_trace_bvh8, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
+}
+void rt_launch_trace_shadow(const RtParams & p, int bounce, hipStream_t stream) {
+	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8);
+	hipLaunchKernelGGL(kernel_trace_shadow_bvh8, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
+}
+void rt_launch_trace_explicit(const RtParams & p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired_counter, hipStream_t stream) {
+	static int grid = trace_grid_size((const void *)kernel_trace_bvh8_explicit);
+	hipLaunchKernelGGL(kernel_trace_bvh8_explicit, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, origin, direction, hits, ray_count, retired_counter);
+}
+void rt_launch_trace_shadow_explicit(const RtParams & p, RtVec3SoA origin, RtVec3SoA direction, const float * max_distance, uint8_t * occluded, int ray_count, int * retired_counter, hipStream_t stream) {
+	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8_explicit);
+	hipLaunchKernelGGL(kernel_trace_shadow_bvh8_explicit, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, origin, direction, max_distance, occluded, ray_count, retired_counter);
+}

@@ -1,0 +1,779 @@
+// rt_api.hip -- implementation of the C ABI in include/gpu_raytracer_amd.h.
+//
+// One rt_context owns one HIP device: a stream, every device buffer, and the RtParams block
+// handed to the kernels by value. It plays the role of the reference's Device/ layer plus the
+// device half of Integrator/Pathtracer (buffer ownership, `buffer_sizes` handling, the
+// wavefront launch loop of Pathtracer::render, Pathtracer.cpp:738-855).
+#include "rt_types.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_global_error;
+
+struct rt_context {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string error;
+
+	RtParams params;               // zero-initialised in rt_create
+	std::vector<void *> owned;     // every hipMalloc'd pointer, freed in rt_destroy
+
+	// named allocations that get replaced on re-upload
+	void * triangles = nullptr, * bvh8_nodes = nullptr, * bvh2_nodes = nullptr;
+	size_t bvh8_node_count = 0, bvh2_node_count = 0, triangle_count = 0;
+	void * instances[5] = { };     size_t mesh_count = 0;
+	void * material_types = nullptr, * materials = nullptr, * media = nullptr;
+	bool has_material[4] = { false, false, false, false };
+	bool has_lights = false;
+	void * texture_table = nullptr; std::vector<void *> texture_data;
+	void * lights[5] = { };
+	void * pmj = nullptr, * blue_noise = nullptr;
+	void * sky = nullptr;
+	void * luts[6] = { }; bool luts_ready = false;
+	int bvh_width = 8;
+
+	// frame resources
+	void * aov_buffers[RT_AOV_COUNT][2] = { };
+	void * final_image = nullptr;
+	void * svgf_buffers[12] = { }; bool svgf_allocated = false;
+	size_t frame_pixels = 0; // pitch * height
+
+	RtBufferSizes * sizes = nullptr;
+	int * counter_totals = nullptr;          // 6 x RT_MAX_BOUNCES ints accumulated over batches
+	RtBufferSizes * pinned_counters = nullptr;
+	int * explicit_retired = nullptr;
+
+	bool queues_allocated = false;
+	int pixel_offset = 0, pixel_count = -1;  // -1 = whole frame
+
+	rt_counters last_counters;
+	bool profiling = false;
+	hipEvent_t ev_frame_start = nullptr, ev_frame_end = nullptr;
+	std::vector<hipEvent_t> stage_events; std::vector<int> stage_kinds; size_t stage_used = 0;
+};
+
+static int fail(rt_context * ctx, int status, const char * fmt, ...) {
+	char buffer[512];
+	va_list args; va_start(args, fmt); vsnprintf(buffer, sizeof(buffer), fmt, args); va_end(args);
+	if (ctx) ctx->error = buffer;
+	g_global_error = buffer;
+	return status;
+}
+
+#define RT_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, RT_ERROR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+#define RT_REQUIRE(ctx, cond, msg) do { if (!(cond)) return fail(ctx, RT_ERROR_INVALID_ARG, "%s", msg); } while (0)
+
+static int device_alloc(rt_context * ctx, void ** out, size_t bytes) {
+	if (bytes == 0) bytes = 16;
+	RT_HIP(ctx, hipMalloc(out, bytes));
+	ctx->owned.push_back(*out);
+	return RT_OK;
+}
+static void device_free(rt_context * ctx, void * p) {
+	if (!p) return;
+	for (size_t i = 0; i < ctx->owned.size(); i++) if (ctx->owned[i] == p) { ctx->owned[i] = ctx->owned.back(); ctx->owned.pop_back(); break; }
+	(void)hipFree(p);
+}
+// (re)allocate + synchronous upload
+static int upload(rt_context * ctx, void ** slot, const void * src, size_t bytes) {
+	device_free(ctx, *slot);
+	*slot = nullptr;
+	int s = device_alloc(ctx, slot, bytes);
+	if (s != RT_OK) return s;
+	if (bytes && src) RT_HIP(ctx, hipMemcpy(*slot, src, bytes, hipMemcpyHostToDevice));
+	return RT_OK;
+}
+
+extern "C" {
+
+const char * rt_version(void) { return "gpu-raytracer_amd 0.1 (gfx950, HIP)"; }
+
+const char * rt_last_error(const rt_context * ctx) { return ctx ? ctx->error.c_str() : g_global_error.c_str(); }
+
+int rt_create(int device_ordinal, rt_context ** out_ctx) {
+	if (!out_ctx) return fail(nullptr, RT_ERROR_INVALID_ARG, "rt_create: out_ctx is NULL");
+	*out_ctx = nullptr;
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count == 0) return fail(nullptr, RT_ERROR_NO_DEVICE, "rt_create: no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+	if (device_ordinal < 0 || device_ordinal >= count) return fail(nullptr, RT_ERROR_NO_DEVICE, "rt_create: device ordinal %d out of range [0,%d)", device_ordinal, count);
+	if (hipSetDevice(device_ordinal) != hipSuccess) return fail(nullptr, RT_ERROR_NO_DEVICE, "rt_create: hipSetDevice(%d) failed", device_ordinal);
+
+	rt_context * ctx = new rt_context();
+	ctx->device = device_ordinal;
+	memset(&ctx->params, 0, sizeof(ctx->params));
+	memset(&ctx->last_counters, 0, sizeof(ctx->last_counters));
+	RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+	RT_HIP(ctx, hipEventCreate(&ctx->ev_frame_start));
+	RT_HIP(ctx, hipEventCreate(&ctx->ev_frame_end));
+
+	int s = device_alloc(ctx, (void **)&ctx->sizes, sizeof(RtBufferSizes)); if (s) return s;
+	s = device_alloc(ctx, (void **)&ctx->counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int)); if (s) return s;
+	s = device_alloc(ctx, (void **)&ctx->explicit_retired, 16); if (s) return s;
+	RT_HIP(ctx, hipHostMalloc((void **)&ctx->pinned_counters, sizeof(RtBufferSizes)));
+	ctx->params.sizes = ctx->sizes;
+
+	// default config = reference defaults (Common.h:39-67)
+	rt_gpu_config c = { RT_FILTER_GAUSSIAN, 1u << RT_AOV_RADIANCE, 10, 1, 1, 1, 1, 0, 1, 1, 0.1f, 0.1f, 6, 4.0f, 16.0f, 10.0f };
+	ctx->params.config = c;
+	*out_ctx = ctx;
+	return RT_OK;
+}
+
+void rt_destroy(rt_context * ctx) {
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	for (void * p : ctx->owned) (void)hipFree(p);
+	if (ctx->pinned_counters) (void)hipHostFree(ctx->pinned_counters);
+	for (hipEvent_t e : ctx->stage_events) (void)hipEventDestroy(e);
+	(void)hipEventDestroy(ctx->ev_frame_start);
+	(void)hipEventDestroy(ctx->ev_frame_end);
+	(void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+// ---- scene upload ----------------------------------------------------------------------------------
+
+int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle_count, const void * bvh8_nodes, size_t node_count) {
+	RT_REQUIRE(ctx, ctx && triangles && bvh8_nodes, "rt_upload_geometry: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	int s = upload(ctx, &ctx->triangles, triangles, triangle_count * 96); if (s) return s;
+	s = upload(ctx, &ctx->bvh8_nodes, bvh8_nodes, node_count * 80); if (s) return s;
+	ctx->triangle_count = triangle_count; ctx->bvh8_node_count = node_count;
+	ctx->params.triangles  = (const float4 *)ctx->triangles;
+	ctx->params.bvh8_nodes = (const float4 *)ctx->bvh8_nodes;
+	return RT_OK;
+}
+
+int rt_upload_tlas(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count) {
+	RT_REQUIRE(ctx, ctx && tlas_nodes, "rt_upload_tlas: NULL argument");
+	RT_REQUIRE(ctx, ctx->bvh8_nodes && tlas_node_count <= ctx->bvh8_node_count, "rt_upload_tlas: geometry not uploaded or TLAS larger than the node array");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, hipMemcpyAsync(ctx->bvh8_nodes, tlas_nodes, tlas_node_count * 80, hipMemcpyHostToDevice, ctx->stream));
+	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return RT_OK;
+}
+
+int rt_upload_geometry_bvh2(rt_context * ctx, const void * triangles, size_t triangle_count, const void * bvh2_nodes, size_t node_count) {
+	RT_REQUIRE(ctx, ctx && triangles && bvh2_nodes, "rt_upload_geometry_bvh2: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	int s = upload(ctx, &ctx->triangles, triangles, triangle_count * 96); if (s) return s;
+	s = upload(ctx, &ctx->bvh2_nodes, bvh2_nodes, node_count * 32); if (s) return s;
+	ctx->triangle_count = triangle_count; ctx->bvh2_node_count = node_count;
+	ctx->params.triangles  = (const float4 *)ctx->triangles;
+	ctx->params.bvh2_nodes = (const float4 *)ctx->bvh2_nodes;
+	return RT_OK;
+}
+
+int rt_upload_tlas_bvh2(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count) {
+	RT_REQUIRE(ctx, ctx && tlas_nodes, "rt_upload_tlas_bvh2: NULL argument");
+	RT_REQUIRE(ctx, ctx->bvh2_nodes && tlas_node_count <= ctx->bvh2_node_count, "rt_upload_tlas_bvh2: geometry not uploaded or TLAS larger than the node array");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, hipMemcpy(ctx->bvh2_nodes, tlas_nodes, tlas_node_count * 32, hipMemcpyHostToDevice));
+	return RT_OK;
+}
+
+int rt_set_bvh_type(rt_context * ctx, int bvh_width) {
+	RT_REQUIRE(ctx, ctx, "rt_set_bvh_type: NULL context");
+	if (bvh_width != 8) return fail(ctx, RT_ERROR_INVALID_ARG, "rt_set_bvh_type: only the 8-wide CWBVH kernels exist on the device (got %d); the binary BVH is a CPU-oracle configuration", bvh_width);
+	ctx->bvh_width = bvh_width;
+	return RT_OK;
+}
+
+int rt_upload_instances(rt_context * ctx, const int32_t * root_indices, const int32_t * material_ids,
+                        const float * transforms, const float * transforms_inv, const float * transforms_prev, size_t mesh_count) {
+	RT_REQUIRE(ctx, ctx && root_indices && material_ids && transforms && transforms_inv && transforms_prev, "rt_upload_instances: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	const void * src[5] = { root_indices, material_ids, transforms, transforms_inv, transforms_prev };
+	size_t bytes[5] = { mesh_count * 4, mesh_count * 4, mesh_count * 48, mesh_count * 48, mesh_count * 48 };
+	for (int i = 0; i < 5; i++) { int s = upload(ctx, &ctx->instances[i], src[i], bytes[i]); if (s) return s; }
+	ctx->mesh_count = mesh_count;
+	ctx->params.mesh_bvh_root_indices = (const int *)ctx->instances[0];
+	ctx->params.mesh_material_ids     = (const int *)ctx->instances[1];
+	ctx->params.mesh_transforms       = (const float4 *)ctx->instances[2];
+	ctx->params.mesh_transforms_inv   = (const float4 *)ctx->instances[3];
+	ctx->params.mesh_transforms_prev  = (const float4 *)ctx->instances[4];
+	return RT_OK;
+}
+
+int rt_upload_materials(rt_context * ctx, const uint8_t * types, const void * materials, size_t count) {
+	RT_REQUIRE(ctx, ctx && types && materials, "rt_upload_materials: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	int s = upload(ctx, &ctx->material_types, types, count); if (s) return s;
+	s = upload(ctx, &ctx->materials, materials, count * 32); if (s) return s;
+	ctx->params.material_types = (const uint8_t *)ctx->material_types;
+	ctx->params.materials      = (const float4 *)ctx->materials;
+
+	// Scene::check_materials (Scene.cpp:50-70): which material kernels have to run at all
+	for (bool & h : ctx->has_material) h = false;
+	ctx->has_lights = false;
+	const float * m = (const float *)materials;
+	for (size_t i = 0; i < count; i++) {
+		switch (types[i]) {
+			case RT_MATERIAL_DIFFUSE:    ctx->has_material[0] = true; break;
+			case RT_MATERIAL_PLASTIC:    ctx->has_material[1] = true; break;
+			case RT_MATERIAL_DIELECTRIC: ctx->has_material[2] = true; break;
+			case RT_MATERIAL_CONDUCTOR:  ctx->has_material[3] = true; break;
+			case RT_MATERIAL_LIGHT:      ctx->has_lights |= (m[8 * i] * m[8 * i] + m[8 * i + 1] * m[8 * i + 1] + m[8 * i + 2] * m[8 * i + 2]) > 0.0f; break;
+			default: return fail(ctx, RT_ERROR_INVALID_ARG, "rt_upload_materials: unknown material type %d at index %zu", int(types[i]), i);
+		}
+	}
+	return RT_OK;
+}
+
+int rt_upload_media(rt_context * ctx, const void * media, size_t count) {
+	RT_REQUIRE(ctx, ctx && (media || count == 0), "rt_upload_media: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	int s = upload(ctx, &ctx->media, media, count * 32); if (s) return s;
+	ctx->params.media = (const float4 *)ctx->media;
+	return RT_OK;
+}
+
+int rt_upload_textures(rt_context * ctx, const rt_texture_desc * descs, size_t count) {
+	RT_REQUIRE(ctx, ctx && (descs || count == 0), "rt_upload_textures: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	for (void * p : ctx->texture_data) device_free(ctx, p);
+	ctx->texture_data.clear();
+	std::vector<RtTexture> table(count);
+	for (size_t i = 0; i < count; i++) {
+		const rt_texture_desc & d = descs[i];
+		RT_REQUIRE(ctx, d.texels && d.width > 0 && d.height > 0 && d.mip_levels > 0, "rt_upload_textures: invalid texture descriptor");
+		size_t texels = 0;
+		for (int l = 0; l < d.mip_levels; l++) { int w = d.width >> l; if (w < 1) w = 1; int h = d.height >> l; if (h < 1) h = 1; texels += size_t(w) * h; }
+		void * dev = nullptr;
+		int s = upload(ctx, &dev, d.texels, texels * 4); if (s) return s;
+		ctx->texture_data.push_back(dev);
+		table[i].texels = (const uchar4 *)dev;
+		table[i].width = d.width; table[i].height = d.height; table[i].mip_levels = d.mip_levels;
+		table[i].lod_bias = 0.5f * log2f(float(d.width * d.height)); // Integrator.cpp:95
+	}
+	int s = upload(ctx, &ctx->texture_table, table.data(), count * sizeof(RtTexture)); if (s) return s;
+	ctx->params.textures = (const RtTexture *)ctx->texture_table;
+	return RT_OK;
+}
+
+int rt_upload_lights(rt_context * ctx,
+                     const int32_t * light_triangle_indices, const float * light_triangle_cumulative_probability, size_t light_triangle_count,
+                     const float * light_mesh_cumulative_probability, const int32_t * light_mesh_triangle_span,
+                     const int32_t * light_mesh_transform_indices, size_t light_mesh_count, float lights_total_weight) {
+	RT_REQUIRE(ctx, ctx, "rt_upload_lights: NULL context");
+	(void)hipSetDevice(ctx->device);
+	const void * src[5] = { light_triangle_indices, light_triangle_cumulative_probability, light_mesh_cumulative_probability, light_mesh_triangle_span, light_mesh_transform_indices };
+	size_t bytes[5] = { light_triangle_count * 4, light_triangle_count * 4, light_mesh_count * 4, light_mesh_count * 8, light_mesh_count * 4 };
+	for (int i = 0; i < 5; i++) { int s = upload(ctx, &ctx->lights[i], src[i], src[i] ? bytes[i] : 0); if (s) return s; }
+	ctx->params.light_triangle_indices                = (const int *)ctx->lights[0];
+	ctx->params.light_triangle_cumulative_probability = (const float *)ctx->lights[1];
+	ctx->params.light_mesh_cumulative_probability     = (const float *)ctx->lights[2];
+	ctx->params.light_mesh_triangle_span              = (const int2 *)ctx->lights[3];
+	ctx->params.light_mesh_transform_indices          = (const int *)ctx->lights[4];
+	ctx->params.light_mesh_count    = int(light_mesh_count);
+	ctx->params.lights_total_weight = lights_total_weight;
+	return RT_OK;
+}
+
+static int ensure_luts(rt_context * ctx); // needs the RNG tables
+
+int rt_upload_rng(rt_context * ctx, const float * pmj_samples, const uint8_t * blue_noise) {
+	RT_REQUIRE(ctx, ctx && pmj_samples && blue_noise, "rt_upload_rng: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	int s = upload(ctx, &ctx->pmj, pmj_samples, size_t(RT_PMJ_NUM_SEQUENCES) * RT_PMJ_NUM_SAMPLES_PER_SEQUENCE * 8); if (s) return s;
+	s = upload(ctx, &ctx->blue_noise, blue_noise, size_t(RT_BLUE_NOISE_NUM_TEXTURES) * RT_BLUE_NOISE_TEXTURE_DIM * RT_BLUE_NOISE_TEXTURE_DIM * 2); if (s) return s;
+	ctx->params.pmj_samples = (const float2 *)ctx->pmj;
+	ctx->params.blue_noise  = (const uchar2 *)ctx->blue_noise;
+	ctx->luts_ready = false;
+	return RT_OK;
+}
+
+int rt_set_sky(rt_context * ctx, const float * rgba, int width, int height, float scale) {
+	RT_REQUIRE(ctx, ctx && rgba && width > 0 && height > 0, "rt_set_sky: invalid argument");
+	(void)hipSetDevice(ctx->device);
+	int s = upload(ctx, &ctx->sky, rgba, size_t(width) * height * 16); if (s) return s;
+	ctx->params.sky = (const float4 *)ctx->sky;
+	ctx->params.sky_width = width; ctx->params.sky_height = height; ctx->params.sky_scale = scale;
+	return RT_OK;
+}
+
+// ---- frame state ---------------------------------------------------------------------------------------
+
+static int alloc_vec3(rt_context * ctx, RtVec3SoA & v, size_t n) {
+	int s = device_alloc(ctx, (void **)&v.x, n * 4); if (s) return s;
+	s = device_alloc(ctx, (void **)&v.y, n * 4); if (s) return s;
+	return device_alloc(ctx, (void **)&v.z, n * 4);
+}
+
+static int ensure_queues(rt_context * ctx) {
+	if (ctx->queues_allocated) return RT_OK;
+	size_t n = RT_BATCH_SIZE;
+	int s;
+	for (int i = 0; i < 2; i++) {
+		RtTraceBuffer & t = ctx->params.trace[i];
+		if ((s = alloc_vec3(ctx, t.origin, n))) return s;
+		if ((s = alloc_vec3(ctx, t.direction, n))) return s;
+		if ((s = device_alloc(ctx, (void **)&t.hits, n * 16))) return s;
+		if ((s = device_alloc(ctx, (void **)&t.cone_angle, n * 4))) return s;
+		if ((s = device_alloc(ctx, (void **)&t.cone_width, n * 4))) return s;
+		if ((s = device_alloc(ctx, (void **)&t.medium, n * 4))) return s;
+		if ((s = device_alloc(ctx, (void **)&t.pixel_index_and_flags, n * 4))) return s;
+		if ((s = alloc_vec3(ctx, t.throughput, n))) return s;
+		if ((s = device_alloc(ctx, (void **)&t.last_pdf, n * 4))) return s;
+	}
+	for (int i = 0; i < 4; i++) {
+		RtMaterialBuffer & m = ctx->params.material[i];
+		if ((s = alloc_vec3(ctx, m.direction, n))) return s;
+		if ((s = device_alloc(ctx, (void **)&m.hits, n * 16))) return s;
+		if ((s = device_alloc(ctx, (void **)&m.cone_angle, n * 4))) return s;
+		if ((s = device_alloc(ctx, (void **)&m.cone_width, n * 4))) return s;
+		if ((s = device_alloc(ctx, (void **)&m.medium, n * 4))) return s;
+		if ((s = device_alloc(ctx, (void **)&m.pixel_index_and_flags, n * 4))) return s;
+		if ((s = alloc_vec3(ctx, m.throughput, n))) return s;
+	}
+	RtShadowBuffer & sh = ctx->params.shadow;
+	if ((s = alloc_vec3(ctx, sh.origin, n))) return s;
+	if ((s = alloc_vec3(ctx, sh.direction, n))) return s;
+	if ((s = device_alloc(ctx, (void **)&sh.max_distance, n * 4))) return s;
+	if ((s = device_alloc(ctx, (void **)&sh.illumination_and_pixel_index, n * 16))) return s;
+	ctx->queues_allocated = true;
+	return RT_OK;
+}
+
+static int sync_aovs(rt_context * ctx) {
+	size_t bytes = ctx->frame_pixels * 16;
+	for (int i = 0; i < RT_AOV_COUNT; i++) {
+		bool enabled = (ctx->params.config.aov_mask >> i) & 1u;
+		bool allocated = ctx->aov_buffers[i][0] != nullptr;
+		if (enabled && !allocated && bytes) {
+			for (int k = 0; k < 2; k++) {
+				int s = device_alloc(ctx, &ctx->aov_buffers[i][k], bytes); if (s) return s;
+				RT_HIP(ctx, hipMemsetAsync(ctx->aov_buffers[i][k], 0, bytes, ctx->stream));
+			}
+		} else if (!enabled && allocated) {
+			RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			for (int k = 0; k < 2; k++) { device_free(ctx, ctx->aov_buffers[i][k]); ctx->aov_buffers[i][k] = nullptr; }
+		}
+		ctx->params.aovs[i].framebuffer = (float4 *)ctx->aov_buffers[i][0];
+		ctx->params.aovs[i].accumulator = (float4 *)ctx->aov_buffers[i][1];
+	}
+	return RT_OK;
+}
+
+static int sync_svgf(rt_context * ctx) {
+	bool want = ctx->params.config.enable_svgf != 0;
+	if (want == ctx->svgf_allocated || ctx->frame_pixels == 0) return RT_OK;
+	if (want) {
+		// gbuffers (float4, int2, float2), moment, history x5 (length is int), taa x2, scratch
+		const size_t elem[12] = { 16, 8, 8, 16, 4, 16, 16, 16, 16, 16, 16, 16 };
+		for (int i = 0; i < 12; i++) {
+			int s = device_alloc(ctx, &ctx->svgf_buffers[i], ctx->frame_pixels * elem[i]); if (s) return s;
+			RT_HIP(ctx, hipMemsetAsync(ctx->svgf_buffers[i], 0, ctx->frame_pixels * elem[i], ctx->stream));
+		}
+	} else {
+		RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		for (int i = 0; i < 12; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
+	}
+	ctx->svgf_allocated = want;
+	RtParams & p = ctx->params;
+	p.gbuffer_normal_and_depth        = (float4 *)ctx->svgf_buffers[0];
+	p.gbuffer_mesh_id_and_triangle_id = (int2   *)ctx->svgf_buffers[1];
+	p.gbuffer_screen_position_prev    = (float2 *)ctx->svgf_buffers[2];
+	p.frame_buffer_moment             = (float4 *)ctx->svgf_buffers[3];
+	p.history_length                  = (int    *)ctx->svgf_buffers[4];
+	p.history_direct                  = (float4 *)ctx->svgf_buffers[5];
+	p.history_indirect                = (float4 *)ctx->svgf_buffers[6];
+	p.history_moment                  = (float4 *)ctx->svgf_buffers[7];
+	p.history_normal_and_depth        = (float4 *)ctx->svgf_buffers[8];
+	p.taa_frame_prev                  = (float4 *)ctx->svgf_buffers[9];
+	p.taa_frame_curr                  = (float4 *)ctx->svgf_buffers[10];
+	p.taa_scratch                     = (float4 *)ctx->svgf_buffers[11];
+	return RT_OK;
+}
+
+int rt_resize(rt_context * ctx, int width, int height) {
+	RT_REQUIRE(ctx, ctx && width > 0 && height > 0, "rt_resize: invalid size");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	int pitch = (width + 31) / 32 * 32; // Math::round_up(width, WARP_SIZE), Pathtracer.cpp:258
+	ctx->params.screen_width = width; ctx->params.screen_height = height; ctx->params.screen_pitch = pitch;
+	ctx->frame_pixels = size_t(pitch) * height;
+
+	for (int i = 0; i < RT_AOV_COUNT; i++) for (int k = 0; k < 2; k++) { device_free(ctx, ctx->aov_buffers[i][k]); ctx->aov_buffers[i][k] = nullptr; }
+	for (int i = 0; i < 12; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
+	ctx->svgf_allocated = false;
+	device_free(ctx, ctx->final_image); ctx->final_image = nullptr;
+	int s = device_alloc(ctx, &ctx->final_image, ctx->frame_pixels * 16); if (s) return s;
+	RT_HIP(ctx, hipMemsetAsync(ctx->final_image, 0, ctx->frame_pixels * 16, ctx->stream));
+	ctx->params.final_image = (float4 *)ctx->final_image;
+	if ((s = sync_aovs(ctx))) return s;
+	if ((s = sync_svgf(ctx))) return s;
+	return RT_OK;
+}
+
+int rt_set_camera(rt_context * ctx, const rt_camera * camera) {
+	RT_REQUIRE(ctx, ctx && camera, "rt_set_camera: NULL argument");
+	ctx->params.camera = *camera;
+	return RT_OK;
+}
+
+int rt_set_svgf_matrices(rt_context * ctx, const float * view_projection, const float * view_projection_prev) {
+	RT_REQUIRE(ctx, ctx && view_projection && view_projection_prev, "rt_set_svgf_matrices: NULL argument");
+	memcpy(ctx->params.view_projection,      view_projection,      64);
+	memcpy(ctx->params.view_projection_prev, view_projection_prev, 64);
+	return RT_OK;
+}
+
+int rt_set_config(rt_context * ctx, const rt_gpu_config * config) {
+	RT_REQUIRE(ctx, ctx && config, "rt_set_config: NULL argument");
+	RT_REQUIRE(ctx, config->num_bounces >= 0 && config->num_bounces <= RT_MAX_BOUNCES, "rt_set_config: num_bounces out of range");
+	RT_REQUIRE(ctx, config->num_atrous_iterations >= 0 && config->num_atrous_iterations <= RT_MAX_ATROUS_ITERATIONS, "rt_set_config: num_atrous_iterations out of range");
+	(void)hipSetDevice(ctx->device);
+	ctx->params.config = *config;
+	ctx->params.config.aov_mask |= 1u << RT_AOV_RADIANCE;
+	if (config->enable_svgf) ctx->params.config.aov_mask |= (1u << RT_AOV_RADIANCE_DIRECT) | (1u << RT_AOV_RADIANCE_INDIRECT) | (1u << RT_AOV_ALBEDO);
+	int s = sync_aovs(ctx); if (s) return s;
+	return sync_svgf(ctx);
+}
+
+int rt_set_pixel_range(rt_context * ctx, int pixel_offset, int pixel_count) {
+	RT_REQUIRE(ctx, ctx && pixel_offset >= 0, "rt_set_pixel_range: invalid argument");
+	ctx->pixel_offset = pixel_offset;
+	ctx->pixel_count  = pixel_count;
+	return RT_OK;
+}
+
+int rt_set_profiling(rt_context * ctx, int enable) {
+	RT_REQUIRE(ctx, ctx, "rt_set_profiling: NULL context");
+	ctx->profiling = enable != 0;
+	return RT_OK;
+}
+
+// ---- render ------------------------------------------------------------------------------------------------
+
+static int ensure_luts(rt_context * ctx) {
+	if (ctx->luts_ready) return RT_OK;
+	const size_t bytes[6] = { 4096 * 4, 4096 * 4, 256 * 4, 256 * 4, 1024 * 4, 32 * 4 };
+	for (int i = 0; i < 6; i++) if (!ctx->luts[i]) { int s = device_alloc(ctx, &ctx->luts[i], bytes[i]); if (s) return s; }
+	RtParams & p = ctx->params;
+	rt_launch_integrate_luts(p, (float *)ctx->luts[0], (float *)ctx->luts[1], (float *)ctx->luts[2], (float *)ctx->luts[3], (float *)ctx->luts[4], (float *)ctx->luts[5], ctx->stream);
+	RT_HIP(ctx, hipGetLastError());
+	p.lut_dielectric_directional_albedo_enter = (const float *)ctx->luts[0];
+	p.lut_dielectric_directional_albedo_leave = (const float *)ctx->luts[1];
+	p.lut_dielectric_albedo_enter             = (const float *)ctx->luts[2];
+	p.lut_dielectric_albedo_leave             = (const float *)ctx->luts[3];
+	p.lut_conductor_directional_albedo        = (const float *)ctx->luts[4];
+	p.lut_conductor_albedo                    = (const float *)ctx->luts[5];
+	ctx->luts_ready = true;
+	return RT_OK;
+}
+
+enum { STAGE_GENERATE = 0, STAGE_TRACE, STAGE_SORT, STAGE_SHADE, STAGE_SHADOW, STAGE_POST, STAGE_END };
+
+static void stage_mark(rt_context * ctx, int kind) {
+	if (!ctx->profiling) return;
+	if (ctx->stage_used == ctx->stage_events.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->stage_events.push_back(e); ctx->stage_kinds.push_back(0); }
+	ctx->stage_kinds[ctx->stage_used] = kind;
+	(void)hipEventRecord(ctx->stage_events[ctx->stage_used++], ctx->stream);
+}
+
+__global__ void kernel_accumulate_counters(const RtBufferSizes * sizes, int * totals) {
+	int b = threadIdx.x;
+	if (b >= RT_MAX_BOUNCES) return;
+	totals[0 * RT_MAX_BOUNCES + b] += sizes->trace[b];
+	totals[1 * RT_MAX_BOUNCES + b] += sizes->shadow[b];
+	totals[2 * RT_MAX_BOUNCES + b] += sizes->diffuse[b];
+	totals[3 * RT_MAX_BOUNCES + b] += sizes->plastic[b];
+	totals[4 * RT_MAX_BOUNCES + b] += sizes->dielectric[b];
+	totals[5 * RT_MAX_BOUNCES + b] += sizes->conductor[b];
+}
+
+int rt_render_sample(rt_context * ctx, int sample_index) {
+	RT_REQUIRE(ctx, ctx, "rt_render_sample: NULL context");
+	(void)hipSetDevice(ctx->device);
+	RtParams & p = ctx->params;
+	if (!p.triangles || !p.bvh8_nodes)   return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: geometry not uploaded");
+	if (!p.mesh_bvh_root_indices)        return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: instances not uploaded");
+	if (!p.materials)                    return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: materials not uploaded");
+	if (!p.pmj_samples || !p.blue_noise) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: RNG tables not uploaded");
+	if (!p.sky)                          return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: sky not set");
+	if (ctx->frame_pixels == 0)          return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: rt_resize was not called");
+	if (ctx->bvh_width != 8)             return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: unsupported BVH type");
+	int s = ensure_queues(ctx); if (s) return s;
+	if (ctx->has_material[2] || ctx->has_material[3]) { s = ensure_luts(ctx); if (s) return s; }
+
+	int frame_pixels = p.screen_width * p.screen_height;
+	int range_offset = ctx->pixel_offset;
+	int range_count  = ctx->pixel_count < 0 ? frame_pixels - range_offset : ctx->pixel_count;
+	if (range_offset + range_count > frame_pixels) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_sample: pixel range [%d,%d) exceeds the %d pixel frame", range_offset, range_offset + range_count, frame_pixels);
+
+	hipStream_t st = ctx->stream;
+	ctx->stage_used = 0;
+	RT_HIP(ctx, hipEventRecord(ctx->ev_frame_start, st));
+	RT_HIP(ctx, hipMemsetAsync(ctx->counter_totals, 0, 6 * RT_MAX_BOUNCES * sizeof(int), st));
+
+	int pixels_left = range_count;
+	int batch_size  = range_count < RT_BATCH_SIZE ? range_count : RT_BATCH_SIZE;
+	bool trace_shadows = ctx->has_lights && p.config.enable_next_event_estimation && p.lights_total_weight > 0.0f;
+
+	while (pixels_left > 0) {
+		int pixel_offset = range_offset + (range_count - pixels_left);
+		int pixel_count  = batch_size < pixels_left ? batch_size : pixels_left;
+
+		RT_HIP(ctx, hipMemsetAsync(ctx->sizes, 0, sizeof(RtBufferSizes), st));
+		stage_mark(ctx, STAGE_GENERATE);
+		rt_launch_generate(p, sample_index, pixel_offset, pixel_count, st);
+
+		for (int bounce = 0; bounce < p.config.num_bounces; bounce++) {
+			stage_mark(ctx, STAGE_TRACE);
+			rt_launch_trace(p, bounce, st);
+			stage_mark(ctx, STAGE_SORT);
+			rt_launch_sort(p, bounce, sample_index, st);
+			stage_mark(ctx, STAGE_SHADE);
+			for (int m = 0; m < 4; m++) if (ctx->has_material[m]) rt_launch_material(p, m, bounce, sample_index, st);
+			if (trace_shadows) {
+				stage_mark(ctx, STAGE_SHADOW);
+				rt_launch_trace_shadow(p, bounce, st);
+			}
+		}
+		hipLaunchKernelGGL(kernel_accumulate_counters, dim3(1), dim3(RT_MAX_BOUNCES), 0, st, ctx->sizes, ctx->counter_totals);
+		pixels_left -= batch_size;
+	}
+
+	stage_mark(ctx, STAGE_POST);
+	if (p.config.enable_svgf) rt_launch_svgf_taa(p, sample_index, st);
+	else rt_launch_accumulate(p, float(sample_index), range_offset, range_count, st);
+	stage_mark(ctx, STAGE_END);
+
+	// aovs_clear_to_zero (Integrator.cpp:379-385)
+	for (int i = 0; i < RT_AOV_COUNT; i++) if (ctx->aov_buffers[i][0]) RT_HIP(ctx, hipMemsetAsync(ctx->aov_buffers[i][0], 0, ctx->frame_pixels * 16, st));
+
+	RT_HIP(ctx, hipMemcpyAsync(ctx->pinned_counters, ctx->counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int), hipMemcpyDeviceToHost, st));
+	RT_HIP(ctx, hipEventRecord(ctx->ev_frame_end, st));
+	RT_HIP(ctx, hipGetLastError());
+	return RT_OK;
+}
+
+int rt_synchronize(rt_context * ctx) {
+	RT_REQUIRE(ctx, ctx, "rt_synchronize: NULL context");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return RT_OK;
+}
+
+int rt_get_counters(rt_context * ctx, rt_counters * out) {
+	RT_REQUIRE(ctx, ctx && out, "rt_get_counters: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	rt_counters c; memset(&c, 0, sizeof(c));
+	const int * totals = (const int *)ctx->pinned_counters;
+	memcpy(c.trace,      totals + 0 * RT_MAX_BOUNCES, sizeof(c.trace));
+	memcpy(c.shadow,     totals + 1 * RT_MAX_BOUNCES, sizeof(c.shadow));
+	memcpy(c.diffuse,    totals + 2 * RT_MAX_BOUNCES, sizeof(c.diffuse));
+	memcpy(c.plastic,    totals + 3 * RT_MAX_BOUNCES, sizeof(c.plastic));
+	memcpy(c.dielectric, totals + 4 * RT_MAX_BOUNCES, sizeof(c.dielectric));
+	memcpy(c.conductor,  totals + 5 * RT_MAX_BOUNCES, sizeof(c.conductor));
+	float ms = 0.0f;
+	if (hipEventElapsedTime(&ms, ctx->ev_frame_start, ctx->ev_frame_end) == hipSuccess) c.ms_total = ms;
+	if (ctx->profiling) {
+		float * bucket[STAGE_END] = { &c.ms_generate, &c.ms_trace, &c.ms_sort, &c.ms_shade, &c.ms_shadow, &c.ms_post };
+		for (size_t i = 0; i + 1 < ctx->stage_used; i++) {
+			float d = 0.0f;
+			if (hipEventElapsedTime(&d, ctx->stage_events[i], ctx->stage_events[i + 1]) == hipSuccess && ctx->stage_kinds[i] < STAGE_END) *bucket[ctx->stage_kinds[i]] += d;
+		}
+	}
+	ctx->last_counters = c;
+	*out = c;
+	return RT_OK;
+}
+
+// ---- results ---------------------------------------------------------------------------------------------------
+
+int rt_read_aov(rt_context * ctx, int aov_type, float * dst, int accumulated) {
+	RT_REQUIRE(ctx, ctx && dst && aov_type >= 0 && aov_type < RT_AOV_COUNT, "rt_read_aov: invalid argument");
+	(void)hipSetDevice(ctx->device);
+	void * src = ctx->aov_buffers[aov_type][accumulated ? 1 : 0];
+	if (!src) return fail(ctx, RT_ERROR_NOT_READY, "rt_read_aov: AOV %d is not enabled", aov_type);
+	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, hipMemcpy(dst, src, ctx->frame_pixels * 16, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_read_framebuffer(rt_context * ctx, float * dst) {
+	RT_REQUIRE(ctx, ctx && dst, "rt_read_framebuffer: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->final_image) return fail(ctx, RT_ERROR_NOT_READY, "rt_read_framebuffer: rt_resize was not called");
+	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, hipMemcpy(dst, ctx->final_image, ctx->frame_pixels * 16, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_framebuffer_device_ptr(rt_context * ctx, void ** out_ptr, size_t * out_bytes) {
+	RT_REQUIRE(ctx, ctx && out_ptr && out_bytes, "rt_framebuffer_device_ptr: NULL argument");
+	if (!ctx->final_image) return fail(ctx, RT_ERROR_NOT_READY, "rt_framebuffer_device_ptr: rt_resize was not called");
+	*out_ptr = ctx->final_image;
+	*out_bytes = ctx->frame_pixels * 16;
+	return RT_OK;
+}
+
+int rt_screen_pitch(rt_context * ctx) { return ctx ? ctx->params.screen_pitch : 0; }
+
+int rt_read_luts(rt_context * ctx, float * dielectric_dir_enter, float * dielectric_dir_leave, float * dielectric_enter, float * dielectric_leave, float * conductor_dir, float * conductor) {
+	RT_REQUIRE(ctx, ctx, "rt_read_luts: NULL context");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->params.pmj_samples) return fail(ctx, RT_ERROR_NOT_READY, "rt_read_luts: RNG tables not uploaded");
+	int s = ensure_luts(ctx); if (s) return s;
+	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	float * dst[6] = { dielectric_dir_enter, dielectric_dir_leave, dielectric_enter, dielectric_leave, conductor_dir, conductor };
+	const size_t bytes[6] = { 4096 * 4, 4096 * 4, 256 * 4, 256 * 4, 1024 * 4, 32 * 4 };
+	for (int i = 0; i < 6; i++) if (dst[i]) RT_HIP(ctx, hipMemcpy(dst[i], ctx->luts[i], bytes[i], hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+// ---- kernel-level entry points ------------------------------------------------------------------------------------
+
+struct TempBuffers {
+	rt_context * ctx; std::vector<void *> ptrs;
+	explicit TempBuffers(rt_context * c) : ctx(c) { }
+	~TempBuffers() { for (void * p : ptrs) (void)hipFree(p); }
+	void * get(size_t bytes, const void * src) {
+		void * p = nullptr;
+		if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+		ptrs.push_back(p);
+		if (src && bytes && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+		return p;
+	}
+};
+
+
+
+int rt_trace_rays(rt_context * ctx, const float * ox, const float * oy, const float * oz,
+                  const float * dx, const float * dy, const float * dz, size_t ray_count,
+                  uint32_t * hits, int repeat, float * out_ms) {
+	RT_REQUIRE(ctx, ctx && ox && oy && oz && dx && dy && dz && hits, "rt_trace_rays: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->params.triangles || !ctx->params.bvh8_nodes || !ctx->params.mesh_bvh_root_indices) return fail(ctx, RT_ERROR_NOT_READY, "rt_trace_rays: geometry / instances not uploaded");
+	TempBuffers tmp(ctx);
+	size_t bytes = ray_count * 4;
+	RtVec3SoA o = { (float *)tmp.get(bytes, ox), (float *)tmp.get(bytes, oy), (float *)tmp.get(bytes, oz) };
+	RtVec3SoA d = { (float *)tmp.get(bytes, dx), (float *)tmp.get(bytes, dy), (float *)tmp.get(bytes, dz) };
+	uint4 * dev_hits = (uint4 *)tmp.get(ray_count * 16, nullptr);
+	if (!o.x || !o.y || !o.z || !d.x || !d.y || !d.z || !dev_hits) return fail(ctx, RT_ERROR_HIP, "rt_trace_rays: device allocation failed");
+
+	if (repeat < 1) repeat = 1;
+	hipEvent_t e0, e1; RT_HIP(ctx, hipEventCreate(&e0)); RT_HIP(ctx, hipEventCreate(&e1));
+	float total = 0.0f;
+	for (int r = 0; r < repeat; r++) {
+		RT_HIP(ctx, hipMemsetAsync(ctx->explicit_retired, 0, 4, ctx->stream));
+		RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+		rt_launch_trace_explicit(ctx->params, o, d, dev_hits, int(ray_count), ctx->explicit_retired, ctx->stream);
+		RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+		RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		float ms = 0.0f; RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+		total += ms;
+	}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	RT_HIP(ctx, hipGetLastError());
+	if (out_ms) *out_ms = total / float(repeat);
+	RT_HIP(ctx, hipMemcpy(hits, dev_hits, ray_count * 16, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_trace_shadow_rays(rt_context * ctx, const float * ox, const float * oy, const float * oz,
+                         const float * dx, const float * dy, const float * dz, const float * max_distance,
+                         size_t ray_count, uint8_t * occluded, int repeat, float * out_ms) {
+	RT_REQUIRE(ctx, ctx && ox && oy && oz && dx && dy && dz && max_distance && occluded, "rt_trace_shadow_rays: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->params.triangles || !ctx->params.bvh8_nodes || !ctx->params.mesh_bvh_root_indices) return fail(ctx, RT_ERROR_NOT_READY, "rt_trace_shadow_rays: geometry / instances not uploaded");
+	TempBuffers tmp(ctx);
+	size_t bytes = ray_count * 4;
+	RtVec3SoA o = { (float *)tmp.get(bytes, ox), (float *)tmp.get(bytes, oy), (float *)tmp.get(bytes, oz) };
+	RtVec3SoA d = { (float *)tmp.get(bytes, dx), (float *)tmp.get(bytes, dy), (float *)tmp.get(bytes, dz) };
+	float * dev_max = (float *)tmp.get(bytes, max_distance);
+	uint8_t * dev_occ = (uint8_t *)tmp.get(ray_count, nullptr);
+	if (!o.x || !o.y || !o.z || !d.x || !d.y || !d.z || !dev_max || !dev_occ) return fail(ctx, RT_ERROR_HIP, "rt_trace_shadow_rays: device allocation failed");
+
+	if (repeat < 1) repeat = 1;
+	hipEvent_t e0, e1; RT_HIP(ctx, hipEventCreate(&e0)); RT_HIP(ctx, hipEventCreate(&e1));
+	float total = 0.0f;
+	for (int r = 0; r < repeat; r++) {
+		RT_HIP(ctx, hipMemsetAsync(ctx->explicit_retired, 0, 4, ctx->stream));
+		RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+		rt_launch_trace_shadow_explicit(ctx->params, o, d, dev_max, dev_occ, int(ray_count), ctx->explicit_retired, ctx->stream);
+		RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+		RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		float ms = 0.0f; RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+		total += ms;
+	}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	RT_HIP(ctx, hipGetLastError());
+	if (out_ms) *out_ms = total / float(repeat);
+	RT_HIP(ctx, hipMemcpy(occluded, dev_occ, ray_count, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_generate_rays(rt_context * ctx, int sample_index, int pixel_offset, int pixel_count,
+                     float * ox, float * oy, float * oz, float * dx, float * dy, float * dz, uint32_t * pixel_index_and_flags) {
+	RT_REQUIRE(ctx, ctx && ox && oy && oz && dx && dy && dz && pixel_index_and_flags, "rt_generate_rays: NULL argument");
+	RT_REQUIRE(ctx, pixel_count >= 0 && pixel_count <= RT_BATCH_SIZE, "rt_generate_rays: pixel_count exceeds RT_BATCH_SIZE");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->params.pmj_samples || ctx->frame_pixels == 0) return fail(ctx, RT_ERROR_NOT_READY, "rt_generate_rays: RNG tables not uploaded or rt_resize not called");
+	int s = ensure_queues(ctx); if (s) return s;
+	rt_launch_generate(ctx->params, sample_index, pixel_offset, pixel_count, ctx->stream);
+	RT_HIP(ctx, hipGetLastError());
+	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const RtTraceBuffer & t = ctx->params.trace[0];
+	size_t bytes = size_t(pixel_count) * 4;
+	RT_HIP(ctx, hipMemcpy(ox, t.origin.x, bytes, hipMemcpyDeviceToHost));
+	RT_HIP(ctx, hipMemcpy(oy, t.origin.y, bytes, hipMemcpyDeviceToHost));
+	RT_HIP(ctx, hipMemcpy(oz, t.origin.z, bytes, hipMemcpyDeviceToHost));
+	RT_HIP(ctx, hipMemcpy(dx, t.direction.x, bytes, hipMemcpyDeviceToHost));
+	RT_HIP(ctx, hipMemcpy(dy, t.direction.y, bytes, hipMemcpyDeviceToHost));
+	RT_HIP(ctx, hipMemcpy(dz, t.direction.z, bytes, hipMemcpyDeviceToHost));
+	RT_HIP(ctx, hipMemcpy(pixel_index_and_flags, t.pixel_index_and_flags, bytes, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_random_samples(rt_context * ctx, int dimension, const uint32_t * pixel_indices, size_t count, uint32_t bounce, uint32_t sample_index, float * out_xy) {
+	RT_REQUIRE(ctx, ctx && pixel_indices && out_xy && dimension >= 0 && dimension < 7, "rt_random_samples: invalid argument");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->params.pmj_samples || ctx->params.screen_pitch == 0) return fail(ctx, RT_ERROR_NOT_READY, "rt_random_samples: RNG tables not uploaded or rt_resize not called");
+	TempBuffers tmp(ctx);
+	unsigned * dev_px = (unsigned *)tmp.get(count * 4, pixel_indices);
+	float2 * dev_out = (float2 *)tmp.get(count * 8, nullptr);
+	if (!dev_px || !dev_out) return fail(ctx, RT_ERROR_HIP, "rt_random_samples: device allocation failed");
+	rt_launch_random(ctx->params, dimension, dev_px, int(count), bounce, sample_index, dev_out, ctx->stream);
+	RT_HIP(ctx, hipGetLastError());
+	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, hipMemcpy(out_xy, dev_out, count * 8, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_measure_stream_bandwidth(rt_context * ctx, size_t bytes, int repeat, float * out_gbps) {
+	RT_REQUIRE(ctx, ctx && out_gbps && bytes >= 1024, "rt_measure_stream_bandwidth: invalid argument");
+	(void)hipSetDevice(ctx->device);
+	TempBuffers tmp(ctx);
+	size_t count = bytes / 16;
+	float4 * src = (float4 *)tmp.get(count * 16, nullptr);
+	float * sink = (float *)tmp.get(16, nullptr);
+	if (!src || !sink) return fail(ctx, RT_ERROR_HIP, "rt_measure_stream_bandwidth: device allocation failed");
+	RT_HIP(ctx, hipMemsetAsync(src, 0x3c, count * 16, ctx->stream));
+	if (repeat < 1) repeat = 1;
+	hipEvent_t e0, e1; RT_HIP(ctx, hipEventCreate(&e0)); RT_HIP(ctx, hipEventCreate(&e1));
+	rt_launch_stream_read(src, count, sink, ctx->stream); // warm-up
+	float best = 1e30f;
+	for (int r = 0; r < repeat; r++) {
+		RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+		rt_launch_stream_read(src, count, sink, ctx->stream);
+		RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+		RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		float ms = 0.0f; RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+		if (ms < best) best = ms;
+	}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	*out_gbps = float(double(count * 16) / (double(best) * 1e-3) / 1e9);
+	return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,93 @@
+// rt_math.h -- small device vector library. Every operator is a plain component-wise
+// IEEE fp32 operation (the translation units are built with -ffp-contract=off); a fused
+// multiply-add only happens where fmaf is written out. That makes the traversal arithmetic
+// reproducible bit for bit on the host (see DESIGN.md "arithmetic contract").
+#pragma once
+#include "rt_types.h"
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+#define RT_DEV __device__ __forceinline__
+
+RT_DEV f2 mk2(float x, float y) { return { x, y }; }
+RT_DEV f3 mk3(float x, float y, float z) { return { x, y, z }; }
+RT_DEV f3 mk3(float s) { return { s, s, s }; }
+RT_DEV f3 mk3(f4 v) { return { v.x, v.y, v.z }; }
+RT_DEV f3 mk3(float4 v) { return { v.x, v.y, v.z }; }
+RT_DEV f4 mk4(float x, float y, float z, float w) { return { x, y, z, w }; }
+RT_DEV f4 mk4(float s) { return { s, s, s, s }; }
+RT_DEV f4 mk4(f3 v) { return { v.x, v.y, v.z, 0.0f }; }
+RT_DEV f4 mk4(float4 v) { return { v.x, v.y, v.z, v.w }; }
+RT_DEV float4 to_float4(f4 v) { return make_float4(v.x, v.y, v.z, v.w); }
+RT_DEV float4 to_float4(f3 v) { return make_float4(v.x, v.y, v.z, 0.0f); }
+
+RT_DEV f2 operator+(f2 a, f2 b) { return { a.x + b.x, a.y + b.y }; }
+RT_DEV f2 operator-(f2 a, f2 b) { return { a.x - b.x, a.y - b.y }; }
+RT_DEV f2 operator*(float s, f2 a) { return { s * a.x, s * a.y }; }
+RT_DEV f2 operator*(f2 a, float s) { return { a.x * s, a.y * s }; }
+RT_DEV float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
+
+RT_DEV f3 operator-(f3 a) { return { -a.x, -a.y, -a.z }; }
+RT_DEV f3 operator+(f3 a, f3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+RT_DEV f3 operator-(f3 a, f3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+RT_DEV f3 operator*(f3 a, f3 b) { return { a.x * b.x, a.y * b.y, a.z * b.z }; }
+RT_DEV f3 operator/(f3 a, f3 b) { return { a.x / b.x, a.y / b.y, a.z / b.z }; }
+RT_DEV f3 operator*(f3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+RT_DEV f3 operator*(float s, f3 a) { return { s * a.x, s * a.y, s * a.z }; }
+RT_DEV f3 operator/(f3 a, float s) { return { a.x / s, a.y / s, a.z / s }; }
+RT_DEV f3 operator/(float s, f3 a) { return { s / a.x, s / a.y, s / a.z }; }
+RT_DEV f3 operator+(f3 a, float s) { return { a.x + s, a.y + s, a.z + s }; }
+RT_DEV f3 operator-(f3 a, float s) { return { a.x - s, a.y - s, a.z - s }; }
+RT_DEV f3 operator-(float s, f3 a) { return { s - a.x, s - a.y, s - a.z }; }
+RT_DEV f3 & operator+=(f3 & a, f3 b) { a = a + b; return a; }
+RT_DEV f3 & operator*=(f3 & a, f3 b) { a = a * b; return a; }
+RT_DEV f3 & operator*=(f3 & a, float s) { a = a * s; return a; }
+RT_DEV f3 & operator/=(f3 & a, float s) { a = a / s; return a; }
+
+RT_DEV f4 operator+(f4 a, f4 b) { return { a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w }; }
+RT_DEV f4 operator-(f4 a, f4 b) { return { a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w }; }
+RT_DEV f4 operator*(f4 a, float s) { return { a.x * s, a.y * s, a.z * s, a.w * s }; }
+RT_DEV f4 operator*(float s, f4 a) { return { s * a.x, s * a.y, s * a.z, s * a.w }; }
+RT_DEV f4 operator*(f4 a, f4 b) { return { a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w }; }
+RT_DEV f4 operator/(f4 a, float s) { return { a.x / s, a.y / s, a.z / s, a.w / s }; }
+RT_DEV f4 & operator+=(f4 & a, f4 b) { a = a + b; return a; }
+RT_DEV f4 & operator*=(f4 & a, float s) { a = a * s; return a; }
+
+RT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV f3 cross(f3 a, f3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+RT_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
+RT_DEV float length(f2 a) { return sqrtf(dot(a, a)); }
+RT_DEV f3 normalize(f3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
+RT_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+RT_DEV float saturate(float v) { return clampf(v, 0.0f, 1.0f); }
+RT_DEV float square(float x) { return x * x; }
+RT_DEV float safe_sqrt(float x) { return sqrtf(fmaxf(0.0f, x)); }
+
+// Explicitly fused forms used by traversal (arithmetic contract)
+RT_DEV float dot_fma(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+RT_DEV f3 cross_fma(f3 a, f3 b) {
+	return {
+		__builtin_fmaf(a.y, b.z, -(a.z * b.y)),
+		__builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+		__builtin_fmaf(a.x, b.y, -(a.y * b.x)) };
+}
+
+RT_DEV f3 load3(RtVec3SoA v, int i) { return { v.x[i], v.y[i], v.z[i] }; }
+RT_DEV void store3(RtVec3SoA v, int i, f3 a) { v.x[i] = a.x; v.y[i] = a.y; v.z[i] = a.z; }
+
+// ---- wave64 helpers -------------------------------------------------------------------------
+RT_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// One returning atomic per wave for all lanes that append to a queue: the active lanes are
+// ranked with mbcnt over the exec mask and the leader adds popcount(exec).
+RT_DEV int wave_aggregated_append(int * counter) {
+	unsigned long long active = __ballot(1);
+	unsigned rank  = __builtin_amdgcn_mbcnt_hi(unsigned(active >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(active), 0u));
+	int leader = __ffsll((long long)active) - 1;
+	int base = 0;
+	if (rank == 0) base = atomicAdd(counter, __popcll(active));
+	base = __shfl(base, leader);
+	return base + int(rank);
+}

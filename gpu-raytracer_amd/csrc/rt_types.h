@@ -1,0 +1,146 @@
+// rt_types.h -- device-side data layout shared by the C ABI implementation and the kernels.
+//
+// HBM layout (all buffers are plain hipMalloc'd linear memory, 16-byte aligned):
+//   triangles      float4[6 * T]   device triangle = 96 B (reference CUDA/Raytracing/Triangle.h:4-11)
+//   bvh8_nodes     float4[5 * N]   CWBVH node = 80 B        (reference CUDA/Raytracing/BVH8.h:19-25)
+//   per-instance   int[M], float4[3 * M] x3                 (reference CUDA/Raytracing/Mesh.h:29-36)
+//   ray queues     SoA, one float/uint array per component, RT_BATCH_SIZE entries each
+//                  (reference Pathtracer.cu:32-66) -- every queue access by consecutive lanes
+//                  is a fully coalesced 256 B transaction per 64-lane wave.
+//   AOVs           float4[pitch * height] framebuffer + accumulator per enabled AOV
+// Material queues: the reference packs two material types into one allocation growing from
+// both ends to save VRAM (Pathtracer.cu:73-90); with 288 GB of HBM3E each type simply gets
+// its own queue.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gpu_raytracer_amd.h"
+
+#define RT_WAVE_SIZE 64
+#define RT_INFINITY __builtin_huge_valf()
+
+struct RtVec3SoA { float * x, * y, * z; };
+
+struct RtTraceBuffer { // Pathtracer.cu:33-46
+	RtVec3SoA origin, direction;
+	uint4   * hits;
+	float   * cone_angle, * cone_width;
+	int     * medium;
+	unsigned * pixel_index_and_flags;
+	RtVec3SoA throughput;
+	float   * last_pdf;
+};
+
+struct RtMaterialBuffer { // Pathtracer.cu:49-61
+	RtVec3SoA direction;
+	uint4   * hits;
+	float   * cone_angle, * cone_width;
+	int     * medium;
+	unsigned * pixel_index_and_flags;
+	RtVec3SoA throughput;
+};
+
+struct RtShadowBuffer { // Pathtracer.cu:64-68, BVH.h:16-21
+	RtVec3SoA origin, direction;
+	float  * max_distance;
+	float4 * illumination_and_pixel_index;
+};
+
+struct RtBufferSizes { // Pathtracer.cu:103-114
+	int trace     [RT_MAX_BOUNCES];
+	int diffuse   [RT_MAX_BOUNCES];
+	int plastic   [RT_MAX_BOUNCES];
+	int dielectric[RT_MAX_BOUNCES];
+	int conductor [RT_MAX_BOUNCES];
+	int shadow    [RT_MAX_BOUNCES];
+	int rays_retired       [RT_MAX_BOUNCES];
+	int rays_retired_shadow[RT_MAX_BOUNCES];
+};
+
+struct RtTexture {
+	const uchar4 * texels;   // linear RGBA8, mip levels back to back
+	int   width, height, mip_levels;
+	float lod_bias;          // 0.5 * log2(width * height)   (Integrator.cpp:95)
+};
+
+struct RtAOV { float4 * framebuffer, * accumulator; };
+
+// Everything a kernel needs, passed BY VALUE as kernel argument (lives in the kernarg
+// segment and is read with scalar loads; no __constant__ symbols, so several contexts
+// can coexist in one process).
+struct RtParams {
+	// geometry
+	const float4 * triangles;
+	const float4 * bvh8_nodes;
+	const float4 * bvh2_nodes;  // 2 float4 per node
+	const int    * mesh_bvh_root_indices;
+	const int    * mesh_material_ids;
+	const float4 * mesh_transforms, * mesh_transforms_inv, * mesh_transforms_prev;
+	// materials
+	const uint8_t * material_types;
+	const float4  * materials;  // 2 float4 per material
+	const float4  * media;      // 2 float4 per medium
+	const RtTexture * textures;
+	// lights
+	const int   * light_triangle_indices;
+	const float * light_triangle_cumulative_probability;
+	const float * light_mesh_cumulative_probability;
+	const int2  * light_mesh_triangle_span;
+	const int   * light_mesh_transform_indices;
+	int   light_mesh_count;
+	float lights_total_weight;
+	// rng
+	const float2 * pmj_samples;
+	const uchar2 * blue_noise;
+	// sky
+	const float4 * sky;
+	int sky_width, sky_height;
+	float sky_scale;
+	// Kulla-Conty LUTs
+	const float * lut_dielectric_directional_albedo_enter, * lut_dielectric_directional_albedo_leave;
+	const float * lut_dielectric_albedo_enter, * lut_dielectric_albedo_leave;
+	const float * lut_conductor_directional_albedo, * lut_conductor_albedo;
+	// frame
+	rt_camera     camera;
+	rt_gpu_config config;
+	float view_projection[16], view_projection_prev[16];
+	int screen_width, screen_height, screen_pitch;
+	// queues
+	RtTraceBuffer    trace[2];
+	RtMaterialBuffer material[4];   // diffuse, plastic, dielectric, conductor
+	RtShadowBuffer   shadow;
+	RtBufferSizes  * sizes;
+	// outputs
+	RtAOV    aovs[RT_AOV_COUNT];
+	float4 * final_image;           // the reference's `accumulator` surface
+	// SVGF / TAA
+	float4 * gbuffer_normal_and_depth;
+	int2   * gbuffer_mesh_id_and_triangle_id;
+	float2 * gbuffer_screen_position_prev;
+	float4 * frame_buffer_moment;
+	int    * history_length;
+	float4 * history_direct, * history_indirect, * history_moment, * history_normal_and_depth;
+	float4 * taa_frame_prev, * taa_frame_curr;
+	float4 * taa_scratch;
+};
+
+#define RT_FLAG_ALLOW_NEE     (1u << 31)
+#define RT_FLAG_INSIDE_MEDIUM (1u << 30)
+#define RT_FLAGS_ALL          (RT_FLAG_ALLOW_NEE | RT_FLAG_INSIDE_MEDIUM)
+
+// Launch helpers implemented in the kernel translation units
+void rt_launch_generate(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, hipStream_t stream);
+void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream);
+void rt_launch_trace_shadow(const RtParams & p, int bounce, hipStream_t stream);
+void rt_launch_sort(const RtParams & p, int bounce, int sample_index, hipStream_t stream);
+void rt_launch_material(const RtParams & p, int material_slot, int bounce, int sample_index, hipStream_t stream);
+void rt_launch_accumulate(const RtParams & p, float frames_accumulated, int pixel_offset, int pixel_count, hipStream_t stream);
+void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream);
+void rt_launch_random(const RtParams & p, int dimension, const unsigned * pixel_indices, int count, unsigned bounce, unsigned sample_index, float2 * out, hipStream_t stream);
+void rt_launch_integrate_luts(const RtParams & p, float * dielectric_dir_enter, float * dielectric_dir_leave, float * dielectric_enter, float * dielectric_leave,
+                              float * conductor_dir, float * conductor, hipStream_t stream);
+void rt_launch_stream_read(const float4 * src, size_t count, float * sink, hipStream_t stream);
+// Stand-alone trace on explicit ray arrays (rt_trace_rays / rt_trace_shadow_rays)
+void rt_launch_trace_explicit(const RtParams & p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired_counter, hipStream_t stream);
+void rt_launch_trace_shadow_explicit(const RtParams & p, RtVec3SoA origin, RtVec3SoA direction, const float * max_distance, uint8_t * occluded, int ray_count, int * retired_counter, hipStream_t stream);

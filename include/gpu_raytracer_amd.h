@@ -183,6 +183,10 @@ int rt_set_pixel_range(rt_context * ctx, int pixel_offset, int pixel_count);
  * bounces, then accumulate or SVGF/TAA.  Asynchronous; rt_synchronize or a read waits.    */
 int rt_render_sample(rt_context * ctx, int sample_index);
 int rt_synchronize(rt_context * ctx);
+/* Per-stage HIP-event timing (ms_generate..ms_post of rt_counters) costs ~2 events per
+ * kernel launch, so it is opt-in; ms_total is always measured. Replaces the CUDAEventPool
+ * instrumentation of the reference (Pathtracer.cpp:751-843, Device/CUDAEvent.h:31-53).      */
+int rt_set_profiling(rt_context * ctx, int enable);
 /* Counters of the most recent completed rt_render_sample (synchronous).                    */
 int rt_get_counters(rt_context * ctx, rt_counters * out);
 
@@ -195,6 +199,12 @@ int rt_read_framebuffer(rt_context * ctx, float * dst);
 /* Device pointer of the final image for zero-copy consumers (RCCL gather).                 */
 int rt_framebuffer_device_ptr(rt_context * ctx, void ** out_ptr, size_t * out_bytes);
 int rt_screen_pitch(rt_context * ctx);
+
+/* Kulla-Conty LUTs as computed on the device at first use (kernel_integrate_* /
+ * kernel_average_*, CUDA/KullaConty.h:83-240): 16^3, 16^3, 16^2, 16^2, 32^2, 32 floats.
+ * Any pointer may be NULL. Synchronous.                                                     */
+int rt_read_luts(rt_context * ctx, float * dielectric_directional_enter, float * dielectric_directional_leave,
+                 float * dielectric_enter, float * dielectric_leave, float * conductor_directional, float * conductor);
 
 /* ---- kernel-level entry points (parity tests and micro-benchmarks) ----------------------*/
 /* kernel_trace_bvh8 / kernel_trace_shadow_bvh8 on caller-supplied rays (SoA host arrays).

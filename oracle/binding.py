@@ -1,0 +1,263 @@
+"""ctypes binding of liboracle.so / _ref/libref_bvh.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+It turns the host staging arrays of a gpu_raytracer_amd.Pathtracer (exactly what the device
+is given) into an ``oracle_scene`` and calls the CPU restatement on it.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_LIB_PATH = os.path.join(_HERE, "_ref", "libref_bvh.so")
+
+RT_MAX_BOUNCES = 128
+RT_AOV_COUNT = 6
+
+
+class GPUConfig(Structure):
+    _fields_ = [("reconstruction_filter", c_int32), ("aov_mask", c_uint32), ("num_bounces", c_int32),
+                ("enable_mipmapping", c_int32), ("enable_next_event_estimation", c_int32),
+                ("enable_multiple_importance_sampling", c_int32), ("enable_russian_roulette", c_int32),
+                ("enable_svgf", c_int32), ("enable_spatial_variance", c_int32), ("enable_taa", c_int32),
+                ("alpha_colour", c_float), ("alpha_moment", c_float), ("num_atrous_iterations", c_int32),
+                ("sigma_z", c_float), ("sigma_n", c_float), ("sigma_l", c_float)]
+
+
+class Camera(Structure):
+    _fields_ = [("position", c_float * 3), ("bottom_left_corner", c_float * 3), ("x_axis", c_float * 3),
+                ("y_axis", c_float * 3), ("pixel_spread_angle", c_float), ("aperture_radius", c_float),
+                ("focal_distance", c_float)]
+
+
+class OracleTexture(Structure):
+    _fields_ = [("texels", c_void_p), ("width", c_int32), ("height", c_int32), ("mip_levels", c_int32)]
+
+
+class OracleScene(Structure):
+    _fields_ = [
+        ("triangles", c_void_p), ("triangle_count", c_int32),
+        ("bvh8_nodes", c_void_p), ("bvh2_nodes", c_void_p), ("bvh_type", c_int32),
+        ("mesh_bvh_root_indices", c_void_p), ("mesh_material_ids", c_void_p),
+        ("mesh_transforms", c_void_p), ("mesh_transforms_inv", c_void_p), ("mesh_transforms_prev", c_void_p), ("mesh_count", c_int32),
+        ("material_types", c_void_p), ("materials", c_void_p), ("material_count", c_int32),
+        ("media", c_void_p), ("medium_count", c_int32),
+        ("textures", c_void_p), ("texture_count", c_int32),
+        ("light_triangle_indices", c_void_p), ("light_triangle_cumulative_probability", c_void_p), ("light_triangle_count", c_int32),
+        ("light_mesh_cumulative_probability", c_void_p), ("light_mesh_triangle_span", c_void_p), ("light_mesh_transform_indices", c_void_p),
+        ("light_mesh_count", c_int32), ("lights_total_weight", c_float),
+        ("pmj_samples", c_void_p), ("blue_noise", c_void_p),
+        ("lut_dielectric_directional_albedo_enter", c_void_p), ("lut_dielectric_directional_albedo_leave", c_void_p),
+        ("lut_dielectric_albedo_enter", c_void_p), ("lut_dielectric_albedo_leave", c_void_p),
+        ("lut_conductor_directional_albedo", c_void_p), ("lut_conductor_albedo", c_void_p),
+        ("sky", c_void_p), ("sky_width", c_int32), ("sky_height", c_int32), ("sky_scale", c_float),
+        ("camera", Camera), ("config", GPUConfig),
+        ("view_projection", c_float * 16), ("view_projection_prev", c_float * 16),
+        ("screen_width", c_int32), ("screen_height", c_int32), ("screen_pitch", c_int32),
+    ]
+
+
+class TraceStats(Structure):
+    _fields_ = [("nodes", c_uint64), ("triangles", c_uint64), ("instances_transformed", c_uint64), ("instances_identity", c_uint64), ("rays", c_uint64)]
+
+    def algorithmic_bytes(self, shadow=False):
+        """24 B ray + 16 B hit (4 B max_distance for shadow rays) + 80 B/node
+        + 48 B/triangle + 52 B per transformed instance entry + 4 B per identity entry."""
+        per_ray = 24 + (4 if shadow else 16)
+        return per_ray * self.rays + 80 * self.nodes + 48 * self.triangles + 52 * self.instances_transformed + 4 * self.instances_identity
+
+
+class OracleFrame(Structure):
+    _fields_ = [("framebuffer", c_void_p * RT_AOV_COUNT), ("accumulator", c_void_p * RT_AOV_COUNT), ("final_image", c_void_p),
+                ("gbuffer_normal_and_depth", c_void_p), ("gbuffer_mesh_id_and_triangle_id", c_void_p), ("gbuffer_screen_position_prev", c_void_p),
+                ("frame_buffer_moment", c_void_p), ("history_length", c_void_p),
+                ("history_direct", c_void_p), ("history_indirect", c_void_p), ("history_moment", c_void_p), ("history_normal_and_depth", c_void_p),
+                ("taa_frame_prev", c_void_p), ("taa_frame_curr", c_void_p), ("scratch_direct", c_void_p), ("scratch_indirect", c_void_p)]
+
+
+class OracleCounters(Structure):
+    _fields_ = [("trace", c_int32 * RT_MAX_BOUNCES), ("shadow", c_int32 * RT_MAX_BOUNCES),
+                ("diffuse", c_int32 * RT_MAX_BOUNCES), ("plastic", c_int32 * RT_MAX_BOUNCES),
+                ("dielectric", c_int32 * RT_MAX_BOUNCES), ("conductor", c_int32 * RT_MAX_BOUNCES),
+                ("trace_stats", TraceStats), ("shadow_stats", TraceStats)]
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_LIB_PATH):
+            raise RuntimeError("%s missing: run `make -C oracle` (build() does)" % ORACLE_LIB_PATH)
+        l = ctypes.CDLL(ORACLE_LIB_PATH)
+        l.oracle_trace.argtypes = [POINTER(OracleScene)] + [c_void_p] * 6 + [c_size_t, c_void_p, POINTER(TraceStats), c_int]
+        l.oracle_trace_shadow.argtypes = [POINTER(OracleScene)] + [c_void_p] * 7 + [c_size_t, c_void_p, POINTER(TraceStats), c_int]
+        l.oracle_generate.argtypes = [POINTER(OracleScene), c_int, c_int, c_int] + [c_void_p] * 7
+        l.oracle_random.argtypes = [POINTER(OracleScene), c_int, c_void_p, c_size_t, c_uint32, c_uint32, c_void_p]
+        l.oracle_render_sample.argtypes = [POINTER(OracleScene), POINTER(OracleFrame), c_int, c_int, c_int, POINTER(OracleCounters), c_int]
+        _lib = l
+    return _lib
+
+
+def ref_lib():
+    """The reference's own BVH builder (oracle/_ref), or None where it has not been built."""
+    global _ref
+    if _ref is None and os.path.exists(REF_LIB_PATH):
+        r = ctypes.CDLL(REF_LIB_PATH)
+        r.ref_bvh_build_triangles.restype = c_void_p
+        r.ref_bvh_build_triangles.argtypes = [c_void_p, c_int]
+        r.ref_bvh_build_meshes.restype = c_void_p
+        r.ref_bvh_build_meshes.argtypes = [c_void_p, c_int]
+        for f in ("ref_bvh2_node_count", "ref_bvh2_index_count", "ref_bvh8_node_count", "ref_bvh8_index_count", "ref_bvh_free"):
+            getattr(r, f).argtypes = [c_void_p]
+        for f in ("ref_bvh2_copy_nodes", "ref_bvh2_copy_indices", "ref_bvh8_copy_nodes", "ref_bvh8_copy_indices"):
+            getattr(r, f).argtypes = [c_void_p, c_void_p]
+        for f in ("ref_bvh_ms_bvh2", "ref_bvh_ms_bvh8"):
+            getattr(r, f).argtypes = [c_void_p]
+            getattr(r, f).restype = ctypes.c_double
+        _ref = r
+    return _ref
+
+
+def ref_build(tris24):
+    """Reference BVH2 + BVH8 over (n,24) float32 triangles -> dict of byte/int arrays + timings."""
+    r = ref_lib()
+    t = np.ascontiguousarray(tris24, dtype=np.float32)
+    n = t.size // 24
+    h = r.ref_bvh_build_triangles(t.ctypes.data, n)
+    out = {}
+    n2, n8 = r.ref_bvh2_node_count(h), r.ref_bvh8_node_count(h)
+    out["bvh2_nodes"] = np.zeros(n2 * 32, np.uint8); r.ref_bvh2_copy_nodes(h, out["bvh2_nodes"].ctypes.data)
+    out["bvh8_nodes"] = np.zeros(n8 * 80, np.uint8); r.ref_bvh8_copy_nodes(h, out["bvh8_nodes"].ctypes.data)
+    out["bvh2_indices"] = np.zeros(r.ref_bvh2_index_count(h), np.int32); r.ref_bvh2_copy_indices(h, out["bvh2_indices"].ctypes.data)
+    out["bvh8_indices"] = np.zeros(r.ref_bvh8_index_count(h), np.int32); r.ref_bvh8_copy_indices(h, out["bvh8_indices"].ctypes.data)
+    out["ms_bvh2"], out["ms_bvh8"] = r.ref_bvh_ms_bvh2(h), r.ref_bvh_ms_bvh8(h)
+    r.ref_bvh_free(h)
+    return out
+
+
+class SceneView:
+    """Keeps the numpy arrays alive that an OracleScene points into."""
+
+    def __init__(self, pathtracer, bvh_type=8, luts=None):
+        pt = pathtracer
+        self.keep = {}
+        s = OracleScene()
+
+        def arr(name):
+            a = pt.array(name)
+            self.keep[name] = a
+            return a.ctypes.data if a.size else None
+
+        s.triangles = arr("triangles"); s.triangle_count = self.keep["triangles"].size // 24
+        s.bvh8_nodes = arr("bvh8_nodes"); s.bvh2_nodes = arr("bvh2_nodes"); s.bvh_type = bvh_type
+        s.mesh_bvh_root_indices = arr("mesh_bvh_root_indices"); s.mesh_material_ids = arr("mesh_material_ids")
+        s.mesh_transforms = arr("mesh_transforms"); s.mesh_transforms_inv = arr("mesh_transforms_inv"); s.mesh_transforms_prev = arr("mesh_transforms_prev")
+        s.mesh_count = self.keep["mesh_material_ids"].size
+        s.material_types = arr("material_types"); s.materials = arr("materials"); s.material_count = self.keep["material_types"].size
+        s.media = arr("media"); s.medium_count = self.keep["media"].size // 8
+
+        tex = pt.textures()
+        self.keep["tex"] = tex
+        table = (OracleTexture * max(len(tex), 1))()
+        for i, (texels, w, h, levels) in enumerate(tex):
+            table[i].texels = texels.ctypes.data; table[i].width = w; table[i].height = h; table[i].mip_levels = levels
+        self.keep["tex_table"] = table
+        s.textures = ctypes.cast(table, c_void_p); s.texture_count = len(tex)
+
+        s.light_triangle_indices = arr("light_triangle_indices"); s.light_triangle_cumulative_probability = arr("light_triangle_cumulative_probability")
+        s.light_triangle_count = self.keep["light_triangle_indices"].size
+        s.light_mesh_cumulative_probability = arr("light_mesh_cumulative_probability"); s.light_mesh_triangle_span = arr("light_mesh_triangle_span")
+        s.light_mesh_transform_indices = arr("light_mesh_transform_indices"); s.light_mesh_count = self.keep["light_mesh_transform_indices"].size
+        s.lights_total_weight = pt.lights_total_weight
+        s.pmj_samples = arr("pmj_samples"); s.blue_noise = arr("blue_noise")
+
+        if luts is not None:
+            self.keep["luts"] = [np.ascontiguousarray(l, dtype=np.float32) for l in luts]
+            (s.lut_dielectric_directional_albedo_enter, s.lut_dielectric_directional_albedo_leave, s.lut_dielectric_albedo_enter,
+             s.lut_dielectric_albedo_leave, s.lut_conductor_directional_albedo, s.lut_conductor_albedo) = [l.ctypes.data for l in self.keep["luts"]]
+
+        sky, w, h, scale = pt.sky()
+        self.keep["sky"] = sky
+        s.sky = sky.ctypes.data; s.sky_width = w; s.sky_height = h; s.sky_scale = scale
+
+        cam = pt.camera()
+        ctypes.memmove(byref(s.camera), byref(cam), ctypes.sizeof(cam))
+        cfg = pt.device_config()
+        ctypes.memmove(byref(s.config), byref(cfg), ctypes.sizeof(cfg))
+        s.config.aov_mask |= 1
+        s.screen_width = pt.width; s.screen_height = pt.height; s.screen_pitch = pt.pitch
+        self.scene = s
+
+    def trace(self, origin, direction, threads=0):
+        o = np.ascontiguousarray(origin, np.float32); d = np.ascontiguousarray(direction, np.float32)
+        n = o.shape[1]
+        hits = np.zeros((n, 4), np.uint32)
+        stats = TraceStats()
+        lib().oracle_trace(byref(self.scene), o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data, d[0].ctypes.data, d[1].ctypes.data, d[2].ctypes.data, n, hits.ctypes.data, byref(stats), threads)
+        return hits, stats
+
+    def trace_shadow(self, origin, direction, max_distance, threads=0):
+        o = np.ascontiguousarray(origin, np.float32); d = np.ascontiguousarray(direction, np.float32); m = np.ascontiguousarray(max_distance, np.float32)
+        n = o.shape[1]
+        occ = np.zeros(n, np.uint8)
+        stats = TraceStats()
+        lib().oracle_trace_shadow(byref(self.scene), o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data, d[0].ctypes.data, d[1].ctypes.data, d[2].ctypes.data, m.ctypes.data, n, occ.ctypes.data, byref(stats), threads)
+        return occ, stats
+
+    def generate(self, sample_index, pixel_offset, pixel_count):
+        o = np.zeros((3, pixel_count), np.float32); d = np.zeros((3, pixel_count), np.float32); px = np.zeros(pixel_count, np.uint32)
+        lib().oracle_generate(byref(self.scene), sample_index, pixel_offset, pixel_count, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data, d[0].ctypes.data, d[1].ctypes.data, d[2].ctypes.data, px.ctypes.data)
+        return o, d, px
+
+    def random(self, dimension, pixel_indices, bounce, sample_index):
+        px = np.ascontiguousarray(pixel_indices, np.uint32)
+        out = np.zeros((px.size, 2), np.float32)
+        lib().oracle_random(byref(self.scene), dimension, px.ctypes.data, px.size, bounce, sample_index, out.ctypes.data)
+        return out
+
+
+class Frame:
+    """AOV + SVGF state for oracle_render_sample, zero-initialised (the device memsets too)."""
+
+    def __init__(self, view):
+        s = view.scene
+        n = s.screen_pitch * s.screen_height
+        self.view = view
+        self.f = OracleFrame()
+        self.buffers = {}
+        mask = s.config.aov_mask
+        if s.config.enable_svgf:
+            mask |= 0b1110
+        for i in range(RT_AOV_COUNT):
+            if (mask >> i) & 1:
+                fb = np.zeros((n, 4), np.float32); acc = np.zeros((n, 4), np.float32)
+                self.buffers["fb%d" % i] = fb; self.buffers["acc%d" % i] = acc
+                self.f.framebuffer[i] = fb.ctypes.data; self.f.accumulator[i] = acc.ctypes.data
+        self.final = np.zeros((s.screen_height, s.screen_pitch, 4), np.float32)
+        self.f.final_image = self.final.ctypes.data
+        if s.config.enable_svgf:
+            def mk(name, shape, dtype=np.float32):
+                a = np.zeros(shape, dtype); self.buffers[name] = a; return a.ctypes.data
+            self.f.gbuffer_normal_and_depth = mk("gnd", (n, 4)); self.f.gbuffer_mesh_id_and_triangle_id = mk("gid", (n, 2), np.int32)
+            self.f.gbuffer_screen_position_prev = mk("gsp", (n, 2)); self.f.frame_buffer_moment = mk("mom", (n, 4))
+            self.f.history_length = mk("hl", (n,), np.int32)
+            self.f.history_direct = mk("hd", (n, 4)); self.f.history_indirect = mk("hi", (n, 4)); self.f.history_moment = mk("hm", (n, 4))
+            self.f.history_normal_and_depth = mk("hnd", (n, 4)); self.f.taa_frame_prev = mk("tp", (n, 4)); self.f.taa_frame_curr = mk("tc", (n, 4))
+
+    def render_sample(self, sample_index, pixel_offset=0, pixel_count=None, threads=0):
+        s = self.view.scene
+        if pixel_count is None:
+            pixel_count = s.screen_width * s.screen_height - pixel_offset
+        counters = OracleCounters()
+        lib().oracle_render_sample(byref(s), byref(self.f), sample_index, pixel_offset, pixel_count, byref(counters), threads)
+        return counters
+
+    def accumulator(self, aov):
+        s = self.view.scene
+        return self.buffers["acc%d" % aov].reshape(s.screen_height, s.screen_pitch, 4)
