@@ -1,0 +1,108 @@
+"""The product's SAH + CWBVH builder must reproduce the REFERENCE builder's bytes.
+
+Golden digests (tests/golden/bvh_golden.json) come from the reference's own sources compiled
+verbatim (oracle/_ref, see tests/golden/make_golden.py); where that library is present the
+comparison is also made live, byte by byte.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bvh_golden.json")))
+
+
+def digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def soup(seed, n):
+    rng = np.random.default_rng(seed)
+    p0 = (rng.random((n, 3)) * 50).astype(np.float32)
+    t = np.zeros((n, 24), np.float32)
+    t[:, 0:3] = p0
+    t[:, 3:6] = p0 + (rng.random((n, 3)) * 2 - 1).astype(np.float32)
+    t[:, 6:9] = p0 + (rng.random((n, 3)) * 2 - 1).astype(np.float32)
+    return t
+
+
+def product_build(grt, tris24):
+    import ctypes
+    lib = grt.host_lib()
+    t = np.ascontiguousarray(tris24, np.float32)
+    h = lib.grt_build_blas(t.ctypes.data, t.size // 24)
+    assert h
+    out = {}
+    for name, dtype in (("bvh2_nodes", np.uint8), ("bvh2_indices", np.int32), ("bvh8_nodes", np.uint8), ("bvh8_indices", np.int32)):
+        n = ctypes.c_size_t()
+        ptr = lib.grt_built_array(h, name.encode(), ctypes.byref(n))
+        out[name] = np.frombuffer((ctypes.c_char * n.value).from_address(ptr), dtype=dtype).copy()
+    lib.grt_built_free(h)
+    return out
+
+
+@pytest.mark.parametrize("key", sorted(GOLDEN["soups"]))
+def test_triangle_soups_match_reference_digest(grt, key):
+    seed, n = map(int, key.split("_"))
+    built = product_build(grt, soup(seed, n))
+    assert built["bvh2_nodes"].size // 32 == GOLDEN["soups"][key]["bvh2_nodes"]
+    assert built["bvh8_nodes"].size // 80 == GOLDEN["soups"][key]["bvh8_nodes"]
+    assert digest(built["bvh2_nodes"], built["bvh2_indices"], built["bvh8_nodes"], built["bvh8_indices"]) == GOLDEN["soups"][key]["sha256"]
+
+
+@pytest.mark.parametrize("scene_name", ["cornellbox", "sponza"])
+def test_scene_blas_match_reference_digest(grt, scene_name):
+    grt.config_reset()
+    scene = grt.Scene(grt.scene_path(scene_name))
+    scene.wait_until_loaded()
+    want = GOLDEN["meshes"][scene_name]
+    assert scene.mesh_data_count == want["mesh_data_count"]
+    agg = hashlib.sha256()
+    for m in range(scene.mesh_data_count):
+        d = digest(scene.mesh_data_array(m, "bvh2_nodes", np.uint8), scene.mesh_data_array(m, "bvh2_indices", np.int32),
+                   scene.mesh_data_array(m, "bvh8_nodes", np.uint8), scene.mesh_data_array(m, "bvh8_indices", np.int32))
+        agg.update(d.encode())
+        if str(m) in want["individual"]:
+            assert d == want["individual"][str(m)]["sha256"], "mesh %d" % m
+    assert agg.hexdigest() == want["aggregate"]
+    scene.close()
+
+
+def test_live_against_reference_builder(grt, oracle):
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    for seed, n in ((11, 3), (12, 257), (13, 5000)):
+        tris = soup(seed, n)
+        ref, built = oracle.ref_build(tris), product_build(grt, tris)
+        for key in ("bvh2_nodes", "bvh2_indices", "bvh8_nodes", "bvh8_indices"):
+            assert np.array_equal(ref[key], built[key]), key
+
+
+def test_cwbvh_structural_invariants(grt):
+    """Asserts of the reference converter (BVH8Converter.cpp:21,252-254,293,303,322-323)."""
+    built = product_build(grt, soup(5, 3000))
+    nodes = built["bvh8_nodes"].reshape(-1, 80)
+    assert built["bvh8_indices"].size == 3000 and sorted(built["bvh8_indices"].tolist()) == list(range(3000))
+    meta = nodes[:, 24:32]
+    imask = nodes[:, 15]
+    for n in range(nodes.shape[0]):
+        tri_total = 0
+        for slot in range(8):
+            m = int(meta[n, slot])
+            if m == 0:
+                continue
+            if (m & 0x1f) >= 24:                      # inner child
+                assert m == (0x20 | (24 + slot)) and (imask[n] >> slot) & 1
+            else:                                     # leaf: unary count in the top 3 bits
+                count = bin(m >> 5).count("1")
+                assert 1 <= count <= 3 and (m >> 5) in (1, 3, 7) and (m & 0x1f) == tri_total
+                tri_total += count
+        assert tri_total <= 24
+    child_base = nodes[:, 16:20].copy().view(np.uint32).reshape(-1)
+    inner_counts = np.array([bin(int(x)).count("1") for x in imask])
+    assert child_base[0] == 1 and (child_base + inner_counts <= nodes.shape[0]).all()

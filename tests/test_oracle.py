@@ -1,0 +1,174 @@
+"""Pins the CPU oracle itself (no GPU): traversal against brute force, hashing against an
+independent numpy restatement, and the committed golden render."""
+import os
+
+import numpy as np
+
+from conftest import make_pathtracer, unpack_hits
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "render_golden.npz")
+
+
+def brute_force(tris, origins, dirs):
+    """Double-precision Moeller-Trumbore against every triangle (closest t per ray)."""
+    p0, e1, e2 = tris[:, 0:3].astype(np.float64), tris[:, 3:6].astype(np.float64), tris[:, 6:9].astype(np.float64)
+    best_t = np.full(origins.shape[1], np.inf)
+    best_id = np.full(origins.shape[1], -1)
+    for r in range(origins.shape[1]):
+        o, d = origins[:, r].astype(np.float64), dirs[:, r].astype(np.float64)
+        h = np.cross(d, e2)
+        a = (e1 * h).sum(1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            f = 1.0 / a
+            s = o - p0
+            u = f * (s * h).sum(1)
+            q = np.cross(s, e1)
+            v = f * (q * d).sum(1)
+            t = f * (e2 * q).sum(1)
+        ok = (u >= 0) & (u <= 1) & (v >= 0) & (u + v <= 1) & (t > 0)
+        if ok.any():
+            tt = np.where(ok, t, np.inf)
+            best_id[r] = int(tt.argmin()); best_t[r] = tt.min()
+    return best_id, best_t
+
+
+def test_bvh8_and_bvh2_traversal_agree_with_brute_force(grt, oracle):
+    scene, pt = make_pathtracer(grt, "cornellbox", 32, 32, -1)
+    view8 = oracle.SceneView(pt, bvh_type=8)
+    o, d, _ = view8.generate(0, 0, 32 * 32)
+    rng = np.random.default_rng(3)
+    o2 = np.tile(np.array([[0.1], [1.0], [0.2]], np.float32), (1, 500))
+    d2 = rng.normal(size=(3, 500)).astype(np.float32); d2 /= np.linalg.norm(d2, axis=0)
+    O, D = np.concatenate([o, o2], 1), np.concatenate([d, d2], 1)
+    hits8, stats8 = view8.trace(O, D)
+    tris = pt.array("triangles").reshape(-1, 24)
+    bid, bt = brute_force(tris, O, D)
+    _, tid, t, _, _ = unpack_hits(hits8)
+    miss = bid < 0
+    assert ((tid == -1) == miss).all()
+    assert np.allclose(t[~miss], bt[~miss], rtol=2e-5)
+    same = tid[~miss] == bid[~miss]
+    assert same.mean() > 0.995    # ties on shared edges may pick the neighbour triangle
+    assert stats8.rays == O.shape[1] and stats8.nodes > 0
+
+    # binary BVH (BASELINE config #1): same closest hits
+    pt.close(); scene.close()
+    scene, pt = make_pathtracer(grt, "cornellbox", 32, 32, -1, bvh_type=2)
+    view2 = oracle.SceneView(pt, bvh_type=2)
+    hits2, _ = view2.trace(O, D)
+    _, tid2, t2, _, _ = unpack_hits(hits2)
+    assert ((tid2 == -1) == miss).all() and np.allclose(t2[~miss], bt[~miss], rtol=2e-5)
+    # shadow rays: occluded iff brute force finds a hit closer than max_distance
+    md = np.full(O.shape[1], 3.0, np.float32)
+    occ, _ = view2.trace_shadow(O, D, md)
+    occ8, _ = view8.trace_shadow(O, D, md)
+    expect = (~miss) & (bt < 3.0)
+    assert (occ.astype(bool) == expect).mean() > 0.999 and (occ8 == occ).all()
+    pt.close(); scene.close()
+
+
+def test_instanced_traversal_uses_object_space_rays(grt, oracle, tmp_path):
+    """Non-identity instance: transform_inv applied without renormalising, so t is world distance (BVH8.h:222-228)."""
+    (tmp_path / "tri.obj").write_text("v -1 -1 0\nv 1 -1 0\nv 0 1 0\nf 1 2 3\n")
+    (tmp_path / "s.xml").write_text("""<scene version="0.5.0"><shape type="obj"><string name="filename" value="tri.obj"/>
+      <transform name="toWorld"><scale value="3"/><translate z="-10"/></transform><bsdf type="diffuse"/></shape></scene>""")
+    grt.config_reset()
+    scene = grt.Scene(str(tmp_path / "s.xml"))
+    pt = grt.Pathtracer(scene, 16, 16, device=-1); pt.update()
+    view = oracle.SceneView(pt)
+    o = np.array([[0.0], [0.0], [5.0]], np.float32); d = np.array([[0.0], [0.0], [-1.0]], np.float32)
+    hits, stats = view.trace(o, d)
+    mesh, tri, t, u, v = unpack_hits(hits)
+    assert tri[0] == 0 and abs(t[0] - 15.0) < 1e-5 and stats.instances_transformed == 1
+    pt.close(); scene.close()
+
+
+# ---- independent numpy restatement of the integer sample-index path (Util.h:104-149, Sampling.h:44-84)
+def np_pcg(seed):
+    seed = np.uint32(seed)
+    with np.errstate(over="ignore"):
+        state = seed * np.uint32(747796405) + np.uint32(2891336453)
+        word = ((state >> ((state >> np.uint32(28)) + np.uint32(4))) ^ state) * np.uint32(277803737)
+    return (word >> np.uint32(22)) ^ word
+
+
+def np_permute(index, length, seed):
+    u = np.uint32
+    mask = u(length - 1); index = u(index); seed = u(seed)
+    with np.errstate(over="ignore"):
+        index ^= seed; index *= u(0xe170893d); index ^= seed >> u(16); index ^= (index & mask) >> u(4)
+        index ^= seed >> u(8); index *= u(0x0929eb3f); index ^= seed >> u(23); index ^= (index & mask) >> u(1)
+        index *= u(1) | seed >> u(27); index *= u(0x6935fa69); index ^= (index & mask) >> u(11)
+        index *= u(0x74dcb303); index ^= (index & mask) >> u(2); index *= u(0x9e501cc3); index ^= (index & mask) >> u(2)
+        index *= u(0xc860a3df); index &= mask; index ^= index >> u(5)
+        return (index + seed) & mask
+
+
+def test_random_sample_index_path_is_bit_exact(grt, oracle):
+    scene, pt = make_pathtracer(grt, "cornellbox", 200, 100, -1)
+    view = oracle.SceneView(pt)
+    pmj = pt.array("pmj_samples").reshape(64, 4096, 2)
+    bn = pt.array("blue_noise").reshape(16, 128, 128, 2)
+    pitch = pt.pitch
+    rng = np.random.default_rng(7)
+    for dim_enum, bounce, sample in ((0, 0, 0), (5, 2, 17), (6, 12, 4095), (2, 20, 1000), (4, 127, 3)):
+        px = rng.integers(0, pitch * 100, 64).astype(np.uint32)
+        got = view.random(dim_enum, px, bounce, sample)
+        for k, pixel in enumerate(px):
+            with np.errstate(over="ignore"):
+                h = np_pcg((np.uint32(pixel) * np.uint32(7) + np.uint32(dim_enum)) * np.uint32(128) + np.uint32(bounce))
+            dim = dim_enum + 5 * bounce
+            si = sample if dim < 64 else int(np_permute(sample, 4096, h))
+            s = pmj[dim % 64, si].copy()
+            x, y = (int(pixel) % pitch) % 128, (int(pixel) // pitch) % 128
+            b = bn[dim % 16, y, x].astype(np.float32) * np.float32(1.0 / 255.0)
+            s = s + b
+            s = np.where(s >= 1.0, s - np.float32(1.0), s).astype(np.float32)
+            assert got[k].view(np.uint32).tolist() == s.view(np.uint32).tolist()
+    pt.close(); scene.close()
+
+
+def test_pmj_table_is_a_stratified_02_sequence(grt):
+    """Every power-of-two prefix of each sequence has one sample per elementary interval (pmj02 property)."""
+    scene, pt = make_pathtracer(grt, "cornellbox", 32, 32, -1)
+    pmj = pt.array("pmj_samples").reshape(64, 4096, 2)
+    assert pmj.min() >= 0.0 and pmj.max() < 1.0
+    for seq in (0, 1, 31, 63):
+        for log_n in (2, 4, 6, 10, 12):
+            n = 1 << log_n
+            pts = pmj[seq, :n].astype(np.float64)
+            for a in range(log_n + 1):           # strata of 2^a x 2^(log_n - a)
+                nx, ny = 1 << a, 1 << (log_n - a)
+                cell = np.floor(pts[:, 0] * nx).astype(int) * ny + np.floor(pts[:, 1] * ny).astype(int)
+                assert np.unique(cell).size == n, (seq, log_n, a)
+    pt.close(); scene.close()
+
+
+def test_oracle_matches_committed_golden_render(grt, oracle):
+    g = np.load(GOLDEN)
+    scene, pt = make_pathtracer(grt, "cornellbox", 48, 48, -1, num_bounces=4)
+    view = oracle.SceneView(pt)
+    o, d, _ = view.generate(0, 0, 48 * 48)
+    assert np.array_equal(o, g["ray_origin"]) and np.allclose(d, g["ray_direction"], atol=2e-7)
+    hits, stats = view.trace(g["ray_origin"], g["ray_direction"])
+    assert np.array_equal(hits, g["hits"]) and stats.nodes == int(g["nodes"]) and stats.triangles == int(g["triangles"])
+    frame = oracle.Frame(view)
+    for s in range(2):
+        c = frame.render_sample(s)
+        assert (list(c.trace[:4]) + list(c.shadow[:4])) == g["counters"][s].tolist()
+    rel = np.abs(frame.final[:, :48, :3] - g["image"]).sum() / g["image"].sum()
+    assert rel < 1e-5
+    # physical sanity of the golden: light visible, image finite, red/green wall colour bleeding present
+    img = g["image"]
+    assert np.isfinite(img).all() and img.max() > 10.0 and img[:, :8, 0].mean() != img[:, -8:, 0].mean()
+    pt.close(); scene.close()
+
+
+def test_accumulation_quirk_divides_by_sample_index(grt, oracle):
+    """Frame 1 overwrites frame 0 (AOV.h:35-41 divides by n, not n+1): acc after samples 0,1 == sample 1."""
+    scene, pt = make_pathtracer(grt, "cornellbox", 24, 24, -1, num_bounces=3)
+    view = oracle.SceneView(pt)
+    a = oracle.Frame(view); a.render_sample(0); a.render_sample(1)
+    b = oracle.Frame(view); b.render_sample(1)
+    assert np.allclose(a.final, b.final, rtol=1e-5, atol=2e-5)  # acc + (fb - acc) / 1 rounds at the scale of the overwritten sample
+    pt.close(); scene.close()
