@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + secondary) and ms/frame on Sponza 1920x1080, BVH8,
+diffuse + plastic materials, NEE + MIS + Russian roulette, 10 bounces, samples 0..3 (4 spp).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over the whole frame = one sample per pixel:
+generate -> (trace, sort, shade, shadow-trace) x bounces for each 777 600-pixel batch ->
+accumulate (Pathtracer::render of the reference, Pathtracer.cpp:738-855).  With N > 1 the frame
+is split into row tiles dealt round-robin to the ranks (each rank holds a full scene replica) and
+one RCCL all-gather per step rebuilds the float4 frame on every rank: the total work is fixed, so
+the scaling is STRONG.  Scene data is resident in HBM before the timed region; nothing crosses
+PCIe inside it.
+
+Rank 0 prints ONE JSON line.  `value` counts closest-hit rays (bounce 0 = primary, bounces >= 1 =
+secondary) of all ranks per second of max-over-ranks wall time; shadow rays are reported
+separately in `config`.  `roofline` prices the dominant kernel (kernel_trace_bvh8) in ALGORITHMIC
+bytes (40 B per ray + 80 B per BVH8 node fetched + 48 B per triangle tested + 52 B
+per transformed instance entry + 4 B per identity entry, the node / triangle counts measured by the
+counting variant of the same kernel on the same rays) over its HIP-event time, against the 8 TB/s
+HBM3E peak of MI355X.  `cpu_baseline` times the CPU oracle (a port of the reference's device
+traversal, OpenMP over rays) on a bounded sample of the same rays on this box's host cores, and
+the reference's own BVH builder (oracle/_ref, compiled verbatim) where it has been built.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT = 1920, 1080
+NUM_BOUNCES = 10
+SPP = 4
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3-6.6 TB/s is achievable
+
+
+def build_scene(grt):
+    """BASELINE config #2: Sponza, every odd diffuse material -> roughplastic alpha 0.3."""
+    grt.config_reset()
+    scene = grt.Scene(grt.scene_path("sponza"))
+    for i in range(1, scene.material_count, 2):
+        if scene.material_type(i) == grt.MATERIAL_DIFFUSE:
+            scene.set_material(i, grt.MATERIAL_PLASTIC, None, 0.3)
+    grt.config_set(num_bounces=NUM_BOUNCES)
+    return scene
+
+
+def cpu_baseline(grt, pt, scene):
+    """CPU leg (rank 0, N = 1 only): bounded sample, ~10-30 s of host work."""
+    from oracle import binding as oracle  # checker only: never on the product path
+    view = oracle.SceneView(pt)
+    threads = os.cpu_count() or 1
+    n = grt.RT_BATCH_SIZE
+    o, d, _ = view.generate(0, 0, n)
+    t0 = time.perf_counter()
+    hits, stats_primary = view.trace(o, d, threads)
+    t_primary = time.perf_counter() - t0
+    # diffuse-bounce stand-in rays leaving the primary hit points (seeded)
+    rng = np.random.default_rng(1234)
+    t = hits[:, 2].view(np.float32)
+    ok = hits[:, 1] != 0xffffffff
+    org = (o + d * np.where(ok, t, 1.0).astype(np.float32) * np.float32(0.999))[:, ok]
+    dirs = rng.normal(size=org.shape).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=0)
+    t0 = time.perf_counter()
+    _, stats_secondary = view.trace(org, dirs, threads)
+    t_secondary = time.perf_counter() - t0
+    rays = n + org.shape[1]
+    out = {
+        "value": round(rays / (t_primary + t_secondary) / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": "oracle bvh8_trace (OpenMP, %d threads) over the %d primary rays of batch 0 / sample 0 plus %d seeded diffuse-bounce rays from their hit points" % (threads, n, org.shape[1]),
+        "primary_mrays_s": round(n / t_primary / 1e6, 3), "secondary_mrays_s": round(org.shape[1] / t_secondary / 1e6, 3),
+    }
+    # same rays on the GPU through the C ABI: like-for-like ratio + algorithmic GB/s per ray class
+    _, ms_p = grt.trace_rays(pt.ctx, o, d, repeat=5)
+    _, ms_s = grt.trace_rays(pt.ctx, org, dirs, repeat=5)
+    out["gpu_same_rays"] = {
+        "primary_mrays_s": round(n / ms_p / 1e3, 1), "secondary_mrays_s": round(org.shape[1] / ms_s / 1e3, 1),
+        "primary_alg_gbps": round(stats_primary.algorithmic_bytes() / (ms_p * 1e-3) / 1e9, 1),
+        "secondary_alg_gbps": round(stats_secondary.algorithmic_bytes() / (ms_s * 1e-3) / 1e9, 1),
+        "nodes_per_ray": [round(stats_primary.nodes / stats_primary.rays, 2), round(stats_secondary.nodes / stats_secondary.rays, 2)],
+        "triangles_per_ray": [round(stats_primary.triangles / stats_primary.rays, 2), round(stats_secondary.triangles / stats_secondary.rays, 2)],
+    }
+    if oracle.ref_lib() is not None:  # the reference's own CPU path: BVH2 + BVH8 build of all 383 Sponza meshes
+        scene.wait_until_loaded()
+        t0 = time.perf_counter()
+        ms2 = ms8 = 0.0
+        for m in range(scene.mesh_data_count):
+            ref = oracle.ref_build(scene.mesh_data_array(m, "triangles", np.float32))
+            ms2 += ref["ms_bvh2"]; ms8 += ref["ms_bvh8"]
+        out["reference_bvh_build"] = {"kind": "reference", "cores": 1, "ms_sah_bvh2": round(ms2, 1), "ms_bvh8_convert": round(ms8, 1),
+                                      "ms_wall": round((time.perf_counter() - t0) * 1e3, 1), "meshes": scene.mesh_data_count,
+                                      "product_builder_ms_parallel": round(scene.bvh_build_ms, 1)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)   # PerfTest BUFFER_SIZE = 32 frames (Util/PerfTest.h:9)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import gpu_raytracer_amd as grt
+    import importlib
+    parallel = importlib.import_module("gpu_raytracer_amd.parallel")
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene = build_scene(grt)
+    pt = grt.Pathtracer(scene, WIDTH, HEIGHT, device=local_rank)
+    pt.update()
+    lib = grt.device_lib()
+    ctx = pt.ctx
+    split = parallel.TileSplit(rank, world, WIDTH, HEIGHT)
+    pitch = pt.pitch
+    device = torch.device("cuda", local_rank)
+
+    # this rank's tiles, rendered as scan-order pixel ranges; the gather buffers live in torch
+    packed = torch.zeros((split.local_pixels, 4), dtype=torch.float32, device=device)
+    gathered = torch.zeros((world * split.local_pixels, 4), dtype=torch.float32, device=device)
+    import ctypes
+    lib.rt_pack_pixels.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.rt_synchronize.argtypes = [ctypes.c_void_p]
+
+    def check(status):
+        if status != 0:
+            raise RuntimeError(lib.rt_last_error(ctx).decode())
+
+    def render_step(sample_index):
+        """One sample for this rank's share of the frame, then the frame gather."""
+        if world == 1:
+            check(lib.rt_set_pixel_range(ctx, 0, WIDTH * HEIGHT))
+            check(lib.rt_render_sample(ctx, sample_index))
+        else:
+            check(lib.rt_set_pixel_tiles(ctx, split.tile_pixels, rank, world))
+            check(lib.rt_render_sample(ctx, sample_index))
+            check(lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, world, split.tiles_per_rank))
+            check(lib.rt_synchronize(ctx))            # the tracer runs on its own HIP stream
+            dist.all_gather_into_tensor(gathered, packed)
+
+    def counters():
+        c = pt.counters()
+        return c, sum(c.trace[:NUM_BOUNCES]), sum(c.shadow[:NUM_BOUNCES])
+
+    if world > 1:
+        lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+
+    # ---- warm-up (untimed) ---------------------------------------------------------------------
+    for w in range(args.warmup):
+        render_step(w % SPP)
+    check(lib.rt_synchronize(ctx))
+
+    # ---- untimed statistics pass: rays per sample and the work counters of the trace kernels ---
+    rays_per_sample, shadow_per_sample, alg_bytes_per_sample, trace_rays_stat = [], [], [], []
+    grt.set_trace_statistics(ctx, True)
+    for s in range(SPP):
+        render_step(s)
+        _, closest, shadow = counters()
+        stats = grt.get_trace_statistics(ctx)
+        rays_per_sample.append(closest); shadow_per_sample.append(shadow)
+        alg_bytes_per_sample.append(stats["closest"]["algorithmic_bytes"])
+        trace_rays_stat.append(stats)
+    grt.set_trace_statistics(ctx, False)
+
+    # ---- profiled pass (HIP events per stage, on the tracer's stream): kernel time of the trace launches
+    grt.set_profiling(ctx, True)
+    trace_ms, stage_ms = [], {}
+    for rep in range(2):
+        for s in range(SPP):
+            render_step(s)
+            c, _, _ = counters()
+            if rep == 1:
+                trace_ms.append(c.ms_trace)
+                for k in ("ms_generate", "ms_trace", "ms_sort", "ms_shade", "ms_shadow", "ms_post"):
+                    stage_ms[k] = stage_ms.get(k, 0.0) + getattr(c, k) / SPP
+    grt.set_profiling(ctx, False)
+
+    # ---- timed region: exactly K steps -------------------------------------------------------------
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    check(lib.rt_synchronize(ctx))
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        render_step(k % SPP)
+    check(lib.rt_synchronize(ctx))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    local = torch.tensor([elapsed, float(sum(rays_per_sample)), float(sum(shadow_per_sample)), float(sum(alg_bytes_per_sample)), float(sum(trace_ms))], dtype=torch.float64, device=device)
+    if world > 1:
+        mx = local.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = local.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0]); rays_4spp = float(sm[1]); shadow_4spp = float(sm[2])
+    else:
+        rays_4spp, shadow_4spp = float(local[1]), float(local[2])
+
+    if rank == 0:
+        rays_per_step = rays_4spp / SPP
+        total_rays = rays_per_step * args.steps
+        value = total_rays / elapsed / 1e6
+        launches_per_sample = NUM_BOUNCES  # one batch = this rank's whole share of the frame
+        achieved = sum(alg_bytes_per_sample) / (sum(trace_ms) * 1e-3) / 1e9  # rank 0's launches
+        roofline = {
+            "bound": "hbm", "kernel": "kernel_trace_bvh8", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": round(sum(alg_bytes_per_sample) / SPP / launches_per_sample),
+            "avg_launch_ms": round(sum(trace_ms) / SPP / launches_per_sample, 4), "launches_per_step": launches_per_sample,
+            "bytes_per_ray": round(sum(alg_bytes_per_sample) / max(sum(rays_per_sample), 1), 1),
+            "nodes_per_ray": round(sum(s["closest"]["nodes"] for s in trace_rays_stat) / max(sum(rays_per_sample), 1), 2),
+            "triangles_per_ray": round(sum(s["closest"]["triangles"] for s in trace_rays_stat) / max(sum(rays_per_sample), 1), 2),
+            "measured_stream_read_gbps": round(grt.measure_stream_bandwidth(ctx, 1 << 30, 5), 1),
+            "note": "working set (2.6 MB nodes + 25 MB triangles) is L2/Infinity-Cache resident; algorithmic bytes >> DRAM traffic",
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "pmc_trace_traffic.json")
+        if os.path.exists(traffic_file):
+            roofline["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
+        result = {
+            "metric": "Mrays/s (primary+secondary) + ms/frame, Sponza 1920x1080 4spp BVH8", "value": round(value, 1), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "Sponza (Crytek, 262 687 triangles, 384 instances) 1920x1080, samples 0..3 (4 spp), BVH8/CWBVH, diffuse + roughplastic(odd materials, alpha 0.3), NEE+MIS+RR, 10 bounces, constant white sky, mipmapping on; textures absent on this box fall back to the reference's 1x1 pink texel",
+                "step": "one sample per pixel for the whole frame, one wavefront batch per rank (the reference cuts it into 777 600-pixel batches only to bound VRAM)",
+                "rays_per_step": round(rays_per_step), "shadow_rays_per_step": round(shadow_4spp / SPP),
+                "mrays_s_including_shadow": round((rays_4spp + shadow_4spp) / SPP * args.steps / elapsed / 1e6, 1),
+                "ms_per_4spp_frame": round(elapsed / args.steps * SPP * 1e3, 3),
+                "parallelism": "tile-split x%d + RCCL all-gather of the float4 frame" % world if world > 1 else "single GPU",
+                "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
+            },
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(grt, pt, scene)
+        print(json.dumps(result))
+
+    pt.close()
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

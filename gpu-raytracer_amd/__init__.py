@@ -20,7 +20,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 ASSET_DIR = os.path.join(REPO_ROOT, "assets")
-DEVICE_LIB_PATH = os.path.join(_HERE, "csrc", "libgrt_device.so")
+DEVICE_LIB_PATH = os.environ.get("GRT_DEVICE_LIB") or os.path.join(_HERE, "csrc", "libgrt_device.so")  # override: kernel-variant experiments
 HOST_LIB_PATH = os.path.join(_HERE, "host", "libgrt_host.so")
 
 RT_MAX_BOUNCES = 128
@@ -429,6 +429,29 @@ def read_luts(ctx):
     arrays = [np.zeros(s, np.float32) for s in shapes]
     _dev_check(ctx, device_lib().rt_read_luts(ctx, *[a.ctypes.data for a in arrays]))
     return arrays
+
+
+def set_trace_statistics(ctx, enable):
+    lib = device_lib()
+    lib.rt_set_trace_statistics.argtypes = [c_void_p, c_int]
+    _dev_check(ctx, lib.rt_set_trace_statistics(ctx, 1 if enable else 0))
+
+
+def get_trace_statistics(ctx):
+    """Returns {'closest': {...}, 'shadow': {...}} with nodes / triangles / instances / rays and the
+    algorithmic bytes they imply (24 B ray + 16 B hit | 4 B max_distance, 80 B per node, 48 B per
+    triangle, 52 B per transformed instance entry, 4 B per identity entry)."""
+    lib = device_lib()
+    lib.rt_get_trace_statistics.argtypes = [c_void_p, c_void_p]
+    raw = np.zeros(10, np.uint64)
+    _dev_check(ctx, lib.rt_get_trace_statistics(ctx, raw.ctypes.data))
+    out = {}
+    for k, name in enumerate(("closest", "shadow")):
+        nodes, tris, ix, ii, rays = [int(v) for v in raw[5 * k:5 * k + 5]]
+        per_ray = 24 + (16 if k == 0 else 4)
+        out[name] = dict(nodes=nodes, triangles=tris, instances_transformed=ix, instances_identity=ii, rays=rays,
+                         algorithmic_bytes=per_ray * rays + 80 * nodes + 48 * tris + 52 * ix + 4 * ii)
+    return out
 
 
 def set_profiling(ctx, enable):

@@ -30,7 +30,7 @@ RT_DEV f4 aov_accumulate(const RtParams & p, int aov, int pixel_index, float n) 
 
 __global__ void __launch_bounds__(256) kernel_accumulate(RtParams p, float frames_accumulated, int pixel_offset, int pixel_count) {
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pixel_count; i += gridDim.x * blockDim.x) {
-		int idx = i + pixel_offset;
+		int idx = rt_map_pixel(p, i + pixel_offset);
 		int x = idx % p.screen_width, y = idx / p.screen_width;
 		int pixel_index = x + y * p.screen_pitch;
 
@@ -543,6 +543,36 @@ void rt_launch_integrate_luts(const RtParams & p, float * dielectric_dir_enter, 
 	hipLaunchKernelGGL(kernel_average_dielectric, dim3(1), dim3(256), 0, stream, dielectric_dir_leave, dielectric_leave);
 	hipLaunchKernelGGL(kernel_integrate_conductor, dim3(1024 / 64), dim3(64), 0, stream, p, conductor_dir);
 	hipLaunchKernelGGL(kernel_average_conductor, dim3(1), dim3(64), 0, stream, conductor_dir, conductor);
+}
+
+// ---- multi-GPU frame exchange: pack this rank's tiles / scatter the all-gathered tiles -------------------------
+
+__global__ void __launch_bounds__(256) kernel_pack_pixels(RtParams p, float4 * dst, int tile_pixels, int tile_first, int tile_stride, int count) {
+	int frame_pixels = p.screen_width * p.screen_height;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+		int g = ((i / tile_pixels) * tile_stride + tile_first) * tile_pixels + i % tile_pixels;
+		float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (g < frame_pixels) v = p.final_image[g % p.screen_width + (g / p.screen_width) * p.screen_pitch];
+		dst[i] = v;
+	}
+}
+
+__global__ void __launch_bounds__(256) kernel_unpack_pixels(RtParams p, const float4 * src, int tile_pixels, int world, int tiles_per_rank) {
+	int frame_pixels = p.screen_width * p.screen_height;
+	for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < frame_pixels; g += gridDim.x * blockDim.x) {
+		int tile = g / tile_pixels;
+		int owner = tile % world, slot = tile / world;
+		p.final_image[g % p.screen_width + (g / p.screen_width) * p.screen_pitch] = src[size_t(owner * tiles_per_rank + slot) * tile_pixels + g % tile_pixels];
+	}
+}
+
+void rt_launch_pack_pixels(const RtParams & p, float4 * dst, int tile_pixels, int tile_first, int tile_stride, int tiles, hipStream_t stream) {
+	int count = tiles * tile_pixels;
+	int blocks = (count + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+	hipLaunchKernelGGL(kernel_pack_pixels, dim3(blocks), dim3(256), 0, stream, p, dst, tile_pixels, tile_first, tile_stride, count);
+}
+void rt_launch_unpack_pixels(const RtParams & p, const float4 * src, int tile_pixels, int world, int tiles_per_rank, hipStream_t stream) {
+	hipLaunchKernelGGL(kernel_unpack_pixels, dim3(4096), dim3(256), 0, stream, p, src, tile_pixels, world, tiles_per_rank);
 }
 
 // ---- streaming-read probe: the measured HBM roofline the trace kernel is priced against --------------------

@@ -64,7 +64,7 @@ RT_DEV void camera_generate_ray(const RtParams & p, int pixel_index, int sample_
 __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate(RtParams p, int sample_index, int pixel_offset, int pixel_count) {
 	if (blockIdx.x == 0 && threadIdx.x == 0) p.sizes->trace[0] = pixel_count; // BufferSizes::reset (Pathtracer.h:143)
 	for (int index = blockIdx.x * blockDim.x + threadIdx.x; index < pixel_count; index += gridDim.x * blockDim.x) {
-		int index_offset = index + pixel_offset;
+		int index_offset = rt_map_pixel(p, index + pixel_offset);
 		int x = index_offset % p.screen_width;
 		int y = index_offset / p.screen_width;
 		int pixel_index = x + y * p.screen_pitch;
@@ -807,10 +807,10 @@ void rt_launch_generate(const RtParams & p, int sample_index, int pixel_offset, 
 	hipLaunchKernelGGL(kernel_generate, dim3(streaming_grid(pixel_count)), dim3(RT_SHADE_BLOCK), 0, stream, p, sample_index, pixel_offset, pixel_count);
 }
 void rt_launch_sort(const RtParams & p, int bounce, int sample_index, hipStream_t stream) {
-	hipLaunchKernelGGL(kernel_sort, dim3(streaming_grid(RT_BATCH_SIZE)), dim3(RT_SHADE_BLOCK), 0, stream, p, bounce, sample_index);
+	hipLaunchKernelGGL(kernel_sort, dim3(2048), dim3(RT_SHADE_BLOCK), 0, stream, p, bounce, sample_index);
 }
 void rt_launch_material(const RtParams & p, int material_slot, int bounce, int sample_index, hipStream_t stream) {
-	dim3 grid(streaming_grid(RT_BATCH_SIZE)), block(RT_SHADE_BLOCK);
+	dim3 grid(2048), block(RT_SHADE_BLOCK);
 	switch (material_slot) {
 		case 0: hipLaunchKernelGGL(kernel_material_diffuse,    grid, block, 0, stream, p, bounce, sample_index); break;
 		case 1: hipLaunchKernelGGL(kernel_material_plastic,    grid, block, 0, stream, p, bounce, sample_index); break;

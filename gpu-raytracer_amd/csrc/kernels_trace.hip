@@ -20,9 +20,24 @@
 // bit-identical to the CPU oracle even when two triangles tie in t.
 #include "rt_math.h"
 
-#define RT_LDS_STACK   12   // stack entries per lane kept in LDS
+#include <cstdio>
+#include <cstdlib>
+
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK   12   // stack entries per lane kept in LDS (6 KB per wave; 20 waves per CU = 120 KB of 160 KB)
+#endif
 #define RT_STACK_SIZE  32   // total entries per lane (reference: BVH_STACK_SIZE, Common.h:103)
 #define RT_TRACE_BLOCK 256  // 4 waves per workgroup
+#ifndef RT_TRACE_WAVES_PER_SIMD
+// Measured on MI355X (profiles/r01_trace_variants.txt): 5 waves/SIMD (<= 96 VGPRs, no spills) beats 6 and
+// 8 (64 VGPRs, 13 dwords of scratch spills in the loop); throughput is not limited by the wave count.
+#define RT_TRACE_WAVES_PER_SIMD 5
+#endif
+#ifndef RT_NUM_XCD
+// 8 = per-XCD chunks of the ray range (L2 affinity); measured SLOWER than one shared cursor on Sponza
+// (1.84 vs 2.01 Grays/s at 8M incoherent rays, and 8x the refill atomics), so the default is 1.
+#define RT_NUM_XCD 1
+#endif
 #define RT_N_D 8            // dynamic fetch: tolerated idle lanes per iteration (N_d = 4 of 32 in the reference)
 #define RT_N_W 32           // dynamic fetch: lost lane-iterations before refilling  (N_w = 16 of 32)
 
@@ -111,9 +126,11 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 struct HitRecord { float t, u, v; int mesh_id, triangle_id; };
 
 template<bool SHADOW>
-RT_DEV bool triangle_test(const float4 * __restrict__ triangles, int mesh_id, int triangle_id, const Ray3 & ray, float max_distance, HitRecord & hit) {
-	const float4 * tri = triangles + size_t(triangle_id) * 6;
-	float4 part_0 = tri[0], part_1 = tri[1], part_2 = tri[2]; // 48 B: position_0, edge_1, edge_2 (+3 unused floats)
+RT_DEV bool triangle_test(const float4 * __restrict__ triangle_positions, int mesh_id, int triangle_id, const Ray3 & ray, float max_distance, HitRecord & hit) {
+	// traversal reads the positions-only copy (48 B stride): half the cache footprint of the
+	// 96-byte shading triangles, whose normals/uvs the trace kernels never touch
+	const float4 * tri = triangle_positions + size_t(triangle_id) * 3;
+	float4 part_0 = tri[0], part_1 = tri[1], part_2 = tri[2]; // position_0, edge_1, edge_2 (+3 pad floats)
 	f3 p0 = mk3(part_0.x, part_0.y, part_0.z);
 	f3 e1 = mk3(part_0.w, part_1.x, part_1.y);
 	f3 e2 = mk3(part_1.z, part_1.w, part_2.x);
@@ -140,44 +157,105 @@ RT_DEV bool triangle_test(const float4 * __restrict__ triangles, int mesh_id, in
 	return false;
 }
 
-// Per-lane stack: first RT_LDS_STACK entries in LDS, the rest in scratch.
+// Per-lane stack: the first RT_LDS_STACK entries live in LDS ([entry][lane] stripes, see the
+// file header), deeper entries spill to a context-owned HBM buffer laid out [entry][global lane]
+// so that even the spill traffic is coalesced. No private arrays => no compiler scratch.
 struct TraversalStack {
-	uint2 * lds;                                   // &shared[wave][0][lane]
-	uint2 spill[RT_STACK_SIZE - RT_LDS_STACK];
+	uint2 * lds;       // this lane's column of the LDS stripe (address space 3 after inlining)
+	uint2 * spill;     // this lane's column of the HBM spill area
+	int spill_stride;  // lanes in the grid
 	int size;
 
 	RT_DEV void push(uint2 item) {
 		if (size < RT_LDS_STACK) lds[size * RT_WAVE_SIZE] = item;
-		else                     spill[size - RT_LDS_STACK] = item;
+		else                     spill[size_t(size - RT_LDS_STACK) * spill_stride] = item;
 		size++;
 	}
 	RT_DEV uint2 pop() {
 		size--;
 		if (size < RT_LDS_STACK) return lds[size * RT_WAVE_SIZE];
-		return spill[size - RT_LDS_STACK];
+		return spill[size_t(size - RT_LDS_STACK) * spill_stride];
 	}
 };
 
+// Ray distribution. The ray range of a launch is cut into RT_NUM_XCD contiguous chunks and the
+// waves of XCD k drain chunk k first (queue order follows pixel order, so a chunk is a band of
+// the image and its rays share geometry: each XCD's private 4 MB L2 then mostly holds "its"
+// part of the scene), moving on to the other chunks only when their own is exhausted.
+// One returning atomic per wave per refill.
+struct RayFetcher {
+	int * counters;   // RT_NUM_XCD ints, zeroed before the launch
+	int ray_count;
+	int chunk;        // current chunk of this wave
+	int * drained;    // LDS flag of this wave: set once a fetch found every chunk empty
+
+	RT_DEV int chunk_begin(int c) const { return int((long long)ray_count * c / RT_NUM_XCD); }
+
+	// Called by the lanes that need a ray; returns its index or -1 when the launch is drained.
+	// Every round all participating lanes use the leader's chunk; a failed round means that
+	// chunk is exhausted (it never refills), so RT_NUM_XCD failed rounds have seen every chunk.
+	// Without the `drained` flag every lane that retires its last ray would issue its own failing
+	// atomics: ~64 x RT_NUM_XCD same-address atomics per wave at the tail of every launch, which
+	// serialise in L2 and were measured to add >1 ms to each launch.
+	RT_DEV int fetch() {
+		if (*drained) return -1;
+		for (int attempt = 0; attempt < RT_NUM_XCD; attempt++) {
+			unsigned long long want = __ballot(1);
+			int n_want = __popcll(want);
+			unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(want >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(want), 0u));
+			int leader = __ffsll((long long)want) - 1;
+			int c = __shfl(chunk, leader);
+			int begin = chunk_begin(c), end = chunk_begin(c + 1);
+			int base = 0;
+			if (rank == 0) base = atomicAdd(&counters[c], n_want);
+			base = __shfl(base, leader);
+			chunk = (base + n_want >= end - begin) ? (c + 1) % RT_NUM_XCD : c;
+			int index = begin + base + int(rank);
+			if (index < end) return index;
+		}
+		*drained = 1;
+		return -1;
+	}
+};
+
+RT_DEV unsigned xcc_id() {
+	// HW_REG_XCC_ID (hwreg 20), bits [3:0]: the XCD this wave runs on. Used for cache affinity only.
+	return (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0x7u) % RT_NUM_XCD;
+}
+
 // The common traversal engine. RaySource supplies rays and consumes results so that the same
 // code serves the wavefront queues and the stand-alone entry points.
-template<bool SHADOW, typename Source>
-RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_count, int * rays_retired) {
+// COUNT adds per-ray work counters (nodes fetched, triangles tested, instance entries) that are
+// flushed with atomics when a ray retires; it exists to MEASURE the algorithmic bytes of a launch
+// (rt_set_trace_statistics) and is never used in a timed frame.
+template<bool SHADOW, bool COUNT, typename Source>
+RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr) {
 	__shared__ uint2 shared_stack[(RT_TRACE_BLOCK / RT_WAVE_SIZE) * RT_LDS_STACK * RT_WAVE_SIZE];
+	__shared__ int   shared_drained[RT_TRACE_BLOCK / RT_WAVE_SIZE];
 
 	const float4 * __restrict__ nodes     = p.bvh8_nodes;
-	const float4 * __restrict__ triangles = p.triangles;
+	const float4 * __restrict__ triangles = p.triangle_positions;
 
 	unsigned lane = threadIdx.x & (RT_WAVE_SIZE - 1);
 	unsigned wave = threadIdx.x / RT_WAVE_SIZE;
 
 	TraversalStack stack;
-	stack.lds  = shared_stack + wave * (RT_LDS_STACK * RT_WAVE_SIZE) + lane;
-	stack.size = 0;
+	stack.lds   = &shared_stack[wave * (RT_LDS_STACK * RT_WAVE_SIZE) + lane];
+	stack.spill_stride = int(gridDim.x * blockDim.x);
+	stack.spill = p.stack_spill + (blockIdx.x * blockDim.x + threadIdx.x);
+	stack.size  = 0;
+
+	// Only as many waves as there are 64-ray packets take part; the rest of the (machine-sized)
+	// persistent grid leaves without touching the shared cursor -- a same-address atomic costs
+	// ~15 ns in L2, i.e. ~80 us for a full grid, more than a small launch needs for its rays.
+	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * RT_WAVE_SIZE >= unsigned(ray_count)) return;
+	if (lane == 0) shared_drained[wave] = 0; // same wave reads it later: program order suffices
+	RayFetcher fetcher { xcd_counters, ray_count, int(xcc_id()), &shared_drained[wave] };
 
 	uint2 current_group = make_uint2(0, 0);
 
 	int  ray_index = 0;
-	Ray3 ray, ray_untransformed;
+	Ray3 ray;
 	f3   inv_dir;
 	unsigned oct_inv4 = 0;
 	float max_distance = 0.0f;
@@ -185,23 +263,16 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 	int  tlas_stack_size = RT_INVALID;
 	int  mesh_id = 0;
 	bool mesh_has_identity_transform = true;
+	unsigned count_nodes = 0, count_triangles = 0, count_inst_xform = 0, count_inst_ident = 0;
 
 	while (true) {
 		bool inactive = stack.size == 0 && current_group.y == 0;
 
 		if (inactive) {
-			// wave-aggregated ray fetch
-			unsigned long long want = __ballot(1);
-			unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(want >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(want), 0u));
-			int leader = __ffsll((long long)want) - 1;
-			int base = 0;
-			if (rank == 0) base = atomicAdd(rays_retired, __popcll(want));
-			base = __shfl(base, leader);
-			ray_index = base + int(rank);
-			if (ray_index >= ray_count) return;
+			ray_index = fetcher.fetch();
+			if (ray_index < 0) return;
 
 			src.load(ray_index, ray, max_distance);
-			ray_untransformed = ray;
 			inv_dir  = reciprocal(ray.direction);
 			oct_inv4 = ray_get_octant_inv4(ray.direction);
 
@@ -228,6 +299,7 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 
 				const float4 * node = nodes + size_t(child_node_index) * 5;
 				float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
+				if (COUNT) count_nodes++;
 
 				unsigned hitmask = bvh8_node_intersect(ray, inv_dir, oct_inv4, SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
 				unsigned imask = extract_byte(__float_as_uint(n0.w), 3);
@@ -260,12 +332,14 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 						ray.direction = transform_direction(m, ray.direction);
 						inv_dir  = reciprocal(ray.direction);
 						oct_inv4 = ray_get_octant_inv4(ray.direction);
-					}
+						if (COUNT) count_inst_xform++;
+					} else if (COUNT) count_inst_ident++;
 					current_group = make_uint2(root & 0x7fffffffu, 0x80000000u);
 					break;
 				} else {
 					int triangle_index = int(msb(triangle_group.y));
 					triangle_group.y &= ~(1u << triangle_index);
+					if (COUNT) count_triangles++;
 					if (triangle_test<SHADOW>(triangles, mesh_id, int(triangle_group.x) + triangle_index, ray, max_distance, hit)) {
 						occluded = true;
 						break;
@@ -273,6 +347,12 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 				}
 			}
 
+			if (COUNT && ((SHADOW && occluded) || ((current_group.y & 0xff000000u) == 0 && stack.size == 0))) {
+				atomicAdd(&stats[0], (unsigned long long)count_nodes);     atomicAdd(&stats[1], (unsigned long long)count_triangles);
+				atomicAdd(&stats[2], (unsigned long long)count_inst_xform); atomicAdd(&stats[3], (unsigned long long)count_inst_ident);
+				atomicAdd(&stats[4], 1ull);
+				count_nodes = count_triangles = count_inst_xform = count_inst_ident = 0;
+			}
 			if (SHADOW && occluded) {
 				src.finish(ray_index, hit, true);
 				stack.size = 0;
@@ -289,7 +369,8 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 				if (stack.size == tlas_stack_size) {
 					tlas_stack_size = RT_INVALID;
 					if (!mesh_has_identity_transform) {
-						ray = ray_untransformed;
+						float unused;
+						src.load(ray_index, ray, unused); // world-space ray again (kept in memory, not in registers)
 						inv_dir  = reciprocal(ray.direction);
 						oct_inv4 = ray_get_octant_inv4(ray.direction);
 					}
@@ -348,24 +429,34 @@ struct ShadowExplicitSource {
 
 // ---- kernels ---------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(RT_TRACE_BLOCK) kernel_trace_bvh8(RtParams p, int bounce) {
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_WAVES_PER_SIMD) kernel_trace_bvh8(RtParams p, int bounce) {
 	ClosestHitSource src { p.trace[bounce & 1].origin, p.trace[bounce & 1].direction, p.trace[bounce & 1].hits };
-	bvh8_trace_persistent<false>(p, src, p.sizes->trace[bounce], &p.sizes->rays_retired[bounce]);
+	bvh8_trace_persistent<false, false>(p, src, p.sizes->trace[bounce], p.xcd_counters + (2 * bounce) * RT_NUM_XCD);
 }
 
-__global__ void __launch_bounds__(RT_TRACE_BLOCK) kernel_trace_shadow_bvh8(RtParams p, int bounce) {
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_WAVES_PER_SIMD) kernel_trace_shadow_bvh8(RtParams p, int bounce) {
 	ShadowQueueSource src { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT], bounce };
-	bvh8_trace_persistent<true>(p, src, p.sizes->shadow[bounce], &p.sizes->rays_retired_shadow[bounce]);
+	bvh8_trace_persistent<true, false>(p, src, p.sizes->shadow[bounce], p.xcd_counters + (2 * bounce + 1) * RT_NUM_XCD);
 }
 
-__global__ void __launch_bounds__(RT_TRACE_BLOCK) kernel_trace_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_WAVES_PER_SIMD) kernel_trace_bvh8_counting(RtParams p, int bounce, unsigned long long * stats) {
+	ClosestHitSource src { p.trace[bounce & 1].origin, p.trace[bounce & 1].direction, p.trace[bounce & 1].hits };
+	bvh8_trace_persistent<false, true>(p, src, p.sizes->trace[bounce], p.xcd_counters + (2 * bounce) * RT_NUM_XCD, stats);
+}
+
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_WAVES_PER_SIMD) kernel_trace_shadow_bvh8_counting(RtParams p, int bounce, unsigned long long * stats) {
+	ShadowQueueSource src { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT], bounce };
+	bvh8_trace_persistent<true, true>(p, src, p.sizes->shadow[bounce], p.xcd_counters + (2 * bounce + 1) * RT_NUM_XCD, stats + 5);
+}
+
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_WAVES_PER_SIMD) kernel_trace_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {
 	ClosestHitSource src { origin, direction, hits };
-	bvh8_trace_persistent<false>(p, src, ray_count, retired);
+	bvh8_trace_persistent<false, false>(p, src, ray_count, retired);
 }
 
-__global__ void __launch_bounds__(RT_TRACE_BLOCK) kernel_trace_shadow_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, const float * max_distance, uint8_t * occluded, int ray_count, int * retired) {
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_WAVES_PER_SIMD) kernel_trace_shadow_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, const float * max_distance, uint8_t * occluded, int ray_count, int * retired) {
 	ShadowExplicitSource src { origin, direction, max_distance, occluded };
-	bvh8_trace_persistent<true>(p, src, ray_count, retired);
+	bvh8_trace_persistent<true, false>(p, src, ray_count, retired);
 }
 
 // Persistent grid: enough workgroups to fill every CU to the occupancy the kernel reaches,
@@ -374,13 +465,14 @@ static int trace_grid_size(const void * kernel) {
 	static int cached_cus = 0;
 	if (!cached_cus) {
 		int device = 0;
-		hipGetDevice(&device);
-		hipDeviceGetAttribute(&cached_cus, hipDeviceAttributeMultiprocessorCount, device);
+		(void)hipGetDevice(&device);
+		(void)hipDeviceGetAttribute(&cached_cus, hipDeviceAttributeMultiprocessorCount, device);
 		if (cached_cus <= 0) cached_cus = 256;
 	}
 	int blocks_per_cu = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, RT_TRACE_BLOCK, 0) != hipSuccess || blocks_per_cu <= 0) blocks_per_cu = 2;
 	if (blocks_per_cu > 8) blocks_per_cu = 8;
+	if (getenv("GRT_DEBUG")) fprintf(stderr, "[grt] trace kernel grid: %d CUs x %d workgroups of %d threads\n", cached_cus, blocks_per_cu, RT_TRACE_BLOCK);
 	return cached_cus * blocks_per_cu;
 }
 
@@ -391,6 +483,14 @@ void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream) {
 void rt_launch_trace_shadow(const RtParams & p, int bounce, hipStream_t stream) {
 	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8);
 	hipLaunchKernelGGL(kernel_trace_shadow_bvh8, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
+}
+void rt_launch_trace_counting(const RtParams & p, int bounce, unsigned long long * stats, hipStream_t stream) {
+	static int grid = trace_grid_size((const void *)kernel_trace_bvh8_counting);
+	hipLaunchKernelGGL(kernel_trace_bvh8_counting, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce, stats);
+}
+void rt_launch_trace_shadow_counting(const RtParams & p, int bounce, unsigned long long * stats, hipStream_t stream) {
+	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8_counting);
+	hipLaunchKernelGGL(kernel_trace_shadow_bvh8_counting, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce, stats);
 }
 void rt_launch_trace_explicit(const RtParams & p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired_counter, hipStream_t stream) {
 	static int grid = trace_grid_size((const void *)kernel_trace_bvh8_explicit);

@@ -23,7 +23,8 @@ struct rt_context {
 	std::vector<void *> owned;     // every hipMalloc'd pointer, freed in rt_destroy
 
 	// named allocations that get replaced on re-upload
-	void * triangles = nullptr, * bvh8_nodes = nullptr, * bvh2_nodes = nullptr;
+	void * triangles = nullptr, * triangle_positions = nullptr, * bvh8_nodes = nullptr, * bvh2_nodes = nullptr;
+	void * stack_spill = nullptr; int * xcd_counters = nullptr;
 	size_t bvh8_node_count = 0, bvh2_node_count = 0, triangle_count = 0;
 	void * instances[5] = { };     size_t mesh_count = 0;
 	void * material_types = nullptr, * materials = nullptr, * media = nullptr;
@@ -48,10 +49,15 @@ struct rt_context {
 	int * explicit_retired = nullptr;
 
 	bool queues_allocated = false;
+	size_t queue_capacity = 0;               // entries per queue
+	int batch_size_request = 0;              // 0 = whole frame (288 GB of HBM: no reason to cut a frame into pieces)
 	int pixel_offset = 0, pixel_count = -1;  // -1 = whole frame
 
 	rt_counters last_counters;
 	bool profiling = false;
+	bool trace_statistics = false;
+	unsigned long long * trace_stats = nullptr;    // device, 10 x u64
+	unsigned long long host_trace_stats[10] = { };
 	hipEvent_t ev_frame_start = nullptr, ev_frame_end = nullptr;
 	std::vector<hipEvent_t> stage_events; std::vector<int> stage_kinds; size_t stage_used = 0;
 };
@@ -113,7 +119,12 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 
 	int s = device_alloc(ctx, (void **)&ctx->sizes, sizeof(RtBufferSizes)); if (s) return s;
 	s = device_alloc(ctx, (void **)&ctx->counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int)); if (s) return s;
-	s = device_alloc(ctx, (void **)&ctx->explicit_retired, 16); if (s) return s;
+	s = device_alloc(ctx, (void **)&ctx->explicit_retired, 8 * sizeof(int)); if (s) return s;
+	s = device_alloc(ctx, (void **)&ctx->xcd_counters, RT_MAX_BOUNCES * 2 * 8 * sizeof(int)); if (s) return s;
+	// spill area for traversal stacks deeper than the LDS part: 24 entries x 8 B x (256 CUs x 8 workgroups x 256 lanes)
+	s = device_alloc(ctx, &ctx->stack_spill, size_t(24) * 8 * 256 * 8 * 256); if (s) return s;
+	ctx->params.xcd_counters = ctx->xcd_counters;
+	ctx->params.stack_spill  = (uint2 *)ctx->stack_spill;
 	RT_HIP(ctx, hipHostMalloc((void **)&ctx->pinned_counters, sizeof(RtBufferSizes)));
 	ctx->params.sizes = ctx->sizes;
 
@@ -144,8 +155,15 @@ int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle
 	(void)hipSetDevice(ctx->device);
 	int s = upload(ctx, &ctx->triangles, triangles, triangle_count * 96); if (s) return s;
 	s = upload(ctx, &ctx->bvh8_nodes, bvh8_nodes, node_count * 80); if (s) return s;
+	{ // traversal copy: positions only, 48 B stride (first 36 B of each 96 B triangle + 12 B pad)
+		std::vector<float> positions(triangle_count * 12, 0.0f);
+		const float * src = (const float *)triangles;
+		for (size_t t = 0; t < triangle_count; t++) memcpy(&positions[t * 12], src + t * 24, 36);
+		s = upload(ctx, &ctx->triangle_positions, positions.data(), triangle_count * 48); if (s) return s;
+	}
 	ctx->triangle_count = triangle_count; ctx->bvh8_node_count = node_count;
 	ctx->params.triangles  = (const float4 *)ctx->triangles;
+	ctx->params.triangle_positions = (const float4 *)ctx->triangle_positions;
 	ctx->params.bvh8_nodes = (const float4 *)ctx->bvh8_nodes;
 	return RT_OK;
 }
@@ -306,9 +324,25 @@ static int alloc_vec3(rt_context * ctx, RtVec3SoA & v, size_t n) {
 	return device_alloc(ctx, (void **)&v.z, n * 4);
 }
 
+static size_t wanted_batch_size(const rt_context * ctx) {
+	size_t frame = size_t(ctx->params.screen_width) * ctx->params.screen_height;
+	size_t n = ctx->batch_size_request > 0 ? size_t(ctx->batch_size_request) : frame;
+	if (n < 1) n = 1;
+	return n;
+}
+
 static int ensure_queues(rt_context * ctx) {
-	if (ctx->queues_allocated) return RT_OK;
-	size_t n = RT_BATCH_SIZE;
+	size_t n = wanted_batch_size(ctx);
+	if (ctx->queues_allocated && ctx->queue_capacity >= n) return RT_OK;
+	if (ctx->queues_allocated) { // grow: release the old queues
+		RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		auto free3 = [&](RtVec3SoA & v) { device_free(ctx, v.x); device_free(ctx, v.y); device_free(ctx, v.z); };
+		for (int i = 0; i < 2; i++) { RtTraceBuffer & t = ctx->params.trace[i]; free3(t.origin); free3(t.direction); device_free(ctx, t.hits); device_free(ctx, t.cone_angle); device_free(ctx, t.cone_width); device_free(ctx, t.medium); device_free(ctx, t.pixel_index_and_flags); free3(t.throughput); device_free(ctx, t.last_pdf); }
+		for (int i = 0; i < 4; i++) { RtMaterialBuffer & m = ctx->params.material[i]; free3(m.direction); device_free(ctx, m.hits); device_free(ctx, m.cone_angle); device_free(ctx, m.cone_width); device_free(ctx, m.medium); device_free(ctx, m.pixel_index_and_flags); free3(m.throughput); }
+		RtShadowBuffer & sh = ctx->params.shadow; free3(sh.origin); free3(sh.direction); device_free(ctx, sh.max_distance); device_free(ctx, sh.illumination_and_pixel_index);
+		ctx->queues_allocated = false;
+	}
+	ctx->queue_capacity = n;
 	int s;
 	for (int i = 0; i < 2; i++) {
 		RtTraceBuffer & t = ctx->params.trace[i];
@@ -441,6 +475,56 @@ int rt_set_pixel_range(rt_context * ctx, int pixel_offset, int pixel_count) {
 	RT_REQUIRE(ctx, ctx && pixel_offset >= 0, "rt_set_pixel_range: invalid argument");
 	ctx->pixel_offset = pixel_offset;
 	ctx->pixel_count  = pixel_count;
+	ctx->params.tile_pixels = 0;
+	return RT_OK;
+}
+
+int rt_set_pixel_tiles(rt_context * ctx, int tile_pixels, int first_tile, int tile_stride) {
+	RT_REQUIRE(ctx, ctx && tile_pixels > 0 && first_tile >= 0 && tile_stride > 0 && first_tile < tile_stride, "rt_set_pixel_tiles: invalid argument");
+	ctx->params.tile_pixels = tile_pixels;
+	ctx->params.tile_first  = first_tile;
+	ctx->params.tile_stride = tile_stride;
+	return RT_OK;
+}
+
+int rt_pack_pixels(rt_context * ctx, void * dst_device, int tile_pixels, int first_tile, int tile_stride, int tiles) {
+	RT_REQUIRE(ctx, ctx && dst_device && tile_pixels > 0 && tile_stride > 0 && tiles >= 0, "rt_pack_pixels: invalid argument");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->final_image) return fail(ctx, RT_ERROR_NOT_READY, "rt_pack_pixels: rt_resize was not called");
+	rt_launch_pack_pixels(ctx->params, (float4 *)dst_device, tile_pixels, first_tile, tile_stride, tiles, ctx->stream);
+	RT_HIP(ctx, hipGetLastError());
+	return RT_OK;
+}
+
+int rt_unpack_pixels(rt_context * ctx, const void * src_device, int tile_pixels, int world, int tiles_per_rank) {
+	RT_REQUIRE(ctx, ctx && src_device && tile_pixels > 0 && world > 0 && tiles_per_rank > 0, "rt_unpack_pixels: invalid argument");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->final_image) return fail(ctx, RT_ERROR_NOT_READY, "rt_unpack_pixels: rt_resize was not called");
+	rt_launch_unpack_pixels(ctx->params, (const float4 *)src_device, tile_pixels, world, tiles_per_rank, ctx->stream);
+	RT_HIP(ctx, hipGetLastError());
+	return RT_OK;
+}
+
+int rt_set_trace_statistics(rt_context * ctx, int enable) {
+	RT_REQUIRE(ctx, ctx, "rt_set_trace_statistics: NULL context");
+	(void)hipSetDevice(ctx->device);
+	if (enable && !ctx->trace_stats) { int s = device_alloc(ctx, (void **)&ctx->trace_stats, 10 * sizeof(unsigned long long)); if (s) return s; }
+	ctx->trace_statistics = enable != 0;
+	return RT_OK;
+}
+
+int rt_get_trace_statistics(rt_context * ctx, uint64_t * out10) {
+	RT_REQUIRE(ctx, ctx && out10, "rt_get_trace_statistics: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->trace_stats) return fail(ctx, RT_ERROR_NOT_READY, "rt_get_trace_statistics: statistics were never enabled");
+	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, hipMemcpy(out10, ctx->trace_stats, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_set_batch_size(rt_context * ctx, int batch_size) {
+	RT_REQUIRE(ctx, ctx && batch_size >= 0, "rt_set_batch_size: invalid argument");
+	ctx->batch_size_request = batch_size;
 	return RT_OK;
 }
 
@@ -506,15 +590,25 @@ int rt_render_sample(rt_context * ctx, int sample_index) {
 	int frame_pixels = p.screen_width * p.screen_height;
 	int range_offset = ctx->pixel_offset;
 	int range_count  = ctx->pixel_count < 0 ? frame_pixels - range_offset : ctx->pixel_count;
-	if (range_offset + range_count > frame_pixels) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_sample: pixel range [%d,%d) exceeds the %d pixel frame", range_offset, range_offset + range_count, frame_pixels);
+	if (p.tile_pixels > 0) { // tile mode: local pixels 0..count-1 are mapped to this context's tiles by rt_map_pixel
+		int tiles_total = (frame_pixels + p.tile_pixels - 1) / p.tile_pixels;
+		int owned = p.tile_first < tiles_total ? (tiles_total - p.tile_first + p.tile_stride - 1) / p.tile_stride : 0;
+		range_offset = 0;
+		range_count = owned * p.tile_pixels;
+		int last_tile = p.tile_first + (owned - 1) * p.tile_stride;
+		if (owned > 0 && last_tile == tiles_total - 1) range_count -= tiles_total * p.tile_pixels - frame_pixels; // clipped last tile
+	}
+	if (p.tile_pixels == 0 && range_offset + range_count > frame_pixels) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_sample: pixel range [%d,%d) exceeds the %d pixel frame", range_offset, range_offset + range_count, frame_pixels);
 
 	hipStream_t st = ctx->stream;
 	ctx->stage_used = 0;
 	RT_HIP(ctx, hipEventRecord(ctx->ev_frame_start, st));
 	RT_HIP(ctx, hipMemsetAsync(ctx->counter_totals, 0, 6 * RT_MAX_BOUNCES * sizeof(int), st));
+	if (ctx->trace_statistics) RT_HIP(ctx, hipMemsetAsync(ctx->trace_stats, 0, 10 * sizeof(unsigned long long), st));
 
 	int pixels_left = range_count;
-	int batch_size  = range_count < RT_BATCH_SIZE ? range_count : RT_BATCH_SIZE;
+	int batch_limit = int(wanted_batch_size(ctx));
+	int batch_size  = range_count < batch_limit ? range_count : batch_limit;
 	bool trace_shadows = ctx->has_lights && p.config.enable_next_event_estimation && p.lights_total_weight > 0.0f;
 
 	while (pixels_left > 0) {
@@ -522,19 +616,22 @@ int rt_render_sample(rt_context * ctx, int sample_index) {
 		int pixel_count  = batch_size < pixels_left ? batch_size : pixels_left;
 
 		RT_HIP(ctx, hipMemsetAsync(ctx->sizes, 0, sizeof(RtBufferSizes), st));
+		RT_HIP(ctx, hipMemsetAsync(ctx->xcd_counters, 0, RT_MAX_BOUNCES * 2 * 8 * sizeof(int), st));
 		stage_mark(ctx, STAGE_GENERATE);
 		rt_launch_generate(p, sample_index, pixel_offset, pixel_count, st);
 
 		for (int bounce = 0; bounce < p.config.num_bounces; bounce++) {
 			stage_mark(ctx, STAGE_TRACE);
-			rt_launch_trace(p, bounce, st);
+			if (ctx->trace_statistics) rt_launch_trace_counting(p, bounce, ctx->trace_stats, st);
+			else rt_launch_trace(p, bounce, st);
 			stage_mark(ctx, STAGE_SORT);
 			rt_launch_sort(p, bounce, sample_index, st);
 			stage_mark(ctx, STAGE_SHADE);
 			for (int m = 0; m < 4; m++) if (ctx->has_material[m]) rt_launch_material(p, m, bounce, sample_index, st);
 			if (trace_shadows) {
 				stage_mark(ctx, STAGE_SHADOW);
-				rt_launch_trace_shadow(p, bounce, st);
+				if (ctx->trace_statistics) rt_launch_trace_shadow_counting(p, bounce, ctx->trace_stats, st);
+				else rt_launch_trace_shadow(p, bounce, st);
 			}
 		}
 		hipLaunchKernelGGL(kernel_accumulate_counters, dim3(1), dim3(RT_MAX_BOUNCES), 0, st, ctx->sizes, ctx->counter_totals);
@@ -665,7 +762,7 @@ int rt_trace_rays(rt_context * ctx, const float * ox, const float * oy, const fl
 	hipEvent_t e0, e1; RT_HIP(ctx, hipEventCreate(&e0)); RT_HIP(ctx, hipEventCreate(&e1));
 	float total = 0.0f;
 	for (int r = 0; r < repeat; r++) {
-		RT_HIP(ctx, hipMemsetAsync(ctx->explicit_retired, 0, 4, ctx->stream));
+		RT_HIP(ctx, hipMemsetAsync(ctx->explicit_retired, 0, 8 * sizeof(int), ctx->stream));
 		RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
 		rt_launch_trace_explicit(ctx->params, o, d, dev_hits, int(ray_count), ctx->explicit_retired, ctx->stream);
 		RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -698,7 +795,7 @@ int rt_trace_shadow_rays(rt_context * ctx, const float * ox, const float * oy, c
 	hipEvent_t e0, e1; RT_HIP(ctx, hipEventCreate(&e0)); RT_HIP(ctx, hipEventCreate(&e1));
 	float total = 0.0f;
 	for (int r = 0; r < repeat; r++) {
-		RT_HIP(ctx, hipMemsetAsync(ctx->explicit_retired, 0, 4, ctx->stream));
+		RT_HIP(ctx, hipMemsetAsync(ctx->explicit_retired, 0, 8 * sizeof(int), ctx->stream));
 		RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
 		rt_launch_trace_shadow_explicit(ctx->params, o, d, dev_max, dev_occ, int(ray_count), ctx->explicit_retired, ctx->stream);
 		RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -716,10 +813,11 @@ int rt_trace_shadow_rays(rt_context * ctx, const float * ox, const float * oy, c
 int rt_generate_rays(rt_context * ctx, int sample_index, int pixel_offset, int pixel_count,
                      float * ox, float * oy, float * oz, float * dx, float * dy, float * dz, uint32_t * pixel_index_and_flags) {
 	RT_REQUIRE(ctx, ctx && ox && oy && oz && dx && dy && dz && pixel_index_and_flags, "rt_generate_rays: NULL argument");
-	RT_REQUIRE(ctx, pixel_count >= 0 && pixel_count <= RT_BATCH_SIZE, "rt_generate_rays: pixel_count exceeds RT_BATCH_SIZE");
+	RT_REQUIRE(ctx, pixel_count >= 0, "rt_generate_rays: negative pixel_count");
 	(void)hipSetDevice(ctx->device);
 	if (!ctx->params.pmj_samples || ctx->frame_pixels == 0) return fail(ctx, RT_ERROR_NOT_READY, "rt_generate_rays: RNG tables not uploaded or rt_resize not called");
 	int s = ensure_queues(ctx); if (s) return s;
+	if (size_t(pixel_count) > ctx->queue_capacity) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_generate_rays: pixel_count %d exceeds the queue capacity %zu", pixel_count, ctx->queue_capacity);
 	rt_launch_generate(ctx->params, sample_index, pixel_offset, pixel_count, ctx->stream);
 	RT_HIP(ctx, hipGetLastError());
 	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -71,7 +71,8 @@ struct RtAOV { float4 * framebuffer, * accumulator; };
 // can coexist in one process).
 struct RtParams {
 	// geometry
-	const float4 * triangles;
+	const float4 * triangles;            // 6 float4: full shading triangle
+	const float4 * triangle_positions;   // 3 float4: position_0, edge_1, edge_2 (traversal copy)
 	const float4 * bvh8_nodes;
 	const float4 * bvh2_nodes;  // 2 float4 per node
 	const int    * mesh_bvh_root_indices;
@@ -106,11 +107,15 @@ struct RtParams {
 	rt_gpu_config config;
 	float view_projection[16], view_projection_prev[16];
 	int screen_width, screen_height, screen_pitch;
+	// multi-GPU tile split: local pixel i -> scan-order pixel (tile_pixels == 0: identity)
+	int tile_pixels, tile_first, tile_stride;
 	// queues
 	RtTraceBuffer    trace[2];
 	RtMaterialBuffer material[4];   // diffuse, plastic, dielectric, conductor
 	RtShadowBuffer   shadow;
 	RtBufferSizes  * sizes;
+	int   * xcd_counters;               // [RT_MAX_BOUNCES][2 (closest, shadow)][8 XCDs] ray-fetch cursors
+	uint2 * stack_spill;                // traversal stack entries beyond the LDS part, [entry][grid lane]
 	// outputs
 	RtAOV    aovs[RT_AOV_COUNT];
 	float4 * final_image;           // the reference's `accumulator` surface
@@ -124,6 +129,13 @@ struct RtParams {
 	float4 * taa_frame_prev, * taa_frame_curr;
 	float4 * taa_scratch;
 };
+
+// Scan-order index of local pixel i of this context: its tiles are tile_first, tile_first +
+// tile_stride, ... each tile_pixels long (whole rows), see gpu-raytracer_amd/parallel.py.
+__device__ __forceinline__ int rt_map_pixel(const RtParams & p, int i) {
+	if (p.tile_pixels == 0) return i;
+	return ((i / p.tile_pixels) * p.tile_stride + p.tile_first) * p.tile_pixels + i % p.tile_pixels;
+}
 
 #define RT_FLAG_ALLOW_NEE     (1u << 31)
 #define RT_FLAG_INSIDE_MEDIUM (1u << 30)
@@ -140,7 +152,12 @@ void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream
 void rt_launch_random(const RtParams & p, int dimension, const unsigned * pixel_indices, int count, unsigned bounce, unsigned sample_index, float2 * out, hipStream_t stream);
 void rt_launch_integrate_luts(const RtParams & p, float * dielectric_dir_enter, float * dielectric_dir_leave, float * dielectric_enter, float * dielectric_leave,
                               float * conductor_dir, float * conductor, hipStream_t stream);
+void rt_launch_pack_pixels(const RtParams & p, float4 * dst, int tile_pixels, int tile_first, int tile_stride, int tiles, hipStream_t stream);
+void rt_launch_unpack_pixels(const RtParams & p, const float4 * src, int tile_pixels, int world, int tiles_per_rank, hipStream_t stream);
 void rt_launch_stream_read(const float4 * src, size_t count, float * sink, hipStream_t stream);
+// Counting variants: stats = 10 x u64 {closest: nodes, triangles, inst_xform, inst_ident, rays; shadow: same}
+void rt_launch_trace_counting(const RtParams & p, int bounce, unsigned long long * stats, hipStream_t stream);
+void rt_launch_trace_shadow_counting(const RtParams & p, int bounce, unsigned long long * stats, hipStream_t stream);
 // Stand-alone trace on explicit ray arrays (rt_trace_rays / rt_trace_shadow_rays)
 void rt_launch_trace_explicit(const RtParams & p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired_counter, hipStream_t stream);
 void rt_launch_trace_shadow_explicit(const RtParams & p, RtVec3SoA origin, RtVec3SoA direction, const float * max_distance, uint8_t * occluded, int ray_count, int * retired_counter, hipStream_t stream);

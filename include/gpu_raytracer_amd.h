@@ -178,6 +178,23 @@ int rt_set_config(rt_context * ctx, const rt_gpu_config * config);
  * Pathtracer.cu:122-131). Default = whole frame.                                          */
 int rt_set_pixel_range(rt_context * ctx, int pixel_offset, int pixel_count);
 
+/* Interleaved variant for load balance: this context owns tiles first_tile, first_tile +
+ * tile_stride, ... of `tile_pixels` consecutive scan-order pixels each (whole rows).
+ * rt_set_pixel_range switches back to one contiguous range.                                */
+int rt_set_pixel_tiles(rt_context * ctx, int tile_pixels, int first_tile, int tile_stride);
+/* Frame exchange for the tile split (both asynchronous on the context's stream, DEVICE pointers):
+ * pack   copies this context's `tiles` tiles of the final image into dst (tiles*tile_pixels
+ *        float4, zero padded) -- the send buffer of one all-gather over RCCL;
+ * unpack scatters the all-gathered buffer [world][tiles_per_rank*tile_pixels] float4 back into
+ *        the final image in scan order.                                                       */
+int rt_pack_pixels(rt_context * ctx, void * dst_device, int tile_pixels, int first_tile, int tile_stride, int tiles);
+int rt_unpack_pixels(rt_context * ctx, const void * src_device, int tile_pixels, int world, int tiles_per_rank);
+
+/* Pixels per wavefront batch. The reference hard-codes BATCH_SIZE = 1080*720 to bound VRAM
+ * (Common.h:69-71) and loops over batches; results do not depend on it. Default 0 = the whole
+ * frame in one batch (MI355X has 288 GB of HBM; bigger launches hide traversal latency better). */
+int rt_set_batch_size(rt_context * ctx, int batch_size);
+
 /* ---- render: replaces Pathtracer::render (Pathtracer.cpp:738-855) ---------------------- */
 /* One sample for this context's pixel range: generate, (trace, sort, shade*, shadow) x
  * bounces, then accumulate or SVGF/TAA.  Asynchronous; rt_synchronize or a read waits.    */
@@ -187,6 +204,13 @@ int rt_synchronize(rt_context * ctx);
  * kernel launch, so it is opt-in; ms_total is always measured. Replaces the CUDAEventPool
  * instrumentation of the reference (Pathtracer.cpp:751-843, Device/CUDAEvent.h:31-53).      */
 int rt_set_profiling(rt_context * ctx, int enable);
+/* Work statistics of the trace kernels: when enabled, rt_render_sample runs counting variants
+ * of kernel_trace(_shadow)_bvh8 (slower: per-ray atomics) and rt_get_trace_statistics returns,
+ * for the last sample, 10 x u64 {closest-hit: BVH8 nodes fetched, triangles tested, transformed
+ * instance entries, identity instance entries, rays; then the same five for shadow rays}.
+ * These are the N_node / N_tri / N_inst of the algorithmic-bytes roofline.     */
+int rt_set_trace_statistics(rt_context * ctx, int enable);
+int rt_get_trace_statistics(rt_context * ctx, uint64_t * out10);
 /* Counters of the most recent completed rt_render_sample (synchronous).                    */
 int rt_get_counters(rt_context * ctx, rt_counters * out);
 

@@ -210,6 +210,19 @@ def test_render_is_deterministic_and_split_invariant(grt):
     pt.close(); scene.close()
 
 
+def test_batch_size_does_not_change_the_image(grt):
+    """The reference's BATCH_SIZE loop (Pathtracer.cpp:746-796) vs one whole-frame batch: same pixels."""
+    import ctypes
+    scene, pt = make_pathtracer(grt, "cornellbox", 300, 200, 0, num_bounces=4)
+    lib = grt.device_lib()
+    lib.rt_set_batch_size.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    pt.render(); whole = pt.read_framebuffer().copy(); c0 = pt.counters()
+    assert lib.rt_set_batch_size(pt.ctx, 7777) == 0
+    pt.render(); pieces = pt.read_framebuffer().copy(); c1 = pt.counters()
+    assert np.array_equal(whole, pieces) and list(c0.trace[:4]) == list(c1.trace[:4])
+    pt.close(); scene.close()
+
+
 def test_device_errors_are_reported(grt):
     import ctypes
     lib = grt.device_lib()
@@ -218,3 +231,66 @@ def test_device_errors_are_reported(grt):
     assert lib.rt_render_sample(ctx, 0) != 0 and b"not uploaded" in lib.rt_last_error(ctx)
     assert lib.rt_create(9999, ctypes.byref(ctypes.c_void_p())) != 0
     lib.rt_destroy(ctx)
+
+
+def test_tile_split_pack_unpack_rebuilds_the_frame(grt):
+    """The multi-GPU path on one GPU: render the tiles of 3 virtual ranks one after the other
+    (rt_set_pixel_tiles), pack each rank's tiles, concatenate as an all-gather would, unpack:
+    the frame must equal the single-range render bit for bit."""
+    import ctypes
+    import importlib
+    import torch
+    parallel = importlib.import_module("gpu_raytracer_amd.parallel")
+    W, H, world = 400, 230, 3
+    scene, pt = make_pathtracer(grt, "cornellbox", W, H, 0, num_bounces=4)
+    lib, ctx = grt.device_lib(), pt.ctx
+    lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.rt_pack_pixels.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.rt_unpack_pixels.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    pt.render()
+    full = pt.read_framebuffer().copy()
+    rays_full = sum(pt.counters().trace[:4])
+
+    gathered = torch.zeros((0, 4), device="cuda")
+    rays = 0
+    for rank in range(world):
+        split = parallel.TileSplit(rank, world, W, H)
+        assert lib.rt_set_pixel_tiles(ctx, split.tile_pixels, rank, world) == 0
+        pt.render()
+        rays += sum(pt.counters().trace[:4])
+        packed = torch.zeros((split.local_pixels, 4), device="cuda")
+        assert lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, world, split.tiles_per_rank) == 0
+        assert lib.rt_synchronize(ctx) == 0
+        gathered = torch.cat([gathered, packed])
+        # the torch-side unpack used by bench.py agrees with the device-side one (checked below)
+    assert rays == rays_full
+    split = parallel.TileSplit(0, world, W, H)
+    assert np.array_equal(split.unpack(gathered).cpu().numpy(), full[:, :W, :])
+    # wipe the frame, then scatter the gathered tiles back on the device
+    lib.rt_set_pixel_range(ctx, 0, 0)
+    zeros = torch.zeros_like(gathered)
+    assert lib.rt_unpack_pixels(ctx, zeros.data_ptr(), split.tile_pixels, world, split.tiles_per_rank) == 0
+    assert lib.rt_synchronize(ctx) == 0 and not pt.read_framebuffer().any()
+    assert lib.rt_unpack_pixels(ctx, gathered.data_ptr(), split.tile_pixels, world, split.tiles_per_rank) == 0
+    assert lib.rt_synchronize(ctx) == 0
+    assert np.array_equal(pt.read_framebuffer()[:, :W], full[:, :W])
+    pt.close(); scene.close()
+
+
+def test_trace_statistics_equal_the_oracle_counters(grt, oracle):
+    """N_node / N_tri / N_inst of the roofline: the counting kernel visits exactly the nodes and
+    triangles the sequential algorithm visits."""
+    scene, pt = make_pathtracer(grt, "sponza", 240, 135, 0, num_bounces=3)
+    view = oracle.SceneView(pt)
+    frame = oracle.Frame(view)
+    grt.set_trace_statistics(pt.ctx, True)
+    pt.render()
+    stats = grt.get_trace_statistics(pt.ctx)
+    grt.set_trace_statistics(pt.ctx, False)
+    oc = frame.render_sample(pt.sample_index)
+    assert stats["closest"]["rays"] == oc.trace_stats.rays == sum(pt.counters().trace[:3])
+    for key, ref in (("nodes", oc.trace_stats.nodes), ("triangles", oc.trace_stats.triangles), ("instances_identity", oc.trace_stats.instances_identity)):
+        assert abs(stats["closest"][key] - ref) <= 1e-3 * ref, key   # identical up to the few ulp-diverged paths
+    assert abs(stats["shadow"]["nodes"] - oc.shadow_stats.nodes) <= 2e-3 * oc.shadow_stats.nodes
+    assert abs(stats["closest"]["algorithmic_bytes"] - oc.trace_stats.algorithmic_bytes()) <= 1e-3 * oc.trace_stats.algorithmic_bytes()
+    pt.close(); scene.close()
