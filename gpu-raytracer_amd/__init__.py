@@ -267,7 +267,7 @@ _ARRAY_DTYPES = {
     "tlas_raw_nodes": np.uint8, "pmj_samples": np.float32, "blue_noise": np.uint8,
     "light_triangle_indices": np.int32, "light_triangle_cumulative_probability": np.float32,
     "light_mesh_cumulative_probability": np.float32, "light_mesh_triangle_span": np.int32,
-    "light_mesh_transform_indices": np.int32, "sky": np.float32, "camera": np.uint8,
+    "light_mesh_transform_indices": np.int32, "sky": np.float32, "camera": np.uint8, "svgf_matrices": np.float32,
 }
 
 
@@ -326,6 +326,11 @@ class Pathtracer:
         n = c_size_t()
         ptr = host_lib().grt_pathtracer_array(self.handle, name.encode(), byref(n))
         return _view(ptr, n.value, _ARRAY_DTYPES[name])
+
+    def view_projection(self):
+        """(view_projection, view_projection_prev) as uploaded for SVGF, 16 row-major floats each."""
+        m = self.array("svgf_matrices")
+        return m[:16].tolist(), m[16:].tolist()
 
     def camera(self):
         cam = Camera()

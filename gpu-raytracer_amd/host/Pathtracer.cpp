@@ -183,7 +183,9 @@ void Pathtracer::update(float delta) {
 	bool invalidated_light_mesh_weights = invalidated_scene;
 
 	if (gpu_config.enable_svgf) {
-		if (ctx) check(rt_set_svgf_matrices(ctx, scene.camera.view_projection.cells, scene.camera.view_projection_prev.cells));
+		memcpy(&svgf_matrices[0],  scene.camera.view_projection.cells,      64);
+		memcpy(&svgf_matrices[16], scene.camera.view_projection_prev.cells, 64);
+		if (ctx) check(rt_set_svgf_matrices(ctx, &svgf_matrices[0], &svgf_matrices[16]));
 		if (invalidated_aovs && !aov_is_enabled(AOVType::ALBEDO)) aov_enable(AOVType::ALBEDO);
 	}
 

@@ -14,6 +14,9 @@ struct Pathtracer final : Integrator {
 	std::vector<int>   light_mesh_transform_indices;  // TLAS-order mesh id per light mesh
 	float              lights_total_weight = 0.0f;
 
+	// The SVGFData pair last handed to the device (reference: Pathtracer.cpp:707-717)
+	std::vector<float> svgf_matrices = std::vector<float>(32, 0.0f);
+
 	Pathtracer(int width, int height, Scene & scene, int device_ordinal = 0) : Integrator(scene, device_ordinal) {
 		gpu_init(width, height);
 	}

@@ -214,6 +214,7 @@ const void * grt_pathtracer_array(void * pt, const char * name, size_t * bytes) 
 	if (n == "light_mesh_triangle_span")              RET(p->light_mesh_triangle_span)
 	if (n == "light_mesh_transform_indices")          RET(p->light_mesh_transform_indices)
 	if (n == "sky")                   RET(p->scene.sky.data)
+	if (n == "svgf_matrices")         RET(p->svgf_matrices)
 	if (n == "camera") { *bytes = sizeof(rt_camera); return &p->device_camera; }
 	*bytes = 0;
 	return nullptr;

@@ -100,6 +100,10 @@ def lib():
         l.oracle_generate.argtypes = [POINTER(OracleScene), c_int, c_int, c_int] + [c_void_p] * 7
         l.oracle_random.argtypes = [POINTER(OracleScene), c_int, c_void_p, c_size_t, c_uint32, c_uint32, c_void_p]
         l.oracle_render_sample.argtypes = [POINTER(OracleScene), POINTER(OracleFrame), c_int, c_int, c_int, POINTER(OracleCounters), c_int]
+        l.oracle_integrate_dielectric_cells.argtypes = [POINTER(OracleScene), c_int, c_int, c_int, c_int, c_void_p, c_int]
+        l.oracle_integrate_conductor_cells.argtypes = [POINTER(OracleScene), c_int, c_int, c_int, c_void_p, c_int]
+        l.oracle_average_dielectric.argtypes = [c_void_p, c_void_p]
+        l.oracle_average_conductor.argtypes = [c_void_p, c_void_p]
         _lib = l
     return _lib
 
@@ -215,11 +219,33 @@ class SceneView:
         lib().oracle_generate(byref(self.scene), sample_index, pixel_offset, pixel_count, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data, d[0].ctypes.data, d[1].ctypes.data, d[2].ctypes.data, px.ctypes.data)
         return o, d, px
 
+    def integrate_dielectric_cells(self, entering, first_cell, cell_count, num_samples=100000, threads=0):
+        out = np.zeros(cell_count, np.float32)
+        lib().oracle_integrate_dielectric_cells(byref(self.scene), 1 if entering else 0, num_samples, first_cell, cell_count, out.ctypes.data, threads)
+        return out
+
+    def integrate_conductor_cells(self, first_cell, cell_count, num_samples=100000, threads=0):
+        out = np.zeros(cell_count, np.float32)
+        lib().oracle_integrate_conductor_cells(byref(self.scene), num_samples, first_cell, cell_count, out.ctypes.data, threads)
+        return out
+
     def random(self, dimension, pixel_indices, bounce, sample_index):
         px = np.ascontiguousarray(pixel_indices, np.uint32)
         out = np.zeros((px.size, 2), np.float32)
         lib().oracle_random(byref(self.scene), dimension, px.ctypes.data, px.size, bounce, sample_index, out.ctypes.data)
         return out
+
+
+def average_dielectric(directional):
+    d = np.ascontiguousarray(directional, np.float32); out = np.zeros(256, np.float32)
+    lib().oracle_average_dielectric(d.ctypes.data, out.ctypes.data)
+    return out
+
+
+def average_conductor(directional):
+    d = np.ascontiguousarray(directional, np.float32); out = np.zeros(32, np.float32)
+    lib().oracle_average_conductor(d.ctypes.data, out.ctypes.data)
+    return out
 
 
 class Frame:

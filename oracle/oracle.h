@@ -141,10 +141,14 @@ void oracle_random(const oracle_scene * scene, int dimension, const uint32_t * p
 void oracle_render_sample(const oracle_scene * scene, oracle_frame * frame, int sample_index,
                           int pixel_offset, int pixel_count, oracle_counters * counters, int threads);
 /* Kulla-Conty LUT integration kernels (KullaConty.h:83-240); num_samples = 100000 in the reference. */
-/* entering: 1 = air->material. out_directional: 16^3, out_albedo: 16^2 */
-void oracle_integrate_dielectric_lut(const oracle_scene * scene, int entering, int num_samples, float * out_directional, float * out_albedo, int threads);
-/* out_directional: 32^2, out_albedo: 32 */
-void oracle_integrate_conductor_lut(const oracle_scene * scene, int num_samples, float * out_directional, float * out_albedo, int threads);
+/* kernel_integrate_dielectric / kernel_integrate_conductor (KullaConty.h:83-148,179-226) for the
+ * LUT cells [first_cell, first_cell + cell_count) (thread_index of the CUDA kernel); num_samples
+ * = 100000 in the reference. entering: 1 = air -> material. */
+void oracle_integrate_dielectric_cells(const oracle_scene * scene, int entering, int num_samples, int first_cell, int cell_count, float * out, int threads);
+void oracle_integrate_conductor_cells(const oracle_scene * scene, int num_samples, int first_cell, int cell_count, float * out, int threads);
+/* kernel_average_dielectric / kernel_average_conductor (KullaConty.h:150-165,228-240) */
+void oracle_average_dielectric(const float * directional_16x16x16, float * out_16x16);
+void oracle_average_conductor(const float * directional_32x32, float * out_32);
 
 #ifdef __cplusplus
 }

@@ -95,8 +95,8 @@ static inline void clamp_taps(float coord, int n, int & i0, int & i1, float & f)
 	float x0 = floorf(x);
 	f = x - x0;
 	i0 = int(x0); i1 = i0 + 1;
-	if (i0 < 0) i0 = 0; if (i0 > n - 1) i0 = n - 1;
-	if (i1 < 0) i1 = 0; if (i1 > n - 1) i1 = n - 1;
+	i0 = i0 < 0 ? 0 : (i0 > n - 1 ? n - 1 : i0);
+	i1 = i1 < 0 ? 0 : (i1 > n - 1 ? n - 1 : i1);
 }
 static inline float lut_get_1d(const float * lut, int nx, float s) {
 	int a, b; float f; clamp_taps(s, nx, a, b, f);
