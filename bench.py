@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--steps", type=int, default=32)   # PerfTest BUFFER_SIZE = 32 frames (Util/PerfTest.h:9)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--samples-in-flight", type=int, default=2, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
     args = ap.parse_args()
 
     import torch
@@ -132,6 +133,7 @@ def main():
     pt.update()
     lib = grt.device_lib()
     ctx = pt.ctx
+    grt.set_samples_in_flight(ctx, args.samples_in_flight)
     split = parallel.TileSplit(rank, world, WIDTH, HEIGHT)
     pitch = pt.pitch
     device = torch.device("cuda", local_rank)
@@ -147,17 +149,21 @@ def main():
         if status != 0:
             raise RuntimeError(lib.rt_last_error(ctx).decode())
 
-    def render_step(sample_index):
-        """One sample for this rank's share of the frame, then the frame gather."""
+    def render_step(sample_index, frame_complete=False):
+        """One sample for this rank's share of the frame. Samples are only submitted here (the
+        library keeps `samples_in_flight` of them running concurrently); with N > 1 the accumulated
+        frame is gathered once it is complete, i.e. after its last sample -- every rank accumulates
+        its own tiles, so nothing has to be exchanged between the samples of a frame."""
         if world == 1:
             check(lib.rt_set_pixel_range(ctx, 0, WIDTH * HEIGHT))
             check(lib.rt_render_sample(ctx, sample_index))
         else:
             check(lib.rt_set_pixel_tiles(ctx, split.tile_pixels, rank, world))
             check(lib.rt_render_sample(ctx, sample_index))
-            check(lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, world, split.tiles_per_rank))
-            check(lib.rt_synchronize(ctx))            # the tracer runs on its own HIP stream
-            dist.all_gather_into_tensor(gathered, packed)
+            if frame_complete:
+                check(lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, world, split.tiles_per_rank))
+                check(lib.rt_synchronize(ctx))            # the tracer runs on its own HIP streams
+                dist.all_gather_into_tensor(gathered, packed)
 
     def counters():
         c = pt.counters()
@@ -168,7 +174,7 @@ def main():
 
     # ---- warm-up (untimed) ---------------------------------------------------------------------
     for w in range(args.warmup):
-        render_step(w % SPP)
+        render_step(w % SPP, frame_complete=True)
     check(lib.rt_synchronize(ctx))
 
     # ---- untimed statistics pass: rays per sample and the work counters of the trace kernels ---
@@ -203,7 +209,7 @@ def main():
     check(lib.rt_synchronize(ctx))
     t0 = time.perf_counter()
     for k in range(args.steps):
-        render_step(k % SPP)
+        render_step(k % SPP, frame_complete=(k % SPP == SPP - 1 or k == args.steps - 1))
     check(lib.rt_synchronize(ctx))
     torch.cuda.synchronize()
     if world > 1:
@@ -248,7 +254,8 @@ def main():
                 "rays_per_step": round(rays_per_step), "shadow_rays_per_step": round(shadow_4spp / SPP),
                 "mrays_s_including_shadow": round((rays_4spp + shadow_4spp) / SPP * args.steps / elapsed / 1e6, 1),
                 "ms_per_4spp_frame": round(elapsed / args.steps * SPP * 1e3, 3),
-                "parallelism": "tile-split x%d + RCCL all-gather of the float4 frame" % world if world > 1 else "single GPU",
+                "parallelism": "tile-split x%d + one RCCL all-gather of the accumulated float4 frame per %d-spp frame" % (world, SPP) if world > 1 else "single GPU",
+                "samples_in_flight": args.samples_in_flight,
                 "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
             },
             "roofline": roofline,

@@ -80,6 +80,8 @@ def device_lib():
         lib.rt_random_samples.argtypes = [c_void_p, c_int, c_void_p, c_size_t, c_uint32, c_uint32, c_void_p]
         lib.rt_measure_stream_bandwidth.argtypes = [c_void_p, c_size_t, c_int, POINTER(c_float)]
         lib.rt_set_profiling.argtypes = [c_void_p, c_int]
+        lib.rt_set_samples_in_flight.argtypes = [c_void_p, c_int]
+        lib.rt_set_batch_size.argtypes = [c_void_p, c_int]
         lib.rt_get_counters.argtypes = [c_void_p, POINTER(Counters)]
         lib.rt_render_sample.argtypes = [c_void_p, c_int]
         lib.rt_synchronize.argtypes = [c_void_p]
@@ -457,6 +459,11 @@ def get_trace_statistics(ctx):
         out[name] = dict(nodes=nodes, triangles=tris, instances_transformed=ix, instances_identity=ii, rays=rays,
                          algorithmic_bytes=per_ray * rays + 80 * nodes + 48 * tris + 52 * ix + 4 * ii)
     return out
+
+
+def set_samples_in_flight(ctx, count):
+    """Samples per pixel rendered concurrently (1..4); results do not depend on it."""
+    _dev_check(ctx, device_lib().rt_set_samples_in_flight(ctx, int(count)))
 
 
 def set_profiling(ctx, enable):

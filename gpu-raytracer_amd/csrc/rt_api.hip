@@ -8,23 +8,51 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 static thread_local std::string g_global_error;
 
+// Everything one sample per pixel owns while it is in flight. Up to RT_MAX_SAMPLE_SLOTS samples
+// are rendered concurrently (rt_set_samples_in_flight): consecutive rt_render_sample calls take the
+// slots round-robin, each on its own stream, and only the accumulate step is ordered between them.
+// Why: a wavefront pass is a chain of ~40 launches whose deep bounces are too small to fill 256 CUs
+// and whose persistent trace launches each end in a tail; a second sample's kernels fill those holes.
+#define RT_MAX_SAMPLE_SLOTS 4
+struct SampleSlot {
+	bool created = false;
+	hipStream_t stream = nullptr;      // the sample's launch chain
+	hipStream_t side   = nullptr;      // shadow rays of bounce b, concurrent with the closest-hit trace of bounce b+1
+	hipEvent_t ev_shaded = nullptr, ev_shadowed = nullptr, ev_done = nullptr, ev_frame_start = nullptr, ev_frame_end = nullptr;
+	RtTraceBuffer trace[2]; RtMaterialBuffer material[4]; RtShadowBuffer shadow;
+	bool queues_allocated = false; size_t queue_capacity = 0;
+	RtBufferSizes * sizes = nullptr;
+	int * xcd_counters = nullptr;
+	void * spill[2] = { nullptr, nullptr };  // traversal stack spill of the closest-hit / shadow launch
+	int * counter_totals = nullptr;          // 6 x RT_MAX_BOUNCES ints accumulated over batches
+	RtBufferSizes * pinned_counters = nullptr;
+	void * aov_framebuffer[RT_AOV_COUNT] = { };
+};
+
 struct rt_context {
 	int device = 0;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr;      // "main": uploads, read-backs, pack/unpack, kernel-level entry points
+	hipEvent_t ev_main = nullptr;
 	std::string error;
+
+	SampleSlot slots[RT_MAX_SAMPLE_SLOTS];
+	int samples_in_flight = 2;
+	bool overlap_shadows = true;
+	unsigned render_counter = 0;
+	int last_slot = -1;
 
 	RtParams params;               // zero-initialised in rt_create
 	std::vector<void *> owned;     // every hipMalloc'd pointer, freed in rt_destroy
 
 	// named allocations that get replaced on re-upload
 	void * triangles = nullptr, * triangle_positions = nullptr, * bvh8_nodes = nullptr, * bvh2_nodes = nullptr;
-	void * stack_spill = nullptr; int * xcd_counters = nullptr;
 	size_t bvh8_node_count = 0, bvh2_node_count = 0, triangle_count = 0;
 	void * instances[5] = { };     size_t mesh_count = 0;
 	void * material_types = nullptr, * materials = nullptr, * media = nullptr;
@@ -43,13 +71,7 @@ struct rt_context {
 	void * svgf_buffers[12] = { }; bool svgf_allocated = false;
 	size_t frame_pixels = 0; // pitch * height
 
-	RtBufferSizes * sizes = nullptr;
-	int * counter_totals = nullptr;          // 6 x RT_MAX_BOUNCES ints accumulated over batches
-	RtBufferSizes * pinned_counters = nullptr;
 	int * explicit_retired = nullptr;
-
-	bool queues_allocated = false;
-	size_t queue_capacity = 0;               // entries per queue
 	int batch_size_request = 0;              // 0 = whole frame (288 GB of HBM: no reason to cut a frame into pieces)
 	int pixel_offset = 0, pixel_count = -1;  // -1 = whole frame
 
@@ -58,7 +80,6 @@ struct rt_context {
 	bool trace_statistics = false;
 	unsigned long long * trace_stats = nullptr;    // device, 10 x u64
 	unsigned long long host_trace_stats[10] = { };
-	hipEvent_t ev_frame_start = nullptr, ev_frame_end = nullptr;
 	std::vector<hipEvent_t> stage_events; std::vector<int> stage_kinds; size_t stage_used = 0;
 };
 
@@ -85,13 +106,70 @@ static void device_free(rt_context * ctx, void * p) {
 	(void)hipFree(p);
 }
 // (re)allocate + synchronous upload
+static hipError_t quiesce(rt_context * ctx);
 static int upload(rt_context * ctx, void ** slot, const void * src, size_t bytes) {
+	RT_HIP(ctx, quiesce(ctx)); // samples in flight may still read the old buffer
 	device_free(ctx, *slot);
 	*slot = nullptr;
 	int s = device_alloc(ctx, slot, bytes);
 	if (s != RT_OK) return s;
 	if (bytes && src) RT_HIP(ctx, hipMemcpy(*slot, src, bytes, hipMemcpyHostToDevice));
 	return RT_OK;
+}
+
+// Wait for everything the context has in flight: every sample slot (and its side stream), then main.
+static hipError_t quiesce(rt_context * ctx) {
+	for (SampleSlot & slot : ctx->slots) if (slot.created) {
+		hipError_t e = hipStreamSynchronize(slot.side);   if (e != hipSuccess) return e;
+		e = hipStreamSynchronize(slot.stream);            if (e != hipSuccess) return e;
+	}
+	return hipStreamSynchronize(ctx->stream);
+}
+
+// Main-stream work that reads or writes frame results is ordered after every sample already submitted.
+static hipError_t main_waits_for_samples(rt_context * ctx) {
+	for (SampleSlot & slot : ctx->slots) if (slot.created) {
+		hipError_t e = hipStreamWaitEvent(ctx->stream, slot.ev_done, 0); if (e != hipSuccess) return e;
+	}
+	return hipSuccess;
+}
+
+static int ensure_slot(rt_context * ctx, int index) {
+	SampleSlot & slot = ctx->slots[index];
+	if (slot.created) return RT_OK;
+	memset(slot.trace, 0, sizeof(slot.trace)); memset(slot.material, 0, sizeof(slot.material)); memset(&slot.shadow, 0, sizeof(slot.shadow));
+	RT_HIP(ctx, hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
+	RT_HIP(ctx, hipStreamCreateWithFlags(&slot.side,   hipStreamNonBlocking));
+	RT_HIP(ctx, hipEventCreateWithFlags(&slot.ev_shaded,   hipEventDisableTiming));
+	RT_HIP(ctx, hipEventCreateWithFlags(&slot.ev_shadowed, hipEventDisableTiming));
+	RT_HIP(ctx, hipEventCreateWithFlags(&slot.ev_done,     hipEventDisableTiming));
+	RT_HIP(ctx, hipEventCreate(&slot.ev_frame_start));
+	RT_HIP(ctx, hipEventCreate(&slot.ev_frame_end));
+	RT_HIP(ctx, hipEventRecord(slot.ev_done, slot.stream)); // so that waiting on a never-used slot is a no-op
+	int s = device_alloc(ctx, (void **)&slot.sizes, sizeof(RtBufferSizes)); if (s) return s;
+	s = device_alloc(ctx, (void **)&slot.counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int)); if (s) return s;
+	s = device_alloc(ctx, (void **)&slot.xcd_counters, RT_MAX_BOUNCES * 2 * 8 * sizeof(int)); if (s) return s;
+	// spill area for traversal stacks deeper than the LDS part: 24 entries x 8 B x (256 CUs x 8 workgroups x 256 lanes),
+	// one per launch that can be resident at the same time
+	for (int k = 0; k < 2; k++) { s = device_alloc(ctx, &slot.spill[k], size_t(24) * 8 * 256 * 8 * 256); if (s) return s; }
+	RT_HIP(ctx, hipHostMalloc((void **)&slot.pinned_counters, sizeof(RtBufferSizes)));
+	memset(slot.pinned_counters, 0, sizeof(RtBufferSizes));
+	size_t bytes = ctx->frame_pixels * 16;
+	if (index > 0 && bytes) for (int i = 0; i < RT_AOV_COUNT; i++) if (ctx->aov_buffers[i][0]) {
+		s = device_alloc(ctx, &slot.aov_framebuffer[i], bytes); if (s) return s;
+		RT_HIP(ctx, hipMemset(slot.aov_framebuffer[i], 0, bytes));
+	}
+	slot.created = true;
+	return RT_OK;
+}
+
+// The kernels get RtParams by value: the context's block with one slot's per-sample pointers patched in.
+static RtParams slot_params(const rt_context * ctx, const SampleSlot & slot, int index) {
+	RtParams p = ctx->params;
+	memcpy(p.trace, slot.trace, sizeof(p.trace)); memcpy(p.material, slot.material, sizeof(p.material)); p.shadow = slot.shadow;
+	p.sizes = slot.sizes; p.xcd_counters = slot.xcd_counters; p.stack_spill = (uint2 *)slot.spill[0];
+	if (index > 0) for (int i = 0; i < RT_AOV_COUNT; i++) p.aovs[i].framebuffer = (float4 *)slot.aov_framebuffer[i];
+	return p;
 }
 
 extern "C" {
@@ -114,19 +192,16 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 	memset(&ctx->params, 0, sizeof(ctx->params));
 	memset(&ctx->last_counters, 0, sizeof(ctx->last_counters));
 	RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-	RT_HIP(ctx, hipEventCreate(&ctx->ev_frame_start));
-	RT_HIP(ctx, hipEventCreate(&ctx->ev_frame_end));
+	RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+	if (const char * e = getenv("GRT_SAMPLES_IN_FLIGHT")) { int n = atoi(e); if (n >= 1 && n <= RT_MAX_SAMPLE_SLOTS) ctx->samples_in_flight = n; }
+	if (const char * e = getenv("GRT_OVERLAP_SHADOWS")) ctx->overlap_shadows = atoi(e) != 0;
 
-	int s = device_alloc(ctx, (void **)&ctx->sizes, sizeof(RtBufferSizes)); if (s) return s;
-	s = device_alloc(ctx, (void **)&ctx->counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int)); if (s) return s;
+	int s = ensure_slot(ctx, 0); if (s) return s;
 	s = device_alloc(ctx, (void **)&ctx->explicit_retired, 8 * sizeof(int)); if (s) return s;
-	s = device_alloc(ctx, (void **)&ctx->xcd_counters, RT_MAX_BOUNCES * 2 * 8 * sizeof(int)); if (s) return s;
-	// spill area for traversal stacks deeper than the LDS part: 24 entries x 8 B x (256 CUs x 8 workgroups x 256 lanes)
-	s = device_alloc(ctx, &ctx->stack_spill, size_t(24) * 8 * 256 * 8 * 256); if (s) return s;
-	ctx->params.xcd_counters = ctx->xcd_counters;
-	ctx->params.stack_spill  = (uint2 *)ctx->stack_spill;
-	RT_HIP(ctx, hipHostMalloc((void **)&ctx->pinned_counters, sizeof(RtBufferSizes)));
-	ctx->params.sizes = ctx->sizes;
+	// the kernel-level entry points run on the main stream with slot 0's buffers (after quiesce())
+	ctx->params.sizes        = ctx->slots[0].sizes;
+	ctx->params.xcd_counters = ctx->slots[0].xcd_counters;
+	ctx->params.stack_spill  = (uint2 *)ctx->slots[0].spill[0];
 
 	// default config = reference defaults (Common.h:39-67)
 	rt_gpu_config c = { RT_FILTER_GAUSSIAN, 1u << RT_AOV_RADIANCE, 10, 1, 1, 1, 1, 0, 1, 1, 0.1f, 0.1f, 6, 4.0f, 16.0f, 10.0f };
@@ -138,12 +213,16 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 void rt_destroy(rt_context * ctx) {
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
-	(void)hipStreamSynchronize(ctx->stream);
+	(void)quiesce(ctx);
 	for (void * p : ctx->owned) (void)hipFree(p);
-	if (ctx->pinned_counters) (void)hipHostFree(ctx->pinned_counters);
 	for (hipEvent_t e : ctx->stage_events) (void)hipEventDestroy(e);
-	(void)hipEventDestroy(ctx->ev_frame_start);
-	(void)hipEventDestroy(ctx->ev_frame_end);
+	for (SampleSlot & slot : ctx->slots) if (slot.stream) {
+		if (slot.pinned_counters) (void)hipHostFree(slot.pinned_counters);
+		for (hipEvent_t e : { slot.ev_shaded, slot.ev_shadowed, slot.ev_done, slot.ev_frame_start, slot.ev_frame_end }) if (e) (void)hipEventDestroy(e);
+		(void)hipStreamDestroy(slot.side);
+		(void)hipStreamDestroy(slot.stream);
+	}
+	(void)hipEventDestroy(ctx->ev_main);
 	(void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -172,8 +251,9 @@ int rt_upload_tlas(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_c
 	RT_REQUIRE(ctx, ctx && tlas_nodes, "rt_upload_tlas: NULL argument");
 	RT_REQUIRE(ctx, ctx->bvh8_nodes && tlas_node_count <= ctx->bvh8_node_count, "rt_upload_tlas: geometry not uploaded or TLAS larger than the node array");
 	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx)); // samples in flight still traverse the old TLAS
 	RT_HIP(ctx, hipMemcpyAsync(ctx->bvh8_nodes, tlas_nodes, tlas_node_count * 80, hipMemcpyHostToDevice, ctx->stream));
-	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, quiesce(ctx));
 	return RT_OK;
 }
 
@@ -192,6 +272,7 @@ int rt_upload_tlas_bvh2(rt_context * ctx, const void * tlas_nodes, size_t tlas_n
 	RT_REQUIRE(ctx, ctx && tlas_nodes, "rt_upload_tlas_bvh2: NULL argument");
 	RT_REQUIRE(ctx, ctx->bvh2_nodes && tlas_node_count <= ctx->bvh2_node_count, "rt_upload_tlas_bvh2: geometry not uploaded or TLAS larger than the node array");
 	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
 	RT_HIP(ctx, hipMemcpy(ctx->bvh2_nodes, tlas_nodes, tlas_node_count * 32, hipMemcpyHostToDevice));
 	return RT_OK;
 }
@@ -331,21 +412,22 @@ static size_t wanted_batch_size(const rt_context * ctx) {
 	return n;
 }
 
-static int ensure_queues(rt_context * ctx) {
+static int ensure_queues(rt_context * ctx, int slot_index = 0) {
+	SampleSlot & slot = ctx->slots[slot_index];
 	size_t n = wanted_batch_size(ctx);
-	if (ctx->queues_allocated && ctx->queue_capacity >= n) return RT_OK;
-	if (ctx->queues_allocated) { // grow: release the old queues
-		RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (slot.queues_allocated && slot.queue_capacity >= n) return RT_OK;
+	if (slot.queues_allocated) { // grow: release the old queues
+		RT_HIP(ctx, quiesce(ctx));
 		auto free3 = [&](RtVec3SoA & v) { device_free(ctx, v.x); device_free(ctx, v.y); device_free(ctx, v.z); };
-		for (int i = 0; i < 2; i++) { RtTraceBuffer & t = ctx->params.trace[i]; free3(t.origin); free3(t.direction); device_free(ctx, t.hits); device_free(ctx, t.cone_angle); device_free(ctx, t.cone_width); device_free(ctx, t.medium); device_free(ctx, t.pixel_index_and_flags); free3(t.throughput); device_free(ctx, t.last_pdf); }
-		for (int i = 0; i < 4; i++) { RtMaterialBuffer & m = ctx->params.material[i]; free3(m.direction); device_free(ctx, m.hits); device_free(ctx, m.cone_angle); device_free(ctx, m.cone_width); device_free(ctx, m.medium); device_free(ctx, m.pixel_index_and_flags); free3(m.throughput); }
-		RtShadowBuffer & sh = ctx->params.shadow; free3(sh.origin); free3(sh.direction); device_free(ctx, sh.max_distance); device_free(ctx, sh.illumination_and_pixel_index);
-		ctx->queues_allocated = false;
+		for (int i = 0; i < 2; i++) { RtTraceBuffer & t = slot.trace[i]; free3(t.origin); free3(t.direction); device_free(ctx, t.hits); device_free(ctx, t.cone_angle); device_free(ctx, t.cone_width); device_free(ctx, t.medium); device_free(ctx, t.pixel_index_and_flags); free3(t.throughput); device_free(ctx, t.last_pdf); }
+		for (int i = 0; i < 4; i++) { RtMaterialBuffer & m = slot.material[i]; free3(m.direction); device_free(ctx, m.hits); device_free(ctx, m.cone_angle); device_free(ctx, m.cone_width); device_free(ctx, m.medium); device_free(ctx, m.pixel_index_and_flags); free3(m.throughput); }
+		RtShadowBuffer & sh = slot.shadow; free3(sh.origin); free3(sh.direction); device_free(ctx, sh.max_distance); device_free(ctx, sh.illumination_and_pixel_index);
+		slot.queues_allocated = false;
 	}
-	ctx->queue_capacity = n;
+	slot.queue_capacity = n;
 	int s;
 	for (int i = 0; i < 2; i++) {
-		RtTraceBuffer & t = ctx->params.trace[i];
+		RtTraceBuffer & t = slot.trace[i];
 		if ((s = alloc_vec3(ctx, t.origin, n))) return s;
 		if ((s = alloc_vec3(ctx, t.direction, n))) return s;
 		if ((s = device_alloc(ctx, (void **)&t.hits, n * 16))) return s;
@@ -357,7 +439,7 @@ static int ensure_queues(rt_context * ctx) {
 		if ((s = device_alloc(ctx, (void **)&t.last_pdf, n * 4))) return s;
 	}
 	for (int i = 0; i < 4; i++) {
-		RtMaterialBuffer & m = ctx->params.material[i];
+		RtMaterialBuffer & m = slot.material[i];
 		if ((s = alloc_vec3(ctx, m.direction, n))) return s;
 		if ((s = device_alloc(ctx, (void **)&m.hits, n * 16))) return s;
 		if ((s = device_alloc(ctx, (void **)&m.cone_angle, n * 4))) return s;
@@ -366,12 +448,13 @@ static int ensure_queues(rt_context * ctx) {
 		if ((s = device_alloc(ctx, (void **)&m.pixel_index_and_flags, n * 4))) return s;
 		if ((s = alloc_vec3(ctx, m.throughput, n))) return s;
 	}
-	RtShadowBuffer & sh = ctx->params.shadow;
+	RtShadowBuffer & sh = slot.shadow;
 	if ((s = alloc_vec3(ctx, sh.origin, n))) return s;
 	if ((s = alloc_vec3(ctx, sh.direction, n))) return s;
 	if ((s = device_alloc(ctx, (void **)&sh.max_distance, n * 4))) return s;
 	if ((s = device_alloc(ctx, (void **)&sh.illumination_and_pixel_index, n * 16))) return s;
-	ctx->queues_allocated = true;
+	slot.queues_allocated = true;
+	if (slot_index == 0) { memcpy(ctx->params.trace, slot.trace, sizeof(slot.trace)); memcpy(ctx->params.material, slot.material, sizeof(slot.material)); ctx->params.shadow = slot.shadow; }
 	return RT_OK;
 }
 
@@ -381,13 +464,19 @@ static int sync_aovs(rt_context * ctx) {
 		bool enabled = (ctx->params.config.aov_mask >> i) & 1u;
 		bool allocated = ctx->aov_buffers[i][0] != nullptr;
 		if (enabled && !allocated && bytes) {
+			RT_HIP(ctx, quiesce(ctx));
 			for (int k = 0; k < 2; k++) {
 				int s = device_alloc(ctx, &ctx->aov_buffers[i][k], bytes); if (s) return s;
-				RT_HIP(ctx, hipMemsetAsync(ctx->aov_buffers[i][k], 0, bytes, ctx->stream));
+				RT_HIP(ctx, hipMemset(ctx->aov_buffers[i][k], 0, bytes));
+			}
+			for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) { // per-sample frame buffers of the other slots
+				int s = device_alloc(ctx, &ctx->slots[k].aov_framebuffer[i], bytes); if (s) return s;
+				RT_HIP(ctx, hipMemset(ctx->slots[k].aov_framebuffer[i], 0, bytes));
 			}
 		} else if (!enabled && allocated) {
-			RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			RT_HIP(ctx, quiesce(ctx));
 			for (int k = 0; k < 2; k++) { device_free(ctx, ctx->aov_buffers[i][k]); ctx->aov_buffers[i][k] = nullptr; }
+			for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) { device_free(ctx, ctx->slots[k].aov_framebuffer[i]); ctx->slots[k].aov_framebuffer[i] = nullptr; }
 		}
 		ctx->params.aovs[i].framebuffer = (float4 *)ctx->aov_buffers[i][0];
 		ctx->params.aovs[i].accumulator = (float4 *)ctx->aov_buffers[i][1];
@@ -406,7 +495,7 @@ static int sync_svgf(rt_context * ctx) {
 			RT_HIP(ctx, hipMemsetAsync(ctx->svgf_buffers[i], 0, ctx->frame_pixels * elem[i], ctx->stream));
 		}
 	} else {
-		RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		RT_HIP(ctx, quiesce(ctx));
 		for (int i = 0; i < 12; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
 	}
 	ctx->svgf_allocated = want;
@@ -429,12 +518,13 @@ static int sync_svgf(rt_context * ctx) {
 int rt_resize(rt_context * ctx, int width, int height) {
 	RT_REQUIRE(ctx, ctx && width > 0 && height > 0, "rt_resize: invalid size");
 	(void)hipSetDevice(ctx->device);
-	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, quiesce(ctx));
 	int pitch = (width + 31) / 32 * 32; // Math::round_up(width, WARP_SIZE), Pathtracer.cpp:258
 	ctx->params.screen_width = width; ctx->params.screen_height = height; ctx->params.screen_pitch = pitch;
 	ctx->frame_pixels = size_t(pitch) * height;
 
 	for (int i = 0; i < RT_AOV_COUNT; i++) for (int k = 0; k < 2; k++) { device_free(ctx, ctx->aov_buffers[i][k]); ctx->aov_buffers[i][k] = nullptr; }
+	for (int i = 0; i < RT_AOV_COUNT; i++) for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) { device_free(ctx, ctx->slots[k].aov_framebuffer[i]); ctx->slots[k].aov_framebuffer[i] = nullptr; }
 	for (int i = 0; i < 12; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
 	ctx->svgf_allocated = false;
 	device_free(ctx, ctx->final_image); ctx->final_image = nullptr;
@@ -491,6 +581,7 @@ int rt_pack_pixels(rt_context * ctx, void * dst_device, int tile_pixels, int fir
 	RT_REQUIRE(ctx, ctx && dst_device && tile_pixels > 0 && tile_stride > 0 && tiles >= 0, "rt_pack_pixels: invalid argument");
 	(void)hipSetDevice(ctx->device);
 	if (!ctx->final_image) return fail(ctx, RT_ERROR_NOT_READY, "rt_pack_pixels: rt_resize was not called");
+	RT_HIP(ctx, main_waits_for_samples(ctx));
 	rt_launch_pack_pixels(ctx->params, (float4 *)dst_device, tile_pixels, first_tile, tile_stride, tiles, ctx->stream);
 	RT_HIP(ctx, hipGetLastError());
 	return RT_OK;
@@ -500,6 +591,7 @@ int rt_unpack_pixels(rt_context * ctx, const void * src_device, int tile_pixels,
 	RT_REQUIRE(ctx, ctx && src_device && tile_pixels > 0 && world > 0 && tiles_per_rank > 0, "rt_unpack_pixels: invalid argument");
 	(void)hipSetDevice(ctx->device);
 	if (!ctx->final_image) return fail(ctx, RT_ERROR_NOT_READY, "rt_unpack_pixels: rt_resize was not called");
+	RT_HIP(ctx, main_waits_for_samples(ctx));
 	rt_launch_unpack_pixels(ctx->params, (const float4 *)src_device, tile_pixels, world, tiles_per_rank, ctx->stream);
 	RT_HIP(ctx, hipGetLastError());
 	return RT_OK;
@@ -517,7 +609,7 @@ int rt_get_trace_statistics(rt_context * ctx, uint64_t * out10) {
 	RT_REQUIRE(ctx, ctx && out10, "rt_get_trace_statistics: NULL argument");
 	(void)hipSetDevice(ctx->device);
 	if (!ctx->trace_stats) return fail(ctx, RT_ERROR_NOT_READY, "rt_get_trace_statistics: statistics were never enabled");
-	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, quiesce(ctx));
 	RT_HIP(ctx, hipMemcpy(out10, ctx->trace_stats, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	return RT_OK;
 }
@@ -555,11 +647,11 @@ static int ensure_luts(rt_context * ctx) {
 
 enum { STAGE_GENERATE = 0, STAGE_TRACE, STAGE_SORT, STAGE_SHADE, STAGE_SHADOW, STAGE_POST, STAGE_END };
 
-static void stage_mark(rt_context * ctx, int kind) {
+static void stage_mark(rt_context * ctx, int kind, hipStream_t stream) {
 	if (!ctx->profiling) return;
 	if (ctx->stage_used == ctx->stage_events.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->stage_events.push_back(e); ctx->stage_kinds.push_back(0); }
 	ctx->stage_kinds[ctx->stage_used] = kind;
-	(void)hipEventRecord(ctx->stage_events[ctx->stage_used++], ctx->stream);
+	(void)hipEventRecord(ctx->stage_events[ctx->stage_used++], stream);
 }
 
 __global__ void kernel_accumulate_counters(const RtBufferSizes * sizes, int * totals) {
@@ -576,16 +668,25 @@ __global__ void kernel_accumulate_counters(const RtBufferSizes * sizes, int * to
 int rt_render_sample(rt_context * ctx, int sample_index) {
 	RT_REQUIRE(ctx, ctx, "rt_render_sample: NULL context");
 	(void)hipSetDevice(ctx->device);
-	RtParams & p = ctx->params;
-	if (!p.triangles || !p.bvh8_nodes)   return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: geometry not uploaded");
-	if (!p.mesh_bvh_root_indices)        return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: instances not uploaded");
-	if (!p.materials)                    return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: materials not uploaded");
-	if (!p.pmj_samples || !p.blue_noise) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: RNG tables not uploaded");
-	if (!p.sky)                          return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: sky not set");
+	const RtParams & base = ctx->params;
+	if (!base.triangles || !base.bvh8_nodes)   return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: geometry not uploaded");
+	if (!base.mesh_bvh_root_indices)        return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: instances not uploaded");
+	if (!base.materials)                    return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: materials not uploaded");
+	if (!base.pmj_samples || !base.blue_noise) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: RNG tables not uploaded");
+	if (!base.sky)                          return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: sky not set");
 	if (ctx->frame_pixels == 0)          return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: rt_resize was not called");
 	if (ctx->bvh_width != 8)             return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: unsupported BVH type");
-	int s = ensure_queues(ctx); if (s) return s;
+	// Slot choice: round-robin over the samples in flight. Profiling / statistics passes and SVGF
+	// frames (whose history makes frame n+1 depend on all of frame n) use one slot, serialised.
+	bool exclusive = ctx->profiling || ctx->trace_statistics || ctx->params.config.enable_svgf;
+	int slot_index = exclusive ? 0 : int(ctx->render_counter++ % unsigned(ctx->samples_in_flight));
+	int s = ensure_slot(ctx, slot_index); if (s) return s;
+	s = ensure_queues(ctx, slot_index); if (s) return s;
 	if (ctx->has_material[2] || ctx->has_material[3]) { s = ensure_luts(ctx); if (s) return s; }
+	SampleSlot & slot = ctx->slots[slot_index];
+	const RtParams p = slot_params(ctx, slot, slot_index);
+	RtParams p_shadow = p; // the shadow launch may be resident together with the next closest-hit launch
+	p_shadow.stack_spill = (uint2 *)slot.spill[1];
 
 	int frame_pixels = p.screen_width * p.screen_height;
 	int range_offset = ctx->pixel_offset;
@@ -600,71 +701,104 @@ int rt_render_sample(rt_context * ctx, int sample_index) {
 	}
 	if (p.tile_pixels == 0 && range_offset + range_count > frame_pixels) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_sample: pixel range [%d,%d) exceeds the %d pixel frame", range_offset, range_offset + range_count, frame_pixels);
 
-	hipStream_t st = ctx->stream;
+	hipStream_t st = slot.stream;
+	// everything submitted on the main stream so far (uploads are synchronous; unpack_pixels, LUTs are not)
+	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
+	if (exclusive) for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[k].ev_done, 0));
+
 	ctx->stage_used = 0;
-	RT_HIP(ctx, hipEventRecord(ctx->ev_frame_start, st));
-	RT_HIP(ctx, hipMemsetAsync(ctx->counter_totals, 0, 6 * RT_MAX_BOUNCES * sizeof(int), st));
+	RT_HIP(ctx, hipEventRecord(slot.ev_frame_start, st));
+	RT_HIP(ctx, hipMemsetAsync(slot.counter_totals, 0, 6 * RT_MAX_BOUNCES * sizeof(int), st));
 	if (ctx->trace_statistics) RT_HIP(ctx, hipMemsetAsync(ctx->trace_stats, 0, 10 * sizeof(unsigned long long), st));
 
 	int pixels_left = range_count;
 	int batch_limit = int(wanted_batch_size(ctx));
 	int batch_size  = range_count < batch_limit ? range_count : batch_limit;
 	bool trace_shadows = ctx->has_lights && p.config.enable_next_event_estimation && p.lights_total_weight > 0.0f;
+	// Shadow rays of bounce b only feed the frame buffers, so they run on the side stream while the
+	// main chain traces bounce b+1; they are joined before the next kernel that touches the frame
+	// buffers (sort: sky / emissive hits), which keeps the order of the float additions per pixel.
+	bool overlap = trace_shadows && ctx->overlap_shadows && !ctx->profiling && !ctx->trace_statistics;
+	bool shadow_pending = false;
 
 	while (pixels_left > 0) {
 		int pixel_offset = range_offset + (range_count - pixels_left);
 		int pixel_count  = batch_size < pixels_left ? batch_size : pixels_left;
 
-		RT_HIP(ctx, hipMemsetAsync(ctx->sizes, 0, sizeof(RtBufferSizes), st));
-		RT_HIP(ctx, hipMemsetAsync(ctx->xcd_counters, 0, RT_MAX_BOUNCES * 2 * 8 * sizeof(int), st));
-		stage_mark(ctx, STAGE_GENERATE);
+		if (shadow_pending) { RT_HIP(ctx, hipStreamWaitEvent(st, slot.ev_shadowed, 0)); shadow_pending = false; } // the previous batch's queues are reused
+		RT_HIP(ctx, hipMemsetAsync(slot.sizes, 0, sizeof(RtBufferSizes), st));
+		RT_HIP(ctx, hipMemsetAsync(slot.xcd_counters, 0, RT_MAX_BOUNCES * 2 * 8 * sizeof(int), st));
+		stage_mark(ctx, STAGE_GENERATE, st);
 		rt_launch_generate(p, sample_index, pixel_offset, pixel_count, st);
 
 		for (int bounce = 0; bounce < p.config.num_bounces; bounce++) {
-			stage_mark(ctx, STAGE_TRACE);
+			stage_mark(ctx, STAGE_TRACE, st);
 			if (ctx->trace_statistics) rt_launch_trace_counting(p, bounce, ctx->trace_stats, st);
 			else rt_launch_trace(p, bounce, st);
-			stage_mark(ctx, STAGE_SORT);
+			if (shadow_pending) { RT_HIP(ctx, hipStreamWaitEvent(st, slot.ev_shadowed, 0)); shadow_pending = false; }
+			stage_mark(ctx, STAGE_SORT, st);
 			rt_launch_sort(p, bounce, sample_index, st);
-			stage_mark(ctx, STAGE_SHADE);
+			stage_mark(ctx, STAGE_SHADE, st);
 			for (int m = 0; m < 4; m++) if (ctx->has_material[m]) rt_launch_material(p, m, bounce, sample_index, st);
 			if (trace_shadows) {
-				stage_mark(ctx, STAGE_SHADOW);
+				stage_mark(ctx, STAGE_SHADOW, st);
 				if (ctx->trace_statistics) rt_launch_trace_shadow_counting(p, bounce, ctx->trace_stats, st);
-				else rt_launch_trace_shadow(p, bounce, st);
+				else if (!overlap) rt_launch_trace_shadow(p, bounce, st);
+				else {
+					RT_HIP(ctx, hipEventRecord(slot.ev_shaded, st));
+					RT_HIP(ctx, hipStreamWaitEvent(slot.side, slot.ev_shaded, 0));
+					rt_launch_trace_shadow(p_shadow, bounce, slot.side);
+					RT_HIP(ctx, hipEventRecord(slot.ev_shadowed, slot.side));
+					shadow_pending = true;
+				}
 			}
 		}
-		hipLaunchKernelGGL(kernel_accumulate_counters, dim3(1), dim3(RT_MAX_BOUNCES), 0, st, ctx->sizes, ctx->counter_totals);
+		hipLaunchKernelGGL(kernel_accumulate_counters, dim3(1), dim3(RT_MAX_BOUNCES), 0, st, slot.sizes, slot.counter_totals);
 		pixels_left -= batch_size;
 	}
+	if (shadow_pending) RT_HIP(ctx, hipStreamWaitEvent(st, slot.ev_shadowed, 0));
 
-	stage_mark(ctx, STAGE_POST);
+	// The accumulate step folds this sample into the shared accumulators: strictly in sample order.
+	if (ctx->last_slot >= 0 && ctx->last_slot != slot_index) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[ctx->last_slot].ev_done, 0));
+	stage_mark(ctx, STAGE_POST, st);
 	if (p.config.enable_svgf) rt_launch_svgf_taa(p, sample_index, st);
 	else rt_launch_accumulate(p, float(sample_index), range_offset, range_count, st);
-	stage_mark(ctx, STAGE_END);
+	stage_mark(ctx, STAGE_END, st);
 
 	// aovs_clear_to_zero (Integrator.cpp:379-385)
-	for (int i = 0; i < RT_AOV_COUNT; i++) if (ctx->aov_buffers[i][0]) RT_HIP(ctx, hipMemsetAsync(ctx->aov_buffers[i][0], 0, ctx->frame_pixels * 16, st));
+	for (int i = 0; i < RT_AOV_COUNT; i++) if (p.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(p.aovs[i].framebuffer, 0, ctx->frame_pixels * 16, st));
 
-	RT_HIP(ctx, hipMemcpyAsync(ctx->pinned_counters, ctx->counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int), hipMemcpyDeviceToHost, st));
-	RT_HIP(ctx, hipEventRecord(ctx->ev_frame_end, st));
+	RT_HIP(ctx, hipMemcpyAsync(slot.pinned_counters, slot.counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int), hipMemcpyDeviceToHost, st));
+	RT_HIP(ctx, hipEventRecord(slot.ev_frame_end, st));
+	RT_HIP(ctx, hipEventRecord(slot.ev_done, st));
+	ctx->last_slot = slot_index;
 	RT_HIP(ctx, hipGetLastError());
+	return RT_OK;
+}
+
+int rt_set_samples_in_flight(rt_context * ctx, int count) {
+	RT_REQUIRE(ctx, ctx && count >= 1 && count <= RT_MAX_SAMPLE_SLOTS, "rt_set_samples_in_flight: count must be 1..4");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	ctx->samples_in_flight = count;
 	return RT_OK;
 }
 
 int rt_synchronize(rt_context * ctx) {
 	RT_REQUIRE(ctx, ctx, "rt_synchronize: NULL context");
 	(void)hipSetDevice(ctx->device);
-	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, quiesce(ctx));
 	return RT_OK;
 }
 
 int rt_get_counters(rt_context * ctx, rt_counters * out) {
 	RT_REQUIRE(ctx, ctx && out, "rt_get_counters: NULL argument");
 	(void)hipSetDevice(ctx->device);
-	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, quiesce(ctx));
 	rt_counters c; memset(&c, 0, sizeof(c));
-	const int * totals = (const int *)ctx->pinned_counters;
+	const SampleSlot & slot = ctx->slots[ctx->last_slot < 0 ? 0 : ctx->last_slot];
+	const int * totals = (const int *)slot.pinned_counters;
 	memcpy(c.trace,      totals + 0 * RT_MAX_BOUNCES, sizeof(c.trace));
 	memcpy(c.shadow,     totals + 1 * RT_MAX_BOUNCES, sizeof(c.shadow));
 	memcpy(c.diffuse,    totals + 2 * RT_MAX_BOUNCES, sizeof(c.diffuse));
@@ -672,7 +806,7 @@ int rt_get_counters(rt_context * ctx, rt_counters * out) {
 	memcpy(c.dielectric, totals + 4 * RT_MAX_BOUNCES, sizeof(c.dielectric));
 	memcpy(c.conductor,  totals + 5 * RT_MAX_BOUNCES, sizeof(c.conductor));
 	float ms = 0.0f;
-	if (hipEventElapsedTime(&ms, ctx->ev_frame_start, ctx->ev_frame_end) == hipSuccess) c.ms_total = ms;
+	if (hipEventElapsedTime(&ms, slot.ev_frame_start, slot.ev_frame_end) == hipSuccess) c.ms_total = ms;
 	if (ctx->profiling) {
 		float * bucket[STAGE_END] = { &c.ms_generate, &c.ms_trace, &c.ms_sort, &c.ms_shade, &c.ms_shadow, &c.ms_post };
 		for (size_t i = 0; i + 1 < ctx->stage_used; i++) {
@@ -692,7 +826,7 @@ int rt_read_aov(rt_context * ctx, int aov_type, float * dst, int accumulated) {
 	(void)hipSetDevice(ctx->device);
 	void * src = ctx->aov_buffers[aov_type][accumulated ? 1 : 0];
 	if (!src) return fail(ctx, RT_ERROR_NOT_READY, "rt_read_aov: AOV %d is not enabled", aov_type);
-	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, quiesce(ctx));
 	RT_HIP(ctx, hipMemcpy(dst, src, ctx->frame_pixels * 16, hipMemcpyDeviceToHost));
 	return RT_OK;
 }
@@ -701,7 +835,7 @@ int rt_read_framebuffer(rt_context * ctx, float * dst) {
 	RT_REQUIRE(ctx, ctx && dst, "rt_read_framebuffer: NULL argument");
 	(void)hipSetDevice(ctx->device);
 	if (!ctx->final_image) return fail(ctx, RT_ERROR_NOT_READY, "rt_read_framebuffer: rt_resize was not called");
-	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, quiesce(ctx));
 	RT_HIP(ctx, hipMemcpy(dst, ctx->final_image, ctx->frame_pixels * 16, hipMemcpyDeviceToHost));
 	return RT_OK;
 }
@@ -721,7 +855,7 @@ int rt_read_luts(rt_context * ctx, float * dielectric_dir_enter, float * dielect
 	(void)hipSetDevice(ctx->device);
 	if (!ctx->params.pmj_samples) return fail(ctx, RT_ERROR_NOT_READY, "rt_read_luts: RNG tables not uploaded");
 	int s = ensure_luts(ctx); if (s) return s;
-	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, quiesce(ctx));
 	float * dst[6] = { dielectric_dir_enter, dielectric_dir_leave, dielectric_enter, dielectric_leave, conductor_dir, conductor };
 	const size_t bytes[6] = { 4096 * 4, 4096 * 4, 256 * 4, 256 * 4, 1024 * 4, 32 * 4 };
 	for (int i = 0; i < 6; i++) if (dst[i]) RT_HIP(ctx, hipMemcpy(dst[i], ctx->luts[i], bytes[i], hipMemcpyDeviceToHost));
@@ -750,6 +884,7 @@ int rt_trace_rays(rt_context * ctx, const float * ox, const float * oy, const fl
                   uint32_t * hits, int repeat, float * out_ms) {
 	RT_REQUIRE(ctx, ctx && ox && oy && oz && dx && dy && dz && hits, "rt_trace_rays: NULL argument");
 	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx)); // slot 0's spill area and cursors are borrowed
 	if (!ctx->params.triangles || !ctx->params.bvh8_nodes || !ctx->params.mesh_bvh_root_indices) return fail(ctx, RT_ERROR_NOT_READY, "rt_trace_rays: geometry / instances not uploaded");
 	TempBuffers tmp(ctx);
 	size_t bytes = ray_count * 4;
@@ -766,7 +901,7 @@ int rt_trace_rays(rt_context * ctx, const float * ox, const float * oy, const fl
 		RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
 		rt_launch_trace_explicit(ctx->params, o, d, dev_hits, int(ray_count), ctx->explicit_retired, ctx->stream);
 		RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
-		RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		RT_HIP(ctx, quiesce(ctx));
 		float ms = 0.0f; RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
 		total += ms;
 	}
@@ -782,6 +917,7 @@ int rt_trace_shadow_rays(rt_context * ctx, const float * ox, const float * oy, c
                          size_t ray_count, uint8_t * occluded, int repeat, float * out_ms) {
 	RT_REQUIRE(ctx, ctx && ox && oy && oz && dx && dy && dz && max_distance && occluded, "rt_trace_shadow_rays: NULL argument");
 	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx)); // slot 0's spill area and cursors are borrowed
 	if (!ctx->params.triangles || !ctx->params.bvh8_nodes || !ctx->params.mesh_bvh_root_indices) return fail(ctx, RT_ERROR_NOT_READY, "rt_trace_shadow_rays: geometry / instances not uploaded");
 	TempBuffers tmp(ctx);
 	size_t bytes = ray_count * 4;
@@ -799,7 +935,7 @@ int rt_trace_shadow_rays(rt_context * ctx, const float * ox, const float * oy, c
 		RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
 		rt_launch_trace_shadow_explicit(ctx->params, o, d, dev_max, dev_occ, int(ray_count), ctx->explicit_retired, ctx->stream);
 		RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
-		RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		RT_HIP(ctx, quiesce(ctx));
 		float ms = 0.0f; RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
 		total += ms;
 	}
@@ -816,11 +952,12 @@ int rt_generate_rays(rt_context * ctx, int sample_index, int pixel_offset, int p
 	RT_REQUIRE(ctx, pixel_count >= 0, "rt_generate_rays: negative pixel_count");
 	(void)hipSetDevice(ctx->device);
 	if (!ctx->params.pmj_samples || ctx->frame_pixels == 0) return fail(ctx, RT_ERROR_NOT_READY, "rt_generate_rays: RNG tables not uploaded or rt_resize not called");
+	RT_HIP(ctx, quiesce(ctx)); // slot 0's queues are borrowed
 	int s = ensure_queues(ctx); if (s) return s;
-	if (size_t(pixel_count) > ctx->queue_capacity) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_generate_rays: pixel_count %d exceeds the queue capacity %zu", pixel_count, ctx->queue_capacity);
+	if (size_t(pixel_count) > ctx->slots[0].queue_capacity) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_generate_rays: pixel_count %d exceeds the queue capacity %zu", pixel_count, ctx->slots[0].queue_capacity);
 	rt_launch_generate(ctx->params, sample_index, pixel_offset, pixel_count, ctx->stream);
 	RT_HIP(ctx, hipGetLastError());
-	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, quiesce(ctx));
 	const RtTraceBuffer & t = ctx->params.trace[0];
 	size_t bytes = size_t(pixel_count) * 4;
 	RT_HIP(ctx, hipMemcpy(ox, t.origin.x, bytes, hipMemcpyDeviceToHost));
@@ -843,7 +980,7 @@ int rt_random_samples(rt_context * ctx, int dimension, const uint32_t * pixel_in
 	if (!dev_px || !dev_out) return fail(ctx, RT_ERROR_HIP, "rt_random_samples: device allocation failed");
 	rt_launch_random(ctx->params, dimension, dev_px, int(count), bounce, sample_index, dev_out, ctx->stream);
 	RT_HIP(ctx, hipGetLastError());
-	RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	RT_HIP(ctx, quiesce(ctx));
 	RT_HIP(ctx, hipMemcpy(out_xy, dev_out, count * 8, hipMemcpyDeviceToHost));
 	return RT_OK;
 }
@@ -865,7 +1002,7 @@ int rt_measure_stream_bandwidth(rt_context * ctx, size_t bytes, int repeat, floa
 		RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
 		rt_launch_stream_read(src, count, sink, ctx->stream);
 		RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
-		RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		RT_HIP(ctx, quiesce(ctx));
 		float ms = 0.0f; RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
 		if (ms < best) best = ms;
 	}

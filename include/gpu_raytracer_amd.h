@@ -195,6 +195,15 @@ int rt_unpack_pixels(rt_context * ctx, const void * src_device, int tile_pixels,
  * frame in one batch (MI355X has 288 GB of HBM; bigger launches hide traversal latency better). */
 int rt_set_batch_size(rt_context * ctx, int batch_size);
 
+/* Samples per pixel rendered concurrently (1..4, default 2). The reference submits the ~40
+ * launches of one sample strictly one after the other on one stream (Pathtracer.cpp:738-855);
+ * here consecutive rt_render_sample calls alternate between `count` sets of queues / streams and
+ * only the accumulate step is ordered between them, so a sample's small deep-bounce launches
+ * run in the shadow of its neighbour's. Results are identical for every count. SVGF frames and
+ * profiled / statistics passes always run one sample at a time. Memory: one set of wavefront
+ * queues + per-sample frame buffers per sample in flight (~1 GB each at 1920x1080).        */
+int rt_set_samples_in_flight(rt_context * ctx, int count);
+
 /* ---- render: replaces Pathtracer::render (Pathtracer.cpp:738-855) ---------------------- */
 /* One sample for this context's pixel range: generate, (trace, sort, shade*, shadow) x
  * bounces, then accumulate or SVGF/TAA.  Asynchronous; rt_synchronize or a read waits.    */

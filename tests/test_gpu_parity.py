@@ -223,6 +223,27 @@ def test_batch_size_does_not_change_the_image(grt):
     pt.close(); scene.close()
 
 
+def test_samples_in_flight_do_not_change_the_image(grt):
+    """Six progressive samples submitted back to back with 1, 2 and 4 samples in flight
+    (rt_set_samples_in_flight; shadow rays on the side stream in all of them): the accumulated
+    image and the last sample's queue sizes are bit-identical."""
+    images, queues = [], []
+    for in_flight in (1, 2, 4):
+        scene, pt = make_pathtracer(grt, "cornellbox", 320, 240, 0, num_bounces=5)
+        grt.set_samples_in_flight(pt.ctx, in_flight)
+        for f in range(6):
+            if f:
+                pt.update()
+            pt.render()
+        images.append(pt.read_framebuffer().copy())
+        c = pt.counters()
+        queues.append(list(c.trace[:5]) + list(c.shadow[:5]))
+        pt.close(); scene.close()
+    assert np.array_equal(images[0], images[1]) and np.array_equal(images[0], images[2])
+    assert queues[0] == queues[1] == queues[2] and queues[0][0] == 320 * 240
+    assert np.isfinite(images[0]).all() and images[0][..., :3].max() > 0.0
+
+
 def test_device_errors_are_reported(grt):
     import ctypes
     lib = grt.device_lib()
