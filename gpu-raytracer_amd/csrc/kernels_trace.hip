@@ -36,6 +36,9 @@
 // (Per-XCD chunks of the ray range -- L2 affinity via HW_REG_XCC_ID -- were tried and measured slower
 // than one shared cursor: 1.84 vs 2.01 Grays/s at 8M incoherent rays; see profiles/r01_trace_variants.txt.)
 #define RT_NUM_XCD 1
+#ifndef RT_TRI_BATCH
+#define RT_TRI_BATCH 2           // triangles whose loads are issued together
+#endif
 #ifndef RT_FETCH_BLOCK_MAX
 #define RT_FETCH_BLOCK_MAX 128   // rays claimed per cursor atomic; measured 64..1024, see profiles/r01_trace_fetch_block.txt
 #endif
@@ -169,29 +172,31 @@ RT_DEV bool triangle_test(const float4 * __restrict__ triangle_positions, int me
 // Per-lane stack: the first RT_LDS_STACK entries live in LDS ([entry][lane] stripes, see the
 // file header), deeper entries spill to a context-owned HBM buffer laid out [entry][global lane]
 // so that even the spill traffic is coalesced. No private arrays => no compiler scratch.
+// The two pointers carry their address space in the type: with generic pointers the compiler emits
+// FLAT instructions, which go through the texture-address path like a global access (they were
+// 55 % of this kernel's VMEM issue, profiles/r01_pmc_trace_secondary_4M.txt) and tie the LDS
+// accesses to vmcnt; as ds_read/ds_write_b64 they cost no vector-memory issue at all.
+typedef __attribute__((address_space(3))) uint2 LdsUint2;
+typedef __attribute__((address_space(1))) uint2 GlobalUint2;
 struct TraversalStack {
-	uint2 * lds;       // this lane's column of the LDS stripe (address space 3 after inlining)
-	uint2 * spill;     // this lane's column of the HBM spill area
+	LdsUint2    * lds;       // this lane's column of the LDS stripe
+	GlobalUint2 * spill;     // this lane's column of the HBM spill area
 	int spill_stride;  // lanes in the grid
 	int size;
 
 	RT_DEV void push(uint2 item) {
-		if (size < RT_LDS_STACK) lds[size * RT_WAVE_SIZE] = item;
-		else                     spill[size_t(size - RT_LDS_STACK) * spill_stride] = item;
+		if (size < RT_LDS_STACK) { lds[size * RT_WAVE_SIZE].x = item.x; lds[size * RT_WAVE_SIZE].y = item.y; }
+		else { GlobalUint2 * slot = spill + size_t(size - RT_LDS_STACK) * spill_stride; slot->x = item.x; slot->y = item.y; }
 		size++;
 	}
 	RT_DEV uint2 pop() {
 		size--;
-		if (size < RT_LDS_STACK) return lds[size * RT_WAVE_SIZE];
-		return spill[size_t(size - RT_LDS_STACK) * spill_stride];
+		if (size < RT_LDS_STACK) return make_uint2(lds[size * RT_WAVE_SIZE].x, lds[size * RT_WAVE_SIZE].y);
+		const GlobalUint2 * slot = spill + size_t(size - RT_LDS_STACK) * spill_stride;
+		return make_uint2(slot->x, slot->y);
 	}
 };
 
-// Ray distribution. The ray range of a launch is cut into RT_NUM_XCD contiguous chunks and the
-// waves of XCD k drain chunk k first (queue order follows pixel order, so a chunk is a band of
-// the image and its rays share geometry: each XCD's private 4 MB L2 then mostly holds "its"
-// part of the scene), moving on to the other chunks only when their own is exhausted.
-// One returning atomic per wave per refill.
 // Ray distribution: rays are claimed from the shared cursor in BLOCKS, one returning atomic per
 // `ray_block` rays, and dealt to the lanes of the claiming wave as they go idle; the claimed-but-
 // undealt range [next, end) and the drained flag are per-wave words in LDS (refills happen under
@@ -216,9 +221,9 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 	unsigned wave = threadIdx.x / RT_WAVE_SIZE;
 
 	TraversalStack stack;
-	stack.lds   = &shared_stack[wave * (RT_LDS_STACK * RT_WAVE_SIZE) + lane];
+	stack.lds   = (LdsUint2 *)&shared_stack[wave * (RT_LDS_STACK * RT_WAVE_SIZE) + lane];
 	stack.spill_stride = int(gridDim.x * blockDim.x);
-	stack.spill = p.stack_spill + (blockIdx.x * blockDim.x + threadIdx.x);
+	stack.spill = (GlobalUint2 *)(p.stack_spill + (blockIdx.x * blockDim.x + threadIdx.x));
 	stack.size  = 0;
 
 	// Rays per cursor atomic: up to 512 for big launches, 64 for small ones so that every wave gets work.
@@ -229,16 +234,18 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * unsigned(ray_block) >= unsigned(ray_count)) return;
 	// volatile: the words are written by one lane and read by OTHER lanes of the same wave with no
 	// barrier in between; without it the compiler forwards a lane's own last view of them.
-	__shared__ volatile int shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4]; // per wave: next, end, drained
-	if (lane == 0) { shared_fetch[wave][0] = 0; shared_fetch[wave][1] = 0; shared_fetch[wave][2] = 0; }
+	__shared__ int shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4]; // per wave: next, end, drained
+	typedef volatile __attribute__((address_space(3))) int LdsFetchWord; // typed: ds_read/ds_write, not FLAT
+	LdsFetchWord * fetch_state = (LdsFetchWord *)&shared_fetch[wave][0];
+	if (lane == 0) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[2] = 0; }
 	// Called (converged) by the lanes that need a ray; returns its index or -1 once the launch is drained.
 	auto fetch_ray = [&]() -> int {
 		while (true) {
-			if (shared_fetch[wave][2]) return -1;
+			if (fetch_state[2]) return -1;
 			unsigned long long want = __ballot(1);
 			int n_want = __popcll(want);
 			unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(want >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(want), 0u));
-			int next = shared_fetch[wave][0], end = shared_fetch[wave][1];
+			int next = fetch_state[0], end = fetch_state[1];
 			if (next >= end) { // the same for every lane of the ballot: claim the next block
 				int base = 0;
 				int claim = RT_FETCH_BLOCK_MAX > RT_WAVE_SIZE ? ray_block : n_want;
@@ -249,9 +256,9 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 			}
 			int give = min(n_want, end - next);
 			if (rank == 0) {
-				shared_fetch[wave][0] = next + give;
-				shared_fetch[wave][1] = end;
-				if (next >= end) shared_fetch[wave][2] = 1;
+				fetch_state[0] = next + give;
+				fetch_state[1] = end;
+				if (next >= end) fetch_state[2] = 1;
 			}
 			if (int(rank) < give) return next + int(rank);
 			// the block did not cover every lane: the rest goes round again (and claims a new block)
@@ -259,6 +266,7 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 	};
 
 	uint2 current_group = make_uint2(0, 0);
+	uint2 triangle_group = make_uint2(0, 0);  // leaf work of this lane that is still to be tested
 
 	int  ray_index = 0;
 	Ray3 ray;
@@ -270,9 +278,13 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 	int  mesh_id = 0;
 	bool mesh_has_identity_transform = true;
 	unsigned count_nodes = 0, count_triangles = 0, count_inst_xform = 0, count_inst_ident = 0;
+#ifdef RT_PHASE_STATS   // debug build: SIMD lane occupancy of the two phases, reported in the shadow slots stats[5..9]
+	unsigned phase_iterations = 0, phase_node_execs = 0, phase_node_lanes = 0, phase_tri_rounds = 0, phase_tri_lanes = 0;
+	#define RT_PHASE_LEADER() (__builtin_amdgcn_mbcnt_hi(unsigned(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(__ballot(1)), 0u)) == 0)
+#endif
 
 	while (true) {
-		bool inactive = stack.size == 0 && current_group.y == 0;
+		bool inactive = stack.size == 0 && current_group.y == 0 && triangle_group.y == 0;
 
 		if (inactive) {
 			ray_index = fetch_ray();
@@ -289,84 +301,130 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 
 		int iterations_lost = 0;
 		do {
-			uint2 triangle_group;
+			// ---- node phase: lanes with no triangle work pending advance their traversal by one step
+			if (triangle_group.y == 0) {
+				if (current_group.y & 0xff000000u) {
+					// take the closest pending child of current_group (pushing the rest) and fetch its node
+					unsigned hits_imask = current_group.y;
+					unsigned child_index_offset = msb(hits_imask);
+					unsigned child_index_base   = current_group.x;
 
-			if (current_group.y & 0xff000000u) {
-				unsigned hits_imask = current_group.y;
-				unsigned child_index_offset = msb(hits_imask);
-				unsigned child_index_base   = current_group.x;
+					current_group.y &= ~(1u << child_index_offset);
+					if (current_group.y & 0xff000000u) stack.push(current_group);
 
-				current_group.y &= ~(1u << child_index_offset);
+					unsigned slot_index     = (child_index_offset - 24) ^ (oct_inv4 & 0xffu);
+					unsigned relative_index = __popc(hits_imask & ~(0xffffffffu << slot_index));
+					unsigned child_node_index = child_index_base + relative_index;
+
+					const float4 * node = nodes + size_t(child_node_index) * 5;
+					float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
+					if (COUNT) count_nodes++;
+#ifdef RT_PHASE_STATS
+					if (COUNT && !SHADOW) { phase_node_lanes++; if (RT_PHASE_LEADER()) phase_node_execs++; }
+#endif
+					unsigned hitmask = bvh8_node_intersect(ray, inv_dir, oct_inv4, SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
+					unsigned imask = extract_byte(__float_as_uint(n0.w), 3);
+
+					current_group .x = __float_as_uint(n1.x);
+					triangle_group.x = __float_as_uint(n1.y);
+					current_group .y = (hitmask & 0xff000000u) | imask;
+					triangle_group.y = (hitmask & 0x00ffffffu);
+				} else {
+					triangle_group = current_group; // a leaf group popped from the stack
+					current_group  = make_uint2(0, 0);
+				}
+			}
+#ifdef RT_PHASE_STATS
+			if (COUNT && !SHADOW && RT_PHASE_LEADER()) phase_iterations++;
+#endif
+
+			// ---- TLAS leaf: enter the next instance (rare, not gated)
+			if (triangle_group.y != 0 && tlas_stack_size == RT_INVALID) {
+				int mesh_offset = int(msb(triangle_group.y));
+				triangle_group.y &= ~(1u << mesh_offset);
+				mesh_id = int(triangle_group.x) + mesh_offset;
+
+				if (triangle_group.y != 0)         stack.push(triangle_group);
 				if (current_group.y & 0xff000000u) stack.push(current_group);
+				tlas_stack_size = stack.size;
+				triangle_group.y = 0;
 
-				unsigned slot_index     = (child_index_offset - 24) ^ (oct_inv4 & 0xffu);
-				unsigned relative_index = __popc(hits_imask & ~(0xffffffffu << slot_index));
-				unsigned child_node_index = child_index_base + relative_index;
-
-				const float4 * node = nodes + size_t(child_node_index) * 5;
-				float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
-				if (COUNT) count_nodes++;
-
-				unsigned hitmask = bvh8_node_intersect(ray, inv_dir, oct_inv4, SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
-				unsigned imask = extract_byte(__float_as_uint(n0.w), 3);
-
-				current_group .x = __float_as_uint(n1.x);
-				triangle_group.x = __float_as_uint(n1.y);
-				current_group .y = (hitmask & 0xff000000u) | imask;
-				triangle_group.y = (hitmask & 0x00ffffffu);
-			} else {
-				triangle_group = current_group;
-				current_group  = make_uint2(0, 0);
+				unsigned root = unsigned(p.mesh_bvh_root_indices[mesh_id]);
+				mesh_has_identity_transform = (root >> 31) != 0;
+				if (!mesh_has_identity_transform) {
+					const float4 * m = p.mesh_transforms_inv + size_t(mesh_id) * 3;
+					ray.origin    = transform_position (m, ray.origin);
+					ray.direction = transform_direction(m, ray.direction);
+					inv_dir  = reciprocal(ray.direction);
+					oct_inv4 = ray_get_octant_inv4(ray.direction);
+					if (COUNT) count_inst_xform++;
+				} else if (COUNT) count_inst_ident++;
+				current_group = make_uint2(root & 0x7fffffffu, 0x80000000u);
 			}
 
+			// ---- triangle phase: ONE batch per round, then back to the node phase. Lanes with more
+			// triangles than a batch keep them in triangle_group and take part in the next rounds while
+			// the other lanes already traverse on; the earlier form (an inner loop until the lane with
+			// the most triangles was done, 3.2 rounds per node round at 6.6 of 64 lanes) cost +23 % time.
+			// Holding triangle rounds back until more lanes have work ("postponing" without reordering)
+			// was measured too and is slower at every threshold: the kernel is bound by the length of
+			// each ray's dependent chain, not by issue slots (profiles/r01_trace_loop_structure.txt).
 			bool occluded = false;
-			while (triangle_group.y != 0) {
-				if (tlas_stack_size == RT_INVALID) {
-					int mesh_offset = int(msb(triangle_group.y));
-					triangle_group.y &= ~(1u << mesh_offset);
-					mesh_id = int(triangle_group.x) + mesh_offset;
-
-					if (triangle_group.y != 0)         stack.push(triangle_group);
-					if (current_group.y & 0xff000000u) stack.push(current_group);
-					tlas_stack_size = stack.size;
-
-					unsigned root = unsigned(p.mesh_bvh_root_indices[mesh_id]);
-					mesh_has_identity_transform = (root >> 31) != 0;
-					if (!mesh_has_identity_transform) {
-						const float4 * m = p.mesh_transforms_inv + size_t(mesh_id) * 3;
-						ray.origin    = transform_position (m, ray.origin);
-						ray.direction = transform_direction(m, ray.direction);
-						inv_dir  = reciprocal(ray.direction);
-						oct_inv4 = ray_get_octant_inv4(ray.direction);
-						if (COUNT) count_inst_xform++;
-					} else if (COUNT) count_inst_ident++;
-					current_group = make_uint2(root & 0x7fffffffu, 0x80000000u);
-					break;
-				} else {
-					int triangle_index = int(msb(triangle_group.y));
-					triangle_group.y &= ~(1u << triangle_index);
-					if (COUNT) count_triangles++;
-					if (triangle_test<SHADOW>(triangles, mesh_id, int(triangle_group.x) + triangle_index, ray, max_distance, hit)) {
-						occluded = true;
-						break;
+			{
+				bool has_triangles = triangle_group.y != 0;
+				if (has_triangles) {
+#ifdef RT_PHASE_STATS
+					if (COUNT && !SHADOW) { phase_tri_lanes++; if (RT_PHASE_LEADER()) phase_tri_rounds++; }
+#endif
+					// up to RT_TRI_BATCH triangles per round: all their loads are issued before the first
+					// test, the tests run in the sequential order (each sees the hit.t left by the previous)
+					int    tri_id[RT_TRI_BATCH];
+					float4 tri_a[RT_TRI_BATCH], tri_b[RT_TRI_BATCH];
+					float  tri_c[RT_TRI_BATCH];
+					#pragma unroll
+					for (int k = 0; k < RT_TRI_BATCH; k++) {
+						tri_id[k] = RT_INVALID;
+						if (triangle_group.y != 0) {
+							int triangle_index = int(msb(triangle_group.y));
+							triangle_group.y &= ~(1u << triangle_index);
+							tri_id[k] = int(triangle_group.x) + triangle_index;
+							const float4 * tri = triangles + size_t(tri_id[k]) * 3;
+							tri_a[k] = tri[0]; tri_b[k] = tri[1]; tri_c[k] = tri[2].x; // position_0, edge_1, edge_2
+						}
+					}
+					#pragma unroll
+					for (int k = 0; k < RT_TRI_BATCH; k++) {
+						if (tri_id[k] != RT_INVALID && !occluded) {
+							if (COUNT) count_triangles++;
+							if (triangle_test_loaded<SHADOW>(tri_a[k], tri_b[k], make_float4(tri_c[k], 0.0f, 0.0f, 0.0f), mesh_id, tri_id[k], ray, max_distance, hit)) occluded = true;
+						}
 					}
 				}
 			}
 
-			if (COUNT && ((SHADOW && occluded) || ((current_group.y & 0xff000000u) == 0 && stack.size == 0))) {
+			bool traversal_done = triangle_group.y == 0 && (current_group.y & 0xff000000u) == 0 && stack.size == 0;
+			if (COUNT && ((SHADOW && occluded) || traversal_done)) {
 				atomicAdd(&stats[0], (unsigned long long)count_nodes);     atomicAdd(&stats[1], (unsigned long long)count_triangles);
 				atomicAdd(&stats[2], (unsigned long long)count_inst_xform); atomicAdd(&stats[3], (unsigned long long)count_inst_ident);
 				atomicAdd(&stats[4], 1ull);
 				count_nodes = count_triangles = count_inst_xform = count_inst_ident = 0;
+#ifdef RT_PHASE_STATS
+				if (!SHADOW) {
+					atomicAdd(&stats[5], (unsigned long long)phase_iterations); atomicAdd(&stats[6], (unsigned long long)phase_node_execs); atomicAdd(&stats[7], (unsigned long long)phase_node_lanes);
+					atomicAdd(&stats[8], (unsigned long long)phase_tri_rounds); atomicAdd(&stats[9], (unsigned long long)phase_tri_lanes);
+					phase_iterations = phase_node_execs = phase_node_lanes = phase_tri_rounds = phase_tri_lanes = 0;
+				}
+#endif
 			}
 			if (SHADOW && occluded) {
 				src.finish(ray_index, hit, true);
 				stack.size = 0;
 				current_group.y = 0;
+				triangle_group.y = 0;
 				break;
 			}
 
-			if ((current_group.y & 0xff000000u) == 0) {
+			if (triangle_group.y == 0 && (current_group.y & 0xff000000u) == 0) {
 				if (stack.size == 0) {
 					src.finish(ray_index, hit, false);
 					current_group.y = 0;
@@ -722,7 +780,11 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh8_counting(RtParams p, int bounce, unsigned long long * stats) {
 	ShadowQueueSource src { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT], bounce };
+#ifdef RT_PHASE_STATS
+	RT_TRACE_ENGINE<true, false>(p, src, p.sizes->shadow[bounce], p.xcd_counters + (2 * bounce + 1) * RT_NUM_XCD); // slots 5..9 carry the phase statistics
+#else
 	RT_TRACE_ENGINE<true, true>(p, src, p.sizes->shadow[bounce], p.xcd_counters + (2 * bounce + 1) * RT_NUM_XCD, stats + 5);
+#endif
 }
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {

@@ -809,9 +809,14 @@ int rt_get_counters(rt_context * ctx, rt_counters * out) {
 	if (hipEventElapsedTime(&ms, slot.ev_frame_start, slot.ev_frame_end) == hipSuccess) c.ms_total = ms;
 	if (ctx->profiling) {
 		float * bucket[STAGE_END] = { &c.ms_generate, &c.ms_trace, &c.ms_sort, &c.ms_shade, &c.ms_shadow, &c.ms_post };
+		static const bool print_stages = getenv("GRT_STAGE_TRACE") != nullptr; // one line per launch group, in submission order
+		static const char * stage_names[STAGE_END] = { "generate", "trace", "sort", "shade", "shadow", "post" };
 		for (size_t i = 0; i + 1 < ctx->stage_used; i++) {
 			float d = 0.0f;
-			if (hipEventElapsedTime(&d, ctx->stage_events[i], ctx->stage_events[i + 1]) == hipSuccess && ctx->stage_kinds[i] < STAGE_END) *bucket[ctx->stage_kinds[i]] += d;
+			if (hipEventElapsedTime(&d, ctx->stage_events[i], ctx->stage_events[i + 1]) == hipSuccess && ctx->stage_kinds[i] < STAGE_END) {
+				*bucket[ctx->stage_kinds[i]] += d;
+				if (print_stages) fprintf(stderr, "[grt] stage %-8s %8.4f ms\n", stage_names[ctx->stage_kinds[i]], d);
+			}
 		}
 	}
 	ctx->last_counters = c;
