@@ -12,6 +12,9 @@
 #include "rt_shading.h"
 
 #define RT_SHADE_BLOCK 256
+#ifndef RT_SORT_BLOCK
+#define RT_SORT_BLOCK 512   // kernel_sort: 8 waves share one atomic per material queue
+#endif
 
 struct HitInfo { float t, u, v; int mesh_id, triangle_id; };
 
@@ -172,8 +175,7 @@ RT_DEV void svgf_set_gbuffers(const RtParams & p, int x, int y, const HitInfo & 
 	p.gbuffer_screen_position_prev[idx] = make_float2(u_prev.x / u_prev.w, u_prev.y / u_prev.w);
 }
 
-RT_DEV void material_queue_append(const RtParams & p, int slot, int * counter, int bounce, f3 ray_direction, int medium_id, float cone_angle, float cone_width, uint4 hit, int pixel_index, f3 throughput) {
-	int index_out = wave_aggregated_append(counter);
+RT_DEV void material_queue_store(const RtParams & p, int slot, int index_out, int bounce, f3 ray_direction, int medium_id, float cone_angle, float cone_width, uint4 hit, int pixel_index, f3 throughput) {
 	const RtMaterialBuffer & q = p.material[slot];
 	store3(q.direction, index_out, ray_direction);
 	if (medium_id != RT_INVALID) q.medium[index_out] = medium_id;
@@ -184,30 +186,40 @@ RT_DEV void material_queue_append(const RtParams & p, int slot, int * counter, i
 	if (bounce > 0) store3(q.throughput, index_out, throughput);
 }
 
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_sort(RtParams p, int bounce, int sample_index) {
+__global__ void __launch_bounds__(RT_SORT_BLOCK) kernel_sort(RtParams p, int bounce, int sample_index) {
 	const int ray_count = p.sizes->trace[bounce];
 	const RtTraceBuffer & in  = p.trace[bounce & 1];
 	const RtTraceBuffer & out = p.trace[(bounce + 1) & 1];
+	__shared__ BlockAppendLDS<4, RT_SORT_BLOCK / RT_WAVE_SIZE> append_lds;
+	int * const material_counters[4] = { &p.sizes->diffuse[bounce], &p.sizes->plastic[bounce], &p.sizes->dielectric[bounce], &p.sizes->conductor[bounce] };
 
-	for (int index = blockIdx.x * blockDim.x + threadIdx.x; index < ray_count; index += gridDim.x * blockDim.x) {
-		f3 ray_direction = load3(in.direction, index);
-		uint4 packed_hit = in.hits[index];
+	// every thread of the workgroup makes the same number of rounds (block_aggregated_append has barriers)
+	for (int first = blockIdx.x * blockDim.x; first < ray_count; first += gridDim.x * blockDim.x) {
+		const int index = first + int(threadIdx.x);
+		f3 ray_direction = mk3(0.0f); uint4 packed_hit = make_uint4(0, 0, 0, 0);
+		float ray_cone_angle = 0.0f, ray_cone_width = 0.0f;
+		int pixel_index = 0, medium_id = RT_INVALID;
+		f3 throughput = mk3(1.0f);
+
+		// classify one ray: the material queue it continues in, or -1 (missed, hit a light, scattered, terminated)
+		auto classify = [&]() -> int {
+		if (index >= ray_count) return -1;
+		ray_direction = load3(in.direction, index);
+		packed_hit = in.hits[index];
 		HitInfo hit = unpack_hit(packed_hit);
 
-		float ray_cone_angle = 0.0f, ray_cone_width = 0.0f;
 		if (bounce > 0 && p.config.enable_mipmapping) { ray_cone_angle = in.cone_angle[index]; ray_cone_width = in.cone_width[index]; }
 
 		unsigned pixel_index_and_flags = in.pixel_index_and_flags[index];
-		int pixel_index = int(pixel_index_and_flags & ~RT_FLAGS_ALL);
+		pixel_index = int(pixel_index_and_flags & ~RT_FLAGS_ALL);
 		int x = pixel_index % p.screen_pitch;
 		int y = pixel_index / p.screen_pitch;
 
 		bool allow_nee     = pixel_index_and_flags & RT_FLAG_ALLOW_NEE;
 		bool inside_medium = pixel_index_and_flags & RT_FLAG_INSIDE_MEDIUM;
 
-		f3 throughput = bounce == 0 ? mk3(1.0f) : load3(in.throughput, index);
+		throughput = bounce == 0 ? mk3(1.0f) : load3(in.throughput, index);
 
-		int medium_id = RT_INVALID;
 		if (inside_medium) {
 			medium_id = in.medium[index];
 			HomogeneousMedium medium = medium_as_homogeneous(p, medium_id);
@@ -231,7 +243,7 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_sort(RtParams p, int bo
 				if (scatter_distance < hit.t) {
 					f3 pdf = wavelength_pdf * sigma_t * transmittance;
 					throughput *= medium.sigma_s * transmittance / (pdf.x + pdf.y + pdf.z);
-					if (russian_roulette(p, pixel_index, bounce, sample_index, throughput)) continue;
+					if (russian_roulette(p, pixel_index, bounce, sample_index, throughput)) return -1;
 
 					f3 direction_out = sample_henyey_greenstein(-ray_direction, medium.g, rand_phase.x, rand_phase.y);
 					f3 origin_out = load3(in.origin, index) + scatter_distance * ray_direction;
@@ -247,7 +259,7 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_sort(RtParams p, int bo
 					}
 					out.pixel_index_and_flags[index_out] = unsigned(pixel_index) | RT_FLAG_INSIDE_MEDIUM;
 					store3(out.throughput, index_out, throughput);
-					continue;
+					return -1;
 				} else {
 					f3 pdf = wavelength_pdf * transmittance;
 					throughput *= transmittance / (pdf.x + pdf.y + pdf.z);
@@ -260,7 +272,7 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_sort(RtParams p, int bo
 		if (hit.triangle_id == RT_INVALID) { // miss: sky
 			f3 illumination = throughput * sample_sky(p, ray_direction);
 			add_radiance(p, bounce, pixel_index, illumination, illumination);
-			continue;
+			return -1;
 		}
 
 		int material_id = p.mesh_material_ids[hit.mesh_id];
@@ -287,7 +299,7 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_sort(RtParams p, int bo
 			bool count_light = p.config.enable_next_event_estimation ? !allow_nee : true;
 			if (count_light) {
 				add_radiance(p, bounce, pixel_index, throughput * emission, emission);
-				continue;
+				return -1;
 			}
 			if (p.config.enable_multiple_importance_sampling) {
 				float cos_theta_light = abs_dot(ray_direction, light_geometric_normal);
@@ -295,24 +307,30 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_sort(RtParams p, int bo
 				float brdf_pdf = in.last_pdf[index];
 				float light_power = luminance(emission.x, emission.y, emission.z);
 				float light_pdf = light_power * distance_to_light_squared / (cos_theta_light * p.lights_total_weight);
-				if (!pdf_is_valid(light_pdf)) continue;
+				if (!pdf_is_valid(light_pdf)) return -1;
 				float mis_weight = power_heuristic(brdf_pdf, light_pdf);
 				f3 illumination = throughput * emission * mis_weight;
 				aov_add(p, RT_AOV_RADIANCE, pixel_index, mk4(illumination));
 				if (bounce == 1) aov_add(p, RT_AOV_RADIANCE_DIRECT,   pixel_index, mk4(illumination));
 				else             aov_add(p, RT_AOV_RADIANCE_INDIRECT, pixel_index, mk4(illumination));
 			}
-			continue;
+			return -1;
 		}
 
-		if (russian_roulette(p, pixel_index, bounce, sample_index, throughput)) continue;
+		if (russian_roulette(p, pixel_index, bounce, sample_index, throughput)) return -1;
 
 		switch (material_type) {
-			case RT_MATERIAL_DIFFUSE:    material_queue_append(p, 0, &p.sizes->diffuse   [bounce], bounce, ray_direction, medium_id, ray_cone_angle, ray_cone_width, packed_hit, pixel_index, throughput); break;
-			case RT_MATERIAL_PLASTIC:    material_queue_append(p, 1, &p.sizes->plastic   [bounce], bounce, ray_direction, medium_id, ray_cone_angle, ray_cone_width, packed_hit, pixel_index, throughput); break;
-			case RT_MATERIAL_DIELECTRIC: material_queue_append(p, 2, &p.sizes->dielectric[bounce], bounce, ray_direction, medium_id, ray_cone_angle, ray_cone_width, packed_hit, pixel_index, throughput); break;
-			case RT_MATERIAL_CONDUCTOR:  material_queue_append(p, 3, &p.sizes->conductor [bounce], bounce, ray_direction, medium_id, ray_cone_angle, ray_cone_width, packed_hit, pixel_index, throughput); break;
+			case RT_MATERIAL_DIFFUSE:    return 0;
+			case RT_MATERIAL_PLASTIC:    return 1;
+			case RT_MATERIAL_DIELECTRIC: return 2;
+			case RT_MATERIAL_CONDUCTOR:  return 3;
 		}
+		return -1;
+		};
+
+		int slot = classify();
+		int index_out = block_aggregated_append(slot, material_counters, append_lds);
+		if (slot >= 0) material_queue_store(p, slot, index_out, bounce, ray_direction, medium_id, ray_cone_angle, ray_cone_width, packed_hit, pixel_index, throughput);
 	}
 }
 
@@ -597,8 +615,11 @@ RT_DEV int sample_light(const RtParams & p, float u1, float u2, int & transform_
 	return p.light_triangle_indices[light_triangle_id];
 }
 
+struct ShadowRay { f3 origin, direction; float max_distance; f3 illumination; };
+
+// Returns true and fills `shadow` when the light sample has to be traced (the caller appends it).
 template<typename BSDF>
-RT_DEV void next_event_estimation(const RtParams & p, int pixel_index, int bounce, int sample_index, const BSDF & bsdf, f3 hit_point, f3 normal, f3 geometric_normal, f3 throughput) {
+RT_DEV bool next_event_estimation(const RtParams & p, int pixel_index, int bounce, int sample_index, const BSDF & bsdf, f3 hit_point, f3 normal, f3 geometric_normal, f3 throughput, ShadowRay & shadow) {
 	f2 rand_light    = random_sample(p, DIM_NEE_LIGHT,    unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
 	f2 rand_triangle = random_sample(p, DIM_NEE_TRIANGLE, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
 
@@ -629,20 +650,18 @@ RT_DEV void next_event_estimation(const RtParams & p, int pixel_index, int bounc
 	f3 emission = mk3(p.materials[2 * light_material_id]);
 
 	f3 bsdf_value; float bsdf_pdf;
-	if (!bsdf.eval(p, to_light, cos_theta_hit, bsdf_value, bsdf_pdf)) return;
+	if (!bsdf.eval(p, to_light, cos_theta_hit, bsdf_value, bsdf_pdf)) return false;
 
 	float light_power = luminance(emission.x, emission.y, emission.z);
 	float light_pdf   = light_power * square(distance_to_light) / (cos_theta_light * p.lights_total_weight);
-	if (!pdf_is_valid(light_pdf)) return;
+	if (!pdf_is_valid(light_pdf)) return false;
 
 	float mis_weight = p.config.enable_multiple_importance_sampling ? power_heuristic(light_pdf, bsdf_pdf) : 1.0f;
-	f3 illumination = throughput * bsdf_value * emission * mis_weight / light_pdf;
-
-	int shadow_ray_index = wave_aggregated_append(&p.sizes->shadow[bounce]);
-	store3(p.shadow.origin,    shadow_ray_index, hit_point);
-	store3(p.shadow.direction, shadow_ray_index, to_light);
-	p.shadow.max_distance[shadow_ray_index] = distance_to_light;
-	p.shadow.illumination_and_pixel_index[shadow_ray_index] = make_float4(illumination.x, illumination.y, illumination.z, __int_as_float(pixel_index));
+	shadow.illumination = throughput * bsdf_value * emission * mis_weight / light_pdf;
+	shadow.origin = hit_point;
+	shadow.direction = to_light;
+	shadow.max_distance = distance_to_light;
+	return true;
 }
 
 // ---- shade_material<BSDF> (Pathtracer.cu:557-757) -------------------------------------------------------------
@@ -678,19 +697,35 @@ RT_DEV void shade_material(const RtParams & p, int bounce, int sample_index, int
 	const RtMaterialBuffer & q = p.material[SLOT];
 	const RtTraceBuffer & out = p.trace[(bounce + 1) & 1];
 
-	for (int index = blockIdx.x * blockDim.x + threadIdx.x; index < buffer_size; index += gridDim.x * blockDim.x) {
+	__shared__ BlockAppendLDS<1, RT_SHADE_BLOCK / RT_WAVE_SIZE> append_lds;
+	int * const shadow_counter[1] = { &p.sizes->shadow[bounce] };
+	int * const trace_counter[1]  = { &p.sizes->trace[bounce + 1] };
+	const bool nee_enabled = p.config.enable_next_event_estimation && p.lights_total_weight > 0.0f; // uniform
+
+	// every thread of the workgroup makes the same number of rounds (block_aggregated_append has barriers)
+	for (int first = blockIdx.x * blockDim.x; first < buffer_size; first += gridDim.x * blockDim.x) {
+		const int index = first + int(threadIdx.x);
+		// what survives from the surface set-up to the two queue appends
+		BSDF bsdf;
+		int pixel_index = 0, medium_id = RT_INVALID;
+		f3 throughput = mk3(1.0f), hit_point = mk3(0.0f), geometric_normal = mk3(0.0f);
+		float cone_angle = 0.0f, cone_width = 0.0f;
+		ShadowRay shadow; bool has_shadow_ray = false;
+
+		auto set_up_surface = [&]() -> bool { // false: the path ends here
+		if (index >= buffer_size) return false;
 		f3 ray_direction = load3(q.direction, index);
 		HitInfo hit = unpack_hit(q.hits[index]);
 
 		unsigned pixel_index_and_flags = q.pixel_index_and_flags[index];
-		int pixel_index = int(pixel_index_and_flags & ~RT_FLAGS_ALL);
+		pixel_index = int(pixel_index_and_flags & ~RT_FLAGS_ALL);
 		bool inside_medium = pixel_index_and_flags & RT_FLAG_INSIDE_MEDIUM;
-		int medium_id = inside_medium ? q.medium[index] : RT_INVALID;
+		medium_id = inside_medium ? q.medium[index] : RT_INVALID;
 
-		f3 throughput = bounce == 0 ? mk3(1.0f) : load3(q.throughput, index);
+		throughput = bounce == 0 ? mk3(1.0f) : load3(q.throughput, index);
 
 		TriangleFull tri = triangle_get_full(p, hit.triangle_id);
-		f3 hit_point = barycentric(hit.u, hit.v, tri.position_0, tri.position_edge_1, tri.position_edge_2);
+		hit_point = barycentric(hit.u, hit.v, tri.position_0, tri.position_edge_1, tri.position_edge_2);
 		f3 normal    = barycentric(hit.u, hit.v, tri.normal_0,   tri.normal_edge_1,   tri.normal_edge_2);
 		f2 tex_coord = barycentric(hit.u, hit.v, tri.tex_coord_0, tri.tex_coord_edge_1, tri.tex_coord_edge_2);
 		f3 hit_point_local = hit_point;
@@ -702,7 +737,7 @@ RT_DEV void shade_material(const RtParams & p, int bounce, int sample_index, int
 		float4 world_row_0 = world[0];
 		float mesh_scale_inv = 1.0f / length(mk3(world_row_0.x, world_row_0.y, world_row_0.z));
 
-		float cone_angle = 0.0f, cone_width = 0.0f, curvature = 0.0f;
+		float curvature = 0.0f;
 		if (p.config.enable_mipmapping) {
 			if (bounce == 0) { cone_angle = p.camera.pixel_spread_angle; cone_width = cone_angle * hit.t; }
 			else             { cone_angle = q.cone_angle[index]; cone_width = q.cone_width[index] + cone_angle * hit.t; }
@@ -712,7 +747,7 @@ RT_DEV void shade_material(const RtParams & p, int bounce, int sample_index, int
 		tri.position_edge_1 = m_direction(world, tri.position_edge_1);
 		tri.position_edge_2 = m_direction(world, tri.position_edge_2);
 
-		f3 geometric_normal = cross(tri.position_edge_1, tri.position_edge_2);
+		geometric_normal = cross(tri.position_edge_1, tri.position_edge_2);
 		float triangle_double_area_inv = 1.0f / length(geometric_normal);
 		geometric_normal *= triangle_double_area_inv;
 
@@ -722,11 +757,10 @@ RT_DEV void shade_material(const RtParams & p, int bounce, int sample_index, int
 		f3 tangent, bitangent;
 		orthonormal_basis(normal, tangent, bitangent);
 		f3 omega_i = world_to_local(-ray_direction, tangent, bitangent, normal);
-		if (omega_i.z <= 0.0f) continue;
+		if (omega_i.z <= 0.0f) return false;
 
 		int material_id = p.mesh_material_ids[hit.mesh_id];
 
-		BSDF bsdf;
 		bsdf.pixel_index = pixel_index; bsdf.bounce = bounce; bsdf.sample_index = sample_index;
 		bsdf.tangent = tangent; bsdf.bitangent = bitangent; bsdf.normal = normal; bsdf.omega_i = omega_i;
 		bsdf.init(p, entering_material, material_id);
@@ -763,16 +797,31 @@ RT_DEV void shade_material(const RtParams & p, int bounce, int sample_index, int
 			svgf_set_gbuffers(p, x, y, hit, hit_point, normal, hit_point_prev);
 		}
 
-		if (p.config.enable_next_event_estimation && p.lights_total_weight > 0.0f && bsdf.allow_nee()) {
-			next_event_estimation(p, pixel_index, bounce, sample_index, bsdf, hit_point, normal, geometric_normal, throughput);
+		if (nee_enabled && bsdf.allow_nee()) {
+			has_shadow_ray = next_event_estimation(p, pixel_index, bounce, sample_index, bsdf, hit_point, normal, geometric_normal, throughput, shadow);
+		}
+		return true;
+		};
+
+		bool alive = set_up_surface();
+
+		if (nee_enabled) {
+			int shadow_ray_index = block_aggregated_append(has_shadow_ray ? 0 : -1, shadow_counter, append_lds);
+			if (has_shadow_ray) {
+				store3(p.shadow.origin,    shadow_ray_index, shadow.origin);
+				store3(p.shadow.direction, shadow_ray_index, shadow.direction);
+				p.shadow.max_distance[shadow_ray_index] = shadow.max_distance;
+				p.shadow.illumination_and_pixel_index[shadow_ray_index] = make_float4(shadow.illumination.x, shadow.illumination.y, shadow.illumination.z, __int_as_float(pixel_index));
+			}
 		}
 
-		f3 direction_out; float pdf;
-		if (!bsdf.sample(p, throughput, medium_id, direction_out, pdf)) continue;
+		f3 direction_out = mk3(0.0f); float pdf = 0.0f;
+		bool continues = alive && bsdf.sample(p, throughput, medium_id, direction_out, pdf);
+
+		int index_out = block_aggregated_append(continues ? 0 : -1, trace_counter, append_lds);
+		if (!continues) continue;
 
 		f3 origin_out = ray_origin_epsilon_offset(hit_point, direction_out, geometric_normal);
-
-		int index_out = wave_aggregated_append(&p.sizes->trace[bounce + 1]);
 		store3(out.origin,    index_out, origin_out);
 		store3(out.direction, index_out, direction_out);
 		if (medium_id != RT_INVALID) out.medium[index_out] = medium_id;
@@ -807,7 +856,7 @@ void rt_launch_generate(const RtParams & p, int sample_index, int pixel_offset, 
 	hipLaunchKernelGGL(kernel_generate, dim3(streaming_grid(pixel_count)), dim3(RT_SHADE_BLOCK), 0, stream, p, sample_index, pixel_offset, pixel_count);
 }
 void rt_launch_sort(const RtParams & p, int bounce, int sample_index, hipStream_t stream) {
-	hipLaunchKernelGGL(kernel_sort, dim3(2048), dim3(RT_SHADE_BLOCK), 0, stream, p, bounce, sample_index);
+	hipLaunchKernelGGL(kernel_sort, dim3(2048 * RT_SHADE_BLOCK / RT_SORT_BLOCK), dim3(RT_SORT_BLOCK), 0, stream, p, bounce, sample_index);
 }
 void rt_launch_material(const RtParams & p, int material_slot, int bounce, int sample_index, hipStream_t stream) {
 	dim3 grid(2048), block(RT_SHADE_BLOCK);

@@ -91,3 +91,35 @@ RT_DEV int wave_aggregated_append(int * counter) {
 	base = __shfl(base, leader);
 	return base + int(rank);
 }
+
+// One returning atomic per WORKGROUP and queue. A queue counter is one word; the L2 retires about 88
+// returning atomics per microsecond on one word (MI355X_MICROARCH.md, "dequeue"), and the sort /
+// shade kernels of a 2 M ray bounce issued 65 000 wave-level appends to two words: they ran AT that
+// limit (0.30 ms for a pass that moves 200 MB). Aggregating over the WAVES waves of a workgroup
+// divides the atomics by WAVES. Must be called by every thread of the workgroup in uniform control
+// flow; queue = -1 (nothing to append) or 0..NQ-1; returns the slot in that queue.
+template<int NQ, int WAVES>
+struct BlockAppendLDS { int count[WAVES][NQ]; int base[WAVES][NQ]; };
+
+template<int NQ, int WAVES>
+RT_DEV int block_aggregated_append(int queue, int * const (&counters)[NQ], BlockAppendLDS<NQ, WAVES> & lds) {
+	unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	unsigned rank = 0;
+	#pragma unroll
+	for (int k = 0; k < NQ; k++) {
+		unsigned long long mask = __ballot(queue == k);
+		if (queue == k) rank = __builtin_amdgcn_mbcnt_hi(unsigned(mask >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(mask), 0u));
+		if (lane == 0) lds.count[wave][k] = __popcll(mask);
+	}
+	__syncthreads();
+	if (threadIdx.x < NQ) {
+		int k = threadIdx.x, total = 0;
+		#pragma unroll
+		for (int w = 0; w < WAVES; w++) { int c = lds.count[w][k]; lds.base[w][k] = total; total += c; }
+		int base = total > 0 ? atomicAdd(counters[k], total) : 0;
+		#pragma unroll
+		for (int w = 0; w < WAVES; w++) lds.base[w][k] += base;
+	}
+	__syncthreads();
+	return queue >= 0 ? lds.base[wave][queue] + int(rank) : -1;
+}
