@@ -184,7 +184,34 @@ def scene_path(name):
         os.makedirs(cache, exist_ok=True)
         with tarfile.open(os.path.join(ASSET_DIR, "scenes", archive)) as tar:
             tar.extractall(cache)
+    if name == "sponza":
+        _unpack_sponza_textures(cache)
     return target
+
+
+def _unpack_sponza_textures(cache):
+    """The 19 diffuse maps of Data/Sponza/textures travel at a quarter of their side length
+    (tools/pack_sponza_textures.py); every texel is replicated 4x4 here so that the renderer loads
+    textures of the reference's dimensions (mip chain depth, memory footprint, LOD selection)."""
+    done = os.path.join(cache, "Sponza", "textures", ".complete")
+    archive = os.path.join(ASSET_DIR, "scenes", "sponza_textures_256.tar.xz")
+    if os.path.exists(done) or not os.path.exists(archive):
+        return
+    os.makedirs(os.path.dirname(done), exist_ok=True)
+    with tarfile.open(archive) as tar:
+        for member in tar.getmembers():
+            data = tar.extractfile(member).read()
+            w, h, bpp, desc = np.frombuffer(data, np.uint16, 2, 12).tolist() + [data[16], data[17]]
+            channels = bpp // 8
+            px = np.frombuffer(data, np.uint8, w * h * channels, 18).reshape(h, w, channels)
+            big = np.repeat(np.repeat(px, 4, axis=0), 4, axis=1)
+            header = bytearray(data[:18])
+            header[12:16] = np.array([w * 4, h * 4], np.uint16).tobytes()
+            tmp = os.path.join(os.path.dirname(done), os.path.basename(member.name))
+            with open(tmp + ".part", "wb") as f:
+                f.write(bytes(header) + big.tobytes())
+            os.replace(tmp + ".part", tmp)
+    open(done, "w").close()
 
 
 def config_reset():
