@@ -182,6 +182,33 @@ def test_sponza_plastic_variant_matches_oracle(grt, oracle):
     pt.close(); scene.close()
 
 
+def test_sponza_texture_path_albedo_normal_position_aovs(grt, oracle):
+    """The texture unit (a17): bounce-0 ALBEDO is the anisotropic / trilinear fetch of the diffuse map
+    with ray-cone gradients, nothing else; NORMAL and POSITION are the interpolated surface frame.
+    One sample, so accumulator == this sample's AOV. Tolerance: 2e-3 absolute on albedo (8-bit texels,
+    bilinear weights differ by ulps) for all but 0.1 % of the pixels (LOD / probe-count decisions that
+    sit on a rounding edge), 1e-4 relative on position."""
+    scene, pt = make_pathtracer(grt, "sponza", 480, 270, 0, num_bounces=2)
+    for aov in (grt.AOV_ALBEDO, grt.AOV_NORMAL, grt.AOV_POSITION):
+        pt.aov_enable(aov)
+    pt.update()
+    assert sum(1 for t in pt.textures() if t[0].size > 4) == 19   # the real maps are loaded, not the pink fallback
+    view = oracle.SceneView(pt)
+    frame = oracle.Frame(view)
+    pt.render()
+    frame.render_sample(pt.sample_index)
+    w = 480
+    got_albedo, want_albedo = pt.read_aov(grt.AOV_ALBEDO)[:, :w, :3], frame.accumulator(grt.AOV_ALBEDO)[:, :w, :3]
+    assert want_albedo.std() > 0.05                                  # textured, not a constant
+    bad = (np.abs(got_albedo - want_albedo).max(axis=2) > 2e-3).mean()
+    assert bad < 1e-3, bad
+    got_n, want_n = pt.read_aov(grt.AOV_NORMAL)[:, :w, :3], frame.accumulator(grt.AOV_NORMAL)[:, :w, :3]
+    assert (np.abs(got_n - want_n).max(axis=2) > 1e-4).mean() < 1e-4
+    got_p, want_p = pt.read_aov(grt.AOV_POSITION)[:, :w, :3], frame.accumulator(grt.AOV_POSITION)[:, :w, :3]
+    assert (np.abs(got_p - want_p).max(axis=2) > 1e-4 * (1.0 + np.abs(want_p).max(axis=2))).mean() < 1e-4
+    pt.close(); scene.close()
+
+
 def test_feature_toggles_match_oracle(grt, oracle):
     for cfg in (dict(enable_next_event_estimation=0), dict(enable_multiple_importance_sampling=0), dict(enable_russian_roulette=0), dict(reconstruction_filter=1, enable_mipmapping=0)):
         scene, pt = make_pathtracer(grt, "cornellbox", 96, 64, 0, num_bounces=5, **cfg)
