@@ -494,4 +494,5 @@ def set_samples_in_flight(ctx, count):
 
 
 def set_profiling(ctx, enable):
-    _dev_check(ctx, device_lib().rt_set_profiling(ctx, 1 if enable else 0))
+    """False/0 off; True/1 per-stage events (serialised); 2 events around the trace launches only."""
+    _dev_check(ctx, device_lib().rt_set_profiling(ctx, int(enable)))

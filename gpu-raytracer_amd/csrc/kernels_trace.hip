@@ -45,8 +45,10 @@
 #ifndef RT_TRACE_COOPERATIVE
 #define RT_TRACE_COOPERATIVE 0   // 0: one ray per lane with private fetches (default, 3x faster); 1: wave-cooperative LDS-staged fetches
 #endif
-#define RT_N_D 8            // dynamic fetch: tolerated idle lanes per iteration (N_d = 4 of 32 in the reference)
-#define RT_N_W 32           // dynamic fetch: lost lane-iterations before refilling  (N_w = 16 of 32)
+#ifndef RT_N_D
+#define RT_N_D 4            // dynamic fetch: tolerated idle lanes per iteration (N_d = 4 of 32 in the reference)
+#define RT_N_W 16           // dynamic fetch: lost lane-iterations before refilling  (N_w = 16 of 32); swept 0/1 .. 24/64, profiles/r01_trace_fetch_block.txt
+#endif
 
 struct Ray3 { f3 origin, direction; };
 

@@ -21,6 +21,7 @@ static thread_local std::string g_global_error;
 // Why: a wavefront pass is a chain of ~40 launches whose deep bounces are too small to fill 256 CUs
 // and whose persistent trace launches each end in a tail; a second sample's kernels fill those holes.
 #define RT_MAX_SAMPLE_SLOTS 4
+#define RT_LAUNCH_TIMING_STRIDE 3   // profiling mode 2 times the trace launches of every 3rd sample (events between launches cost ~3 % when on every sample)
 struct SampleSlot {
 	bool created = false;
 	hipStream_t stream = nullptr;      // the sample's launch chain
@@ -43,7 +44,7 @@ struct rt_context {
 	std::string error;
 
 	SampleSlot slots[RT_MAX_SAMPLE_SLOTS];
-	int samples_in_flight = 2;
+	int samples_in_flight = 3;
 	bool overlap_shadows = true;
 	unsigned render_counter = 0;
 	int last_slot = -1;
@@ -76,7 +77,10 @@ struct rt_context {
 	int pixel_offset = 0, pixel_count = -1;  // -1 = whole frame
 
 	rt_counters last_counters;
-	bool profiling = false;
+	bool profiling = false;          // mode 1: per-stage events, one sample at a time
+	bool launch_timing = false;      // mode 2: events around the trace launches of every RT_LAUNCH_TIMING_STRIDE-th sample, concurrency untouched
+	bool time_this_sample = false; unsigned timing_counter = 0;
+	std::vector<hipEvent_t> span_events; std::vector<int> span_kinds; size_t span_used = 0; // mode 2: [begin, end] pairs
 	bool trace_statistics = false;
 	unsigned long long * trace_stats = nullptr;    // device, 10 x u64
 	unsigned long long host_trace_stats[10] = { };
@@ -216,6 +220,7 @@ void rt_destroy(rt_context * ctx) {
 	(void)quiesce(ctx);
 	for (void * p : ctx->owned) (void)hipFree(p);
 	for (hipEvent_t e : ctx->stage_events) (void)hipEventDestroy(e);
+	for (hipEvent_t e : ctx->span_events) (void)hipEventDestroy(e);
 	for (SampleSlot & slot : ctx->slots) if (slot.stream) {
 		if (slot.pinned_counters) (void)hipHostFree(slot.pinned_counters);
 		for (hipEvent_t e : { slot.ev_shaded, slot.ev_shadowed, slot.ev_done, slot.ev_frame_start, slot.ev_frame_end }) if (e) (void)hipEventDestroy(e);
@@ -622,7 +627,12 @@ int rt_set_batch_size(rt_context * ctx, int batch_size) {
 
 int rt_set_profiling(rt_context * ctx, int enable) {
 	RT_REQUIRE(ctx, ctx, "rt_set_profiling: NULL context");
-	ctx->profiling = enable != 0;
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	ctx->profiling = enable == 1;
+	ctx->launch_timing = enable == 2;
+	ctx->timing_counter = 0;
+	ctx->span_used = 0;
 	return RT_OK;
 }
 
@@ -652,6 +662,14 @@ static void stage_mark(rt_context * ctx, int kind, hipStream_t stream) {
 	if (ctx->stage_used == ctx->stage_events.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->stage_events.push_back(e); ctx->stage_kinds.push_back(0); }
 	ctx->stage_kinds[ctx->stage_used] = kind;
 	(void)hipEventRecord(ctx->stage_events[ctx->stage_used++], stream);
+}
+
+// mode 2: an event on the launch's own stream before and after it (does not order other streams)
+static void span_mark(rt_context * ctx, int kind, hipStream_t stream) {
+	if (!ctx->time_this_sample) return;
+	if (ctx->span_used == ctx->span_events.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->span_events.push_back(e); ctx->span_kinds.push_back(0); }
+	ctx->span_kinds[ctx->span_used] = kind;
+	(void)hipEventRecord(ctx->span_events[ctx->span_used++], stream);
 }
 
 __global__ void kernel_accumulate_counters(const RtBufferSizes * sizes, int * totals) {
@@ -701,6 +719,7 @@ int rt_render_sample(rt_context * ctx, int sample_index) {
 	}
 	if (p.tile_pixels == 0 && range_offset + range_count > frame_pixels) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_sample: pixel range [%d,%d) exceeds the %d pixel frame", range_offset, range_offset + range_count, frame_pixels);
 
+	ctx->time_this_sample = ctx->launch_timing && (ctx->timing_counter++ % RT_LAUNCH_TIMING_STRIDE) == 0;
 	hipStream_t st = slot.stream;
 	// everything submitted on the main stream so far (uploads are synchronous; unpack_pixels, LUTs are not)
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
@@ -735,7 +754,7 @@ int rt_render_sample(rt_context * ctx, int sample_index) {
 		for (int bounce = 0; bounce < p.config.num_bounces; bounce++) {
 			stage_mark(ctx, STAGE_TRACE, st);
 			if (ctx->trace_statistics) rt_launch_trace_counting(p, bounce, ctx->trace_stats, st);
-			else rt_launch_trace(p, bounce, st);
+			else { span_mark(ctx, STAGE_TRACE, st); rt_launch_trace(p, bounce, st); span_mark(ctx, STAGE_TRACE, st); }
 			if (shadow_pending) { RT_HIP(ctx, hipStreamWaitEvent(st, slot.ev_shadowed, 0)); shadow_pending = false; }
 			stage_mark(ctx, STAGE_SORT, st);
 			rt_launch_sort(p, bounce, sample_index, st);
@@ -748,7 +767,9 @@ int rt_render_sample(rt_context * ctx, int sample_index) {
 				else {
 					RT_HIP(ctx, hipEventRecord(slot.ev_shaded, st));
 					RT_HIP(ctx, hipStreamWaitEvent(slot.side, slot.ev_shaded, 0));
+					span_mark(ctx, STAGE_SHADOW, slot.side);
 					rt_launch_trace_shadow(p_shadow, bounce, slot.side);
+					span_mark(ctx, STAGE_SHADOW, slot.side);
 					RT_HIP(ctx, hipEventRecord(slot.ev_shadowed, slot.side));
 					shadow_pending = true;
 				}
@@ -807,6 +828,13 @@ int rt_get_counters(rt_context * ctx, rt_counters * out) {
 	memcpy(c.conductor,  totals + 5 * RT_MAX_BOUNCES, sizeof(c.conductor));
 	float ms = 0.0f;
 	if (hipEventElapsedTime(&ms, slot.ev_frame_start, slot.ev_frame_end) == hipSuccess) c.ms_total = ms;
+	if (ctx->launch_timing) { // sums over every launch since the mode was enabled / the last call
+		for (size_t i = 0; i + 1 < ctx->span_used; i += 2) {
+			float d = 0.0f;
+			if (hipEventElapsedTime(&d, ctx->span_events[i], ctx->span_events[i + 1]) == hipSuccess) (ctx->span_kinds[i] == STAGE_TRACE ? c.ms_trace : c.ms_shadow) += d;
+		}
+		ctx->span_used = 0;
+	}
 	if (ctx->profiling) {
 		float * bucket[STAGE_END] = { &c.ms_generate, &c.ms_trace, &c.ms_sort, &c.ms_shade, &c.ms_shadow, &c.ms_post };
 		static const bool print_stages = getenv("GRT_STAGE_TRACE") != nullptr; // one line per launch group, in submission order

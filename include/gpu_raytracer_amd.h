@@ -195,7 +195,7 @@ int rt_unpack_pixels(rt_context * ctx, const void * src_device, int tile_pixels,
  * frame in one batch (MI355X has 288 GB of HBM; bigger launches hide traversal latency better). */
 int rt_set_batch_size(rt_context * ctx, int batch_size);
 
-/* Samples per pixel rendered concurrently (1..4, default 2). The reference submits the ~40
+/* Samples per pixel rendered concurrently (1..4, default 3). The reference submits the ~40
  * launches of one sample strictly one after the other on one stream (Pathtracer.cpp:738-855);
  * here consecutive rt_render_sample calls alternate between `count` sets of queues / streams and
  * only the accumulate step is ordered between them, so a sample's small deep-bounce launches
@@ -211,7 +211,14 @@ int rt_render_sample(rt_context * ctx, int sample_index);
 int rt_synchronize(rt_context * ctx);
 /* Per-stage HIP-event timing (ms_generate..ms_post of rt_counters) costs ~2 events per
  * kernel launch, so it is opt-in; ms_total is always measured. Replaces the CUDAEventPool
- * instrumentation of the reference (Pathtracer.cpp:751-843, Device/CUDAEvent.h:31-53).      */
+ * instrumentation of the reference (Pathtracer.cpp:751-843, Device/CUDAEvent.h:31-53).
+ * enable = 1: events around every stage; samples are rendered one at a time with the shadow rays
+ *             on the main chain, so the stage times are those of each kernel running alone.
+ * enable = 2: events only around the closest-hit / shadow trace launches of every 3rd sample
+ *             (the 1st, 4th, 7th ... rt_render_sample call after enabling), on the stream each is
+ *             launched on; concurrency (side stream, samples in flight) stays as in production.
+ *             rt_get_counters then returns in ms_trace / ms_shadow the SUM over those launches
+ *             since the mode was enabled or counters were last read.                          */
 int rt_set_profiling(rt_context * ctx, int enable);
 /* Work statistics of the trace kernels: when enabled, rt_render_sample runs counting variants
  * of kernel_trace(_shadow)_bvh8 (slower: per-ray atomics) and rt_get_trace_statistics returns,
