@@ -6,11 +6,14 @@ diffuse + plastic materials, NEE + MIS + Russian roulette, 10 bounces, samples 0
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over the whole frame = one sample per pixel:
-generate -> (trace, sort, shade, shadow-trace) x bounces for each 777 600-pixel batch ->
-accumulate (Pathtracer::render of the reference, Pathtracer.cpp:738-855).  With N > 1 the frame
-is split into row tiles dealt round-robin to the ranks (each rank holds a full scene replica) and
-one RCCL all-gather per step rebuilds the float4 frame on every rank: the total work is fixed, so
-the scaling is STRONG.  Scene data is resident in HBM before the timed region; nothing crosses
+generate -> (trace, sort, shade, shadow-trace) x bounces -> accumulate (Pathtracer::render of the
+reference, Pathtracer.cpp:738-855).  The steps are submitted the way the library is meant to be
+driven: the 4 samples of a frame as ONE wavefront (rt_render_samples: every launch carries 4 paths
+per pixel; bit-identical to 4 single-sample calls) and up to --samples-in-flight such submissions
+concurrently; --steps K renders exactly K samples.  With N > 1 the frame is split into row tiles
+dealt round-robin to the ranks (each rank holds a full scene replica) and one RCCL all-gather per
+completed 4-spp frame rebuilds the float4 frame on every rank: the total work is fixed, so the
+scaling is STRONG.  Scene data is resident in HBM before the timed region; nothing crosses
 PCIe inside it.
 
 Rank 0 prints ONE JSON line.  `value` counts closest-hit rays (bounce 0 = primary, bounces >= 1 =
@@ -28,6 +31,9 @@ import json
 import os
 import sys
 import time
+
+# HIP maps streams onto 4 hardware queues by default; the tracer keeps (samples in flight) x 2 streams busy
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import numpy as np
 
@@ -107,7 +113,8 @@ def main():
     ap.add_argument("--steps", type=int, default=32)   # PerfTest BUFFER_SIZE = 32 frames (Util/PerfTest.h:9)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--samples-in-flight", type=int, default=3, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
+    ap.add_argument("--batch", type=int, default=SPP, help="samples per pixel per submission (rt_render_samples), 1..%d" % SPP)
+    ap.add_argument("--samples-in-flight", type=int, default=2, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
     args = ap.parse_args()
 
     import torch
@@ -149,18 +156,19 @@ def main():
         if status != 0:
             raise RuntimeError(lib.rt_last_error(ctx).decode())
 
-    def render_step(sample_index, frame_complete=False):
-        """One sample for this rank's share of the frame. Samples are only submitted here (the
-        library keeps `samples_in_flight` of them running concurrently); with N > 1 the accumulated
-        frame is gathered once it is complete, i.e. after its last sample -- every rank accumulates
-        its own tiles, so nothing has to be exchanged between the samples of a frame."""
+    def render_step(sample_index, frame_complete=False, count=1):
+        """`count` consecutive samples for this rank's share of the frame, as one submission (the
+        library keeps `samples_in_flight` submissions running concurrently); with N > 1 the
+        accumulated frame is gathered once it is complete, i.e. after its last sample -- every rank
+        accumulates its own tiles, so nothing has to be exchanged between the samples of a frame."""
         if world == 1:
             check(lib.rt_set_pixel_range(ctx, 0, WIDTH * HEIGHT))
-            check(lib.rt_render_sample(ctx, sample_index))
+            check(lib.rt_render_samples(ctx, sample_index, count))
         else:
             check(lib.rt_set_pixel_tiles(ctx, split.tile_pixels, rank, world))
-            check(lib.rt_render_sample(ctx, sample_index))
+            check(lib.rt_render_samples(ctx, sample_index, count))
             if frame_complete:
+                torch.cuda.current_stream().synchronize()  # the previous all_gather still reads `packed`
                 check(lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, world, split.tiles_per_rank))
                 check(lib.rt_synchronize(ctx))            # the tracer runs on its own HIP streams
                 dist.all_gather_into_tensor(gathered, packed)
@@ -173,8 +181,17 @@ def main():
         lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 
     # ---- warm-up (untimed) ---------------------------------------------------------------------
-    for w in range(args.warmup):
-        render_step(w % SPP, frame_complete=True)
+    def submissions(steps):
+        """[(first sample index, count)] covering exactly `steps` samples, frame by frame."""
+        out, k = [], 0
+        while k < steps:
+            first = k % SPP
+            count = min(SPP - first, steps - k, args.batch)
+            out.append((first, count)); k += count
+        return out
+
+    for first, count in submissions(args.warmup):
+        render_step(first, frame_complete=True, count=count)
     check(lib.rt_synchronize(ctx))
 
     # ---- untimed statistics pass: rays per sample and the work counters of the trace kernels ---
@@ -192,9 +209,10 @@ def main():
     # ---- profiled pass (HIP events per stage, on the tracer's stream): kernel time of the trace launches
     grt.set_profiling(ctx, True)
     trace_ms, stage_ms = [], {}
+    alone_subs = submissions(SPP)
     for rep in range(2):
-        for s in range(SPP):
-            render_step(s)
+        for first, count in alone_subs:
+            render_step(first, count=count)
             c, _, _ = counters()
             if rep == 1:
                 trace_ms.append(c.ms_trace)
@@ -211,17 +229,18 @@ def main():
     # (mode 2: no serialisation -- the side stream and the samples in flight stay as in production)
     grt.set_profiling(ctx, 2)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        render_step(k % SPP, frame_complete=(k % SPP == SPP - 1 or k == args.steps - 1))
+    plan = submissions(args.steps)
+    for i, (first, count) in enumerate(plan):
+        render_step(first, frame_complete=(first + count == SPP or i == len(plan) - 1), count=count)
     check(lib.rt_synchronize(ctx))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     timed_counters = pt.counters()
-    timed_steps = [k for k in range(args.steps) if k % 3 == 0]   # mode 2 times every 3rd sample (events are not free)
+    timed_subs = [plan[i] for i in range(0, len(plan), 3)]       # mode 2 times every 3rd submission (events are not free)
     timed_trace_ms = timed_counters.ms_trace                     # sum over their closest-hit launches
-    timed_alg_bytes = sum(alg_bytes_per_sample[k % SPP] for k in timed_steps)
+    timed_alg_bytes = sum(alg_bytes_per_sample[first + j] for first, count in timed_subs for j in range(count))
     grt.set_profiling(ctx, False)
 
     local = torch.tensor([elapsed, float(sum(rays_per_sample)), float(sum(shadow_per_sample)), float(sum(alg_bytes_per_sample)), float(sum(trace_ms))], dtype=torch.float64, device=device)
@@ -236,15 +255,16 @@ def main():
         rays_per_step = rays_4spp / SPP
         total_rays = rays_per_step * args.steps
         value = total_rays / elapsed / 1e6
-        launches_per_sample = NUM_BOUNCES  # one batch = this rank's whole share of the frame
+        launches_per_sample = NUM_BOUNCES  # closest-hit trace launches per submission (one per bounce)
         achieved = timed_alg_bytes / (timed_trace_ms * 1e-3) / 1e9  # rank 0's launches of the timed region
         achieved_alone = sum(alg_bytes_per_sample) / (sum(trace_ms) * 1e-3) / 1e9
         roofline = {
             "bound": "hbm", "kernel": "kernel_trace_bvh8", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "algorithmic_bytes_per_launch": round(sum(alg_bytes_per_sample) / SPP / launches_per_sample),
-            "avg_launch_ms": round(timed_trace_ms / len(timed_steps) / launches_per_sample, 4), "launches_per_step": launches_per_sample,
-            "avg_launch_ms_running_alone": round(sum(trace_ms) / SPP / launches_per_sample, 4), "frac_running_alone": round(achieved_alone / HBM_PEAK_GBPS, 4),
+            "algorithmic_bytes_per_launch": round(timed_alg_bytes / len(timed_subs) / launches_per_sample),
+            "samples_per_launch": args.batch,
+            "avg_launch_ms": round(timed_trace_ms / len(timed_subs) / launches_per_sample, 4), "launches_per_step": round(launches_per_sample * len(plan) / args.steps, 2),
+            "avg_launch_ms_running_alone": round(sum(trace_ms) / len(alone_subs) / launches_per_sample, 4), "frac_running_alone": round(achieved_alone / HBM_PEAK_GBPS, 4),
             "bytes_per_ray": round(sum(alg_bytes_per_sample) / max(sum(rays_per_sample), 1), 1),
             "nodes_per_ray": round(sum(s["closest"]["nodes"] for s in trace_rays_stat) / max(sum(rays_per_sample), 1), 2),
             "triangles_per_ray": round(sum(s["closest"]["triangles"] for s in trace_rays_stat) / max(sum(rays_per_sample), 1), 2),
@@ -260,12 +280,12 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": "Sponza (Crytek, 262 687 triangles, 384 instances) 1920x1080, samples 0..3 (4 spp), BVH8/CWBVH, diffuse + roughplastic(odd materials, alpha 0.3), NEE+MIS+RR, 10 bounces, constant white sky, mipmapping on, 19 diffuse textures at the reference's dimensions (1024x1024 RGBA8 + mips, ~106 MB; texels replicated 4x4 from the quarter-size maps that travel with the repo), the 5 maps missing upstream are the reference's 1x1 pink fallback",
-                "step": "one sample per pixel for the whole frame, one wavefront batch per rank (the reference cuts it into 777 600-pixel batches only to bound VRAM)",
+                "step": "one sample per pixel for the whole frame; the 4 samples of a frame are submitted as one wavefront (rt_render_samples), the reference's 777 600-pixel batches (a VRAM bound) are not needed",
                 "rays_per_step": round(rays_per_step), "shadow_rays_per_step": round(shadow_4spp / SPP),
                 "mrays_s_including_shadow": round((rays_4spp + shadow_4spp) / SPP * args.steps / elapsed / 1e6, 1),
                 "ms_per_4spp_frame": round(elapsed / args.steps * SPP * 1e3, 3),
                 "parallelism": "tile-split x%d + one RCCL all-gather of the accumulated float4 frame per %d-spp frame" % (world, SPP) if world > 1 else "single GPU",
-                "samples_in_flight": args.samples_in_flight,
+                "samples_per_submission": args.batch, "submissions_in_flight": args.samples_in_flight,
                 "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
             },
             "roofline": roofline,

@@ -84,6 +84,7 @@ def device_lib():
         lib.rt_set_batch_size.argtypes = [c_void_p, c_int]
         lib.rt_get_counters.argtypes = [c_void_p, POINTER(Counters)]
         lib.rt_render_sample.argtypes = [c_void_p, c_int]
+        lib.rt_render_samples.argtypes = [c_void_p, c_int, c_int]
         lib.rt_synchronize.argtypes = [c_void_p]
         lib.rt_set_pixel_range.argtypes = [c_void_p, c_int, c_int]
         lib.rt_read_framebuffer.argtypes = [c_void_p, c_void_p]

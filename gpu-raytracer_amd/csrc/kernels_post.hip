@@ -17,13 +17,16 @@ RT_DEV void st4(float4 * p, int i, f4 v) { p[i] = to_float4(v); }
 
 // ---- accumulate ---------------------------------------------------------------------------------
 
+// The samples of a batch are folded in one after the other, exactly as separate calls would.
 RT_DEV f4 aov_accumulate(const RtParams & p, int aov, int pixel_index, float n) { // AOV.h:35-46
 	const RtAOV & a = p.aovs[aov];
 	if (!a.framebuffer) return mk4(0.0f);
-	f4 fb = mk4(a.framebuffer[pixel_index]);
-	f4 acc;
-	if (n > 0.0f) { acc = mk4(a.accumulator[pixel_index]); acc = acc + (fb - acc) / n; }
-	else acc = fb;
+	f4 acc = mk4(0.0f);
+	for (int s = 0; s < p.batch_samples; s++, n += 1.0f) {
+		f4 fb = mk4(a.framebuffer[size_t(s) * p.frame_pixels + pixel_index]);
+		if (n > 0.0f) { if (s == 0) acc = mk4(a.accumulator[pixel_index]); acc = acc + (fb - acc) / n; }
+		else acc = fb;
+	}
 	a.accumulator[pixel_index] = to_float4(acc);
 	return acc;
 }

@@ -65,19 +65,22 @@ RT_DEV void camera_generate_ray(const RtParams & p, int pixel_index, int sample_
 }
 
 __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate(RtParams p, int sample_index, int pixel_offset, int pixel_count) {
-	if (blockIdx.x == 0 && threadIdx.x == 0) p.sizes->trace[0] = pixel_count; // BufferSizes::reset (Pathtracer.h:143)
-	for (int index = blockIdx.x * blockDim.x + threadIdx.x; index < pixel_count; index += gridDim.x * blockDim.x) {
-		int index_offset = rt_map_pixel(p, index + pixel_offset);
+	const int ray_count = pixel_count * p.batch_samples; // sample s of the batch occupies queue entries [s * pixel_count, (s+1) * pixel_count)
+	if (blockIdx.x == 0 && threadIdx.x == 0) p.sizes->trace[0] = ray_count; // BufferSizes::reset (Pathtracer.h:143)
+	for (int index = blockIdx.x * blockDim.x + threadIdx.x; index < ray_count; index += gridDim.x * blockDim.x) {
+		int sample_in_batch = index / pixel_count;
+		int index_offset = rt_map_pixel(p, index - sample_in_batch * pixel_count + pixel_offset);
 		int x = index_offset % p.screen_width;
 		int y = index_offset / p.screen_width;
 		int pixel_index = x + y * p.screen_pitch;
+		unsigned virtual_pixel = unsigned(sample_in_batch) * p.frame_pixels + unsigned(pixel_index);
 
 		f3 origin, direction;
-		camera_generate_ray(p, pixel_index, sample_index, x, y, origin, direction);
+		camera_generate_ray(p, int(virtual_pixel), sample_index, x, y, origin, direction);
 
 		store3(p.trace[0].origin,    index, origin);
 		store3(p.trace[0].direction, index, direction);
-		p.trace[0].pixel_index_and_flags[index] = unsigned(pixel_index);
+		p.trace[0].pixel_index_and_flags[index] = virtual_pixel;
 	}
 }
 

@@ -20,7 +20,8 @@ static thread_local std::string g_global_error;
 // slots round-robin, each on its own stream, and only the accumulate step is ordered between them.
 // Why: a wavefront pass is a chain of ~40 launches whose deep bounces are too small to fill 256 CUs
 // and whose persistent trace launches each end in a tail; a second sample's kernels fill those holes.
-#define RT_MAX_SAMPLE_SLOTS 4
+#define RT_MAX_SAMPLE_SLOTS 8
+#define RT_MAX_BATCH_SAMPLES 16
 #define RT_LAUNCH_TIMING_STRIDE 3   // profiling mode 2 times the trace launches of every 3rd sample (events between launches cost ~3 % when on every sample)
 struct SampleSlot {
 	bool created = false;
@@ -34,7 +35,8 @@ struct SampleSlot {
 	void * spill[2] = { nullptr, nullptr };  // traversal stack spill of the closest-hit / shadow launch
 	int * counter_totals = nullptr;          // 6 x RT_MAX_BOUNCES ints accumulated over batches
 	RtBufferSizes * pinned_counters = nullptr;
-	void * aov_framebuffer[RT_AOV_COUNT] = { };
+	void * aov_framebuffer[RT_AOV_COUNT] = { };  // slots 1..: per-sample frame buffers (slot 0 uses ctx->aov_buffers[i][0])
+	int aov_samples = 1;                         // samples per batch the frame buffers of this slot are sized for
 };
 
 struct rt_context {
@@ -207,6 +209,7 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 	ctx->params.xcd_counters = ctx->slots[0].xcd_counters;
 	ctx->params.stack_spill  = (uint2 *)ctx->slots[0].spill[0];
 
+	ctx->params.frame_pixels = 1u << 30; ctx->params.frame_pixels_magic = 5; ctx->params.batch_samples = 1; // until rt_resize
 	// default config = reference defaults (Common.h:39-67)
 	rt_gpu_config c = { RT_FILTER_GAUSSIAN, 1u << RT_AOV_RADIANCE, 10, 1, 1, 1, 1, 0, 1, 1, 0.1f, 0.1f, 6, 4.0f, 16.0f, 10.0f };
 	ctx->params.config = c;
@@ -417,9 +420,9 @@ static size_t wanted_batch_size(const rt_context * ctx) {
 	return n;
 }
 
-static int ensure_queues(rt_context * ctx, int slot_index = 0) {
+static int ensure_queues(rt_context * ctx, int slot_index = 0, size_t pixels = 0) {
 	SampleSlot & slot = ctx->slots[slot_index];
-	size_t n = wanted_batch_size(ctx);
+	size_t n = pixels > 0 ? pixels : wanted_batch_size(ctx); // entries: pixels of a batch x samples per batch
 	if (slot.queues_allocated && slot.queue_capacity >= n) return RT_OK;
 	if (slot.queues_allocated) { // grow: release the old queues
 		RT_HIP(ctx, quiesce(ctx));
@@ -470,13 +473,14 @@ static int sync_aovs(rt_context * ctx) {
 		bool allocated = ctx->aov_buffers[i][0] != nullptr;
 		if (enabled && !allocated && bytes) {
 			RT_HIP(ctx, quiesce(ctx));
-			for (int k = 0; k < 2; k++) {
-				int s = device_alloc(ctx, &ctx->aov_buffers[i][k], bytes); if (s) return s;
-				RT_HIP(ctx, hipMemset(ctx->aov_buffers[i][k], 0, bytes));
+			for (int k = 0; k < 2; k++) { // [0]: slot 0's per-sample frame buffer(s), [1]: the accumulator
+				size_t n = k == 0 ? bytes * ctx->slots[0].aov_samples : bytes;
+				int s = device_alloc(ctx, &ctx->aov_buffers[i][k], n); if (s) return s;
+				RT_HIP(ctx, hipMemset(ctx->aov_buffers[i][k], 0, n));
 			}
 			for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) { // per-sample frame buffers of the other slots
-				int s = device_alloc(ctx, &ctx->slots[k].aov_framebuffer[i], bytes); if (s) return s;
-				RT_HIP(ctx, hipMemset(ctx->slots[k].aov_framebuffer[i], 0, bytes));
+				int s = device_alloc(ctx, &ctx->slots[k].aov_framebuffer[i], bytes * ctx->slots[k].aov_samples); if (s) return s;
+				RT_HIP(ctx, hipMemset(ctx->slots[k].aov_framebuffer[i], 0, bytes * ctx->slots[k].aov_samples));
 			}
 		} else if (!enabled && allocated) {
 			RT_HIP(ctx, quiesce(ctx));
@@ -486,6 +490,24 @@ static int sync_aovs(rt_context * ctx) {
 		ctx->params.aovs[i].framebuffer = (float4 *)ctx->aov_buffers[i][0];
 		ctx->params.aovs[i].accumulator = (float4 *)ctx->aov_buffers[i][1];
 	}
+	return RT_OK;
+}
+
+// Frame buffers of one slot for `samples` samples per batch (they only ever grow).
+static int ensure_aov_batch(rt_context * ctx, int slot_index, int samples) {
+	SampleSlot & slot = ctx->slots[slot_index];
+	if (slot.aov_samples >= samples) return RT_OK;
+	RT_HIP(ctx, quiesce(ctx));
+	size_t bytes = ctx->frame_pixels * 16 * size_t(samples);
+	for (int i = 0; i < RT_AOV_COUNT; i++) {
+		void ** fb = slot_index == 0 ? &ctx->aov_buffers[i][0] : &slot.aov_framebuffer[i];
+		if (!*fb) continue;
+		device_free(ctx, *fb); *fb = nullptr;
+		int s = device_alloc(ctx, fb, bytes); if (s) return s;
+		RT_HIP(ctx, hipMemset(*fb, 0, bytes));
+		if (slot_index == 0) ctx->params.aovs[i].framebuffer = (float4 *)*fb;
+	}
+	slot.aov_samples = samples;
 	return RT_OK;
 }
 
@@ -530,6 +552,9 @@ int rt_resize(rt_context * ctx, int width, int height) {
 
 	for (int i = 0; i < RT_AOV_COUNT; i++) for (int k = 0; k < 2; k++) { device_free(ctx, ctx->aov_buffers[i][k]); ctx->aov_buffers[i][k] = nullptr; }
 	for (int i = 0; i < RT_AOV_COUNT; i++) for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) { device_free(ctx, ctx->slots[k].aov_framebuffer[i]); ctx->slots[k].aov_framebuffer[i] = nullptr; }
+	for (SampleSlot & slot : ctx->slots) slot.aov_samples = 1;
+	ctx->params.frame_pixels = unsigned(ctx->frame_pixels);
+	ctx->params.frame_pixels_magic = unsigned((1ull << 32) / ctx->frame_pixels) + 1u;
 	for (int i = 0; i < 12; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
 	ctx->svgf_allocated = false;
 	device_free(ctx, ctx->final_image); ctx->final_image = nullptr;
@@ -683,8 +708,11 @@ __global__ void kernel_accumulate_counters(const RtBufferSizes * sizes, int * to
 	totals[5 * RT_MAX_BOUNCES + b] += sizes->conductor[b];
 }
 
-int rt_render_sample(rt_context * ctx, int sample_index) {
+int rt_render_sample(rt_context * ctx, int sample_index) { return rt_render_samples(ctx, sample_index, 1); }
+
+int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	RT_REQUIRE(ctx, ctx, "rt_render_sample: NULL context");
+	RT_REQUIRE(ctx, sample_count >= 1 && sample_count <= RT_MAX_BATCH_SAMPLES, "rt_render_samples: sample_count must be 1..16");
 	(void)hipSetDevice(ctx->device);
 	const RtParams & base = ctx->params;
 	if (!base.triangles || !base.bvh8_nodes)   return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: geometry not uploaded");
@@ -699,12 +727,14 @@ int rt_render_sample(rt_context * ctx, int sample_index) {
 	bool exclusive = ctx->profiling || ctx->trace_statistics || ctx->params.config.enable_svgf;
 	int slot_index = exclusive ? 0 : int(ctx->render_counter++ % unsigned(ctx->samples_in_flight));
 	int s = ensure_slot(ctx, slot_index); if (s) return s;
-	s = ensure_queues(ctx, slot_index); if (s) return s;
 	if (ctx->has_material[2] || ctx->has_material[3]) { s = ensure_luts(ctx); if (s) return s; }
 	SampleSlot & slot = ctx->slots[slot_index];
-	const RtParams p = slot_params(ctx, slot, slot_index);
+	if (ctx->params.config.enable_svgf && sample_count != 1) return fail(ctx, RT_ERROR_INVALID_ARG, "rt_render_samples: SVGF frames are rendered one sample at a time");
+	if (size_t(sample_count) * ctx->frame_pixels >= (1u << 30)) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_samples: %d samples of a %zu pixel frame exceed the 30-bit path index", sample_count, ctx->frame_pixels);
+	s = ensure_aov_batch(ctx, slot_index, sample_count); if (s) return s;
+	RtParams p = slot_params(ctx, slot, slot_index);
+	p.batch_samples = sample_count;
 	RtParams p_shadow = p; // the shadow launch may be resident together with the next closest-hit launch
-	p_shadow.stack_spill = (uint2 *)slot.spill[1];
 
 	int frame_pixels = p.screen_width * p.screen_height;
 	int range_offset = ctx->pixel_offset;
@@ -718,6 +748,11 @@ int rt_render_sample(rt_context * ctx, int sample_index) {
 		if (owned > 0 && last_tile == tiles_total - 1) range_count -= tiles_total * p.tile_pixels - frame_pixels; // clipped last tile
 	}
 	if (p.tile_pixels == 0 && range_offset + range_count > frame_pixels) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_sample: pixel range [%d,%d) exceeds the %d pixel frame", range_offset, range_offset + range_count, frame_pixels);
+	int batch_limit = int(wanted_batch_size(ctx));
+	int batch_size  = range_count < batch_limit ? range_count : batch_limit; // pixels per wavefront batch; each carries sample_count paths
+	s = ensure_queues(ctx, slot_index, size_t(batch_size > 0 ? batch_size : 1) * sample_count); if (s) return s;
+	memcpy(p.trace, slot.trace, sizeof(p.trace)); memcpy(p.material, slot.material, sizeof(p.material)); p.shadow = slot.shadow; // (re)allocated just now
+	p_shadow = p; p_shadow.stack_spill = (uint2 *)slot.spill[1];
 
 	ctx->time_this_sample = ctx->launch_timing && (ctx->timing_counter++ % RT_LAUNCH_TIMING_STRIDE) == 0;
 	hipStream_t st = slot.stream;
@@ -728,57 +763,61 @@ int rt_render_sample(rt_context * ctx, int sample_index) {
 
 	ctx->stage_used = 0;
 	RT_HIP(ctx, hipEventRecord(slot.ev_frame_start, st));
-	RT_HIP(ctx, hipMemsetAsync(slot.counter_totals, 0, 6 * RT_MAX_BOUNCES * sizeof(int), st));
-	if (ctx->trace_statistics) RT_HIP(ctx, hipMemsetAsync(ctx->trace_stats, 0, 10 * sizeof(unsigned long long), st));
 
-	int pixels_left = range_count;
-	int batch_limit = int(wanted_batch_size(ctx));
-	int batch_size  = range_count < batch_limit ? range_count : batch_limit;
 	bool trace_shadows = ctx->has_lights && p.config.enable_next_event_estimation && p.lights_total_weight > 0.0f;
 	// Shadow rays of bounce b only feed the frame buffers, so they run on the side stream while the
 	// main chain traces bounce b+1; they are joined before the next kernel that touches the frame
 	// buffers (sort: sky / emissive hits), which keeps the order of the float additions per pixel.
 	bool overlap = trace_shadows && ctx->overlap_shadows && !ctx->profiling && !ctx->trace_statistics;
-	bool shadow_pending = false;
 
-	while (pixels_left > 0) {
-		int pixel_offset = range_offset + (range_count - pixels_left);
-		int pixel_count  = batch_size < pixels_left ? batch_size : pixels_left;
+	// generate -> (trace, sort, shade, shadow) x bounces for every batch of the range, on st (+ side)
+	auto submit_wavefront = [&]() -> int {
+		RT_HIP(ctx, hipMemsetAsync(slot.counter_totals, 0, 6 * RT_MAX_BOUNCES * sizeof(int), st));
+		if (ctx->trace_statistics) RT_HIP(ctx, hipMemsetAsync(ctx->trace_stats, 0, 10 * sizeof(unsigned long long), st));
+		int pixels_left = range_count;
+		bool shadow_pending = false;
+		while (pixels_left > 0) {
+			int pixel_offset = range_offset + (range_count - pixels_left);
+			int pixel_count  = batch_size < pixels_left ? batch_size : pixels_left;
 
-		if (shadow_pending) { RT_HIP(ctx, hipStreamWaitEvent(st, slot.ev_shadowed, 0)); shadow_pending = false; } // the previous batch's queues are reused
-		RT_HIP(ctx, hipMemsetAsync(slot.sizes, 0, sizeof(RtBufferSizes), st));
-		RT_HIP(ctx, hipMemsetAsync(slot.xcd_counters, 0, RT_MAX_BOUNCES * 2 * 8 * sizeof(int), st));
-		stage_mark(ctx, STAGE_GENERATE, st);
-		rt_launch_generate(p, sample_index, pixel_offset, pixel_count, st);
+			if (shadow_pending) { RT_HIP(ctx, hipStreamWaitEvent(st, slot.ev_shadowed, 0)); shadow_pending = false; } // the previous batch's queues are reused
+			RT_HIP(ctx, hipMemsetAsync(slot.sizes, 0, sizeof(RtBufferSizes), st));
+			RT_HIP(ctx, hipMemsetAsync(slot.xcd_counters, 0, RT_MAX_BOUNCES * 2 * 8 * sizeof(int), st));
+			stage_mark(ctx, STAGE_GENERATE, st);
+			rt_launch_generate(p, sample_index, pixel_offset, pixel_count, st);
 
-		for (int bounce = 0; bounce < p.config.num_bounces; bounce++) {
-			stage_mark(ctx, STAGE_TRACE, st);
-			if (ctx->trace_statistics) rt_launch_trace_counting(p, bounce, ctx->trace_stats, st);
-			else { span_mark(ctx, STAGE_TRACE, st); rt_launch_trace(p, bounce, st); span_mark(ctx, STAGE_TRACE, st); }
-			if (shadow_pending) { RT_HIP(ctx, hipStreamWaitEvent(st, slot.ev_shadowed, 0)); shadow_pending = false; }
-			stage_mark(ctx, STAGE_SORT, st);
-			rt_launch_sort(p, bounce, sample_index, st);
-			stage_mark(ctx, STAGE_SHADE, st);
-			for (int m = 0; m < 4; m++) if (ctx->has_material[m]) rt_launch_material(p, m, bounce, sample_index, st);
-			if (trace_shadows) {
-				stage_mark(ctx, STAGE_SHADOW, st);
-				if (ctx->trace_statistics) rt_launch_trace_shadow_counting(p, bounce, ctx->trace_stats, st);
-				else if (!overlap) rt_launch_trace_shadow(p, bounce, st);
-				else {
-					RT_HIP(ctx, hipEventRecord(slot.ev_shaded, st));
-					RT_HIP(ctx, hipStreamWaitEvent(slot.side, slot.ev_shaded, 0));
-					span_mark(ctx, STAGE_SHADOW, slot.side);
-					rt_launch_trace_shadow(p_shadow, bounce, slot.side);
-					span_mark(ctx, STAGE_SHADOW, slot.side);
-					RT_HIP(ctx, hipEventRecord(slot.ev_shadowed, slot.side));
-					shadow_pending = true;
+			for (int bounce = 0; bounce < p.config.num_bounces; bounce++) {
+				stage_mark(ctx, STAGE_TRACE, st);
+				if (ctx->trace_statistics) rt_launch_trace_counting(p, bounce, ctx->trace_stats, st);
+				else { span_mark(ctx, STAGE_TRACE, st); rt_launch_trace(p, bounce, st); span_mark(ctx, STAGE_TRACE, st); }
+				if (shadow_pending) { RT_HIP(ctx, hipStreamWaitEvent(st, slot.ev_shadowed, 0)); shadow_pending = false; }
+				stage_mark(ctx, STAGE_SORT, st);
+				rt_launch_sort(p, bounce, sample_index, st);
+				stage_mark(ctx, STAGE_SHADE, st);
+				for (int m = 0; m < 4; m++) if (ctx->has_material[m]) rt_launch_material(p, m, bounce, sample_index, st);
+				if (trace_shadows) {
+					stage_mark(ctx, STAGE_SHADOW, st);
+					if (ctx->trace_statistics) rt_launch_trace_shadow_counting(p, bounce, ctx->trace_stats, st);
+					else if (!overlap) rt_launch_trace_shadow(p, bounce, st);
+					else {
+						RT_HIP(ctx, hipEventRecord(slot.ev_shaded, st));
+						RT_HIP(ctx, hipStreamWaitEvent(slot.side, slot.ev_shaded, 0));
+						span_mark(ctx, STAGE_SHADOW, slot.side);
+						rt_launch_trace_shadow(p_shadow, bounce, slot.side);
+						span_mark(ctx, STAGE_SHADOW, slot.side);
+						RT_HIP(ctx, hipEventRecord(slot.ev_shadowed, slot.side));
+						shadow_pending = true;
+					}
 				}
 			}
+			hipLaunchKernelGGL(kernel_accumulate_counters, dim3(1), dim3(RT_MAX_BOUNCES), 0, st, slot.sizes, slot.counter_totals);
+			pixels_left -= batch_size;
 		}
-		hipLaunchKernelGGL(kernel_accumulate_counters, dim3(1), dim3(RT_MAX_BOUNCES), 0, st, slot.sizes, slot.counter_totals);
-		pixels_left -= batch_size;
-	}
-	if (shadow_pending) RT_HIP(ctx, hipStreamWaitEvent(st, slot.ev_shadowed, 0));
+		if (shadow_pending) RT_HIP(ctx, hipStreamWaitEvent(st, slot.ev_shadowed, 0));
+		return RT_OK;
+	};
+
+	{ int status = submit_wavefront(); if (status) return status; }
 
 	// The accumulate step folds this sample into the shared accumulators: strictly in sample order.
 	if (ctx->last_slot >= 0 && ctx->last_slot != slot_index) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[ctx->last_slot].ev_done, 0));
@@ -788,7 +827,7 @@ int rt_render_sample(rt_context * ctx, int sample_index) {
 	stage_mark(ctx, STAGE_END, st);
 
 	// aovs_clear_to_zero (Integrator.cpp:379-385)
-	for (int i = 0; i < RT_AOV_COUNT; i++) if (p.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(p.aovs[i].framebuffer, 0, ctx->frame_pixels * 16, st));
+	for (int i = 0; i < RT_AOV_COUNT; i++) if (p.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(p.aovs[i].framebuffer, 0, ctx->frame_pixels * 16 * sample_count, st));
 
 	RT_HIP(ctx, hipMemcpyAsync(slot.pinned_counters, slot.counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int), hipMemcpyDeviceToHost, st));
 	RT_HIP(ctx, hipEventRecord(slot.ev_frame_end, st));
@@ -799,7 +838,7 @@ int rt_render_sample(rt_context * ctx, int sample_index) {
 }
 
 int rt_set_samples_in_flight(rt_context * ctx, int count) {
-	RT_REQUIRE(ctx, ctx && count >= 1 && count <= RT_MAX_SAMPLE_SLOTS, "rt_set_samples_in_flight: count must be 1..4");
+	RT_REQUIRE(ctx, ctx && count >= 1 && count <= RT_MAX_SAMPLE_SLOTS, "rt_set_samples_in_flight: count must be 1..8");
 	(void)hipSetDevice(ctx->device);
 	RT_HIP(ctx, quiesce(ctx));
 	ctx->samples_in_flight = count;

@@ -56,6 +56,10 @@ RT_DEV unsigned permute(unsigned index, unsigned length, unsigned seed) {
 
 // random<Dim>() of the reference (CUDA/Sampling.h:44-84)
 RT_DEV f2 random_sample(const RtParams & p, int dimension, unsigned pixel_index, unsigned bounce, unsigned sample_index) {
+	// callers pass the virtual pixel index of the path and the first sample of the batch (rt_types.h)
+	unsigned sample_in_batch;
+	pixel_index = rt_split_virtual_pixel(p, pixel_index, sample_in_batch);
+	sample_index += sample_in_batch;
 	unsigned hash = pcg_hash((pixel_index * unsigned(DIM_NUM_DIMENSIONS) + unsigned(dimension)) * RT_MAX_BOUNCES + bounce);
 
 	if (sample_index >= RT_PMJ_NUM_SAMPLES_PER_SEQUENCE) {

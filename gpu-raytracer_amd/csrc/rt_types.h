@@ -107,6 +107,12 @@ struct RtParams {
 	rt_gpu_config config;
 	float view_projection[16], view_projection_prev[16];
 	int screen_width, screen_height, screen_pitch;
+	// Sample batching: rt_render_samples renders `batch_samples` consecutive samples of every pixel as
+	// ONE wavefront. The queues and the per-sample AOV frame buffers are addressed with a "virtual"
+	// pixel index v = s * frame_pixels + pixel (s = sample within the batch, frame_pixels = pitch *
+	// height); only the RNG needs (pixel, first_sample + s) back, see rt_split_virtual_pixel.
+	unsigned frame_pixels, frame_pixels_magic; // magic = floor(2^32 / frame_pixels) + 1
+	int batch_samples;
 	// multi-GPU tile split: local pixel i -> scan-order pixel (tile_pixels == 0: identity)
 	int tile_pixels, tile_first, tile_stride;
 	// queues
@@ -135,6 +141,14 @@ struct RtParams {
 __device__ __forceinline__ int rt_map_pixel(const RtParams & p, int i) {
 	if (p.tile_pixels == 0) return i;
 	return ((i / p.tile_pixels) * p.tile_stride + p.tile_first) * p.tile_pixels + i % p.tile_pixels;
+}
+
+// v -> pixel, and the sample within the batch (v < 2^30, at most 16 samples per batch)
+__device__ __forceinline__ unsigned rt_split_virtual_pixel(const RtParams & p, unsigned v, unsigned & sample_in_batch) {
+	unsigned s = __umulhi(v, p.frame_pixels_magic);   // floor(v / frame_pixels) or one too many
+	if (s * p.frame_pixels > v) s--;
+	sample_in_batch = s;
+	return v - s * p.frame_pixels;
 }
 
 #define RT_FLAG_ALLOW_NEE     (1u << 31)

@@ -195,7 +195,7 @@ int rt_unpack_pixels(rt_context * ctx, const void * src_device, int tile_pixels,
  * frame in one batch (MI355X has 288 GB of HBM; bigger launches hide traversal latency better). */
 int rt_set_batch_size(rt_context * ctx, int batch_size);
 
-/* Samples per pixel rendered concurrently (1..4, default 3). The reference submits the ~40
+/* Samples per pixel rendered concurrently (1..8, default 3). The reference submits the ~40
  * launches of one sample strictly one after the other on one stream (Pathtracer.cpp:738-855);
  * here consecutive rt_render_sample calls alternate between `count` sets of queues / streams and
  * only the accumulate step is ordered between them, so a sample's small deep-bounce launches
@@ -208,6 +208,14 @@ int rt_set_samples_in_flight(rt_context * ctx, int count);
 /* One sample for this context's pixel range: generate, (trace, sort, shade*, shadow) x
  * bounces, then accumulate or SVGF/TAA.  Asynchronous; rt_synchronize or a read waits.    */
 int rt_render_sample(rt_context * ctx, int sample_index);
+/* sample_count (1..16) consecutive samples per pixel, sample_index .. sample_index+count-1, as
+ * ONE wavefront: every launch carries count x as many paths, so the deep bounces (and the small
+ * pixel share of one rank of a multi-GPU job) fill the GPU, and the launch-latency floor of a
+ * bounce is paid once per batch. Each path is keyed on (pixel, its own sample index) and the
+ * per-sample frame buffers are folded into the accumulators in sample order, so the result is
+ * bit-identical to count calls of rt_render_sample (tests/test_gpu_parity.py). Not for SVGF.
+ * rt_get_counters reports the batch totals.                                               */
+int rt_render_samples(rt_context * ctx, int sample_index, int sample_count);
 int rt_synchronize(rt_context * ctx);
 /* Per-stage HIP-event timing (ms_generate..ms_post of rt_counters) costs ~2 events per
  * kernel launch, so it is opt-in; ms_total is always measured. Replaces the CUDAEventPool

@@ -271,6 +271,42 @@ def test_samples_in_flight_do_not_change_the_image(grt):
     assert np.isfinite(images[0]).all() and images[0][..., :3].max() > 0.0
 
 
+def test_sample_batches_equal_single_samples(grt):
+    """rt_render_samples(first, count) renders `count` samples of every pixel as one wavefront
+    (virtual pixel index = sample * frame_pixels + pixel). Six samples as 6 x 1, 2 x 3 and 4 + 2:
+    the accumulated image is bit-identical and the queue totals add up."""
+    import ctypes
+    lib = grt.device_lib()
+    lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    images, rays = [], []
+    for plan in ([1] * 6, [3, 3], [4, 2]):
+        scene, pt = make_pathtracer(grt, "cornellbox", 320, 240, 0, num_bounces=5)
+        first, total = 0, np.zeros(10, np.int64)
+        for count in plan:
+            assert lib.rt_render_samples(pt.ctx, first, count) == 0, lib.rt_last_error(pt.ctx)
+            c = pt.counters()
+            total += np.array(list(c.trace[:5]) + list(c.shadow[:5]), np.int64)
+            first += count
+        images.append(pt.read_framebuffer().copy()); rays.append(total)
+        pt.close(); scene.close()
+    assert np.array_equal(images[0], images[1]) and np.array_equal(images[0], images[2])
+    assert np.array_equal(rays[0], rays[1]) and np.array_equal(rays[0], rays[2]) and rays[0][0] == 6 * 320 * 240
+    # and on the textured 1080p scene, split over tiles as one rank of four would render it
+    scene, pt = make_pathtracer(grt, "sponza", 1920, 1080, 0, num_bounces=3)
+    lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3
+    assert lib.rt_set_pixel_tiles(pt.ctx, 1920 * 8, 1, 4) == 0
+    for s in range(4):
+        assert lib.rt_render_sample(pt.ctx, s) == 0
+    single = pt.read_framebuffer().copy()
+    pt.close(); scene.close()
+    scene, pt = make_pathtracer(grt, "sponza", 1920, 1080, 0, num_bounces=3)
+    assert lib.rt_set_pixel_tiles(pt.ctx, 1920 * 8, 1, 4) == 0
+    assert lib.rt_render_samples(pt.ctx, 0, 4) == 0
+    batched = pt.read_framebuffer().copy()
+    assert np.array_equal(single, batched) and single[8:16, :1920, :3].max() > 0.0 and single[0:8].max() == 0.0
+    pt.close(); scene.close()
+
+
 def test_device_errors_are_reported(grt):
     import ctypes
     lib = grt.device_lib()
@@ -307,6 +343,7 @@ def test_tile_split_pack_unpack_rebuilds_the_frame(grt):
         pt.render()
         rays += sum(pt.counters().trace[:4])
         packed = torch.zeros((split.local_pixels, 4), device="cuda")
+        torch.cuda.synchronize()   # the fill runs on torch's stream, the pack on the tracer's
         assert lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, world, split.tiles_per_rank) == 0
         assert lib.rt_synchronize(ctx) == 0
         gathered = torch.cat([gathered, packed])
@@ -317,6 +354,7 @@ def test_tile_split_pack_unpack_rebuilds_the_frame(grt):
     # wipe the frame, then scatter the gathered tiles back on the device
     lib.rt_set_pixel_range(ctx, 0, 0)
     zeros = torch.zeros_like(gathered)
+    torch.cuda.synchronize()
     assert lib.rt_unpack_pixels(ctx, zeros.data_ptr(), split.tile_pixels, world, split.tiles_per_rank) == 0
     assert lib.rt_synchronize(ctx) == 0 and not pt.read_framebuffer().any()
     assert lib.rt_unpack_pixels(ctx, gathered.data_ptr(), split.tile_pixels, world, split.tiles_per_rank) == 0
