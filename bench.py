@@ -113,8 +113,9 @@ def main():
     ap.add_argument("--steps", type=int, default=32)   # PerfTest BUFFER_SIZE = 32 frames (Util/PerfTest.h:9)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0, help="debug: render only rank 0's tiles of an N-GPU split on one GPU (no collective), to exercise the N > 1 code path")
     ap.add_argument("--batch", type=int, default=SPP, help="samples per pixel per submission (rt_render_samples), 1..%d" % SPP)
-    ap.add_argument("--samples-in-flight", type=int, default=2, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
+    ap.add_argument("--samples-in-flight", type=int, default=0, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
     args = ap.parse_args()
 
     import torch
@@ -140,17 +141,22 @@ def main():
     pt.update()
     lib = grt.device_lib()
     ctx = pt.ctx
+    if args.samples_in_flight <= 0:   # measured optimum (profiles/r01_sample_batching.txt): 3 for a whole frame, 4 for a rank's share
+        args.samples_in_flight = 3 if (world == 1 and args.emulate_world <= 1) else 4
     grt.set_samples_in_flight(ctx, args.samples_in_flight)
-    split = parallel.TileSplit(rank, world, WIDTH, HEIGHT)
+    split_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
+    split = parallel.TileSplit(rank, split_world, WIDTH, HEIGHT)
     pitch = pt.pitch
     device = torch.device("cuda", local_rank)
 
     # this rank's tiles, rendered as scan-order pixel ranges; the gather buffers live in torch
     packed = torch.zeros((split.local_pixels, 4), dtype=torch.float32, device=device)
-    gathered = torch.zeros((world * split.local_pixels, 4), dtype=torch.float32, device=device)
+    gathered = torch.zeros((split_world * split.local_pixels, 4), dtype=torch.float32, device=device)
     import ctypes
     lib.rt_pack_pixels.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.rt_synchronize.argtypes = [ctypes.c_void_p]
+    lib.rt_stream_wait_for_context.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.rt_context_wait_for_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 
     def check(status):
         if status != 0:
@@ -161,24 +167,29 @@ def main():
         library keeps `samples_in_flight` submissions running concurrently); with N > 1 the
         accumulated frame is gathered once it is complete, i.e. after its last sample -- every rank
         accumulates its own tiles, so nothing has to be exchanged between the samples of a frame."""
-        if world == 1:
+        if split_world == 1:
             check(lib.rt_set_pixel_range(ctx, 0, WIDTH * HEIGHT))
             check(lib.rt_render_samples(ctx, sample_index, count))
         else:
-            check(lib.rt_set_pixel_tiles(ctx, split.tile_pixels, rank, world))
+            check(lib.rt_set_pixel_tiles(ctx, split.tile_pixels, rank, split_world))
             check(lib.rt_render_samples(ctx, sample_index, count))
-            if frame_complete:
-                torch.cuda.current_stream().synchronize()  # the previous all_gather still reads `packed`
-                check(lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, world, split.tiles_per_rank))
-                check(lib.rt_synchronize(ctx))            # the tracer runs on its own HIP streams
-                dist.all_gather_into_tensor(gathered, packed)
+            if frame_complete and not os.environ.get("BENCH_NO_GATHER"):
+                # stream-ordered, the host does not block: pack after the previous all_gather has read
+                # `packed`, all_gather after the pack; the next frames are already being traced meanwhile
+                torch_stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                check(lib.rt_context_wait_for_stream(ctx, torch_stream))
+                check(lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, split_world, split.tiles_per_rank))
+                check(lib.rt_stream_wait_for_context(ctx, torch_stream))
+                if world > 1:
+                    dist.all_gather_into_tensor(gathered, packed)
+                else:
+                    gathered[:split.local_pixels].copy_(packed)   # --emulate-world: stand-in for the collective
 
     def counters():
         c = pt.counters()
         return c, sum(c.trace[:NUM_BOUNCES]), sum(c.shadow[:NUM_BOUNCES])
 
-    if world > 1:
-        lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 
     # ---- warm-up (untimed) ---------------------------------------------------------------------
     def submissions(steps):
@@ -190,6 +201,10 @@ def main():
             out.append((first, count)); k += count
         return out
 
+    # untimed priming: every submission slot allocates its queues / streams on first use (GBs of hipMalloc)
+    for _ in range(args.samples_in_flight):
+        render_step(0, frame_complete=True, count=min(args.batch, SPP))
+    check(lib.rt_synchronize(ctx))
     for first, count in submissions(args.warmup):
         render_step(first, frame_complete=True, count=count)
     check(lib.rt_synchronize(ctx))
@@ -227,7 +242,7 @@ def main():
     check(lib.rt_synchronize(ctx))
     # HIP events around every trace launch of the timed region, each on the stream the launch runs on
     # (mode 2: no serialisation -- the side stream and the samples in flight stay as in production)
-    grt.set_profiling(ctx, 2)
+    grt.set_profiling(ctx, 0 if os.environ.get("BENCH_NO_LAUNCH_TIMING") else 2)
     t0 = time.perf_counter()
     plan = submissions(args.steps)
     for i, (first, count) in enumerate(plan):
@@ -256,7 +271,7 @@ def main():
         total_rays = rays_per_step * args.steps
         value = total_rays / elapsed / 1e6
         launches_per_sample = NUM_BOUNCES  # closest-hit trace launches per submission (one per bounce)
-        achieved = timed_alg_bytes / (timed_trace_ms * 1e-3) / 1e9  # rank 0's launches of the timed region
+        achieved = timed_alg_bytes / (max(timed_trace_ms, 1e-9) * 1e-3) / 1e9  # rank 0's launches of the timed region
         achieved_alone = sum(alg_bytes_per_sample) / (sum(trace_ms) * 1e-3) / 1e9
         roofline = {
             "bound": "hbm", "kernel": "kernel_trace_bvh8", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -284,6 +299,7 @@ def main():
                 "rays_per_step": round(rays_per_step), "shadow_rays_per_step": round(shadow_4spp / SPP),
                 "mrays_s_including_shadow": round((rays_4spp + shadow_4spp) / SPP * args.steps / elapsed / 1e6, 1),
                 "ms_per_4spp_frame": round(elapsed / args.steps * SPP * 1e3, 3),
+                "emulated_world": args.emulate_world,
                 "parallelism": "tile-split x%d + one RCCL all-gather of the accumulated float4 frame per %d-spp frame" % (world, SPP) if world > 1 else "single GPU",
                 "samples_per_submission": args.batch, "submissions_in_flight": args.samples_in_flight,
                 "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},

@@ -128,6 +128,7 @@ def host_lib():
         lib.grt_pathtracer_free.argtypes = [c_void_p]
         lib.grt_pathtracer_update.argtypes = [c_void_p, c_float]
         lib.grt_pathtracer_render.argtypes = [c_void_p]
+        lib.grt_pathtracer_render_samples.argtypes = [c_void_p, c_int]
         lib.grt_pathtracer_resize.argtypes = [c_void_p, c_int, c_int]
         lib.grt_pathtracer_set_pixel_range.argtypes = [c_void_p, c_int, c_int]
         lib.grt_pathtracer_sample_index.argtypes = [c_void_p]
@@ -342,6 +343,10 @@ class Pathtracer:
 
     def render(self):
         _host_check(host_lib().grt_pathtracer_render(self.handle))
+
+    def render_samples(self, count):
+        """`count` samples per pixel as one wavefront; same image as `count` x (update(); render())."""
+        _host_check(host_lib().grt_pathtracer_render_samples(self.handle, int(count)))
 
     def invalidate(self, what):
         host_lib().grt_pathtracer_invalidate(self.handle, what.encode())

@@ -42,7 +42,7 @@ struct SampleSlot {
 struct rt_context {
 	int device = 0;
 	hipStream_t stream = nullptr;      // "main": uploads, read-backs, pack/unpack, kernel-level entry points
-	hipEvent_t ev_main = nullptr;
+	hipEvent_t ev_main = nullptr, ev_interop = nullptr;
 	std::string error;
 
 	SampleSlot slots[RT_MAX_SAMPLE_SLOTS];
@@ -199,6 +199,7 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 	memset(&ctx->last_counters, 0, sizeof(ctx->last_counters));
 	RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
 	RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+	RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_interop, hipEventDisableTiming));
 	if (const char * e = getenv("GRT_SAMPLES_IN_FLIGHT")) { int n = atoi(e); if (n >= 1 && n <= RT_MAX_SAMPLE_SLOTS) ctx->samples_in_flight = n; }
 	if (const char * e = getenv("GRT_OVERLAP_SHADOWS")) ctx->overlap_shadows = atoi(e) != 0;
 
@@ -231,6 +232,7 @@ void rt_destroy(rt_context * ctx) {
 		(void)hipStreamDestroy(slot.stream);
 	}
 	(void)hipEventDestroy(ctx->ev_main);
+	(void)hipEventDestroy(ctx->ev_interop);
 	(void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -627,6 +629,22 @@ int rt_unpack_pixels(rt_context * ctx, const void * src_device, int tile_pixels,
 	return RT_OK;
 }
 
+int rt_stream_wait_for_context(rt_context * ctx, void * stream) {
+	RT_REQUIRE(ctx, ctx, "rt_stream_wait_for_context: NULL context");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, hipEventRecord(ctx->ev_interop, ctx->stream));
+	RT_HIP(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_interop, 0));
+	return RT_OK;
+}
+
+int rt_context_wait_for_stream(rt_context * ctx, void * stream) {
+	RT_REQUIRE(ctx, ctx, "rt_context_wait_for_stream: NULL context");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, hipEventRecord(ctx->ev_interop, (hipStream_t)stream));
+	RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_interop, 0));
+	return RT_OK;
+}
+
 int rt_set_trace_statistics(rt_context * ctx, int enable) {
 	RT_REQUIRE(ctx, ctx, "rt_set_trace_statistics: NULL context");
 	(void)hipSetDevice(ctx->device);
@@ -677,6 +695,7 @@ static int ensure_luts(rt_context * ctx) {
 	p.lut_conductor_directional_albedo        = (const float *)ctx->luts[4];
 	p.lut_conductor_albedo                    = (const float *)ctx->luts[5];
 	ctx->luts_ready = true;
+	RT_HIP(ctx, quiesce(ctx)); // once per context: the sample streams read the tables without further ordering
 	return RT_OK;
 }
 
@@ -756,9 +775,10 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 
 	ctx->time_this_sample = ctx->launch_timing && (ctx->timing_counter++ % RT_LAUNCH_TIMING_STRIDE) == 0;
 	hipStream_t st = slot.stream;
-	// everything submitted on the main stream so far (uploads are synchronous; unpack_pixels, LUTs are not)
+	// The wavefront part depends on nothing the main stream does asynchronously (uploads and the LUT
+	// integration synchronise); only the accumulate step below has to follow the main-stream work
+	// submitted so far (rt_pack_pixels of the previous frame reads, rt_unpack_pixels writes the image).
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
-	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
 	if (exclusive) for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[k].ev_done, 0));
 
 	ctx->stage_used = 0;
@@ -820,6 +840,7 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	{ int status = submit_wavefront(); if (status) return status; }
 
 	// The accumulate step folds this sample into the shared accumulators: strictly in sample order.
+	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
 	if (ctx->last_slot >= 0 && ctx->last_slot != slot_index) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[ctx->last_slot].ev_done, 0));
 	stage_mark(ctx, STAGE_POST, st);
 	if (p.config.enable_svgf) rt_launch_svgf_taa(p, sample_index, st);

@@ -207,3 +207,19 @@ void Pathtracer::render() {
 	require_device();
 	check(rt_render_sample(ctx, sample_index));
 }
+
+void Pathtracer::render_samples(int count) {
+	require_device();
+	if (count < 1) return;
+	if (gpu_config.enable_svgf) { // SVGF frames feed each other's history: one at a time
+		for (int i = 0; i < count; i++) { if (i) sample_index++; check(rt_render_sample(ctx, sample_index)); }
+		return;
+	}
+	while (count > 0) {
+		int n = count < 16 ? count : 16;
+		check(rt_render_samples(ctx, sample_index, n));
+		sample_index += n - 1;
+		count -= n;
+		if (count > 0) sample_index++;
+	}
+}

@@ -31,6 +31,10 @@ struct Pathtracer final : Integrator {
 
 	void update(float delta) override;
 	void render() override;
+	// `count` samples per pixel in one wavefront (rt_render_samples): the same image as calling
+	// update(); render(); `count` times. sample_index ends on the last sample rendered, so the next
+	// update() continues the progression where the reference's loop would be.
+	void render_samples(int count);
 
 	void calc_light_power();
 	void calc_light_mesh_weights();

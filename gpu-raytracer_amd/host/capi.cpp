@@ -139,6 +139,12 @@ int grt_pathtracer_render(void * pt) {
 		return 0;
 	GRT_CATCH(-1)
 }
+int grt_pathtracer_render_samples(void * pt, int count) {
+	GRT_TRY
+		((Pathtracer *)pt)->render_samples(count);
+		return 0;
+	GRT_CATCH(-1)
+}
 int grt_pathtracer_resize(void * pt, int width, int height) {
 	GRT_TRY
 		Pathtracer * p = (Pathtracer *)pt;

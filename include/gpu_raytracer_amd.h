@@ -189,6 +189,14 @@ int rt_set_pixel_tiles(rt_context * ctx, int tile_pixels, int first_tile, int ti
  *        the final image in scan order.                                                       */
 int rt_pack_pixels(rt_context * ctx, void * dst_device, int tile_pixels, int first_tile, int tile_stride, int tiles);
 int rt_unpack_pixels(rt_context * ctx, const void * src_device, int tile_pixels, int world, int tiles_per_rank);
+/* Stream-ordered hand-over of device buffers between the context and a consumer's HIP stream
+ * (e.g. the stream RCCL runs on), so that the host never has to block between frames:
+ *   rt_stream_wait_for_context: `stream` (a hipStream_t) waits for everything the context has
+ *       enqueued on its transfer stream so far (rt_pack_pixels, rt_unpack_pixels);
+ *   rt_context_wait_for_stream: the context's transfer stream waits for everything enqueued on
+ *       `stream` so far (e.g. the collective that still reads the buffer the next pack writes). */
+int rt_stream_wait_for_context(rt_context * ctx, void * stream);
+int rt_context_wait_for_stream(rt_context * ctx, void * stream);
 
 /* Pixels per wavefront batch. The reference hard-codes BATCH_SIZE = 1080*720 to bound VRAM
  * (Common.h:69-71) and loops over batches; results do not depend on it. Default 0 = the whole

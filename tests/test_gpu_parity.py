@@ -291,6 +291,12 @@ def test_sample_batches_equal_single_samples(grt):
         pt.close(); scene.close()
     assert np.array_equal(images[0], images[1]) and np.array_equal(images[0], images[2])
     assert np.array_equal(rays[0], rays[1]) and np.array_equal(rays[0], rays[2]) and rays[0][0] == 6 * 320 * 240
+    # the host class: render_samples(6) == 6 x (update, render), and the progression continues after it
+    scene, pt = make_pathtracer(grt, "cornellbox", 320, 240, 0, num_bounces=5)
+    pt.render_samples(6)
+    assert pt.sample_index == 5 and np.array_equal(pt.read_framebuffer(), images[0])
+    pt.update(); assert pt.sample_index == 6
+    pt.close(); scene.close()
     # and on the textured 1080p scene, split over tiles as one rank of four would render it
     scene, pt = make_pathtracer(grt, "sponza", 1920, 1080, 0, num_bounces=3)
     lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3
@@ -331,6 +337,8 @@ def test_tile_split_pack_unpack_rebuilds_the_frame(grt):
     lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.rt_pack_pixels.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.rt_unpack_pixels.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.rt_stream_wait_for_context.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.rt_context_wait_for_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     pt.render()
     full = pt.read_framebuffer().copy()
     rays_full = sum(pt.counters().trace[:4])
@@ -343,9 +351,11 @@ def test_tile_split_pack_unpack_rebuilds_the_frame(grt):
         pt.render()
         rays += sum(pt.counters().trace[:4])
         packed = torch.zeros((split.local_pixels, 4), device="cuda")
-        torch.cuda.synchronize()   # the fill runs on torch's stream, the pack on the tracer's
+        # the fill runs on torch's stream, the pack on the tracer's: order them on the device, both ways
+        torch_stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert lib.rt_context_wait_for_stream(ctx, torch_stream) == 0
         assert lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, world, split.tiles_per_rank) == 0
-        assert lib.rt_synchronize(ctx) == 0
+        assert lib.rt_stream_wait_for_context(ctx, torch_stream) == 0
         gathered = torch.cat([gathered, packed])
         # the torch-side unpack used by bench.py agrees with the device-side one (checked below)
     assert rays == rays_full
