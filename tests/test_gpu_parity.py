@@ -216,6 +216,33 @@ def test_feature_toggles_match_oracle(grt, oracle):
         pt.close(); scene.close()
 
 
+def test_edge_sizes_and_sample_ranges_match_oracle(grt, oracle):
+    """Degenerate launch sizes and the RNG's table boundary, each against the oracle:
+    a 1x1 and a 33x17 frame (pitch 64: most of a row is padding), a single bounce, no bounce at all,
+    and a batch of samples that straddles sample_index 4095 -> 4096, where random<Dim>() switches
+    from the PMJ table to the hash fallback (Sampling.h:48-58)."""
+    import ctypes
+    for w, h, bounces in ((1, 1, 3), (33, 17, 1), (40, 24, 0)):
+        scene, pt = make_pathtracer(grt, "cornellbox", w, h, 0, num_bounces=bounces)
+        view = oracle.SceneView(pt); frame = oracle.Frame(view)
+        pt.render(); c = pt.counters(); oc = frame.render_sample(pt.sample_index)
+        assert list(c.trace[:bounces]) == list(oc.trace[:bounces]), (w, h, bounces)
+        got, want = pt.read_framebuffer()[:, :w, :3], frame.final[:, :w, :3]
+        assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-5 * (1.0 + np.abs(want).max()), (w, h, bounces)
+        pt.close(); scene.close()
+    scene, pt = make_pathtracer(grt, "cornellbox", 96, 64, 0, num_bounces=4)
+    view = oracle.SceneView(pt); frame = oracle.Frame(view)
+    lib = grt.device_lib()
+    lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    assert lib.rt_render_samples(pt.ctx, 4094, 4) == 0, lib.rt_last_error(pt.ctx)
+    for sample in range(4094, 4098):
+        frame.render_sample(sample)
+    got, want = pt.read_framebuffer()[:, :96, :3], frame.final[:, :96, :3]
+    rel = np.abs(got - want).sum() / want.sum()
+    assert rel < REL_L1_TOL, rel
+    pt.close(); scene.close()
+
+
 def test_render_is_deterministic_and_split_invariant(grt):
     """Size-independent properties at the full BASELINE frame size (1920x1080 Sponza):
     the same sample rendered twice is bit-identical, and rendering the frame as two pixel ranges
