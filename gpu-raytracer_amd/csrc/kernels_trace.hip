@@ -5,11 +5,15 @@
 // octant-ordered traversal of 80-byte compressed 8-wide nodes, TLAS -> BLAS instancing with
 // un-normalised object-space rays, Moeller-Trumbore on pre-subtracted edges -- re-designed
 // for CDNA4:
-//   * persistent 64-lane waves pull rays with ONE wave-aggregated atomic per refill
-//     (ballot + mbcnt prefix rank) instead of one atomicAdd per lane;
+//   * persistent 64-lane waves claim rays in blocks of 64..128 with ONE returning atomic per
+//     block and deal them to their lanes as they go idle (ballot + mbcnt prefix rank), instead
+//     of one atomicAdd per lane;
+//   * per round a lane does one node step and then at most one batch of RT_TRI_BATCH triangle
+//     tests (no inner triangle loop: on a 64-wide wave it ran at 10 % lane occupancy);
 //   * the traversal stack lives in LDS, striped [entry][lane] so that a ds_write_b64 /
 //     ds_read_b64 of any mix of per-lane depths is bank-conflict free (entry stride is 512 B,
-//     a multiple of the 256 B bank row); only entries beyond RT_LDS_STACK spill to scratch;
+//     a multiple of the 256 B bank row); only entries beyond RT_LDS_STACK spill, to a
+//     coalesced [entry][grid lane] area in HBM (no compiler scratch);
 //   * the reciprocal ray direction is computed once per ray (and per BLAS entry) so the
 //     node test is 6 fma + min3/max3 per child; child bytes are unpacked with
 //     v_cvt_f32_ubyte0..3;
@@ -18,6 +22,9 @@
 // Triangle postponing (BVH8.h:200,234-240) is intentionally absent: every ray visits nodes
 // and triangles in exactly the order of the sequential algorithm, which keeps hits
 // bit-identical to the CPU oracle even when two triangles tie in t.
+// A wave-cooperative variant (nodes fetched coalesced by 5 adjacent lanes and handed to their
+// owners through LDS, the "LDS-staged node" of the design brief) was written and measured 3x
+// slower than private fetches; it was removed, see DESIGN.md 4.1 and profiles/r01_trace_variants.txt.
 #include "rt_math.h"
 
 #include <cstdio>
@@ -41,9 +48,6 @@
 #endif
 #ifndef RT_FETCH_BLOCK_MAX
 #define RT_FETCH_BLOCK_MAX 128   // rays claimed per cursor atomic; measured 64..1024, see profiles/r01_trace_fetch_block.txt
-#endif
-#ifndef RT_TRACE_COOPERATIVE
-#define RT_TRACE_COOPERATIVE 0   // 0: one ray per lane with private fetches (default, 3x faster); 1: wave-cooperative LDS-staged fetches
 #endif
 #ifndef RT_N_D
 #define RT_N_D 4            // dynamic fetch: tolerated idle lanes per iteration (N_d = 4 of 32 in the reference)
@@ -450,274 +454,8 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 }
 
 
-// =================================================================================================
-// Wave-cooperative engine (default).
-//
-// Measured on MI355X (profiles/r01_pmc_trace_secondary_4M.txt): with one ray per lane fetching its
-// own 80-byte node as five 16-byte loads, a wave issues 5 VMEM instructions whose 64 lanes each
-// touch a different cache line -> 5.5 L1 tag look-ups per node; the CU's vector cache retires
-// about one look-up per clock, waves sit in s_waitcnt for 78 % of their cycles and neither more
-// waves per SIMD nor sorting the rays changes the rate. The fix is to make the LOADS coalesced even
-// though the RAYS are not: the lanes of a wave fetch the nodes (and triangles) the wave needs
-// TOGETHER, five (three) adjacent lanes per node (triangle), so that a 16-byte x 5 request is one
-// or two cache lines in ONE instruction, and the chunks are handed to their owners through LDS:
-//
-//   owners publish their node index        ds_write_b32   idx[rank]
-//   slot s = round*64 + lane -> owner s/5, chunk s%5     global_load_dwordx4  (coalesced per owner)
-//   stage[s] = chunk                       ds_write_b128  (contiguous: conflict free)
-//   owner reads stage[rank*5 + 0..4]       ds_read_b128   (stride 80 B: conflict free)
-//
-// i.e. the "LDS-staged BVH8 node" of the design brief. All 64 lanes stay in one converged loop
-// (finished lanes keep helping with fetches until the wave refills), which also turns the refill
-// into one uniform decision per iteration. Per ray, nodes and triangles are still visited in
-// exactly the sequential order, so results remain bit-identical to the oracle.
-// =================================================================================================
-
-#define RT_COOP_LDS_STACK 8
-#ifndef RT_COOP_WAVES_PER_SIMD
-#define RT_COOP_WAVES_PER_SIMD 4
-#endif
-#ifndef RT_REFILL_THRESHOLD
-#define RT_REFILL_THRESHOLD 16   // refill the wave once this many lanes have no ray
-#endif
-
-struct WaveLDS {
-	uint2  stack[RT_COOP_LDS_STACK][RT_WAVE_SIZE];   // 4 KB
-	float4 stage[RT_WAVE_SIZE * 5];                  // 5 KB: 64 nodes x 5 chunks (triangles use the first 3 KB)
-	int    idx[RT_WAVE_SIZE];                        // owner rank -> node / triangle index
-};
-
-// Fetch `CH` consecutive float4 starting at base[index * CH] for every lane with want == true.
-template<int CH>
-RT_DEV void cooperative_fetch(bool want, unsigned index, const float4 * __restrict__ base, WaveLDS & w, unsigned lane, float4 (&out)[CH]) {
-	unsigned long long owners = __ballot(want);
-	if (owners == 0) return;
-	int total = __popcll(owners) * CH;
-	unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(owners >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(owners), 0u));
-	if (want) w.idx[rank] = int(index);
-
-	float4 chunk[CH];
-	#pragma unroll
-	for (int r = 0; r < CH; r++) {
-		int slot = r * RT_WAVE_SIZE + int(lane);
-		if (r * RT_WAVE_SIZE < total && slot < total) {
-			int o = slot / CH, c = slot - o * CH;
-			chunk[r] = base[size_t(unsigned(w.idx[o])) * CH + c];
-		}
-	}
-	#pragma unroll
-	for (int r = 0; r < CH; r++) {
-		int slot = r * RT_WAVE_SIZE + int(lane);
-		if (r * RT_WAVE_SIZE < total && slot < total) w.stage[slot] = chunk[r];
-	}
-	if (want) {
-		#pragma unroll
-		for (int c = 0; c < CH; c++) out[c] = w.stage[rank * CH + c];
-	}
-}
-
-template<bool SHADOW, bool COUNT, typename Source>
-RT_DEV void bvh8_trace_cooperative(const RtParams & p, Source & src, int ray_count, int * cursor, unsigned long long * stats = nullptr) {
-	__shared__ WaveLDS shared_wave[RT_TRACE_BLOCK / RT_WAVE_SIZE];
-
-	const float4 * __restrict__ nodes     = p.bvh8_nodes;
-	const float4 * __restrict__ positions = p.triangle_positions;
-
-	unsigned lane = threadIdx.x & (RT_WAVE_SIZE - 1);
-	unsigned wave = threadIdx.x / RT_WAVE_SIZE;
-	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * RT_WAVE_SIZE >= unsigned(ray_count)) return; // surplus wave
-
-	WaveLDS & w = shared_wave[wave];
-	uint2 * spill = p.stack_spill + (blockIdx.x * blockDim.x + threadIdx.x);
-	const int spill_stride = int(gridDim.x * blockDim.x);
-	int stack_size = 0;
-	auto push = [&](uint2 item) {
-		if (stack_size < RT_COOP_LDS_STACK) w.stack[stack_size][lane] = item;
-		else spill[size_t(stack_size - RT_COOP_LDS_STACK) * spill_stride] = item;
-		stack_size++;
-	};
-	auto pop = [&]() -> uint2 {
-		stack_size--;
-		if (stack_size < RT_COOP_LDS_STACK) return w.stack[stack_size][lane];
-		return spill[size_t(stack_size - RT_COOP_LDS_STACK) * spill_stride];
-	};
-
-	bool alive = false;      // this lane holds a ray
-	bool drained = false;    // wave-uniform: the cursor ran past the last ray
-	int  local_next = 0, local_end = 0;   // wave-uniform: rays claimed from the cursor, not yet dealt
-	// block size: big launches claim up to 512 rays per atomic, small ones 64 so that every wave gets work
-	const int waves_in_grid = int(gridDim.x) * (RT_TRACE_BLOCK / RT_WAVE_SIZE);
-	const int ray_block = max(RT_WAVE_SIZE, min(512, (ray_count / (2 * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
-	uint2 current_group = make_uint2(0, 0);
-	int  ray_index = 0;
-	Ray3 ray;
-	f3   inv_dir = mk3(0.0f);
-	unsigned oct_inv4 = 0;
-	float max_distance = 0.0f;
-	HitRecord hit;
-	int  tlas_stack_size = RT_INVALID;
-	int  mesh_id = 0;
-	bool mesh_has_identity_transform = true;
-	unsigned count_nodes = 0, count_triangles = 0, count_inst_xform = 0, count_inst_ident = 0;
-	ray.origin = mk3(0.0f); ray.direction = mk3(0.0f);
-	hit.t = RT_INFINITY; hit.u = hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
-
-	while (true) {
-		// ---- refill: wave-uniform. Rays are claimed from the shared cursor in BLOCKS (one returning
-		// atomic per `ray_block` rays, kept in the wave-uniform [local_next, local_end) range) and
-		// dealt to the lanes as they go idle: a same-address atomic retires at ~88 per microsecond in
-		// L2 on this chip, so claiming ~23 rays at a time -- what per-refill atomics averaged --
-		// capped the whole GPU at 2.0 Grays/s regardless of the traversal code.
-		unsigned long long idle = __ballot(!alive);
-		int n_idle = __popcll(idle);
-		if (n_idle == RT_WAVE_SIZE || n_idle >= RT_REFILL_THRESHOLD) {
-			if (local_next >= local_end && !drained) {
-				int base = 0;
-				if (lane == 0) base = atomicAdd(cursor, ray_block);
-				base = __builtin_amdgcn_readfirstlane(base);
-				local_next = base;
-				local_end  = min(base + ray_block, ray_count);
-				drained = base + ray_block >= ray_count;
-			}
-			int available = local_end - local_next;
-			if (available > 0) {
-				if (!alive) {
-					unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(idle >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(idle), 0u));
-					if (int(rank) < available) {
-						ray_index = local_next + int(rank);
-						src.load(ray_index, ray, max_distance);
-						inv_dir  = reciprocal(ray.direction);
-						oct_inv4 = ray_get_octant_inv4(ray.direction);
-						current_group = make_uint2(0, 0x80000000u);
-						hit.t = RT_INFINITY; hit.u = 0.0f; hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
-						tlas_stack_size = RT_INVALID;
-						stack_size = 0;
-						alive = true;
-					}
-				}
-				local_next += min(n_idle, available);
-			}
-		}
-		if (__ballot(alive) == 0) {
-			if (drained && local_next >= local_end) return;
-			continue;
-		}
-
-		// ---- node phase ---------------------------------------------------------------------------------
-		bool want_node = alive && (current_group.y & 0xff000000u) != 0;
-		unsigned child_node_index = 0;
-		uint2 triangle_group = make_uint2(0, 0);
-		if (want_node) {
-			unsigned hits_imask = current_group.y;
-			unsigned child_index_offset = msb(hits_imask);
-			unsigned child_index_base   = current_group.x;
-			current_group.y &= ~(1u << child_index_offset);
-			if (current_group.y & 0xff000000u) push(current_group);
-			unsigned slot_index     = (child_index_offset - 24) ^ (oct_inv4 & 0xffu);
-			unsigned relative_index = __popc(hits_imask & ~(0xffffffffu << slot_index));
-			child_node_index = child_index_base + relative_index;
-		}
-		float4 n[5];
-		cooperative_fetch<5>(want_node, child_node_index, nodes, w, lane, n);
-		if (want_node) {
-			if (COUNT) count_nodes++;
-			unsigned hitmask = bvh8_node_intersect(ray, inv_dir, oct_inv4, SHADOW ? max_distance : hit.t, n[0], n[1], n[2], n[3], n[4]);
-			unsigned imask = extract_byte(__float_as_uint(n[0].w), 3);
-			current_group .x = __float_as_uint(n[1].x);
-			triangle_group.x = __float_as_uint(n[1].y);
-			current_group .y = (hitmask & 0xff000000u) | imask;
-			triangle_group.y = (hitmask & 0x00ffffffu);
-		} else if (alive) {
-			triangle_group = current_group;
-			current_group  = make_uint2(0, 0);
-		}
-
-		// ---- TLAS leaf: descend into the first mesh of the group (divergent, a few loads) -----------------
-		if (alive && triangle_group.y != 0 && tlas_stack_size == RT_INVALID) {
-			int mesh_offset = int(msb(triangle_group.y));
-			triangle_group.y &= ~(1u << mesh_offset);
-			mesh_id = int(triangle_group.x) + mesh_offset;
-			if (triangle_group.y != 0)         push(triangle_group);
-			if (current_group.y & 0xff000000u) push(current_group);
-			tlas_stack_size = stack_size;
-
-			unsigned root = unsigned(p.mesh_bvh_root_indices[mesh_id]);
-			mesh_has_identity_transform = (root >> 31) != 0;
-			if (!mesh_has_identity_transform) {
-				const float4 * m = p.mesh_transforms_inv + size_t(mesh_id) * 3;
-				ray.origin    = transform_position (m, ray.origin);
-				ray.direction = transform_direction(m, ray.direction);
-				inv_dir  = reciprocal(ray.direction);
-				oct_inv4 = ray_get_octant_inv4(ray.direction);
-				if (COUNT) count_inst_xform++;
-			} else if (COUNT) count_inst_ident++;
-			current_group = make_uint2(root & 0x7fffffffu, 0x80000000u);
-			triangle_group.y = 0;
-		}
-
-		// ---- triangle phase: every lane with leaf triangles left tests its next one -----------------------
-		bool occluded = false;
-		while (true) {
-			bool want_triangle = alive && triangle_group.y != 0 && !occluded;
-			if (__ballot(want_triangle) == 0) break;
-			unsigned triangle_id = 0;
-			if (want_triangle) {
-				int triangle_index = int(msb(triangle_group.y));
-				triangle_group.y &= ~(1u << triangle_index);
-				triangle_id = triangle_group.x + unsigned(triangle_index);
-			}
-			float4 t[3];
-			cooperative_fetch<3>(want_triangle, triangle_id, positions, w, lane, t);
-			if (want_triangle) {
-				if (COUNT) count_triangles++;
-				if (triangle_test_loaded<SHADOW>(t[0], t[1], t[2], mesh_id, int(triangle_id), ray, max_distance, hit)) occluded = true;
-			}
-		}
-
-		// ---- retire / pop -----------------------------------------------------------------------------------
-		if (alive) {
-			bool finished = false;
-			if (SHADOW && occluded) {
-				finished = true;
-			} else if ((current_group.y & 0xff000000u) == 0) {
-				if (stack_size == 0) {
-					finished = true;
-				} else {
-					if (stack_size == tlas_stack_size) {
-						tlas_stack_size = RT_INVALID;
-						if (!mesh_has_identity_transform) {
-							float unused;
-							src.load(ray_index, ray, unused);
-							inv_dir  = reciprocal(ray.direction);
-							oct_inv4 = ray_get_octant_inv4(ray.direction);
-						}
-					}
-					current_group = pop();
-				}
-			}
-			if (finished) {
-				src.finish(ray_index, hit, SHADOW && occluded);
-				if (COUNT) {
-					atomicAdd(&stats[0], (unsigned long long)count_nodes);      atomicAdd(&stats[1], (unsigned long long)count_triangles);
-					atomicAdd(&stats[2], (unsigned long long)count_inst_xform); atomicAdd(&stats[3], (unsigned long long)count_inst_ident);
-					atomicAdd(&stats[4], 1ull);
-					count_nodes = count_triangles = count_inst_xform = count_inst_ident = 0;
-				}
-				alive = false;
-				stack_size = 0;
-				current_group = make_uint2(0, 0);
-			}
-		}
-	}
-}
-
-#if RT_TRACE_COOPERATIVE
-#define RT_TRACE_ENGINE bvh8_trace_cooperative
-#define RT_TRACE_LAUNCH_WAVES RT_COOP_WAVES_PER_SIMD
-#else
 #define RT_TRACE_ENGINE bvh8_trace_persistent
 #define RT_TRACE_LAUNCH_WAVES RT_TRACE_WAVES_PER_SIMD
-#endif
 
 RT_DEV uint4 pack_hit(const HitRecord & h) { // Buffers.h:25-32
 	unsigned uv = unsigned(int(h.u * 65535.0f)) | (unsigned(int(h.v * 65535.0f)) << 16);
@@ -812,7 +550,7 @@ static int trace_grid_size(const void * kernel) {
 	int blocks_per_cu = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, RT_TRACE_BLOCK, 0) != hipSuccess || blocks_per_cu <= 0) blocks_per_cu = 2;
 	if (blocks_per_cu > 8) blocks_per_cu = 8;
-	if (getenv("GRT_DEBUG")) fprintf(stderr, "[grt] trace kernel grid: %d CUs x %d workgroups of %d threads, engine=%s\n", cached_cus, blocks_per_cu, RT_TRACE_BLOCK, RT_TRACE_COOPERATIVE ? "cooperative" : "private");
+	if (getenv("GRT_DEBUG")) fprintf(stderr, "[grt] trace kernel grid: %d CUs x %d workgroups of %d threads\n", cached_cus, blocks_per_cu, RT_TRACE_BLOCK);
 	return cached_cus * blocks_per_cu;
 }
 
