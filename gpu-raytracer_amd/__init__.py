@@ -125,6 +125,9 @@ def host_lib():
         lib.grt_mesh_data_array.argtypes = [c_void_p, c_int, c_char_p, POINTER(c_size_t)]
         lib.grt_pathtracer_create.restype = c_void_p
         lib.grt_pathtracer_create.argtypes = [c_void_p, c_int, c_int, c_int]
+        lib.grt_ao_create.restype = c_void_p
+        lib.grt_ao_create.argtypes = [c_void_p, c_int, c_int, c_int]
+        lib.grt_ao_set_radius.argtypes = [c_void_p, c_float]
         lib.grt_pathtracer_free.argtypes = [c_void_p]
         lib.grt_pathtracer_update.argtypes = [c_void_p, c_float]
         lib.grt_pathtracer_render.argtypes = [c_void_p]
@@ -309,12 +312,14 @@ class Pathtracer:
     render (used by the CPU tests and the oracle).
     """
 
+    _create = "grt_pathtracer_create"
+
     def __init__(self, scene, width, height, device=0):
         lib = host_lib()
         self.scene = scene
-        self.handle = lib.grt_pathtracer_create(scene.handle, width, height, device)
+        self.handle = getattr(lib, self._create)(scene.handle, width, height, device)
         if not self.handle:
-            raise RuntimeError("Pathtracer creation failed: " + lib.grt_last_error().decode())
+            raise RuntimeError("%s creation failed: %s" % (type(self).__name__, lib.grt_last_error().decode()))
         self.width, self.height = width, height
 
     def close(self):
@@ -414,6 +419,25 @@ class Pathtracer:
 
 
 # ---- kernel-level entry points of the C ABI -----------------------------------------------------------
+
+class AO(Pathtracer):
+    """reference: Src/Renderer/Integrators/AO.h -- the ambient-occlusion integrator. Shares the
+    update()/render()/read_* protocol and the staging arrays with Pathtracer; `radius` is AO::ao_radius."""
+    _create = "grt_ao_create"
+
+    def __init__(self, scene, width, height, device=0, radius=1.0):
+        super().__init__(scene, width, height, device)
+        self.radius = radius
+
+    @property
+    def radius(self):
+        return self._radius
+
+    @radius.setter
+    def radius(self, value):
+        _host_check(host_lib().grt_ao_set_radius(self.handle, float(value)))
+        self._radius = float(value)
+
 
 def _dev_check(ctx, status):
     if status != 0:

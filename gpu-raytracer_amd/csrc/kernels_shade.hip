@@ -845,6 +845,61 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_plastic(RtPara
 __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_dielectric(RtParams p, int bounce, int sample_index) { shade_material<BSDFDielectric, 2>(p, bounce, sample_index, p.sizes->dielectric[bounce]); }
 __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_conductor(RtParams p, int bounce, int sample_index)  { shade_material<BSDFConductor,  3>(p, bounce, sample_index, p.sizes->conductor [bounce]); }
 
+// ---- ambient occlusion (CUDA/AO.cu:103-159) -------------------------------------------------------
+// One cosine-weighted occlusion ray of length ao_radius per primary hit; the AO shadow kernel sets
+// RADIANCE to 1 where it escapes. Same block-aggregated queue append as the material kernels.
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_ambient_occlusion(RtParams p, int sample_index, float ao_radius) {
+	const int ray_count = p.sizes->trace[0];
+	const RtTraceBuffer & in = p.trace[0];
+	__shared__ BlockAppendLDS<1, RT_SHADE_BLOCK / RT_WAVE_SIZE> append_lds;
+	int * const shadow_counter[1] = { &p.sizes->shadow[0] };
+
+	for (int first = blockIdx.x * blockDim.x; first < ray_count; first += gridDim.x * blockDim.x) {
+		const int index = first + int(threadIdx.x);
+		ShadowRay shadow; int pixel_index = 0;
+		bool emit = false;
+		if (index < ray_count) {
+			HitInfo hit = unpack_hit(in.hits[index]);
+			pixel_index = int(in.pixel_index_and_flags[index] & ~RT_FLAGS_ALL);
+			if (hit.triangle_id != RT_INVALID) {
+				f3 ray_direction = load3(in.direction, index);
+				TriangleFull tri = triangle_get_full(p, hit.triangle_id);
+				f3 geometric_normal = normalize(cross(tri.position_edge_1, tri.position_edge_2)); // object space, as in AO.cu:123
+				f3 hit_point  = barycentric(hit.u, hit.v, tri.position_0, tri.position_edge_1, tri.position_edge_2);
+				f3 hit_normal = barycentric(hit.u, hit.v, tri.normal_0,   tri.normal_edge_1,   tri.normal_edge_2);
+
+				const float4 * world = p.mesh_transforms + size_t(hit.mesh_id) * 3;
+				hit_point  = m_position(world, hit_point);
+				hit_normal = normalize(m_direction(world, hit_normal));
+				if (dot(ray_direction, hit_normal) > 0.0f) hit_normal = -hit_normal;
+
+				aov_set(p, RT_AOV_NORMAL,   pixel_index, mk4(hit_normal));
+				aov_set(p, RT_AOV_POSITION, pixel_index, mk4(hit_point));
+
+				f3 tangent, bitangent;
+				orthonormal_basis(hit_normal, tangent, bitangent);
+				f2 rand_brdf = random_sample(p, DIM_BSDF_0, unsigned(pixel_index), 0, unsigned(sample_index));
+				f3 omega_o = sample_cosine_weighted_direction(rand_brdf.x, rand_brdf.y);
+				f3 direction_out = local_to_world(omega_o, tangent, bitangent, hit_normal);
+				float pdf = omega_o.z * RT_ONE_OVER_PI;
+				if (pdf_is_valid(pdf)) {
+					emit = true;
+					shadow.origin = ray_origin_epsilon_offset(hit_point, direction_out, geometric_normal);
+					shadow.direction = direction_out;
+					shadow.max_distance = ao_radius;
+				}
+			}
+		}
+		int shadow_ray_index = block_aggregated_append(emit ? 0 : -1, shadow_counter, append_lds);
+		if (emit) {
+			store3(p.shadow.origin,    shadow_ray_index, shadow.origin);
+			store3(p.shadow.direction, shadow_ray_index, shadow.direction);
+			p.shadow.max_distance[shadow_ray_index] = shadow.max_distance;
+			p.shadow.illumination_and_pixel_index[shadow_ray_index] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(pixel_index));
+		}
+	}
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------------
 
 static int streaming_grid(int work_items) {
@@ -869,6 +924,9 @@ void rt_launch_material(const RtParams & p, int material_slot, int bounce, int s
 		case 2: hipLaunchKernelGGL(kernel_material_dielectric, grid, block, 0, stream, p, bounce, sample_index); break;
 		case 3: hipLaunchKernelGGL(kernel_material_conductor,  grid, block, 0, stream, p, bounce, sample_index); break;
 	}
+}
+void rt_launch_ambient_occlusion(const RtParams & p, int sample_index, float ao_radius, hipStream_t stream) {
+	hipLaunchKernelGGL(kernel_ambient_occlusion, dim3(2048), dim3(RT_SHADE_BLOCK), 0, stream, p, sample_index, ao_radius);
 }
 void rt_launch_random(const RtParams & p, int dimension, const unsigned * pixel_indices, int count, unsigned bounce, unsigned sample_index, float2 * out, hipStream_t stream) {
 	hipLaunchKernelGGL(kernel_random, dim3((count + 255) / 256), dim3(256), 0, stream, p, dimension, pixel_indices, count, bounce, sample_index, out);

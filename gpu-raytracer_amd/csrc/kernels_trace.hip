@@ -493,6 +493,18 @@ struct ShadowQueueSource {
 	}
 };
 
+// AO integrator: an occlusion ray that escapes sets RADIANCE to 1 (CUDA/AO.cu:77-101)
+struct ShadowAOSource {
+	RtShadowBuffer buffer;
+	RtAOV radiance;
+	RT_DEV void load(int i, Ray3 & ray, float & max_distance) const { ray.origin = load3(buffer.origin, i); ray.direction = load3(buffer.direction, i); max_distance = buffer.max_distance[i]; }
+	RT_DEV void finish(int i, const HitRecord &, bool occluded) const {
+		if (occluded || !radiance.framebuffer) return;
+		int pixel_index = __float_as_int(buffer.illumination_and_pixel_index[i].w);
+		radiance.framebuffer[pixel_index] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+	}
+};
+
 struct ShadowExplicitSource {
 	RtVec3SoA origin, direction;
 	const float * max_dist;
@@ -511,6 +523,11 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh8(RtParams p, int bounce) {
 	ShadowQueueSource src { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT], bounce };
 	RT_TRACE_ENGINE<true, false>(p, src, p.sizes->shadow[bounce], p.xcd_counters + (2 * bounce + 1) * RT_NUM_XCD);
+}
+
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh8_ao(RtParams p) {
+	ShadowAOSource src { p.shadow, p.aovs[RT_AOV_RADIANCE] };
+	RT_TRACE_ENGINE<true, false>(p, src, p.sizes->shadow[0], p.xcd_counters + RT_NUM_XCD);
 }
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh8_counting(RtParams p, int bounce, unsigned long long * stats) {
@@ -561,6 +578,10 @@ void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream) {
 void rt_launch_trace_shadow(const RtParams & p, int bounce, hipStream_t stream) {
 	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8);
 	hipLaunchKernelGGL(kernel_trace_shadow_bvh8, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
+}
+void rt_launch_trace_shadow_ao(const RtParams & p, hipStream_t stream) {
+	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8_ao);
+	hipLaunchKernelGGL(kernel_trace_shadow_bvh8_ao, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p);
 }
 void rt_launch_trace_counting(const RtParams & p, int bounce, unsigned long long * stats, hipStream_t stream) {
 	static int grid = trace_grid_size((const void *)kernel_trace_bvh8_counting);

@@ -858,6 +858,66 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	return RT_OK;
 }
 
+// Ambient-occlusion integrator (AO::render, Integrators/AO.cpp:148-200): generate -> trace ->
+// kernel_ambient_occlusion -> shadow trace (sets RADIANCE) per batch, then accumulate. One sample at
+// a time on slot 0; it shares the queues, the trace kernels and the accumulate kernel of the path tracer.
+int rt_render_ao_sample(rt_context * ctx, int sample_index, float ao_radius) {
+	RT_REQUIRE(ctx, ctx, "rt_render_ao_sample: NULL context");
+	RT_REQUIRE(ctx, ao_radius > 0.0f, "rt_render_ao_sample: ao_radius must be positive");
+	(void)hipSetDevice(ctx->device);
+	const RtParams & base = ctx->params;
+	if (!base.triangles || !base.bvh8_nodes)   return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: geometry not uploaded");
+	if (!base.mesh_bvh_root_indices)           return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: instances not uploaded");
+	if (!base.pmj_samples || !base.blue_noise) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: RNG tables not uploaded");
+	if (ctx->frame_pixels == 0)                return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: rt_resize was not called");
+	if (base.tile_pixels > 0)                  return fail(ctx, RT_ERROR_INVALID_ARG, "rt_render_ao_sample: tile mode is not supported, use rt_set_pixel_range");
+
+	int frame_pixels = base.screen_width * base.screen_height;
+	int range_offset = ctx->pixel_offset;
+	int range_count  = ctx->pixel_count < 0 ? frame_pixels - range_offset : ctx->pixel_count;
+	if (range_offset + range_count > frame_pixels) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_ao_sample: pixel range [%d,%d) exceeds the %d pixel frame", range_offset, range_offset + range_count, frame_pixels);
+
+	int s = ensure_slot(ctx, 0); if (s) return s;
+	int batch_limit = int(wanted_batch_size(ctx));
+	int batch_size  = range_count < batch_limit ? range_count : batch_limit;
+	s = ensure_queues(ctx, 0, size_t(batch_size > 0 ? batch_size : 1)); if (s) return s;
+	SampleSlot & slot = ctx->slots[0];
+	RtParams p = slot_params(ctx, slot, 0);
+	p.batch_samples = 1;
+	p.config.enable_svgf = 0; // the AO integrator has no SVGF path; the TAA jitter of kernel_generate stays off
+
+	hipStream_t st = slot.stream;
+	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
+	for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[k].ev_done, 0));
+
+	RT_HIP(ctx, hipEventRecord(slot.ev_frame_start, st));
+	RT_HIP(ctx, hipMemsetAsync(slot.counter_totals, 0, 6 * RT_MAX_BOUNCES * sizeof(int), st));
+	int pixels_left = range_count;
+	while (pixels_left > 0) {
+		int pixel_offset = range_offset + (range_count - pixels_left);
+		int pixel_count  = batch_size < pixels_left ? batch_size : pixels_left;
+		RT_HIP(ctx, hipMemsetAsync(slot.sizes, 0, sizeof(RtBufferSizes), st));
+		RT_HIP(ctx, hipMemsetAsync(slot.xcd_counters, 0, RT_MAX_BOUNCES * 2 * 8 * sizeof(int), st));
+		rt_launch_generate(p, sample_index, pixel_offset, pixel_count, st);
+		rt_launch_trace(p, 0, st);
+		rt_launch_ambient_occlusion(p, sample_index, ao_radius, st);
+		rt_launch_trace_shadow_ao(p, st);
+		hipLaunchKernelGGL(kernel_accumulate_counters, dim3(1), dim3(RT_MAX_BOUNCES), 0, st, slot.sizes, slot.counter_totals);
+		pixels_left -= batch_size;
+	}
+	RtParams p_acc = p; // kernel_accumulate of AO.cu:161-183 folds RADIANCE, NORMAL and POSITION only
+	p_acc.aovs[RT_AOV_ALBEDO].framebuffer = nullptr;
+	rt_launch_accumulate(p_acc, float(sample_index), range_offset, range_count, st);
+	for (int i = 0; i < RT_AOV_COUNT; i++) if (p.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(p.aovs[i].framebuffer, 0, ctx->frame_pixels * 16, st));
+	RT_HIP(ctx, hipMemcpyAsync(slot.pinned_counters, slot.counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int), hipMemcpyDeviceToHost, st));
+	RT_HIP(ctx, hipEventRecord(slot.ev_frame_end, st));
+	RT_HIP(ctx, hipEventRecord(slot.ev_done, st));
+	ctx->last_slot = 0;
+	RT_HIP(ctx, hipGetLastError());
+	return RT_OK;
+}
+
 int rt_set_samples_in_flight(rt_context * ctx, int count) {
 	RT_REQUIRE(ctx, ctx && count >= 1 && count <= RT_MAX_SAMPLE_SLOTS, "rt_set_samples_in_flight: count must be 1..8");
 	(void)hipSetDevice(ctx->device);

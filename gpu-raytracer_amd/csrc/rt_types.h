@@ -159,6 +159,8 @@ __device__ __forceinline__ unsigned rt_split_virtual_pixel(const RtParams & p, u
 void rt_launch_generate(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, hipStream_t stream);
 void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream);
 void rt_launch_trace_shadow(const RtParams & p, int bounce, hipStream_t stream);
+void rt_launch_ambient_occlusion(const RtParams & p, int sample_index, float ao_radius, hipStream_t stream);
+void rt_launch_trace_shadow_ao(const RtParams & p, hipStream_t stream);
 void rt_launch_sort(const RtParams & p, int bounce, int sample_index, hipStream_t stream);
 void rt_launch_material(const RtParams & p, int material_slot, int bounce, int sample_index, hipStream_t stream);
 void rt_launch_accumulate(const RtParams & p, float frames_accumulated, int pixel_offset, int pixel_count, hipStream_t stream);

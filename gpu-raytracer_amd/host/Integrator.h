@@ -120,6 +120,9 @@ struct Integrator {
 
 	rt_gpu_config make_device_config() const;
 
+	// queue sizes per bounce and stage times of the last render() (rt_get_counters)
+	rt_counters counters() { require_device(); rt_counters c; check(rt_get_counters(ctx, &c)); return c; }
+
 protected:
 	void check(int status) const; // throws std::runtime_error with rt_last_error on failure
 	void require_device() const;

@@ -39,5 +39,4 @@ struct Pathtracer final : Integrator {
 	void calc_light_power();
 	void calc_light_mesh_weights();
 
-	rt_counters counters() { require_device(); rt_counters c; check(rt_get_counters(ctx, &c)); return c; }
 };

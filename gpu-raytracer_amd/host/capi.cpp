@@ -1,7 +1,9 @@
 // Flat C entry points over the C++ host classes, for ctypes (tests, bench.py) and for
 // host applications written in C. Nothing here touches the GPU directly: the device is
 // reached only through the Pathtracer, i.e. through include/gpu_raytracer_amd.h.
+#include <stdexcept>
 #include "Pathtracer.h"
+#include "AO.h"
 
 #include <cstring>
 #include <string>
@@ -120,34 +122,57 @@ const void * grt_mesh_data_array(void * scene, int mesh_data, const char * name,
 }
 
 // device_ordinal < 0: host-only baking (no GPU needed)
-void * grt_pathtracer_create(void * scene, int width, int height, int device_ordinal) {
+// The handles below are Integrator pointers: the path tracer and the AO integrator share every
+// accessor except the few that only the path tracer has (light tables, render_samples).
+static Integrator * as_integrator(void * handle) { return (Integrator *)handle; }
+static Pathtracer * as_pathtracer(void * handle) {
+	Pathtracer * p = dynamic_cast<Pathtracer *>((Integrator *)handle);
+	if (!p) throw std::runtime_error("this call needs a Pathtracer handle");
+	return p;
+}
+
+void * grt_ao_create(void * scene, int width, int height, int device_ordinal) {
 	GRT_TRY
-		return new Pathtracer(width, height, *(Scene *)scene, device_ordinal);
+		return static_cast<Integrator *>(new AO(width, height, *(Scene *)scene, device_ordinal));
 	GRT_CATCH(nullptr)
 }
-void grt_pathtracer_free(void * pt) { delete (Pathtracer *)pt; }
+int grt_ao_set_radius(void * ao, float radius) {
+	GRT_TRY
+		AO * a = dynamic_cast<AO *>(as_integrator(ao));
+		if (!a) throw std::runtime_error("grt_ao_set_radius needs an AO handle");
+		a->ao_radius = radius;
+		return 0;
+	GRT_CATCH(-1)
+}
+
+void * grt_pathtracer_create(void * scene, int width, int height, int device_ordinal) {
+	GRT_TRY
+		return static_cast<Integrator *>(new Pathtracer(width, height, *(Scene *)scene, device_ordinal));
+	GRT_CATCH(nullptr)
+}
+void grt_pathtracer_free(void * pt) { delete as_integrator(pt); }
 
 int grt_pathtracer_update(void * pt, float delta) {
 	GRT_TRY
-		((Pathtracer *)pt)->update(delta);
+		as_integrator(pt)->update(delta);
 		return 0;
 	GRT_CATCH(-1)
 }
 int grt_pathtracer_render(void * pt) {
 	GRT_TRY
-		((Pathtracer *)pt)->render();
+		as_integrator(pt)->render();
 		return 0;
 	GRT_CATCH(-1)
 }
 int grt_pathtracer_render_samples(void * pt, int count) {
 	GRT_TRY
-		((Pathtracer *)pt)->render_samples(count);
+		as_pathtracer(pt)->render_samples(count);
 		return 0;
 	GRT_CATCH(-1)
 }
 int grt_pathtracer_resize(void * pt, int width, int height) {
 	GRT_TRY
-		Pathtracer * p = (Pathtracer *)pt;
+		Integrator * p = as_integrator(pt);
 		p->resize_free();
 		p->resize_init(width, height);
 		return 0;
@@ -155,14 +180,14 @@ int grt_pathtracer_resize(void * pt, int width, int height) {
 }
 int grt_pathtracer_set_pixel_range(void * pt, int offset, int count) {
 	GRT_TRY
-		((Pathtracer *)pt)->set_pixel_range(offset, count);
+		as_integrator(pt)->set_pixel_range(offset, count);
 		return 0;
 	GRT_CATCH(-1)
 }
-int  grt_pathtracer_sample_index(void * pt) { return ((Pathtracer *)pt)->sample_index; }
-int  grt_pathtracer_screen_pitch(void * pt) { return ((Pathtracer *)pt)->screen_pitch; }
+int  grt_pathtracer_sample_index(void * pt) { return as_integrator(pt)->sample_index; }
+int  grt_pathtracer_screen_pitch(void * pt) { return as_integrator(pt)->screen_pitch; }
 void grt_pathtracer_invalidate(void * pt, const char * what) {
-	Pathtracer * p = (Pathtracer *)pt;
+	Integrator * p = as_integrator(pt);
 	std::string w(what);
 	if (w == "scene")      p->invalidated_scene = true;
 	if (w == "sky")        p->invalidated_sky = true;
@@ -173,21 +198,21 @@ void grt_pathtracer_invalidate(void * pt, const char * what) {
 	if (w == "aovs")       p->invalidated_aovs = true;
 }
 void grt_pathtracer_aov_enable(void * pt, int aov, int enable) {
-	if (enable) ((Pathtracer *)pt)->aov_enable(AOVType(aov)); else ((Pathtracer *)pt)->aov_disable(AOVType(aov));
+	if (enable) as_integrator(pt)->aov_enable(AOVType(aov)); else as_integrator(pt)->aov_disable(AOVType(aov));
 }
-void * grt_pathtracer_context(void * pt) { return ((Pathtracer *)pt)->ctx; }
-float  grt_pathtracer_lights_total_weight(void * pt) { return ((Pathtracer *)pt)->lights_total_weight; }
+void * grt_pathtracer_context(void * pt) { return as_integrator(pt)->ctx; }
+float  grt_pathtracer_lights_total_weight(void * pt) { { Pathtracer * p = dynamic_cast<Pathtracer *>(as_integrator(pt)); return p ? p->lights_total_weight : 0.0f; } }
 
 int grt_pathtracer_read_aov(void * pt, int aov, int accumulated, float * dst) {
 	GRT_TRY
-		std::vector<float> image = ((Pathtracer *)pt)->read_aov(AOVType(aov), accumulated != 0);
+		std::vector<float> image = as_integrator(pt)->read_aov(AOVType(aov), accumulated != 0);
 		memcpy(dst, image.data(), image.size() * sizeof(float));
 		return 0;
 	GRT_CATCH(-1)
 }
 int grt_pathtracer_read_framebuffer(void * pt, float * dst) {
 	GRT_TRY
-		std::vector<float> image = ((Pathtracer *)pt)->read_framebuffer();
+		std::vector<float> image = as_integrator(pt)->read_framebuffer();
 		memcpy(dst, image.data(), image.size() * sizeof(float));
 		return 0;
 	GRT_CATCH(-1)
@@ -195,7 +220,7 @@ int grt_pathtracer_read_framebuffer(void * pt, float * dst) {
 
 // Host staging arrays by name (what the device was / would be given), read-only views.
 const void * grt_pathtracer_array(void * pt, const char * name, size_t * bytes) {
-	Pathtracer * p = (Pathtracer *)pt;
+	Integrator * p = as_integrator(pt);
 	std::string n(name);
 	if (n == "triangles")             RET(p->aggregated_triangles)
 	if (n == "bvh8_nodes")            RET(p->aggregated_bvh_nodes_8)
@@ -214,34 +239,36 @@ const void * grt_pathtracer_array(void * pt, const char * name, size_t * bytes) 
 	if (n == "tlas_raw_nodes")        RET(p->tlas_raw.nodes)
 	if (n == "pmj_samples")           RET(p->pmj_samples)
 	if (n == "blue_noise")            RET(p->blue_noise)
-	if (n == "light_triangle_indices")                RET(p->light_triangle_indices)
-	if (n == "light_triangle_cumulative_probability") RET(p->light_triangle_cumulative_probability)
-	if (n == "light_mesh_cumulative_probability")     RET(p->light_mesh_cumulative_probability)
-	if (n == "light_mesh_triangle_span")              RET(p->light_mesh_triangle_span)
-	if (n == "light_mesh_transform_indices")          RET(p->light_mesh_transform_indices)
+	if (Pathtracer * pt_only = dynamic_cast<Pathtracer *>(p)) {
+		if (n == "light_triangle_indices")                RET(pt_only->light_triangle_indices)
+		if (n == "light_triangle_cumulative_probability") RET(pt_only->light_triangle_cumulative_probability)
+		if (n == "light_mesh_cumulative_probability")     RET(pt_only->light_mesh_cumulative_probability)
+		if (n == "light_mesh_triangle_span")              RET(pt_only->light_mesh_triangle_span)
+		if (n == "light_mesh_transform_indices")          RET(pt_only->light_mesh_transform_indices)
+		if (n == "svgf_matrices")         RET(pt_only->svgf_matrices)
+	}
 	if (n == "sky")                   RET(p->scene.sky.data)
-	if (n == "svgf_matrices")         RET(p->svgf_matrices)
 	if (n == "camera") { *bytes = sizeof(rt_camera); return &p->device_camera; }
 	*bytes = 0;
 	return nullptr;
 #undef RET
 }
 void grt_pathtracer_sky_size(void * pt, int * w, int * h, float * scale) {
-	Pathtracer * p = (Pathtracer *)pt;
+	Integrator * p = as_integrator(pt);
 	*w = p->scene.sky.width; *h = p->scene.sky.height; *scale = p->scene.sky.scale;
 }
 // Texture table views
 int grt_pathtracer_texture(void * pt, int index, const unsigned char ** texels, int * width, int * height, int * mip_levels) {
-	Pathtracer * p = (Pathtracer *)pt;
+	Integrator * p = as_integrator(pt);
 	const std::vector<Texture> & t = p->scene.asset_manager.textures;
 	if (index < 0 || index >= int(t.size())) return -1;
 	*texels = t[index].texels.data(); *width = t[index].width; *height = t[index].height; *mip_levels = t[index].mip_levels();
 	return 0;
 }
-void grt_pathtracer_device_config(void * pt, rt_gpu_config * out) { *out = ((Pathtracer *)pt)->make_device_config(); }
+void grt_pathtracer_device_config(void * pt, rt_gpu_config * out) { *out = as_integrator(pt)->make_device_config(); }
 int  grt_pathtracer_counters(void * pt, rt_counters * out) {
 	GRT_TRY
-		*out = ((Pathtracer *)pt)->counters();
+		*out = as_integrator(pt)->counters();
 		return 0;
 	GRT_CATCH(-1)
 }

@@ -224,6 +224,11 @@ int rt_render_sample(rt_context * ctx, int sample_index);
  * bit-identical to count calls of rt_render_sample (tests/test_gpu_parity.py). Not for SVGF.
  * rt_get_counters reports the batch totals.                                               */
 int rt_render_samples(rt_context * ctx, int sample_index, int sample_count);
+/* The reference's second integrator, AO::render (Integrators/AO.cpp:148-200, CUDA/AO.cu):
+ * primary hit -> one cosine-weighted occlusion ray of length ao_radius -> RADIANCE = 1 where it
+ * escapes, NORMAL / POSITION AOVs; needs geometry, instances, RNG tables, rt_resize, rt_set_camera
+ * (materials, lights and sky are not used). One sample per call for the context's pixel range. */
+int rt_render_ao_sample(rt_context * ctx, int sample_index, float ao_radius);
 int rt_synchronize(rt_context * ctx);
 /* Per-stage HIP-event timing (ms_generate..ms_post of rt_counters) costs ~2 events per
  * kernel launch, so it is opt-in; ms_total is always measured. Replaces the CUDAEventPool

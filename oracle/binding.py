@@ -100,6 +100,7 @@ def lib():
         l.oracle_generate.argtypes = [POINTER(OracleScene), c_int, c_int, c_int] + [c_void_p] * 7
         l.oracle_random.argtypes = [POINTER(OracleScene), c_int, c_void_p, c_size_t, c_uint32, c_uint32, c_void_p]
         l.oracle_render_sample.argtypes = [POINTER(OracleScene), POINTER(OracleFrame), c_int, c_int, c_int, POINTER(OracleCounters), c_int]
+        l.oracle_render_ao_sample.argtypes = [POINTER(OracleScene), POINTER(OracleFrame), c_int, c_float, c_int, c_int, POINTER(OracleCounters), c_int]
         l.oracle_integrate_dielectric_cells.argtypes = [POINTER(OracleScene), c_int, c_int, c_int, c_int, c_void_p, c_int]
         l.oracle_integrate_conductor_cells.argtypes = [POINTER(OracleScene), c_int, c_int, c_int, c_void_p, c_int]
         l.oracle_average_dielectric.argtypes = [c_void_p, c_void_p]
@@ -282,6 +283,15 @@ class Frame:
             pixel_count = s.screen_width * s.screen_height - pixel_offset
         counters = OracleCounters()
         lib().oracle_render_sample(byref(s), byref(self.f), sample_index, pixel_offset, pixel_count, byref(counters), threads)
+        return counters
+
+    def render_ao_sample(self, sample_index, ao_radius=1.0, pixel_offset=0, pixel_count=None, threads=0):
+        """AO::render (Integrators/AO.cpp:148-200) for one sample."""
+        s = self.view.scene
+        if pixel_count is None:
+            pixel_count = s.screen_width * s.screen_height - pixel_offset
+        counters = OracleCounters()
+        lib().oracle_render_ao_sample(byref(s), byref(self.f), sample_index, float(ao_radius), pixel_offset, pixel_count, byref(counters), threads)
         return counters
 
     def accumulator(self, aov):

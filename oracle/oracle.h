@@ -140,6 +140,10 @@ void oracle_random(const oracle_scene * scene, int dimension, const uint32_t * p
  * (Pathtracer.cpp:738-855): batches, bounces, accumulate or SVGF/TAA. */
 void oracle_render_sample(const oracle_scene * scene, oracle_frame * frame, int sample_index,
                           int pixel_offset, int pixel_count, oracle_counters * counters, int threads);
+/* AO::render for one sample (Integrators/AO.cpp:148-200, CUDA/AO.cu): primary hit -> one cosine-
+ * weighted occlusion ray of length ao_radius -> RADIANCE = 1 where it escapes; NORMAL / POSITION AOVs. */
+void oracle_render_ao_sample(const oracle_scene * scene, oracle_frame * frame, int sample_index, float ao_radius,
+                             int pixel_offset, int pixel_count, oracle_counters * counters, int threads);
 /* Kulla-Conty LUT integration kernels (KullaConty.h:83-240); num_samples = 100000 in the reference. */
 /* kernel_integrate_dielectric / kernel_integrate_conductor (KullaConty.h:83-148,179-226) for the
  * LUT cells [first_cell, first_cell + cell_count) (thread_index of the CUDA kernel); num_samples

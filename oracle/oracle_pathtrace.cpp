@@ -894,6 +894,108 @@ void oracle_random(const oracle_scene * scene, int dimension, const uint32_t * p
 	}
 }
 
+// Ambient-occlusion integrator: AO::render (Integrators/AO.cpp:148-200) with the kernels of
+// CUDA/AO.cu -- generate (:48-63), trace, kernel_ambient_occlusion (:103-159), shadow trace whose
+// miss lambda sets RADIANCE to 1 (:77-101), kernel_accumulate (:161-183: RADIANCE, NORMAL, POSITION).
+void oracle_render_ao_sample(const oracle_scene * scene, oracle_frame * frame, int sample_index, float ao_radius,
+                             int range_offset, int range_count, oracle_counters * counters, int threads) {
+	const oracle_scene & s = *scene;
+	if (threads <= 0) threads = omp_get_max_threads();
+	Context c(s, *frame);
+	oracle_counters local; memset(&local, 0, sizeof(local));
+
+	int pixels_left = range_count;
+	int batch_size  = range_count < RT_BATCH_SIZE ? range_count : RT_BATCH_SIZE;
+	while (pixels_left > 0) {
+		int pixel_offset = range_offset + (range_count - pixels_left);
+		int pixel_count  = batch_size < pixels_left ? batch_size : pixels_left;
+
+		std::vector<TraceRay> rays;
+		rays.resize(size_t(pixel_count));
+		for (int index = 0; index < pixel_count; index++) { // kernel_generate
+			int index_offset = index + pixel_offset;
+			int x = index_offset % s.screen_width, y = index_offset / s.screen_width;
+			int pixel_index = x + y * s.screen_pitch;
+			camera_generate_ray(c, pixel_index, sample_index, x, y, rays[index].origin, rays[index].direction);
+			rays[index].pixel_index_and_flags = unsigned(pixel_index);
+		}
+		local.trace[0] += pixel_count;
+
+		#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
+		for (long long i = 0; i < (long long)rays.size(); i++) oracle_trace_one(s, rays[i].origin, rays[i].direction, rays[i].hit, nullptr);
+
+		std::vector<ShadowRay> shadow;
+		for (const TraceRay & r : rays) { // kernel_ambient_occlusion
+			RayHit hit = unpack_hit(r.hit);
+			int pixel_index = int(r.pixel_index_and_flags);
+			if (hit.triangle_id == RT_INVALID) continue;
+
+			TrianglePosNorTex tri = triangle_get(s, hit.triangle_id);
+			float3 geometric_normal = normalize(cross(tri.position_edge_1, tri.position_edge_2)); // object space, as in AO.cu:123
+			float3 hit_point  = barycentric(hit.u, hit.v, tri.position_0, tri.position_edge_1, tri.position_edge_2);
+			float3 hit_normal = barycentric(hit.u, hit.v, tri.normal_0,   tri.normal_edge_1,   tri.normal_edge_2);
+
+			const float * world = mesh_transform(s, hit.mesh_id);
+			hit_point  = m_position (world, hit_point);
+			hit_normal = normalize(m_direction(world, hit_normal));
+			if (dot(r.direction, hit_normal) > 0.0f) hit_normal = -hit_normal;
+
+			c.aov_set(RT_AOV_NORMAL,   pixel_index, make_float4(hit_normal));
+			c.aov_set(RT_AOV_POSITION, pixel_index, make_float4(hit_point));
+
+			float3 tangent, bitangent;
+			orthonormal_basis(hit_normal, tangent, bitangent);
+			float2 rand_brdf = c.random(DIM_BSDF_0, pixel_index, 0, sample_index);
+			float3 omega_o = sample_cosine_weighted_direction(rand_brdf.x, rand_brdf.y);
+			float3 direction_out = local_to_world(omega_o, tangent, bitangent, hit_normal);
+			float pdf = omega_o.z * O_ONE_OVER_PI;
+			if (!pdf_is_valid(pdf)) continue;
+
+			ShadowRay sr;
+			sr.origin = ray_origin_epsilon_offset(hit_point, direction_out, geometric_normal);
+			sr.direction = direction_out;
+			sr.max_distance = ao_radius;
+			sr.illumination = make_float3(1.0f);
+			sr.pixel_index = pixel_index;
+			shadow.push_back(sr);
+		}
+		local.shadow[0] += int(shadow.size());
+
+		std::vector<unsigned char> occluded(shadow.size());
+		#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
+		for (long long i = 0; i < (long long)shadow.size(); i++) occluded[i] = oracle_trace_shadow_one(s, shadow[i].origin, shadow[i].direction, shadow[i].max_distance, nullptr);
+		for (size_t i = 0; i < shadow.size(); i++) if (!occluded[i]) c.aov_set(RT_AOV_RADIANCE, shadow[i].pixel_index, make_float4(1.0f));
+
+		pixels_left -= batch_size;
+	}
+
+	for (int i = 0; i < range_count; i++) { // kernel_accumulate of AO.cu: no ALBEDO
+		int idx = i + range_offset;
+		int x = idx % s.screen_width, y = idx / s.screen_width;
+		int pixel_index = x + y * s.screen_pitch;
+		float frames_accumulated = float(sample_index);
+		auto accumulate = [&](int aov) -> float4 {
+			if (!c.f.framebuffer[aov]) return make_float4(0.0f);
+			float * fb = c.f.framebuffer[aov] + size_t(pixel_index) * 4;
+			float * acc = c.f.accumulator[aov] + size_t(pixel_index) * 4;
+			for (int k = 0; k < 4; k++) {
+				if (frames_accumulated > 0.0f) acc[k] += (fb[k] - acc[k]) / frames_accumulated;
+				else                           acc[k] = fb[k];
+			}
+			return make_float4(acc[0], acc[1], acc[2], acc[3]);
+		};
+		float4 colour = accumulate(RT_AOV_RADIANCE);
+		accumulate(RT_AOV_NORMAL);
+		accumulate(RT_AOV_POSITION);
+		if (!std::isfinite(colour.x + colour.y + colour.z)) colour = make_float4(1000.0f, 0.0f, 1000.0f, 1.0f);
+		float * out = c.f.final_image + size_t(pixel_index) * 4;
+		out[0] = colour.x; out[1] = colour.y; out[2] = colour.z; out[3] = colour.w;
+	}
+	// aovs_clear_to_zero (AO.cpp:193)
+	for (int i = 0; i < RT_AOV_COUNT; i++) if (c.f.framebuffer[i]) memset(c.f.framebuffer[i], 0, size_t(s.screen_pitch) * s.screen_height * 16);
+	if (counters) *counters = local;
+}
+
 void oracle_render_sample(const oracle_scene * scene, oracle_frame * frame, int sample_index,
                           int range_offset, int range_count, oracle_counters * counters, int threads) {
 	const oracle_scene & s = *scene;

@@ -209,6 +209,35 @@ def test_sponza_texture_path_albedo_normal_position_aovs(grt, oracle):
     pt.close(); scene.close()
 
 
+@pytest.mark.parametrize("scene_name,w,h,radius", [("cornellbox", 160, 120, 0.5), ("sponza", 320, 180, 2.0)])
+def test_ambient_occlusion_integrator_matches_oracle(grt, oracle, scene_name, w, h, radius):
+    """The reference's second integrator (AO.cpp / AO.cu) through the host class AO and
+    rt_render_ao_sample: 3 progressive samples. Occlusion is binary per sample, so pixels are either
+    equal to ~1e-7 or differ by a multiple of 1/n; the occlusion-ray count must agree within the queue
+    tolerance and all but 0.1 % of the pixels must agree."""
+    grt.config_reset()
+    scene = grt.Scene(grt.scene_path(scene_name))
+    ao = grt.AO(scene, w, h, device=0, radius=radius)
+    ao.aov_enable(grt.AOV_NORMAL); ao.aov_enable(grt.AOV_POSITION)
+    ao.update()
+    view = oracle.SceneView(ao); frame = oracle.Frame(view)
+    for f in range(3):
+        if f:
+            ao.update()
+        ao.render()
+        c = ao.counters()
+        oc = frame.render_ao_sample(ao.sample_index, radius)
+        assert c.trace[0] == oc.trace[0] == w * h
+        assert abs(c.shadow[0] - oc.shadow[0]) <= 2 + 0.002 * oc.shadow[0]
+    got, want = ao.read_framebuffer()[:, :w, :3], frame.final[:, :w, :3]
+    assert got.min() >= 0.0 and got.max() <= 1.0 + 1e-6 and 0.05 < want.mean() < 0.999   # partly occluded
+    assert (np.abs(got - want).max(axis=2) > 1e-5).mean() < 1e-3
+    for aov, tol in ((grt.AOV_NORMAL, 1e-4), (grt.AOV_POSITION, 1e-3)):
+        g, o = ao.read_aov(aov)[:, :w, :3], frame.accumulator(aov)[:, :w, :3]
+        assert (np.abs(g - o).max(axis=2) > tol * (1.0 + np.abs(o).max(axis=2))).mean() < 1e-3, aov
+    ao.close(); scene.close()
+
+
 def test_feature_toggles_match_oracle(grt, oracle):
     for cfg in (dict(enable_next_event_estimation=0), dict(enable_multiple_importance_sampling=0), dict(enable_russian_roulette=0), dict(reconstruction_filter=1, enable_mipmapping=0)):
         scene, pt = make_pathtracer(grt, "cornellbox", 96, 64, 0, num_bounces=5, **cfg)

@@ -172,3 +172,31 @@ def test_accumulation_quirk_divides_by_sample_index(grt, oracle):
     b = oracle.Frame(view); b.render_sample(1)
     assert np.allclose(a.final, b.final, rtol=1e-5, atol=2e-5)  # acc + (fb - acc) / 1 rounds at the scale of the overwritten sample
     pt.close(); scene.close()
+
+
+def test_oracle_ambient_occlusion_properties(grt, oracle):
+    """AO integrator restatement (AO.cu): occlusion is 0/1 per sample; an occlusion ray of
+    (almost) zero length always escapes, so every pixel that hits geometry gets exactly 1 and
+    every other pixel 0; longer rays can only be occluded more often."""
+    grt.config_reset()
+    scene = grt.Scene(grt.scene_path("cornellbox"))
+    ao = grt.AO(scene, 48, 36, device=-1)
+    ao.update()
+    view = oracle.SceneView(ao)
+    means = []
+    for radius in (1e-4, 0.25, 1.0, 100.0):
+        frame = oracle.Frame(view)
+        c = frame.render_ao_sample(0, radius)
+        img = frame.final[:, :48, 0]
+        assert set(np.unique(img)).issubset({0.0, 1.0}) and c.trace[0] == 48 * 36 and c.shadow[0] <= c.trace[0]
+        if radius == 1e-4:
+            assert int(img.sum()) == c.shadow[0]
+        means.append(float(img.mean()))
+    assert means[0] >= means[1] >= means[2] >= means[3] and means[3] < means[0]
+    # three samples average to multiples of 1/3 (frame 1 overwrites frame 0: AOV.h:35-46 divides by sample_index)
+    frame = oracle.Frame(view)
+    for s in range(4):
+        frame.render_ao_sample(s, 0.5)
+    vals = np.unique(np.round(frame.final[:, :48, 0] * 3.0, 4))
+    assert set(vals).issubset({0.0, 1.0, 2.0, 3.0})
+    ao.close(); scene.close()
