@@ -347,6 +347,13 @@ def test_sample_batches_equal_single_samples(grt):
         pt.close(); scene.close()
     assert np.array_equal(images[0], images[1]) and np.array_equal(images[0], images[2])
     assert np.array_equal(rays[0], rays[1]) and np.array_equal(rays[0], rays[2]) and rays[0][0] == 6 * 320 * 240
+    # sample batches x pixel batches (rt_set_batch_size): queue capacity is pixels-per-batch x samples
+    scene, pt = make_pathtracer(grt, "cornellbox", 320, 240, 0, num_bounces=5)
+    lib.rt_set_batch_size.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert lib.rt_set_batch_size(pt.ctx, 5000) == 0
+    assert lib.rt_render_samples(pt.ctx, 0, 4) == 0 and lib.rt_render_samples(pt.ctx, 4, 2) == 0
+    assert np.array_equal(pt.read_framebuffer(), images[0])
+    pt.close(); scene.close()
     # the host class: render_samples(6) == 6 x (update, render), and the progression continues after it
     scene, pt = make_pathtracer(grt, "cornellbox", 320, 240, 0, num_bounces=5)
     pt.render_samples(6)
