@@ -37,6 +37,13 @@ struct SampleSlot {
 	RtBufferSizes * pinned_counters = nullptr;
 	void * aov_framebuffer[RT_AOV_COUNT] = { };  // slots 1..: per-sample frame buffers (slot 0 uses ctx->aov_buffers[i][0])
 	int aov_samples = 1;                         // samples per batch the frame buffers of this slot are sized for
+	// SVGF g-buffers (normal+depth, mesh+triangle id, previous screen position) are written by the
+	// bounce-0 kernels of a frame and read by its filter stage: one set per slot lets frame n+1 be
+	// traced while frame n is filtered. Pixels that miss all geometry keep the value of the last
+	// frame that hit something (the reference never clears them), so a frame starts from a copy of
+	// its predecessor's set, taken as soon as that frame's bounce-0 shading is done (ev_gbuffers).
+	void * gbuffers[3] = { };                    // slots 1..; slot 0 uses ctx->svgf_buffers[0..2]
+	hipEvent_t ev_gbuffers = nullptr;
 };
 
 struct rt_context {
@@ -151,7 +158,9 @@ static int ensure_slot(rt_context * ctx, int index) {
 	RT_HIP(ctx, hipEventCreateWithFlags(&slot.ev_done,     hipEventDisableTiming));
 	RT_HIP(ctx, hipEventCreate(&slot.ev_frame_start));
 	RT_HIP(ctx, hipEventCreate(&slot.ev_frame_end));
+	RT_HIP(ctx, hipEventCreateWithFlags(&slot.ev_gbuffers, hipEventDisableTiming));
 	RT_HIP(ctx, hipEventRecord(slot.ev_done, slot.stream)); // so that waiting on a never-used slot is a no-op
+	RT_HIP(ctx, hipEventRecord(slot.ev_gbuffers, slot.stream));
 	int s = device_alloc(ctx, (void **)&slot.sizes, sizeof(RtBufferSizes)); if (s) return s;
 	s = device_alloc(ctx, (void **)&slot.counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int)); if (s) return s;
 	s = device_alloc(ctx, (void **)&slot.xcd_counters, RT_MAX_BOUNCES * 2 * 8 * sizeof(int)); if (s) return s;
@@ -165,6 +174,13 @@ static int ensure_slot(rt_context * ctx, int index) {
 		s = device_alloc(ctx, &slot.aov_framebuffer[i], bytes); if (s) return s;
 		RT_HIP(ctx, hipMemset(slot.aov_framebuffer[i], 0, bytes));
 	}
+	if (index > 0 && ctx->svgf_allocated) {
+		const size_t elem[3] = { 16, 8, 8 };
+		for (int i = 0; i < 3; i++) {
+			s = device_alloc(ctx, &slot.gbuffers[i], ctx->frame_pixels * elem[i]); if (s) return s;
+			RT_HIP(ctx, hipMemset(slot.gbuffers[i], 0, ctx->frame_pixels * elem[i]));
+		}
+	}
 	slot.created = true;
 	return RT_OK;
 }
@@ -175,6 +191,11 @@ static RtParams slot_params(const rt_context * ctx, const SampleSlot & slot, int
 	memcpy(p.trace, slot.trace, sizeof(p.trace)); memcpy(p.material, slot.material, sizeof(p.material)); p.shadow = slot.shadow;
 	p.sizes = slot.sizes; p.xcd_counters = slot.xcd_counters; p.stack_spill = (uint2 *)slot.spill[0];
 	if (index > 0) for (int i = 0; i < RT_AOV_COUNT; i++) p.aovs[i].framebuffer = (float4 *)slot.aov_framebuffer[i];
+	if (index > 0 && slot.gbuffers[0]) {
+		p.gbuffer_normal_and_depth        = (float4 *)slot.gbuffers[0];
+		p.gbuffer_mesh_id_and_triangle_id = (int2   *)slot.gbuffers[1];
+		p.gbuffer_screen_position_prev    = (float2 *)slot.gbuffers[2];
+	}
 	return p;
 }
 
@@ -227,7 +248,7 @@ void rt_destroy(rt_context * ctx) {
 	for (hipEvent_t e : ctx->span_events) (void)hipEventDestroy(e);
 	for (SampleSlot & slot : ctx->slots) if (slot.stream) {
 		if (slot.pinned_counters) (void)hipHostFree(slot.pinned_counters);
-		for (hipEvent_t e : { slot.ev_shaded, slot.ev_shadowed, slot.ev_done, slot.ev_frame_start, slot.ev_frame_end }) if (e) (void)hipEventDestroy(e);
+		for (hipEvent_t e : { slot.ev_shaded, slot.ev_shadowed, slot.ev_done, slot.ev_gbuffers, slot.ev_frame_start, slot.ev_frame_end }) if (e) (void)hipEventDestroy(e);
 		(void)hipStreamDestroy(slot.side);
 		(void)hipStreamDestroy(slot.stream);
 	}
@@ -523,9 +544,14 @@ static int sync_svgf(rt_context * ctx) {
 			int s = device_alloc(ctx, &ctx->svgf_buffers[i], ctx->frame_pixels * elem[i]); if (s) return s;
 			RT_HIP(ctx, hipMemsetAsync(ctx->svgf_buffers[i], 0, ctx->frame_pixels * elem[i], ctx->stream));
 		}
+		for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) for (int i = 0; i < 3; i++) {
+			int s = device_alloc(ctx, &ctx->slots[k].gbuffers[i], ctx->frame_pixels * elem[i]); if (s) return s;
+			RT_HIP(ctx, hipMemsetAsync(ctx->slots[k].gbuffers[i], 0, ctx->frame_pixels * elem[i], ctx->stream));
+		}
 	} else {
 		RT_HIP(ctx, quiesce(ctx));
 		for (int i = 0; i < 12; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
+		for (SampleSlot & slot : ctx->slots) for (int i = 0; i < 3; i++) { device_free(ctx, slot.gbuffers[i]); slot.gbuffers[i] = nullptr; }
 	}
 	ctx->svgf_allocated = want;
 	RtParams & p = ctx->params;
@@ -558,6 +584,7 @@ int rt_resize(rt_context * ctx, int width, int height) {
 	ctx->params.frame_pixels = unsigned(ctx->frame_pixels);
 	ctx->params.frame_pixels_magic = unsigned((1ull << 32) / ctx->frame_pixels) + 1u;
 	for (int i = 0; i < 12; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
+	for (SampleSlot & slot : ctx->slots) for (int i = 0; i < 3; i++) { device_free(ctx, slot.gbuffers[i]); slot.gbuffers[i] = nullptr; }
 	ctx->svgf_allocated = false;
 	device_free(ctx, ctx->final_image); ctx->final_image = nullptr;
 	int s = device_alloc(ctx, &ctx->final_image, ctx->frame_pixels * 16); if (s) return s;
@@ -741,9 +768,9 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	if (!base.sky)                          return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: sky not set");
 	if (ctx->frame_pixels == 0)          return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: rt_resize was not called");
 	if (ctx->bvh_width != 8)             return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: unsupported BVH type");
-	// Slot choice: round-robin over the samples in flight. Profiling / statistics passes and SVGF
-	// frames (whose history makes frame n+1 depend on all of frame n) use one slot, serialised.
-	bool exclusive = ctx->profiling || ctx->trace_statistics || ctx->params.config.enable_svgf;
+	// Slot choice: round-robin over the samples in flight. Profiling / statistics passes use one slot,
+	// serialised. SVGF frames pipeline like plain samples: only their filter stage is ordered.
+	bool exclusive = ctx->profiling || ctx->trace_statistics;
 	int slot_index = exclusive ? 0 : int(ctx->render_counter++ % unsigned(ctx->samples_in_flight));
 	int s = ensure_slot(ctx, slot_index); if (s) return s;
 	if (ctx->has_material[2] || ctx->has_material[3]) { s = ensure_luts(ctx); if (s) return s; }
@@ -783,6 +810,15 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 
 	ctx->stage_used = 0;
 	RT_HIP(ctx, hipEventRecord(slot.ev_frame_start, st));
+	const bool svgf = p.config.enable_svgf != 0;
+	if (svgf && ctx->last_slot >= 0 && ctx->last_slot != slot_index) { // inherit the g-buffers of the previous frame
+		SampleSlot & prev = ctx->slots[ctx->last_slot];
+		void * from[3] = { ctx->last_slot == 0 ? ctx->svgf_buffers[0] : prev.gbuffers[0], ctx->last_slot == 0 ? ctx->svgf_buffers[1] : prev.gbuffers[1], ctx->last_slot == 0 ? ctx->svgf_buffers[2] : prev.gbuffers[2] };
+		void * to[3]   = { p.gbuffer_normal_and_depth, p.gbuffer_mesh_id_and_triangle_id, p.gbuffer_screen_position_prev };
+		const size_t elem[3] = { 16, 8, 8 };
+		RT_HIP(ctx, hipStreamWaitEvent(st, prev.ev_gbuffers, 0));
+		for (int i = 0; i < 3; i++) if (from[i] && to[i] && from[i] != to[i]) RT_HIP(ctx, hipMemcpyAsync(to[i], from[i], ctx->frame_pixels * elem[i], hipMemcpyDeviceToDevice, st));
+	}
 
 	bool trace_shadows = ctx->has_lights && p.config.enable_next_event_estimation && p.lights_total_weight > 0.0f;
 	// Shadow rays of bounce b only feed the frame buffers, so they run on the side stream while the
@@ -815,6 +851,7 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 				rt_launch_sort(p, bounce, sample_index, st);
 				stage_mark(ctx, STAGE_SHADE, st);
 				for (int m = 0; m < 4; m++) if (ctx->has_material[m]) rt_launch_material(p, m, bounce, sample_index, st);
+				if (svgf && bounce == 0 && pixels_left <= batch_size) RT_HIP(ctx, hipEventRecord(slot.ev_gbuffers, st)); // last pixel batch: the g-buffers of this frame are complete
 				if (trace_shadows) {
 					stage_mark(ctx, STAGE_SHADOW, st);
 					if (ctx->trace_statistics) rt_launch_trace_shadow_counting(p, bounce, ctx->trace_stats, st);

@@ -207,8 +207,8 @@ int rt_set_batch_size(rt_context * ctx, int batch_size);
  * launches of one sample strictly one after the other on one stream (Pathtracer.cpp:738-855);
  * here consecutive rt_render_sample calls alternate between `count` sets of queues / streams and
  * only the accumulate step is ordered between them, so a sample's small deep-bounce launches
- * run in the shadow of its neighbour's. Results are identical for every count. SVGF frames and
- * profiled / statistics passes always run one sample at a time. Memory: one set of wavefront
+ * run in the shadow of its neighbour's. Results are identical for every count (SVGF frames
+ * included: only their filter stage is ordered). Profiled / statistics passes run one at a time. Memory: one set of wavefront
  * queues + per-sample frame buffers per sample in flight (~1 GB each at 1920x1080).        */
 int rt_set_samples_in_flight(rt_context * ctx, int count);
 

@@ -106,3 +106,20 @@ def test_svgf_taa_pipeline_matches_oracle(grt, oracle, taa):
     # denoised image is smoother than the raw one-sample radiance
     assert got.std() > 0
     pt.close(); scene.close()
+
+
+def test_svgf_frames_pipeline_without_changing_the_image(grt):
+    """SVGF frames in flight (per-slot g-buffers, the filter stage ordered by events): six frames
+    submitted back to back with 1 and with 3 frames in flight give bit-identical filtered images,
+    also where rays miss all geometry (those pixels keep the g-buffer of the last frame that hit)."""
+    images = []
+    for in_flight in (1, 3):
+        scene, pt = make_pathtracer(grt, "cornellbox", 200, 150, 0, num_bounces=4, enable_svgf=1, enable_taa=1)
+        grt.set_samples_in_flight(pt.ctx, in_flight)
+        for f in range(6):
+            if f:
+                pt.update()
+            pt.render()
+        images.append(pt.read_framebuffer().copy())
+        pt.close(); scene.close()
+    assert np.array_equal(images[0], images[1]) and np.isfinite(images[0]).all() and images[0][..., :3].max() > 0.0
