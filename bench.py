@@ -141,8 +141,9 @@ def main():
     pt.update()
     lib = grt.device_lib()
     ctx = pt.ctx
-    if args.samples_in_flight <= 0:   # measured optimum (profiles/r01_sample_batching.txt): 3 for a whole frame, 4 for a rank's share
-        args.samples_in_flight = 3 if (world == 1 and args.emulate_world <= 1) else 4
+    if args.samples_in_flight <= 0:   # measured optima (profiles/r01_sample_batching.txt): the smaller a rank's share, the more submissions
+        split_n = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
+        args.samples_in_flight = 3 if split_n == 1 else (4 if split_n == 2 else 8)
     grt.set_samples_in_flight(ctx, args.samples_in_flight)
     split_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
     split = parallel.TileSplit(rank, split_world, WIDTH, HEIGHT)
