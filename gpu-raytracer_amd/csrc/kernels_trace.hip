@@ -513,6 +513,159 @@ struct ShadowExplicitSource {
 	RT_DEV void finish(int i, const HitRecord &, bool occluded) const { occluded_out[i] = occluded ? 1 : 0; }
 };
 
+
+// =================================================================================================
+// Binary BVH (BVH2.h:46-244): the reference's `bvh_type = BVH` configuration (BASELINE config #1).
+// Same persistent-wave machinery (block-claimed rays, LDS stack with HBM spill, one node step or one
+// triangle batch per round); a node is 32 B (AABB + left_or_first + count/axis), children are visited
+// near-first by the sign of the ray direction on the split axis. Not the fast path -- it exists so that
+// every BVH type the host can build can also be traced on the device, bit-exactly like the oracle.
+// =================================================================================================
+template<bool SHADOW, typename Source>
+RT_DEV void bvh2_trace_persistent(const RtParams & p, Source & src, int ray_count, int * cursor) {
+	__shared__ uint2 shared_stack[(RT_TRACE_BLOCK / RT_WAVE_SIZE) * RT_LDS_STACK * RT_WAVE_SIZE];
+
+	const float4 * __restrict__ nodes     = p.bvh2_nodes;
+	const float4 * __restrict__ triangles = p.triangle_positions;
+
+	unsigned lane = threadIdx.x & (RT_WAVE_SIZE - 1);
+	unsigned wave = threadIdx.x / RT_WAVE_SIZE;
+
+	TraversalStack stack;
+	stack.lds   = (LdsUint2 *)&shared_stack[wave * (RT_LDS_STACK * RT_WAVE_SIZE) + lane];
+	stack.spill_stride = int(gridDim.x * blockDim.x);
+	stack.spill = (GlobalUint2 *)(p.stack_spill + (blockIdx.x * blockDim.x + threadIdx.x));
+	stack.size  = 0;
+
+	const int waves_in_grid = int(gridDim.x) * (RT_TRACE_BLOCK / RT_WAVE_SIZE);
+	const int ray_block = max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (ray_count / (2 * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
+	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * unsigned(ray_block) >= unsigned(ray_count)) return;
+	__shared__ int shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4];
+	typedef volatile __attribute__((address_space(3))) int LdsFetchWord;
+	LdsFetchWord * fetch_state = (LdsFetchWord *)&shared_fetch[wave][0];
+	if (lane == 0) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[2] = 0; }
+	auto fetch_ray = [&]() -> int { // see bvh8_trace_persistent
+		while (true) {
+			if (fetch_state[2]) return -1;
+			unsigned long long want = __ballot(1);
+			int n_want = __popcll(want);
+			unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(want >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(want), 0u));
+			int next = fetch_state[0], end = fetch_state[1];
+			if (next >= end) {
+				int base = 0;
+				if (rank == 0) base = atomicAdd(cursor, ray_block);
+				base = __builtin_amdgcn_readfirstlane(base);
+				next = min(base, ray_count);
+				end  = min(base + ray_block, ray_count);
+			}
+			int give = min(n_want, end - next);
+			if (rank == 0) {
+				fetch_state[0] = next + give;
+				fetch_state[1] = end;
+				if (next >= end) fetch_state[2] = 1;
+			}
+			if (int(rank) < give) return next + int(rank);
+		}
+	};
+
+	int  ray_index = 0;
+	Ray3 ray;
+	f3   inv_dir;
+	float max_distance = 0.0f;
+	HitRecord hit;
+	int  tlas_stack_size = RT_INVALID;
+	int  mesh_id = 0;
+	bool mesh_has_identity_transform = true;
+	int  tri_next = 0, tri_end = 0; // triangles of the current leaf still to be tested
+
+	while (true) {
+		bool inactive = stack.size == 0 && tri_next >= tri_end;
+		if (inactive) {
+			ray_index = fetch_ray();
+			if (ray_index < 0) return;
+			src.load(ray_index, ray, max_distance);
+			inv_dir = reciprocal(ray.direction);
+			hit.t = RT_INFINITY; hit.u = 0.0f; hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
+			tlas_stack_size = RT_INVALID;
+			stack.push(make_uint2(0, 0)); // root of the TLAS
+		}
+
+		int iterations_lost = 0;
+		do {
+			bool occluded = false;
+			if (tri_next < tri_end) {
+				#pragma unroll
+				for (int k = 0; k < RT_TRI_BATCH; k++) {
+					if (tri_next < tri_end && !occluded) {
+						const float4 * tri = triangles + size_t(tri_next) * 3;
+						if (triangle_test_loaded<SHADOW>(tri[0], tri[1], make_float4(tri[2].x, 0.0f, 0.0f, 0.0f), mesh_id, tri_next, ray, max_distance, hit)) occluded = true;
+						tri_next++;
+					}
+				}
+			} else {
+				if (stack.size == tlas_stack_size) { // left the BLAS: back to the world-space ray
+					tlas_stack_size = RT_INVALID;
+					if (!mesh_has_identity_transform) {
+						float unused;
+						src.load(ray_index, ray, unused);
+						inv_dir = reciprocal(ray.direction);
+					}
+				}
+				unsigned node_index = stack.pop().x;
+				float4 a = nodes[size_t(node_index) * 2], b = nodes[size_t(node_index) * 2 + 1];
+				int      left_or_first = __float_as_int(b.z);
+				unsigned count_axis    = __float_as_uint(b.w);
+				unsigned count = count_axis & 0x3fffffffu, axis = count_axis >> 30;
+
+				// AABB::intersects (BVH2.h:8-16) with t = (plane - origin) * inv_dir
+				float t0x = (a.x - ray.origin.x) * inv_dir.x, t1x = (a.w - ray.origin.x) * inv_dir.x;
+				float t0y = (a.y - ray.origin.y) * inv_dir.y, t1y = (b.x - ray.origin.y) * inv_dir.y;
+				float t0z = (a.z - ray.origin.z) * inv_dir.z, t1z = (b.y - ray.origin.z) * inv_dir.z;
+				float t_near = fmaxf(fminf(t0x, t1x), fmaxf(fminf(t0y, t1y), fmaxf(fminf(t0z, t1z), 0.0f)));
+				float t_far  = fminf(fmaxf(t0x, t1x), fminf(fmaxf(t0y, t1y), fminf(fmaxf(t0z, t1z), SHADOW ? max_distance : hit.t)));
+
+				if (t_near < t_far) {
+					if (count > 0) {
+						if (tlas_stack_size == RT_INVALID) { // TLAS leaf: enter the instance
+							tlas_stack_size = stack.size;
+							mesh_id = left_or_first;
+							unsigned root = unsigned(p.mesh_bvh_root_indices[mesh_id]);
+							mesh_has_identity_transform = (root >> 31) != 0;
+							if (!mesh_has_identity_transform) {
+								const float4 * m = p.mesh_transforms_inv + size_t(mesh_id) * 3;
+								ray.origin    = transform_position (m, ray.origin);
+								ray.direction = transform_direction(m, ray.direction);
+								inv_dir = reciprocal(ray.direction);
+							}
+							stack.push(make_uint2(root & 0x7fffffffu, 0));
+						} else {
+							tri_next = left_or_first; tri_end = left_or_first + int(count);
+						}
+					} else {
+						float d = axis == 0 ? ray.direction.x : (axis == 1 ? ray.direction.y : ray.direction.z);
+						bool left_first = d > 0.0f;
+						unsigned first  = unsigned(left_first ? left_or_first     : left_or_first + 1);
+						unsigned second = unsigned(left_first ? left_or_first + 1 : left_or_first);
+						stack.push(make_uint2(second, 0));
+						stack.push(make_uint2(first, 0));
+					}
+				}
+			}
+
+			if (SHADOW && occluded) {
+				src.finish(ray_index, hit, true);
+				stack.size = 0; tri_next = tri_end = 0;
+				break;
+			}
+			if (stack.size == 0 && tri_next >= tri_end) {
+				src.finish(ray_index, hit, false);
+				break;
+			}
+			iterations_lost += RT_WAVE_SIZE - __popcll(__ballot(1)) - RT_N_D;
+		} while (iterations_lost < RT_N_W);
+	}
+}
+
 // ---- kernels ---------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh8(RtParams p, int bounce) {
@@ -523,6 +676,27 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh8(RtParams p, int bounce) {
 	ShadowQueueSource src { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT], bounce };
 	RT_TRACE_ENGINE<true, false>(p, src, p.sizes->shadow[bounce], p.xcd_counters + (2 * bounce + 1) * RT_NUM_XCD);
+}
+
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh2(RtParams p, int bounce) {
+	ClosestHitSource src { p.trace[bounce & 1].origin, p.trace[bounce & 1].direction, p.trace[bounce & 1].hits };
+	bvh2_trace_persistent<false>(p, src, p.sizes->trace[bounce], p.xcd_counters + (2 * bounce) * RT_NUM_XCD);
+}
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh2(RtParams p, int bounce) {
+	ShadowQueueSource src { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT], bounce };
+	bvh2_trace_persistent<true>(p, src, p.sizes->shadow[bounce], p.xcd_counters + (2 * bounce + 1) * RT_NUM_XCD);
+}
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh2_ao(RtParams p) {
+	ShadowAOSource src { p.shadow, p.aovs[RT_AOV_RADIANCE] };
+	bvh2_trace_persistent<true>(p, src, p.sizes->shadow[0], p.xcd_counters + RT_NUM_XCD);
+}
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh2_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {
+	ClosestHitSource src { origin, direction, hits };
+	bvh2_trace_persistent<false>(p, src, ray_count, retired);
+}
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh2_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, const float * max_distance, uint8_t * occluded, int ray_count, int * retired) {
+	ShadowExplicitSource src { origin, direction, max_distance, occluded };
+	bvh2_trace_persistent<true>(p, src, ray_count, retired);
 }
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh8_ao(RtParams p) {
@@ -572,14 +746,29 @@ static int trace_grid_size(const void * kernel) {
 }
 
 void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream) {
+	if (p.bvh_width == 2) {
+		static int grid2 = trace_grid_size((const void *)kernel_trace_bvh2);
+		hipLaunchKernelGGL(kernel_trace_bvh2, dim3(grid2), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
+		return;
+	}
 	static int grid = trace_grid_size((const void *)kernel_trace_bvh8);
 	hipLaunchKernelGGL(kernel_trace_bvh8, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
 }
 void rt_launch_trace_shadow(const RtParams & p, int bounce, hipStream_t stream) {
+	if (p.bvh_width == 2) {
+		static int grid2 = trace_grid_size((const void *)kernel_trace_shadow_bvh2);
+		hipLaunchKernelGGL(kernel_trace_shadow_bvh2, dim3(grid2), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
+		return;
+	}
 	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8);
 	hipLaunchKernelGGL(kernel_trace_shadow_bvh8, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
 }
 void rt_launch_trace_shadow_ao(const RtParams & p, hipStream_t stream) {
+	if (p.bvh_width == 2) {
+		static int grid2 = trace_grid_size((const void *)kernel_trace_shadow_bvh2_ao);
+		hipLaunchKernelGGL(kernel_trace_shadow_bvh2_ao, dim3(grid2), dim3(RT_TRACE_BLOCK), 0, stream, p);
+		return;
+	}
 	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8_ao);
 	hipLaunchKernelGGL(kernel_trace_shadow_bvh8_ao, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p);
 }
@@ -592,10 +781,20 @@ void rt_launch_trace_shadow_counting(const RtParams & p, int bounce, unsigned lo
 	hipLaunchKernelGGL(kernel_trace_shadow_bvh8_counting, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce, stats);
 }
 void rt_launch_trace_explicit(const RtParams & p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired_counter, hipStream_t stream) {
+	if (p.bvh_width == 2) {
+		static int grid2 = trace_grid_size((const void *)kernel_trace_bvh2_explicit);
+		hipLaunchKernelGGL(kernel_trace_bvh2_explicit, dim3(grid2), dim3(RT_TRACE_BLOCK), 0, stream, p, origin, direction, hits, ray_count, retired_counter);
+		return;
+	}
 	static int grid = trace_grid_size((const void *)kernel_trace_bvh8_explicit);
 	hipLaunchKernelGGL(kernel_trace_bvh8_explicit, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, origin, direction, hits, ray_count, retired_counter);
 }
 void rt_launch_trace_shadow_explicit(const RtParams & p, RtVec3SoA origin, RtVec3SoA direction, const float * max_distance, uint8_t * occluded, int ray_count, int * retired_counter, hipStream_t stream) {
+	if (p.bvh_width == 2) {
+		static int grid2 = trace_grid_size((const void *)kernel_trace_shadow_bvh2_explicit);
+		hipLaunchKernelGGL(kernel_trace_shadow_bvh2_explicit, dim3(grid2), dim3(RT_TRACE_BLOCK), 0, stream, p, origin, direction, max_distance, occluded, ray_count, retired_counter);
+		return;
+	}
 	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8_explicit);
 	hipLaunchKernelGGL(kernel_trace_shadow_bvh8_explicit, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, origin, direction, max_distance, occluded, ray_count, retired_counter);
 }

@@ -232,6 +232,7 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 	ctx->params.stack_spill  = (uint2 *)ctx->slots[0].spill[0];
 
 	ctx->params.frame_pixels = 1u << 30; ctx->params.frame_pixels_magic = 5; ctx->params.batch_samples = 1; // until rt_resize
+	ctx->params.bvh_width = 8;
 	// default config = reference defaults (Common.h:39-67)
 	rt_gpu_config c = { RT_FILTER_GAUSSIAN, 1u << RT_AOV_RADIANCE, 10, 1, 1, 1, 1, 0, 1, 1, 0.1f, 0.1f, 6, 4.0f, 16.0f, 10.0f };
 	ctx->params.config = c;
@@ -260,20 +261,24 @@ void rt_destroy(rt_context * ctx) {
 
 // ---- scene upload ----------------------------------------------------------------------------------
 
+// traversal copy of the triangles: positions only, 48 B stride (first 36 B of each 96 B triangle + 12 B pad)
+static int upload_triangle_positions(rt_context * ctx, const void * triangles, size_t triangle_count) {
+	std::vector<float> positions(triangle_count * 12, 0.0f);
+	const float * src = (const float *)triangles;
+	for (size_t t = 0; t < triangle_count; t++) memcpy(&positions[t * 12], src + t * 24, 36);
+	int s = upload(ctx, &ctx->triangle_positions, positions.data(), triangle_count * 48); if (s) return s;
+	ctx->params.triangle_positions = (const float4 *)ctx->triangle_positions;
+	return RT_OK;
+}
+
 int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle_count, const void * bvh8_nodes, size_t node_count) {
 	RT_REQUIRE(ctx, ctx && triangles && bvh8_nodes, "rt_upload_geometry: NULL argument");
 	(void)hipSetDevice(ctx->device);
 	int s = upload(ctx, &ctx->triangles, triangles, triangle_count * 96); if (s) return s;
 	s = upload(ctx, &ctx->bvh8_nodes, bvh8_nodes, node_count * 80); if (s) return s;
-	{ // traversal copy: positions only, 48 B stride (first 36 B of each 96 B triangle + 12 B pad)
-		std::vector<float> positions(triangle_count * 12, 0.0f);
-		const float * src = (const float *)triangles;
-		for (size_t t = 0; t < triangle_count; t++) memcpy(&positions[t * 12], src + t * 24, 36);
-		s = upload(ctx, &ctx->triangle_positions, positions.data(), triangle_count * 48); if (s) return s;
-	}
+	s = upload_triangle_positions(ctx, triangles, triangle_count); if (s) return s;
 	ctx->triangle_count = triangle_count; ctx->bvh8_node_count = node_count;
 	ctx->params.triangles  = (const float4 *)ctx->triangles;
-	ctx->params.triangle_positions = (const float4 *)ctx->triangle_positions;
 	ctx->params.bvh8_nodes = (const float4 *)ctx->bvh8_nodes;
 	return RT_OK;
 }
@@ -293,6 +298,7 @@ int rt_upload_geometry_bvh2(rt_context * ctx, const void * triangles, size_t tri
 	(void)hipSetDevice(ctx->device);
 	int s = upload(ctx, &ctx->triangles, triangles, triangle_count * 96); if (s) return s;
 	s = upload(ctx, &ctx->bvh2_nodes, bvh2_nodes, node_count * 32); if (s) return s;
+	s = upload_triangle_positions(ctx, triangles, triangle_count); if (s) return s;
 	ctx->triangle_count = triangle_count; ctx->bvh2_node_count = node_count;
 	ctx->params.triangles  = (const float4 *)ctx->triangles;
 	ctx->params.bvh2_nodes = (const float4 *)ctx->bvh2_nodes;
@@ -310,8 +316,11 @@ int rt_upload_tlas_bvh2(rt_context * ctx, const void * tlas_nodes, size_t tlas_n
 
 int rt_set_bvh_type(rt_context * ctx, int bvh_width) {
 	RT_REQUIRE(ctx, ctx, "rt_set_bvh_type: NULL context");
-	if (bvh_width != 8) return fail(ctx, RT_ERROR_INVALID_ARG, "rt_set_bvh_type: only the 8-wide CWBVH kernels exist on the device (got %d); the binary BVH is a CPU-oracle configuration", bvh_width);
+	if (bvh_width != 8 && bvh_width != 2) return fail(ctx, RT_ERROR_INVALID_ARG, "rt_set_bvh_type: the device has kernels for the binary BVH (2) and the 8-wide CWBVH (8), got %d", bvh_width);
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
 	ctx->bvh_width = bvh_width;
+	ctx->params.bvh_width = bvh_width;
 	return RT_OK;
 }
 
@@ -761,13 +770,13 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	RT_REQUIRE(ctx, sample_count >= 1 && sample_count <= RT_MAX_BATCH_SAMPLES, "rt_render_samples: sample_count must be 1..16");
 	(void)hipSetDevice(ctx->device);
 	const RtParams & base = ctx->params;
-	if (!base.triangles || !base.bvh8_nodes)   return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: geometry not uploaded");
+	if (!base.triangles || (ctx->bvh_width == 8 && !base.bvh8_nodes)) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: geometry not uploaded");
 	if (!base.mesh_bvh_root_indices)        return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: instances not uploaded");
 	if (!base.materials)                    return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: materials not uploaded");
 	if (!base.pmj_samples || !base.blue_noise) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: RNG tables not uploaded");
 	if (!base.sky)                          return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: sky not set");
 	if (ctx->frame_pixels == 0)          return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: rt_resize was not called");
-	if (ctx->bvh_width != 8)             return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: unsupported BVH type");
+	if (ctx->bvh_width == 2 && (!base.bvh2_nodes || ctx->trace_statistics)) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: binary-BVH nodes not uploaded, or trace statistics requested (they exist for the CWBVH kernels only)");
 	// Slot choice: round-robin over the samples in flight. Profiling / statistics passes use one slot,
 	// serialised. SVGF frames pipeline like plain samples: only their filter stage is ordered.
 	bool exclusive = ctx->profiling || ctx->trace_statistics;
@@ -903,7 +912,7 @@ int rt_render_ao_sample(rt_context * ctx, int sample_index, float ao_radius) {
 	RT_REQUIRE(ctx, ao_radius > 0.0f, "rt_render_ao_sample: ao_radius must be positive");
 	(void)hipSetDevice(ctx->device);
 	const RtParams & base = ctx->params;
-	if (!base.triangles || !base.bvh8_nodes)   return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: geometry not uploaded");
+	if (!base.triangles || (ctx->bvh_width == 8 ? !base.bvh8_nodes : !base.bvh2_nodes)) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: geometry not uploaded");
 	if (!base.mesh_bvh_root_indices)           return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: instances not uploaded");
 	if (!base.pmj_samples || !base.blue_noise) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: RNG tables not uploaded");
 	if (ctx->frame_pixels == 0)                return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: rt_resize was not called");
@@ -1075,7 +1084,7 @@ int rt_trace_rays(rt_context * ctx, const float * ox, const float * oy, const fl
 	RT_REQUIRE(ctx, ctx && ox && oy && oz && dx && dy && dz && hits, "rt_trace_rays: NULL argument");
 	(void)hipSetDevice(ctx->device);
 	RT_HIP(ctx, quiesce(ctx)); // slot 0's spill area and cursors are borrowed
-	if (!ctx->params.triangles || !ctx->params.bvh8_nodes || !ctx->params.mesh_bvh_root_indices) return fail(ctx, RT_ERROR_NOT_READY, "rt_trace_rays: geometry / instances not uploaded");
+	if (!ctx->params.triangles || (ctx->bvh_width == 8 ? !ctx->params.bvh8_nodes : !ctx->params.bvh2_nodes) || !ctx->params.mesh_bvh_root_indices) return fail(ctx, RT_ERROR_NOT_READY, "rt_trace_rays: geometry / instances not uploaded");
 	TempBuffers tmp(ctx);
 	size_t bytes = ray_count * 4;
 	RtVec3SoA o = { (float *)tmp.get(bytes, ox), (float *)tmp.get(bytes, oy), (float *)tmp.get(bytes, oz) };
@@ -1108,7 +1117,7 @@ int rt_trace_shadow_rays(rt_context * ctx, const float * ox, const float * oy, c
 	RT_REQUIRE(ctx, ctx && ox && oy && oz && dx && dy && dz && max_distance && occluded, "rt_trace_shadow_rays: NULL argument");
 	(void)hipSetDevice(ctx->device);
 	RT_HIP(ctx, quiesce(ctx)); // slot 0's spill area and cursors are borrowed
-	if (!ctx->params.triangles || !ctx->params.bvh8_nodes || !ctx->params.mesh_bvh_root_indices) return fail(ctx, RT_ERROR_NOT_READY, "rt_trace_shadow_rays: geometry / instances not uploaded");
+	if (!ctx->params.triangles || (ctx->bvh_width == 8 ? !ctx->params.bvh8_nodes : !ctx->params.bvh2_nodes) || !ctx->params.mesh_bvh_root_indices) return fail(ctx, RT_ERROR_NOT_READY, "rt_trace_shadow_rays: geometry / instances not uploaded");
 	TempBuffers tmp(ctx);
 	size_t bytes = ray_count * 4;
 	RtVec3SoA o = { (float *)tmp.get(bytes, ox), (float *)tmp.get(bytes, oy), (float *)tmp.get(bytes, oz) };

@@ -111,6 +111,44 @@ def blob_obj(n):
     return "\n".join(lines) + "\n"
 
 
+@pytest.mark.parametrize("scene_name,w,h", [("cornellbox", 256, 256), ("sponza", 480, 270)])
+def test_binary_bvh_trace_is_bit_exact_and_config_1_renders(grt, oracle, scene_name, w, h):
+    """bvh_type = BVH (BVH2.h, BASELINE config #1 on the device): primary and incoherent rays through
+    kernel_trace_bvh2 give the oracle's hits bit for bit (the host permutes the triangles by the BVH2
+    indices, so ids differ from the CWBVH run but t / u / v of primary hits agree with it), shadow rays
+    agree, and a full frame matches the oracle's render."""
+    scene, pt = make_pathtracer(grt, scene_name, w, h, 0, bvh_type=2, num_bounces=4)
+    view = oracle.SceneView(pt, bvh_type=2)
+    o, d, _ = view.generate(0, 0, w * h)
+    hits_cpu, stats = view.trace(o, d)
+    hits_gpu, _ = grt.trace_rays(pt.ctx, o, d)
+    assert np.array_equal(hits_gpu, hits_cpu) and (hits_cpu[:, 1] != 0xffffffff).mean() > 0.5
+    # incoherent rays: from the primary hit points into seeded random directions, and as shadow rays
+    rng = np.random.default_rng(11)
+    t = hits_cpu[:, 2].view(np.float32)
+    ok = hits_cpu[:, 1] != 0xffffffff
+    origin = (o + d * np.where(ok, t, 0.0) * 0.999)[:, ok][:, :60000]
+    direction = rng.normal(size=origin.shape).astype(np.float32)
+    direction /= np.linalg.norm(direction, axis=0)
+    h2_cpu, _ = view.trace(origin, direction)
+    h2_gpu, _ = grt.trace_rays(pt.ctx, origin, direction)
+    assert np.array_equal(h2_gpu, h2_cpu)
+    max_dist = rng.uniform(0.05, 5.0, origin.shape[1]).astype(np.float32)
+    occ_gpu, _ = grt.trace_shadow_rays(pt.ctx, origin, direction, max_dist)
+    assert np.array_equal(occ_gpu.astype(bool), view.trace_shadow(origin, direction, max_dist)[0].astype(bool))
+    pt.close(); scene.close()
+    if scene_name == "cornellbox":   # BASELINE config #1: 512 x 512, one sample, binary SAH BVH
+        scene, pt = make_pathtracer(grt, "cornellbox", 512, 512, 0, bvh_type=2)
+        view = oracle.SceneView(pt, bvh_type=2); frame = oracle.Frame(view)
+        pt.render(); c = pt.counters(); oc = frame.render_sample(pt.sample_index)
+        nb = pt.device_config().num_bounces
+        assert c.trace[0] == oc.trace[0] == 512 * 512
+        assert all(abs(a - b) <= 2 + 0.002 * b for a, b in zip(list(c.trace[:nb]), list(oc.trace[:nb])))
+        got, want = pt.read_framebuffer()[:, :512, :3], frame.final[:, :512, :3]
+        assert np.abs(got - want).sum() / want.sum() < REL_L1_TOL
+        pt.close(); scene.close()
+
+
 def test_random_samples_are_bit_exact(grt, oracle):
     scene, pt = make_pathtracer(grt, "cornellbox", 300, 200, 0)
     view = oracle.SceneView(pt)

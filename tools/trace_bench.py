@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of kernel_trace_bvh8 through rt_trace_rays: Sponza primary rays and seeded
+"""Micro-benchmark of kernel_trace_bvh8 (BVH_TYPE=2: kernel_trace_bvh2) through rt_trace_rays: Sponza primary rays and seeded
 incoherent bounce rays at several batch sizes (tail effects vs. steady-state throughput)."""
 import os, sys, time
 import numpy as np
@@ -10,6 +10,8 @@ import gpu_raytracer_amd as grt
 def main():
     sizes = [int(a) for a in sys.argv[1:]] or [100_000, 777_600, 2_073_600, 8_000_000]
     grt.config_reset()
+    bvh_type = int(os.environ.get("BVH_TYPE", "8"))   # 8: CWBVH kernels, 2: binary-BVH kernels
+    grt.config_set(bvh_type=bvh_type)
     scene = grt.Scene(grt.scene_path("sponza"))
     pt = grt.Pathtracer(scene, 1920, 1080, device=0); pt.update()
     prim_o, prim_d = [], []
