@@ -131,10 +131,18 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    # debug only: BENCH_DIST_BACKEND=gloo BENCH_SHARE_GPU=1 runs the N-rank flow (rendezvous, tile split,
+    # stream hand-over, reductions) with every rank on GPU 0 and the gather staged through the host
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     scene = build_scene(grt)
     pt = grt.Pathtracer(scene, WIDTH, HEIGHT, device=local_rank)
@@ -181,8 +189,12 @@ def main():
                 check(lib.rt_context_wait_for_stream(ctx, torch_stream))
                 check(lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, split_world, split.tiles_per_rank))
                 check(lib.rt_stream_wait_for_context(ctx, torch_stream))
-                if world > 1:
+                if world > 1 and backend == "nccl":
                     dist.all_gather_into_tensor(gathered, packed)
+                elif world > 1:
+                    host = torch.empty(gathered.shape, dtype=gathered.dtype)
+                    dist.all_gather_into_tensor(host, packed.cpu())
+                    gathered.copy_(host)
                 else:
                     gathered[:split.local_pixels].copy_(packed)   # --emulate-world: stand-in for the collective
 
