@@ -294,7 +294,7 @@ class Scene:
 
 
 _ARRAY_DTYPES = {
-    "triangles": np.float32, "bvh8_nodes": np.uint8, "bvh2_nodes": np.uint8, "reverse_indices": np.int32,
+    "triangles": np.float32, "bvh8_nodes": np.uint8, "bvh2_nodes": np.uint8, "bvh4_nodes": np.uint8, "reverse_indices": np.int32,
     "mesh_bvh_root_indices": np.int32, "mesh_material_ids": np.int32, "mesh_transforms": np.float32,
     "mesh_transforms_inv": np.float32, "mesh_transforms_prev": np.float32, "material_types": np.uint8,
     "materials": np.float32, "media": np.float32, "tlas_indices": np.int32, "tlas_nodes": np.uint8,

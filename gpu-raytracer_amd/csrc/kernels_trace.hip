@@ -666,6 +666,169 @@ RT_DEV void bvh2_trace_persistent(const RtParams & p, Source & src, int ray_coun
 	}
 }
 
+
+// =================================================================================================
+// 4-wide BVH (BVH4.h:4-295, `bvh_type = BVH4`). 128-B nodes: the boxes of up to four children in SoA
+// form plus (index, count) per child. The reference's stack holds (node, child id) and re-reads the
+// child's (index, count) when it pops; here the stack entry IS (index, count) -- the same values, one
+// dependent load less per step. Children are pushed far-to-near (near distances tagged with the child
+// id in two mantissa bits and sorted, as in bvh4_node_intersect), so the nearest is popped first.
+// =================================================================================================
+template<bool SHADOW, typename Source>
+RT_DEV void bvh4_trace_persistent(const RtParams & p, Source & src, int ray_count, int * cursor) {
+	__shared__ uint2 shared_stack[(RT_TRACE_BLOCK / RT_WAVE_SIZE) * RT_LDS_STACK * RT_WAVE_SIZE];
+
+	const float4 * __restrict__ nodes     = p.bvh4_nodes;
+	const float4 * __restrict__ triangles = p.triangle_positions;
+
+	unsigned lane = threadIdx.x & (RT_WAVE_SIZE - 1);
+	unsigned wave = threadIdx.x / RT_WAVE_SIZE;
+
+	TraversalStack stack;
+	stack.lds   = (LdsUint2 *)&shared_stack[wave * (RT_LDS_STACK * RT_WAVE_SIZE) + lane];
+	stack.spill_stride = int(gridDim.x * blockDim.x);
+	stack.spill = (GlobalUint2 *)(p.stack_spill + (blockIdx.x * blockDim.x + threadIdx.x));
+	stack.size  = 0;
+
+	const int waves_in_grid = int(gridDim.x) * (RT_TRACE_BLOCK / RT_WAVE_SIZE);
+	const int ray_block = max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (ray_count / (2 * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
+	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * unsigned(ray_block) >= unsigned(ray_count)) return;
+	__shared__ int shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4];
+	typedef volatile __attribute__((address_space(3))) int LdsFetchWord;
+	LdsFetchWord * fetch_state = (LdsFetchWord *)&shared_fetch[wave][0];
+	if (lane == 0) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[2] = 0; }
+	auto fetch_ray = [&]() -> int { // see bvh8_trace_persistent
+		while (true) {
+			if (fetch_state[2]) return -1;
+			unsigned long long want = __ballot(1);
+			int n_want = __popcll(want);
+			unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(want >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(want), 0u));
+			int next = fetch_state[0], end = fetch_state[1];
+			if (next >= end) {
+				int base = 0;
+				if (rank == 0) base = atomicAdd(cursor, ray_block);
+				base = __builtin_amdgcn_readfirstlane(base);
+				next = min(base, ray_count);
+				end  = min(base + ray_block, ray_count);
+			}
+			int give = min(n_want, end - next);
+			if (rank == 0) {
+				fetch_state[0] = next + give;
+				fetch_state[1] = end;
+				if (next >= end) fetch_state[2] = 1;
+			}
+			if (int(rank) < give) return next + int(rank);
+		}
+	};
+
+	int  ray_index = 0;
+	Ray3 ray;
+	f3   inv_dir;
+	float max_distance = 0.0f;
+	HitRecord hit;
+	int  tlas_stack_size = RT_INVALID;
+	int  mesh_id = 0;
+	bool mesh_has_identity_transform = true;
+	int  tri_next = 0, tri_end = 0;
+
+	while (true) {
+		bool inactive = stack.size == 0 && tri_next >= tri_end;
+		if (inactive) {
+			ray_index = fetch_ray();
+			if (ray_index < 0) return;
+			src.load(ray_index, ray, max_distance);
+			inv_dir = reciprocal(ray.direction);
+			hit.t = RT_INFINITY; hit.u = 0.0f; hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
+			tlas_stack_size = RT_INVALID;
+			stack.push(make_uint2(0, 0)); // child 0 of the entry node (node 1): the TLAS root, an inner node
+		}
+
+		int iterations_lost = 0;
+		do {
+			bool occluded = false;
+			if (tri_next < tri_end) {
+				#pragma unroll
+				for (int k = 0; k < RT_TRI_BATCH; k++) {
+					if (tri_next < tri_end && !occluded) {
+						const float4 * tri = triangles + size_t(tri_next) * 3;
+						if (triangle_test_loaded<SHADOW>(tri[0], tri[1], make_float4(tri[2].x, 0.0f, 0.0f, 0.0f), mesh_id, tri_next, ray, max_distance, hit)) occluded = true;
+						tri_next++;
+					}
+				}
+			} else {
+				if (stack.size == tlas_stack_size) {
+					tlas_stack_size = RT_INVALID;
+					if (!mesh_has_identity_transform) {
+						float unused;
+						src.load(ray_index, ray, unused);
+						inv_dir = reciprocal(ray.direction);
+					}
+				}
+				uint2 entry = stack.pop();
+				int index = int(entry.x), count = int(entry.y);
+
+				if (count > 0) {
+					if (tlas_stack_size == RT_INVALID) { // TLAS leaf: enter the instance through its entry node
+						tlas_stack_size = stack.size;
+						mesh_id = index;
+						unsigned root = unsigned(p.mesh_bvh_root_indices[mesh_id]);
+						mesh_has_identity_transform = (root >> 31) != 0;
+						if (!mesh_has_identity_transform) {
+							const float4 * m = p.mesh_transforms_inv + size_t(mesh_id) * 3;
+							ray.origin    = transform_position (m, ray.origin);
+							ray.direction = transform_direction(m, ray.direction);
+							inv_dir = reciprocal(ray.direction);
+						}
+						stack.push(make_uint2(root & 0x7fffffffu, 0)); // = child 0 of node root + 1
+					} else {
+						tri_next = index; tri_end = index + count;
+					}
+				} else {
+					const float4 * node = nodes + size_t(index) * 8;
+					float4 min_x = node[0], min_y = node[1], min_z = node[2], max_x = node[3], max_y = node[4], max_z = node[5], ic01 = node[6], ic23 = node[7];
+					float limit = SHADOW ? max_distance : hit.t;
+					float t_near[4]; unsigned hit_mask = 0;
+					#define RT_BVH4_CHILD(i, c) { \
+						float t0x = (min_x.c - ray.origin.x) * inv_dir.x, t1x = (max_x.c - ray.origin.x) * inv_dir.x; \
+						float t0y = (min_y.c - ray.origin.y) * inv_dir.y, t1y = (max_y.c - ray.origin.y) * inv_dir.y; \
+						float t0z = (min_z.c - ray.origin.z) * inv_dir.z, t1z = (max_z.c - ray.origin.z) * inv_dir.z; \
+						float tn = fmaxf(fminf(t0x, t1x), fmaxf(fminf(t0y, t1y), fmaxf(fminf(t0z, t1z), 0.0f))); \
+						float tf = fminf(fmaxf(t0x, t1x), fminf(fmaxf(t0y, t1y), fminf(fmaxf(t0z, t1z), limit))); \
+						if (tn < tf) hit_mask |= 1u << i; \
+						t_near[i] = __uint_as_float((__float_as_uint(tn) & 0xfffffffcu) | unsigned(i)); }
+					RT_BVH4_CHILD(0, x) RT_BVH4_CHILD(1, y) RT_BVH4_CHILD(2, z) RT_BVH4_CHILD(3, w)
+					#undef RT_BVH4_CHILD
+					#pragma unroll
+					for (int i = 1; i < 4; i++) {
+						#pragma unroll
+						for (int j = i - 1; j >= 0; j--) if (t_near[j] < t_near[j + 1]) { float t = t_near[j]; t_near[j] = t_near[j + 1]; t_near[j + 1] = t; }
+					}
+					#pragma unroll
+					for (int i = 0; i < 4; i++) {
+						unsigned id = __float_as_uint(t_near[i]) & 3u;
+						if ((hit_mask >> id) & 1u) {
+							float cx = id == 0 ? ic01.x : (id == 1 ? ic01.z : (id == 2 ? ic23.x : ic23.z));
+							float cy = id == 0 ? ic01.y : (id == 1 ? ic01.w : (id == 2 ? ic23.y : ic23.w));
+							stack.push(make_uint2(__float_as_uint(cx), __float_as_uint(cy)));
+						}
+					}
+				}
+			}
+
+			if (SHADOW && occluded) {
+				src.finish(ray_index, hit, true);
+				stack.size = 0; tri_next = tri_end = 0;
+				break;
+			}
+			if (stack.size == 0 && tri_next >= tri_end) {
+				src.finish(ray_index, hit, false);
+				break;
+			}
+			iterations_lost += RT_WAVE_SIZE - __popcll(__ballot(1)) - RT_N_D;
+		} while (iterations_lost < RT_N_W);
+	}
+}
+
 // ---- kernels ---------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh8(RtParams p, int bounce) {
@@ -697,6 +860,27 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh2_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, const float * max_distance, uint8_t * occluded, int ray_count, int * retired) {
 	ShadowExplicitSource src { origin, direction, max_distance, occluded };
 	bvh2_trace_persistent<true>(p, src, ray_count, retired);
+}
+
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh4(RtParams p, int bounce) {
+	ClosestHitSource src { p.trace[bounce & 1].origin, p.trace[bounce & 1].direction, p.trace[bounce & 1].hits };
+	bvh4_trace_persistent<false>(p, src, p.sizes->trace[bounce], p.xcd_counters + (2 * bounce) * RT_NUM_XCD);
+}
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh4(RtParams p, int bounce) {
+	ShadowQueueSource src { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT], bounce };
+	bvh4_trace_persistent<true>(p, src, p.sizes->shadow[bounce], p.xcd_counters + (2 * bounce + 1) * RT_NUM_XCD);
+}
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh4_ao(RtParams p) {
+	ShadowAOSource src { p.shadow, p.aovs[RT_AOV_RADIANCE] };
+	bvh4_trace_persistent<true>(p, src, p.sizes->shadow[0], p.xcd_counters + RT_NUM_XCD);
+}
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh4_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {
+	ClosestHitSource src { origin, direction, hits };
+	bvh4_trace_persistent<false>(p, src, ray_count, retired);
+}
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh4_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, const float * max_distance, uint8_t * occluded, int ray_count, int * retired) {
+	ShadowExplicitSource src { origin, direction, max_distance, occluded };
+	bvh4_trace_persistent<true>(p, src, ray_count, retired);
 }
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh8_ao(RtParams p) {
@@ -751,6 +935,11 @@ void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream) {
 		hipLaunchKernelGGL(kernel_trace_bvh2, dim3(grid2), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
 		return;
 	}
+	if (p.bvh_width == 4) {
+		static int grid4 = trace_grid_size((const void *)kernel_trace_bvh4);
+		hipLaunchKernelGGL(kernel_trace_bvh4, dim3(grid4), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
+		return;
+	}
 	static int grid = trace_grid_size((const void *)kernel_trace_bvh8);
 	hipLaunchKernelGGL(kernel_trace_bvh8, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
 }
@@ -760,6 +949,11 @@ void rt_launch_trace_shadow(const RtParams & p, int bounce, hipStream_t stream) 
 		hipLaunchKernelGGL(kernel_trace_shadow_bvh2, dim3(grid2), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
 		return;
 	}
+	if (p.bvh_width == 4) {
+		static int grid4 = trace_grid_size((const void *)kernel_trace_shadow_bvh4);
+		hipLaunchKernelGGL(kernel_trace_shadow_bvh4, dim3(grid4), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
+		return;
+	}
 	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8);
 	hipLaunchKernelGGL(kernel_trace_shadow_bvh8, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, bounce);
 }
@@ -767,6 +961,11 @@ void rt_launch_trace_shadow_ao(const RtParams & p, hipStream_t stream) {
 	if (p.bvh_width == 2) {
 		static int grid2 = trace_grid_size((const void *)kernel_trace_shadow_bvh2_ao);
 		hipLaunchKernelGGL(kernel_trace_shadow_bvh2_ao, dim3(grid2), dim3(RT_TRACE_BLOCK), 0, stream, p);
+		return;
+	}
+	if (p.bvh_width == 4) {
+		static int grid4 = trace_grid_size((const void *)kernel_trace_shadow_bvh4_ao);
+		hipLaunchKernelGGL(kernel_trace_shadow_bvh4_ao, dim3(grid4), dim3(RT_TRACE_BLOCK), 0, stream, p);
 		return;
 	}
 	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8_ao);
@@ -786,6 +985,11 @@ void rt_launch_trace_explicit(const RtParams & p, RtVec3SoA origin, RtVec3SoA di
 		hipLaunchKernelGGL(kernel_trace_bvh2_explicit, dim3(grid2), dim3(RT_TRACE_BLOCK), 0, stream, p, origin, direction, hits, ray_count, retired_counter);
 		return;
 	}
+	if (p.bvh_width == 4) {
+		static int grid4 = trace_grid_size((const void *)kernel_trace_bvh4_explicit);
+		hipLaunchKernelGGL(kernel_trace_bvh4_explicit, dim3(grid4), dim3(RT_TRACE_BLOCK), 0, stream, p, origin, direction, hits, ray_count, retired_counter);
+		return;
+	}
 	static int grid = trace_grid_size((const void *)kernel_trace_bvh8_explicit);
 	hipLaunchKernelGGL(kernel_trace_bvh8_explicit, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p, origin, direction, hits, ray_count, retired_counter);
 }
@@ -793,6 +997,11 @@ void rt_launch_trace_shadow_explicit(const RtParams & p, RtVec3SoA origin, RtVec
 	if (p.bvh_width == 2) {
 		static int grid2 = trace_grid_size((const void *)kernel_trace_shadow_bvh2_explicit);
 		hipLaunchKernelGGL(kernel_trace_shadow_bvh2_explicit, dim3(grid2), dim3(RT_TRACE_BLOCK), 0, stream, p, origin, direction, max_distance, occluded, ray_count, retired_counter);
+		return;
+	}
+	if (p.bvh_width == 4) {
+		static int grid4 = trace_grid_size((const void *)kernel_trace_shadow_bvh4_explicit);
+		hipLaunchKernelGGL(kernel_trace_shadow_bvh4_explicit, dim3(grid4), dim3(RT_TRACE_BLOCK), 0, stream, p, origin, direction, max_distance, occluded, ray_count, retired_counter);
 		return;
 	}
 	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8_explicit);

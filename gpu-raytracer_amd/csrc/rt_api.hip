@@ -62,7 +62,8 @@ struct rt_context {
 	std::vector<void *> owned;     // every hipMalloc'd pointer, freed in rt_destroy
 
 	// named allocations that get replaced on re-upload
-	void * triangles = nullptr, * triangle_positions = nullptr, * bvh8_nodes = nullptr, * bvh2_nodes = nullptr;
+	void * triangles = nullptr, * triangle_positions = nullptr, * bvh8_nodes = nullptr, * bvh2_nodes = nullptr, * bvh4_nodes = nullptr;
+	size_t bvh4_node_count = 0;
 	size_t bvh8_node_count = 0, bvh2_node_count = 0, triangle_count = 0;
 	void * instances[5] = { };     size_t mesh_count = 0;
 	void * material_types = nullptr, * materials = nullptr, * media = nullptr;
@@ -199,6 +200,12 @@ static RtParams slot_params(const rt_context * ctx, const SampleSlot & slot, int
 	return p;
 }
 
+// the node array of the selected BVH type has been uploaded
+static bool bvh_nodes_present(const rt_context * ctx) {
+	const RtParams & p = ctx->params;
+	return ctx->bvh_width == 8 ? p.bvh8_nodes != nullptr : (ctx->bvh_width == 4 ? p.bvh4_nodes != nullptr : p.bvh2_nodes != nullptr);
+}
+
 extern "C" {
 
 const char * rt_version(void) { return "gpu-raytracer_amd 0.1 (gfx950, HIP)"; }
@@ -314,9 +321,30 @@ int rt_upload_tlas_bvh2(rt_context * ctx, const void * tlas_nodes, size_t tlas_n
 	return RT_OK;
 }
 
+int rt_upload_geometry_bvh4(rt_context * ctx, const void * triangles, size_t triangle_count, const void * bvh4_nodes, size_t node_count) {
+	RT_REQUIRE(ctx, ctx && triangles && bvh4_nodes, "rt_upload_geometry_bvh4: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	int s = upload(ctx, &ctx->triangles, triangles, triangle_count * 96); if (s) return s;
+	s = upload(ctx, &ctx->bvh4_nodes, bvh4_nodes, node_count * 128); if (s) return s;
+	s = upload_triangle_positions(ctx, triangles, triangle_count); if (s) return s;
+	ctx->triangle_count = triangle_count; ctx->bvh4_node_count = node_count;
+	ctx->params.triangles  = (const float4 *)ctx->triangles;
+	ctx->params.bvh4_nodes = (const float4 *)ctx->bvh4_nodes;
+	return RT_OK;
+}
+
+int rt_upload_tlas_bvh4(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count) {
+	RT_REQUIRE(ctx, ctx && tlas_nodes, "rt_upload_tlas_bvh4: NULL argument");
+	RT_REQUIRE(ctx, ctx->bvh4_nodes && tlas_node_count <= ctx->bvh4_node_count, "rt_upload_tlas_bvh4: geometry not uploaded or TLAS larger than the node array");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	RT_HIP(ctx, hipMemcpy(ctx->bvh4_nodes, tlas_nodes, tlas_node_count * 128, hipMemcpyHostToDevice));
+	return RT_OK;
+}
+
 int rt_set_bvh_type(rt_context * ctx, int bvh_width) {
 	RT_REQUIRE(ctx, ctx, "rt_set_bvh_type: NULL context");
-	if (bvh_width != 8 && bvh_width != 2) return fail(ctx, RT_ERROR_INVALID_ARG, "rt_set_bvh_type: the device has kernels for the binary BVH (2) and the 8-wide CWBVH (8), got %d", bvh_width);
+	if (bvh_width != 8 && bvh_width != 4 && bvh_width != 2) return fail(ctx, RT_ERROR_INVALID_ARG, "rt_set_bvh_type: the device has kernels for the binary BVH (2), the 4-wide BVH (4) and the 8-wide CWBVH (8), got %d", bvh_width);
 	(void)hipSetDevice(ctx->device);
 	RT_HIP(ctx, quiesce(ctx));
 	ctx->bvh_width = bvh_width;
@@ -770,13 +798,13 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	RT_REQUIRE(ctx, sample_count >= 1 && sample_count <= RT_MAX_BATCH_SAMPLES, "rt_render_samples: sample_count must be 1..16");
 	(void)hipSetDevice(ctx->device);
 	const RtParams & base = ctx->params;
-	if (!base.triangles || (ctx->bvh_width == 8 && !base.bvh8_nodes)) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: geometry not uploaded");
+	if (!base.triangles || !bvh_nodes_present(ctx)) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: geometry not uploaded");
 	if (!base.mesh_bvh_root_indices)        return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: instances not uploaded");
 	if (!base.materials)                    return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: materials not uploaded");
 	if (!base.pmj_samples || !base.blue_noise) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: RNG tables not uploaded");
 	if (!base.sky)                          return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: sky not set");
 	if (ctx->frame_pixels == 0)          return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: rt_resize was not called");
-	if (ctx->bvh_width == 2 && (!base.bvh2_nodes || ctx->trace_statistics)) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: binary-BVH nodes not uploaded, or trace statistics requested (they exist for the CWBVH kernels only)");
+	if (ctx->bvh_width != 8 && ctx->trace_statistics) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: trace statistics exist for the CWBVH kernels only");
 	// Slot choice: round-robin over the samples in flight. Profiling / statistics passes use one slot,
 	// serialised. SVGF frames pipeline like plain samples: only their filter stage is ordered.
 	bool exclusive = ctx->profiling || ctx->trace_statistics;
@@ -912,7 +940,7 @@ int rt_render_ao_sample(rt_context * ctx, int sample_index, float ao_radius) {
 	RT_REQUIRE(ctx, ao_radius > 0.0f, "rt_render_ao_sample: ao_radius must be positive");
 	(void)hipSetDevice(ctx->device);
 	const RtParams & base = ctx->params;
-	if (!base.triangles || (ctx->bvh_width == 8 ? !base.bvh8_nodes : !base.bvh2_nodes)) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: geometry not uploaded");
+	if (!base.triangles || !bvh_nodes_present(ctx)) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: geometry not uploaded");
 	if (!base.mesh_bvh_root_indices)           return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: instances not uploaded");
 	if (!base.pmj_samples || !base.blue_noise) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: RNG tables not uploaded");
 	if (ctx->frame_pixels == 0)                return fail(ctx, RT_ERROR_NOT_READY, "rt_render_ao_sample: rt_resize was not called");
@@ -1084,7 +1112,7 @@ int rt_trace_rays(rt_context * ctx, const float * ox, const float * oy, const fl
 	RT_REQUIRE(ctx, ctx && ox && oy && oz && dx && dy && dz && hits, "rt_trace_rays: NULL argument");
 	(void)hipSetDevice(ctx->device);
 	RT_HIP(ctx, quiesce(ctx)); // slot 0's spill area and cursors are borrowed
-	if (!ctx->params.triangles || (ctx->bvh_width == 8 ? !ctx->params.bvh8_nodes : !ctx->params.bvh2_nodes) || !ctx->params.mesh_bvh_root_indices) return fail(ctx, RT_ERROR_NOT_READY, "rt_trace_rays: geometry / instances not uploaded");
+	if (!ctx->params.triangles || !bvh_nodes_present(ctx) || !ctx->params.mesh_bvh_root_indices) return fail(ctx, RT_ERROR_NOT_READY, "rt_trace_rays: geometry / instances not uploaded");
 	TempBuffers tmp(ctx);
 	size_t bytes = ray_count * 4;
 	RtVec3SoA o = { (float *)tmp.get(bytes, ox), (float *)tmp.get(bytes, oy), (float *)tmp.get(bytes, oz) };
@@ -1117,7 +1145,7 @@ int rt_trace_shadow_rays(rt_context * ctx, const float * ox, const float * oy, c
 	RT_REQUIRE(ctx, ctx && ox && oy && oz && dx && dy && dz && max_distance && occluded, "rt_trace_shadow_rays: NULL argument");
 	(void)hipSetDevice(ctx->device);
 	RT_HIP(ctx, quiesce(ctx)); // slot 0's spill area and cursors are borrowed
-	if (!ctx->params.triangles || (ctx->bvh_width == 8 ? !ctx->params.bvh8_nodes : !ctx->params.bvh2_nodes) || !ctx->params.mesh_bvh_root_indices) return fail(ctx, RT_ERROR_NOT_READY, "rt_trace_shadow_rays: geometry / instances not uploaded");
+	if (!ctx->params.triangles || !bvh_nodes_present(ctx) || !ctx->params.mesh_bvh_root_indices) return fail(ctx, RT_ERROR_NOT_READY, "rt_trace_shadow_rays: geometry / instances not uploaded");
 	TempBuffers tmp(ctx);
 	size_t bytes = ray_count * 4;
 	RtVec3SoA o = { (float *)tmp.get(bytes, ox), (float *)tmp.get(bytes, oy), (float *)tmp.get(bytes, oz) };

@@ -75,7 +75,8 @@ struct RtParams {
 	const float4 * triangle_positions;   // 3 float4: position_0, edge_1, edge_2 (traversal copy)
 	const float4 * bvh8_nodes;
 	const float4 * bvh2_nodes;  // 2 float4 per node
-	int bvh_width;              // 8: CWBVH kernels (default), 2: binary-BVH kernels
+	const float4 * bvh4_nodes;  // 8 float4 per node
+	int bvh_width;              // 8: CWBVH kernels (default), 4: 4-wide BVH kernels, 2: binary-BVH kernels
 	const int    * mesh_bvh_root_indices;
 	const int    * mesh_material_ids;
 	const float4 * mesh_transforms, * mesh_transforms_inv, * mesh_transforms_prev;

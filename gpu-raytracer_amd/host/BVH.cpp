@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 // ---------------------------------------------------------------------------------------------
 // SAH builder
@@ -365,5 +366,87 @@ void BVH8Converter::emit_node(int out_index, int bvh2_index) {
 	for (int i = 0; i < 8; i++) {
 		if (children[i] == INVALID) continue;
 		if (node.imask & (1 << i)) emit_node(int(node.base_index_child) + next++, children[i]);
+	}
+}
+
+
+// ---- BVH4 ------------------------------------------------------------------------------------------
+
+static void set_child_box(BVHNode4 & node, int slot, const AABB & box) {
+	node.aabb_min_x[slot] = box.min.x; node.aabb_min_y[slot] = box.min.y; node.aabb_min_z[slot] = box.min.z;
+	node.aabb_max_x[slot] = box.max.x; node.aabb_max_y[slot] = box.max.y; node.aabb_max_z[slot] = box.max.z;
+}
+
+static void copy_child(BVHNode4 & dst, int dst_slot, const BVHNode4 & src, int src_slot) {
+	dst.aabb_min_x[dst_slot] = src.aabb_min_x[src_slot]; dst.aabb_min_y[dst_slot] = src.aabb_min_y[src_slot]; dst.aabb_min_z[dst_slot] = src.aabb_min_z[src_slot];
+	dst.aabb_max_x[dst_slot] = src.aabb_max_x[src_slot]; dst.aabb_max_y[dst_slot] = src.aabb_max_y[src_slot]; dst.aabb_max_z[dst_slot] = src.aabb_max_z[src_slot];
+	dst.index_and_count[dst_slot] = src.index_and_count[src_slot];
+}
+
+void BVH4Converter::convert() {
+	bvh4.nodes.assign(bvh2.nodes.size(), BVHNode4());
+	memset((void *)bvh4.nodes.data(), 0, bvh4.nodes.size() * sizeof(BVHNode4));
+
+	for (size_t i = 0; i < bvh4.nodes.size(); i++) {
+		BVHNode4 & out = bvh4.nodes[i];
+		if (i == 1) { // entry point: its first child is the root
+			out.get_index(0) = 0;
+			out.get_count(0) = 0;
+			continue;
+		}
+		const BVHNode2 & in = bvh2.nodes[i];
+		if (in.is_leaf()) continue;
+
+		for (int side = 0; side < 2; side++) {
+			const BVHNode2 & child = bvh2.nodes[in.left + side];
+			set_child_box(out, side, child.aabb);
+			if (child.is_leaf()) { out.get_index(side) = child.first;    out.get_count(side) = int(child.count); }
+			else                 { out.get_index(side) = in.left + side; out.get_count(side) = 0; }
+		}
+		for (int slot = 2; slot < 4; slot++) { out.get_index(slot) = INVALID; out.get_count(slot) = INVALID; }
+	}
+
+	if (bvh2.nodes[0].is_leaf()) { // a single-leaf tree: the root node holds that leaf
+		BVHNode4 & root = bvh4.nodes[0];
+		set_child_box(root, 0, bvh2.nodes[0].aabb);
+		root.get_index(0) = bvh2.nodes[0].first;
+		root.get_count(0) = int(bvh2.nodes[0].count);
+		for (int slot = 1; slot < 4; slot++) { root.get_index(slot) = INVALID; root.get_count(slot) = INVALID; }
+	} else {
+		collapse(0);
+	}
+	bvh4.indices = bvh2.indices;
+}
+
+void BVH4Converter::collapse(int node_index) {
+	BVHNode4 & node = bvh4.nodes[node_index];
+
+	while (true) {
+		int child_count = node.get_child_count();
+
+		// the adoptable inner child with the largest half area; ties keep the first
+		float best_area = -INFINITY;
+		int   best = INVALID;
+		for (int i = 0; i < child_count; i++) {
+			if (node.is_leaf(i)) continue;
+			int grandchildren = bvh4.nodes[node.get_index(i)].get_child_count();
+			if (child_count + grandchildren - 1 > 4) continue;
+			float dx = node.aabb_max_x[i] - node.aabb_min_x[i];
+			float dy = node.aabb_max_y[i] - node.aabb_min_y[i];
+			float dz = node.aabb_max_z[i] - node.aabb_min_z[i];
+			float half_area = dx * dy + dy * dz + dz * dx;
+			if (half_area > best_area) { best_area = half_area; best = i; }
+		}
+		if (best == INVALID) break;
+
+		const BVHNode4 adopted = bvh4.nodes[node.get_index(best)];
+		int adopted_count = adopted.get_child_count();
+		copy_child(node, best, adopted, 0);                                                  // its first child takes its slot
+		for (int i = 1; i < adopted_count; i++) copy_child(node, child_count + i - 1, adopted, i); // the others are appended
+	}
+
+	for (int i = 0; i < 4; i++) {
+		if (node.get_count(i) == INVALID) break;
+		if (node.get_count(i) == 0) collapse(node.get_index(i));
 	}
 }

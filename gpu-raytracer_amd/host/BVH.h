@@ -42,9 +42,30 @@ struct BVHNode8 {
 };
 static_assert(sizeof(BVHNode8) == 80, "BVHNode8 is 80 bytes on the device");
 
+// 4-wide BVH node, SoA over the (up to) four children (Src/BVH/BVH.h:25-57): count > 0 leaf with
+// `count` primitives from `index`, count == 0 inner node `index`, count == -1 unused slot.
+struct BVHNode4 {
+	float aabb_min_x[4], aabb_min_y[4], aabb_min_z[4];
+	float aabb_max_x[4], aabb_max_y[4], aabb_max_z[4];
+	struct { int index, count; } index_and_count[4];
+
+	int & get_index(int i)       { return index_and_count[i].index; }
+	int   get_index(int i) const { return index_and_count[i].index; }
+	int & get_count(int i)       { return index_and_count[i].count; }
+	int   get_count(int i) const { return index_and_count[i].count; }
+	bool  is_leaf(int i) const   { return get_count(i) > 0; }
+	int   get_child_count() const { int n = 0; for (int i = 0; i < 4; i++) { if (get_count(i) == -1) break; n++; } return n; }
+};
+static_assert(sizeof(BVHNode4) == 128, "BVHNode4 is 128 bytes on the device");
+
 struct BVH2 {
 	std::vector<int>      indices;
 	std::vector<BVHNode2> nodes;
+};
+
+struct BVH4 {
+	std::vector<int>      indices;
+	std::vector<BVHNode4> nodes;
 };
 
 struct BVH8 {
@@ -90,6 +111,21 @@ private:
 	void assign_octant_slots(int node_index, int children[8], int child_count);
 	int  emit_leaf_indices(int node_index);
 	void emit_node(int out_index, int bvh2_index);
+};
+
+// Greedy top-down collapse of the binary BVH into 4-wide nodes (Converters/BVH4Converter.cpp:3-148):
+// node i of the binary tree becomes 4-wide node i holding its two children; a node then repeatedly
+// adopts the children of its largest (half-area) inner child while they fit. Node 1 is the entry
+// point whose only child is the root; nodes that were adopted away stay in the array unused.
+struct BVH4Converter {
+	BVH4       & bvh4;
+	const BVH2 & bvh2;
+
+	BVH4Converter(BVH4 & bvh4, const BVH2 & bvh2) : bvh4(bvh4), bvh2(bvh2) { }
+	void convert();
+
+private:
+	void collapse(int node_index);
 };
 
 namespace BVH {

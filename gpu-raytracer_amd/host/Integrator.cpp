@@ -121,6 +121,25 @@ void Integrator::init_geometry() {
 	tlas_builder = std::make_unique<SAHBuilder>(tlas_raw, mesh_count);
 	tlas_converter = std::make_unique<BVH8Converter>(tlas, tlas_raw);
 
+	if (cpu_config.bvh_type == BVHType::BVH4) { // reference: Integrator.cpp:216-251
+		aggregated_bvh_nodes_4.assign(node_total, BVHNode4());
+		memset((void *)aggregated_bvh_nodes_4.data(), 0, node_total * sizeof(BVHNode4));
+		for (size_t m = 0; m < mesh_data_count; m++) {
+			const std::vector<BVHNode4> & nodes = mesh_datas[m].bvh4.nodes;
+			BVHNode4 * dst = aggregated_bvh_nodes_4.data() + mesh_data_bvh_offsets[m];
+			for (size_t n = 0; n < nodes.size(); n++) {
+				dst[n] = nodes[n];
+				int child_count = dst[n].get_child_count();
+				for (int c = 0; c < child_count; c++) {
+					if (dst[n].is_leaf(c)) dst[n].get_index(c) += mesh_data_index_offsets[m];
+					else                   dst[n].get_index(c) += mesh_data_bvh_offsets[m];
+				}
+			}
+		}
+		if (ctx) check(rt_upload_geometry_bvh4(ctx, aggregated_triangles.data(), aggregated_triangles.size(), aggregated_bvh_nodes_4.data(), aggregated_bvh_nodes_4.size()));
+		if (ctx) check(rt_set_bvh_type(ctx, 4));
+		return;
+	}
 	if (use_bvh8) {
 		aggregated_bvh_nodes_8.assign(node_total, BVHNode8());
 		memset(aggregated_bvh_nodes_8.data(), 0, node_total * sizeof(BVHNode8));
@@ -169,7 +188,13 @@ void Integrator::build_tlas() {
 	size_t mesh_count = scene.meshes.size();
 	bool use_bvh8 = cpu_config.bvh_type == BVHType::BVH8;
 	const std::vector<int> * leaf_order;
-	if (use_bvh8) {
+	if (cpu_config.bvh_type == BVHType::BVH4) {
+		BVH4Converter(tlas_4, tlas_raw).convert();
+		memcpy((void *)aggregated_bvh_nodes_4.data(), tlas_4.nodes.data(), tlas_4.nodes.size() * sizeof(BVHNode4));
+		if (ctx) check(rt_upload_tlas_bvh4(ctx, tlas_4.nodes.data(), tlas_4.nodes.size()));
+		tlas.indices = tlas_4.indices;
+		leaf_order = &tlas_4.indices;
+	} else if (use_bvh8) {
 		tlas_converter->convert();
 		memcpy(aggregated_bvh_nodes_8.data(), tlas.nodes.data(), tlas.nodes.size() * sizeof(BVHNode8));
 		if (ctx) check(rt_upload_tlas(ctx, tlas.nodes.data(), tlas.nodes.size()));

@@ -63,6 +63,7 @@ struct Integrator {
 	std::vector<DeviceTriangle> aggregated_triangles;
 	std::vector<BVHNode8>       aggregated_bvh_nodes_8;   // slots [0, 2*meshes) = TLAS
 	std::vector<BVHNode2>       aggregated_bvh_nodes_2;   // same layout, binary BVH
+	std::vector<BVHNode4>       aggregated_bvh_nodes_4;   // same layout, 4-wide BVH
 	std::vector<int>            reverse_indices;          // original triangle -> position in aggregated_triangles
 	std::vector<int>            mesh_data_bvh_offsets;
 	std::vector<int>            mesh_data_triangle_offsets;
@@ -78,6 +79,7 @@ struct Integrator {
 
 	BVH2 tlas_raw;
 	BVH8 tlas;                                   // tlas.indices[i] = scene mesh index of TLAS leaf i
+	BVH4 tlas_4;                                 // bvh_type = BVH4
 	std::unique_ptr<SAHBuilder>    tlas_builder;
 	std::unique_ptr<BVH8Converter> tlas_converter;
 

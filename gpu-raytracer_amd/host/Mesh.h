@@ -12,6 +12,7 @@ struct MeshData {
 	std::vector<Triangle> triangles;
 	BVH2 bvh2; // binary SAH BVH, one triangle per leaf
 	BVH8 bvh8; // its CWBVH collapse
+	BVH4 bvh4; // its 4-wide collapse (bvh_type = BVH4)
 };
 
 struct Scene;

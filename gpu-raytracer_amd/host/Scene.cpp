@@ -76,6 +76,7 @@ static void build_blas(MeshData & mesh_data) {
 	}
 	mesh_data.bvh2 = BVH::create_from_triangles(mesh_data.triangles);
 	BVH8Converter(mesh_data.bvh8, mesh_data.bvh2).convert();
+	BVH4Converter(mesh_data.bvh4, mesh_data.bvh2).convert();
 }
 
 Handle<MeshData> AssetManager::add_mesh_data(std::vector<Triangle> triangles) {

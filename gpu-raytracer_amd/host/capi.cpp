@@ -36,7 +36,7 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "sigma_n")                             gpu_config.sigma_n = float(value);
 	else if (k == "sigma_l")                             gpu_config.sigma_l = float(value);
 	else if (k == "aov_mask")                            gpu_config.aov_mask = unsigned(value);
-	else if (k == "bvh_type")                            cpu_config.bvh_type = int(value) == 2 ? BVHType::BVH : BVHType::BVH8;
+	else if (k == "bvh_type")                            cpu_config.bvh_type = int(value) == 2 ? BVHType::BVH : (int(value) == 4 ? BVHType::BVH4 : BVHType::BVH8);
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
 	else if (k == "initial_height")                      cpu_config.initial_height = int(value);
 	else { g_host_error = "unknown config key '" + k + "'"; return -1; }
@@ -115,6 +115,8 @@ const void * grt_mesh_data_array(void * scene, int mesh_data, const char * name,
 	if (n == "triangles")    RET(md.triangles)
 	if (n == "bvh2_nodes")   RET(md.bvh2.nodes)
 	if (n == "bvh2_indices") RET(md.bvh2.indices)
+	if (n == "bvh4_nodes")   RET(md.bvh4.nodes)
+	if (n == "bvh4_indices") RET(md.bvh4.indices)
 	if (n == "bvh8_nodes")   RET(md.bvh8.nodes)
 	if (n == "bvh8_indices") RET(md.bvh8.indices)
 	*bytes = 0;
@@ -225,6 +227,7 @@ const void * grt_pathtracer_array(void * pt, const char * name, size_t * bytes) 
 	if (n == "triangles")             RET(p->aggregated_triangles)
 	if (n == "bvh8_nodes")            RET(p->aggregated_bvh_nodes_8)
 	if (n == "bvh2_nodes")            RET(p->aggregated_bvh_nodes_2)
+	if (n == "bvh4_nodes")            RET(p->aggregated_bvh_nodes_4)
 	if (n == "reverse_indices")       RET(p->reverse_indices)
 	if (n == "mesh_bvh_root_indices") RET(p->mesh_bvh_root_indices)
 	if (n == "mesh_material_ids")     RET(p->mesh_material_ids)
@@ -282,6 +285,7 @@ void * grt_build_blas(const float * tris24, int n) {
 		memcpy((void *)md->triangles.data(), tris24, size_t(n) * sizeof(Triangle));
 		md->bvh2 = BVH::create_from_triangles(md->triangles);
 		BVH8Converter(md->bvh8, md->bvh2).convert();
+		BVH4Converter(md->bvh4, md->bvh2).convert();
 		return md;
 	GRT_CATCH(nullptr)
 }
@@ -291,6 +295,8 @@ const void * grt_built_array(void * mesh_data, const char * name, size_t * bytes
 #define RET(vec) { *bytes = (vec).size() * sizeof((vec)[0]); return (vec).data(); }
 	if (n == "bvh2_nodes")   RET(md.bvh2.nodes)
 	if (n == "bvh2_indices") RET(md.bvh2.indices)
+	if (n == "bvh4_nodes")   RET(md.bvh4.nodes)
+	if (n == "bvh4_indices") RET(md.bvh4.indices)
 	if (n == "bvh8_nodes")   RET(md.bvh8.nodes)
 	if (n == "bvh8_indices") RET(md.bvh8.indices)
 #undef RET

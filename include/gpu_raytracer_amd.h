@@ -139,7 +139,13 @@ int rt_upload_tlas(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_c
 int rt_upload_geometry_bvh2(rt_context * ctx, const void * triangles, size_t triangle_count,
                             const void * bvh2_nodes, size_t node_count);
 int rt_upload_tlas_bvh2(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count);
-int rt_set_bvh_type(rt_context * ctx, int bvh_width /* 2 or 8 */);
+/* Replaces `bvh4_nodes` (Integrator.cpp:216-251): 4-wide BVH, 128 B nodes (BVH/BVH.h:25-57), node 1
+ * of the TLAS and of every BLAS is the entry point; for rt_set_bvh_type(ctx, 4).            */
+int rt_upload_geometry_bvh4(rt_context * ctx, const void * triangles, size_t triangle_count,
+                            const void * bvh4_nodes, size_t node_count);
+int rt_upload_tlas_bvh4(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count);
+/* Selects the trace kernels (kernel_trace_bvh2 / bvh4 / bvh8 of the reference, Pathtracer.cpp:115-135). */
+int rt_set_bvh_type(rt_context * ctx, int bvh_width /* 2, 4 or 8 */);
 /* Replaces mesh_bvh_root_indices / mesh_material_ids / mesh_transforms{,_inv,_prev}
  * (Integrator.cpp:412-429). Index = TLAS-order mesh id. Matrices are 12 floats, row-major
  * 3x4.  MSB of root_indices[i] = "identity transform" (Integrator.cpp:415).              */

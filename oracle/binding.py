@@ -40,7 +40,7 @@ class OracleTexture(Structure):
 class OracleScene(Structure):
     _fields_ = [
         ("triangles", c_void_p), ("triangle_count", c_int32),
-        ("bvh8_nodes", c_void_p), ("bvh2_nodes", c_void_p), ("bvh_type", c_int32),
+        ("bvh8_nodes", c_void_p), ("bvh2_nodes", c_void_p), ("bvh4_nodes", c_void_p), ("bvh_type", c_int32),
         ("mesh_bvh_root_indices", c_void_p), ("mesh_material_ids", c_void_p),
         ("mesh_transforms", c_void_p), ("mesh_transforms_inv", c_void_p), ("mesh_transforms_prev", c_void_p), ("mesh_count", c_int32),
         ("material_types", c_void_p), ("materials", c_void_p), ("material_count", c_int32),
@@ -122,6 +122,9 @@ def ref_lib():
             getattr(r, f).argtypes = [c_void_p]
         for f in ("ref_bvh2_copy_nodes", "ref_bvh2_copy_indices", "ref_bvh8_copy_nodes", "ref_bvh8_copy_indices"):
             getattr(r, f).argtypes = [c_void_p, c_void_p]
+        if hasattr(r, "ref_bvh4_node_count"):
+            r.ref_bvh4_node_count.argtypes = [c_void_p]
+            r.ref_bvh4_copy_nodes.argtypes = [c_void_p, c_void_p]
         for f in ("ref_bvh_ms_bvh2", "ref_bvh_ms_bvh8"):
             getattr(r, f).argtypes = [c_void_p]
             getattr(r, f).restype = ctypes.c_double
@@ -141,6 +144,8 @@ def ref_build(tris24):
     out["bvh8_nodes"] = np.zeros(n8 * 80, np.uint8); r.ref_bvh8_copy_nodes(h, out["bvh8_nodes"].ctypes.data)
     out["bvh2_indices"] = np.zeros(r.ref_bvh2_index_count(h), np.int32); r.ref_bvh2_copy_indices(h, out["bvh2_indices"].ctypes.data)
     out["bvh8_indices"] = np.zeros(r.ref_bvh8_index_count(h), np.int32); r.ref_bvh8_copy_indices(h, out["bvh8_indices"].ctypes.data)
+    if hasattr(r, "ref_bvh4_node_count"):
+        out["bvh4_nodes"] = np.zeros(r.ref_bvh4_node_count(h) * 128, np.uint8); r.ref_bvh4_copy_nodes(h, out["bvh4_nodes"].ctypes.data)
     out["ms_bvh2"], out["ms_bvh8"] = r.ref_bvh_ms_bvh2(h), r.ref_bvh_ms_bvh8(h)
     r.ref_bvh_free(h)
     return out
@@ -160,7 +165,7 @@ class SceneView:
             return a.ctypes.data if a.size else None
 
         s.triangles = arr("triangles"); s.triangle_count = self.keep["triangles"].size // 24
-        s.bvh8_nodes = arr("bvh8_nodes"); s.bvh2_nodes = arr("bvh2_nodes"); s.bvh_type = bvh_type
+        s.bvh8_nodes = arr("bvh8_nodes"); s.bvh2_nodes = arr("bvh2_nodes"); s.bvh4_nodes = arr("bvh4_nodes"); s.bvh_type = bvh_type
         s.mesh_bvh_root_indices = arr("mesh_bvh_root_indices"); s.mesh_material_ids = arr("mesh_material_ids")
         s.mesh_transforms = arr("mesh_transforms"); s.mesh_transforms_inv = arr("mesh_transforms_inv"); s.mesh_transforms_prev = arr("mesh_transforms_prev")
         s.mesh_count = self.keep["mesh_material_ids"].size

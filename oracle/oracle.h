@@ -42,7 +42,8 @@ typedef struct oracle_scene {
 	int32_t         triangle_count;
 	const uint8_t * bvh8_nodes;           /* 80 B each (may be NULL when bvh_type == 2)     */
 	const uint8_t * bvh2_nodes;           /* 32 B each (may be NULL when bvh_type == 8)     */
-	int32_t         bvh_type;             /* 8 or 2                                         */
+	const uint8_t * bvh4_nodes;           /* 128 B each (only needed when bvh_type == 4)    */
+	int32_t         bvh_type;             /* 8, 4 or 2                                      */
 
 	const int32_t * mesh_bvh_root_indices;
 	const int32_t * mesh_material_ids;

@@ -357,6 +357,95 @@ inline bool bvh2_traverse(const oracle_scene & s, Ray ray, float max_distance, R
 	}
 }
 
+
+// ---- BVH4 (CUDA/Raytracing/BVH4.h:4-295) ------------------------------------------------------
+
+struct Node4 { float min_x[4], min_y[4], min_z[4], max_x[4], max_y[4], max_z[4]; int index_and_count[4][2]; };
+
+struct AABBHits4 { float t_near[4]; bool hit[4]; };
+
+// bvh4_node_intersect (BVH4.h:22-67) with t = (plane - origin) * inv_dir (the arithmetic contract of
+// this repository): slab test of the four children, then the near distances are tagged with
+// the child id in their two low mantissa bits and sorted in descending order.
+inline AABBHits4 bvh4_node_intersect(const Node4 & n, const Ray & ray, float3 inv_dir, float max_distance) {
+	AABBHits4 r;
+	for (int i = 0; i < 4; i++) {
+		float t0x = (n.min_x[i] - ray.origin.x) * inv_dir.x, t1x = (n.max_x[i] - ray.origin.x) * inv_dir.x;
+		float t0y = (n.min_y[i] - ray.origin.y) * inv_dir.y, t1y = (n.max_y[i] - ray.origin.y) * inv_dir.y;
+		float t0z = (n.min_z[i] - ray.origin.z) * inv_dir.z, t1z = (n.max_z[i] - ray.origin.z) * inv_dir.z;
+		r.t_near[i] = fmaxf(fminf(t0x, t1x), fmaxf(fminf(t0y, t1y), fmaxf(fminf(t0z, t1z), 0.0f)));
+		float t_far = fminf(fmaxf(t0x, t1x), fminf(fmaxf(t0y, t1y), fminf(fmaxf(t0z, t1z), max_distance)));
+		r.hit[i] = r.t_near[i] < t_far;
+	}
+	for (int i = 0; i < 4; i++) r.t_near[i] = uint_as_float((float_as_uint(r.t_near[i]) & 0xfffffffcu) | unsigned(i));
+	for (int i = 1; i < 4; i++) for (int j = i - 1; j >= 0; j--) if (r.t_near[j] < r.t_near[j + 1]) { float t = r.t_near[j]; r.t_near[j] = r.t_near[j + 1]; r.t_near[j + 1] = t; }
+	return r;
+}
+
+template<bool SHADOW>
+inline bool bvh4_traverse(const oracle_scene & s, Ray ray, float max_distance, RayHit & ray_hit, Counters & c) {
+	unsigned stack[ORACLE_STACK_SIZE];
+	int stack_size = 1;
+	stack[0] = 1; // node 1, child 0: the entry point whose child is the root (BVH4Converter.cpp:8-12)
+
+	Ray ray_untransformed = ray;
+	float3 inv_dir = reciprocal(ray.direction);
+
+	int  tlas_stack_size = RT_INVALID;
+	int  mesh_id = 0;
+	bool mesh_has_identity_transform = true;
+
+	const Node4 * nodes = reinterpret_cast<const Node4 *>(s.bvh4_nodes);
+
+	while (true) {
+		if (stack_size == tlas_stack_size) {
+			tlas_stack_size = RT_INVALID;
+			if (!mesh_has_identity_transform) { ray = ray_untransformed; inv_dir = reciprocal(ray.direction); }
+		}
+		unsigned packed = stack[--stack_size];
+		int node_index = int(packed & 0x3fffffffu), node_id = int(packed >> 30);
+		int index = nodes[node_index].index_and_count[node_id][0];
+		int count = nodes[node_index].index_and_count[node_id][1];
+
+		if (count > 0) {
+			if (tlas_stack_size == RT_INVALID) {
+				tlas_stack_size = stack_size;
+				mesh_id = index;
+				unsigned root = unsigned(s.mesh_bvh_root_indices[mesh_id]);
+				mesh_has_identity_transform = root >> 31;
+				if (!mesh_has_identity_transform) {
+					const float * m = s.mesh_transforms_inv + size_t(mesh_id) * 12;
+					ray.origin    = transform_position (m, ray.origin);
+					ray.direction = transform_direction(m, ray.direction);
+					inv_dir = reciprocal(ray.direction);
+					c.inst_xform++;
+				} else c.inst_ident++;
+				stack[stack_size++] = (root & 0x7fffffffu) + 1u; // the BLAS's own entry node
+			} else {
+				for (int j = index; j < index + count; j++) {
+					c.triangles++;
+					if (SHADOW) { if (triangle_intersect_shadow(s, j, ray, max_distance)) return true; }
+					else triangle_intersect(s, mesh_id, j, ray, ray_hit);
+				}
+			}
+		} else {
+			int child = index;
+			Node4 node;
+			memcpy(&node, &nodes[child], sizeof(Node4));
+			c.nodes++;
+			AABBHits4 hits = bvh4_node_intersect(node, ray, inv_dir, SHADOW ? max_distance : ray_hit.t);
+			for (int i = 0; i < 4; i++) {
+				int id = int(float_as_uint(hits.t_near[i]) & 3u);
+				if (hits.hit[id]) {
+					if (stack_size + 1 > ORACLE_STACK_SIZE) { fprintf(stderr, "oracle: traversal stack overflow\n"); abort(); }
+					stack[stack_size++] = (unsigned(id) << 30) | unsigned(child);
+				}
+			}
+		}
+		if (stack_size == 0) return false;
+	}
+}
+
 inline void store_hit(uint32_t * out, const RayHit & h) { // Buffers.h:25-32
 	uint32_t uv = uint32_t(int(h.u * 65535.0f)) | (uint32_t(int(h.v * 65535.0f)) << 16);
 	out[0] = uint32_t(h.mesh_id); out[1] = uint32_t(h.triangle_id); out[2] = float_as_uint(h.t); out[3] = uv;
@@ -369,7 +458,7 @@ void oracle_trace_one(const oracle_scene & s, float3 origin, float3 direction, u
 	Ray ray = { origin, direction };
 	RayHit hit; hit.t = INFINITY; hit.u = 0.0f; hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
 	Counters c;
-	if (s.bvh_type == 2) bvh2_traverse<false>(s, ray, 0.0f, hit, c); else bvh8_traverse<false>(s, ray, 0.0f, hit, c);
+	if (s.bvh_type == 2) bvh2_traverse<false>(s, ray, 0.0f, hit, c); else if (s.bvh_type == 4) bvh4_traverse<false>(s, ray, 0.0f, hit, c); else bvh8_traverse<false>(s, ray, 0.0f, hit, c);
 	store_hit(hit4, hit);
 	if (stats) { stats->nodes += c.nodes; stats->triangles += c.triangles; stats->instances_transformed += c.inst_xform; stats->instances_identity += c.inst_ident; stats->rays++; }
 }
@@ -378,7 +467,7 @@ bool oracle_trace_shadow_one(const oracle_scene & s, float3 origin, float3 direc
 	Ray ray = { origin, direction };
 	RayHit hit; hit.t = INFINITY; hit.u = hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
 	Counters c;
-	bool occluded = s.bvh_type == 2 ? bvh2_traverse<true>(s, ray, max_distance, hit, c) : bvh8_traverse<true>(s, ray, max_distance, hit, c);
+	bool occluded = s.bvh_type == 2 ? bvh2_traverse<true>(s, ray, max_distance, hit, c) : (s.bvh_type == 4 ? bvh4_traverse<true>(s, ray, max_distance, hit, c) : bvh8_traverse<true>(s, ray, max_distance, hit, c));
 	if (stats) { stats->nodes += c.nodes; stats->triangles += c.triangles; stats->instances_transformed += c.inst_xform; stats->instances_identity += c.inst_ident; stats->rays++; }
 	return occluded;
 }

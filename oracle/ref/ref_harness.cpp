@@ -9,10 +9,12 @@
 // Entry points used: BVH::create_from_triangles  (Src/BVH/BVH.cpp:14-36)
 //                    BVH8Converter::convert       (Src/BVH/Converters/BVH8Converter.cpp:7-22)
 //                    SAHBuilder::build(meshes)    (Src/BVH/Builders/SAHBuilder.cpp:102-104)
+//                    BVH4Converter::convert       (Src/BVH/Converters/BVH4Converter.cpp:3-78)
 #include "Core/Format.h"
 #include "BVH/BVH.h"
 #include "BVH/Builders/SAHBuilder.h"
 #include "BVH/Converters/BVH8Converter.h"
+#include "BVH/Converters/BVH4Converter.h"
 #include "Renderer/Mesh.h"
 
 #include <vector>
@@ -43,10 +45,12 @@ Mesh::Mesh(String name, Handle<MeshData> mesh_data_handle, Handle<Material> mate
 static_assert(sizeof(Triangle) == 96, "reference host Triangle is 24 floats");
 static_assert(sizeof(BVHNode2) == 32, "BVHNode2");
 static_assert(sizeof(BVHNode8) == 80, "BVHNode8");
+static_assert(sizeof(BVHNode4) == 128, "BVHNode4");
 
 struct RefBVH {
 	BVH2 bvh2;
 	BVH8 bvh8;
+	BVH4 bvh4;
 	double ms_bvh2 = 0.0, ms_bvh8 = 0.0;
 };
 
@@ -70,6 +74,7 @@ void * ref_bvh_build_triangles(const float * tris24, int n) {
 	double t1 = now_ms();
 	BVH8Converter(r->bvh8, r->bvh2).convert();
 	double t2 = now_ms();
+	BVH4Converter(r->bvh4, r->bvh2).convert();
 	r->ms_bvh2 = t1 - t0;
 	r->ms_bvh8 = t2 - t1;
 	return r;
@@ -93,11 +98,14 @@ void * ref_bvh_build_meshes(const float * aabbs6, int n) {
 	double t1 = now_ms();
 	BVH8Converter(r->bvh8, r->bvh2).convert();
 	double t2 = now_ms();
+	BVH4Converter(r->bvh4, r->bvh2).convert();
 	r->ms_bvh2 = t1 - t0;
 	r->ms_bvh8 = t2 - t1;
 	return r;
 }
 
+int  ref_bvh4_node_count (void * h) { return int(((RefBVH *)h)->bvh4.nodes.size()); }
+void ref_bvh4_copy_nodes  (void * h, void * dst) { RefBVH * r = (RefBVH *)h; memcpy(dst, r->bvh4.nodes.data(), r->bvh4.nodes.size() * sizeof(BVHNode4)); }
 int  ref_bvh2_node_count (void * h) { return int(((RefBVH *)h)->bvh2.nodes.size()); }
 int  ref_bvh2_index_count(void * h) { return int(((RefBVH *)h)->bvh2.indices.size()); }
 int  ref_bvh8_node_count (void * h) { return int(((RefBVH *)h)->bvh8.nodes.size()); }

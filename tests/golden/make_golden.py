@@ -2,7 +2,7 @@
 """Regenerates the golden fixtures. Needs /root/reference (for oracle/_ref) -- run in the build
 container only; the fixtures it writes are what travels to the GPU box.
 
-bvh_golden.json   sha256 of the BVH2 nodes / BVH8 nodes / BVH8 indices that the REFERENCE'S OWN
+bvh_golden.json   sha256 of the BVH2 nodes / BVH8 nodes / BVH8 indices (and, separately, the BVH4 nodes) that the REFERENCE'S OWN
                   builder (oracle/_ref/libref_bvh.so = /root/reference/Src/BVH compiled verbatim)
                   produces for every Cornell mesh, every Sponza mesh (one aggregate digest plus the
                   10 largest individually) and three seeded random triangle soups.
@@ -45,6 +45,7 @@ def main():
         scene = grt.Scene(grt.scene_path(name))
         scene.wait_until_loaded()
         agg = hashlib.sha256()
+        agg4 = hashlib.sha256()
         sizes = []
         per_mesh = []
         for m in range(scene.mesh_data_count):
@@ -52,9 +53,10 @@ def main():
             ref = oracle.ref_build(tris)
             d = digest(ref["bvh2_nodes"], ref["bvh2_indices"], ref["bvh8_nodes"], ref["bvh8_indices"])
             agg.update(d.encode())
+            agg4.update(digest(ref["bvh4_nodes"]).encode())
             per_mesh.append(d)
             sizes.append(tris.size // 24)
-        entry = {"mesh_data_count": scene.mesh_data_count, "aggregate": agg.hexdigest(), "triangles": int(sum(sizes))}
+        entry = {"mesh_data_count": scene.mesh_data_count, "aggregate": agg.hexdigest(), "aggregate_bvh4": agg4.hexdigest(), "triangles": int(sum(sizes))}
         order = np.argsort(sizes)[::-1][:10] if name == "sponza" else range(scene.mesh_data_count)
         entry["individual"] = {str(int(m)): {"triangles": int(sizes[m]), "sha256": per_mesh[m]} for m in order}
         golden["meshes"][name] = entry
@@ -64,6 +66,7 @@ def main():
         ref = oracle.ref_build(soup(seed, n))
         golden["soups"]["%d_%d" % (seed, n)] = {
             "sha256": digest(ref["bvh2_nodes"], ref["bvh2_indices"], ref["bvh8_nodes"], ref["bvh8_indices"]),
+            "sha256_bvh4": digest(ref["bvh4_nodes"]),
             "bvh2_nodes": int(ref["bvh2_nodes"].size // 32), "bvh8_nodes": int(ref["bvh8_nodes"].size // 80)}
     json.dump(golden, open(os.path.join(HERE, "bvh_golden.json"), "w"), indent=1, sort_keys=True)
 

@@ -38,7 +38,7 @@ def product_build(grt, tris24):
     h = lib.grt_build_blas(t.ctypes.data, t.size // 24)
     assert h
     out = {}
-    for name, dtype in (("bvh2_nodes", np.uint8), ("bvh2_indices", np.int32), ("bvh8_nodes", np.uint8), ("bvh8_indices", np.int32)):
+    for name, dtype in (("bvh2_nodes", np.uint8), ("bvh2_indices", np.int32), ("bvh8_nodes", np.uint8), ("bvh8_indices", np.int32), ("bvh4_nodes", np.uint8)):
         n = ctypes.c_size_t()
         ptr = lib.grt_built_array(h, name.encode(), ctypes.byref(n))
         out[name] = np.frombuffer((ctypes.c_char * n.value).from_address(ptr), dtype=dtype).copy()
@@ -53,6 +53,7 @@ def test_triangle_soups_match_reference_digest(grt, key):
     assert built["bvh2_nodes"].size // 32 == GOLDEN["soups"][key]["bvh2_nodes"]
     assert built["bvh8_nodes"].size // 80 == GOLDEN["soups"][key]["bvh8_nodes"]
     assert digest(built["bvh2_nodes"], built["bvh2_indices"], built["bvh8_nodes"], built["bvh8_indices"]) == GOLDEN["soups"][key]["sha256"]
+    assert digest(built["bvh4_nodes"]) == GOLDEN["soups"][key]["sha256_bvh4"]   # BVH4Converter.cpp, 128-B nodes
 
 
 @pytest.mark.parametrize("scene_name", ["cornellbox", "sponza"])
@@ -63,13 +64,16 @@ def test_scene_blas_match_reference_digest(grt, scene_name):
     want = GOLDEN["meshes"][scene_name]
     assert scene.mesh_data_count == want["mesh_data_count"]
     agg = hashlib.sha256()
+    agg4 = hashlib.sha256()
     for m in range(scene.mesh_data_count):
         d = digest(scene.mesh_data_array(m, "bvh2_nodes", np.uint8), scene.mesh_data_array(m, "bvh2_indices", np.int32),
                    scene.mesh_data_array(m, "bvh8_nodes", np.uint8), scene.mesh_data_array(m, "bvh8_indices", np.int32))
         agg.update(d.encode())
+        agg4.update(digest(scene.mesh_data_array(m, "bvh4_nodes", np.uint8)).encode())
         if str(m) in want["individual"]:
             assert d == want["individual"][str(m)]["sha256"], "mesh %d" % m
     assert agg.hexdigest() == want["aggregate"]
+    assert agg4.hexdigest() == want["aggregate_bvh4"]
     scene.close()
 
 
@@ -79,7 +83,7 @@ def test_live_against_reference_builder(grt, oracle):
     for seed, n in ((11, 3), (12, 257), (13, 5000)):
         tris = soup(seed, n)
         ref, built = oracle.ref_build(tris), product_build(grt, tris)
-        for key in ("bvh2_nodes", "bvh2_indices", "bvh8_nodes", "bvh8_indices"):
+        for key in ("bvh2_nodes", "bvh2_indices", "bvh8_nodes", "bvh8_indices", "bvh4_nodes"):
             assert np.array_equal(ref[key], built[key]), key
 
 

@@ -111,14 +111,15 @@ def blob_obj(n):
     return "\n".join(lines) + "\n"
 
 
+@pytest.mark.parametrize("bvh_type", [2, 4])
 @pytest.mark.parametrize("scene_name,w,h", [("cornellbox", 256, 256), ("sponza", 480, 270)])
-def test_binary_bvh_trace_is_bit_exact_and_config_1_renders(grt, oracle, scene_name, w, h):
-    """bvh_type = BVH (BVH2.h, BASELINE config #1 on the device): primary and incoherent rays through
-    kernel_trace_bvh2 give the oracle's hits bit for bit (the host permutes the triangles by the BVH2
-    indices, so ids differ from the CWBVH run but t / u / v of primary hits agree with it), shadow rays
-    agree, and a full frame matches the oracle's render."""
-    scene, pt = make_pathtracer(grt, scene_name, w, h, 0, bvh_type=2, num_bounces=4)
-    view = oracle.SceneView(pt, bvh_type=2)
+def test_binary_and_4_wide_bvh_trace_is_bit_exact_and_config_1_renders(grt, oracle, scene_name, w, h, bvh_type):
+    """bvh_type = BVH (BVH2.h, BASELINE config #1 on the device) and BVH4 (BVH4.h): primary and
+    incoherent rays through kernel_trace_bvh2 / kernel_trace_bvh4 give the oracle's hits bit for bit
+    (the host permutes the triangles by the BVH2 indices, so ids differ from the CWBVH run), shadow
+    rays agree, and a full frame matches the oracle's render."""
+    scene, pt = make_pathtracer(grt, scene_name, w, h, 0, bvh_type=bvh_type, num_bounces=4)
+    view = oracle.SceneView(pt, bvh_type=bvh_type)
     o, d, _ = view.generate(0, 0, w * h)
     hits_cpu, stats = view.trace(o, d)
     hits_gpu, _ = grt.trace_rays(pt.ctx, o, d)
@@ -138,8 +139,8 @@ def test_binary_bvh_trace_is_bit_exact_and_config_1_renders(grt, oracle, scene_n
     assert np.array_equal(occ_gpu.astype(bool), view.trace_shadow(origin, direction, max_dist)[0].astype(bool))
     pt.close(); scene.close()
     if scene_name == "cornellbox":   # BASELINE config #1: 512 x 512, one sample, binary SAH BVH
-        scene, pt = make_pathtracer(grt, "cornellbox", 512, 512, 0, bvh_type=2)
-        view = oracle.SceneView(pt, bvh_type=2); frame = oracle.Frame(view)
+        scene, pt = make_pathtracer(grt, "cornellbox", 512, 512, 0, bvh_type=bvh_type)
+        view = oracle.SceneView(pt, bvh_type=bvh_type); frame = oracle.Frame(view)
         pt.render(); c = pt.counters(); oc = frame.render_sample(pt.sample_index)
         nb = pt.device_config().num_bounces
         assert c.trace[0] == oc.trace[0] == 512 * 512

@@ -66,6 +66,15 @@ def test_bvh8_and_bvh2_traversal_agree_with_brute_force(grt, oracle):
     assert (occ.astype(bool) == expect).mean() > 0.999 and (occ8 == occ).all()
     pt.close(); scene.close()
 
+    # 4-wide BVH (BVH4.h): same closest hits, same occlusion; the host uses the BVH2 triangle order for it
+    scene, pt = make_pathtracer(grt, "cornellbox", 32, 32, -1, bvh_type=4)
+    view4 = oracle.SceneView(pt, bvh_type=4)
+    hits4, stats4 = view4.trace(O, D)
+    assert np.array_equal(hits4[:, 1:], hits2[:, 1:]) and stats4.nodes > 0   # triangle id, t bits, u/v: identical to the binary BVH
+    occ4, _ = view4.trace_shadow(O, D, md)
+    assert (occ4 == occ).all()
+    pt.close(); scene.close()
+
 
 def test_instanced_traversal_uses_object_space_rays(grt, oracle, tmp_path):
     """Non-identity instance: transform_inv applied without renormalising, so t is world distance (BVH8.h:222-228)."""

@@ -10,7 +10,7 @@ import gpu_raytracer_amd as grt
 def main():
     sizes = [int(a) for a in sys.argv[1:]] or [100_000, 777_600, 2_073_600, 8_000_000]
     grt.config_reset()
-    bvh_type = int(os.environ.get("BVH_TYPE", "8"))   # 8: CWBVH kernels, 2: binary-BVH kernels
+    bvh_type = int(os.environ.get("BVH_TYPE", "8"))   # 8: CWBVH kernels, 4: 4-wide BVH kernels, 2: binary-BVH kernels
     grt.config_set(bvh_type=bvh_type)
     scene = grt.Scene(grt.scene_path("sponza"))
     pt = grt.Pathtracer(scene, 1920, 1080, device=0); pt.update()
