@@ -11,6 +11,7 @@ libraries must have been built (``python __graft_entry__.py`` or ``make -C gpu-r
 there is no Python or CPU fallback for the device path.
 """
 import ctypes
+import fcntl
 import os
 import tarfile
 from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_void_p
@@ -185,12 +186,17 @@ def scene_path(name):
         raise KeyError("unknown bundled scene %r" % name)
     archive, xml = table[name]
     target = os.path.join(cache, xml)
-    if not os.path.exists(target):
-        os.makedirs(cache, exist_ok=True)
-        with tarfile.open(os.path.join(ASSET_DIR, "scenes", archive)) as tar:
-            tar.extractall(cache)
-    if name == "sponza":
-        _unpack_sponza_textures(cache)
+    os.makedirs(cache, exist_ok=True)
+    with open(os.path.join(cache, ".lock"), "w") as lock:   # the ranks of a multi-GPU job start together
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(target):
+                with tarfile.open(os.path.join(ASSET_DIR, "scenes", archive)) as tar:
+                    tar.extractall(cache)
+            if name == "sponza":
+                _unpack_sponza_textures(cache)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return target
 
 
