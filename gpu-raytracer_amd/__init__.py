@@ -124,6 +124,8 @@ def host_lib():
         lib.grt_scene_material_type.argtypes = [c_void_p, c_int]
         lib.grt_mesh_data_array.restype = c_void_p
         lib.grt_mesh_data_array.argtypes = [c_void_p, c_int, c_char_p, POINTER(c_size_t)]
+        lib.grt_scene_set_mesh_transform.argtypes = [c_void_p, c_int, POINTER(c_float), POINTER(c_float), c_float]
+        lib.grt_scene_get_mesh_transform.argtypes = [c_void_p, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_float)]
         lib.grt_pathtracer_create.restype = c_void_p
         lib.grt_pathtracer_create.argtypes = [c_void_p, c_int, c_int, c_int]
         lib.grt_ao_create.restype = c_void_p
@@ -290,6 +292,17 @@ class Scene:
 
     def set_sky_scale(self, scale):
         host_lib().grt_scene_set_sky_scale(self.handle, float(scale))
+
+    def mesh_transform(self, index):
+        """(position[3], rotation quaternion xyzw[4], scale) of mesh `index` (Mesh.h: position / rotation / scale)."""
+        pos, rot, scale = (c_float * 3)(), (c_float * 4)(), c_float()
+        _host_check(host_lib().grt_scene_get_mesh_transform(self.handle, index, pos, rot, byref(scale)))
+        return list(pos), list(rot), scale.value
+
+    def set_mesh_transform(self, index, position, rotation_xyzw, scale):
+        """Edit a mesh's transform as the reference's UI does; the next update() with invalidate("scene")
+        (or enable_scene_update) rebuilds the TLAS."""
+        _host_check(host_lib().grt_scene_set_mesh_transform(self.handle, index, (c_float * 3)(*position), (c_float * 4)(*rotation_xyzw), float(scale)))
 
     def set_material(self, index, mtype, diffuse=None, linear_roughness=0.5):
         d = (c_float * 3)(*diffuse) if diffuse is not None else None

@@ -322,7 +322,7 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 					unsigned relative_index = __popc(hits_imask & ~(0xffffffffu << slot_index));
 					unsigned child_node_index = child_index_base + relative_index;
 
-					const float4 * node = nodes + size_t(child_node_index) * 5;
+					const float4 * node = (child_node_index < unsigned(p.tlas_node_count) ? p.tlas_nodes : nodes) + size_t(child_node_index) * 5;
 					float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
 					if (COUNT) count_nodes++;
 #ifdef RT_PHASE_STATS
@@ -612,7 +612,8 @@ RT_DEV void bvh2_trace_persistent(const RtParams & p, Source & src, int ray_coun
 					}
 				}
 				unsigned node_index = stack.pop().x;
-				float4 a = nodes[size_t(node_index) * 2], b = nodes[size_t(node_index) * 2 + 1];
+				const float4 * node = (node_index < unsigned(p.tlas_node_count) ? p.tlas_nodes : nodes) + size_t(node_index) * 2;
+				float4 a = node[0], b = node[1];
 				int      left_or_first = __float_as_int(b.z);
 				unsigned count_axis    = __float_as_uint(b.w);
 				unsigned count = count_axis & 0x3fffffffu, axis = count_axis >> 30;
@@ -784,7 +785,7 @@ RT_DEV void bvh4_trace_persistent(const RtParams & p, Source & src, int ray_coun
 						tri_next = index; tri_end = index + count;
 					}
 				} else {
-					const float4 * node = nodes + size_t(index) * 8;
+					const float4 * node = (index < p.tlas_node_count ? p.tlas_nodes : nodes) + size_t(index) * 8;
 					float4 min_x = node[0], min_y = node[1], min_z = node[2], max_x = node[3], max_y = node[4], max_z = node[5], ic01 = node[6], ic23 = node[7];
 					float limit = SHADOW ? max_distance : hit.t;
 					float t_near[4]; unsigned hit_mask = 0;

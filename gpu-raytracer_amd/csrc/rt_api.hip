@@ -37,6 +37,7 @@ struct SampleSlot {
 	RtBufferSizes * pinned_counters = nullptr;
 	void * aov_framebuffer[RT_AOV_COUNT] = { };  // slots 1..: per-sample frame buffers (slot 0 uses ctx->aov_buffers[i][0])
 	int aov_samples = 1;                         // samples per batch the frame buffers of this slot are sized for
+	int tlas_version = -1, instance_version = -1, light_version = -1; // scene-ring versions the last submission of this slot reads
 	// SVGF g-buffers (normal+depth, mesh+triangle id, previous screen position) are written by the
 	// bounce-0 kernels of a frame and read by its filter stage: one set per slot lets frame n+1 be
 	// traced while frame n is filtered. Pixels that miss all geometry keep the value of the last
@@ -44,6 +45,22 @@ struct SampleSlot {
 	// its predecessor's set, taken as soon as that frame's bounce-0 shading is done (ev_gbuffers).
 	void * gbuffers[3] = { };                    // slots 1..; slot 0 uses ctx->svgf_buffers[0..2]
 	hipEvent_t ev_gbuffers = nullptr;
+};
+
+// Per-frame scene data (the TLAS and the five per-instance tables, rebuilt by Integrator::build_tlas for
+// every frame of an animated scene) lives in a ring of versions: an upload fills the next version
+// through pinned staging with an asynchronous copy, the kernels of later samples get its address (the
+// parameter block is passed by value), samples already in flight keep reading theirs. No upload of this
+// kind drains the pipeline; a version is only waited for when the ring wraps around onto a sample
+// that still uses it.
+#define RT_SCENE_VERSIONS 12
+struct SceneRing {
+	void * device[RT_SCENE_VERSIONS] = { };
+	void * pinned[RT_SCENE_VERSIONS] = { };
+	hipEvent_t copied[RT_SCENE_VERSIONS] = { };
+	size_t capacity = 0;   // bytes allocated per version (grows only)
+	size_t bytes = 0;      // bytes of the current version
+	int current = -1;
 };
 
 struct rt_context {
@@ -65,7 +82,9 @@ struct rt_context {
 	void * triangles = nullptr, * triangle_positions = nullptr, * bvh8_nodes = nullptr, * bvh2_nodes = nullptr, * bvh4_nodes = nullptr;
 	size_t bvh4_node_count = 0;
 	size_t bvh8_node_count = 0, bvh2_node_count = 0, triangle_count = 0;
-	void * instances[5] = { };     size_t mesh_count = 0;
+	size_t mesh_count = 0;
+	SceneRing tlas_ring, instance_ring, light_ring;
+	hipEvent_t ev_scene = nullptr;  // the last asynchronous scene upload on the main stream
 	void * material_types = nullptr, * materials = nullptr, * media = nullptr;
 	bool has_material[4] = { false, false, false, false };
 	bool has_lights = false;
@@ -200,6 +219,41 @@ static RtParams slot_params(const rt_context * ctx, const SampleSlot & slot, int
 	return p;
 }
 
+// Next version of a scene ring, sized `bytes`: returns its pinned staging buffer for the caller to fill;
+// ring_commit() then starts the copy. `which` selects the slot field that remembers the version in use.
+static int ring_begin(rt_context * ctx, SceneRing & ring, size_t bytes, int SampleSlot::* which, void ** staging) {
+	if (bytes == 0) bytes = 16;
+	if (bytes > ring.capacity) { // first use, or the scene outgrew the ring: start over (the only case that drains)
+		RT_HIP(ctx, quiesce(ctx));
+		size_t capacity = bytes + bytes / 2 + 256; // a TLAS changes its node count a little from frame to frame
+		for (int v = 0; v < RT_SCENE_VERSIONS; v++) {
+			device_free(ctx, ring.device[v]); ring.device[v] = nullptr;
+			if (ring.pinned[v]) { (void)hipHostFree(ring.pinned[v]); ring.pinned[v] = nullptr; }
+			int s = device_alloc(ctx, &ring.device[v], capacity); if (s) return s;
+			RT_HIP(ctx, hipHostMalloc(&ring.pinned[v], capacity));
+			if (!ring.copied[v]) RT_HIP(ctx, hipEventCreateWithFlags(&ring.copied[v], hipEventDisableTiming));
+		}
+		ring.capacity = capacity;
+		ring.current = -1;
+		for (SampleSlot & slot : ctx->slots) slot.*which = -1;
+	}
+	ring.bytes = bytes;
+	int v = (ring.current + 1) % RT_SCENE_VERSIONS;
+	for (SampleSlot & slot : ctx->slots) if (slot.created && slot.*which == v) { RT_HIP(ctx, hipEventSynchronize(slot.ev_done)); slot.*which = -1; }
+	if (ring.current >= 0) RT_HIP(ctx, hipEventSynchronize(ring.copied[v])); // its previous staging copy (recorded when it was last filled)
+	*staging = ring.pinned[v];
+	ring.current = v;
+	return RT_OK;
+}
+
+static int ring_commit(rt_context * ctx, SceneRing & ring) {
+	int v = ring.current;
+	RT_HIP(ctx, hipMemcpyAsync(ring.device[v], ring.pinned[v], ring.bytes, hipMemcpyHostToDevice, ctx->stream));
+	RT_HIP(ctx, hipEventRecord(ring.copied[v], ctx->stream));
+	RT_HIP(ctx, hipEventRecord(ctx->ev_scene, ctx->stream));
+	return RT_OK;
+}
+
 // the node array of the selected BVH type has been uploaded
 static bool bvh_nodes_present(const rt_context * ctx) {
 	const RtParams & p = ctx->params;
@@ -228,6 +282,8 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 	RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
 	RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
 	RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_interop, hipEventDisableTiming));
+	RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_scene, hipEventDisableTiming));
+	RT_HIP(ctx, hipEventRecord(ctx->ev_scene, ctx->stream));
 	if (const char * e = getenv("GRT_SAMPLES_IN_FLIGHT")) { int n = atoi(e); if (n >= 1 && n <= RT_MAX_SAMPLE_SLOTS) ctx->samples_in_flight = n; }
 	if (const char * e = getenv("GRT_OVERLAP_SHADOWS")) ctx->overlap_shadows = atoi(e) != 0;
 
@@ -262,6 +318,11 @@ void rt_destroy(rt_context * ctx) {
 	}
 	(void)hipEventDestroy(ctx->ev_main);
 	(void)hipEventDestroy(ctx->ev_interop);
+	(void)hipEventDestroy(ctx->ev_scene);
+	for (SceneRing * ring : { &ctx->tlas_ring, &ctx->instance_ring, &ctx->light_ring }) for (int v = 0; v < RT_SCENE_VERSIONS; v++) {
+		if (ring->pinned[v]) (void)hipHostFree(ring->pinned[v]);
+		if (ring->copied[v]) (void)hipEventDestroy(ring->copied[v]);
+	}
 	(void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -290,14 +351,22 @@ int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle
 	return RT_OK;
 }
 
+// TLAS of the selected BVH type: node_bytes = 80 (CWBVH), 32 (binary) or 128 (4-wide)
+static int upload_tlas_version(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count, size_t node_bytes) {
+	void * staging = nullptr;
+	int s = ring_begin(ctx, ctx->tlas_ring, tlas_node_count * node_bytes, &SampleSlot::tlas_version, &staging); if (s) return s;
+	memcpy(staging, tlas_nodes, tlas_node_count * node_bytes);
+	s = ring_commit(ctx, ctx->tlas_ring); if (s) return s;
+	ctx->params.tlas_nodes = (const float4 *)ctx->tlas_ring.device[ctx->tlas_ring.current];
+	ctx->params.tlas_node_count = int(tlas_node_count);
+	return RT_OK;
+}
+
 int rt_upload_tlas(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count) {
 	RT_REQUIRE(ctx, ctx && tlas_nodes, "rt_upload_tlas: NULL argument");
 	RT_REQUIRE(ctx, ctx->bvh8_nodes && tlas_node_count <= ctx->bvh8_node_count, "rt_upload_tlas: geometry not uploaded or TLAS larger than the node array");
 	(void)hipSetDevice(ctx->device);
-	RT_HIP(ctx, quiesce(ctx)); // samples in flight still traverse the old TLAS
-	RT_HIP(ctx, hipMemcpyAsync(ctx->bvh8_nodes, tlas_nodes, tlas_node_count * 80, hipMemcpyHostToDevice, ctx->stream));
-	RT_HIP(ctx, quiesce(ctx));
-	return RT_OK;
+	return upload_tlas_version(ctx, tlas_nodes, tlas_node_count, 80);
 }
 
 int rt_upload_geometry_bvh2(rt_context * ctx, const void * triangles, size_t triangle_count, const void * bvh2_nodes, size_t node_count) {
@@ -316,9 +385,7 @@ int rt_upload_tlas_bvh2(rt_context * ctx, const void * tlas_nodes, size_t tlas_n
 	RT_REQUIRE(ctx, ctx && tlas_nodes, "rt_upload_tlas_bvh2: NULL argument");
 	RT_REQUIRE(ctx, ctx->bvh2_nodes && tlas_node_count <= ctx->bvh2_node_count, "rt_upload_tlas_bvh2: geometry not uploaded or TLAS larger than the node array");
 	(void)hipSetDevice(ctx->device);
-	RT_HIP(ctx, quiesce(ctx));
-	RT_HIP(ctx, hipMemcpy(ctx->bvh2_nodes, tlas_nodes, tlas_node_count * 32, hipMemcpyHostToDevice));
-	return RT_OK;
+	return upload_tlas_version(ctx, tlas_nodes, tlas_node_count, 32);
 }
 
 int rt_upload_geometry_bvh4(rt_context * ctx, const void * triangles, size_t triangle_count, const void * bvh4_nodes, size_t node_count) {
@@ -337,9 +404,7 @@ int rt_upload_tlas_bvh4(rt_context * ctx, const void * tlas_nodes, size_t tlas_n
 	RT_REQUIRE(ctx, ctx && tlas_nodes, "rt_upload_tlas_bvh4: NULL argument");
 	RT_REQUIRE(ctx, ctx->bvh4_nodes && tlas_node_count <= ctx->bvh4_node_count, "rt_upload_tlas_bvh4: geometry not uploaded or TLAS larger than the node array");
 	(void)hipSetDevice(ctx->device);
-	RT_HIP(ctx, quiesce(ctx));
-	RT_HIP(ctx, hipMemcpy(ctx->bvh4_nodes, tlas_nodes, tlas_node_count * 128, hipMemcpyHostToDevice));
-	return RT_OK;
+	return upload_tlas_version(ctx, tlas_nodes, tlas_node_count, 128);
 }
 
 int rt_set_bvh_type(rt_context * ctx, int bvh_width) {
@@ -356,15 +421,22 @@ int rt_upload_instances(rt_context * ctx, const int32_t * root_indices, const in
                         const float * transforms, const float * transforms_inv, const float * transforms_prev, size_t mesh_count) {
 	RT_REQUIRE(ctx, ctx && root_indices && material_ids && transforms && transforms_inv && transforms_prev, "rt_upload_instances: NULL argument");
 	(void)hipSetDevice(ctx->device);
+	// one allocation per version: roots | material ids | transforms | inverse | previous (48-byte rows are 16-byte aligned)
+	size_t padded = (mesh_count + 3) / 4 * 4;
+	size_t offset[6] = { 0, padded * 4, padded * 8, padded * 8 + mesh_count * 48, padded * 8 + mesh_count * 96, padded * 8 + mesh_count * 144 };
 	const void * src[5] = { root_indices, material_ids, transforms, transforms_inv, transforms_prev };
 	size_t bytes[5] = { mesh_count * 4, mesh_count * 4, mesh_count * 48, mesh_count * 48, mesh_count * 48 };
-	for (int i = 0; i < 5; i++) { int s = upload(ctx, &ctx->instances[i], src[i], bytes[i]); if (s) return s; }
+	void * staging = nullptr;
+	int s = ring_begin(ctx, ctx->instance_ring, offset[5], &SampleSlot::instance_version, &staging); if (s) return s;
+	for (int i = 0; i < 5; i++) memcpy((char *)staging + offset[i], src[i], bytes[i]);
+	s = ring_commit(ctx, ctx->instance_ring); if (s) return s;
+	const char * base = (const char *)ctx->instance_ring.device[ctx->instance_ring.current];
 	ctx->mesh_count = mesh_count;
-	ctx->params.mesh_bvh_root_indices = (const int *)ctx->instances[0];
-	ctx->params.mesh_material_ids     = (const int *)ctx->instances[1];
-	ctx->params.mesh_transforms       = (const float4 *)ctx->instances[2];
-	ctx->params.mesh_transforms_inv   = (const float4 *)ctx->instances[3];
-	ctx->params.mesh_transforms_prev  = (const float4 *)ctx->instances[4];
+	ctx->params.mesh_bvh_root_indices = (const int *)(base + offset[0]);
+	ctx->params.mesh_material_ids     = (const int *)(base + offset[1]);
+	ctx->params.mesh_transforms       = (const float4 *)(base + offset[2]);
+	ctx->params.mesh_transforms_inv   = (const float4 *)(base + offset[3]);
+	ctx->params.mesh_transforms_prev  = (const float4 *)(base + offset[4]);
 	return RT_OK;
 }
 
@@ -430,14 +502,21 @@ int rt_upload_lights(rt_context * ctx,
                      const int32_t * light_mesh_transform_indices, size_t light_mesh_count, float lights_total_weight) {
 	RT_REQUIRE(ctx, ctx, "rt_upload_lights: NULL context");
 	(void)hipSetDevice(ctx->device);
+	// the per-mesh tables change with every TLAS rebuild (they are in TLAS order): versioned like the TLAS itself
 	const void * src[5] = { light_triangle_indices, light_triangle_cumulative_probability, light_mesh_cumulative_probability, light_mesh_triangle_span, light_mesh_transform_indices };
 	size_t bytes[5] = { light_triangle_count * 4, light_triangle_count * 4, light_mesh_count * 4, light_mesh_count * 8, light_mesh_count * 4 };
-	for (int i = 0; i < 5; i++) { int s = upload(ctx, &ctx->lights[i], src[i], src[i] ? bytes[i] : 0); if (s) return s; }
-	ctx->params.light_triangle_indices                = (const int *)ctx->lights[0];
-	ctx->params.light_triangle_cumulative_probability = (const float *)ctx->lights[1];
-	ctx->params.light_mesh_cumulative_probability     = (const float *)ctx->lights[2];
-	ctx->params.light_mesh_triangle_span              = (const int2 *)ctx->lights[3];
-	ctx->params.light_mesh_transform_indices          = (const int *)ctx->lights[4];
+	size_t offset[6] = { 0 };
+	for (int i = 0; i < 5; i++) offset[i + 1] = offset[i] + ((src[i] ? bytes[i] : 0) + 15) / 16 * 16;
+	void * staging = nullptr;
+	int s = ring_begin(ctx, ctx->light_ring, offset[5], &SampleSlot::light_version, &staging); if (s) return s;
+	for (int i = 0; i < 5; i++) if (src[i] && bytes[i]) memcpy((char *)staging + offset[i], src[i], bytes[i]);
+	s = ring_commit(ctx, ctx->light_ring); if (s) return s;
+	const char * base = (const char *)ctx->light_ring.device[ctx->light_ring.current];
+	ctx->params.light_triangle_indices                = (const int *)(base + offset[0]);
+	ctx->params.light_triangle_cumulative_probability = (const float *)(base + offset[1]);
+	ctx->params.light_mesh_cumulative_probability     = (const float *)(base + offset[2]);
+	ctx->params.light_mesh_triangle_span              = (const int2 *)(base + offset[3]);
+	ctx->params.light_mesh_transform_indices          = (const int *)(base + offset[4]);
 	ctx->params.light_mesh_count    = int(light_mesh_count);
 	ctx->params.lights_total_weight = lights_total_weight;
 	return RT_OK;
@@ -843,6 +922,9 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	// integration synchronise); only the accumulate step below has to follow the main-stream work
 	// submitted so far (rt_pack_pixels of the previous frame reads, rt_unpack_pixels writes the image).
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+	// ... and it reads the scene version that is current now (asynchronous TLAS / instance uploads)
+	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));
+	slot.tlas_version = ctx->tlas_ring.current; slot.instance_version = ctx->instance_ring.current; slot.light_version = ctx->light_ring.current;
 	if (exclusive) for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[k].ev_done, 0));
 
 	ctx->stage_used = 0;
@@ -963,6 +1045,7 @@ int rt_render_ao_sample(rt_context * ctx, int sample_index, float ao_radius) {
 	hipStream_t st = slot.stream;
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
+	slot.tlas_version = ctx->tlas_ring.current; slot.instance_version = ctx->instance_ring.current; slot.light_version = ctx->light_ring.current;
 	for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[k].ev_done, 0));
 
 	RT_HIP(ctx, hipEventRecord(slot.ev_frame_start, st));

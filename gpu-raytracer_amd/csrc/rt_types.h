@@ -76,6 +76,10 @@ struct RtParams {
 	const float4 * bvh8_nodes;
 	const float4 * bvh2_nodes;  // 2 float4 per node
 	const float4 * bvh4_nodes;  // 8 float4 per node
+	// The TLAS (node indices [0, tlas_node_count) of whichever BVH type is selected) is versioned per
+	// frame and lives outside the static node arrays, see rt_api.hip (SceneRing).
+	const float4 * tlas_nodes;
+	int tlas_node_count;
 	int bvh_width;              // 8: CWBVH kernels (default), 4: 4-wide BVH kernels, 2: binary-BVH kernels
 	const int    * mesh_bvh_root_indices;
 	const int    * mesh_material_ids;

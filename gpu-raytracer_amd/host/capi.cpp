@@ -37,6 +37,7 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "sigma_l")                             gpu_config.sigma_l = float(value);
 	else if (k == "aov_mask")                            gpu_config.aov_mask = unsigned(value);
 	else if (k == "bvh_type")                            cpu_config.bvh_type = int(value) == 2 ? BVHType::BVH : (int(value) == 4 ? BVHType::BVH4 : BVHType::BVH8);
+	else if (k == "enable_scene_update")                 cpu_config.enable_scene_update = value != 0;
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
 	else if (k == "initial_height")                      cpu_config.initial_height = int(value);
 	else { g_host_error = "unknown config key '" + k + "'"; return -1; }
@@ -88,6 +89,27 @@ void grt_scene_get_camera(void * scene, float * position, float * rotation, floa
 }
 
 // Overrides one material (used by the "odd materials -> roughplastic" Sponza variant)
+// Mesh::position / rotation (quaternion x, y, z, w) / scale, as the reference's UI edits them; takes effect
+// at the next Integrator::update() that rebuilds the TLAS (invalidated_scene or enable_scene_update).
+int grt_scene_set_mesh_transform(void * scene, int index, const float * position, const float * rotation_xyzw, float scale) {
+	Scene * s = (Scene *)scene;
+	if (index < 0 || index >= int(s->meshes.size())) { g_host_error = "grt_scene_set_mesh_transform: mesh index out of range"; return -1; }
+	Mesh & m = s->meshes[index];
+	m.position = Vector3(position[0], position[1], position[2]);
+	m.rotation = Quaternion(rotation_xyzw[0], rotation_xyzw[1], rotation_xyzw[2], rotation_xyzw[3]);
+	m.scale = scale;
+	return 0;
+}
+int grt_scene_get_mesh_transform(void * scene, int index, float * position, float * rotation_xyzw, float * scale) {
+	Scene * s = (Scene *)scene;
+	if (index < 0 || index >= int(s->meshes.size())) { g_host_error = "grt_scene_get_mesh_transform: mesh index out of range"; return -1; }
+	const Mesh & m = s->meshes[index];
+	position[0] = m.position.x; position[1] = m.position.y; position[2] = m.position.z;
+	rotation_xyzw[0] = m.rotation.x; rotation_xyzw[1] = m.rotation.y; rotation_xyzw[2] = m.rotation.z; rotation_xyzw[3] = m.rotation.w;
+	*scale = m.scale;
+	return 0;
+}
+
 int grt_scene_set_material(void * scene, int index, int type, const float * diffuse, float linear_roughness) {
 	Scene * s = (Scene *)scene;
 	if (index < 0 || index >= int(s->asset_manager.materials.size())) { g_host_error = "material index out of range"; return -1; }

@@ -132,7 +132,12 @@ const char * rt_version(void);
  * (BVH/BVH.h:61-80); slots [0, 2*mesh_count) are reserved for the TLAS.                 */
 int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle_count,
                        const void * bvh8_nodes, size_t node_count);
-/* Replaces the per-frame TLAS memcpy into the front of `bvh8_nodes` (Integrator.cpp:404-409). */
+/* Replaces the per-frame TLAS memcpy into the front of `bvh8_nodes` (Integrator.cpp:404-409). The
+ * TLAS, the instance tables (rt_upload_instances) and the light tables (rt_upload_lights) are
+ * versioned on the device: the call copies the host data into pinned staging and returns (the
+ * caller's buffers are free again), the device copy is asynchronous, samples already in flight keep
+ * the version they were submitted with and later rt_render_sample calls see the new one. The GPU is
+ * only drained when a table outgrows its ring.                                                   */
 int rt_upload_tlas(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count);
 /* Replaces `bvh2_nodes` (Integrator.cpp:205-206): binary SAH BVH, 32 B nodes, for
  * rt_set_bvh_type(ctx, 2) (BASELINE config #1).  TLAS occupies the first slots likewise. */
