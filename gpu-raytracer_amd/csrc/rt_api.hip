@@ -89,7 +89,6 @@ struct rt_context {
 	bool has_material[4] = { false, false, false, false };
 	bool has_lights = false;
 	void * texture_table = nullptr; std::vector<void *> texture_data;
-	void * lights[5] = { };
 	void * pmj = nullptr, * blue_noise = nullptr;
 	void * sky = nullptr;
 	void * luts[6] = { }; bool luts_ready = false;
