@@ -134,6 +134,8 @@ def host_lib():
         lib.grt_pathtracer_free.argtypes = [c_void_p]
         lib.grt_pathtracer_update.argtypes = [c_void_p, c_float]
         lib.grt_pathtracer_render.argtypes = [c_void_p]
+        lib.grt_pathtracer_set_pixel_query.argtypes = [c_void_p, c_int, c_int]
+        lib.grt_pathtracer_get_pixel_query.argtypes = [c_void_p] + [POINTER(c_int)] * 4
         lib.grt_pathtracer_render_samples.argtypes = [c_void_p, c_int]
         lib.grt_pathtracer_resize.argtypes = [c_void_p, c_int, c_int]
         lib.grt_pathtracer_set_pixel_range.argtypes = [c_void_p, c_int, c_int]
@@ -371,6 +373,18 @@ class Pathtracer:
     def render_samples(self, count):
         """`count` samples per pixel as one wavefront; same image as `count` x (update(); render())."""
         _host_check(host_lib().grt_pathtracer_render_samples(self.handle, int(count)))
+
+    def set_pixel_query(self, x, y):
+        """Integrator::set_pixel_query (window coordinates, y top-down): which mesh / triangle is under
+        this pixel? Armed for the next render(); the update() after it fetches the answer."""
+        host_lib().grt_pathtracer_set_pixel_query(self.handle, int(x), int(y))
+
+    @property
+    def pixel_query(self):
+        """(pixel_index, scene mesh index, triangle id, status) -- status 0 inactive, 1 pending, 2 output ready."""
+        v = [c_int() for _ in range(4)]
+        host_lib().grt_pathtracer_get_pixel_query(self.handle, *[byref(i) for i in v])
+        return tuple(i.value for i in v)
 
     def invalidate(self, what):
         host_lib().grt_pathtracer_invalidate(self.handle, what.encode())

@@ -278,6 +278,11 @@ __global__ void __launch_bounds__(RT_SORT_BLOCK) kernel_sort(RtParams p, int bou
 			return -1;
 		}
 
+		if (bounce == 0 && p.pixel_query_pixel == pixel_index) { // Pathtracer.cu:345-348 (sample 0 of a batch: virtual == real index)
+			p.pixel_query_out[0] = hit.mesh_id;
+			p.pixel_query_out[1] = hit.triangle_id;
+		}
+
 		int material_id = p.mesh_material_ids[hit.mesh_id];
 		int material_type = p.material_types[material_id];
 
@@ -862,6 +867,7 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_ambient_occlusion(RtPar
 			HitInfo hit = unpack_hit(in.hits[index]);
 			pixel_index = int(in.pixel_index_and_flags[index] & ~RT_FLAGS_ALL);
 			if (hit.triangle_id != RT_INVALID) {
+				if (p.pixel_query_pixel == pixel_index) { p.pixel_query_out[0] = hit.mesh_id; p.pixel_query_out[1] = hit.triangle_id; } // AO.cu:115-118
 				f3 ray_direction = load3(in.direction, index);
 				TriangleFull tri = triangle_get_full(p, hit.triangle_id);
 				f3 geometric_normal = normalize(cross(tri.position_edge_1, tri.position_edge_2)); // object space, as in AO.cu:123

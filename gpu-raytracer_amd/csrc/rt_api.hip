@@ -101,6 +101,7 @@ struct rt_context {
 	size_t frame_pixels = 0; // pitch * height
 
 	int * explicit_retired = nullptr;
+	int * pixel_query_out = nullptr;   // device { mesh_id, triangle_id }
 	int batch_size_request = 0;              // 0 = whole frame (288 GB of HBM: no reason to cut a frame into pieces)
 	int pixel_offset = 0, pixel_count = -1;  // -1 = whole frame
 
@@ -288,6 +289,10 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 
 	int s = ensure_slot(ctx, 0); if (s) return s;
 	s = device_alloc(ctx, (void **)&ctx->explicit_retired, 8 * sizeof(int)); if (s) return s;
+	s = device_alloc(ctx, (void **)&ctx->pixel_query_out, 2 * sizeof(int)); if (s) return s;
+	RT_HIP(ctx, hipMemset(ctx->pixel_query_out, 0xff, 2 * sizeof(int)));
+	ctx->params.pixel_query_out = ctx->pixel_query_out;
+	ctx->params.pixel_query_pixel = -1;
 	// the kernel-level entry points run on the main stream with slot 0's buffers (after quiesce())
 	ctx->params.sizes        = ctx->slots[0].sizes;
 	ctx->params.xcd_counters = ctx->slots[0].xcd_counters;
@@ -1071,6 +1076,25 @@ int rt_render_ao_sample(rt_context * ctx, int sample_index, float ao_radius) {
 	RT_HIP(ctx, hipEventRecord(slot.ev_done, st));
 	ctx->last_slot = 0;
 	RT_HIP(ctx, hipGetLastError());
+	return RT_OK;
+}
+
+int rt_set_pixel_query(rt_context * ctx, int pixel_index) {
+	RT_REQUIRE(ctx, ctx, "rt_set_pixel_query: NULL context");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	RT_HIP(ctx, hipMemset(ctx->pixel_query_out, 0xff, 2 * sizeof(int))); // { INVALID, INVALID }
+	ctx->params.pixel_query_pixel = pixel_index;
+	return RT_OK;
+}
+
+int rt_get_pixel_query(rt_context * ctx, int * mesh_id, int * triangle_id) {
+	RT_REQUIRE(ctx, ctx && mesh_id && triangle_id, "rt_get_pixel_query: NULL argument");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	int out[2] = { -1, -1 };
+	RT_HIP(ctx, hipMemcpy(out, ctx->pixel_query_out, sizeof(out), hipMemcpyDeviceToHost));
+	*mesh_id = out[0]; *triangle_id = out[1];
 	return RT_OK;
 }
 

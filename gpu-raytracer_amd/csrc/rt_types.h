@@ -119,6 +119,10 @@ struct RtParams {
 	// height); only the RNG needs (pixel, first_sample + s) back, see rt_split_virtual_pixel.
 	unsigned frame_pixels, frame_pixels_magic; // magic = floor(2^32 / frame_pixels) + 1
 	int batch_samples;
+	// pixel query (PixelQuery of the reference, CUDA/Pathtracer.cu:345-348): the bounce-0 hit of this pixel
+	// index (x + y * pitch, -1 = none) is written to pixel_query_out[0..1] = { mesh_id, triangle_id }
+	int   pixel_query_pixel;
+	int * pixel_query_out;
 	// multi-GPU tile split: local pixel i -> scan-order pixel (tile_pixels == 0: identity)
 	int tile_pixels, tile_first, tile_stride;
 	// queues

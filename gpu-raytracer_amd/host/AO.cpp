@@ -25,4 +25,5 @@ void AO::update(float delta) {
 void AO::render() {
 	require_device();
 	check(rt_render_ao_sample(ctx, sample_index, ao_radius));
+	if (pixel_query_status == PixelQueryStatus::PENDING) pixel_query_status = PixelQueryStatus::OUTPUT_READY; // AO.cpp:196-198
 }

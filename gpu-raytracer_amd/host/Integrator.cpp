@@ -255,6 +255,14 @@ void Integrator::update(float delta) {
 		scene.update(0.0f);
 	}
 
+	if (pixel_query_status == PixelQueryStatus::OUTPUT_READY) { // reference: Integrator.cpp:483-495
+		if (ctx) check(rt_get_pixel_query(ctx, &pixel_query.mesh_id, &pixel_query.triangle_id));
+		if (pixel_query.mesh_id != INVALID) pixel_query.mesh_id = tlas.indices[pixel_query.mesh_id]; // TLAS order -> scene mesh index
+		pixel_query.pixel_index = INVALID;
+		if (ctx) check(rt_set_pixel_query(ctx, INVALID));
+		pixel_query_status = PixelQueryStatus::INACTIVE;
+	}
+
 	if (invalidated_scene) {
 		invalidated_scene = false;
 		build_tlas();
@@ -301,6 +309,8 @@ void Integrator::set_pixel_query(int x, int y) {
 	pixel_query.pixel_index = x + y * screen_pitch;
 	pixel_query.mesh_id     = INVALID;
 	pixel_query.triangle_id = INVALID;
+	if (ctx) check(rt_set_pixel_query(ctx, pixel_query.pixel_index));
+	pixel_query_status = PixelQueryStatus::PENDING;
 }
 
 std::vector<float> Integrator::read_aov(AOVType type, bool accumulated) {

@@ -58,6 +58,7 @@ struct Integrator {
 	int pixel_range_offset = 0, pixel_range_count = -1;
 
 	PixelQuery pixel_query = { INVALID, INVALID, INVALID };
+	enum struct PixelQueryStatus { INACTIVE, PENDING, OUTPUT_READY } pixel_query_status = PixelQueryStatus::INACTIVE; // Integrator.h:75-79
 
 	// ---- host staging of everything the device consumes (filled by init_* / build_tlas) ----
 	std::vector<DeviceTriangle> aggregated_triangles;

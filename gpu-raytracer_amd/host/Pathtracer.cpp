@@ -206,11 +206,13 @@ void Pathtracer::update(float delta) {
 void Pathtracer::render() {
 	require_device();
 	check(rt_render_sample(ctx, sample_index));
+	if (pixel_query_status == PixelQueryStatus::PENDING) pixel_query_status = PixelQueryStatus::OUTPUT_READY; // Pathtracer.cpp:852-854
 }
 
 void Pathtracer::render_samples(int count) {
 	require_device();
 	if (count < 1) return;
+	if (pixel_query_status == PixelQueryStatus::PENDING) pixel_query_status = PixelQueryStatus::OUTPUT_READY;
 	if (gpu_config.enable_svgf) { // SVGF frames feed each other's history: one at a time
 		for (int i = 0; i < count; i++) { if (i) sample_index++; check(rt_render_sample(ctx, sample_index)); }
 		return;

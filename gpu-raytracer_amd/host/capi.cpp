@@ -224,6 +224,12 @@ void grt_pathtracer_invalidate(void * pt, const char * what) {
 void grt_pathtracer_aov_enable(void * pt, int aov, int enable) {
 	if (enable) as_integrator(pt)->aov_enable(AOVType(aov)); else as_integrator(pt)->aov_disable(AOVType(aov));
 }
+void grt_pathtracer_set_pixel_query(void * pt, int x, int y) { as_integrator(pt)->set_pixel_query(x, y); }
+void grt_pathtracer_get_pixel_query(void * pt, int * pixel_index, int * mesh_id, int * triangle_id, int * status) {
+	Integrator * p = as_integrator(pt);
+	*pixel_index = p->pixel_query.pixel_index; *mesh_id = p->pixel_query.mesh_id; *triangle_id = p->pixel_query.triangle_id;
+	*status = int(p->pixel_query_status);
+}
 void * grt_pathtracer_context(void * pt) { return as_integrator(pt)->ctx; }
 float  grt_pathtracer_lights_total_weight(void * pt) { { Pathtracer * p = dynamic_cast<Pathtracer *>(as_integrator(pt)); return p ? p->lights_total_weight : 0.0f; } }
 

@@ -235,6 +235,11 @@ int rt_render_sample(rt_context * ctx, int sample_index);
  * bit-identical to count calls of rt_render_sample (tests/test_gpu_parity.py). Not for SVGF.
  * rt_get_counters reports the batch totals.                                               */
 int rt_render_samples(rt_context * ctx, int sample_index, int sample_count);
+/* Replaces the `pixel_query` global (Integrator.h:266-277, Integrator.cpp:483-495, Pathtracer.cu:345-348):
+ * the mesh (TLAS-order id) and triangle that the primary ray of pixel `pixel_index` = x + y * pitch hits
+ * in the next sample rendered (-1 disarms it). rt_get_pixel_query waits and returns -1, -1 for a miss. */
+int rt_set_pixel_query(rt_context * ctx, int pixel_index);
+int rt_get_pixel_query(rt_context * ctx, int * mesh_id, int * triangle_id);
 /* The reference's second integrator, AO::render (Integrators/AO.cpp:148-200, CUDA/AO.cu):
  * primary hit -> one cosine-weighted occlusion ray of length ao_radius -> RADIANCE = 1 where it
  * escapes, NORMAL / POSITION AOVs; needs geometry, instances, RNG tables, rt_resize, rt_set_camera

@@ -472,6 +472,33 @@ def test_sample_batches_equal_single_samples(grt):
     pt.close(); scene.close()
 
 
+def test_pixel_query_returns_the_primary_hit(grt, oracle):
+    """Integrator::set_pixel_query protocol (Integrator.h:266-277, Integrator.cpp:483-495): armed before
+    a render, answered at the update() after it, mesh id translated from TLAS order to the scene's."""
+    scene, pt = make_pathtracer(grt, "cornellbox", 200, 160, 0, num_bounces=3)
+    view = oracle.SceneView(pt)
+    o, d, px = view.generate(pt.sample_index, 0, 200 * 160)
+    hits, _ = view.trace(o, d)
+    tlas_indices = pt.array("tlas_indices")
+    for (x, y) in ((100, 80), (20, 30), (180, 140)):
+        pt.set_pixel_query(x, y)
+        assert pt.pixel_query[3] == 1                       # pending
+        pt.render()
+        assert pt.pixel_query[3] == 2                       # output ready
+        pt.update()
+        _, mesh, tri, status = pt.pixel_query
+        assert status == 0
+        row = 160 - y                                       # window y is top-down
+        ray = row * 200 + x                                 # generate() order: scan lines of `width` pixels
+        assert int(px[ray]) == x + row * pt.pitch
+        want_mesh, want_tri = int(hits[ray, 0]), int(hits[ray, 1])
+        if want_tri == 0xffffffff:
+            assert (mesh, tri) == (-1, -1)
+        else:
+            assert (mesh, tri) == (int(tlas_indices[want_mesh]), want_tri)
+    pt.close(); scene.close()
+
+
 def test_device_errors_are_reported(grt):
     import ctypes
     lib = grt.device_lib()
