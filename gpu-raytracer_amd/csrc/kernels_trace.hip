@@ -136,7 +136,94 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 	return hit_mask;
 }
 
+// ---- narrow mode: 8 lanes per ray ---------------------------------------------------------------
+// A launch of a few thousand rays cannot fill 64-lane waves with one ray per lane, and its duration is
+// the dependent chain of its longest ray: ~150 steps of ~400 VALU instructions (4 cycles each on a
+// 16-wide SIMD). In narrow mode the 8 lanes of a group work on ONE ray: lane c tests child slot c of a
+// node (the same fused multiply-adds as the wide loop body), the group ORs the partial hit masks with
+// three DPP moves; up to 8 triangles of a leaf group are tested at once, one per lane, and the
+// sequential outcome (smallest t, ties to the triangle tested first) is rebuilt with a group minimum.
+// All other per-ray state is simply replicated in the 8 lanes. A step costs about half the issue slots.
+RT_DEV unsigned group8_or(unsigned v) {
+	v |= unsigned(__builtin_amdgcn_mov_dpp(int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+	v |= unsigned(__builtin_amdgcn_mov_dpp(int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+	v |= unsigned(__builtin_amdgcn_mov_dpp(int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror: lane i <- lane 7 - i
+	return v;
+}
+RT_DEV unsigned group8_min(unsigned v) {
+	v = min(v, unsigned(__builtin_amdgcn_mov_dpp(int(v), 0xB1, 0xf, 0xf, true)));
+	v = min(v, unsigned(__builtin_amdgcn_mov_dpp(int(v), 0x4E, 0xf, 0xf, true)));
+	v = min(v, unsigned(__builtin_amdgcn_mov_dpp(int(v), 0x141, 0xf, 0xf, true)));
+	return v;
+}
+
+// The part of bvh8_node_intersect's hit mask that child slot `child` (0..7) contributes.
+RT_DEV unsigned bvh8_node_intersect_child(const Ray3 & ray, f3 inv_dir, unsigned oct_inv4, float max_distance,
+                                          float4 n0, float4 n1, float4 n2, float4 n3, float4 n4, unsigned child) {
+	f3 p = mk3(n0.x, n0.y, n0.z);
+	unsigned e_imask = __float_as_uint(n0.w);
+
+	f3 adjusted_dir_inv = mk3(
+		__uint_as_float(extract_byte(e_imask, 0) << 23) * inv_dir.x,
+		__uint_as_float(extract_byte(e_imask, 1) << 23) * inv_dir.y,
+		__uint_as_float(extract_byte(e_imask, 2) << 23) * inv_dir.z);
+	f3 adjusted_origin = (p - ray.origin) * inv_dir;
+
+	bool neg_x = ray.direction.x < 0.0f, neg_y = ray.direction.y < 0.0f, neg_z = ray.direction.z < 0.0f;
+	bool upper = child >= 4u; // slots 4..7 live in the second word of each pair
+	unsigned j = child & 3u;
+
+	unsigned meta4 = __float_as_uint(upper ? n1.w : n1.z);
+	unsigned is_inner4   = (meta4 & (meta4 << 1)) & 0x10101010u;
+	unsigned inner_mask4 = sign_extend_s8x4(is_inner4 << 3);
+	unsigned bit_index4  = (meta4 ^ (oct_inv4 & inner_mask4)) & 0x1f1f1f1fu;
+	unsigned child_bits4 = (meta4 >> 5) & 0x07070707u;
+
+	unsigned q_lo_x = __float_as_uint(upper ? n2.y : n2.x), q_hi_x = __float_as_uint(upper ? n2.w : n2.z);
+	unsigned q_lo_y = __float_as_uint(upper ? n3.y : n3.x), q_hi_y = __float_as_uint(upper ? n3.w : n3.z);
+	unsigned q_lo_z = __float_as_uint(upper ? n4.y : n4.x), q_hi_z = __float_as_uint(upper ? n4.w : n4.z);
+
+	unsigned x_min = neg_x ? q_hi_x : q_lo_x, x_max = neg_x ? q_lo_x : q_hi_x;
+	unsigned y_min = neg_y ? q_hi_y : q_lo_y, y_max = neg_y ? q_lo_y : q_hi_y;
+	unsigned z_min = neg_z ? q_hi_z : q_lo_z, z_max = neg_z ? q_lo_z : q_hi_z;
+
+	float tx0 = __builtin_fmaf(float(extract_byte(x_min, j)), adjusted_dir_inv.x, adjusted_origin.x);
+	float ty0 = __builtin_fmaf(float(extract_byte(y_min, j)), adjusted_dir_inv.y, adjusted_origin.y);
+	float tz0 = __builtin_fmaf(float(extract_byte(z_min, j)), adjusted_dir_inv.z, adjusted_origin.z);
+	float tx1 = __builtin_fmaf(float(extract_byte(x_max, j)), adjusted_dir_inv.x, adjusted_origin.x);
+	float ty1 = __builtin_fmaf(float(extract_byte(y_max, j)), adjusted_dir_inv.y, adjusted_origin.y);
+	float tz1 = __builtin_fmaf(float(extract_byte(z_max, j)), adjusted_dir_inv.z, adjusted_origin.z);
+
+	float tmin = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, 0.0f));
+	float tmax = fminf(fminf(tx1, ty1), fminf(tz1, max_distance));
+
+	return tmin < tmax ? extract_byte(child_bits4, j) << extract_byte(bit_index4, j) : 0u;
+}
+
 struct HitRecord { float t, u, v; int mesh_id, triangle_id; };
+
+// The same Moeller-Trumbore arithmetic, returning t, u, v and whether (u, v) is inside and t > 0; the
+// comparison against the current best / the maximum distance is left to the caller (narrow mode).
+RT_DEV bool triangle_test_values(float4 part_0, float4 part_1, float part_2_x, const Ray3 & ray, float & t, float & u, float & v) {
+	f3 p0 = mk3(part_0.x, part_0.y, part_0.z);
+	f3 e1 = mk3(part_0.w, part_1.x, part_1.y);
+	f3 e2 = mk3(part_1.z, part_1.w, part_2_x);
+
+	f3 h = cross_fma(ray.direction, e2);
+	float a = dot_fma(e1, h);
+	float f = 1.0f / a;
+	f3 s = ray.origin - p0;
+	u = f * dot_fma(s, h);
+	if (u >= 0.0f && u <= 1.0f) {
+		f3 q = cross_fma(s, e1);
+		v = f * dot_fma(ray.direction, q);
+		if (v >= 0.0f && u + v <= 1.0f) {
+			t = f * dot_fma(e2, q);
+			return t > 0.0f;
+		}
+	}
+	return false;
+}
 
 // Moeller-Trumbore on an already fetched triangle (position_0, edge_1, edge_2 in 3 float4).
 template<bool SHADOW>
@@ -211,20 +298,26 @@ struct TraversalStack {
 // one atomic per refill (~23 rays for incoherent rays, ~57 for primary rays) the WHOLE GPU was
 // capped at 88 x 23 = 2.0 Grays/s resp. 88 x 57 = 5.0 Grays/s whatever the traversal code did.
 
+// Workgroup memory of every engine below (a kernel runs one of them): the traversal stacks and the
+// per-wave ray-claim words. File scope, so that the wide and the narrow instantiation of the CWBVH
+// engine inside one kernel share ONE allocation.
+__shared__ uint2 shared_stack[(RT_TRACE_BLOCK / RT_WAVE_SIZE) * RT_LDS_STACK * RT_WAVE_SIZE];
+__shared__ int   shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4]; // per wave: next, end, drained
+
 // The common traversal engine. RaySource supplies rays and consumes results so that the same
 // code serves the wavefront queues and the stand-alone entry points.
 // COUNT adds per-ray work counters (nodes fetched, triangles tested, instance entries) that are
 // flushed with atomics when a ray retires; it exists to MEASURE the algorithmic bytes of a launch
 // (rt_set_trace_statistics) and is never used in a timed frame.
-template<bool SHADOW, bool COUNT, typename Source>
-RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr) {
-	__shared__ uint2 shared_stack[(RT_TRACE_BLOCK / RT_WAVE_SIZE) * RT_LDS_STACK * RT_WAVE_SIZE];
-
+template<bool SHADOW, bool COUNT, bool NARROW, typename Source>
+RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr) {
 	const float4 * __restrict__ nodes     = p.bvh8_nodes;
 	const float4 * __restrict__ triangles = p.triangle_positions;
 
 	unsigned lane = threadIdx.x & (RT_WAVE_SIZE - 1);
 	unsigned wave = threadIdx.x / RT_WAVE_SIZE;
+	const unsigned group_child = lane & 7u;   // narrow mode: this lane's child slot / triangle rank within its 8-lane group
+	const unsigned group_base  = lane & ~7u;  //              first lane of the group
 
 	TraversalStack stack;
 	stack.lds   = (LdsUint2 *)&shared_stack[wave * (RT_LDS_STACK * RT_WAVE_SIZE) + lane];
@@ -232,36 +325,39 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 	stack.spill = (GlobalUint2 *)(p.stack_spill + (blockIdx.x * blockDim.x + threadIdx.x));
 	stack.size  = 0;
 
-	// Rays per cursor atomic: up to 512 for big launches, 64 for small ones so that every wave gets work.
+	// Rays per cursor atomic: up to 128 for big launches, 64 for small ones so that every wave gets work
+	// (narrow mode: 8, one ray per 8-lane group).
 	const int waves_in_grid = int(gridDim.x) * (RT_TRACE_BLOCK / RT_WAVE_SIZE);
-	const int ray_block = max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (ray_count / (2 * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
+	const int ray_block = NARROW ? 8 : max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (ray_count / (2 * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
 	// Only as many waves as there are blocks take part; the rest of the (machine-sized) persistent
 	// grid leaves without touching the shared cursor.
 	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * unsigned(ray_block) >= unsigned(ray_count)) return;
 	// volatile: the words are written by one lane and read by OTHER lanes of the same wave with no
 	// barrier in between; without it the compiler forwards a lane's own last view of them.
-	__shared__ int shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4]; // per wave: next, end, drained
 	typedef volatile __attribute__((address_space(3))) int LdsFetchWord; // typed: ds_read/ds_write, not FLAT
 	LdsFetchWord * fetch_state = (LdsFetchWord *)&shared_fetch[wave][0];
 	if (lane == 0) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[2] = 0; }
 	// Called (converged) by the lanes that need a ray; returns its index or -1 once the launch is drained.
+	// Narrow mode: whole groups call it, every lane of a group gets the group's ray.
 	auto fetch_ray = [&]() -> int {
 		while (true) {
 			if (fetch_state[2]) return -1;
 			unsigned long long want = __ballot(1);
-			int n_want = __popcll(want);
-			unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(want >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(want), 0u));
+			unsigned long long askers = NARROW ? (want & 0x0101010101010101ull) : want; // one per ray wanted
+			int n_want = __popcll(askers);
+			bool elected = __builtin_amdgcn_mbcnt_hi(unsigned(want >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(want), 0u)) == 0;
+			unsigned rank = NARROW ? unsigned(__popcll(askers & ((1ull << group_base) - 1ull)))
+			                       : __builtin_amdgcn_mbcnt_hi(unsigned(want >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(want), 0u));
 			int next = fetch_state[0], end = fetch_state[1];
 			if (next >= end) { // the same for every lane of the ballot: claim the next block
 				int base = 0;
-				int claim = RT_FETCH_BLOCK_MAX > RT_WAVE_SIZE ? ray_block : n_want;
-				if (rank == 0) base = atomicAdd(xcd_counters, claim);
+				if (elected) base = atomicAdd(xcd_counters, ray_block);
 				base = __builtin_amdgcn_readfirstlane(base);
 				next = min(base, ray_count);
-				end  = min(base + claim, ray_count);
+				end  = min(base + ray_block, ray_count);
 			}
 			int give = min(n_want, end - next);
-			if (rank == 0) {
+			if (elected) {
 				fetch_state[0] = next + give;
 				fetch_state[1] = end;
 				if (next >= end) fetch_state[2] = 1;
@@ -328,7 +424,8 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 #ifdef RT_PHASE_STATS
 					if (COUNT && !SHADOW) { phase_node_lanes++; if (RT_PHASE_LEADER()) phase_node_execs++; }
 #endif
-					unsigned hitmask = bvh8_node_intersect(ray, inv_dir, oct_inv4, SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
+					unsigned hitmask = NARROW ? group8_or(bvh8_node_intersect_child(ray, inv_dir, oct_inv4, SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, group_child))
+					                          : bvh8_node_intersect(ray, inv_dir, oct_inv4, SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
 					unsigned imask = extract_byte(__float_as_uint(n0.w), 3);
 
 					current_group .x = __float_as_uint(n1.x);
@@ -382,6 +479,36 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 #ifdef RT_PHASE_STATS
 					if (COUNT && !SHADOW) { phase_tri_lanes++; if (RT_PHASE_LEADER()) phase_tri_rounds++; }
 #endif
+					if (NARROW) {
+						// lane c of the group takes the c-th triangle from the top; all 8 lanes compute the rest mask
+						unsigned rest = triangle_group.y; int my_bit = -1;
+						#pragma unroll
+						for (unsigned k = 0; k < 8; k++) {
+							if (rest != 0) { int b = int(msb(rest)); if (k == group_child) my_bit = b; rest &= ~(1u << b); }
+						}
+						triangle_group.y = rest;
+						float t = 0.0f, u = 0.0f, v = 0.0f; bool valid = false; int my_triangle = RT_INVALID;
+						if (my_bit >= 0) {
+							my_triangle = int(triangle_group.x) + my_bit;
+							const float4 * tri = triangles + size_t(my_triangle) * 3;
+							valid = triangle_test_values(tri[0], tri[1], tri[2].x, ray, t, u, v) && t < (SHADOW ? max_distance : hit.t);
+						}
+						if (SHADOW) {
+							if ((__ballot(valid) >> group_base) & 0xffull) occluded = true;
+						} else {
+							// the sequential loop keeps the smallest t and, among equal t, the triangle tested first
+							unsigned key  = valid ? __float_as_uint(t) : 0xffffffffu; // t > 0: bit patterns order like the values
+							unsigned best = group8_min(key);
+							if (best != 0xffffffffu) {
+								unsigned winners = unsigned((__ballot(valid && key == best) >> group_base) & 0xffull);
+								int from = int(group_base) + __ffs(int(winners)) - 1;
+								hit.t = __uint_as_float(best);
+								hit.u = __shfl(u, from); hit.v = __shfl(v, from);
+								hit.triangle_id = __shfl(my_triangle, from);
+								hit.mesh_id = mesh_id;
+							}
+						}
+					} else {
 					// up to RT_TRI_BATCH triangles per round: all their loads are issued before the first
 					// test, the tests run in the sequential order (each sees the hit.t left by the previous)
 					int    tri_id[RT_TRI_BATCH];
@@ -408,6 +535,7 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 				}
 			}
 
+					}
 			bool traversal_done = triangle_group.y == 0 && (current_group.y & 0xff000000u) == 0 && stack.size == 0;
 			if (COUNT && ((SHADOW && occluded) || traversal_done)) {
 				atomicAdd(&stats[0], (unsigned long long)count_nodes);     atomicAdd(&stats[1], (unsigned long long)count_triangles);
@@ -423,7 +551,7 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 #endif
 			}
 			if (SHADOW && occluded) {
-				src.finish(ray_index, hit, true);
+				if (!NARROW || group_child == 0) src.finish(ray_index, hit, true);
 				stack.size = 0;
 				current_group.y = 0;
 				triangle_group.y = 0;
@@ -432,7 +560,7 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 
 			if (triangle_group.y == 0 && (current_group.y & 0xff000000u) == 0) {
 				if (stack.size == 0) {
-					src.finish(ray_index, hit, false);
+					if (!NARROW || group_child == 0) src.finish(ray_index, hit, false);
 					current_group.y = 0;
 					break;
 				}
@@ -454,8 +582,19 @@ RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_coun
 }
 
 
-#define RT_TRACE_ENGINE bvh8_trace_persistent
 #define RT_TRACE_LAUNCH_WAVES RT_TRACE_WAVES_PER_SIMD
+#ifndef RT_NARROW_MAX_RAYS
+#define RT_NARROW_MAX_RAYS 16384   // incoherent launches up to this many rays run 8 lanes per ray (measured cross-over ~20 k rays)
+#endif
+
+// One kernel, two instantiations: the ray count is only known on the device.
+// `coherent`: primary rays keep one ray per lane at any count (neighbouring lanes walk the same nodes).
+template<bool SHADOW, bool COUNT, typename Source>
+RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_count, int * cursor, unsigned long long * stats = nullptr, bool coherent = false) {
+	if (!COUNT && !coherent && ray_count <= RT_NARROW_MAX_RAYS) bvh8_trace_engine<SHADOW, false, true>(p, src, ray_count, cursor);
+	else bvh8_trace_engine<SHADOW, COUNT, false>(p, src, ray_count, cursor, stats);
+}
+#define RT_TRACE_ENGINE bvh8_trace_persistent
 
 RT_DEV uint4 pack_hit(const HitRecord & h) { // Buffers.h:25-32
 	unsigned uv = unsigned(int(h.u * 65535.0f)) | (unsigned(int(h.v * 65535.0f)) << 16);
@@ -523,8 +662,6 @@ struct ShadowExplicitSource {
 // =================================================================================================
 template<bool SHADOW, typename Source>
 RT_DEV void bvh2_trace_persistent(const RtParams & p, Source & src, int ray_count, int * cursor) {
-	__shared__ uint2 shared_stack[(RT_TRACE_BLOCK / RT_WAVE_SIZE) * RT_LDS_STACK * RT_WAVE_SIZE];
-
 	const float4 * __restrict__ nodes     = p.bvh2_nodes;
 	const float4 * __restrict__ triangles = p.triangle_positions;
 
@@ -540,7 +677,6 @@ RT_DEV void bvh2_trace_persistent(const RtParams & p, Source & src, int ray_coun
 	const int waves_in_grid = int(gridDim.x) * (RT_TRACE_BLOCK / RT_WAVE_SIZE);
 	const int ray_block = max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (ray_count / (2 * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
 	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * unsigned(ray_block) >= unsigned(ray_count)) return;
-	__shared__ int shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4];
 	typedef volatile __attribute__((address_space(3))) int LdsFetchWord;
 	LdsFetchWord * fetch_state = (LdsFetchWord *)&shared_fetch[wave][0];
 	if (lane == 0) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[2] = 0; }
@@ -677,8 +813,6 @@ RT_DEV void bvh2_trace_persistent(const RtParams & p, Source & src, int ray_coun
 // =================================================================================================
 template<bool SHADOW, typename Source>
 RT_DEV void bvh4_trace_persistent(const RtParams & p, Source & src, int ray_count, int * cursor) {
-	__shared__ uint2 shared_stack[(RT_TRACE_BLOCK / RT_WAVE_SIZE) * RT_LDS_STACK * RT_WAVE_SIZE];
-
 	const float4 * __restrict__ nodes     = p.bvh4_nodes;
 	const float4 * __restrict__ triangles = p.triangle_positions;
 
@@ -694,7 +828,6 @@ RT_DEV void bvh4_trace_persistent(const RtParams & p, Source & src, int ray_coun
 	const int waves_in_grid = int(gridDim.x) * (RT_TRACE_BLOCK / RT_WAVE_SIZE);
 	const int ray_block = max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (ray_count / (2 * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
 	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * unsigned(ray_block) >= unsigned(ray_count)) return;
-	__shared__ int shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4];
 	typedef volatile __attribute__((address_space(3))) int LdsFetchWord;
 	LdsFetchWord * fetch_state = (LdsFetchWord *)&shared_fetch[wave][0];
 	if (lane == 0) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[2] = 0; }
@@ -834,7 +967,7 @@ RT_DEV void bvh4_trace_persistent(const RtParams & p, Source & src, int ray_coun
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh8(RtParams p, int bounce) {
 	ClosestHitSource src { p.trace[bounce & 1].origin, p.trace[bounce & 1].direction, p.trace[bounce & 1].hits };
-	RT_TRACE_ENGINE<false, false>(p, src, p.sizes->trace[bounce], p.xcd_counters + (2 * bounce) * RT_NUM_XCD);
+	RT_TRACE_ENGINE<false, false>(p, src, p.sizes->trace[bounce], p.xcd_counters + (2 * bounce) * RT_NUM_XCD, nullptr, bounce == 0);
 }
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh8(RtParams p, int bounce) {
