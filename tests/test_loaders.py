@@ -123,3 +123,85 @@ def test_mitsuba_materials_media_and_instances(grt, tmp_path):
     assert abs(cam.aperture_radius - 0.1) < 1e-7 and np.allclose(list(cam.position), [0, 0, 5])
     assert scene.mesh_count == 4 and pt.array("triangles").size // 24 == 1 + 20 * 64 + 2 + 12
     pt.close(); scene.close()
+
+
+def test_mesh_transform_edit_rebuilds_the_tlas_tables(grt, oracle):
+    """Mesh::position / rotation / scale edits (the reference's UI) + invalidate("scene"): the next
+    update() writes the new matrices in TLAS order, clears the identity flag of the moved mesh, and the
+    oracle finds the mesh at its new place."""
+    scene, pt = make_pathtracer(grt, "cornellbox", 64, 64, -1)
+    moved = 5                                                   # the short cube (12 triangles)
+    pos, rot, scale = scene.mesh_transform(moved)
+    assert pos == [0.0, 0.0, 0.0] and rot == [0.0, 0.0, 0.0, 1.0] and scale == 1.0
+    view = oracle.SceneView(pt)
+    o, d, _ = view.generate(0, 0, 64 * 64)
+    before, _ = view.trace(o, d)
+    scene.set_mesh_transform(moved, [0.0, 0.25, 0.0], [0.0, 0.38268343, 0.0, 0.92387953], 1.25)
+    pt.invalidate("scene"); pt.update()
+    order = pt.array("tlas_indices").tolist()
+    slot = order.index(moved)
+    roots = pt.array("mesh_bvh_root_indices").view(np.uint32)
+    assert (roots[slot] >> 31) == 0 and ((roots >> 31) == 0).sum() == 1
+    xf = pt.array("mesh_transforms").reshape(-1, 3, 4)[slot]
+    assert np.allclose(xf[:, 3], [0.0, 0.25, 0.0]) and np.allclose(np.linalg.norm(xf[:, 0]), 1.25, atol=1e-5)
+    inv = pt.array("mesh_transforms_inv").reshape(-1, 3, 4)[slot]
+    full, full_inv = np.vstack([xf, [0, 0, 0, 1]]), np.vstack([inv, [0, 0, 0, 1]])
+    assert np.allclose(full @ full_inv, np.eye(4), atol=1e-5)
+    prev = pt.array("mesh_transforms_prev").reshape(-1, 3, 4)[slot]
+    assert np.allclose(prev, np.eye(4)[:3])                     # transform_prev = the transform before this update
+    after, stats = oracle.SceneView(pt).trace(o, d)
+    assert stats.instances_transformed > 0 and not np.array_equal(before[:, 2], after[:, 2])
+    pt.close(); scene.close()
+
+
+def test_pixel_query_protocol_without_a_device(grt):
+    """set_pixel_query arms the query (window y is top-down, Integrator.h:266-277); the status only
+    advances when something renders."""
+    scene, pt = make_pathtracer(grt, "cornellbox", 64, 48, -1)
+    assert pt.pixel_query == (-1, -1, -1, 0)
+    pt.set_pixel_query(10, 8)
+    assert pt.pixel_query == (10 + (48 - 8) * pt.pitch, -1, -1, 1)
+    pt.set_pixel_query(640, 8)                                  # outside the frame: ignored
+    assert pt.pixel_query[0] == 10 + (48 - 8) * pt.pitch
+    pt.update()
+    assert pt.pixel_query[3] == 1                               # still pending: nothing was rendered
+    pt.close(); scene.close()
+
+
+def test_bvh4_collapse_invariants(grt):
+    """BVH4Converter.cpp: node 1 is the entry point, every reachable node has 2..4 children, leaves cover
+    every primitive index exactly once, child boxes lie inside their parent's box."""
+    import ctypes
+    lib = grt.host_lib()
+    rng = np.random.default_rng(21)
+    n = 3000
+    p0 = (rng.random((n, 3)) * 40).astype(np.float32)
+    tris = np.zeros((n, 24), np.float32)
+    tris[:, 0:3] = p0; tris[:, 3:6] = p0 + rng.random((n, 3)).astype(np.float32); tris[:, 6:9] = p0 + rng.random((n, 3)).astype(np.float32)
+    h = lib.grt_build_blas(tris.ctypes.data, n)
+    size = ctypes.c_size_t()
+    ptr = lib.grt_built_array(h, b"bvh4_nodes", ctypes.byref(size))
+    raw = np.frombuffer((ctypes.c_char * size.value).from_address(ptr), dtype=np.uint8).copy()
+    lib.grt_built_free(h)
+    boxes = raw.view(np.float32).reshape(-1, 32)[:, :24].reshape(-1, 6, 4)      # min x,y,z / max x,y,z per child
+    ic = raw.view(np.int32).reshape(-1, 32)[:, 24:].reshape(-1, 4, 2)
+    assert tuple(ic[1, 0]) == (0, 0)
+    covered = np.zeros(n, np.int32)
+    stack, visited = [(0, None)], 0
+    while stack:
+        node, parent_box = stack.pop()
+        counts = ic[node, :, 1]
+        children = 4 if (counts != -1).all() else int(np.argmax(counts == -1))
+        assert 2 <= children <= 4
+        visited += 1
+        for c in range(children):
+            box = boxes[node, :, c]
+            assert (box[:3] <= box[3:]).all()
+            if parent_box is not None:
+                assert (box[:3] >= parent_box[:3] - 1e-4).all() and (box[3:] <= parent_box[3:] + 1e-4).all()
+            index, count = ic[node, c]
+            if count > 0:
+                covered[index:index + count] += 1
+            else:
+                stack.append((index, box))
+    assert (covered == 1).all() and visited > n // 4
