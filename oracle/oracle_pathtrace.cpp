@@ -1016,6 +1016,11 @@ void oracle_render_sample(const oracle_scene * scene, oracle_frame * frame, int 
 		}
 	}
 
+	if ((has[2] && (!s.lut_dielectric_directional_albedo_enter || !s.lut_dielectric_albedo_enter)) || (has[3] && (!s.lut_conductor_directional_albedo || !s.lut_conductor_albedo))) {
+		fprintf(stderr, "oracle_render_sample: the scene has dielectric / conductor materials but no Kulla-Conty LUTs were supplied (SceneView(..., luts=...))\n");
+		abort();
+	}
+
 	int pixels_left = range_count;
 	int batch_size  = range_count < RT_BATCH_SIZE ? range_count : RT_BATCH_SIZE;
 	while (pixels_left > 0) { // Pathtracer.cpp:746-796

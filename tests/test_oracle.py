@@ -3,6 +3,7 @@ independent numpy restatement, and the committed golden render."""
 import os
 
 import numpy as np
+import pytest
 
 from conftest import make_pathtracer, unpack_hits
 
@@ -209,3 +210,32 @@ def test_oracle_ambient_occlusion_properties(grt, oracle):
     vals = np.unique(np.round(frame.final[:, :48, 0] * 3.0, 4))
     assert set(vals).issubset({0.0, 1.0, 2.0, 3.0})
     ao.close(); scene.close()
+
+
+FURNACE_XML = ('<scene version="0.5.0"><integrator type="path"><integer name="maxDepth" value="24"/></integrator>'
+               '<sensor type="perspective"><float name="fov" value="30"/><transform name="toWorld"><lookat origin="0, 0, 6" target="0, 0, 0" up="0, 1, 0"/></transform></sensor>'
+               '<shape type="sphere"><float name="radius" value="1"/>%(bsdf)s</shape>'
+               '<shape type="sphere"><float name="radius" value="0.6"/><transform name="toWorld"><translate x="1.2" y="0.8" z="0.5"/></transform>%(bsdf)s</shape></scene>')
+
+
+@pytest.mark.parametrize("bsdf,lo,hi", [
+    ('<bsdf type="diffuse"><rgb name="reflectance" value="1, 1, 1"/></bsdf>', 0.998, 1.0001),
+    ('<bsdf type="roughplastic"><rgb name="diffuseReflectance" value="1, 1, 1"/><float name="alpha" value="0.3"/></bsdf>', 0.97, 1.01)])
+def test_white_furnace(grt, oracle, tmp_path, bsdf, lo, hi):
+    """Physical pin of the BSDF restatement, independent of any reference output: two white objects
+    under the constant white sky, Russian roulette off -- every path that escapes carries
+    throughput = product of f * cos / pdf. A lossless diffuse surface must return exactly the sky
+    (1.0 up to the paths cut at 24 bounces); the plastic of BSDF.h:72-190 is built to conserve energy.
+    A mismatch between a sample() and its pdf, or between eval() and the sampled lobe, shows up here."""
+    (tmp_path / "f.xml").write_text(FURNACE_XML % {"bsdf": bsdf})
+    grt.config_reset()
+    scene = grt.Scene(str(tmp_path / "f.xml"))
+    grt.config_set(enable_russian_roulette=0)
+    pt = grt.Pathtracer(scene, 40, 40, device=-1); pt.update()
+    frame = oracle.Frame(oracle.SceneView(pt))
+    for s in range(17):          # sample 0 is overwritten by sample 1 (AOV.h:35-46): 16 samples count
+        frame.render_sample(s)
+    img = frame.final[:, :40, :3]
+    assert lo <= img.mean() <= hi, img.mean()
+    assert np.isfinite(img).all() and img.min() > 0.7
+    pt.close(); scene.close()
