@@ -239,3 +239,34 @@ def test_white_furnace(grt, oracle, tmp_path, bsdf, lo, hi):
     assert lo <= img.mean() <= hi, img.mean()
     assert np.isfinite(img).all() and img.min() > 0.7
     pt.close(); scene.close()
+
+
+FORM_FACTOR_XML = ('<scene version="0.5.0"><integrator type="path"><integer name="maxDepth" value="2"/></integrator>'
+                   '<sensor type="perspective"><float name="fov" value="2"/><transform name="toWorld"><lookat origin="0.001, 0.5, 0" target="0, 0, 0" up="0, 0, 1"/></transform></sensor>'
+                   '<shape type="rectangle"><transform name="toWorld"><rotate x="1" angle="-90"/><scale value="20"/></transform><bsdf type="diffuse"><rgb name="reflectance" value="1, 1, 1"/></bsdf></shape>'
+                   '<shape type="rectangle"><transform name="toWorld"><rotate x="1" angle="90"/><scale value="0.5"/><translate y="1"/></transform><emitter type="area"><rgb name="radiance" value="1, 1, 1"/></emitter></shape></scene>')
+
+
+@pytest.mark.parametrize("toggles", [{}, {"enable_multiple_importance_sampling": 0}, {"enable_next_event_estimation": 0}],
+                         ids=["nee+mis", "nee", "bsdf-sampling"])
+def test_direct_lighting_matches_the_analytic_form_factor(grt, oracle, tmp_path, toggles):
+    """Physical pin of the light sampling (Pathtracer.cu:354-422, 1040-1120): a white diffuse floor
+    seen from straight above, lit by a 1x1 unit-radiance square 1 above it. The radiance leaving the
+    point under the light's centre is the form factor of the square, 4 * F(1/2, 1/2) with
+    F(X, Y) = (X/sqrt(1+X^2) atan(Y/sqrt(1+X^2)) + Y/sqrt(1+Y^2) atan(X/sqrt(1+Y^2))) / (2 pi)
+    = 0.23944. All three estimators the config can select (light sampling with and without MIS,
+    BSDF sampling alone) must converge to it: a wrong light pdf, MIS weight or double count does not."""
+    x = 0.5 / np.sqrt(1.25)
+    analytic = 4.0 * (2.0 * x * np.arctan(x)) / (2.0 * np.pi)
+    (tmp_path / "ff.xml").write_text(FORM_FACTOR_XML)
+    grt.config_reset()
+    scene = grt.Scene(str(tmp_path / "ff.xml"))
+    scene.set_sky_scale(0.0)     # the default constant sky would light the floor as well
+    grt.config_set(num_bounces=2, enable_russian_roulette=0, **toggles)
+    pt = grt.Pathtracer(scene, 12, 12, device=-1); pt.update()
+    frame = oracle.Frame(oracle.SceneView(pt))
+    for s in range(513):
+        frame.render_sample(s)
+    mean = float(frame.final[:, :12, :3].mean())
+    assert abs(mean - analytic) < 0.01 * analytic, (mean, analytic)
+    pt.close(); scene.close(); grt.config_reset()
