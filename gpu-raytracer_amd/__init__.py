@@ -157,6 +157,8 @@ def host_lib():
         lib.grt_pathtracer_counters.argtypes = [c_void_p, POINTER(Counters)]
         lib.grt_build_blas.restype = c_void_p
         lib.grt_build_blas.argtypes = [c_void_p, c_int]
+        lib.grt_build_device_bvh.restype = c_void_p
+        lib.grt_build_device_bvh.argtypes = [c_void_p, c_int, c_int]
         lib.grt_built_array.restype = c_void_p
         lib.grt_built_array.argtypes = [c_void_p, c_char_p, POINTER(c_size_t)]
         lib.grt_built_free.argtypes = [c_void_p]
@@ -233,9 +235,14 @@ def config_reset():
     host_lib().grt_config_reset()
 
 
+BVH_TYPES = {"sbvh": 1, "sah": 2, "bvh": 2, "bvh4": 4, "bvh8": 8}   # the reference's --bvh names (Args.cpp:71-84)
+
+
 def config_set(**kwargs):
     lib = host_lib()
     for key, value in kwargs.items():
+        if key == "bvh_type" and isinstance(value, str):
+            value = BVH_TYPES[value.lower()]
         if lib.grt_config_set(key.encode(), float(value)) != 0:
             raise KeyError(lib.grt_last_error().decode())
 

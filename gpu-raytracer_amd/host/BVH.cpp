@@ -1,4 +1,5 @@
 #include "BVH.h"
+#include "Config.h"
 #include "Mesh.h"
 
 #include <algorithm>
@@ -22,54 +23,13 @@ SAHBuilder::SAHBuilder(BVH2 & bvh, size_t primitive_count) : bvh(bvh) {
 	bvh.nodes.reserve(2 * primitive_count);
 }
 
-// Monotone float -> unsigned key (the reference radix-sorts on it, Core/Sort.h:133-140),
-// so -0.0 orders before +0.0 and the sort is stable on equal keys.
-static inline unsigned float_sort_key(float x) {
-	unsigned u; memcpy(&u, &x, 4);
-	unsigned mask = unsigned(-int(u >> 31)) | 0x80000000u;
-	return u ^ mask;
-}
-
 namespace {
-struct Split {
-	int   index = -1;     // first primitive (position in the sorted list) of the right side
-	int   axis  = -1;
-	float cost  = INFINITY;
-	AABB  left  = AABB::create_empty();
-	AABB  right = AABB::create_empty();
-};
-
 struct BuildContext {
 	SAHBuilder & b;
 	const std::vector<AABB> & prim_aabb;
 
-	// Evaluate every object split along every axis (reference: BVHPartitions.cpp:6-54).
-	// '<=' keeps the LAST best candidate, i.e. later axes and smaller indices win ties.
-	Split find_split(int first, int count) const {
-		Split s;
-		float * partial = b.sweep_cost.data();
-		for (int axis = 0; axis < 3; axis++) {
-			const int * order = b.sorted[axis].data();
-			AABB grow_l = AABB::create_empty();
-			for (int i = 1; i < count; i++) {
-				grow_l.expand(prim_aabb[order[first + i - 1]]);
-				partial[i] = grow_l.surface_area() * float(i);
-			}
-			AABB grow_r = AABB::create_empty();
-			for (int i = count - 1; i > 0; i--) {
-				grow_r.expand(prim_aabb[order[first + i]]);
-				float c = partial[i] + grow_r.surface_area() * float(count - i);
-				if (c <= s.cost) {
-					s.cost  = c;
-					s.index = first + i;
-					s.axis  = axis;
-					s.right = grow_r;
-				}
-			}
-		}
-		const int * order = b.sorted[s.axis].data();
-		for (int i = first; i < s.index; i++) s.left.expand(prim_aabb[order[i]]);
-		return s;
+	BVHObjectSplit find_split(int first, int count) const {
+		return bvh_find_object_split([this](int axis, int i) -> const AABB & { return prim_aabb[b.sorted[axis][i]]; }, first, count, b.sweep_cost.data());
 	}
 
 	void build_node(int node_index, int first, int count) {
@@ -79,7 +39,7 @@ struct BuildContext {
 			leaf.count = 1;
 			return;
 		}
-		Split s = find_split(first, count);
+		BVHObjectSplit s = find_split(first, count);
 
 		const int * split_order = b.sorted[s.axis].data();
 		for (int i = first;   i < s.index;       i++) b.goes_left[split_order[i]] = 1;
@@ -133,7 +93,7 @@ static void build_from_bounds(SAHBuilder & b, const std::vector<AABB> & prim_aab
 	// TLAS rebuild re-sorts the last frame's order), then get stably sorted by centroid.
 	for (int axis = 0; axis < 3; axis++) {
 		std::stable_sort(b.sorted[axis].begin(), b.sorted[axis].end(), [&](int l, int r) {
-			return float_sort_key(prim_center[l][axis]) < float_sort_key(prim_center[r][axis]);
+			return bvh_float_sort_key(prim_center[l][axis]) < bvh_float_sort_key(prim_center[r][axis]);
 		});
 	}
 
@@ -163,9 +123,16 @@ void SAHBuilder::build(const std::vector<Mesh> & meshes) {
 	build_from_bounds(*this, bounds, centers);
 }
 
-BVH2 BVH::create_from_triangles(const std::vector<Triangle> & triangles) {
+BVH2 BVH::create_sah_from_triangles(const std::vector<Triangle> & triangles) {
 	BVH2 bvh;
 	SAHBuilder(bvh, triangles.size()).build(triangles);
+	return bvh;
+}
+
+BVH2 BVH::create_from_triangles(const std::vector<Triangle> & triangles) {
+	if (cpu_config.bvh_type != BVHType::SBVH) return create_sah_from_triangles(triangles);
+	BVH2 bvh;
+	SBVHBuilder(bvh, triangles.size()).build(triangles);
 	return bvh;
 }
 

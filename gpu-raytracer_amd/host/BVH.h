@@ -7,7 +7,10 @@
 // the verbatim reference build in oracle/_ref.
 #pragma once
 #include <vector>
+#include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <stdexcept>
 
 #include "Triangle.h"
 
@@ -75,6 +78,50 @@ struct BVH8 {
 
 struct Mesh;
 
+// Monotone float -> unsigned key (the reference radix-sorts on it, Core/Sort.h:133-140),
+// so -0.0 orders before +0.0 and a stable sort on it reproduces the reference's order.
+inline unsigned bvh_float_sort_key(float x) {
+	unsigned u; memcpy(&u, &x, 4);
+	unsigned mask = unsigned(-int(u >> 31)) | 0x80000000u;
+	return u ^ mask;
+}
+
+struct BVHObjectSplit {
+	int   index = -1;     // first primitive (position in the sorted list) of the right side
+	int   axis  = -1;
+	float cost  = INFINITY;
+	AABB  left  = AABB::create_empty();
+	AABB  right = AABB::create_empty();
+};
+
+// Full-sweep SAH over the three pre-sorted orders (reference: BVHPartitions.cpp:6-54);
+// box_at(axis, i) is the box of the i-th primitive in that axis' order. '<=' keeps the LAST best
+// candidate, i.e. later axes and smaller indices win ties.
+template<typename BoxAt>
+BVHObjectSplit bvh_find_object_split(BoxAt box_at, int first, int count, float * partial) {
+	BVHObjectSplit s;
+	for (int axis = 0; axis < 3; axis++) {
+		AABB grow_l = AABB::create_empty();
+		for (int i = 1; i < count; i++) {
+			grow_l.expand(box_at(axis, first + i - 1));
+			partial[i] = grow_l.surface_area() * float(i);
+		}
+		AABB grow_r = AABB::create_empty();
+		for (int i = count - 1; i > 0; i--) {
+			grow_r.expand(box_at(axis, first + i));
+			float c = partial[i] + grow_r.surface_area() * float(count - i);
+			if (c <= s.cost) {
+				s.cost  = c;
+				s.index = first + i;
+				s.axis  = axis;
+				s.right = grow_r;
+			}
+		}
+	}
+	for (int i = first; i < s.index; i++) s.left.expand(box_at(s.axis, i));
+	return s;
+}
+
 // Top-down SAH builder over pre-sorted index lists.
 struct SAHBuilder {
 	BVH2 & bvh;
@@ -128,6 +175,29 @@ private:
 	void collapse(int node_index);
 };
 
+// SAH object splits + binned spatial splits (SBVH.cpp); leaves hold one reference each and a
+// triangle may be referenced from several leaves, so indices.size() >= triangle count.
+struct SBVHBuilder {
+	struct Ref { int triangle; AABB box; }; // the part of a triangle that lies in a subtree
+
+	BVH2 & bvh;
+
+	std::vector<Ref>   refs[3];   // the references of the subtree under construction, per axis order
+	std::vector<float> sweep_cost;
+	std::vector<char>  goes_left;
+
+	SBVHBuilder(BVH2 & bvh, size_t /*triangle_count*/) : bvh(bvh) { }
+
+	void build(const std::vector<Triangle> & triangles);
+};
+
+namespace BVHCollapser {
+	void collapse(BVH2 & bvh); // SBVH.cpp
+}
+
 namespace BVH {
+	// Binary BVH of cpu_config.bvh_type: spatial-split builder for SBVH, plain SAH otherwise
+	// (reference: BVH.cpp:14-36)
 	BVH2 create_from_triangles(const std::vector<Triangle> & triangles);
+	BVH2 create_sah_from_triangles(const std::vector<Triangle> & triangles);
 }

@@ -61,6 +61,10 @@ struct CPUConfig {
 	MipmapFilterType mipmap_filter = MipmapFilterType::BOX;
 	BVHType bvh_type = BVHType::BVH8;
 
+	float sah_cost_node = 4.0f;   // BVH8 conversion and leaf collapse
+	float sah_cost_leaf = 1.0f;
+	float sbvh_alpha    = 10e-5f; // 1: never split spatially, 0: always consider it
+
 	static constexpr int INVALID_SAMPLE = -1;
 };
 

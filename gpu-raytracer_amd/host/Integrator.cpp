@@ -65,6 +65,7 @@ void Integrator::init_materials() {
 //   * each BLAS' child / triangle base offsets are rebased into the shared arrays
 void Integrator::init_geometry() {
 	scene.asset_manager.wait_until_loaded();
+	scene.asset_manager.prepare_device_bvhs(cpu_config.bvh_type);
 	for (Mesh & mesh : scene.meshes) mesh.calc_aabb(scene);
 
 	const std::vector<MeshData> & mesh_datas = scene.asset_manager.mesh_datas;
@@ -84,16 +85,16 @@ void Integrator::init_geometry() {
 		mesh_data_bvh_offsets     [m] = int(node_total);
 		mesh_data_triangle_offsets[m] = int(triangle_total);
 		mesh_data_index_offsets   [m] = int(index_total);
-		node_total     += use_bvh8 ? mesh_datas[m].bvh8.nodes.size()   : mesh_datas[m].bvh2.nodes.size();
+		node_total     += use_bvh8 ? mesh_datas[m].bvh8.nodes.size()   : mesh_datas[m].device_bvh2.nodes.size();
 		triangle_total += mesh_datas[m].triangles.size();
-		index_total    += use_bvh8 ? mesh_datas[m].bvh8.indices.size() : mesh_datas[m].bvh2.indices.size();
+		index_total    += use_bvh8 ? mesh_datas[m].bvh8.indices.size() : mesh_datas[m].device_bvh2.indices.size();
 	}
 
 	aggregated_triangles.assign(index_total, DeviceTriangle());
 	reverse_indices.assign(triangle_total, 0);
 	for (size_t m = 0; m < mesh_data_count; m++) {
 		const MeshData & md = mesh_datas[m];
-		const std::vector<int> & order = use_bvh8 ? md.bvh8.indices : md.bvh2.indices;
+		const std::vector<int> & order = use_bvh8 ? md.bvh8.indices : md.device_bvh2.indices; // a spatial-split tree lists a triangle once per leaf that holds a part of it
 		for (size_t i = 0; i < order.size(); i++) {
 			const Triangle & t = md.triangles[order[i]];
 			DeviceTriangle & d = aggregated_triangles[mesh_data_index_offsets[m] + i];
@@ -125,7 +126,7 @@ void Integrator::init_geometry() {
 		aggregated_bvh_nodes_4.assign(node_total, BVHNode4());
 		memset((void *)aggregated_bvh_nodes_4.data(), 0, node_total * sizeof(BVHNode4));
 		for (size_t m = 0; m < mesh_data_count; m++) {
-			const std::vector<BVHNode4> & nodes = mesh_datas[m].bvh4.nodes;
+			const std::vector<BVHNode4> & nodes = mesh_datas[m].device_bvh4.nodes;
 			BVHNode4 * dst = aggregated_bvh_nodes_4.data() + mesh_data_bvh_offsets[m];
 			for (size_t n = 0; n < nodes.size(); n++) {
 				dst[n] = nodes[n];
@@ -157,7 +158,7 @@ void Integrator::init_geometry() {
 		aggregated_bvh_nodes_2.assign(node_total, BVHNode2());
 		memset(aggregated_bvh_nodes_2.data(), 0, node_total * sizeof(BVHNode2));
 		for (size_t m = 0; m < mesh_data_count; m++) {
-			const std::vector<BVHNode2> & nodes = mesh_datas[m].bvh2.nodes;
+			const std::vector<BVHNode2> & nodes = mesh_datas[m].device_bvh2.nodes;
 			BVHNode2 * dst = aggregated_bvh_nodes_2.data() + mesh_data_bvh_offsets[m];
 			for (size_t n = 0; n < nodes.size(); n++) {
 				dst[n] = nodes[n];

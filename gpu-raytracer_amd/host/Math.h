@@ -255,6 +255,11 @@ struct AABB {
 		b.fix_if_needed();
 		return b;
 	}
+	// Intersection of two boxes; empty unless it has volume (reference: Math/AABB.cpp:39-50)
+	static AABB overlap(const AABB & a, const AABB & b) {
+		AABB r; r.min = Vector3::max(a.min, b.min); r.max = Vector3::min(a.max, b.max);
+		return r.is_valid() ? r : create_empty();
+	}
 	// AABB of an OBB via component-wise |M| (reference: Math/AABB.cpp:55-69)
 	static AABB transform(const AABB & aabb, const Matrix4 & m) {
 		Vector3 center = 0.5f * (aabb.min + aabb.max);

@@ -6,13 +6,25 @@
 #include <vector>
 
 #include "BVH.h"
+#include "Config.h"
 #include "Material.h"
 
 struct MeshData {
 	std::vector<Triangle> triangles;
+	bool from_file = false; // loaded from a mesh file (as opposed to generated shapes)
+
 	BVH2 bvh2; // binary SAH BVH, one triangle per leaf
 	BVH8 bvh8; // its CWBVH collapse
-	BVH4 bvh4; // its 4-wide collapse (bvh_type = BVH4)
+	BVH4 bvh4; // its 4-wide collapse
+
+	// What the device traverses when cpu_config.bvh_type is not BVH8 (reference:
+	// AssetManager.cpp:57-95, BVH.cpp:14-59): the SAH or spatial-split binary tree, leaf-collapsed
+	// for file-loaded meshes, and for BVH4 the 4-wide collapse of that tree. Built on first use.
+	BVH2 device_bvh2;
+	BVH4 device_bvh4;
+	int  device_bvh_type = -1; // BVHType the two members above were built for
+
+	void prepare_device_bvh(BVHType type);
 };
 
 struct Scene;

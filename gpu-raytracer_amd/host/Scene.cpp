@@ -4,6 +4,8 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <mutex>
+#include <stdexcept>
 #include <thread>
 
 GPUConfig gpu_config;
@@ -74,9 +76,48 @@ static void build_blas(MeshData & mesh_data) {
 			Vector3(0.0f, 0.0f, 1.0f), Vector3(0.0f, 0.0f, 1.0f), Vector3(0.0f, 0.0f, 1.0f),
 			Vector2(0.0f, 1.0f), Vector2(0.5f, 0.0f), Vector2(1.0f, 1.0f)));
 	}
-	mesh_data.bvh2 = BVH::create_from_triangles(mesh_data.triangles);
+	mesh_data.bvh2 = BVH::create_sah_from_triangles(mesh_data.triangles);
 	BVH8Converter(mesh_data.bvh8, mesh_data.bvh2).convert();
 	BVH4Converter(mesh_data.bvh4, mesh_data.bvh2).convert();
+}
+
+void MeshData::prepare_device_bvh(BVHType type) {
+	if (type == BVHType::BVH8 || device_bvh_type == int(type)) return;
+	if (type == BVHType::SBVH) {
+		device_bvh2 = BVH2();
+		SBVHBuilder(device_bvh2, triangles.size()).build(triangles);
+	} else {
+		device_bvh2 = bvh2;
+	}
+	if (from_file) BVHCollapser::collapse(device_bvh2);
+	device_bvh4 = BVH4();
+	if (type == BVHType::BVH4) BVH4Converter(device_bvh4, device_bvh2).convert();
+	device_bvh_type = int(type);
+}
+
+void AssetManager::prepare_device_bvhs(BVHType type) {
+	wait_until_loaded();
+	std::atomic<size_t> next { 0 };
+	std::string failure;
+	std::mutex  failure_mutex;
+	auto work = [&]() {
+		while (true) {
+			size_t i = next.fetch_add(1);
+			if (i >= mesh_datas.size()) break;
+			try {
+				mesh_datas[i].prepare_device_bvh(type);
+			} catch (const std::exception & e) {
+				std::lock_guard<std::mutex> lock(failure_mutex);
+				failure = e.what();
+			}
+		}
+	};
+	unsigned worker_count = std::max(1u, std::thread::hardware_concurrency());
+	std::vector<std::thread> workers;
+	for (unsigned w = 1; w < worker_count; w++) workers.emplace_back(work);
+	work();
+	for (std::thread & t : workers) t.join();
+	if (!failure.empty()) throw std::runtime_error(failure);
 }
 
 Handle<MeshData> AssetManager::add_mesh_data(std::vector<Triangle> triangles) {
@@ -124,7 +165,10 @@ void AssetManager::wait_until_loaded() {
 				if (i >= pending_meshes.size()) break;
 				PendingMesh & job = pending_meshes[i];
 				MeshData & mesh_data = mesh_datas[job.handle];
-				if (job.loader) mesh_data.triangles = job.loader(job.filename);
+				if (job.loader) {
+					mesh_data.triangles = job.loader(job.filename);
+					mesh_data.from_file = true;
+				}
 				build_blas(mesh_data);
 			}
 		};

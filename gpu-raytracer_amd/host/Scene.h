@@ -40,6 +40,7 @@ struct AssetManager {
 
 	// Builds every pending BLAS (one job per mesh file on a thread pool) and decodes textures.
 	void wait_until_loaded();
+	void prepare_device_bvhs(BVHType type); // builds MeshData::device_bvh* for a non-BVH8 type, in parallel
 
 	MeshData & get_mesh_data(Handle<MeshData> h) { return mesh_datas[h.handle]; }
 	Material & get_material (Handle<Material> h) { return materials [h.handle]; }

@@ -36,7 +36,18 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "sigma_n")                             gpu_config.sigma_n = float(value);
 	else if (k == "sigma_l")                             gpu_config.sigma_l = float(value);
 	else if (k == "aov_mask")                            gpu_config.aov_mask = unsigned(value);
-	else if (k == "bvh_type")                            cpu_config.bvh_type = int(value) == 2 ? BVHType::BVH : (int(value) == 4 ? BVHType::BVH4 : BVHType::BVH8);
+	else if (k == "bvh_type") { // 2: binary SAH, 1: binary with spatial splits (SBVH), 4, 8: the wide collapses
+		switch (int(value)) {
+			case 1:  cpu_config.bvh_type = BVHType::SBVH; break;
+			case 2:  cpu_config.bvh_type = BVHType::BVH;  break;
+			case 4:  cpu_config.bvh_type = BVHType::BVH4; break;
+			case 8:  cpu_config.bvh_type = BVHType::BVH8; break;
+			default: g_host_error = "bvh_type must be 1 (sbvh), 2 (sah), 4 (bvh4) or 8 (bvh8)"; return -1;
+		}
+	}
+	else if (k == "sah_cost_node")                       cpu_config.sah_cost_node = float(value);
+	else if (k == "sah_cost_leaf")                       cpu_config.sah_cost_leaf = float(value);
+	else if (k == "sbvh_alpha")                          cpu_config.sbvh_alpha = float(value);
 	else if (k == "enable_scene_update")                 cpu_config.enable_scene_update = value != 0;
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
 	else if (k == "initial_height")                      cpu_config.initial_height = int(value);
@@ -141,6 +152,9 @@ const void * grt_mesh_data_array(void * scene, int mesh_data, const char * name,
 	if (n == "bvh4_indices") RET(md.bvh4.indices)
 	if (n == "bvh8_nodes")   RET(md.bvh8.nodes)
 	if (n == "bvh8_indices") RET(md.bvh8.indices)
+	if (n == "device_bvh2_nodes")   RET(md.device_bvh2.nodes)
+	if (n == "device_bvh2_indices") RET(md.device_bvh2.indices)
+	if (n == "device_bvh4_nodes")   RET(md.device_bvh4.nodes)
 	*bytes = 0;
 	return nullptr;
 }
@@ -311,9 +325,25 @@ void * grt_build_blas(const float * tris24, int n) {
 		MeshData * md = new MeshData();
 		md->triangles.resize(n);
 		memcpy((void *)md->triangles.data(), tris24, size_t(n) * sizeof(Triangle));
-		md->bvh2 = BVH::create_from_triangles(md->triangles);
+		md->bvh2 = BVH::create_sah_from_triangles(md->triangles);
 		BVH8Converter(md->bvh8, md->bvh2).convert();
 		BVH4Converter(md->bvh4, md->bvh2).convert();
+		return md;
+	GRT_CATCH(nullptr)
+}
+// The binary tree of cpu_config.bvh_type (SAH or SBVH), optionally leaf-collapsed as for a
+// file-loaded mesh, and its 4-wide form: query with "device_bvh2_nodes" / "device_bvh2_indices" /
+// "device_bvh4_nodes".
+void * grt_build_device_bvh(const float * tris24, int n, int collapse) {
+	GRT_TRY
+		MeshData * md = new MeshData();
+		md->triangles.resize(n);
+		memcpy((void *)md->triangles.data(), tris24, size_t(n) * sizeof(Triangle));
+		md->from_file = collapse != 0;
+		if (cpu_config.bvh_type != BVHType::SBVH) md->bvh2 = BVH::create_sah_from_triangles(md->triangles);
+		BVHType type = cpu_config.bvh_type == BVHType::BVH8 ? BVHType::BVH : cpu_config.bvh_type;
+		md->prepare_device_bvh(type);
+		if (type != BVHType::BVH4) BVH4Converter(md->device_bvh4, md->device_bvh2).convert();
 		return md;
 	GRT_CATCH(nullptr)
 }
@@ -327,6 +357,9 @@ const void * grt_built_array(void * mesh_data, const char * name, size_t * bytes
 	if (n == "bvh4_indices") RET(md.bvh4.indices)
 	if (n == "bvh8_nodes")   RET(md.bvh8.nodes)
 	if (n == "bvh8_indices") RET(md.bvh8.indices)
+	if (n == "device_bvh2_nodes")   RET(md.device_bvh2.nodes)
+	if (n == "device_bvh2_indices") RET(md.device_bvh2.indices)
+	if (n == "device_bvh4_nodes")   RET(md.device_bvh4.nodes)
 #undef RET
 	*bytes = 0;
 	return nullptr;

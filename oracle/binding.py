@@ -125,6 +125,9 @@ def ref_lib():
         if hasattr(r, "ref_bvh4_node_count"):
             r.ref_bvh4_node_count.argtypes = [c_void_p]
             r.ref_bvh4_copy_nodes.argtypes = [c_void_p, c_void_p]
+        if hasattr(r, "ref_bvh_build_binary_variant"):
+            r.ref_bvh_build_binary_variant.restype = c_void_p
+            r.ref_bvh_build_binary_variant.argtypes = [c_void_p, c_int, c_int, c_int, ctypes.c_float]
         for f in ("ref_bvh_ms_bvh2", "ref_bvh_ms_bvh8"):
             getattr(r, f).argtypes = [c_void_p]
             getattr(r, f).restype = ctypes.c_double
@@ -147,6 +150,21 @@ def ref_build(tris24):
     if hasattr(r, "ref_bvh4_node_count"):
         out["bvh4_nodes"] = np.zeros(r.ref_bvh4_node_count(h) * 128, np.uint8); r.ref_bvh4_copy_nodes(h, out["bvh4_nodes"].ctypes.data)
     out["ms_bvh2"], out["ms_bvh8"] = r.ref_bvh_ms_bvh2(h), r.ref_bvh_ms_bvh8(h)
+    r.ref_bvh_free(h)
+    return out
+
+
+def ref_build_binary_variant(tris24, sbvh, collapse, sbvh_alpha=10e-5):
+    """The reference's device-side binary tree for bvh_type = BVH / SBVH (optionally leaf-collapsed
+    like a file-loaded mesh) and the BVH4 converted from it."""
+    r = ref_lib()
+    t = np.ascontiguousarray(tris24, dtype=np.float32)
+    h = r.ref_bvh_build_binary_variant(t.ctypes.data, t.size // 24, int(sbvh), int(collapse), sbvh_alpha)
+    out = {}
+    out["bvh2_nodes"] = np.zeros(r.ref_bvh2_node_count(h) * 32, np.uint8); r.ref_bvh2_copy_nodes(h, out["bvh2_nodes"].ctypes.data)
+    out["bvh2_indices"] = np.zeros(r.ref_bvh2_index_count(h), np.int32); r.ref_bvh2_copy_indices(h, out["bvh2_indices"].ctypes.data)
+    out["bvh4_nodes"] = np.zeros(r.ref_bvh4_node_count(h) * 128, np.uint8); r.ref_bvh4_copy_nodes(h, out["bvh4_nodes"].ctypes.data)
+    out["ms_bvh2"] = r.ref_bvh_ms_bvh2(h)
     r.ref_bvh_free(h)
     return out
 

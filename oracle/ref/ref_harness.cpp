@@ -10,11 +10,14 @@
 //                    BVH8Converter::convert       (Src/BVH/Converters/BVH8Converter.cpp:7-22)
 //                    SAHBuilder::build(meshes)    (Src/BVH/Builders/SAHBuilder.cpp:102-104)
 //                    BVH4Converter::convert       (Src/BVH/Converters/BVH4Converter.cpp:3-78)
+//                    SBVHBuilder::build           (Src/BVH/Builders/SBVHBuilder.cpp:13-68, via BVH::create_from_triangles)
+//                    BVHCollapser::collapse       (Src/BVH/BVHCollapser.cpp:97-114)
 #include "Core/Format.h"
 #include "BVH/BVH.h"
 #include "BVH/Builders/SAHBuilder.h"
 #include "BVH/Converters/BVH8Converter.h"
 #include "BVH/Converters/BVH4Converter.h"
+#include "BVH/BVHCollapser.h"
 #include "Renderer/Mesh.h"
 
 #include <vector>
@@ -77,6 +80,29 @@ void * ref_bvh_build_triangles(const float * tris24, int n) {
 	BVH4Converter(r->bvh4, r->bvh2).convert();
 	r->ms_bvh2 = t1 - t0;
 	r->ms_bvh8 = t2 - t1;
+	return r;
+}
+
+// The binary tree the reference hands to the device for bvh_type = BVH (sbvh = 0) or SBVH
+// (sbvh = 1), leaf-collapsed like a file-loaded mesh when collapse != 0
+// (Assets/AssetManager.cpp:80-89), and the BVH4 built from it. bvh8 stays empty.
+void * ref_bvh_build_binary_variant(const float * tris24, int n, int sbvh, int collapse, float sbvh_alpha) {
+	Array<Triangle> triangles(n);
+	memcpy((void *)triangles.data(), tris24, size_t(n) * sizeof(Triangle));
+
+	RefBVH * r = new RefBVH();
+	MuteStdout mute;
+	float saved_alpha = cpu_config.sbvh_alpha;
+	cpu_config.bvh_type   = sbvh ? BVHType::SBVH : BVHType::BVH;
+	cpu_config.sbvh_alpha = sbvh_alpha;
+	double t0 = now_ms();
+	r->bvh2 = BVH::create_from_triangles(triangles);
+	if (collapse) BVHCollapser::collapse(r->bvh2);
+	double t1 = now_ms();
+	BVH4Converter(r->bvh4, r->bvh2).convert();
+	cpu_config.bvh_type   = BVHType::BVH8;
+	cpu_config.sbvh_alpha = saved_alpha;
+	r->ms_bvh2 = t1 - t0;
 	return r;
 }
 

@@ -2,7 +2,9 @@
 """Regenerates the golden fixtures. Needs /root/reference (for oracle/_ref) -- run in the build
 container only; the fixtures it writes are what travels to the GPU box.
 
-bvh_golden.json   sha256 of the BVH2 nodes / BVH8 nodes / BVH8 indices (and, separately, the BVH4 nodes) that the REFERENCE'S OWN
+bvh_golden.json   ("variants": the same for the binary trees the device gets with bvh_type = BVH / SBVH,
+                  leaf-collapsed as the reference does for file-loaded meshes, and their BVH4 form)
+                  sha256 of the BVH2 nodes / BVH8 nodes / BVH8 indices (and, separately, the BVH4 nodes) that the REFERENCE'S OWN
                   builder (oracle/_ref/libref_bvh.so = /root/reference/Src/BVH compiled verbatim)
                   produces for every Cornell mesh, every Sponza mesh (one aggregate digest plus the
                   10 largest individually) and three seeded random triangle soups.
@@ -37,7 +39,63 @@ def soup(seed, n):
     return t
 
 
+def slivers(seed, n):
+    """Long thin overlapping triangles: the case spatial splits exist for."""
+    rng = np.random.default_rng(seed)
+    p0 = (rng.random((n, 3)) * 10).astype(np.float32)
+    t = np.zeros((n, 24), np.float32)
+    t[:, 0:3] = p0
+    t[:, 3:6] = p0 + (rng.random((n, 3)) * 8 - 4).astype(np.float32)
+    t[:, 6:9] = p0 + (rng.random((n, 3)) * 0.5).astype(np.float32)
+    return t
+
+
+VARIANT_SOUPS = (("soup", 12, 257), ("soup", 13, 5000), ("slivers", 3, 400), ("slivers", 4, 1500))
+SPONZA_SBVH_STRIDE = 32   # every 32nd Sponza mesh goes through the (slow) spatial-split builder
+
+
+def variant_digests(tris, sbvh_alpha=10e-5):
+    out = {}
+    for sbvh in (0, 1):
+        for collapse in (0, 1):
+            ref = oracle.ref_build_binary_variant(tris, sbvh, collapse, sbvh_alpha)
+            out["%s_%s" % ("sbvh" if sbvh else "sah", "collapsed" if collapse else "raw")] = {
+                "sha256": digest(ref["bvh2_nodes"], ref["bvh2_indices"]), "sha256_bvh4": digest(ref["bvh4_nodes"]),
+                "nodes": int(ref["bvh2_nodes"].size // 32), "indices": int(ref["bvh2_indices"].size)}
+    return out
+
+
+def make_variants():
+    variants = {"soups": {}, "sponza": {}}
+    for kind, seed, n in VARIANT_SOUPS:
+        tris = soup(seed, n) if kind == "soup" else slivers(seed, n)
+        variants["soups"]["%s_%d_%d" % (kind, seed, n)] = variant_digests(tris)
+    variants["soups"]["slivers_3_400_alpha0"] = variant_digests(slivers(3, 400), 0.0)["sbvh_collapsed"]
+    grt.config_reset()
+    scene = grt.Scene(grt.scene_path("sponza"))
+    scene.wait_until_loaded()
+    agg = hashlib.sha256()
+    for m in range(scene.mesh_data_count):
+        tris = scene.mesh_data_array(m, "triangles", np.float32)
+        ref = oracle.ref_build_binary_variant(tris, 0, 1)
+        agg.update(digest(ref["bvh2_nodes"], ref["bvh2_indices"], ref["bvh4_nodes"]).encode())
+        if m % SPONZA_SBVH_STRIDE == 0:
+            ref = oracle.ref_build_binary_variant(tris, 1, 1)
+            variants["sponza"][str(m)] = {"sha256": digest(ref["bvh2_nodes"], ref["bvh2_indices"], ref["bvh4_nodes"]),
+                                          "triangles": int(tris.size // 24), "indices": int(ref["bvh2_indices"].size)}
+    variants["sponza_sah_collapsed_aggregate"] = agg.hexdigest()
+    scene.close()
+    return variants
+
+
 def main():
+    if "--only-variants" in sys.argv:
+        path = os.path.join(HERE, "bvh_golden.json")
+        golden = json.load(open(path))
+        golden["variants"] = make_variants()
+        json.dump(golden, open(path, "w"), indent=1, sort_keys=True)
+        print("updated variants")
+        return
     assert oracle.ref_lib() is not None, "oracle/_ref/libref_bvh.so missing: run `make -C oracle ref` where /root/reference exists"
     golden = {"source": "reference BVH builder compiled verbatim (oracle/_ref)", "meshes": {}}
     for name in ("cornellbox", "sponza"):
@@ -68,6 +126,7 @@ def main():
             "sha256": digest(ref["bvh2_nodes"], ref["bvh2_indices"], ref["bvh8_nodes"], ref["bvh8_indices"]),
             "sha256_bvh4": digest(ref["bvh4_nodes"]),
             "bvh2_nodes": int(ref["bvh2_nodes"].size // 32), "bvh8_nodes": int(ref["bvh8_nodes"].size // 80)}
+    golden["variants"] = make_variants()
     json.dump(golden, open(os.path.join(HERE, "bvh_golden.json"), "w"), indent=1, sort_keys=True)
 
     grt.config_reset()

@@ -46,6 +46,80 @@ def product_build(grt, tris24):
     return out
 
 
+def slivers(seed, n):
+    rng = np.random.default_rng(seed)
+    p0 = (rng.random((n, 3)) * 10).astype(np.float32)
+    t = np.zeros((n, 24), np.float32)
+    t[:, 0:3] = p0
+    t[:, 3:6] = p0 + (rng.random((n, 3)) * 8 - 4).astype(np.float32)
+    t[:, 6:9] = p0 + (rng.random((n, 3)) * 0.5).astype(np.float32)
+    return t
+
+
+def product_device_bvh(grt, tris24, sbvh, collapse, sbvh_alpha=None):
+    """The binary tree (and its BVH4 form) the host hands to the device for bvh_type = BVH / SBVH."""
+    import ctypes
+    lib = grt.host_lib()
+    grt.config_reset()
+    grt.config_set(bvh_type=1 if sbvh else 2)
+    if sbvh_alpha is not None:
+        grt.config_set(sbvh_alpha=sbvh_alpha)
+    t = np.ascontiguousarray(tris24, np.float32)
+    h = lib.grt_build_device_bvh(t.ctypes.data, t.size // 24, int(collapse))
+    grt.config_reset()
+    assert h, lib.grt_last_error()
+    out = {}
+    for name, key, dtype in (("device_bvh2_nodes", "bvh2_nodes", np.uint8), ("device_bvh2_indices", "bvh2_indices", np.int32), ("device_bvh4_nodes", "bvh4_nodes", np.uint8)):
+        n = ctypes.c_size_t()
+        ptr = lib.grt_built_array(h, name.encode(), ctypes.byref(n))
+        out[key] = np.frombuffer((ctypes.c_char * n.value).from_address(ptr), dtype=dtype).copy()
+    lib.grt_built_free(h)
+    return out
+
+
+@pytest.mark.parametrize("key", sorted(k for k in GOLDEN["variants"]["soups"] if not k.endswith("alpha0")))
+def test_sbvh_and_collapsed_trees_match_reference_digest(grt, key):
+    """SBVHBuilder.cpp + BVHPartitions.cpp:103-282 (spatial splits, unsplitting) and BVHCollapser.cpp:
+    node bytes, index lists (longer than the triangle count once a triangle is split) and the BVH4
+    converted from them equal the verbatim reference build."""
+    kind, seed, n = key.split("_")
+    tris = soup(int(seed), int(n)) if kind == "soup" else slivers(int(seed), int(n))
+    for variant, want in GOLDEN["variants"]["soups"][key].items():
+        built = product_device_bvh(grt, tris, variant.startswith("sbvh"), variant.endswith("collapsed"))
+        assert built["bvh2_nodes"].size // 32 == want["nodes"] and built["bvh2_indices"].size == want["indices"], variant
+        assert digest(built["bvh2_nodes"], built["bvh2_indices"]) == want["sha256"], variant
+        assert digest(built["bvh4_nodes"]) == want["sha256_bvh4"], variant
+    if kind == "slivers":
+        assert GOLDEN["variants"]["soups"][key]["sbvh_raw"]["indices"] > int(n)   # the fixture does exercise spatial splits
+
+
+def test_full_sbvh_alpha_zero_matches_reference_digest(grt):
+    want = GOLDEN["variants"]["soups"]["slivers_3_400_alpha0"]
+    built = product_device_bvh(grt, slivers(3, 400), True, True, sbvh_alpha=0.0)
+    assert digest(built["bvh2_nodes"], built["bvh2_indices"]) == want["sha256"] and digest(built["bvh4_nodes"]) == want["sha256_bvh4"]
+
+
+def test_sponza_device_trees_match_reference_digest(grt):
+    """File-loaded meshes: the SAH tree is leaf-collapsed before it (or its BVH4) reaches the device
+    (AssetManager.cpp:85-87) -- all 383 Sponza meshes; the spatial-split tree for every 32nd of them."""
+    want = GOLDEN["variants"]
+    grt.config_reset()
+    grt.config_set(bvh_type=4)
+    scene = grt.Scene(grt.scene_path("sponza"))
+    pt = grt.Pathtracer(scene, 8, 8, device=-1)      # init_geometry builds the device variants
+    agg = hashlib.sha256()
+    for m in range(scene.mesh_data_count):
+        agg.update(digest(scene.mesh_data_array(m, "device_bvh2_nodes", np.uint8), scene.mesh_data_array(m, "device_bvh2_indices", np.int32),
+                          scene.mesh_data_array(m, "device_bvh4_nodes", np.uint8)).encode())
+    assert agg.hexdigest() == want["sponza_sah_collapsed_aggregate"]
+    for m, entry in want["sponza"].items():
+        tris = scene.mesh_data_array(int(m), "triangles", np.float32)
+        built = product_device_bvh(grt, tris, True, True)
+        assert built["bvh2_indices"].size == entry["indices"]
+        assert digest(built["bvh2_nodes"], built["bvh2_indices"], built["bvh4_nodes"]) == entry["sha256"], m
+    pt.close(); scene.close(); grt.config_reset()
+
+
 @pytest.mark.parametrize("key", sorted(GOLDEN["soups"]))
 def test_triangle_soups_match_reference_digest(grt, key):
     seed, n = map(int, key.split("_"))
@@ -85,6 +159,12 @@ def test_live_against_reference_builder(grt, oracle):
         ref, built = oracle.ref_build(tris), product_build(grt, tris)
         for key in ("bvh2_nodes", "bvh2_indices", "bvh8_nodes", "bvh8_indices", "bvh4_nodes"):
             assert np.array_equal(ref[key], built[key]), key
+    for tris in (soup(31, 700), slivers(32, 300)):
+        for sbvh in (0, 1):
+            for collapse in (0, 1):
+                ref, built = oracle.ref_build_binary_variant(tris, sbvh, collapse), product_device_bvh(grt, tris, sbvh, collapse)
+                for key in ("bvh2_nodes", "bvh2_indices", "bvh4_nodes"):
+                    assert np.array_equal(ref[key], built[key]), (sbvh, collapse, key)
 
 
 def test_cwbvh_structural_invariants(grt):
