@@ -61,6 +61,12 @@ struct CPUConfig {
 	MipmapFilterType mipmap_filter = MipmapFilterType::BOX;
 	BVHType bvh_type = BVHType::BVH8;
 
+	// "<mesh file>.bvh" caches (BVHCache.h). The reference always reads and writes them; a library
+	// that may sit on a read-only asset tree only does so when asked to.
+	bool enable_bvh_cache        = false;
+	bool bvh_force_rebuild       = false; // ignore existing caches (they are still rewritten)
+	bool enable_bvh_optimization = false; // recorded in the cache header; the optimiser itself is not part of this path
+
 	float sah_cost_node = 4.0f;   // BVH8 conversion and leaf collapse
 	float sah_cost_leaf = 1.0f;
 	float sbvh_alpha    = 10e-5f; // 1: never split spatially, 0: always consider it

@@ -12,6 +12,7 @@
 struct MeshData {
 	std::vector<Triangle> triangles;
 	bool from_file = false; // loaded from a mesh file (as opposed to generated shapes)
+	std::string filename;   // of that file; its BVH cache is filename + ".bvh"
 
 	BVH2 bvh2; // binary SAH BVH, one triangle per leaf
 	BVH8 bvh8; // its CWBVH collapse
@@ -20,6 +21,7 @@ struct MeshData {
 	// What the device traverses when cpu_config.bvh_type is not BVH8 (reference:
 	// AssetManager.cpp:57-95, BVH.cpp:14-59): the SAH or spatial-split binary tree, leaf-collapsed
 	// for file-loaded meshes, and for BVH4 the 4-wide collapse of that tree. Built on first use.
+	BVH2 sbvh;        // the uncollapsed spatial-split tree (built, or read from the mesh's .bvh cache)
 	BVH2 device_bvh2;
 	BVH4 device_bvh4;
 	int  device_bvh_type = -1; // BVHType the two members above were built for

@@ -1,4 +1,5 @@
 #include "Scene.h"
+#include "BVHCache.h"
 #include "Parser.h"
 
 #include <atomic>
@@ -68,6 +69,34 @@ Handle<MeshData> AssetManager::add_mesh_data(const std::string & filename, Fallb
 	return handle;
 }
 
+static void build_blas(MeshData & mesh_data);
+
+// One mesh file: triangles and tree come from the "<file>.bvh" cache when caching is on and the
+// cache is current, else from the loader and the builder (reference: AssetManager.cpp:57-95). The
+// cache holds the tree kind of the current bvh_type -- SAH or spatial-split -- so with SBVH
+// selected the SAH tree (which the CWBVH is made from) is still built here.
+static void load_mesh_file(MeshData & mesh_data, const std::string & filename, const AssetManager::FallbackLoader & loader) {
+	mesh_data.from_file = true;
+	mesh_data.filename  = filename;
+
+	bool use_cache = cpu_config.enable_bvh_cache;
+	std::string bvh_filename = BVHCache::get_bvh_filename(filename);
+	BVH2 cached;
+	bool cache_hit = use_cache && BVHCache::try_to_load(filename, bvh_filename, &mesh_data.triangles, &cached);
+	if (!cache_hit) mesh_data.triangles = loader(filename);
+
+	bool cache_is_sbvh = BVHCache::underlying_bvh_type() == BVHType::SBVH;
+	if (cache_hit && cache_is_sbvh) mesh_data.sbvh = std::move(cached);
+	if (cache_hit && !cache_is_sbvh) {
+		mesh_data.bvh2 = std::move(cached);
+		BVH8Converter(mesh_data.bvh8, mesh_data.bvh2).convert();
+		BVH4Converter(mesh_data.bvh4, mesh_data.bvh2).convert();
+		return;
+	}
+	build_blas(mesh_data);
+	if (use_cache && !cache_is_sbvh) BVHCache::save(bvh_filename, mesh_data.triangles, mesh_data.bvh2);
+}
+
 static void build_blas(MeshData & mesh_data) {
 	if (mesh_data.triangles.empty()) {
 		// An empty mesh is replaced by one dummy triangle (reference: AssetManager.cpp:64-78)
@@ -84,8 +113,11 @@ static void build_blas(MeshData & mesh_data) {
 void MeshData::prepare_device_bvh(BVHType type) {
 	if (type == BVHType::BVH8 || device_bvh_type == int(type)) return;
 	if (type == BVHType::SBVH) {
-		device_bvh2 = BVH2();
-		SBVHBuilder(device_bvh2, triangles.size()).build(triangles);
+		if (sbvh.nodes.empty()) {
+			SBVHBuilder(sbvh, triangles.size()).build(triangles);
+			if (from_file && cpu_config.enable_bvh_cache && cpu_config.bvh_type == BVHType::SBVH) BVHCache::save(BVHCache::get_bvh_filename(filename), triangles, sbvh);
+		}
+		device_bvh2 = sbvh;
 	} else {
 		device_bvh2 = bvh2;
 	}
@@ -165,11 +197,8 @@ void AssetManager::wait_until_loaded() {
 				if (i >= pending_meshes.size()) break;
 				PendingMesh & job = pending_meshes[i];
 				MeshData & mesh_data = mesh_datas[job.handle];
-				if (job.loader) {
-					mesh_data.triangles = job.loader(job.filename);
-					mesh_data.from_file = true;
-				}
-				build_blas(mesh_data);
+				if (job.loader) load_mesh_file(mesh_data, job.filename, job.loader);
+				else            build_blas(mesh_data);
 			}
 		};
 		std::vector<std::thread> workers;

@@ -45,6 +45,8 @@ int grt_config_set(const char * key, double value) {
 			default: g_host_error = "bvh_type must be 1 (sbvh), 2 (sah), 4 (bvh4) or 8 (bvh8)"; return -1;
 		}
 	}
+	else if (k == "enable_bvh_cache")                    cpu_config.enable_bvh_cache = value != 0;
+	else if (k == "bvh_force_rebuild")                   cpu_config.bvh_force_rebuild = value != 0;
 	else if (k == "sah_cost_node")                       cpu_config.sah_cost_node = float(value);
 	else if (k == "sah_cost_leaf")                       cpu_config.sah_cost_leaf = float(value);
 	else if (k == "sbvh_alpha")                          cpu_config.sbvh_alpha = float(value);

@@ -205,3 +205,97 @@ def test_bvh4_collapse_invariants(grt):
             else:
                 stack.append((index, box))
     assert (covered == 1).all() and visited > n // 4
+
+
+def _read_bvh_cache(path):
+    """Parses a .bvh cache the way the reference's BVHLoader does (BVHLoader.cpp:19-33,150-176):
+    28-byte header, then one raw deflate stream with triangles, nodes, indices."""
+    import struct, zlib
+    raw = open(path, "rb").read()
+    ident, version, bvh_type, optimized, cost_node, cost_leaf, n_tri, n_node, n_index = struct.unpack("<4sbb?xffiii", raw[:28])
+    payload = zlib.decompressobj(-15).decompress(raw[28:])
+    assert len(payload) == 96 * n_tri + 32 * n_node + 4 * n_index
+    tris = np.frombuffer(payload[:96 * n_tri], np.float32).reshape(-1, 24)
+    nodes = np.frombuffer(payload[96 * n_tri:96 * n_tri + 32 * n_node], np.uint8)
+    indices = np.frombuffer(payload[96 * n_tri + 32 * n_node:], np.int32)
+    return dict(ident=ident, version=version, bvh_type=bvh_type, optimized=optimized, cost_node=cost_node, cost_leaf=cost_leaf,
+                triangles=tris, nodes=nodes, indices=indices)
+
+
+def _write_bvh_cache(path, c):
+    import struct, zlib
+    z = zlib.compressobj(9, zlib.DEFLATED, -15)
+    body = z.compress(c["triangles"].tobytes() + c["nodes"].tobytes() + c["indices"].tobytes()) + z.flush()
+    header = struct.pack("<4sbb?xffiii", c["ident"], c["version"], c["bvh_type"], c["optimized"], c["cost_node"], c["cost_leaf"],
+                         c["triangles"].shape[0], c["nodes"].size // 32, c["indices"].size)
+    open(path, "wb").write(header + body)
+
+
+def test_bvh_cache_files_follow_the_reference_format(grt, tmp_path):
+    """<mesh>.bvh (BVHLoader.cpp): written on the first load, read on the next, ignored when stale,
+    built with other settings, truncated or inconsistent; holds the SAH tree, or the spatial-split
+    tree when bvh_type = SBVH."""
+    rng = np.random.default_rng(2)
+    n = 300
+    p0 = rng.random((n, 3)) * 4; p1 = p0 + rng.random((n, 3)) * 3 - 1.5; p2 = p0 + rng.random((n, 3)) * 0.4
+    obj = tmp_path / "m.obj"
+    with open(obj, "w") as f:
+        for a, b, c in zip(p0, p1, p2):
+            f.write("v %.6f %.6f %.6f\nv %.6f %.6f %.6f\nv %.6f %.6f %.6f\n" % (*a, *b, *c))
+        for i in range(n):
+            f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+    cache = str(obj) + ".bvh"
+
+    def load(**config):
+        grt.config_reset()
+        grt.config_set(**config)
+        scene = grt.Scene(str(obj)); scene.wait_until_loaded()
+        out = {k: scene.mesh_data_array(0, k, dt).copy() for k, dt in (("triangles", np.float32), ("bvh2_nodes", np.uint8), ("bvh2_indices", np.int32), ("bvh8_nodes", np.uint8))}
+        scene.close()
+        return out
+
+    built = load()                                   # caching is opt-in: nothing is written by default
+    assert not os.path.exists(cache)
+    first = load(enable_bvh_cache=1)
+    c = _read_bvh_cache(cache)
+    assert c["ident"] == b"BVH\0" and c["version"] == 7 and c["bvh_type"] == 0 and not c["optimized"] and (c["cost_node"], c["cost_leaf"]) == (4.0, 1.0)
+    assert np.array_equal(c["triangles"].ravel(), built["triangles"]) and np.array_equal(c["nodes"], built["bvh2_nodes"]) and np.array_equal(c["indices"], built["bvh2_indices"])
+    assert all(np.array_equal(first[k], built[k]) for k in built)
+
+    # a cache written by someone else (here: python, in the reference's layout) is what gets loaded ...
+    marked = dict(c); marked["triangles"] = c["triangles"].copy(); marked["triangles"][5, 0] += 0.125
+    _write_bvh_cache(cache, marked)
+    second = load(enable_bvh_cache=1)
+    assert second["triangles"].reshape(-1, 24)[5, 0] == marked["triangles"][5, 0] and np.array_equal(second["bvh2_nodes"], built["bvh2_nodes"])
+    assert np.array_equal(second["bvh8_nodes"], built["bvh8_nodes"])             # the CWBVH is re-derived from the cached tree
+    # ... unless rebuilding is forced, the settings differ, or the mesh file is newer
+    assert np.array_equal(load(enable_bvh_cache=1, bvh_force_rebuild=1)["triangles"], built["triangles"])
+    _write_bvh_cache(cache, marked)
+    assert np.array_equal(load(enable_bvh_cache=1, sah_cost_node=3.0)["triangles"], built["triangles"])
+    _write_bvh_cache(cache, marked)
+    later = os.stat(cache).st_mtime + 10
+    os.utime(obj, (later, later))
+    assert np.array_equal(load(enable_bvh_cache=1)["triangles"], built["triangles"])
+    assert np.array_equal(_read_bvh_cache(cache)["triangles"].ravel(), built["triangles"])   # and the cache was refreshed
+
+    # damaged caches are rejected, not trusted: truncated stream, child index out of range
+    raw = open(cache, "rb").read()
+    open(cache, "wb").write(raw[:len(raw) // 2])
+    os.utime(cache, (later + 5, later + 5))
+    assert np.array_equal(load(enable_bvh_cache=1)["bvh2_nodes"], built["bvh2_nodes"])
+    bad = _read_bvh_cache(cache); bad["indices"] = bad["indices"].copy(); bad["indices"][3] = n + 7
+    _write_bvh_cache(cache, bad)
+    os.utime(cache, (later + 5, later + 5))
+    assert np.array_equal(load(enable_bvh_cache=1)["bvh2_indices"], built["bvh2_indices"])
+
+    # bvh_type = SBVH caches the spatial-split tree (header type 1, more references than triangles)
+    os.remove(cache)
+    grt.config_reset(); grt.config_set(bvh_type="sbvh", enable_bvh_cache=1)
+    scene = grt.Scene(str(obj)); pt = grt.Pathtracer(scene, 8, 8, device=-1)
+    device_nodes = scene.mesh_data_array(0, "device_bvh2_nodes", np.uint8).copy()
+    pt.close(); scene.close()
+    c = _read_bvh_cache(cache)
+    assert c["bvh_type"] == 1 and c["indices"].size > n and c["triangles"].shape[0] == n
+    scene = grt.Scene(str(obj)); pt = grt.Pathtracer(scene, 8, 8, device=-1)   # second time: from the cache
+    assert np.array_equal(scene.mesh_data_array(0, "device_bvh2_nodes", np.uint8), device_nodes)
+    pt.close(); scene.close(); grt.config_reset()
