@@ -300,10 +300,10 @@ bool is_primitive_shape(std::string_view type) {
 Handle<MeshData> parse_shape(const XMLNode * node, Scene & scene, LoadState & state, std::string * name) {
 	std::string_view type = node->get_attribute_value("type");
 
-	if (type == "obj") {
+	if (type == "obj" || type == "ply") { // reference: MitsubaLoader.cpp:434-442
 		std::string filename = join_path(state.directory, node->require_child_by_name("filename").get_attribute_value("value"));
 		*name = strip_directory(filename);
-		return scene.asset_manager.add_mesh_data(filename, OBJLoader::load);
+		return scene.asset_manager.add_mesh_data(filename, type == "obj" ? OBJLoader::load : PLYLoader::load);
 	}
 	if (is_primitive_shape(type)) {
 		Matrix4 transform = parse_transform_matrix(node);
@@ -331,7 +331,7 @@ Handle<MeshData> parse_shape(const XMLNode * node, Scene & scene, LoadState & st
 		*name = std::string(type);
 		return scene.asset_manager.add_mesh_data(std::move(triangles));
 	}
-	// ply / serialized / hair need loaders outside this path's scope
+	// serialized / hair need loaders outside this path's scope
 	warn(*node, "shape type '" + std::string(type) + "' not supported");
 	return Handle<MeshData> { INVALID };
 }

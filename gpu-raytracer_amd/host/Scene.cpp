@@ -191,20 +191,31 @@ void AssetManager::wait_until_loaded() {
 	auto t0 = std::chrono::steady_clock::now();
 	{
 		std::atomic<size_t> next { 0 };
+		std::string failure;
+		std::mutex  failure_mutex;
 		auto work = [&]() {
 			while (true) {
 				size_t i = next.fetch_add(1);
 				if (i >= pending_meshes.size()) break;
 				PendingMesh & job = pending_meshes[i];
 				MeshData & mesh_data = mesh_datas[job.handle];
-				if (job.loader) load_mesh_file(mesh_data, job.filename, job.loader);
-				else            build_blas(mesh_data);
+				try {
+					if (job.loader) load_mesh_file(mesh_data, job.filename, job.loader);
+					else            build_blas(mesh_data);
+				} catch (const std::exception & e) { // a worker must not let it escape: report it from the calling thread
+					std::lock_guard<std::mutex> lock(failure_mutex);
+					if (failure.empty()) failure = e.what();
+				}
 			}
 		};
 		std::vector<std::thread> workers;
 		for (unsigned w = 1; w < worker_count; w++) workers.emplace_back(work);
 		work();
 		for (std::thread & t : workers) t.join();
+		if (!failure.empty()) {
+			pending_meshes.clear();
+			throw ParseError(failure);
+		}
 	}
 	bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	{
@@ -296,10 +307,12 @@ Scene::Scene() : camera(Math::deg_to_rad(85.0f)) {
 		std::string ext = file_extension(scene_filename);
 		if (ext == "obj") {
 			add_mesh(scene_filename, asset_manager.add_mesh_data(scene_filename, OBJLoader::load));
+		} else if (ext == "ply") {
+			add_mesh(scene_filename, asset_manager.add_mesh_data(scene_filename, PLYLoader::load));
 		} else if (ext == "xml") {
 			MitsubaLoader::load(scene_filename, *this);
 		} else {
-			throw ParseError("'" + scene_filename + "': file format is not supported (expected .xml or .obj)");
+			throw ParseError("'" + scene_filename + "': file format is not supported (expected .xml, .obj or .ply)");
 		}
 	}
 	sky.load(cpu_config.sky_filename);

@@ -85,6 +85,7 @@ struct Scene {
 };
 
 namespace OBJLoader     { std::vector<Triangle> load(const std::string & filename); }
+namespace PLYLoader     { std::vector<Triangle> load(const std::string & filename); }
 namespace MitsubaLoader { void load(const std::string & filename, Scene & scene); }
 namespace TextureLoader { bool load(const std::string & filename, Texture * texture); }
 

@@ -69,8 +69,8 @@ def test_obj_loader_fan_triangulation_and_negative_indices(grt, tmp_path):
 
 
 def test_unsupported_scene_format_is_an_error(grt, tmp_path):
-    bad = tmp_path / "scene.ply"
-    bad.write_text("ply\n")
+    bad = tmp_path / "scene.serialized"
+    bad.write_text("x\n")
     grt.config_reset()
     with pytest.raises(RuntimeError, match="not supported"):
         grt.Scene(str(bad))
@@ -299,3 +299,91 @@ def test_bvh_cache_files_follow_the_reference_format(grt, tmp_path):
     scene = grt.Scene(str(obj)); pt = grt.Pathtracer(scene, 8, 8, device=-1)   # second time: from the cache
     assert np.array_equal(scene.mesh_data_array(0, "device_bvh2_nodes", np.uint8), device_nodes)
     pt.close(); scene.close(); grt.config_reset()
+
+
+def _ply_bytes(fmt, positions, normals, uvs, faces, index_type="int", with_extras=False):
+    """Serialises a mesh as PLY in one of the three encodings (an independent writer for the reader under test)."""
+    import struct
+    header = ["ply", "format %s 1.0" % fmt, "comment made by the test", "element vertex %d" % len(positions),
+              "property float x", "property float y", "property float z"]
+    if normals is not None:
+        header += ["property float nx", "property float ny", "property float nz"]
+    if with_extras:
+        header += ["property uchar red"]
+    if uvs is not None:
+        header += ["property double s", "property double t"]
+    header += ["element face %d" % len(faces), "property list uchar %s vertex_indices" % index_type]
+    if with_extras:
+        header += ["property short flags"]
+    header += ["end_header"]
+    out = ("\n".join(header) + "\n").encode()
+    e = "<" if fmt == "binary_little_endian" else ">"
+    icode = {"int": "i", "uint": "I", "ushort": "H"}[index_type]
+    for v in range(len(positions)):
+        if fmt == "ascii":
+            vals = list(positions[v]) + (list(normals[v]) if normals is not None else []) + ([200] if with_extras else []) + (list(uvs[v]) if uvs is not None else [])
+            out += (" ".join(repr(float(x)) if not isinstance(x, int) else str(x) for x in vals) + "\n").encode()
+        else:
+            out += struct.pack(e + "3f", *positions[v])
+            if normals is not None: out += struct.pack(e + "3f", *normals[v])
+            if with_extras: out += struct.pack("B", 200)
+            if uvs is not None: out += struct.pack(e + "2d", *uvs[v])
+    for f in faces:
+        if fmt == "ascii":
+            out += ("%d %s%s\n" % (len(f), " ".join(map(str, f)), " 3" if with_extras else "")).encode()
+        else:
+            out += struct.pack("B", len(f)) + struct.pack(e + "%d%s" % (len(f), icode), *f)
+            if with_extras: out += struct.pack(e + "h", 3)
+    return out
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary_little_endian", "binary_big_endian"])
+def test_ply_loader_reads_all_three_encodings(grt, tmp_path, fmt):
+    """PLYLoader.cpp: scalar types by name, s/t as texture coordinates with the v flip, polygons
+    fan-triangulated around their first corner, unknown properties skipped, and a mesh without
+    normals gets face normals from the Triangle constructor."""
+    rng = np.random.default_rng(4)
+    positions = np.round(rng.random((7, 3)) * 4 - 2, 3).astype(np.float32)
+    normals = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (7, 1))
+    uvs = np.round(rng.random((7, 2)), 3)
+    faces = [[0, 1, 2], [2, 3, 4, 5], [1, 6, 5, 4, 3]]
+    want_corners = [(0, 1, 2), (2, 3, 4), (2, 4, 5), (1, 6, 5), (1, 5, 4), (1, 4, 3)]
+    for variant, (with_normals, extras, index_type) in enumerate(((True, False, "int"), (False, True, "ushort" if fmt != "ascii" else "uint"))):
+        path = tmp_path / ("m%d.ply" % variant)
+        path.write_bytes(_ply_bytes(fmt, positions, normals if with_normals else None, uvs, faces, index_type, extras))
+        grt.config_reset()
+        scene = grt.Scene(str(path)); scene.wait_until_loaded()
+        tris = scene.mesh_data_array(0, "triangles", np.float32).reshape(-1, 24).copy()
+        scene.close()
+        assert tris.shape[0] == len(want_corners)
+        for t, corners in zip(tris, want_corners):
+            got_p = t[0:9].reshape(3, 3); got_uv = t[18:24].reshape(3, 2); got_n = t[9:18].reshape(3, 3)
+            face_n = np.cross(positions[corners[1]] - positions[corners[0]], positions[corners[2]] - positions[corners[0]])
+            flipped = with_normals and face_n[2] < 0        # the Triangle constructor swaps corners 1 and 2 when every normal opposes the face
+            order = (corners[0], corners[2], corners[1]) if flipped else corners
+            assert np.array_equal(got_p, positions[list(order)])
+            want_uv = np.stack([uvs[list(order), 0].astype(np.float32), 1.0 - uvs[list(order), 1].astype(np.float32)], 1)
+            assert np.allclose(got_uv, want_uv, atol=1e-6)
+            if with_normals:
+                assert np.array_equal(got_n, normals[list(order)])
+            else:
+                unit = face_n / np.linalg.norm(face_n)
+                assert np.allclose(got_n, np.tile(unit, (3, 1)), atol=1e-5)
+
+
+def test_ply_in_a_mitsuba_scene_and_malformed_files(grt, tmp_path):
+    positions = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], np.float32)
+    (tmp_path / "quad.ply").write_bytes(_ply_bytes("binary_little_endian", positions, None, None, [[0, 1, 3, 2]]))
+    (tmp_path / "s.xml").write_text('<scene version="0.5.0"><shape type="ply"><string name="filename" value="quad.ply"/></shape></scene>')
+    grt.config_reset()
+    scene = grt.Scene(str(tmp_path / "s.xml")); scene.wait_until_loaded()
+    assert scene.mesh_data_array(0, "triangles", np.float32).size == 2 * 24
+    scene.close()
+    for name, data in (("short.ply", _ply_bytes("binary_little_endian", positions, None, None, [[0, 1, 3, 2]])[:-5]),
+                       ("range.ply", _ply_bytes("ascii", positions, None, None, [[0, 1, 9]])),
+                       ("edge.ply", _ply_bytes("ascii", positions, None, None, [[0, 1]])),
+                       ("elem.ply", b"ply\nformat ascii 1.0\nelement edge 1\nproperty int a\nend_header\n1\n"),
+                       ("nohdr.ply", b"plx\n")):
+        (tmp_path / name).write_bytes(data)
+        with pytest.raises(Exception):
+            s = grt.Scene(str(tmp_path / name)); s.wait_until_loaded()
