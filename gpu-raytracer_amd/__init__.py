@@ -149,6 +149,8 @@ def host_lib():
         lib.grt_pathtracer_lights_total_weight.argtypes = [c_void_p]
         lib.grt_pathtracer_read_aov.argtypes = [c_void_p, c_int, c_int, c_void_p]
         lib.grt_pathtracer_read_framebuffer.argtypes = [c_void_p, c_void_p]
+        lib.grt_pathtracer_save_image.argtypes = [c_void_p, c_char_p]
+        lib.grt_export_image.argtypes = [c_char_p, c_int, c_int, c_int, c_void_p]
         lib.grt_pathtracer_array.restype = c_void_p
         lib.grt_pathtracer_array.argtypes = [c_void_p, c_char_p, POINTER(c_size_t)]
         lib.grt_pathtracer_sky_size.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_float)]
@@ -245,6 +247,15 @@ def config_set(**kwargs):
             value = BVH_TYPES[value.lower()]
         if lib.grt_config_set(key.encode(), float(value)) != 0:
             raise KeyError(lib.grt_last_error().decode())
+
+
+def export_image(filename, rgb):
+    """Writes a (height, width, 3) float32 image (row 0 at the bottom, as the integrator holds frames)
+    through the host's PPM / EXR exporters."""
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w, _ = rgb.shape
+    lib = host_lib()
+    _host_check(lib.grt_export_image(str(filename).encode(), w, w, h, rgb.ctypes.data))
 
 
 def config_get(key):
@@ -446,6 +457,11 @@ class Pathtracer:
         image = np.zeros((self.height, self.pitch, 4), np.float32)
         _host_check(host_lib().grt_pathtracer_read_framebuffer(self.handle, image.ctypes.data))
         return image
+
+    def save_image(self, filename):
+        """Screenshot like the reference's `-o`: .ppm (ACES + gamma, 8 bit) or .exr (raw radiance, half),
+        plus albedo.exr / normal.exr / position.exr next to it for the enabled AOVs (Main.cpp:199-246)."""
+        _host_check(host_lib().grt_pathtracer_save_image(self.handle, str(filename).encode()))
 
     def read_aov(self, aov, accumulated=True):
         image = np.zeros((self.height, self.pitch, 4), np.float32)

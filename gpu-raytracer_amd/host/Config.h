@@ -44,6 +44,7 @@ struct GPUConfig {
 };
 
 enum struct BVHType { BVH, SBVH, BVH4, BVH8 };
+enum struct IntegratorType { PATHTRACER, AO };
 enum struct MipmapFilterType { BOX, LANCZOS, KAISER };
 
 struct CPUConfig {
@@ -57,6 +58,8 @@ struct CPUConfig {
 	std::string output_filename     = "render.ppm";
 
 	bool enable_scene_update = false;
+
+	IntegratorType integrator = IntegratorType::PATHTRACER; // read by the command-line front end
 
 	MipmapFilterType mipmap_filter = MipmapFilterType::BOX;
 	BVHType bvh_type = BVHType::BVH8;

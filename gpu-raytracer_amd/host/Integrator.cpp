@@ -1,4 +1,5 @@
 #include "Integrator.h"
+#include "Exporters.h"
 
 #include <stdexcept>
 
@@ -319,6 +320,28 @@ std::vector<float> Integrator::read_aov(AOVType type, bool accumulated) {
 	std::vector<float> image(size_t(screen_pitch) * screen_height * 4);
 	check(rt_read_aov(ctx, int(type), image.data(), accumulated ? 1 : 0));
 	return image;
+}
+
+static std::vector<Vector3> rgb_of(const std::vector<float> & rgba) {
+	std::vector<Vector3> rgb(rgba.size() / 4);
+	for (size_t i = 0; i < rgb.size(); i++) rgb[i] = Vector3(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2]);
+	return rgb;
+}
+
+void Integrator::save_image(const std::string & filename) {
+	std::string error;
+	if (!Exporters::save(filename, screen_pitch, screen_width, screen_height, rgb_of(read_framebuffer()), &error)) throw std::runtime_error(error);
+
+	size_t slash = filename.find_last_of('/');
+	std::string directory = slash == std::string::npos ? std::string() : filename.substr(0, slash + 1);
+	const struct { AOVType type; const char * name; } extras[] = {
+		{ AOVType::ALBEDO, "albedo.exr" }, { AOVType::NORMAL, "normal.exr" }, { AOVType::POSITION, "position.exr" } };
+	for (const auto & extra : extras) {
+		if (!aov_is_enabled(extra.type)) continue;
+		if (!EXRExporter::save(directory + extra.name, screen_pitch, screen_width, screen_height, rgb_of(read_aov(extra.type, true)))) {
+			throw std::runtime_error("failed to write '" + directory + extra.name + "'");
+		}
+	}
 }
 
 std::vector<float> Integrator::read_framebuffer() {

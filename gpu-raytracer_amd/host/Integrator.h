@@ -121,6 +121,11 @@ struct Integrator {
 	std::vector<float> read_aov(AOVType type, bool accumulated = true);
 	std::vector<float> read_framebuffer();
 
+	// Screenshot as the reference takes it (Main.cpp:199-246): the frame to `filename` (.ppm tone-mapped,
+	// .exr raw radiance) and, for each enabled auxiliary AOV, albedo.exr / normal.exr / position.exr
+	// next to it. Throws on an unsupported extension or a write failure.
+	void save_image(const std::string & filename);
+
 	rt_gpu_config make_device_config() const;
 
 	// queue sizes per bounce and stage times of the last render() (rt_get_counters)

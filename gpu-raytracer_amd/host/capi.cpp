@@ -3,6 +3,7 @@
 // reached only through the Pathtracer, i.e. through include/gpu_raytracer_amd.h.
 #include <stdexcept>
 #include "Pathtracer.h"
+#include "Exporters.h"
 #include "AO.h"
 
 #include <cstring>
@@ -253,6 +254,22 @@ int grt_pathtracer_read_aov(void * pt, int aov, int accumulated, float * dst) {
 	GRT_TRY
 		std::vector<float> image = as_integrator(pt)->read_aov(AOVType(aov), accumulated != 0);
 		memcpy(dst, image.data(), image.size() * sizeof(float));
+		return 0;
+	GRT_CATCH(-1)
+}
+int grt_pathtracer_save_image(void * pt, const char * filename) {
+	GRT_TRY
+		as_integrator(pt)->save_image(filename);
+		return 0;
+	GRT_CATCH(-1)
+}
+// Writes an RGB float image (x + y * pitch, row 0 at the bottom) through the exporters, without an integrator
+int grt_export_image(const char * filename, int pitch, int width, int height, const float * rgb) {
+	GRT_TRY
+		std::vector<Vector3> data(size_t(pitch) * height);
+		memcpy((void *)data.data(), rgb, data.size() * sizeof(Vector3));
+		std::string error;
+		if (!Exporters::save(filename, pitch, width, height, data, &error)) throw std::runtime_error(error);
 		return 0;
 	GRT_CATCH(-1)
 }

@@ -581,3 +581,42 @@ def test_trace_statistics_equal_the_oracle_counters(grt, oracle):
     assert abs(stats["shadow"]["nodes"] - oc.shadow_stats.nodes) <= 2e-3 * oc.shadow_stats.nodes
     assert abs(stats["closest"]["algorithmic_bytes"] - oc.trace_stats.algorithmic_bytes()) <= 1e-3 * oc.trace_stats.algorithmic_bytes()
     pt.close(); scene.close()
+
+
+@pytest.mark.gpu
+def test_command_line_render_and_screenshots_match_the_library(grt, tmp_path):
+    """host/pathtracer (Args.cpp + the headless part of Main.cpp:75-150) renders what the library
+    renders for the same options, and Integrator::save_image writes the frame the exporters' way."""
+    import subprocess
+    from test_loaders import CLI, _parse_exr
+    scene_file = grt.scene_path("cornellbox")
+    out = tmp_path / "cli.exr"
+    # -W / -H / -b are given, but what the scene file says (<film> size, maxDepth) is applied later and
+    # wins, as in the reference (MitsubaLoader.cpp:611-613, Main.cpp:109)
+    r = subprocess.run([CLI, "-s", scene_file, "-W", "96", "-H", "64", "-N", "5", "-b", "2", "--bvh", "bvh8", "-o", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "Wrote" in r.stdout
+    _, cli = _parse_exr(out)
+
+    grt.config_reset()
+    scene = grt.Scene(scene_file)
+    w, h = int(grt.config_get("initial_width")), int(grt.config_get("initial_height"))
+    assert (w, h) == (1024, 1024) and cli["R"].shape == (h, w) and grt.config_get("num_bounces") > 2
+    pt = grt.Pathtracer(scene, w, h, device=0)
+    pt.update()
+    while True:
+        pt.render()
+        if pt.sample_index >= 5:
+            break
+        pt.update()
+    assert pt.sample_index == 5
+    pt.save_image(tmp_path / "lib.exr"); pt.save_image(tmp_path / "lib.ppm")
+    _, lib = _parse_exr(tmp_path / "lib.exr")
+    frame = pt.read_framebuffer()[:, :w, :3][::-1]
+    for k, name in enumerate("RGB"):
+        assert lib[name].shape == (h, w) and np.array_equal(lib[name], frame[:, :, k].astype(np.float16).astype(np.float32))
+        assert np.allclose(cli[name], lib[name], rtol=2e-3, atol=1e-4), name
+    raw = open(tmp_path / "lib.ppm", "rb").read()
+    header = b"P6\n %d\n %d\n 255\n" % (w, h)
+    assert raw.startswith(header) and len(raw) == len(header) + w * h * 3 and np.frombuffer(raw[len(header):], np.uint8).mean() > 20
+    pt.close(); scene.close()

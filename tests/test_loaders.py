@@ -387,3 +387,100 @@ def test_ply_in_a_mitsuba_scene_and_malformed_files(grt, tmp_path):
         (tmp_path / name).write_bytes(data)
         with pytest.raises(Exception):
             s = grt.Scene(str(tmp_path / name)); s.wait_until_loaded()
+
+
+def _parse_exr(path):
+    """Minimal reader for uncompressed scan-line OpenEXR files, written from the file format
+    description (magic, attribute list, offset table, one chunk per line with channels in
+    alphabetical order)."""
+    import struct
+    raw = open(path, "rb").read()
+    assert raw[:4] == bytes([0x76, 0x2f, 0x31, 0x01]) and struct.unpack("<I", raw[4:8])[0] == 2
+    pos, attrs = 8, {}
+    def cstr():
+        nonlocal pos
+        end = raw.index(b"\0", pos); s = raw[pos:end].decode(); pos = end + 1; return s
+    while raw[pos] != 0:
+        name, kind = cstr(), cstr()
+        size = struct.unpack("<i", raw[pos:pos + 4])[0]; pos += 4
+        attrs[name] = (kind, raw[pos:pos + size]); pos += size
+    pos += 1
+    kind, ch = attrs["channels"]
+    channels, cp = [], 0
+    while ch[cp] != 0:
+        end = ch.index(b"\0", cp); nm = ch[cp:end].decode(); cp = end + 1
+        ptype, _, xs, ys = struct.unpack("<iIii", ch[cp:cp + 16]); cp += 16
+        channels.append((nm, ptype)); assert xs == ys == 1
+    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0"
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    offsets = struct.unpack("<%dQ" % h, raw[pos:pos + 8 * h])
+    image = {nm: np.zeros((h, w), np.float32) for nm, _ in channels}
+    for row in range(h):
+        y, size = struct.unpack("<ii", raw[offsets[row]:offsets[row] + 8])
+        p = offsets[row] + 8
+        for nm, ptype in channels:
+            assert ptype == 1
+            image[nm][y - y0] = np.frombuffer(raw[p:p + 2 * w], np.float16).astype(np.float32); p += 2 * w
+        assert p - offsets[row] - 8 == size
+    assert offsets[-1] + 8 + size == len(raw)
+    return channels, image
+
+
+def test_exporters_write_the_reference_file_formats(grt, tmp_path):
+    """PPMExporter.cpp / EXRExporter.cpp: rows flipped (the frame's row 0 is the bottom), PPM header
+    'P6\\n w\\n h\\n 255\\n' with truncating 8-bit conversion of the tone-mapped frame (post.frag: ACES,
+    gamma 2.2, through the 8-bit back buffer), EXR with half channels B, G, R and no compression."""
+    rng = np.random.default_rng(8)
+    h, w = 5, 7
+    img = (rng.random((h, w, 3)) * 3).astype(np.float32)
+    img[0, 0] = (-1.0, 0.0, 70000.0)     # negative, zero, beyond the half range
+    img[1, 1] = (1e-8, 6.1e-5, 0.333)    # flushes to zero, the smallest normal half, an inexact value
+
+    grt.export_image(tmp_path / "a.ppm", img)
+    raw = open(tmp_path / "a.ppm", "rb").read()
+    header = b"P6\n %d\n %d\n 255\n" % (w, h)
+    assert raw.startswith(header) and len(raw) == len(header) + w * h * 3
+    got = np.frombuffer(raw[len(header):], np.uint8).reshape(h, w, 3)
+    c = np.maximum(img.astype(np.float64), 0)
+    aces = np.clip(c * (2.51 * c + 0.03) / (c * (2.43 * c + 0.59) + 0.14), 0, 1) ** (1 / 2.2)
+    want = np.floor(aces * 255 + 0.5)[::-1]
+    assert np.abs(got.astype(np.int32) - want).max() <= 1 and (got == want).mean() > 0.9   # k/255*255 may land just under k in fp32
+
+    grt.export_image(tmp_path / "a.exr", img)
+    channels, image = _parse_exr(tmp_path / "a.exr")
+    assert channels == [("B", 1), ("G", 1), ("R", 1)]
+    with np.errstate(over="ignore"):
+        want16 = img[::-1].astype(np.float16).astype(np.float32)      # numpy rounds to nearest even as well
+    for k, name in enumerate("RGB"):
+        assert np.array_equal(image[name], want16[:, :, k]), name
+    assert np.isinf(image["B"][h - 1, 0]) and image["R"][h - 1, 0] == -1.0
+
+    with pytest.raises(RuntimeError, match="unsupported output file extension"):
+        grt.export_image(tmp_path / "a.png", img)
+    with pytest.raises(RuntimeError, match="failed to write"):
+        grt.export_image(tmp_path / "no_such_dir" / "a.ppm", img)
+
+
+CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-raytracer_amd", "host", "pathtracer")
+
+
+def test_command_line_front_end_parses_like_the_reference():
+    """Args.cpp:51-184 -- option names, the messages for unknown options and bad values; no device needed."""
+    import subprocess
+    run = lambda *a: subprocess.run([CLI, *a], capture_output=True, text=True, timeout=60)
+    r = run("--help")
+    assert r.returncode == 0
+    for name in ("--integrator", "--width", "--height", "--bounce", "--samples", "--output", "--scene", "--sky", "--bvh", "--nee", "--mis",
+                 "--force-rebuild", "--sah-node", "--sah-leaf", "--sbvh-alpha", "--mipmap", "--help"):
+        assert name in r.stdout, name
+    r = run()
+    assert r.returncode == 1 and "no scene file" in r.stderr
+    r = run("--bvh", "bvh16", "x.xml")
+    assert r.returncode == 1 and "not a recognized BVH type" in r.stderr
+    r = run("-I", "photonmap", "x.xml")
+    assert r.returncode == 1 and "not a recognized integrator type" in r.stderr
+    r = run("--frobnicate", "-s", "/no/such/scene.xml", "--device", "-1")
+    assert "Unrecognized command line option '--frobnicate'" in r.stdout and r.returncode == 1 and "unable to open" in r.stderr
+    r = run("/no/such/scene.obj", "--device", "-1")                 # a bare argument is a scene file
+    assert r.returncode == 1 and "scene.obj" in r.stderr
