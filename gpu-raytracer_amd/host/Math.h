@@ -87,6 +87,7 @@ namespace Math {
 		return diff / (fabsf(a) + fabsf(b)) < epsilon;
 	}
 	inline float deg_to_rad(float deg) { return deg / 180.0f * PI; }
+	template<typename T> inline T lerp(const T & a, const T & b, float t) { return (1.0f - t) * a + t * b; }
 	inline float luminance(float r, float g, float b) { return 0.299f * r + 0.587f * g + 0.114f * b; }
 	inline float luminance(const Vector3 & c) { return luminance(c.x, c.y, c.z); }
 	inline float gamma_to_linear(float x) {

@@ -12,7 +12,8 @@
 struct MeshData {
 	std::vector<Triangle> triangles;
 	bool from_file = false; // loaded from a mesh file (as opposed to generated shapes)
-	std::string filename;   // of that file; its BVH cache is filename + ".bvh"
+	std::string filename;   // of that file
+	std::string bvh_filename; // its BVH cache: filename + ".bvh", or "<archive>.shape_<i>.bvh" for serialized meshes
 
 	BVH2 bvh2; // binary SAH BVH, one triangle per leaf
 	BVH8 bvh8; // its CWBVH collapse

@@ -331,7 +331,22 @@ Handle<MeshData> parse_shape(const XMLNode * node, Scene & scene, LoadState & st
 		*name = std::string(type);
 		return scene.asset_manager.add_mesh_data(std::move(triangles));
 	}
-	// serialized / hair need loaders outside this path's scope
+	if (type == "serialized") { // reference: MitsubaLoader.cpp:487-500
+		std::string relative = std::string(node->require_child_by_name("filename").get_attribute_value("value"));
+		std::string filename = join_path(state.directory, relative);
+		int shape_index = node->get_child_value_optional("shapeIndex", 0);
+		*name = relative + "_" + std::to_string(shape_index);
+		// one archive holds many meshes: the reference keys (and caches) each by "<archive>.shape_<i>.bvh"
+		std::string key = filename + ".shape_" + std::to_string(shape_index) + ".bvh";
+		return scene.asset_manager.add_mesh_data(key, key, [filename, shape_index](const std::string &) { return SerializedLoader::load(filename, shape_index); });
+	}
+	if (type == "hair") { // reference: MitsubaLoader.cpp:501-512
+		std::string relative = std::string(node->require_child_by_name("filename").get_attribute_value("value"));
+		std::string filename = join_path(state.directory, relative);
+		*name = relative;
+		float radius = node->get_child_value_optional("radius", 0.0025f);
+		return scene.asset_manager.add_mesh_data(filename, [radius](const std::string & f) { return MitshairLoader::load(f, radius); });
+	}
 	warn(*node, "shape type '" + std::string(type) + "' not supported");
 	return Handle<MeshData> { INVALID };
 }

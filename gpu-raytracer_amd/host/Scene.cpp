@@ -59,13 +59,17 @@ AssetManager::AssetManager() {
 }
 
 Handle<MeshData> AssetManager::add_mesh_data(const std::string & filename, FallbackLoader loader) {
+	return add_mesh_data(filename, BVHCache::get_bvh_filename(filename), std::move(loader));
+}
+
+Handle<MeshData> AssetManager::add_mesh_data(const std::string & filename, const std::string & bvh_filename, FallbackLoader loader) {
 	auto it = mesh_data_cache.find(filename);
 	if (it != mesh_data_cache.end()) return it->second;
 
 	Handle<MeshData> handle { int(mesh_datas.size()) };
 	mesh_datas.emplace_back();
 	mesh_data_cache[filename] = handle;
-	pending_meshes.push_back({ handle.handle, filename, std::move(loader) });
+	pending_meshes.push_back({ handle.handle, filename, std::move(loader), bvh_filename });
 	return handle;
 }
 
@@ -75,12 +79,12 @@ static void build_blas(MeshData & mesh_data);
 // cache is current, else from the loader and the builder (reference: AssetManager.cpp:57-95). The
 // cache holds the tree kind of the current bvh_type -- SAH or spatial-split -- so with SBVH
 // selected the SAH tree (which the CWBVH is made from) is still built here.
-static void load_mesh_file(MeshData & mesh_data, const std::string & filename, const AssetManager::FallbackLoader & loader) {
-	mesh_data.from_file = true;
-	mesh_data.filename  = filename;
+static void load_mesh_file(MeshData & mesh_data, const std::string & filename, const std::string & bvh_filename, const AssetManager::FallbackLoader & loader) {
+	mesh_data.from_file    = true;
+	mesh_data.filename     = filename;
+	mesh_data.bvh_filename = bvh_filename;
 
 	bool use_cache = cpu_config.enable_bvh_cache;
-	std::string bvh_filename = BVHCache::get_bvh_filename(filename);
 	BVH2 cached;
 	bool cache_hit = use_cache && BVHCache::try_to_load(filename, bvh_filename, &mesh_data.triangles, &cached);
 	if (!cache_hit) mesh_data.triangles = loader(filename);
@@ -115,7 +119,7 @@ void MeshData::prepare_device_bvh(BVHType type) {
 	if (type == BVHType::SBVH) {
 		if (sbvh.nodes.empty()) {
 			SBVHBuilder(sbvh, triangles.size()).build(triangles);
-			if (from_file && cpu_config.enable_bvh_cache && cpu_config.bvh_type == BVHType::SBVH) BVHCache::save(BVHCache::get_bvh_filename(filename), triangles, sbvh);
+			if (from_file && cpu_config.enable_bvh_cache && cpu_config.bvh_type == BVHType::SBVH) BVHCache::save(bvh_filename, triangles, sbvh);
 		}
 		device_bvh2 = sbvh;
 	} else {
@@ -156,7 +160,7 @@ Handle<MeshData> AssetManager::add_mesh_data(std::vector<Triangle> triangles) {
 	Handle<MeshData> handle { int(mesh_datas.size()) };
 	mesh_datas.emplace_back();
 	mesh_datas.back().triangles = std::move(triangles);
-	pending_meshes.push_back({ handle.handle, std::string(), nullptr });
+	pending_meshes.push_back({ handle.handle, std::string(), nullptr, std::string() });
 	return handle;
 }
 
@@ -200,7 +204,7 @@ void AssetManager::wait_until_loaded() {
 				PendingMesh & job = pending_meshes[i];
 				MeshData & mesh_data = mesh_datas[job.handle];
 				try {
-					if (job.loader) load_mesh_file(mesh_data, job.filename, job.loader);
+					if (job.loader) load_mesh_file(mesh_data, job.filename, job.bvh_filename, job.loader);
 					else            build_blas(mesh_data);
 				} catch (const std::exception & e) { // a worker must not let it escape: report it from the calling thread
 					std::lock_guard<std::mutex> lock(failure_mutex);

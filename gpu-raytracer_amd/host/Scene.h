@@ -33,6 +33,8 @@ struct AssetManager {
 	using FallbackLoader = std::function<std::vector<Triangle>(const std::string & filename)>;
 
 	Handle<MeshData> add_mesh_data(const std::string & filename, FallbackLoader loader);
+	// `filename` keys the mesh (and is what the loader receives); `bvh_filename` names its cache file
+	Handle<MeshData> add_mesh_data(const std::string & filename, const std::string & bvh_filename, FallbackLoader loader);
 	Handle<MeshData> add_mesh_data(std::vector<Triangle> triangles);
 	Handle<Material> add_material(Material material);
 	Handle<Medium>   add_medium(Medium medium);
@@ -55,7 +57,7 @@ private:
 	std::map<std::string, Handle<MeshData>> mesh_data_cache;
 	std::map<std::string, Handle<Texture>>  texture_cache;
 
-	struct PendingMesh    { int handle; std::string filename; FallbackLoader loader; };
+	struct PendingMesh    { int handle; std::string filename; FallbackLoader loader; std::string bvh_filename; };
 	struct PendingTexture { int handle; std::string filename; };
 	std::vector<PendingMesh>    pending_meshes;
 	std::vector<PendingTexture> pending_textures;
@@ -86,6 +88,8 @@ struct Scene {
 
 namespace OBJLoader     { std::vector<Triangle> load(const std::string & filename); }
 namespace PLYLoader     { std::vector<Triangle> load(const std::string & filename); }
+namespace SerializedLoader { std::vector<Triangle> load(const std::string & filename, int shape_index); }
+namespace MitshairLoader   { std::vector<Triangle> load(const std::string & filename, float radius); }
 namespace MitsubaLoader { void load(const std::string & filename, Scene & scene); }
 namespace TextureLoader { bool load(const std::string & filename, Texture * texture); }
 

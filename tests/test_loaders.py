@@ -484,3 +484,97 @@ def test_command_line_front_end_parses_like_the_reference():
     assert "Unrecognized command line option '--frobnicate'" in r.stdout and r.returncode == 1 and "unable to open" in r.stderr
     r = run("/no/such/scene.obj", "--device", "-1")                 # a bare argument is a scene file
     assert r.returncode == 1 and "scene.obj" in r.stderr
+
+
+def _serialized_archive(meshes, version):
+    """Mitsuba .serialized writer for the test: [0x041c, version, zlib(mesh)]* + offsets + count."""
+    import struct, zlib
+    out, offsets = b"", []
+    for m in meshes:
+        offsets.append(len(out))
+        real = "d" if m["double"] else "f"
+        flags = (0x0001 if m.get("normals") is not None else 0) | (0x0002 if m.get("uvs") is not None else 0) | \
+                (0x0008 if m.get("colours") is not None else 0) | (0x0010 if m.get("face_normals") else 0) | (0x2000 if m["double"] else 0x1000)
+        body = struct.pack("<I", flags)
+        if version > 3:
+            body += m["name"].encode() + b"\0"
+        body += struct.pack("<QQ", len(m["positions"]), len(m["faces"]))
+        for key in ("positions", "normals", "uvs", "colours"):
+            if m.get(key) is not None:
+                body += np.asarray(m[key], np.float64 if m["double"] else np.float32).tobytes()
+        body += np.asarray(m["faces"], np.uint32).tobytes()
+        out += struct.pack("<HH", 0x041c, version) + zlib.compress(body)
+    for o in offsets:
+        out += struct.pack("<Q" if version > 3 else "<I", o)
+    return out + struct.pack("<I", len(meshes))
+
+
+@pytest.mark.parametrize("version", [3, 4])
+def test_serialized_mesh_archives(grt, tmp_path, version):
+    """SerializedLoader.cpp: end-of-file dictionary with 32-bit (<= v3) or 64-bit offsets, per-mesh zlib
+    stream, flags for normals / uvs / colours / face normals / precision, shapeIndex selection."""
+    rng = np.random.default_rng(6)
+    quad = dict(name="quad", double=(version > 3), positions=[[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], normals=[[0, 0, 1]] * 4,
+                uvs=[[0, 0], [1, 0], [1, 1], [0, 1]], colours=[[1, 0, 0]] * 4, faces=[[0, 1, 2], [0, 2, 3]])
+    pos = np.round(rng.random((5, 3)) * 2, 3)
+    fan = dict(name="fan", double=False, positions=pos, faces=[[0, 1, 2], [0, 2, 3], [0, 3, 4]], face_normals=True)
+    (tmp_path / "meshes.serialized").write_bytes(_serialized_archive([quad, fan], version))
+    (tmp_path / "s.xml").write_text('<scene version="0.5.0">'
+                                    '<shape type="serialized"><string name="filename" value="meshes.serialized"/></shape>'
+                                    '<shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="1"/></shape></scene>')
+    grt.config_reset()
+    scene = grt.Scene(str(tmp_path / "s.xml")); scene.wait_until_loaded()
+    assert scene.mesh_data_count == 2
+    q = scene.mesh_data_array(0, "triangles", np.float32).reshape(-1, 24)
+    f = scene.mesh_data_array(1, "triangles", np.float32).reshape(-1, 24)
+    scene.close()
+    assert q.shape[0] == 2 and np.array_equal(q[1, 0:9], [0, 0, 0, 1, 1, 0, 0, 1, 0]) and np.array_equal(q[0, 9:18], [0, 0, 1] * 3)
+    assert np.array_equal(q[1, 18:24], [0, 0, 1, 1, 0, 1])             # serialized uvs are taken as they are (no v flip)
+    assert f.shape[0] == 3
+    for t, (a, b, c) in zip(f, fan["faces"]):
+        p = pos.astype(np.float32)
+        n = np.cross(p[b] - p[a], p[c] - p[a]); n /= np.linalg.norm(n)
+        assert np.array_equal(t[0:9].reshape(3, 3), p[[a, b, c]]) and np.allclose(t[9:18].reshape(3, 3), n, atol=1e-6)
+    # a shape index beyond the dictionary and a truncated archive are errors, not crashes
+    (tmp_path / "bad.xml").write_text('<scene version="0.5.0"><shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="2"/></shape></scene>')
+    with pytest.raises(RuntimeError, match="no shape #2"):
+        s = grt.Scene(str(tmp_path / "bad.xml")); s.wait_until_loaded()
+    (tmp_path / "meshes.serialized").write_bytes(_serialized_archive([quad, fan], version)[:40])
+    with pytest.raises(RuntimeError):
+        s = grt.Scene(str(tmp_path / "s.xml")); s.wait_until_loaded()
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_hair_strands_become_tapered_ribbons(grt, tmp_path, binary):
+    """MitshairLoader.cpp: ascii (blank line ends a strand) and BINARY_HAIR (+inf ends a strand) files;
+    every segment gives two triangles of a flat ribbon, `radius` wide on each side at the root and
+    closing to a point at the tip; strands with fewer than 2 vertices are dropped."""
+    import struct
+    strands = [np.array([[0, 0, 0], [0, 1, 0], [0.2, 2, 0], [0.2, 3, 0.1]], np.float32), np.array([[5, 5, 5]], np.float32),
+               np.array([[1, 0, 0], [1, 0.5, 0.5], [1, 1, 1]], np.float32)]
+    if binary:
+        data = b"BINARY_HAIR" + struct.pack("<I", sum(len(s) for s in strands))
+        for s in strands:
+            data += s.tobytes() + struct.pack("<f", np.inf)
+    else:
+        data = "".join("".join("%g %g %g\n" % tuple(v) for v in s) + "\n" for s in strands).encode()
+    (tmp_path / "h.hair").write_bytes(data)
+    (tmp_path / "s.xml").write_text('<scene version="0.5.0"><shape type="hair"><string name="filename" value="h.hair"/><float name="radius" value="0.05"/></shape></scene>')
+    grt.config_reset()
+    loads = []
+    for _ in range(2):
+        scene = grt.Scene(str(tmp_path / "s.xml")); scene.wait_until_loaded()
+        loads.append(scene.mesh_data_array(0, "triangles", np.float32).reshape(-1, 24).copy())
+        scene.close()
+    tris = loads[0]
+    # the random ribbon angle is seeded by the file name; the last triangle of a strand is degenerate
+    # (both tip corners coincide), so its generated face normal is NaN -- as in the reference
+    assert np.array_equal(loads[0], loads[1], equal_nan=True)
+    assert tris.shape[0] == 2 * 3 + 2 * 2
+    first, last = tris[0], tris[5]
+    root_a, root_b = first[0:3], first[3:6]
+    assert np.allclose((root_a + root_b) / 2, strands[0][0], atol=1e-6) and abs(np.linalg.norm(root_a - root_b) - 0.1) < 1e-5
+    assert abs(np.dot(root_a - root_b, strands[0][1] - strands[0][0])) < 1e-5        # across the strand direction
+    assert np.allclose(last[3:6], strands[0][3], atol=1e-6) and np.allclose(last[6:9], strands[0][3], atol=1e-6)   # both tip corners meet
+    mid = tris[2]                                                 # second segment starts at 2/3 of the radius
+    assert abs(np.linalg.norm(mid[0:3] - mid[3:6]) - 0.1 * 2 / 3) < 1e-5
