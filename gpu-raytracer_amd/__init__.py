@@ -249,6 +249,30 @@ def config_set(**kwargs):
             raise KeyError(lib.grt_last_error().decode())
 
 
+def load_texture(filename):
+    """Decodes an image file the way the scene loader does (TGA / PPM / PNG / BMP: sRGB -> linear RGBA8 +
+    box-filtered mips; DDS: stored DXT levels as they are). Returns a list of (height, width, 4) uint8 levels."""
+    lib = host_lib()
+    lib.grt_texture_load.restype = c_void_p
+    lib.grt_texture_load.argtypes = [c_char_p]
+    lib.grt_texture_data.restype = c_void_p
+    lib.grt_texture_data.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]
+    lib.grt_texture_free.argtypes = [c_void_p]
+    handle = lib.grt_texture_load(str(filename).encode())
+    if not handle:
+        raise RuntimeError(lib.grt_last_error().decode())
+    w, h, levels, nbytes = c_int(), c_int(), c_int(), c_size_t()
+    ptr = lib.grt_texture_data(handle, byref(w), byref(h), byref(levels), byref(nbytes))
+    data = _view(ptr, nbytes.value, np.uint8).copy()
+    lib.grt_texture_free(handle)
+    out, offset = [], 0
+    for l in range(levels.value):
+        lw, lh = max(w.value >> l, 1), max(h.value >> l, 1)
+        out.append(data[offset:offset + lw * lh * 4].reshape(lh, lw, 4))
+        offset += lw * lh * 4
+    return out
+
+
 def export_image(filename, rgb):
     """Writes a (height, width, 3) float32 image (row 0 at the bottom, as the integrator holds frames)
     through the host's PPM / EXR exporters."""

@@ -4,9 +4,11 @@
 // (Src/Math/Mipmap.cpp:72-152), quantise back to 8 bits by truncation. The reference then
 // BC1-compresses power-of-two textures for the texture unit; CDNA has none, so the RGBA8
 // levels are what the shade kernel filters.
-// Decoders: TGA (types 2/3/10/11, 8/24/32 bpp, either origin) and binary PPM (P6) -- the
-// formats the BASELINE scenes use; stb_image is not linked.
+// Decoders: TGA (types 2/3/10/11, 8/24/32 bpp, either origin) and binary PPM (P6) here, PNG / BMP /
+// DXT-compressed DDS in ImageDecoders.cpp; stb_image is not linked (JPEG, PSD, GIF, PIC and
+// Radiance-HDR textures are not read: such a texture gets the reference's pink 1x1 fallback).
 #include "Scene.h"
+#include "ImageDecoders.h"
 #include "Parser.h"
 
 #include <cstdio>
@@ -171,7 +173,25 @@ bool TextureLoader::load(const std::string & filename, Texture * texture) {
 	if (!read_file(filename, file)) return false;
 
 	int width = 0, height = 0;
-	if (!decode_tga(file, width, height, rgba8) && !decode_ppm(file, width, height, rgba8)) return false;
+
+	// DDS files carry their own mip chain of block-compressed levels, used as stored -- no gamma
+	// conversion, no re-filtering (reference: TextureLoader.cpp:19-106)
+	std::vector<std::vector<unsigned char>> dds_levels;
+	if (ImageDecoders::decode_dds(file, width, height, dds_levels)) {
+		if (!gpu_config.enable_mipmapping) dds_levels.resize(1);
+		texture->width  = width;
+		texture->height = height;
+		texture->mip_offsets.clear();
+		texture->texels.clear();
+		for (const std::vector<unsigned char> & level : dds_levels) {
+			texture->mip_offsets.push_back(texture->texels.size() / 4);
+			texture->texels.insert(texture->texels.end(), level.begin(), level.end());
+		}
+		return true;
+	}
+
+	if (!ImageDecoders::decode_png(file, width, height, rgba8) && !ImageDecoders::decode_bmp(file, width, height, rgba8) &&
+		!decode_ppm(file, width, height, rgba8) && !decode_tga(file, width, height, rgba8)) return false;
 
 	// Mip level sizes: halve each dimension down to 1 (reference mip_count, TextureLoader.cpp:108-127)
 	std::vector<std::pair<int, int>> level_size;

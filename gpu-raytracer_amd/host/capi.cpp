@@ -337,6 +337,24 @@ int  grt_pathtracer_counters(void * pt, rt_counters * out) {
 	GRT_CATCH(-1)
 }
 
+// Stand-alone texture decode (file -> linear RGBA8 mip chain), for the decoder tests
+void * grt_texture_load(const char * filename) {
+	GRT_TRY
+		Texture * texture = new Texture();
+		if (!TextureLoader::load(filename, texture)) {
+			delete texture;
+			throw std::runtime_error(std::string("cannot decode texture '") + filename + "'");
+		}
+		return texture;
+	GRT_CATCH(nullptr)
+}
+const unsigned char * grt_texture_data(void * texture, int * width, int * height, int * mip_levels, size_t * bytes) {
+	Texture * t = (Texture *)texture;
+	*width = t->width; *height = t->height; *mip_levels = t->mip_levels(); *bytes = t->texels.size();
+	return t->texels.data();
+}
+void grt_texture_free(void * texture) { delete (Texture *)texture; }
+
 // Stand-alone builders for the parity tests against oracle/_ref
 // tris24: n x 24 floats (Triangle layout). Returns a MeshData* to query with grt_built_*.
 void * grt_build_blas(const float * tris24, int n) {

@@ -578,3 +578,161 @@ def test_hair_strands_become_tapered_ribbons(grt, tmp_path, binary):
     assert np.allclose(last[3:6], strands[0][3], atol=1e-6) and np.allclose(last[6:9], strands[0][3], atol=1e-6)   # both tip corners meet
     mid = tris[2]                                                 # second segment starts at 2/3 of the radius
     assert abs(np.linalg.norm(mid[0:3] - mid[3:6]) - 0.1 * 2 / 3) < 1e-5
+
+
+def _png_bytes(pixels, colour_type, depth, interlace=False, palette=None, trns=None, filters=(0, 1, 2, 3, 4)):
+    """PNG encoder for the decoder test. pixels: (h, w, channels) integer samples in [0, 2^depth)."""
+    import struct, zlib
+    h, w, ch = pixels.shape
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xffffffff)
+
+    def pack_rows(img):
+        rows = []
+        for y in range(img.shape[0]):
+            samples = img[y].reshape(-1)
+            if depth == 16:
+                rows.append(samples.astype(">u2").tobytes())
+            elif depth == 8:
+                rows.append(samples.astype(np.uint8).tobytes())
+            else:
+                bits = "".join(format(int(s), "0%db" % depth) for s in samples)
+                bits += "0" * (-len(bits) % 8)
+                rows.append(bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)))
+        return rows
+
+    def filter_rows(rows, bpp):
+        out, prior = b"", bytes(len(rows[0])) if rows else b""
+        for y, row in enumerate(rows):
+            f = filters[y % len(filters)]
+            enc = bytearray(len(row))
+            for i in range(len(row)):
+                a = row[i - bpp] if i >= bpp else 0
+                b = prior[i]
+                c = prior[i - bpp] if i >= bpp else 0
+                if f == 0: pred = 0
+                elif f == 1: pred = a
+                elif f == 2: pred = b
+                elif f == 3: pred = (a + b) // 2
+                else:
+                    p = a + b - c; pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+                enc[i] = (row[i] - pred) & 255
+            out += bytes([f]) + bytes(enc)
+            prior = row
+        return out
+
+    bpp = max(1, ch * depth // 8)
+    if interlace:
+        raw = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = pixels[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += filter_rows(pack_rows(sub), bpp)
+    else:
+        raw = filter_rows(pack_rows(pixels), bpp)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, colour_type, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    if trns is not None:
+        out += chunk(b"tRNS", trns)
+    comp = zlib.compress(raw)
+    out += chunk(b"IDAT", comp[:len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:])    # split across two chunks
+    return out + chunk(b"IEND", b"")
+
+
+def _srgb_to_linear_u8(rgba8):
+    """What the texture loader stores for an 8-bit sRGB image: gamma_to_linear in float32, truncated to 8 bits."""
+    c = rgba8.astype(np.float32) / np.float32(255.0)
+    lin = np.where(c <= np.float32(0.04045), c / np.float32(12.92), ((c + np.float32(0.055)) / np.float32(1.055)) ** np.float32(2.4))
+    return np.clip(lin * np.float32(255.0), 0, 255).astype(np.uint8)
+
+
+def test_png_bmp_and_dds_textures_decode(grt, tmp_path):
+    """Texture formats besides TGA: PNG in every colour type / depth / interlace mode with all five
+    scanline filters, BMP 24 / 32 / palettised, DXT1 / DXT3 / DXT5 DDS. Level 0 of the loaded texture is
+    the decoded image converted from sRGB to linear (DDS: stored values unchanged)."""
+    import struct
+    rng = np.random.default_rng(10)
+    grt.config_reset()
+    h, w = 13, 11
+    cases = []
+    for interlace in (False, True):
+        rgb8 = rng.integers(0, 256, (h, w, 3)); cases.append((_png_bytes(rgb8, 2, 8, interlace), np.dstack([rgb8, np.full((h, w), 255)])))
+        rgba8 = rng.integers(0, 256, (h, w, 4)); cases.append((_png_bytes(rgba8, 6, 8, interlace), rgba8))
+        rgba16 = rng.integers(0, 65536, (h, w, 4)); cases.append((_png_bytes(rgba16, 6, 16, interlace), rgba16 >> 8))
+        ga8 = rng.integers(0, 256, (h, w, 2)); cases.append((_png_bytes(ga8, 4, 8, interlace), np.dstack([ga8[:, :, 0]] * 3 + [ga8[:, :, 1]])))
+        for depth in (1, 2, 4, 8, 16):
+            g = rng.integers(0, 1 << depth, (h, w, 1))
+            g8 = (g * 255 // ((1 << depth) - 1)) if depth < 8 else (g >> (depth - 8))
+            cases.append((_png_bytes(g, 0, depth, interlace), np.dstack([g8[:, :, 0]] * 3 + [np.full((h, w), 255)])))
+        for depth in (1, 2, 4, 8):
+            n = 1 << depth
+            palette = rng.integers(0, 256, (n, 3)); alpha = rng.integers(0, 256, max(1, n // 2))
+            idx = rng.integers(0, n, (h, w, 1))
+            a = np.where(idx[:, :, 0] < len(alpha), np.concatenate([alpha, np.full(n, 255)])[idx[:, :, 0]], 255)
+            cases.append((_png_bytes(idx, 3, depth, interlace, palette=palette, trns=bytes(alpha.astype(np.uint8))), np.dstack([palette[idx[:, :, 0]], a])))
+    key = rng.integers(0, 256, (h, w, 3)); key[2, 3] = (9, 8, 7)          # colour-key transparency
+    want = np.dstack([key, np.where((key == (9, 8, 7)).all(axis=2), 0, 255)])
+    cases.append((_png_bytes(key, 2, 8, trns=struct.pack(">HHH", 9, 8, 7)), want))
+    for i, (data, rgba) in enumerate(cases):
+        path = tmp_path / ("t%d.png" % i); path.write_bytes(data)
+        levels = grt.load_texture(path)
+        assert levels[0].shape == (h, w, 4) and np.array_equal(levels[0], _srgb_to_linear_u8(rgba)), i
+        assert [l.shape[:2] for l in levels][-1] == (1, 1) and len(levels) == 4           # 13x11 -> 6x5 -> 3x2 -> 1x1
+
+    # BMP: bottom-up 24 bit with row padding, top-down 32 bit BI_RGB (alpha ignored), 8 bit palettised
+    rgb = rng.integers(0, 256, (5, 3, 3)).astype(np.uint8)
+    row = lambda r: bytes(r[:, ::-1].reshape(-1)) + b"\0" * ((-3 * 3) % 4)
+    bmp24 = b"BM" + struct.pack("<IHHI", 54 + 12 * 5, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 3, 5, 1, 24, 0, 0, 0, 0, 0, 0) + b"".join(row(rgb[y]) for y in range(4, -1, -1))
+    bgra = np.dstack([rgb[:, :, ::-1], np.full((5, 3), 77, np.uint8)])
+    bmp32 = b"BM" + struct.pack("<IHHI", 54 + 60, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 3, -5, 1, 32, 0, 0, 0, 0, 0, 0) + bgra.tobytes()
+    pal = rng.integers(0, 256, (256, 3)).astype(np.uint8); idx = rng.integers(0, 256, (5, 3)).astype(np.uint8)
+    bmp8 = b"BM" + struct.pack("<IHHI", 54 + 1024 + 20, 0, 0, 54 + 1024) + struct.pack("<IiiHHIIiiII", 40, 3, 5, 1, 8, 0, 0, 0, 0, 256, 0) + \
+        np.hstack([pal[:, ::-1], np.zeros((256, 1), np.uint8)]).tobytes() + b"".join(bytes(idx[y]) + b"\0" for y in range(4, -1, -1))
+    for name, data, want in (("a.bmp", bmp24, rgb), ("b.bmp", bmp32, rgb), ("c.bmp", bmp8, pal[idx])):
+        (tmp_path / name).write_bytes(data)
+        got = grt.load_texture(tmp_path / name)[0]
+        assert np.array_equal(got, _srgb_to_linear_u8(np.dstack([want, np.full((5, 3), 255, np.uint8)]))), name
+
+    # DDS: 8x4 DXT1 with two mip levels; block 0 in 4-colour mode, block 1 in 3-colour + transparent mode
+    def rgb565(r, g, b): return (r << 11) | (g << 5) | b
+    def expand(c): r, g, b = c >> 11, (c >> 5) & 63, c & 31; return np.array([(r << 3) | (r >> 2), (g << 2) | (g >> 4), (b << 3) | (b >> 2)])
+    c0, c1 = rgb565(31, 10, 3), rgb565(4, 50, 20)
+    idx0 = rng.integers(0, 4, 16); idx1 = rng.integers(0, 4, 16)
+    pack = lambda ix: sum(int(v) << (2 * i) for i, v in enumerate(ix))
+    blocks = struct.pack("<HHI", c0, c1, pack(idx0)) + struct.pack("<HHI", c1, c0, pack(idx1)) + struct.pack("<HHI", c0, c1, 0)   # level 1: 4x2 -> one block
+    header = b"DDS " + struct.pack("<IIIIIII", 124, 0x1007 | 0x20000, 4, 8, 0, 0, 2) + b"\0" * 44 + struct.pack("<II4sIIIII", 32, 4, b"DXT1", 0, 0, 0, 0, 0) + struct.pack("<IIIII", 0x1000, 0, 0, 0, 0)
+    assert len(header) == 128
+    (tmp_path / "t.dds").write_bytes(header + blocks)
+    levels = grt.load_texture(tmp_path / "t.dds")
+    assert [l.shape for l in levels] == [(4, 8, 4), (2, 4, 4)]
+    e0, e1 = expand(c0), expand(c1)
+    four = [e0, e1, (2 * e0 + e1 + 1) // 3, (e0 + 2 * e1 + 1) // 3]
+    three = [e1, e0, (e0 + e1) // 2, np.zeros(3, int)]
+    for i in range(16):
+        assert np.array_equal(levels[0][i // 4, i % 4, :3], four[idx0[i]]) and levels[0][i // 4, i % 4, 3] == 255
+        assert np.array_equal(levels[0][i // 4, 4 + i % 4, :3], three[idx1[i]]) and levels[0][i // 4, 4 + i % 4, 3] == (0 if idx1[i] == 3 else 255)
+    assert (levels[1][:, :, :3] == e0).all()
+    # DXT5: interpolated alpha; DXT3: explicit 4-bit alpha
+    alpha_idx = rng.integers(0, 8, 16)
+    a_bits = sum(int(v) << (3 * i) for i, v in enumerate(alpha_idx))
+    dxt5 = bytes([200, 40]) + a_bits.to_bytes(6, "little") + struct.pack("<HHI", c1, c0, pack(idx0))
+    hdr5 = header[:84] + b"DXT5" + header[88:]; hdr5 = hdr5[:12] + struct.pack("<II", 4, 4) + hdr5[20:28] + struct.pack("<I", 1) + hdr5[32:]
+    (tmp_path / "t5.dds").write_bytes(hdr5 + dxt5)
+    l5 = grt.load_texture(tmp_path / "t5.dds")[0]
+    ramp = [200, 40] + [((7 - k) * 200 + k * 40 + 3) // 7 for k in range(1, 7)]
+    assert [int(l5[i // 4, i % 4, 3]) for i in range(16)] == [ramp[v] for v in alpha_idx]
+    four_b = [e1, e0, (2 * e1 + e0 + 1) // 3, (e1 + 2 * e0 + 1) // 3]                 # c1 < c0 numerically, but DXT5 colour blocks are always 4-colour
+    assert all(np.array_equal(l5[i // 4, i % 4, :3], four_b[idx0[i]]) for i in range(16))
+    nibbles = rng.integers(0, 16, 16)
+    dxt3 = bytes(int(nibbles[2 * i]) | (int(nibbles[2 * i + 1]) << 4) for i in range(8)) + struct.pack("<HHI", c0, c1, pack(idx0))
+    (tmp_path / "t3.dds").write_bytes(hdr5[:84] + b"DXT3" + hdr5[88:] + dxt3)
+    l3 = grt.load_texture(tmp_path / "t3.dds")[0]
+    assert [int(l3[i // 4, i % 4, 3]) for i in range(16)] == [int(v) * 17 for v in nibbles]
+
+    for name, data in (("bad1.png", cases[0][0][:60]), ("bad2.png", b"\x89PNG\r\n\x1a\n" + b"\0" * 40), ("bad.dds", header[:100]), ("bad.bmp", bmp24[:70])):
+        (tmp_path / name).write_bytes(data)
+        with pytest.raises(RuntimeError, match="cannot decode"):
+            grt.load_texture(tmp_path / name)
