@@ -198,7 +198,8 @@ bool ImageDecoders::decode_bmp(const std::vector<unsigned char> & file, int & wi
 	if (!(bits == 8 || bits == 24 || bits == 32)) return false;
 	if (!(compression == 0 || (compression == 3 && bits == 32))) return false; // BI_RGB, or BI_BITFIELDS for 32 bit
 
-	uint32_t mask[4] = { 0x00ff0000u, 0x0000ff00u, 0x000000ffu, 0u }; // r g b a of BI_RGB 32-bit: alpha byte is unused
+	// r g b a of BI_RGB; like stb_image, the fourth byte of a 32-bit pixel is alpha unless it is zero everywhere
+	uint32_t mask[4] = { 0x00ff0000u, 0x0000ff00u, 0x000000ffu, bits == 32 ? 0xff000000u : 0u };
 	if (compression == 3) {
 		size_t mask_pos = header_size >= 52 ? 14 + 40 : 14 + size_t(header_size);
 		if (mask_pos + 12 > file.size()) return false;
@@ -235,6 +236,9 @@ bool ImageDecoders::decode_bmp(const std::vector<unsigned char> & file, int & wi
 			}
 		}
 	}
+	bool any_alpha = false;
+	for (size_t i = 3; i < rgba.size(); i += 4) any_alpha |= rgba[i] != 0;
+	if (!any_alpha) for (size_t i = 3; i < rgba.size(); i += 4) rgba[i] = 255;
 	return true;
 }
 

@@ -125,6 +125,9 @@ def ref_lib():
         if hasattr(r, "ref_bvh4_node_count"):
             r.ref_bvh4_node_count.argtypes = [c_void_p]
             r.ref_bvh4_copy_nodes.argtypes = [c_void_p, c_void_p]
+        if hasattr(r, "ref_stbi_load_rgba"):
+            r.ref_stbi_load_rgba.argtypes = [ctypes.c_char_p, POINTER(c_int), POINTER(c_int), c_void_p, ctypes.c_size_t]
+            r.ref_stb_compress_bc1_block.argtypes = [c_void_p, c_void_p]
         if hasattr(r, "ref_bvh_build_binary_variant"):
             r.ref_bvh_build_binary_variant.restype = c_void_p
             r.ref_bvh_build_binary_variant.argtypes = [c_void_p, c_int, c_int, c_int, ctypes.c_float]
@@ -151,6 +154,17 @@ def ref_build(tris24):
         out["bvh4_nodes"] = np.zeros(r.ref_bvh4_node_count(h) * 128, np.uint8); r.ref_bvh4_copy_nodes(h, out["bvh4_nodes"].ctypes.data)
     out["ms_bvh2"], out["ms_bvh8"] = r.ref_bvh_ms_bvh2(h), r.ref_bvh_ms_bvh8(h)
     r.ref_bvh_free(h)
+    return out
+
+
+def ref_stbi_load(filename):
+    """The file decoded by the reference's own stb_image (RGBA8, (h, w, 4), row 0 = top), or None."""
+    r = ref_lib()
+    w, h = c_int(), c_int()
+    if not r.ref_stbi_load_rgba(str(filename).encode(), ctypes.byref(w), ctypes.byref(h), None, 0):
+        return None
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    assert r.ref_stbi_load_rgba(str(filename).encode(), ctypes.byref(w), ctypes.byref(h), out.ctypes.data, out.nbytes)
     return out
 
 

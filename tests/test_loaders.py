@@ -682,11 +682,11 @@ def test_png_bmp_and_dds_textures_decode(grt, tmp_path):
         assert levels[0].shape == (h, w, 4) and np.array_equal(levels[0], _srgb_to_linear_u8(rgba)), i
         assert [l.shape[:2] for l in levels][-1] == (1, 1) and len(levels) == 4           # 13x11 -> 6x5 -> 3x2 -> 1x1
 
-    # BMP: bottom-up 24 bit with row padding, top-down 32 bit BI_RGB (alpha ignored), 8 bit palettised
+    # BMP: bottom-up 24 bit with row padding, top-down 32 bit BI_RGB, 8 bit palettised
     rgb = rng.integers(0, 256, (5, 3, 3)).astype(np.uint8)
     row = lambda r: bytes(r[:, ::-1].reshape(-1)) + b"\0" * ((-3 * 3) % 4)
     bmp24 = b"BM" + struct.pack("<IHHI", 54 + 12 * 5, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 3, 5, 1, 24, 0, 0, 0, 0, 0, 0) + b"".join(row(rgb[y]) for y in range(4, -1, -1))
-    bgra = np.dstack([rgb[:, :, ::-1], np.full((5, 3), 77, np.uint8)])
+    bgra = np.dstack([rgb[:, :, ::-1], np.full((5, 3), 0, np.uint8)])       # an all-zero fourth byte means "no alpha", as in stb_image
     bmp32 = b"BM" + struct.pack("<IHHI", 54 + 60, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 3, -5, 1, 32, 0, 0, 0, 0, 0, 0) + bgra.tobytes()
     pal = rng.integers(0, 256, (256, 3)).astype(np.uint8); idx = rng.integers(0, 256, (5, 3)).astype(np.uint8)
     bmp8 = b"BM" + struct.pack("<IHHI", 54 + 1024 + 20, 0, 0, 54 + 1024) + struct.pack("<IiiHHIIiiII", 40, 3, 5, 1, 8, 0, 0, 0, 0, 256, 0) + \
@@ -736,3 +736,51 @@ def test_png_bmp_and_dds_textures_decode(grt, tmp_path):
         (tmp_path / name).write_bytes(data)
         with pytest.raises(RuntimeError, match="cannot decode"):
             grt.load_texture(tmp_path / name)
+
+
+def test_texture_decoders_equal_the_references_stb_image(grt, oracle, tmp_path):
+    """Live pin against the stb_image.h the reference vendors (compiled verbatim into oracle/_ref): every
+    Sponza TGA, and PNG / BMP files of all the kinds the decoder test generates, decode to the same RGBA bytes."""
+    import glob, struct
+    if oracle.ref_lib() is None or not hasattr(oracle.ref_lib(), "ref_stbi_load_rgba"):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    grt.config_reset()
+    grt.config_set(enable_mipmapping=0)
+    files = sorted(glob.glob(os.path.join(os.path.dirname(grt.scene_path("sponza")), "textures", "*.tga")))
+    assert len(files) >= 15
+    rng = np.random.default_rng(12)
+    h, w = 9, 14
+    generated = []
+    for interlace in (False, True):
+        generated.append(_png_bytes(rng.integers(0, 256, (h, w, 3)), 2, 8, interlace))
+        generated.append(_png_bytes(rng.integers(0, 256, (h, w, 4)), 6, 8, interlace))
+        generated.append(_png_bytes(rng.integers(0, 65536, (h, w, 4)), 6, 16, interlace))
+        generated.append(_png_bytes(rng.integers(0, 65536, (h, w, 3)), 2, 16, interlace, trns=struct.pack(">HHH", 300, 2, 1)))
+        generated.append(_png_bytes(rng.integers(0, 256, (h, w, 2)), 4, 8, interlace))
+        generated.append(_png_bytes(rng.integers(0, 65536, (h, w, 2)), 4, 16, interlace))
+        for depth in (1, 2, 4, 8, 16):
+            generated.append(_png_bytes(rng.integers(0, 1 << depth, (h, w, 1)), 0, depth, interlace))
+            generated.append(_png_bytes(rng.integers(0, 1 << depth, (h, w, 1)), 0, depth, interlace, trns=struct.pack(">H", 1)))
+        for depth in (1, 2, 4, 8):
+            n = 1 << depth
+            generated.append(_png_bytes(rng.integers(0, n, (h, w, 1)), 3, depth, interlace, palette=rng.integers(0, 256, (n, 3)),
+                                        trns=bytes(rng.integers(0, 256, max(1, n // 2)).astype(np.uint8))))
+    for i, data in enumerate(generated):
+        path = tmp_path / ("g%d.png" % i); path.write_bytes(data); files.append(str(path))
+    rgb = rng.integers(0, 256, (5, 3, 3)).astype(np.uint8)
+    row = lambda r: bytes(r[:, ::-1].reshape(-1)) + b"\0" * ((-3 * 3) % 4)
+    bmps = {"a.bmp": b"BM" + struct.pack("<IHHI", 54 + 60, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 3, 5, 1, 24, 0, 0, 0, 0, 0, 0) + b"".join(row(rgb[y]) for y in range(4, -1, -1))}
+    for alpha in (0, 77):
+        bgra = np.dstack([rgb[:, :, ::-1], np.full((5, 3), alpha, np.uint8)])
+        bmps["b%d.bmp" % alpha] = b"BM" + struct.pack("<IHHI", 54 + 60, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 3, -5, 1, 32, 0, 0, 0, 0, 0, 0) + bgra.tobytes()
+    pal = rng.integers(0, 256, (256, 3)).astype(np.uint8); idx = rng.integers(0, 256, (5, 3)).astype(np.uint8)
+    bmps["c.bmp"] = b"BM" + struct.pack("<IHHI", 54 + 1024 + 20, 0, 0, 54 + 1024) + struct.pack("<IiiHHIIiiII", 40, 3, 5, 1, 8, 0, 0, 0, 0, 256, 0) + \
+        np.hstack([pal[:, ::-1], np.zeros((256, 1), np.uint8)]).tobytes() + b"".join(bytes(idx[y]) + b"\0" for y in range(4, -1, -1))
+    for name, data in bmps.items():
+        (tmp_path / name).write_bytes(data); files.append(str(tmp_path / name))
+    for f in files:
+        ref = oracle.ref_stbi_load(f)
+        assert ref is not None, f
+        got = grt.load_texture(f)[0]
+        assert got.shape == ref.shape and np.array_equal(got, _srgb_to_linear_u8(ref)), f
+    grt.config_reset()
