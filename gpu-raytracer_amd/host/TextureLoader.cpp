@@ -5,8 +5,8 @@
 // BC1-compresses power-of-two textures for the texture unit; CDNA has none, so the RGBA8
 // levels are what the shade kernel filters.
 // Decoders: TGA (types 2/3/10/11, 8/24/32 bpp, either origin) and binary PPM (P6) here, PNG / BMP /
-// DXT-compressed DDS in ImageDecoders.cpp; stb_image is not linked (JPEG, PSD, GIF, PIC and
-// Radiance-HDR textures are not read: such a texture gets the reference's pink 1x1 fallback).
+// DXT-compressed DDS in ImageDecoders.cpp, JPEG in JPEGDecoder.cpp; stb_image is not linked (PSD, GIF,
+// PIC and Radiance-HDR textures are not read: such a texture gets the reference's pink 1x1 fallback).
 #include "Scene.h"
 #include "ImageDecoders.h"
 #include "Parser.h"
@@ -190,7 +190,8 @@ bool TextureLoader::load(const std::string & filename, Texture * texture) {
 		return true;
 	}
 
-	if (!ImageDecoders::decode_png(file, width, height, rgba8) && !ImageDecoders::decode_bmp(file, width, height, rgba8) &&
+	if (!ImageDecoders::decode_png(file, width, height, rgba8) && !ImageDecoders::decode_jpeg(file, width, height, rgba8) &&
+		!ImageDecoders::decode_bmp(file, width, height, rgba8) &&
 		!decode_ppm(file, width, height, rgba8) && !decode_tga(file, width, height, rgba8)) return false;
 
 	// Mip level sizes: halve each dimension down to 1 (reference mip_count, TextureLoader.cpp:108-127)
