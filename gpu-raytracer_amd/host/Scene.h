@@ -91,7 +91,11 @@ namespace PLYLoader     { std::vector<Triangle> load(const std::string & filenam
 namespace SerializedLoader { std::vector<Triangle> load(const std::string & filename, int shape_index); }
 namespace MitshairLoader   { std::vector<Triangle> load(const std::string & filename, float radius); }
 namespace MitsubaLoader { void load(const std::string & filename, Scene & scene); }
-namespace TextureLoader { bool load(const std::string & filename, Texture * texture); }
+namespace TextureLoader {
+	bool load(const std::string & filename, Texture * texture);
+	// One mip step with the box / lanczos / kaiser kernel of the reference (Src/Math/Mipmap.cpp)
+	void downsample(MipmapFilterType filter, int w_src, int h_src, int w_dst, int h_dst, const Vector4 * src, Vector4 * dst, std::vector<Vector4> & temp);
+}
 
 namespace Geometry {
 	std::vector<Triangle> rectangle(const Matrix4 & transform);

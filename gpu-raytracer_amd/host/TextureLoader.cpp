@@ -112,14 +112,44 @@ bool decode_ppm(const std::vector<unsigned char> & file, int & width, int & heig
 	return true;
 }
 
-// Separable box filter with the window construction of the reference mip generator: the
-// kernel is the box function integrated over each source texel (32 sub-samples).
-void downsample_box(int w_src, int h_src, int w_dst, int h_dst, const Vector4 * src, Vector4 * dst, std::vector<Vector4> & temp) {
-	auto make_kernel = [](int n_src, int n_dst, std::vector<float> & kernel, float & filter_width, float & inv_scale) {
+// The three mip filters of the reference (Src/Math/Mipmap.cpp:14-52): each is a window function and its
+// half-width in destination texels.
+float sinc(float x) { // Math.h:136-142
+	if (fabsf(x) < 0.0001f) return 1.0f + x * x * (-1.0f / 6.0f + x * x * 1.0f / 120.0f);
+	return sinf(x) / x;
+}
+float bessel_0(float x) { // Math.h:145-162: power series until the term no longer changes the sum
+	float xh = 0.5f * x, sum = 1.0f, pow = 1.0f, ds = 1.0f, k = 0.0f;
+	while (ds > sum * 1e-6f) {
+		k += 1.0f;
+		pow = pow * (xh / k);
+		ds  = pow * pow;
+		sum = sum + ds;
+	}
+	return sum;
+}
+float filter_width(MipmapFilterType type) { return type == MipmapFilterType::BOX ? 0.5f : (type == MipmapFilterType::LANCZOS ? 3.0f : 7.0f); }
+float filter_eval(MipmapFilterType type, float x) {
+	switch (type) {
+		case MipmapFilterType::BOX:     return fabsf(x) <= 0.5f ? 1.0f : 0.0f;
+		case MipmapFilterType::LANCZOS: return fabsf(x) < 3.0f ? sinc(PI * x) * sinc(PI * x / 3.0f) : 0.0f;
+		default: { // Kaiser window, alpha 4, width 7
+			float t = x / 7.0f, t2 = t * t;
+			return t2 < 1.0f ? sinc(PI * x * 1.0f) * bessel_0(4.0f * sqrtf(1.0f - t2)) / bessel_0(4.0f) : 0.0f;
+		}
+	}
+}
+} // namespace
+
+// Separable downsampling with the kernel construction of the reference mip generator (Mipmap.cpp:54-152):
+// the filter integrated over each source texel (32 sub-samples), normalised, applied along x into a
+// transposed temporary and then along y; source indices clamp at the borders.
+void TextureLoader::downsample(MipmapFilterType filter, int w_src, int h_src, int w_dst, int h_dst, const Vector4 * src, Vector4 * dst, std::vector<Vector4> & temp) {
+	auto make_kernel = [filter](int n_src, int n_dst, std::vector<float> & kernel, float & half_width, float & inv_scale) {
 		float scale = float(n_dst) / float(n_src);
-		inv_scale = 1.0f / scale;
-		filter_width = 0.5f * inv_scale;
-		int window = int(ceilf(filter_width * 2.0f)) + 1;
+		inv_scale  = 1.0f / scale;
+		half_width = filter_width(filter) * inv_scale;
+		int window = int(ceilf(half_width * 2.0f)) + 1;
 		kernel.assign(window, 0.0f);
 		float sum = 0.0f;
 		for (int i = 0; i < window; i++) {
@@ -127,7 +157,7 @@ void downsample_box(int w_src, int h_src, int w_dst, int h_dst, const Vector4 * 
 			float acc = 0.0f, sample = 0.5f;
 			for (int s = 0; s < 32; s++, sample += 1.0f) {
 				float p = (x + sample * (1.0f / 32.0f)) * scale;
-				acc += fabsf(p) <= 0.5f ? 1.0f : 0.0f;
+				acc += filter_eval(filter, p);
 			}
 			kernel[i] = acc * (1.0f / 32.0f);
 			sum += kernel[i];
@@ -164,6 +194,7 @@ void downsample_box(int w_src, int h_src, int w_dst, int h_dst, const Vector4 * 
 	}
 }
 
+namespace {
 unsigned char quantise(float v) { return (unsigned char)(Math::clamp(v * 255.0f, 0.0f, 255.0f)); }
 
 } // namespace
@@ -223,7 +254,11 @@ bool TextureLoader::load(const std::string & filename, Texture * texture) {
 		texture->mip_offsets.push_back(offset);
 		if (l + 1 < level_size.size()) {
 			size_t next = offset + size_t(level_size[l].first) * level_size[l].second;
-			downsample_box(level_size[l].first, level_size[l].second, level_size[l + 1].first, level_size[l + 1].second, &linear[offset], &linear[next], temp);
+			if (cpu_config.mipmap_filter == MipmapFilterType::BOX) { // the box filter can work from the previous level ...
+				downsample(MipmapFilterType::BOX, level_size[l].first, level_size[l].second, level_size[l + 1].first, level_size[l + 1].second, &linear[offset], &linear[next], temp);
+			} else {                                                  // ... the wider ones resample the original (TextureLoader.cpp:170-178)
+				downsample(cpu_config.mipmap_filter, width, height, level_size[l + 1].first, level_size[l + 1].second, &linear[0], &linear[next], temp);
+			}
 			offset = next;
 		}
 	}

@@ -46,6 +46,10 @@ int grt_config_set(const char * key, double value) {
 			default: g_host_error = "bvh_type must be 1 (sbvh), 2 (sah), 4 (bvh4) or 8 (bvh8)"; return -1;
 		}
 	}
+	else if (k == "mipmap_filter") { // 0 box, 1 lanczos, 2 kaiser (--mip-filter)
+		if (int(value) < 0 || int(value) > 2) { g_host_error = "mipmap_filter must be 0 (box), 1 (lanczos) or 2 (kaiser)"; return -1; }
+		cpu_config.mipmap_filter = MipmapFilterType(int(value));
+	}
 	else if (k == "enable_bvh_cache")                    cpu_config.enable_bvh_cache = value != 0;
 	else if (k == "bvh_force_rebuild")                   cpu_config.bvh_force_rebuild = value != 0;
 	else if (k == "sah_cost_node")                       cpu_config.sah_cost_node = float(value);
@@ -333,6 +337,15 @@ void grt_pathtracer_device_config(void * pt, rt_gpu_config * out) { *out = as_in
 int  grt_pathtracer_counters(void * pt, rt_counters * out) {
 	GRT_TRY
 		*out = as_integrator(pt)->counters();
+		return 0;
+	GRT_CATCH(-1)
+}
+
+// One mip-filter step on float4 texels (filter: 0 box, 1 lanczos, 2 kaiser), for the parity test against oracle/_ref
+int grt_mipmap_downsample(int filter, int w_src, int h_src, int w_dst, int h_dst, const float * src, float * dst) {
+	GRT_TRY
+		std::vector<Vector4> temp;
+		TextureLoader::downsample(MipmapFilterType(filter), w_src, h_src, w_dst, h_dst, (const Vector4 *)src, (Vector4 *)dst, temp);
 		return 0;
 	GRT_CATCH(-1)
 }

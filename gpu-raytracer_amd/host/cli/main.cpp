@@ -95,8 +95,11 @@ std::vector<Option> make_options(CommandLine & cl) {
 	o.push_back({ nullptr, "sah-leaf",   "Sets the SAH cost of a leaf BVH node",      1, [](const char * v) { cpu_config.sah_cost_leaf = parse_float(v, "--sah-leaf"); } });
 	o.push_back({ nullptr, "sbvh-alpha", "Sets the SBVH alpha constant. An alpha of 1 results in a regular BVH, alpha of 0 results in full SBVH", 1, [](const char * v) { cpu_config.sbvh_alpha = parse_float(v, "--sbvh-alpha"); } });
 	o.push_back({ nullptr, "mipmap",     "Enables or disables texture mipmapping",    1, [](const char * v) { gpu_config.enable_mipmapping = parse_bool(v); } });
-	o.push_back({ nullptr, "mip-filter", "Sets the downsampling filter for creating mipmaps. Supported options: box", 1, [](const char * v) {
-		if (strcmp(v, "box") != 0) die(std::string("'") + v + "' is not an available Mipmap Filter (only box)");
+	o.push_back({ nullptr, "mip-filter", "Sets the downsampling filter for creating mipmaps. Supported options: box, lanczos, kaiser", 1, [](const char * v) {
+		if      (strcmp(v, "box")     == 0) cpu_config.mipmap_filter = MipmapFilterType::BOX;
+		else if (strcmp(v, "lanczos") == 0) cpu_config.mipmap_filter = MipmapFilterType::LANCZOS;
+		else if (strcmp(v, "kaiser")  == 0) cpu_config.mipmap_filter = MipmapFilterType::KAISER;
+		else die(std::string("'") + v + "' is not a recognized Mipmap Filter!");
 	} });
 	o.push_back({ "c", "compress",  "Texture block compression (not available: must stay false)", 1, [](const char * v) {
 		if (parse_bool(v)) die("texture block compression is not part of this build: textures stay RGBA8");

@@ -125,6 +125,8 @@ def ref_lib():
         if hasattr(r, "ref_bvh4_node_count"):
             r.ref_bvh4_node_count.argtypes = [c_void_p]
             r.ref_bvh4_copy_nodes.argtypes = [c_void_p, c_void_p]
+        if hasattr(r, "ref_mipmap_downsample"):
+            r.ref_mipmap_downsample.argtypes = [c_int] * 5 + [c_void_p, c_void_p]
         if hasattr(r, "ref_stbi_load_rgba"):
             r.ref_stbi_load_rgba.argtypes = [ctypes.c_char_p, POINTER(c_int), POINTER(c_int), c_void_p, ctypes.c_size_t]
             r.ref_stb_compress_bc1_block.argtypes = [c_void_p, c_void_p]
@@ -155,6 +157,14 @@ def ref_build(tris24):
     out["ms_bvh2"], out["ms_bvh8"] = r.ref_bvh_ms_bvh2(h), r.ref_bvh_ms_bvh8(h)
     r.ref_bvh_free(h)
     return out
+
+
+def ref_mipmap_downsample(filter_type, src, w_dst, h_dst):
+    """One mip step by the reference's own Mipmap::downsample; src (h, w, 4) float32 -> (h_dst, w_dst, 4)."""
+    src = np.ascontiguousarray(src, np.float32)
+    dst = np.zeros((h_dst, w_dst, 4), np.float32)
+    ref_lib().ref_mipmap_downsample(filter_type, src.shape[1], src.shape[0], w_dst, h_dst, src.ctypes.data, dst.ctypes.data)
+    return dst
 
 
 def ref_stbi_load(filename):

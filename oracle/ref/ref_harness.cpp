@@ -12,6 +12,7 @@
 //                    BVH4Converter::convert       (Src/BVH/Converters/BVH4Converter.cpp:3-78)
 //                    SBVHBuilder::build           (Src/BVH/Builders/SBVHBuilder.cpp:13-68, via BVH::create_from_triangles)
 //                    BVHCollapser::collapse       (Src/BVH/BVHCollapser.cpp:97-114)
+//                    Mipmap::downsample           (Src/Math/Mipmap.cpp:154-160)
 #include "Core/Format.h"
 #include "BVH/BVH.h"
 #include "BVH/Builders/SAHBuilder.h"
@@ -145,3 +146,14 @@ double ref_bvh_ms_bvh8(void * h) { return ((RefBVH *)h)->ms_bvh8; }
 void ref_bvh_free(void * h) { delete (RefBVH *)h; }
 
 } // extern "C"
+
+// Mip chain generator, verbatim (Src/Math/Mipmap.cpp:154-160). filter: 0 box, 1 lanczos, 2 kaiser.
+// src: width_src * height_src float4, dst: width_dst * height_dst float4.
+#include "Math/Mipmap.h"
+extern "C" void ref_mipmap_downsample(int filter, int width_src, int height_src, int width_dst, int height_dst, const float * src, float * dst) {
+	MipmapFilterType saved = cpu_config.mipmap_filter;
+	cpu_config.mipmap_filter = filter == 0 ? MipmapFilterType::BOX : (filter == 1 ? MipmapFilterType::LANCZOS : MipmapFilterType::KAISER);
+	std::vector<Vector4> temp(size_t(width_dst) * height_src);
+	Mipmap::downsample(width_src, height_src, width_dst, height_dst, reinterpret_cast<const Vector4 *>(src), reinterpret_cast<Vector4 *>(dst), temp.data());
+	cpu_config.mipmap_filter = saved;
+}

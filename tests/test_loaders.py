@@ -831,3 +831,49 @@ def test_jpeg_decoder_live_against_stb_image(grt, oracle):
         want = _srgb_to_linear_u8(ref)
         assert np.array_equal(got, want), (f, int((got != want).sum()))
     grt.config_reset()
+
+
+def _product_mip_step(grt, filter_type, src, w_dst, h_dst):
+    import ctypes
+    lib = grt.host_lib()
+    lib.grt_mipmap_downsample.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
+    src = np.ascontiguousarray(src, np.float32)
+    dst = np.zeros((h_dst, w_dst, 4), np.float32)
+    assert lib.grt_mipmap_downsample(filter_type, src.shape[1], src.shape[0], w_dst, h_dst, src.ctypes.data, dst.ctypes.data) == 0
+    return dst
+
+
+def test_mip_filters_match_the_reference_generator(grt, oracle):
+    """Mipmap.cpp: box (the default), lanczos and kaiser kernels. Bit-identical float results against the
+    reference's own Mipmap::downsample (oracle/_ref) for halving steps of even, odd and 1-wide levels and for
+    the direct original -> level steps the wide filters use; without _ref, the kernels' basic properties."""
+    rng = np.random.default_rng(14)
+    steps = [((16, 16), (8, 8)), ((13, 11), (6, 5)), ((6, 5), (3, 2)), ((3, 2), (1, 1)), ((64, 1), (32, 1)), ((1, 9), (1, 4)), ((40, 24), (5, 3)), ((33, 17), (1, 1))]
+    have_ref = oracle.ref_lib() is not None and hasattr(oracle.ref_lib(), "ref_mipmap_downsample")
+    for filter_type in (0, 1, 2):
+        for (w, h), (wd, hd) in steps:
+            src = rng.random((h, w, 4)).astype(np.float32)
+            got = _product_mip_step(grt, filter_type, src, wd, hd)
+            if have_ref:
+                want = oracle.ref_mipmap_downsample(filter_type, src, wd, hd)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (filter_type, w, h)
+            const = _product_mip_step(grt, filter_type, np.full((h, w, 4), 0.25, np.float32), wd, hd)
+            assert np.allclose(const, 0.25, atol=1e-6)            # normalised kernels reproduce a constant
+    box = _product_mip_step(grt, 0, np.arange(16 * 4, dtype=np.float32).reshape(1, 16, 4), 8, 1)
+    assert np.allclose(box[0, :, 0], np.arange(16 * 4, dtype=np.float32).reshape(16, 4)[:, 0].reshape(8, 2).mean(1))   # 2:1 box = pair average
+
+
+def test_mip_filter_choice_reaches_the_texture_loader(grt, tmp_path):
+    rng = np.random.default_rng(15)
+    img = rng.integers(0, 256, (16, 16, 3))
+    (tmp_path / "t.png").write_bytes(_png_bytes(img, 2, 8))
+    chains = {}
+    for name, value in (("box", 0), ("lanczos", 1), ("kaiser", 2)):
+        grt.config_reset(); grt.config_set(mipmap_filter=value)
+        chains[name] = grt.load_texture(tmp_path / "t.png")
+        assert [l.shape[:2] for l in chains[name]] == [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    grt.config_reset()
+    assert np.array_equal(chains["box"][0], chains["kaiser"][0])
+    assert not np.array_equal(chains["box"][1], chains["lanczos"][1]) and not np.array_equal(chains["lanczos"][1], chains["kaiser"][1])
+    with pytest.raises(KeyError):
+        grt.config_set(mipmap_filter=3)
