@@ -350,6 +350,37 @@ int grt_mipmap_downsample(int filter, int w_src, int h_src, int w_dst, int h_dst
 	GRT_CATCH(-1)
 }
 
+// Tessellated primitive shapes (shape: 0 rectangle, 1 cube, 2 disk, 3 cylinder, 4 sphere) and the sky loader,
+// for the parity tests against the reference's Geometry.cpp / stbi_loadf in oracle/_ref
+int grt_geometry_shape(int shape, const float * transform16, const float * p0, const float * p1, float radius, int detail, float * dst, int dst_triangles) {
+	GRT_TRY
+		Matrix4 transform;
+		memcpy(transform.cells, transform16, 16 * sizeof(float));
+		std::vector<Triangle> triangles;
+		switch (shape) {
+			case 0: triangles = Geometry::rectangle(transform); break;
+			case 1: triangles = Geometry::cube(transform); break;
+			case 2: triangles = detail > 0 ? Geometry::disk(transform, detail) : Geometry::disk(transform); break;
+			case 3: triangles = detail > 0 ? Geometry::cylinder(transform, Vector3(p0[0], p0[1], p0[2]), Vector3(p1[0], p1[1], p1[2]), radius, detail)
+			                               : Geometry::cylinder(transform, Vector3(p0[0], p0[1], p0[2]), Vector3(p1[0], p1[1], p1[2]), radius); break;
+			default: triangles = detail >= 0 ? Geometry::sphere(transform, detail) : Geometry::sphere(transform); break;
+		}
+		int count = int(triangles.size());
+		if (dst && dst_triangles >= count) memcpy((void *)dst, triangles.data(), size_t(count) * sizeof(Triangle));
+		return count;
+	GRT_CATCH(-1)
+}
+int grt_sky_load(const char * filename, int * width, int * height, float * dst_rgba, size_t dst_floats) {
+	GRT_TRY
+		Sky sky;
+		sky.load(filename);
+		*width = sky.width; *height = sky.height;
+		size_t count = sky.data.size() * 4;
+		if (dst_rgba && dst_floats >= count) memcpy((void *)dst_rgba, sky.data.data(), count * sizeof(float));
+		return int(count);
+	GRT_CATCH(-1)
+}
+
 // Stand-alone texture decode (file -> linear RGBA8 mip chain), for the decoder tests
 void * grt_texture_load(const char * filename) {
 	GRT_TRY

@@ -167,6 +167,30 @@ def ref_mipmap_downsample(filter_type, src, w_dst, h_dst):
     return dst
 
 
+def ref_geometry_shape(shape, transform16, p0=(0, 0, 0), p1=(0, 0, 1), radius=1.0, detail=-1):
+    """Triangles (n, 24) of a primitive shape by the reference's own Geometry.cpp."""
+    r = ref_lib()
+    r.ref_geometry_shape.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int]
+    t = np.ascontiguousarray(transform16, np.float32); a = np.asarray(p0, np.float32); b = np.asarray(p1, np.float32)
+    n = r.ref_geometry_shape(shape, t.ctypes.data, a.ctypes.data, b.ctypes.data, radius, detail, None, 0)
+    out = np.zeros((n, 24), np.float32)
+    r.ref_geometry_shape(shape, t.ctypes.data, a.ctypes.data, b.ctypes.data, radius, detail, out.ctypes.data, n)
+    return out
+
+
+def ref_stbi_loadf(filename):
+    """(h, w, 3) float32 as the reference's Sky::load gets it from stbi_loadf, or None."""
+    r = ref_lib()
+    r.ref_stbi_loadf_rgb.argtypes = [ctypes.c_char_p, POINTER(c_int), POINTER(c_int), c_void_p, ctypes.c_size_t]
+    w, h = c_int(), c_int()
+    n = r.ref_stbi_loadf_rgb(str(filename).encode(), ctypes.byref(w), ctypes.byref(h), None, 0)
+    if n == 0:
+        return None
+    out = np.zeros((h.value, w.value, 3), np.float32)
+    r.ref_stbi_loadf_rgb(str(filename).encode(), ctypes.byref(w), ctypes.byref(h), out.ctypes.data, out.size)
+    return out
+
+
 def ref_stbi_load(filename):
     """The file decoded by the reference's own stb_image (RGBA8, (h, w, 4), row 0 = top), or None."""
     r = ref_lib()

@@ -157,3 +157,24 @@ extern "C" void ref_mipmap_downsample(int filter, int width_src, int height_src,
 	Mipmap::downsample(width_src, height_src, width_dst, height_dst, reinterpret_cast<const Vector4 *>(src), reinterpret_cast<Vector4 *>(dst), temp.data());
 	cpu_config.mipmap_filter = saved;
 }
+
+// Primitive shapes of the Mitsuba loader, verbatim (Src/Util/Geometry.cpp). shape: 0 rectangle, 1 cube, 2 disk,
+// 3 cylinder (p0, p1, radius), 4 sphere (subdivisions in `detail`). transform: 16 floats, row-major Matrix4 cells.
+// Returns the triangle count; dst (may be NULL) receives count * 24 floats.
+#include "Util/Geometry.h"
+extern "C" int ref_geometry_shape(int shape, const float * transform16, const float * p0, const float * p1, float radius, int detail, float * dst, int dst_triangles) {
+	Matrix4 transform;
+	memcpy(transform.cells, transform16, 16 * sizeof(float));
+	Array<Triangle> triangles;
+	switch (shape) {
+		case 0: triangles = Geometry::rectangle(transform); break;
+		case 1: triangles = Geometry::cube(transform); break;
+		case 2: triangles = detail > 0 ? Geometry::disk(transform, detail) : Geometry::disk(transform); break;
+		case 3: triangles = detail > 0 ? Geometry::cylinder(transform, Vector3(p0[0], p0[1], p0[2]), Vector3(p1[0], p1[1], p1[2]), radius, detail)
+		                               : Geometry::cylinder(transform, Vector3(p0[0], p0[1], p0[2]), Vector3(p1[0], p1[1], p1[2]), radius); break;
+		default: triangles = detail >= 0 ? Geometry::sphere(transform, detail) : Geometry::sphere(transform); break;
+	}
+	int count = int(triangles.size());
+	if (dst && dst_triangles >= count) memcpy(dst, triangles.data(), size_t(count) * sizeof(Triangle));
+	return count;
+}

@@ -31,3 +31,15 @@ void ref_stb_compress_bc1_block(const unsigned char * rgba_block, unsigned char 
 }
 
 } // extern "C"
+
+// Radiance .hdr as Sky::load reads it (Src/Renderer/Sky.cpp:12-35): stbi_loadf(..., STBI_rgb). Returns the
+// number of floats written (width * height * 3), 0 on failure; dst may be NULL to query the size.
+extern "C" int ref_stbi_loadf_rgb(const char * filename, int * width, int * height, float * dst, size_t dst_floats) {
+	int channels = 0;
+	float * data = stbi_loadf(filename, width, height, &channels, STBI_rgb);
+	if (!data) return 0;
+	size_t count = size_t(*width) * size_t(*height) * 3;
+	if (dst && dst_floats >= count) memcpy(dst, data, count * sizeof(float));
+	stbi_image_free(data);
+	return int(count);
+}

@@ -877,3 +877,82 @@ def test_mip_filter_choice_reaches_the_texture_loader(grt, tmp_path):
     assert not np.array_equal(chains["box"][1], chains["lanczos"][1]) and not np.array_equal(chains["lanczos"][1], chains["kaiser"][1])
     with pytest.raises(KeyError):
         grt.config_set(mipmap_filter=3)
+
+
+def _product_shape(grt, shape, transform16, p0=(0, 0, 0), p1=(0, 0, 1), radius=1.0, detail=-1):
+    import ctypes
+    lib = grt.host_lib()
+    lib.grt_geometry_shape.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    t = np.ascontiguousarray(transform16, np.float32); a = np.asarray(p0, np.float32); b = np.asarray(p1, np.float32)
+    n = lib.grt_geometry_shape(shape, t.ctypes.data, a.ctypes.data, b.ctypes.data, radius, detail, None, 0)
+    assert n > 0, lib.grt_last_error()
+    out = np.zeros((n, 24), np.float32)
+    lib.grt_geometry_shape(shape, t.ctypes.data, a.ctypes.data, b.ctypes.data, radius, detail, out.ctypes.data, n)
+    return out
+
+
+def test_primitive_shapes_equal_the_references_geometry(grt, oracle):
+    """Mitsuba rectangle / cube / disk / cylinder / sphere shapes are tessellated on load with the transform
+    baked in (Util/Geometry.cpp). Triangle order, vertices, normals and uvs are bit-identical to the reference's
+    own Geometry.cpp (oracle/_ref) -- they feed the BVH and the light CDFs."""
+    if oracle.ref_lib() is None or not hasattr(oracle.ref_lib(), "ref_geometry_shape"):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    rng = np.random.default_rng(17)
+    transforms = [np.eye(4, dtype=np.float32)]
+    for _ in range(3):
+        m = np.eye(4, dtype=np.float32)
+        q, _r = np.linalg.qr(rng.normal(size=(3, 3)))
+        m[:3, :3] = (q * rng.uniform(0.3, 2.5, 3)).astype(np.float32)        # rotation x non-uniform scale (incl. mirroring)
+        m[:3, 3] = rng.uniform(-3, 3, 3)
+        transforms.append(m)
+    counts = {}
+    for m in transforms:
+        for shape, kwargs in ((0, {}), (1, {}), (2, {}), (2, dict(detail=7)), (3, {}), (3, dict(p0=(0.5, -1, 0.25), p1=(-0.5, 2, 1), radius=0.3, detail=9)),
+                              (4, {}), (4, dict(detail=0)), (4, dict(detail=1))):
+            want = oracle.ref_geometry_shape(shape, m.ravel(), **kwargs)
+            got = _product_shape(grt, shape, m.ravel(), **kwargs)
+            assert got.shape == want.shape, (shape, kwargs)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (shape, kwargs)
+            counts[(shape, tuple(sorted(kwargs)))] = got.shape[0]
+    assert counts[(0, ())] == 2 and counts[(1, ())] == 12 and counts[(2, ())] == 32 and counts[(4, ())] == 20 * 4 ** 3
+
+
+def test_hdr_sky_equals_stbi_loadf(grt, oracle, tmp_path):
+    """Sky::load (Sky.cpp:12-35) takes the floats of stbi_loadf: RGBE with run-length and flat scanlines."""
+    import ctypes
+    rng = np.random.default_rng(19)
+    w, h = 40, 6
+    rgbe = rng.integers(0, 256, (h, w, 4)).astype(np.uint8)
+    rgbe[:, :, 3] = rng.integers(110, 150, (h, w)); rgbe[2, 5, 3] = 0; rgbe[1, :12] = rgbe[1, 0]       # a zero exponent, a run
+    def rle_row(row):
+        out = bytes([2, 2, w >> 8, w & 255])
+        for c in range(4):
+            vals, x = row[:, c], 0
+            while x < w:
+                run = 1
+                while x + run < w and run < 127 and vals[x + run] == vals[x]: run += 1
+                if run >= 3:
+                    out += bytes([128 + run, int(vals[x])]); x += run
+                else:
+                    lit = 1
+                    while x + lit < w and lit < 128 and not (x + lit + 2 < w and vals[x + lit] == vals[x + lit + 1] == vals[x + lit + 2]): lit += 1
+                    out += bytes([lit]) + bytes(vals[x:x + lit].tolist()); x += lit
+        return out
+    header = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w)
+    (tmp_path / "rle.hdr").write_bytes(header + b"".join(rle_row(rgbe[y]) for y in range(h)))
+    w2 = 5                                                        # narrower than 8: always stored flat
+    header2 = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w2)
+    (tmp_path / "flat.hdr").write_bytes(header2 + rgbe[:, :w2].tobytes())
+    lib = grt.host_lib()
+    lib.grt_sky_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_void_p, ctypes.c_size_t]
+    for name, (ww, hh) in (("rle.hdr", (w, h)), ("flat.hdr", (w2, h))):
+        sw, sh = ctypes.c_int(), ctypes.c_int()
+        out = np.zeros((hh, ww, 4), np.float32)
+        assert lib.grt_sky_load(str(tmp_path / name).encode(), ctypes.byref(sw), ctypes.byref(sh), out.ctypes.data, out.size) == out.size
+        assert (sw.value, sh.value) == (ww, hh) and (out[:, :, 3] == 0).all()
+        e = rgbe[:, :ww]
+        scale = np.where(e[:, :, 3] > 0, np.ldexp(np.float32(1.0), e[:, :, 3].astype(np.int32) - 136), 0).astype(np.float32)
+        assert np.array_equal(out[:, :, :3], e[:, :, :3].astype(np.float32) * scale[:, :, None])
+        if oracle.ref_lib() is not None and hasattr(oracle.ref_lib(), "ref_stbi_loadf_rgb"):
+            ref = oracle.ref_stbi_loadf(tmp_path / name)
+            assert ref is not None and np.array_equal(ref.view(np.uint32), out[:, :, :3].view(np.uint32)), name
