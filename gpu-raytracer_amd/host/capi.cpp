@@ -370,6 +370,50 @@ int grt_geometry_shape(int shape, const float * transform16, const float * p0, c
 		return count;
 	GRT_CATCH(-1)
 }
+// Camera state after resize(width, height) and `updates` calls of update(0), laid out as oracle/ref's ref_camera_state
+int grt_camera_state(float fov, int width, int height, const float * position3, const float * rotation4, int updates, float * out58) {
+	GRT_TRY
+		Camera camera(fov);
+		camera.resize(width, height);
+		camera.position = Vector3(position3[0], position3[1], position3[2]);
+		camera.rotation = Quaternion(rotation4[0], rotation4[1], rotation4[2], rotation4[3]);
+		memset(camera.view_projection.cells, 0, sizeof(camera.view_projection.cells));
+		for (int i = 0; i < updates; i++) camera.update(0.0f);
+		float * o = out58;
+		for (const Vector3 & v : { camera.bottom_left_corner_rotated, camera.x_axis_rotated, camera.y_axis_rotated }) { *o++ = v.x; *o++ = v.y; *o++ = v.z; }
+		*o++ = camera.pixel_spread_angle;
+		for (const Matrix4 * m : { &camera.projection, &camera.view_projection, &camera.view_projection_prev }) { memcpy(o, m->cells, 64); o += 16; }
+		return 0;
+	GRT_CATCH(-1)
+}
+// Mesh::update and the Medium parameterisation, laid out as oracle/ref's ref_mesh_transform / ref_medium_round_trip
+int grt_mesh_transform(const float * position3, const float * rotation4, float scale, const float * aabb6, float * out38) {
+	GRT_TRY
+		Mesh mesh("", Handle<MeshData> { 0 }, Handle<Material> { 0 });
+		mesh.position = Vector3(position3[0], position3[1], position3[2]);
+		mesh.rotation = Quaternion(rotation4[0], rotation4[1], rotation4[2], rotation4[3]);
+		mesh.scale    = scale;
+		mesh.aabb_untransformed.min = Vector3(aabb6[0], aabb6[1], aabb6[2]);
+		mesh.aabb_untransformed.max = Vector3(aabb6[3], aabb6[4], aabb6[5]);
+		mesh.update();
+		memcpy(out38, mesh.transform.cells, 64); memcpy(out38 + 16, mesh.transform_inv.cells, 64);
+		out38[32] = mesh.aabb.min.x; out38[33] = mesh.aabb.min.y; out38[34] = mesh.aabb.min.z;
+		out38[35] = mesh.aabb.max.x; out38[36] = mesh.aabb.max.y; out38[37] = mesh.aabb.max.z;
+		return 0;
+	GRT_CATCH(-1)
+}
+int grt_medium_round_trip(const float * sigma_a3, const float * sigma_s3, float g, float * out12) {
+	GRT_TRY
+		Medium medium;
+		medium.g = g;
+		medium.from_sigmas(Vector3(sigma_a3[0], sigma_a3[1], sigma_a3[2]), Vector3(sigma_s3[0], sigma_s3[1], sigma_s3[2]));
+		Vector3 a, s;
+		medium.to_sigmas(a, s);
+		const Vector3 * v[4] = { &medium.C, &medium.mfp, &a, &s };
+		for (int i = 0; i < 4; i++) { out12[3 * i] = v[i]->x; out12[3 * i + 1] = v[i]->y; out12[3 * i + 2] = v[i]->z; }
+		return 0;
+	GRT_CATCH(-1)
+}
 int grt_sky_load(const char * filename, int * width, int * height, float * dst_rgba, size_t dst_floats) {
 	GRT_TRY
 		Sky sky;

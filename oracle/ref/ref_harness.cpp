@@ -178,3 +178,52 @@ extern "C" int ref_geometry_shape(int shape, const float * transform16, const fl
 	if (dst && dst_triangles >= count) memcpy(dst, triangles.data(), size_t(count) * sizeof(Triangle));
 	return count;
 }
+
+// Camera, verbatim (Src/Renderer/Camera.cpp). No keys are ever down here; the stubs below stand in for the
+// SDL-backed Input namespace. out: bottom_left_corner_rotated(3) x_axis_rotated(3) y_axis_rotated(3)
+// pixel_spread_angle(1) projection(16) view_projection(16) view_projection_prev(16) = 58 floats, after
+// resize(width, height) and `updates` calls of update(0).
+#include "Renderer/Camera.h"
+#include "Input.h"
+bool Input::is_key_down   (SDL_Scancode) { return false; }
+bool Input::is_key_pressed(SDL_Scancode) { return false; }
+extern "C" void ref_camera_state(float fov, int width, int height, const float * position3, const float * rotation4, int updates, float * out58) {
+	MuteStdout mute;
+	Camera camera(fov);
+	camera.resize(width, height);
+	camera.position = Vector3(position3[0], position3[1], position3[2]);
+	camera.rotation = Quaternion(rotation4[0], rotation4[1], rotation4[2], rotation4[3]);
+	memset(camera.view_projection.cells, 0, sizeof(camera.view_projection.cells));
+	for (int i = 0; i < updates; i++) camera.update(0.0f);
+	float * o = out58;
+	for (const Vector3 & v : { camera.bottom_left_corner_rotated, camera.x_axis_rotated, camera.y_axis_rotated }) { *o++ = v.x; *o++ = v.y; *o++ = v.z; }
+	*o++ = camera.pixel_spread_angle;
+	for (const Matrix4 * m : { &camera.projection, &camera.view_projection, &camera.view_projection_prev }) { memcpy(o, m->cells, 64); o += 16; }
+}
+
+// Instance transform as Mesh::update computes it (Src/Renderer/Mesh.cpp:16-33; that file cannot be compiled
+// alone -- it includes the whole Scene -- so its three expressions are spelled out here over the reference's
+// own Matrix4 / Quaternion / AABB code). out: transform(16) transform_inv(16) aabb min(3) max(3) = 38 floats.
+extern "C" void ref_mesh_transform(const float * position3, const float * rotation4, float scale, const float * aabb6, float * out38) {
+	Vector3    position(position3[0], position3[1], position3[2]);
+	Quaternion rotation(rotation4[0], rotation4[1], rotation4[2], rotation4[3]);
+	Matrix4 transform     = Matrix4::create_translation(position) * Matrix4::create_rotation(rotation) * Matrix4::create_scale(scale);
+	Matrix4 transform_inv = Matrix4::create_scale(1.0f / scale) * Matrix4::create_rotation(Quaternion::conjugate(rotation)) * Matrix4::create_translation(-position);
+	AABB untransformed; untransformed.min = Vector3(aabb6[0], aabb6[1], aabb6[2]); untransformed.max = Vector3(aabb6[3], aabb6[4], aabb6[5]);
+	AABB aabb = AABB::transform(untransformed, transform);
+	aabb.fix_if_needed();
+	memcpy(out38, transform.cells, 64); memcpy(out38 + 16, transform_inv.cells, 64);
+	out38[32] = aabb.min.x; out38[33] = aabb.min.y; out38[34] = aabb.min.z; out38[35] = aabb.max.x; out38[36] = aabb.max.y; out38[37] = aabb.max.z;
+}
+
+// Medium parameterisation, verbatim header (Src/Renderer/Medium.h:16-37): (sigma_a, sigma_s, g) -> (C, mfp) -> sigmas again.
+#include "Renderer/Medium.h"
+extern "C" void ref_medium_round_trip(const float * sigma_a3, const float * sigma_s3, float g, float * out12) {
+	Medium medium;
+	medium.g = g;
+	medium.from_sigmas(Vector3(sigma_a3[0], sigma_a3[1], sigma_a3[2]), Vector3(sigma_s3[0], sigma_s3[1], sigma_s3[2]));
+	Vector3 a, s;
+	medium.to_sigmas(a, s);
+	const Vector3 * v[4] = { &medium.C, &medium.mfp, &a, &s };
+	for (int i = 0; i < 4; i++) { out12[3 * i] = v[i]->x; out12[3 * i + 1] = v[i]->y; out12[3 * i + 2] = v[i]->z; }
+}

@@ -956,3 +956,58 @@ def test_hdr_sky_equals_stbi_loadf(grt, oracle, tmp_path):
         if oracle.ref_lib() is not None and hasattr(oracle.ref_lib(), "ref_stbi_loadf_rgb"):
             ref = oracle.ref_stbi_loadf(tmp_path / name)
             assert ref is not None and np.array_equal(ref.view(np.uint32), out[:, :, :3].view(np.uint32)), name
+
+
+def test_camera_state_equals_the_references_camera(grt, oracle):
+    """Camera::resize / recalibrate / update (Camera.cpp:9-96): the view pyramid the generate kernel reads
+    (3 rotated vectors + pixel spread angle) and the projection / view-projection matrices SVGF reprojects
+    with are bit-identical to the reference's Camera.cpp compiled into oracle/_ref."""
+    import ctypes
+    if oracle.ref_lib() is None or not hasattr(oracle.ref_lib(), "ref_camera_state"):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    sig = [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    ref, lib = oracle.ref_lib(), grt.host_lib()
+    ref.ref_camera_state.argtypes = sig; lib.grt_camera_state.argtypes = sig
+    rng = np.random.default_rng(23)
+    for fov_deg, (w, h) in ((85.0, (1920, 1080)), (19.5, (512, 512)), (60.0, (900, 600)), (120.0, (33, 77))):
+        for updates in (1, 2):
+            pos = rng.uniform(-5, 5, 3).astype(np.float32)
+            q = rng.normal(size=4).astype(np.float32); q /= np.linalg.norm(q)
+            a, b = np.zeros(58, np.float32), np.zeros(58, np.float32)
+            ref.ref_camera_state(np.float32(np.deg2rad(fov_deg)), w, h, pos.ctypes.data, q.ctypes.data, updates, a.ctypes.data)
+            assert lib.grt_camera_state(np.float32(np.deg2rad(fov_deg)), w, h, pos.ctypes.data, q.ctypes.data, updates, b.ctypes.data) == 0
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (fov_deg, w, h, updates, np.flatnonzero(a != b))
+
+
+def test_instance_transforms_and_media_equal_the_reference_math(grt, oracle):
+    """Mesh::update (Mesh.cpp:16-33: transform, its inverse built from the inverted factors, transformed AABB)
+    and Medium::from_sigmas / to_sigmas (Medium.h:16-37) over the reference's own Matrix4 / Quaternion / AABB /
+    Vector3 code in oracle/_ref: bit-identical floats. These are the instance tables and sigma_a / sigma_s the
+    device gets."""
+    import ctypes
+    if oracle.ref_lib() is None or not hasattr(oracle.ref_lib(), "ref_mesh_transform"):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    ref, lib = oracle.ref_lib(), grt.host_lib()
+    sig = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+    ref.ref_mesh_transform.argtypes = sig; lib.grt_mesh_transform.argtypes = sig
+    rng = np.random.default_rng(29)
+    for i in range(50):
+        pos = rng.uniform(-20, 20, 3).astype(np.float32)
+        q = rng.normal(size=4).astype(np.float32); q /= np.linalg.norm(q)
+        if i == 0: pos[:] = 0; q[:] = (0, 0, 0, 1)
+        scale = np.float32(1.0 if i < 2 else rng.uniform(0.05, 30))
+        lo = rng.uniform(-5, 0, 3).astype(np.float32); box = np.concatenate([lo, lo + rng.uniform(0, 8, 3).astype(np.float32)])
+        if i == 3: box[3] = box[0]                                   # a flat box: fix_if_needed widens it
+        a, b = np.zeros(38, np.float32), np.zeros(38, np.float32)
+        ref.ref_mesh_transform(pos.ctypes.data, q.ctypes.data, scale, box.ctypes.data, a.ctypes.data)
+        assert lib.grt_mesh_transform(pos.ctypes.data, q.ctypes.data, scale, box.ctypes.data, b.ctypes.data) == 0
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (i, np.flatnonzero(a != b))
+    sig = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
+    ref.ref_medium_round_trip.argtypes = sig; lib.grt_medium_round_trip.argtypes = sig
+    for g in (0.0, 0.2, -0.7, 0.9999):
+        for _ in range(10):
+            sa = rng.uniform(0.001, 5, 3).astype(np.float32); ss = rng.uniform(0.001, 50, 3).astype(np.float32)
+            a, b = np.zeros(12, np.float32), np.zeros(12, np.float32)
+            ref.ref_medium_round_trip(sa.ctypes.data, ss.ctypes.data, g, a.ctypes.data)
+            assert lib.grt_medium_round_trip(sa.ctypes.data, ss.ctypes.data, g, b.ctypes.data) == 0
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (g, a, b)
