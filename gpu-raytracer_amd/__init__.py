@@ -477,6 +477,15 @@ class Pathtracer:
             i += 1
         return out
 
+    def texture_lod_size(self, index):
+        """(lod_width, lod_height) of texture `index`: what enters its LOD bias; (0, 0) = its own size."""
+        w, h = c_int(), c_int()
+        lib = host_lib()
+        lib.grt_pathtracer_texture_lod_size.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]
+        if lib.grt_pathtracer_texture_lod_size(self.handle, index, byref(w), byref(h)) != 0:
+            raise IndexError(index)
+        return w.value, h.value
+
     def read_framebuffer(self):
         image = np.zeros((self.height, self.pitch, 4), np.float32)
         _host_check(host_lib().grt_pathtracer_read_framebuffer(self.handle, image.ctypes.data))

@@ -493,7 +493,9 @@ int rt_upload_textures(rt_context * ctx, const rt_texture_desc * descs, size_t c
 		ctx->texture_data.push_back(dev);
 		table[i].texels = (const uchar4 *)dev;
 		table[i].width = d.width; table[i].height = d.height; table[i].mip_levels = d.mip_levels;
-		table[i].lod_bias = 0.5f * log2f(float(d.width * d.height)); // Integrator.cpp:95
+		int lod_width  = d.lod_width  > 0 ? d.lod_width  : d.width;
+		int lod_height = d.lod_height > 0 ? d.lod_height : d.height;
+		table[i].lod_bias = 0.5f * log2f(float(lod_width * lod_height)); // Integrator.cpp:95
 	}
 	int s = upload(ctx, &ctx->texture_table, table.data(), count * sizeof(RtTexture)); if (s) return s;
 	ctx->params.textures = (const RtTexture *)ctx->texture_table;

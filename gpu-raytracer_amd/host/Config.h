@@ -62,6 +62,9 @@ struct CPUConfig {
 	IntegratorType integrator = IntegratorType::PATHTRACER; // read by the command-line front end
 
 	MipmapFilterType mipmap_filter = MipmapFilterType::BOX;
+	// BC1-quantise power-of-two textures like the reference does by default (BlockCompression.cpp). Off by
+	// default here until the textured GPU parity tests have been re-run with it.
+	bool enable_block_compression = false;
 	BVHType bvh_type = BVHType::BVH8;
 
 	// "<mesh file>.bvh" caches (BVHCache.h). The reference always reads and writes them; a library

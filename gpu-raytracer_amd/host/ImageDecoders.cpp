@@ -8,6 +8,7 @@
 //        texture unit to hand the blocks to; the values are used as they are (the reference does
 //        not gamma-convert DDS data either).
 #include "ImageDecoders.h"
+#include "BlockCompression.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -271,6 +272,10 @@ void decode_colour_block(const unsigned char * block, bool opaque_only, unsigned
 		for (int k = 0; k < 4; k++) out[i][k] = (unsigned char)c[k];
 	}
 }
+}
+
+void BlockCompression::decode_bc1_block(const unsigned char block[8], unsigned char rgba[16][4]) {
+	decode_colour_block(block, false, rgba);
 }
 
 bool ImageDecoders::decode_dds(const std::vector<unsigned char> & file, int & width, int & height, std::vector<std::vector<unsigned char>> & mip_levels) {

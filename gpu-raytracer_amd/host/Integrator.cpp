@@ -54,6 +54,8 @@ void Integrator::init_materials() {
 			descs[i].width      = textures[i].width;
 			descs[i].height     = textures[i].height;
 			descs[i].mip_levels = textures[i].mip_levels();
+			descs[i].lod_width  = textures[i].lod_width;
+			descs[i].lod_height = textures[i].lod_height;
 		}
 		check(rt_upload_textures(ctx, descs.data(), descs.size()));
 	}

@@ -12,6 +12,9 @@ struct Texture {
 	// Linear-light RGBA8 texels for every mip level, level 0 first.
 	std::vector<unsigned char> texels;
 	std::vector<size_t> mip_offsets; // in texels (4 bytes each)
+	// Size that enters the LOD bias; 0 = width / height. Block counts for a BC1-compressed texture, as in
+	// the reference (TextureLoader.cpp:256-258 overwrite width / height, Integrator.cpp:95 reads them).
+	int lod_width = 0, lod_height = 0;
 
 	int mip_levels() const { return int(mip_offsets.size()); }
 };

@@ -9,6 +9,7 @@
 // PIC and Radiance-HDR textures are not read: such a texture gets the reference's pink 1x1 fallback).
 #include "Scene.h"
 #include "ImageDecoders.h"
+#include "BlockCompression.h"
 #include "Parser.h"
 
 #include <cstdio>
@@ -212,6 +213,8 @@ bool TextureLoader::load(const std::string & filename, Texture * texture) {
 		if (!gpu_config.enable_mipmapping) dds_levels.resize(1);
 		texture->width  = width;
 		texture->height = height;
+		texture->lod_width  = (width  + 3) / 4; // the reference keeps DDS sizes in blocks (TextureLoader.cpp:54-55), and so its LOD bias
+		texture->lod_height = (height + 3) / 4;
 		texture->mip_offsets.clear();
 		texture->texels.clear();
 		for (const std::vector<unsigned char> & level : dds_levels) {
@@ -269,6 +272,31 @@ bool TextureLoader::load(const std::string & filename, Texture * texture) {
 		texture->texels[4 * i + 1] = quantise(linear[i].y);
 		texture->texels[4 * i + 2] = quantise(linear[i].z);
 		texture->texels[4 * i + 3] = quantise(linear[i].w);
+	}
+
+	// Block compression as the reference applies it to power-of-two textures (TextureLoader.cpp:208-262): each
+	// level is BC1-encoded in 4x4 blocks and -- there being no texture unit to decode it later -- decoded
+	// again right away. The compressed chain ends at the level that is one block in size, and the LOD bias
+	// is derived from the block counts (see Texture::lod_width).
+	auto is_power_of_two = [](int x) { return x > 0 && (x & (x - 1)) == 0; };
+	if (cpu_config.enable_block_compression && is_power_of_two(width) && is_power_of_two(height)) {
+		int blocks_w = (width + 3) / 4, blocks_h = (height + 3) / 4;
+		size_t kept_levels = 0;
+		for (int w = blocks_w, h = blocks_h;;) {
+			kept_levels++;
+			if (!gpu_config.enable_mipmapping || (w == 1 && h == 1)) break;
+			if (w > 1) w /= 2;
+			if (h > 1) h /= 2;
+		}
+		if (kept_levels < texture->mip_offsets.size()) {
+			texture->texels.resize(texture->mip_offsets[kept_levels] * 4);
+			texture->mip_offsets.resize(kept_levels);
+		}
+		for (size_t l = 0; l < texture->mip_offsets.size(); l++) {
+			BlockCompression::quantise_level_bc1(&texture->texels[texture->mip_offsets[l] * 4], std::max(width >> l, 1), std::max(height >> l, 1));
+		}
+		texture->lod_width  = blocks_w;
+		texture->lod_height = blocks_h;
 	}
 	return true;
 }

@@ -4,6 +4,7 @@
 #include <stdexcept>
 #include "Pathtracer.h"
 #include "Exporters.h"
+#include "BlockCompression.h"
 #include "AO.h"
 
 #include <cstring>
@@ -50,6 +51,7 @@ int grt_config_set(const char * key, double value) {
 		if (int(value) < 0 || int(value) > 2) { g_host_error = "mipmap_filter must be 0 (box), 1 (lanczos) or 2 (kaiser)"; return -1; }
 		cpu_config.mipmap_filter = MipmapFilterType(int(value));
 	}
+	else if (k == "enable_block_compression")            cpu_config.enable_block_compression = value != 0;
 	else if (k == "enable_bvh_cache")                    cpu_config.enable_bvh_cache = value != 0;
 	else if (k == "bvh_force_rebuild")                   cpu_config.bvh_force_rebuild = value != 0;
 	else if (k == "sah_cost_node")                       cpu_config.sah_cost_node = float(value);
@@ -326,6 +328,12 @@ void grt_pathtracer_sky_size(void * pt, int * w, int * h, float * scale) {
 	*w = p->scene.sky.width; *h = p->scene.sky.height; *scale = p->scene.sky.scale;
 }
 // Texture table views
+int grt_pathtracer_texture_lod_size(void * pt, int index, int * lod_width, int * lod_height) {
+	const std::vector<Texture> & t = as_integrator(pt)->scene.asset_manager.textures;
+	if (index < 0 || index >= int(t.size())) return -1;
+	*lod_width = t[index].lod_width; *lod_height = t[index].lod_height;
+	return 0;
+}
 int grt_pathtracer_texture(void * pt, int index, const unsigned char ** texels, int * width, int * height, int * mip_levels) {
 	Integrator * p = as_integrator(pt);
 	const std::vector<Texture> & t = p->scene.asset_manager.textures;
@@ -424,6 +432,9 @@ int grt_sky_load(const char * filename, int * width, int * height, float * dst_r
 		return int(count);
 	GRT_CATCH(-1)
 }
+
+// One BC1 block through the product's encoder, for the parity test against stb_dxt in oracle/_ref
+void grt_compress_bc1_block(const unsigned char * rgba64, unsigned char * dst8) { BlockCompression::compress_bc1_block(rgba64, dst8); }
 
 // Stand-alone texture decode (file -> linear RGBA8 mip chain), for the decoder tests
 void * grt_texture_load(const char * filename) {

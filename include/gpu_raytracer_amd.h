@@ -100,6 +100,10 @@ typedef struct rt_texture_desc {
 	const uint8_t * texels;      /* all mip levels back to back, level 0 first, 4 B/texel */
 	int32_t         width, height; /* level 0 size; level l is max(w>>l,1) x max(h>>l,1)  */
 	int32_t         mip_levels;
+	/* Size that enters lod_bias = 0.5 * log2(w * h) (Integrator.cpp:95); 0 = width / height. The reference
+	 * overwrites Texture::width/height with the BLOCK counts when it BC1-compresses a texture
+	 * (TextureLoader.cpp:256-258), so compressed textures carry a bias that is 2 lower.                  */
+	int32_t         lod_width, lod_height;
 } rt_texture_desc;
 
 /* Per-stage counters of the last rt_render_sample, replaces the read-back of

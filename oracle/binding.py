@@ -34,7 +34,7 @@ class Camera(Structure):
 
 
 class OracleTexture(Structure):
-    _fields_ = [("texels", c_void_p), ("width", c_int32), ("height", c_int32), ("mip_levels", c_int32)]
+    _fields_ = [("texels", c_void_p), ("width", c_int32), ("height", c_int32), ("mip_levels", c_int32), ("lod_width", c_int32), ("lod_height", c_int32)]
 
 
 class OracleScene(Structure):
@@ -243,6 +243,7 @@ class SceneView:
         table = (OracleTexture * max(len(tex), 1))()
         for i, (texels, w, h, levels) in enumerate(tex):
             table[i].texels = texels.ctypes.data; table[i].width = w; table[i].height = h; table[i].mip_levels = levels
+            table[i].lod_width, table[i].lod_height = pt.texture_lod_size(i)
         self.keep["tex_table"] = table
         s.textures = ctypes.cast(table, c_void_p); s.texture_count = len(tex)
 

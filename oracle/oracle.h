@@ -34,6 +34,7 @@ extern "C" {
 typedef struct oracle_texture {
 	const uint8_t * texels;     /* RGBA8 linear, all mip levels, level 0 first */
 	int32_t width, height, mip_levels;
+	int32_t lod_width, lod_height; /* size that enters the LOD bias; 0 = width / height (rt_texture_desc) */
 } oracle_texture;
 
 /* Flat views of exactly the arrays the device is given (see include/gpu_raytracer_amd.h). */

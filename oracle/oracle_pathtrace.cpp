@@ -133,7 +133,9 @@ inline float3 sample_albedo(const oracle_scene & s, int bounce, float3 diffuse, 
 		if (bounce == 0) {
 			return diffuse * make_float3(texture_get_grad(tex, tex_coord.x, tex_coord.y, lod.gradient_1, lod.gradient_2));
 		} else {
-			float lod_bias = 0.5f * log2f(float(tex.width * tex.height)); // Integrator.cpp:95
+			int lod_width  = tex.lod_width  > 0 ? tex.lod_width  : tex.width;
+			int lod_height = tex.lod_height > 0 ? tex.lod_height : tex.height;
+			float lod_bias = 0.5f * log2f(float(lod_width * lod_height)); // Integrator.cpp:95
 			return diffuse * make_float3(texture_get_lod(tex, tex_coord.x, tex_coord.y, lod.lod + lod_bias));
 		}
 	}

@@ -620,3 +620,29 @@ def test_command_line_render_and_screenshots_match_the_library(grt, tmp_path):
     header = b"P6\n %d\n %d\n 255\n" % (w, h)
     assert raw.startswith(header) and len(raw) == len(header) + w * h * 3 and np.frombuffer(raw[len(header):], np.uint8).mean() > 20
     pt.close(); scene.close()
+
+
+@pytest.mark.gpu
+def test_block_compressed_textures_render_like_the_oracle(grt, oracle):
+    """enable_block_compression: Sponza's power-of-two maps are BC1-quantised on the host and carry the
+    reference's block-count LOD size (rt_texture_desc::lod_width / lod_height), which shifts the bias of the
+    bounce > 0 texture lookups by -2. Bounce-0 albedo and a 3-bounce frame match the oracle, which is given
+    the same descriptors; and the frame differs from the uncompressed one (the switch does something)."""
+    frames = {}
+    for compress in (1, 0):
+        scene, pt = make_pathtracer(grt, "sponza", 320, 180, 0, num_bounces=3, enable_block_compression=compress)
+        if compress:
+            sizes = [pt.texture_lod_size(i) for i in range(len(pt.textures()))]
+            assert sum(1 for s in sizes if s != (0, 0)) == 19 and all(s in ((0, 0), (256, 256)) for s in sizes)   # 1024^2 maps -> 256^2 blocks
+            pt.aov_enable(grt.AOV_ALBEDO); pt.update()
+            view = oracle.SceneView(pt); frame = oracle.Frame(view)
+            pt.render(); frame.render_sample(pt.sample_index)
+            got, want = pt.read_aov(grt.AOV_ALBEDO)[:, :320, :3], frame.accumulator(grt.AOV_ALBEDO)[:, :320, :3]
+            assert (np.abs(got - want).max(axis=2) > 2e-3).mean() < 1e-3
+            got, want = pt.read_framebuffer()[:, :320, :3], frame.final[:, :320, :3]
+            assert np.abs(got - want).sum() / want.sum() < 1e-3
+        else:
+            pt.render()
+        frames[compress] = pt.read_framebuffer()[:, :320, :3].copy()
+        pt.close(); scene.close()
+    assert not np.array_equal(frames[0], frames[1])

@@ -1011,3 +1011,115 @@ def test_instance_transforms_and_media_equal_the_reference_math(grt, oracle):
             ref.ref_medium_round_trip(sa.ctypes.data, ss.ctypes.data, g, a.ctypes.data)
             assert lib.grt_medium_round_trip(sa.ctypes.data, ss.ctypes.data, g, b.ctypes.data) == 0
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (g, a, b)
+
+
+def test_bc1_encoder_equals_the_references_stb_dxt(grt, oracle):
+    """BlockCompression.cpp restates stb_dxt v1.12 HIGHQUAL (TextureLoader.cpp:250): identical 8 bytes per block
+    against stb_compress_dxt_block compiled verbatim into oracle/_ref -- random blocks, smooth gradients,
+    two-colour and constant blocks (every constant value: that is the generated single-colour table), blocks with
+    zero padding as at a level's edge, and every 4x4 block of a real texture."""
+    import ctypes
+    if oracle.ref_lib() is None or not hasattr(oracle.ref_lib(), "ref_stb_compress_bc1_block"):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    ref, lib = oracle.ref_lib(), grt.host_lib()
+    lib.grt_compress_bc1_block.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(31)
+    blocks = [rng.integers(0, 256, (16, 4)).astype(np.uint8) for _ in range(3000)]
+    for _ in range(3000):                                            # smooth blocks: a base colour plus a small gradient and noise
+        base = rng.integers(0, 256, 3); grad = rng.normal(0, 12, 3)
+        b = np.zeros((16, 4), np.uint8)
+        for i in range(16):
+            b[i, :3] = np.clip(base + grad * (i % 4 - 1.5) + rng.normal(0, 3, 3), 0, 255)
+        b[:, 3] = 255
+        blocks.append(b)
+    for _ in range(500):                                             # two colours, and nearly constant blocks
+        c = rng.integers(0, 256, (2, 3)); b = np.zeros((16, 4), np.uint8); b[:, :3] = c[rng.integers(0, 2, 16)]; b[:, 3] = 255; blocks.append(b)
+        b = np.full((16, 4), 255, np.uint8); b[:, :3] = rng.integers(0, 256, 3); b[rng.integers(0, 16), rng.integers(0, 3)] ^= 1; blocks.append(b)
+    for v in range(256):
+        blocks.append(np.full((16, 4), v, np.uint8))
+        b = np.zeros((16, 4), np.uint8); b[:, 0] = v; b[:, 1] = 255 - v; b[:, 2] = (v * 7) & 255; b[:, 3] = 255; blocks.append(b)
+    for _ in range(300):                                             # partially outside the image: zero texels
+        b = rng.integers(0, 256, (16, 4)).astype(np.uint8); keep = rng.integers(1, 4); b.reshape(4, 4, 4)[:, keep:] = 0; blocks.append(b)
+    grt.config_reset(); grt.config_set(enable_mipmapping=0)
+    tex = grt.load_texture(os.path.join(os.path.dirname(grt.scene_path("sponza")), "textures", "sponza_floor_a_diff.tga"))[0]
+    grt.config_reset()
+    crop = tex[:256, :256]
+    for y in range(0, 256, 4):
+        for x in range(0, 256, 4):
+            blocks.append(np.ascontiguousarray(crop[y:y + 4, x:x + 4]).reshape(16, 4))
+    mismatches = 0
+    a, b = np.zeros(8, np.uint8), np.zeros(8, np.uint8)
+    for blk in blocks:
+        blk = np.ascontiguousarray(blk)
+        ref.ref_stb_compress_bc1_block(blk.ctypes.data, a.ctypes.data)
+        lib.grt_compress_bc1_block(blk.ctypes.data, b.ctypes.data)
+        mismatches += not np.array_equal(a, b)
+    assert mismatches == 0, "%d of %d blocks differ" % (mismatches, len(blocks))
+
+
+def test_block_compressed_textures_follow_the_reference_pipeline(grt, oracle, tmp_path):
+    """enable_block_compression (the reference's default, TextureLoader.cpp:208-262): every level of a
+    power-of-two texture is BC1-quantised block by block, the chain ends at the one-block level, and the LOD
+    bias is derived from the block counts (Texture::lod_width). Level 0 equals decode(stb_compress_dxt_block)
+    of the uncompressed level for every block (verbatim stb_dxt in oracle/_ref); non-power-of-two textures are
+    left alone. The oracle renders a scene with such textures (bounce > 0 lookups use the shifted bias)."""
+    import ctypes
+    rng = np.random.default_rng(33)
+    y, x = np.mgrid[0:32, 0:64]
+    img = np.dstack([127 + 100 * np.sin(x / 5.0), 127 + 100 * np.cos(y / 3.0), (x * 4 + y * 2) % 256]) + rng.normal(0, 6, (32, 64, 3))
+    img = np.clip(img, 0, 255).astype(np.int64)
+    (tmp_path / "pow2.png").write_bytes(_png_bytes(img, 2, 8))
+    (tmp_path / "odd.png").write_bytes(_png_bytes(img[:30, :60], 2, 8))
+    grt.config_reset()
+    plain = grt.load_texture(tmp_path / "pow2.png")
+    grt.config_set(enable_block_compression=1)
+    packed = grt.load_texture(tmp_path / "pow2.png")
+    odd = grt.load_texture(tmp_path / "odd.png")
+    grt.config_reset()
+    assert [l.shape[:2] for l in plain] == [(32, 64), (16, 32), (8, 16), (4, 8), (2, 4), (1, 2), (1, 1)]
+    assert [l.shape[:2] for l in packed] == [(32, 64), (16, 32), (8, 16), (4, 8), (2, 4)]      # 16x8 blocks ... 1x1 block
+    assert np.array_equal(odd[0], grt.load_texture(tmp_path / "odd.png")[0])                  # 60x30: not compressed
+    assert not np.array_equal(packed[0], plain[0]) and np.abs(packed[0][:, :, :3].astype(int) - plain[0][:, :, :3]).mean() < 12   # a noisy, colourful image: BC1 has two end points per block
+    assert (packed[0][:, :, 3] == 255).all()
+    if oracle.ref_lib() is not None and hasattr(oracle.ref_lib(), "ref_stb_compress_bc1_block"):
+        ref = oracle.ref_lib()
+        for level, (src, got) in enumerate(zip(plain, packed)):
+            h, w = src.shape[:2]
+            for by in range((h + 3) // 4):
+                for bx in range((w + 3) // 4):
+                    block = np.zeros((4, 4, 4), np.uint8)
+                    part = src[by * 4:by * 4 + 4, bx * 4:bx * 4 + 4]
+                    block[:part.shape[0], :part.shape[1]] = part
+                    comp = np.zeros(8, np.uint8)
+                    ref.ref_stb_compress_bc1_block(block.ctypes.data, comp.ctypes.data)
+                    c0, c1 = int(comp[0]) | int(comp[1]) << 8, int(comp[2]) | int(comp[3]) << 8
+                    ex = lambda c: np.array([((c >> 11) * 33) >> 2, (((c >> 5) & 63) * 65) >> 4, ((c & 31) * 33) >> 2])
+                    e0, e1 = ex(c0), ex(c1)
+                    pal = [e0, e1, (2 * e0 + e1 + 1) // 3, (e0 + 2 * e1 + 1) // 3] if c0 > c1 else [e0, e1, (e0 + e1) // 2, np.zeros(3, int)]
+                    bits = int.from_bytes(bytes(comp[4:8]), "little")
+                    for j in range(part.shape[0]):
+                        for i in range(part.shape[1]):
+                            assert np.array_equal(got[by * 4 + j, bx * 4 + i, :3], pal[(bits >> (2 * (4 * j + i))) & 3]), (level, bx, by)
+
+    # through the scene loader and the oracle: lod size = block counts, and the render reacts to it
+    (tmp_path / "floor.obj").write_text("v -4 0 -4\nv 4 0 -4\nv 4 0 4\nv -4 0 4\nvt 0 0\nvt 6 0\nvt 6 6\nvt 0 6\nf 1/1 3/3 2/2\nf 1/1 4/4 3/3\n")
+    (tmp_path / "s.xml").write_text('<scene version="0.5.0"><sensor type="perspective"><float name="fov" value="50"/><transform name="toWorld"><lookat origin="0, 1.5, 5" target="0, 0, 0" up="0, 1, 0"/></transform></sensor>'
+                                    '<shape type="obj"><string name="filename" value="floor.obj"/><bsdf type="diffuse"><texture type="bitmap" name="reflectance"><string name="filename" value="pow2.png"/></texture></bsdf></shape>'
+                                    '<shape type="sphere"><float name="radius" value="0.7"/><transform name="toWorld"><translate y="0.7"/></transform><bsdf type="diffuse"><rgb name="reflectance" value="0.9, 0.9, 0.9"/></bsdf></shape></scene>')
+    images = {}
+    for compress in (0, 1):
+        grt.config_reset()
+        grt.config_set(enable_block_compression=compress)
+        scene = grt.Scene(str(tmp_path / "s.xml"))
+        grt.config_set(num_bounces=3)
+        pt = grt.Pathtracer(scene, 48, 32, device=-1); pt.update()
+        assert pt.texture_lod_size(0) == ((16, 8) if compress else (0, 0))
+        assert pt.textures()[0][3] == (5 if compress else 7)
+        frame = oracle.Frame(oracle.SceneView(pt))
+        for s in range(3):
+            frame.render_sample(s)
+        images[compress] = frame.final[:, :48, :3].copy()
+        pt.close(); scene.close()
+    grt.config_reset()
+    assert np.isfinite(images[1]).all() and not np.array_equal(images[0], images[1])
+    assert abs(images[0].mean() - images[1].mean()) < 0.05 * images[0].mean()
