@@ -632,8 +632,10 @@ def test_block_compressed_textures_render_like_the_oracle(grt, oracle):
     for compress in (1, 0):
         scene, pt = make_pathtracer(grt, "sponza", 320, 180, 0, num_bounces=3, enable_block_compression=compress)
         if compress:
-            sizes = [pt.texture_lod_size(i) for i in range(len(pt.textures()))]
-            assert sum(1 for s in sizes if s != (0, 0)) == 19 and all(s in ((0, 0), (256, 256)) for s in sizes)   # 1024^2 maps -> 256^2 blocks
+            textures = pt.textures()
+            sizes = [pt.texture_lod_size(i) for i in range(len(textures))]
+            assert sum(1 for s in sizes if s != (0, 0)) == 19                                  # every real map (they are all powers of two)
+            assert all(s == ((0, 0) if t[1] == 1 else (t[1] // 4, t[2] // 4)) for s, t in zip(sizes, textures))   # e.g. 1024^2 texels -> 256^2 blocks
             pt.aov_enable(grt.AOV_ALBEDO); pt.update()
             view = oracle.SceneView(pt); frame = oracle.Frame(view)
             pt.render(); frame.render_sample(pt.sample_index)
