@@ -170,7 +170,7 @@ def host_lib():
 
 def _host_check(status):
     if status != 0:
-        raise RuntimeError(host_lib().grt_last_error().decode())
+        raise RuntimeError(host_lib().grt_last_error().decode(errors="replace"))
 
 
 def _view(ptr, nbytes, dtype):
@@ -246,7 +246,7 @@ def config_set(**kwargs):
         if key == "bvh_type" and isinstance(value, str):
             value = BVH_TYPES[value.lower()]
         if lib.grt_config_set(key.encode(), float(value)) != 0:
-            raise KeyError(lib.grt_last_error().decode())
+            raise KeyError(lib.grt_last_error().decode(errors="replace"))
 
 
 def load_texture(filename):
@@ -260,7 +260,7 @@ def load_texture(filename):
     lib.grt_texture_free.argtypes = [c_void_p]
     handle = lib.grt_texture_load(str(filename).encode())
     if not handle:
-        raise RuntimeError(lib.grt_last_error().decode())
+        raise RuntimeError(lib.grt_last_error().decode(errors="replace"))
     w, h, levels, nbytes = c_int(), c_int(), c_int(), c_size_t()
     ptr = lib.grt_texture_data(handle, byref(w), byref(h), byref(levels), byref(nbytes))
     data = _view(ptr, nbytes.value, np.uint8).copy()
@@ -293,7 +293,7 @@ class Scene:
         lib = host_lib()
         self.handle = lib.grt_scene_load(os.fsencode(filename), os.fsencode(sky) if sky else b"")
         if not self.handle:
-            raise RuntimeError("scene load failed: " + lib.grt_last_error().decode())
+            raise RuntimeError("scene load failed: " + lib.grt_last_error().decode(errors="replace"))
 
     def close(self):
         if self.handle:
@@ -382,7 +382,7 @@ class Pathtracer:
         self.scene = scene
         self.handle = getattr(lib, self._create)(scene.handle, width, height, device)
         if not self.handle:
-            raise RuntimeError("%s creation failed: %s" % (type(self).__name__, lib.grt_last_error().decode()))
+            raise RuntimeError("%s creation failed: %s" % (type(self).__name__, lib.grt_last_error().decode(errors="replace")))
         self.width, self.height = width, height
 
     def close(self):

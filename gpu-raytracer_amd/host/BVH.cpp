@@ -255,6 +255,15 @@ void BVH8Converter::assign_octant_slots(int node_index, int children[8], int chi
 		slot_of_child[best_child] = best_slot;
 	}
 
+	// Children whose costs never compared (NaN boxes, or nothing but +inf left) take the free slots in order
+	for (int c = 0; c < child_count; c++) {
+		if (slot_of_child[c] != INVALID) continue;
+		int s = 0;
+		while (slot_taken[s]) s++;
+		slot_taken[s] = true;
+		slot_of_child[c] = s;
+	}
+
 	int unordered[8];
 	for (int i = 0; i < 8; i++) { unordered[i] = children[i]; children[i] = INVALID; }
 	for (int c = 0; c < child_count; c++) children[slot_of_child[c]] = unordered[c];

@@ -118,6 +118,14 @@ BVHObjectSplit bvh_find_object_split(BoxAt box_at, int first, int count, float *
 			}
 		}
 	}
+	if (s.axis < 0) {
+		// Every candidate cost was NaN (non-finite boxes): no comparison above could succeed. Split in the
+		// middle of the x order so that callers still get a valid partition.
+		s.axis  = 0;
+		s.index = first + count / 2;
+		s.cost  = INFINITY;
+		for (int i = s.index; i < first + count; i++) s.right.expand(box_at(0, i));
+	}
 	for (int i = first; i < s.index; i++) s.left.expand(box_at(s.axis, i));
 	return s;
 }

@@ -1,6 +1,7 @@
 #include "BVHCache.h"
 #include "Config.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <sys/stat.h>
@@ -113,12 +114,18 @@ bool BVHCache::try_to_load(const std::string & mesh_filename, const std::string 
 	}
 	if (memcmp(header.filetype_identifier, "BVH", 4) != 0 || header.filetype_version != FILETYPE_VERSION) return false;
 	if (header.underlying_bvh_type != char(underlying_bvh_type()) ||
-		header.bvh_is_optimized    != cpu_config.enable_bvh_optimization ||
+		(header.bvh_is_optimized != 0) != cpu_config.enable_bvh_optimization || header.bvh_is_optimized > 1 ||
 		header.sah_cost_node       != cpu_config.sah_cost_node ||
 		header.sah_cost_leaf       != cpu_config.sah_cost_leaf) {
 		return false; // built with other settings: rebuild (BVHLoader.cpp:156-164)
 	}
 	if (header.num_triangles < 0 || header.num_nodes < 0 || header.num_indices < 0) return false;
+	{	// deflate cannot expand by more than ~1032 : 1, so counts far beyond the file's size are a damaged header
+		struct stat st;
+		if (stat(bvh_filename.c_str(), &st) != 0) return false;
+		double claimed = double(header.num_triangles) * sizeof(Triangle) + double(header.num_nodes) * sizeof(BVHNode2) + double(header.num_indices) * sizeof(int);
+		if (claimed > double(st.st_size) * 1040.0 + 4096.0) return false;
+	}
 
 	std::vector<Triangle> loaded_triangles(header.num_triangles);
 	BVH2 loaded;
@@ -136,10 +143,17 @@ bool BVHCache::try_to_load(const std::string & mesh_filename, const std::string 
 	}
 	// A cache is trusted for its content but not for memory safety: every index must stay in range.
 	for (int index : loaded.indices) if (index < 0 || index >= header.num_triangles) return false;
-	for (const BVHNode2 & node : loaded.nodes) {
+	// ... every box must be finite, and children must come after their parent (as every builder emits them),
+	// which rules out cycles.
+	for (size_t i = 0; i < loaded.nodes.size(); i++) {
+		if (i == 1) continue; // the unused sibling of the root
+		const BVHNode2 & node = loaded.nodes[i];
+		const float * box = &node.aabb.min.x;
+		for (int k = 0; k < 6; k++) if (!std::isfinite(box[k])) return false;
 		if (node.is_leaf() ? (node.first < 0 || size_t(node.first) + node.count > loaded.indices.size())
-		                   : (node.left  < 0 || size_t(node.left) + 1 >= loaded.nodes.size())) return false;
+		                   : (node.left <= int(i) || size_t(node.left) + 1 >= loaded.nodes.size())) return false;
 	}
+	if (loaded.nodes.size() < 2 || loaded.indices.empty()) return false;
 	*triangles = std::move(loaded_triangles);
 	*bvh       = std::move(loaded);
 	return true;
@@ -157,7 +171,7 @@ bool BVHCache::save(const std::string & bvh_filename, const std::vector<Triangle
 		memcpy(header.filetype_identifier, "BVH", 4);
 		header.filetype_version    = FILETYPE_VERSION;
 		header.underlying_bvh_type = char(underlying_bvh_type());
-		header.bvh_is_optimized    = cpu_config.enable_bvh_optimization;
+		header.bvh_is_optimized    = cpu_config.enable_bvh_optimization ? 1 : 0;
 		header.sah_cost_node       = cpu_config.sah_cost_node;
 		header.sah_cost_leaf       = cpu_config.sah_cost_leaf;
 		header.num_triangles = int(triangles.size());

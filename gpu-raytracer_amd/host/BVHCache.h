@@ -20,7 +20,7 @@ namespace BVHCache {
 
 		// settings the tree was built with; a mismatch with the current ones rejects the file
 		char  underlying_bvh_type;   // BVHType::BVH or BVHType::SBVH
-		bool  bvh_is_optimized;
+		unsigned char bvh_is_optimized; // a bool on disk; read as a byte so that a damaged file cannot produce an invalid bool
 		float sah_cost_node;
 		float sah_cost_leaf;
 

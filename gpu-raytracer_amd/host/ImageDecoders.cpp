@@ -109,6 +109,7 @@ bool ImageDecoders::decode_png(const std::vector<unsigned char> & file, int & wi
 		pos += size_t(length) + 12;
 	}
 	if (!have_header || info.width <= 0 || info.height <= 0 || info.width > (1 << 15) || info.height > (1 << 15)) return false;
+	if (size_t(info.width) * info.height > (size_t(1) << 28)) return false; // a quarter gigapixel is beyond any texture
 	static const int VALID_DEPTHS[7][6] = { { 1, 2, 4, 8, 16, 0 }, { 0 }, { 8, 16, 0 }, { 1, 2, 4, 8, 0 }, { 8, 16, 0 }, { 0 }, { 8, 16, 0 } };
 	if (info.colour_type > 6) return false;
 	bool depth_ok = false;
@@ -195,7 +196,7 @@ bool ImageDecoders::decode_bmp(const std::vector<unsigned char> & file, int & wi
 	uint32_t compression = le32(&file[30]);
 	bool top_down = h < 0;
 	if (top_down) h = -h;
-	if (w <= 0 || h <= 0 || w > (1 << 15) || h > (1 << 15)) return false;
+	if (w <= 0 || h <= 0 || w > (1 << 15) || h > (1 << 15) || size_t(w) * h > (size_t(1) << 28)) return false;
 	if (!(bits == 8 || bits == 24 || bits == 32)) return false;
 	if (!(compression == 0 || (compression == 3 && bits == 32))) return false; // BI_RGB, or BI_BITFIELDS for 32 bit
 

@@ -116,12 +116,14 @@ struct Component {
 	std::vector<int16_t>       coefficients; // progressive only: 64 per block, blocks in raster order
 };
 
-inline unsigned char clamp_u8(int x) { return (unsigned char)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+inline unsigned char clamp_u8(long long x) { return (unsigned char)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 
-// jidctint-style 13-bit fixed point butterflies in the form stb_image uses (constants scaled by 4096)
-#define F2F(x) (int((x) * 4096 + 0.5))
+// jidctint-style 13-bit fixed point butterflies in the form stb_image uses (constants scaled by 4096).
+// 64-bit intermediates: identical results for every valid stream, and no signed overflow on corrupt ones.
+typedef long long wide;
+#define F2F(x) (wide((x) * 4096 + 0.5))
 #define IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7) \
-	int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3; \
+	wide t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3; \
 	p2 = s2; p3 = s6; \
 	p1 = (p2 + p3) * F2F(0.5411961f); \
 	t2 = p1 + p3 * F2F(-1.847759065f); \
@@ -146,10 +148,10 @@ inline unsigned char clamp_u8(int x) { return (unsigned char)(x < 0 ? 0 : (x > 2
 // Dequantised coefficients (row-major) -> 8x8 samples. Columns first, keeping 2 extra bits; rows second
 // with the rounding bias and the +128 level shift folded into one constant.
 void inverse_dct(const int16_t block[64], unsigned char * out, int stride) {
-	int column_pass[64];
+	wide column_pass[64];
 	for (int i = 0; i < 8; i++) {
 		const int16_t * d = block + i;
-		int * v = column_pass + i;
+		wide * v = column_pass + i;
 		IDCT_1D(d[0], d[8], d[16], d[24], d[32], d[40], d[48], d[56])
 		x0 += 512; x1 += 512; x2 += 512; x3 += 512;
 		v[ 0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10;
@@ -158,10 +160,10 @@ void inverse_dct(const int16_t block[64], unsigned char * out, int stride) {
 		v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
 	}
 	for (int i = 0; i < 8; i++) {
-		const int * v = column_pass + 8 * i;
+		const wide * v = column_pass + 8 * i;
 		unsigned char * o = out + size_t(i) * stride;
 		IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
-		const int bias = 65536 + (128 << 17);
+		const wide bias = 65536 + (128 << 17);
 		x0 += bias; x1 += bias; x2 += bias; x3 += bias;
 		o[0] = clamp_u8((x0 + t3) >> 17); o[7] = clamp_u8((x0 - t3) >> 17);
 		o[1] = clamp_u8((x1 + t2) >> 17); o[6] = clamp_u8((x1 - t2) >> 17);
@@ -256,7 +258,7 @@ struct Decoder {
 		if (length < 11 || u8() != 8) return false; // 8-bit samples only
 		height = u16(); width = u16();
 		int count = u8();
-		if (width <= 0 || height <= 0 || width > (1 << 15) || height > (1 << 15)) return false;
+		if (width <= 0 || height <= 0 || width > (1 << 15) || height > (1 << 15) || size_t(width) * height > (size_t(1) << 28)) return false;
 		if (!(count == 1 || count == 3 || count == 4) || length != 8 + 3 * count) return false;
 		components.assign(count, Component());
 		for (int i = 0; i < count; i++) {
@@ -318,8 +320,8 @@ struct Decoder {
 		memset(block, 0, 64 * sizeof(int16_t));
 		int t = reader.decode(dc);
 		if (t < 0 || t > 15) return false;
-		c.dc_pred += reader.receive_extend(t);
-		block[0] = int16_t(c.dc_pred * quant[c.tq][0]);
+		c.dc_pred = int(uint32_t(c.dc_pred) + uint32_t(reader.receive_extend(t))); // wraps instead of overflowing on hostile streams
+		block[0] = int16_t(wide(c.dc_pred) * quant[c.tq][0]);
 		for (int k = 1; k < 64;) {
 			int rs = reader.decode(ac);
 			if (rs < 0) return false;
@@ -343,8 +345,8 @@ struct Decoder {
 			if (!dc.defined) return false;
 			int t = reader.decode(dc);
 			if (t < 0 || t > 15) return false;
-			c.dc_pred += reader.receive_extend(t);
-			block[0] = int16_t(c.dc_pred * (1 << approx_low));
+			c.dc_pred = int(uint32_t(c.dc_pred) + uint32_t(reader.receive_extend(t)));
+			block[0] = int16_t(wide(c.dc_pred) * (1 << approx_low));
 		} else if (reader.get_bit()) {
 			block[0] = int16_t(block[0] + (1 << approx_low));
 		}

@@ -58,9 +58,9 @@ struct Parser {
 		bool negative = match('-');
 		if (!negative) match('+');
 		if (!is_digit(peek())) fail("expected integer digit");
-		int value = 0;
-		while (is_digit(peek())) { value = value * 10 + (*cur - '0'); advance(); }
-		return negative ? -value : value;
+		unsigned value = 0; // unsigned: an absurdly long digit string wraps around instead of overflowing
+		while (is_digit(peek())) { value = value * 10u + unsigned(*cur - '0'); advance(); }
+		return int(negative ? 0u - value : value);
 	}
 
 	float parse_float() {

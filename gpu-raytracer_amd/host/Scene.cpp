@@ -3,6 +3,7 @@
 #include "Parser.h"
 
 #include <atomic>
+#include <cmath>
 #include <chrono>
 #include <cstdio>
 #include <mutex>
@@ -33,6 +34,11 @@ void Mesh::update() {
 		Matrix4::create_translation(-position);
 
 	aabb = AABB::transform(aabb_untransformed, transform);
+	const float * box = &aabb.min.x;
+	for (int k = 0; k < 6; k++) {
+		// (checked before fix_if_needed, whose widening loop would not terminate on NaN / infinite extents)
+		if (!std::isfinite(box[k])) throw std::runtime_error("mesh '" + name + "' has a non-finite transform or bounds");
+	}
 	aabb.fix_if_needed();
 }
 
@@ -88,6 +94,13 @@ static void load_mesh_file(MeshData & mesh_data, const std::string & filename, c
 	BVH2 cached;
 	bool cache_hit = use_cache && BVHCache::try_to_load(filename, bvh_filename, &mesh_data.triangles, &cached);
 	if (!cache_hit) mesh_data.triangles = loader(filename);
+
+	for (const Triangle & triangle : mesh_data.triangles) { // NaN / infinite vertices would poison every SAH comparison of the builders
+		const Vector3 * p = &triangle.position_0;
+		for (int v = 0; v < 3; v++) {
+			if (!std::isfinite(p[v].x) || !std::isfinite(p[v].y) || !std::isfinite(p[v].z)) throw ParseError("'" + filename + "': mesh has a non-finite vertex position");
+		}
+	}
 
 	bool cache_is_sbvh = BVHCache::underlying_bvh_type() == BVHType::SBVH;
 	if (cache_hit && cache_is_sbvh) mesh_data.sbvh = std::move(cached);
@@ -230,7 +243,9 @@ void AssetManager::wait_until_loaded() {
 				if (i >= pending_textures.size()) break;
 				PendingTexture & job = pending_textures[i];
 				Texture & texture = textures[job.handle];
-				if (!TextureLoader::load(job.filename, &texture)) {
+				bool loaded = false;
+				try { loaded = TextureLoader::load(job.filename, &texture); } catch (const std::exception &) { /* e.g. out of memory on a hostile header: fall back */ }
+				if (!loaded) {
 					fprintf(stderr, "WARNING: Failed to load Texture '%s'!\n", job.filename.c_str());
 					// 1x1 pink fallback (reference: AssetManager.cpp:157-169)
 					texture.width = texture.height = 1;
@@ -269,7 +284,7 @@ void Sky::load(const std::string & filename) {
 	while (fgets(line, sizeof(line), f)) {
 		if (sscanf(line, "-Y %d +X %d", &height, &width) == 2) { have_size = true; break; }
 	}
-	if (!have_size || width <= 0 || height <= 0) { fclose(f); fallback(); return; }
+	if (!have_size || width <= 0 || height <= 0 || width > (1 << 15) || height > (1 << 15)) { fclose(f); fallback(); return; }
 
 	data.resize(size_t(width) * height);
 	std::vector<unsigned char> scan(size_t(width) * 4);

@@ -1123,3 +1123,74 @@ def test_block_compressed_textures_follow_the_reference_pipeline(grt, oracle, tm
     grt.config_reset()
     assert np.isfinite(images[1]).all() and not np.array_equal(images[0], images[1])
     assert abs(images[0].mean() - images[1].mean()) < 0.05 * images[0].mean()
+
+
+def test_hostile_inputs_are_rejected_not_trusted(grt, tmp_path):
+    """Regressions from fuzzing the host loaders under ASAN / UBSAN (mutated PNG / JPEG / BMP / DDS / TGA / PPM /
+    PLY / serialized / hair / OBJ / XML / .bvh / .hdr files): every one of these used to read or write out of
+    bounds, overflow, or allocate without bound."""
+    import struct, zlib
+    grt.config_reset()
+    # non-finite vertices poison every SAH comparison (the split search then found no axis at all)
+    (tmp_path / "nan.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 nan 0\nv 2 2 2\nv 3 2 2\nv 2 3 2\nf 1 2 3\nf 4 5 6\n")
+    with pytest.raises(RuntimeError, match="non-finite"):
+        s = grt.Scene(str(tmp_path / "nan.obj")); s.wait_until_loaded()
+    # an integer with far too many digits
+    (tmp_path / "digits.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 99999999999999999999999\n")
+    s = grt.Scene(str(tmp_path / "digits.obj")); s.wait_until_loaded(); s.close()
+    # error messages may quote bytes that are not UTF-8
+    (tmp_path / "bytes.ply").write_bytes(b"ply\nformat ascii 1.0\nelement \xff\xfe 3\nend_header\n")
+    with pytest.raises(RuntimeError):
+        s = grt.Scene(str(tmp_path / "bytes.ply")); s.wait_until_loaded()
+
+    # .bvh caches: NaN boxes, a child that points back at its parent, counts no file of that size can hold, a bool that is neither 0 nor 1
+    obj = tmp_path / "m.obj"
+    rng = np.random.default_rng(3)
+    p = rng.random((30, 3)) * 4
+    obj.write_text("".join("v %f %f %f\n" % tuple(v) for v in p) + "".join("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3) for i in range(10)))
+    grt.config_set(enable_bvh_cache=1)
+    s = grt.Scene(str(obj)); s.wait_until_loaded()
+    good_nodes = s.mesh_data_array(0, "bvh2_nodes", np.uint8).copy(); good_bvh8 = s.mesh_data_array(0, "bvh8_nodes", np.uint8).copy(); s.close()
+    cache = str(obj) + ".bvh"
+    good = _read_bvh_cache(cache)
+    def attempt(mutator):
+        c = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in good.items()}
+        mutator(c)
+        _write_bvh_cache(cache, c)
+        os.utime(cache, (2e9, 2e9))
+        grt.config_reset(); grt.config_set(enable_bvh_cache=1)
+        s = grt.Scene(str(obj)); s.wait_until_loaded()
+        nodes = s.mesh_data_array(0, "bvh2_nodes", np.uint8).copy(); bvh8 = s.mesh_data_array(0, "bvh8_nodes", np.uint8).copy(); s.close()
+        assert np.array_equal(nodes, good_nodes) and np.array_equal(bvh8, good_bvh8)        # rebuilt from the mesh, not taken from the cache
+    def nan_box(c): c["nodes"].view(np.float32)[8 * 2] = np.nan
+    def cycle(c): c["nodes"].view(np.int32)[8 * 2 + 6] = 0                                     # node 2's child index -> the root
+    attempt(nan_box); attempt(cycle)
+    raw = bytearray(open(cache, "rb").read())
+    _write_bvh_cache(cache, good); raw = bytearray(open(cache, "rb").read())
+    for patch in ((16, struct.pack("<i", 0x7fffffff)), (6, bytes([7]))):                       # num_triangles, the bool
+        bad = bytearray(raw); bad[patch[0]:patch[0] + len(patch[1])] = patch[1]
+        open(cache, "wb").write(bytes(bad)); os.utime(cache, (2e9, 2e9))
+        grt.config_reset(); grt.config_set(enable_bvh_cache=1)
+        s = grt.Scene(str(obj)); s.wait_until_loaded()
+        assert np.array_equal(s.mesh_data_array(0, "bvh2_nodes", np.uint8), good_nodes); s.close()
+    grt.config_reset()
+
+    # images that announce absurd sizes, and a JPEG whose coefficients overflow 32-bit IDCT arithmetic
+    png = _png_bytes(rng.integers(0, 256, (4, 4, 3)), 2, 8)
+    huge = bytearray(png); huge[16:24] = struct.pack(">II", 30000, 30000)
+    huge[29:33] = struct.pack(">I", zlib.crc32(bytes(huge[12:29])) & 0xffffffff)
+    (tmp_path / "huge.png").write_bytes(bytes(huge))
+    with pytest.raises(RuntimeError, match="cannot decode"):
+        grt.load_texture(tmp_path / "huge.png")
+    jpg = bytearray(open(os.path.join(JPEG_DIR, "base_444_q90.jpg"), "rb").read())
+    dqt = jpg.index(b"\xff\xdb")
+    jpg[dqt + 5:dqt + 5 + 64] = bytes([255]) * 64                                            # enormous quantisation steps
+    (tmp_path / "loud.jpg").write_bytes(bytes(jpg))
+    grt.load_texture(tmp_path / "loud.jpg")                                                   # decodes (to garbage) without overflow
+    (tmp_path / "big.hdr").write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2000000000 +X 2000000000\n" + bytes(64))
+    (tmp_path / "sky.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    lib = grt.host_lib()
+    import ctypes
+    lib.grt_sky_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_void_p, ctypes.c_size_t]
+    w, h = ctypes.c_int(), ctypes.c_int(); out = np.zeros(16, np.float32)
+    assert lib.grt_sky_load(str(tmp_path / "big.hdr").encode(), ctypes.byref(w), ctypes.byref(h), out.ctypes.data, out.size) == 4 and (w.value, h.value) == (1, 1)   # the white fallback
