@@ -4,7 +4,7 @@
 // (Src/Math/Mipmap.cpp:72-152), quantise back to 8 bits by truncation. The reference then
 // BC1-compresses power-of-two textures for the texture unit; CDNA has none, so the RGBA8
 // levels are what the shade kernel filters.
-// Decoders: TGA (types 2/3/10/11, 8/24/32 bpp, either origin) and binary PPM (P6) here, PNG / BMP /
+// Decoders: TGA (every type and depth stb_image reads) and binary PPM (P6) here, PNG / BMP /
 // DXT-compressed DDS in ImageDecoders.cpp, JPEG in JPEGDecoder.cpp; stb_image is not linked (PSD, GIF,
 // PIC and Radiance-HDR textures are not read: such a texture gets the reference's pink 1x1 fallback).
 #include "Scene.h"
@@ -29,56 +29,115 @@ bool read_file(const std::string & filename, std::vector<unsigned char> & bytes)
 	return ok;
 }
 
+// Truevision TGA, with the coverage and the conventions of the reference's stb_image (stb_image.h
+// stbi__tga_load): types 1 / 2 / 3 and their run-length forms 9 / 10 / 11; 8-bit grey, 16-bit grey + alpha,
+// 15 / 16-bit RGB (5 bits per channel, the top bit is not alpha), 24 / 32-bit BGR(A); colour-mapped images with
+// 8- or 16-bit indices into a 15 / 16 / 24 / 32-bit palette (an out-of-range index reads entry 0); bottom-up
+// unless descriptor bit 5 is set. The right-to-left bit (4) is ignored, as stb_image ignores it.
 bool decode_tga(const std::vector<unsigned char> & file, int & width, int & height, std::vector<unsigned char> & rgba) {
 	if (file.size() < 18) return false;
-	int id_length  = file[0];
-	int cmap_type  = file[1];
-	int image_type = file[2];
+	int id_length     = file[0];
+	int indexed       = file[1];
+	int image_type    = file[2];
+	int palette_start = file[3] | (file[4] << 8);
+	int palette_len   = file[5] | (file[6] << 8);
+	int palette_bits  = file[7];
 	width  = file[12] | (file[13] << 8);
 	height = file[14] | (file[15] << 8);
 	int bpp        = file[16];
 	int descriptor = file[17];
-	if (cmap_type != 0 || width <= 0 || height <= 0) return false;
-	bool rle  = image_type == 10 || image_type == 11;
-	bool grey = image_type == 3  || image_type == 11;
-	if (!(image_type == 2 || image_type == 3 || rle)) return false;
-	int bytes_pp = bpp / 8;
-	if (!((grey && bytes_pp == 1) || (!grey && (bytes_pp == 3 || bytes_pp == 4)))) return false;
+	if (width <= 0 || height <= 0 || indexed > 1) return false;
 
-	size_t pixel_count = size_t(width) * height;
-	std::vector<unsigned char> raw(pixel_count * bytes_pp);
+	bool rle = image_type >= 8;
+	if (rle) image_type -= 8;
+	if (image_type < 1 || image_type > 3 || (image_type == 1) != (indexed == 1)) return false;
+	if (indexed && !(bpp == 8 || bpp == 16)) return false;
+
+	// components per decoded pixel: 1 grey, 2 grey + alpha, 3 rgb, 4 rgba; `packed16`: 5-5-5 in two bytes
+	bool packed16 = false;
+	auto components_of = [&packed16](int bits, bool grey) {
+		switch (bits) {
+			case 8:  return 1;
+			case 16: if (grey) return 2; // fall through: 16-bit colour is 5-5-5
+			case 15: packed16 = true; return 3;
+			case 24: return 3;
+			case 32: return 4;
+			default: return 0;
+		}
+	};
+	int comp = indexed ? components_of(palette_bits, false) : components_of(bpp, image_type == 3);
+	if (!comp || (!indexed && image_type == 3 && comp > 2) || (!indexed && image_type == 2 && comp < 3)) return false;
+
 	size_t pos = 18 + size_t(id_length);
-	if (!rle) {
-		if (file.size() < pos + raw.size()) return false;
-		memcpy(raw.data(), file.data() + pos, raw.size());
-	} else {
-		size_t out = 0;
-		while (out < pixel_count) {
-			if (pos >= file.size()) return false;
-			int header = file[pos++];
-			int count = (header & 0x7f) + 1;
-			if (header & 0x80) {
-				if (pos + bytes_pp > file.size()) return false;
-				for (int i = 0; i < count && out < pixel_count; i++, out++) memcpy(&raw[out * bytes_pp], &file[pos], bytes_pp);
-				pos += bytes_pp;
-			} else {
-				if (pos + size_t(count) * bytes_pp > file.size()) return false;
-				for (int i = 0; i < count && out < pixel_count; i++, out++, pos += bytes_pp) memcpy(&raw[out * bytes_pp], &file[pos], bytes_pp);
-			}
+	auto read_pixel = [&](unsigned char out[4]) { // one palette entry or one direct pixel, in file order
+		if (packed16) {
+			if (pos + 2 > file.size()) return false;
+			unsigned px = file[pos] | (file[pos + 1] << 8); pos += 2;
+			out[0] = (unsigned char)((((px >> 10) & 31) * 255) / 31); // already r, g, b
+			out[1] = (unsigned char)((((px >> 5) & 31) * 255) / 31);
+			out[2] = (unsigned char)(((px & 31) * 255) / 31);
+			return true;
+		}
+		if (pos + size_t(comp) > file.size()) return false;
+		for (int j = 0; j < comp; j++) out[j] = file[pos++];
+		return true;
+	};
+
+	std::vector<unsigned char> palette;
+	if (indexed) {
+		pos += size_t(palette_start);
+		palette.resize(size_t(palette_len) * comp);
+		for (int i = 0; i < palette_len; i++) {
+			unsigned char entry[4];
+			if (!read_pixel(entry)) return false;
+			memcpy(&palette[size_t(i) * comp], entry, size_t(comp));
 		}
 	}
 
-	bool top_down   = (descriptor & 0x20) != 0;
-	bool right_left = (descriptor & 0x10) != 0;
+	size_t pixel_count = size_t(width) * height;
+	std::vector<unsigned char> raw(pixel_count * comp);
+	unsigned char current[4] = { 0, 0, 0, 0 };
+	int  run = 0;
+	bool repeating = false;
+	for (size_t i = 0; i < pixel_count; i++) {
+		bool read_next = true;
+		if (rle) {
+			if (run == 0) {
+				if (pos >= file.size()) return false;
+				int command = file[pos++];
+				run = 1 + (command & 127);
+				repeating = (command >> 7) != 0;
+			} else if (repeating) {
+				read_next = false;
+			}
+		}
+		if (read_next) {
+			if (indexed) {
+				size_t index_bytes = bpp == 8 ? 1 : 2;
+				if (pos + index_bytes > file.size()) return false;
+				int index = bpp == 8 ? file[pos] : (file[pos] | (file[pos + 1] << 8));
+				pos += index_bytes;
+				if (index >= palette_len) index = 0;
+				if (palette_len == 0) return false;
+				memcpy(current, &palette[size_t(index) * comp], size_t(comp));
+			} else if (!read_pixel(current)) {
+				return false;
+			}
+		}
+		memcpy(&raw[i * comp], current, size_t(comp));
+		run--;
+	}
+
+	bool top_down = (descriptor & 0x20) != 0;
+	bool bgr = comp >= 3 && !packed16; // 24 / 32-bit data and palettes are stored blue first
 	rgba.resize(pixel_count * 4);
 	for (int y = 0; y < height; y++) {
 		int src_y = top_down ? y : height - 1 - y; // row 0 of the output is the top of the image
 		for (int x = 0; x < width; x++) {
-			int src_x = right_left ? width - 1 - x : x;
-			const unsigned char * s = &raw[(size_t(src_y) * width + src_x) * bytes_pp];
+			const unsigned char * s = &raw[(size_t(src_y) * width + x) * comp];
 			unsigned char * d = &rgba[(size_t(y) * width + x) * 4];
-			if (grey) { d[0] = d[1] = d[2] = s[0]; d[3] = 255; }
-			else      { d[0] = s[2]; d[1] = s[1]; d[2] = s[0]; d[3] = bytes_pp == 4 ? s[3] : 255; } // BGR(A) on disk
+			if (comp <= 2) { d[0] = d[1] = d[2] = s[0]; d[3] = comp == 2 ? s[1] : 255; }
+			else { d[0] = bgr ? s[2] : s[0]; d[1] = s[1]; d[2] = bgr ? s[0] : s[2]; d[3] = comp == 4 ? s[3] : 255; }
 		}
 	}
 	return true;

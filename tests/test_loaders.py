@@ -1194,3 +1194,71 @@ def test_hostile_inputs_are_rejected_not_trusted(grt, tmp_path):
     lib.grt_sky_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_void_p, ctypes.c_size_t]
     w, h = ctypes.c_int(), ctypes.c_int(); out = np.zeros(16, np.float32)
     assert lib.grt_sky_load(str(tmp_path / "big.hdr").encode(), ctypes.byref(w), ctypes.byref(h), out.ctypes.data, out.size) == 4 and (w.value, h.value) == (1, 1)   # the white fallback
+
+
+def test_tga_variants_equal_stb_image(grt, oracle, tmp_path):
+    """Every TGA flavour stb_image reads: colour-mapped (8 / 16-bit indices; 15 / 16 / 24 / 32-bit palettes), 15 / 16 /
+    24 / 32-bit true colour, 8-bit grey and 16-bit grey + alpha, raw and run-length encoded, both row orders, with an
+    image ID and a palette offset. Compared with the reference's stb_image where oracle/_ref exists."""
+    import struct
+    rng = np.random.default_rng(37)
+    w, h = 7, 5
+
+    def tga(image_type, bpp, pixels, palette=b"", palette_len=0, palette_bits=0, palette_start=0, descriptor=0, ident=b""):
+        header = struct.pack("<BBBHHBHHHHBB", len(ident), 1 if palette_len else 0, image_type, palette_start, palette_len, palette_bits, 0, 0, w, h, bpp, descriptor)
+        return header + ident + palette + pixels
+
+    def rle(pixels, size):
+        out, i, n = b"", 0, len(pixels) // size
+        while i < n:
+            px = pixels[i * size:(i + 1) * size]
+            run = 1
+            while i + run < n and run < 128 and pixels[(i + run) * size:(i + run + 1) * size] == px: run += 1
+            if run > 1:
+                out += bytes([0x80 | (run - 1)]) + px; i += run
+            else:
+                lit = 1
+                while i + lit < n and lit < 128 and pixels[(i + lit) * size:(i + lit + 1) * size] != pixels[(i + lit - 1) * size:(i + lit) * size]: lit += 1
+                out += bytes([lit - 1]) + pixels[i * size:(i + lit) * size]; i += lit
+        return out
+
+    files = {}
+    for bpp in (15, 16, 24, 32):
+        size = (bpp + 7) // 8
+        px = bytes(rng.integers(0, 256, w * h * size).astype(np.uint8))
+        px = px[:8 * size] + px[:size] * 6 + px[14 * size:]                     # a run for the RLE form
+        files["true%d.tga" % bpp] = tga(2, bpp, px)
+        files["true%d_top.tga" % bpp] = tga(2, bpp, px, descriptor=0x20 | (8 if bpp == 32 else 0), ident=b"id!")
+        files["true%d_rle.tga" % bpp] = tga(10, bpp, rle(px, size))
+        files["true%d_rtl.tga" % bpp] = tga(2, bpp, px, descriptor=0x10)        # right-to-left flag: ignored like stb_image does
+    grey = bytes(rng.integers(0, 256, w * h).astype(np.uint8))
+    files["grey8.tga"] = tga(3, 8, grey); files["grey8_rle.tga"] = tga(11, 8, rle(grey[:10] + grey[:1] * 9 + grey[19:], 1))
+    ga = bytes(rng.integers(0, 256, w * h * 2).astype(np.uint8))
+    files["grey16.tga"] = tga(3, 16, ga)
+    for pbits in (15, 16, 24, 32):
+        psize = (pbits + 7) // 8
+        pal = bytes(rng.integers(0, 256, 20 * psize).astype(np.uint8))
+        idx8 = bytes(rng.integers(0, 24, w * h).astype(np.uint8))                # some indices beyond the palette: entry 0
+        files["map%d.tga" % pbits] = tga(1, 8, idx8, palette=pal, palette_len=20, palette_bits=pbits)
+        files["map%d_rle.tga" % pbits] = tga(9, 8, rle(idx8[:5] + idx8[:1] * 12 + idx8[17:], 1), palette=pal, palette_len=20, palette_bits=pbits)
+        idx16 = rng.integers(0, 20, w * h).astype("<u2").tobytes()
+        files["map%d_wide.tga" % pbits] = tga(1, 16, idx16, palette=b"\x00\x00" + pal, palette_len=20, palette_bits=pbits, palette_start=2)
+    grt.config_reset(); grt.config_set(enable_mipmapping=0)
+    have_ref = oracle.ref_lib() is not None and hasattr(oracle.ref_lib(), "ref_stbi_load_rgba")
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+        got = grt.load_texture(tmp_path / name)[0]
+        assert got.shape == (h, w, 4), name
+        if have_ref:
+            ref = oracle.ref_stbi_load(tmp_path / name)
+            assert ref is not None, name
+            assert np.array_equal(got, _srgb_to_linear_u8(ref)), name
+    # spot checks that do not need the reference: 5-5-5 scaling and the bottom-up default
+    px = struct.pack("<H", (31 << 10) | (16 << 5) | 1) * (w * h)
+    (tmp_path / "c.tga").write_bytes(tga(2, 16, px))
+    assert np.array_equal(grt.load_texture(tmp_path / "c.tga")[0][0, 0], _srgb_to_linear_u8(np.array([[[255, (16 * 255) // 31, (1 * 255) // 31, 255]]], np.uint8))[0, 0])
+    rows = bytes([10] * w + [200] * w * (h - 1))
+    (tmp_path / "r.tga").write_bytes(tga(3, 8, rows))
+    lv = grt.load_texture(tmp_path / "r.tga")[0]
+    assert lv[h - 1, 0, 0] == _srgb_to_linear_u8(np.array([[[10, 10, 10, 255]]], np.uint8))[0, 0, 0] and lv[0, 0, 0] > lv[h - 1, 0, 0]
+    grt.config_reset()
