@@ -143,30 +143,34 @@ bool decode_tga(const std::vector<unsigned char> & file, int & width, int & heig
 	return true;
 }
 
+// Binary PNM: P6 (RGB) and P5 (grey), 8 bits per sample, '#' comments in the header (what stb_image reads)
 bool decode_ppm(const std::vector<unsigned char> & file, int & width, int & height, std::vector<unsigned char> & rgba) {
-	if (file.size() < 2 || file[0] != 'P' || file[1] != '6') return false;
+	if (file.size() < 2 || file[0] != 'P' || (file[1] != '6' && file[1] != '5')) return false;
+	int channels = file[1] == '6' ? 3 : 1;
 	size_t pos = 2;
 	auto next_int = [&](int & out) {
 		while (pos < file.size()) {
-			if (file[pos] == '#') { while (pos < file.size() && file[pos] != '\n') pos++; }
-			else if (file[pos] == ' ' || file[pos] == '\n' || file[pos] == '\r' || file[pos] == '\t') pos++;
+			if (file[pos] == '#') { while (pos < file.size() && file[pos] != '\n' && file[pos] != '\r') pos++; }
+			else if (file[pos] == ' ' || file[pos] == '\n' || file[pos] == '\r' || file[pos] == '\t' || file[pos] == '\f' || file[pos] == '\v') pos++;
 			else break;
 		}
 		if (pos >= file.size() || !is_digit(char(file[pos]))) return false;
 		out = 0;
-		while (pos < file.size() && is_digit(char(file[pos]))) out = out * 10 + (file[pos++] - '0');
+		while (pos < file.size() && is_digit(char(file[pos])) && out < (1 << 24)) out = out * 10 + (file[pos++] - '0');
 		return true;
 	};
 	int maxval = 0;
-	if (!next_int(width) || !next_int(height) || !next_int(maxval) || maxval != 255) return false;
+	if (!next_int(width) || !next_int(height) || !next_int(maxval) || maxval > 255 || maxval <= 0) return false;
+	if (width <= 0 || height <= 0 || width > (1 << 15) || height > (1 << 15)) return false;
 	pos++; // single whitespace after maxval
 	size_t pixel_count = size_t(width) * height;
-	if (file.size() < pos + pixel_count * 3) return false;
+	if (file.size() < pos + pixel_count * channels) return false;
 	rgba.resize(pixel_count * 4);
 	for (size_t i = 0; i < pixel_count; i++) {
-		rgba[4 * i + 0] = file[pos + 3 * i + 0];
-		rgba[4 * i + 1] = file[pos + 3 * i + 1];
-		rgba[4 * i + 2] = file[pos + 3 * i + 2];
+		const unsigned char * s = &file[pos + i * channels];
+		rgba[4 * i + 0] = s[0];
+		rgba[4 * i + 1] = s[channels == 3 ? 1 : 0];
+		rgba[4 * i + 2] = s[channels == 3 ? 2 : 0];
 		rgba[4 * i + 3] = 255;
 	}
 	return true;

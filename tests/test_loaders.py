@@ -1262,3 +1262,23 @@ def test_tga_variants_equal_stb_image(grt, oracle, tmp_path):
     lv = grt.load_texture(tmp_path / "r.tga")[0]
     assert lv[h - 1, 0, 0] == _srgb_to_linear_u8(np.array([[[10, 10, 10, 255]]], np.uint8))[0, 0, 0] and lv[0, 0, 0] > lv[h - 1, 0, 0]
     grt.config_reset()
+
+
+def test_pnm_files_equal_stb_image(grt, oracle, tmp_path):
+    rng = np.random.default_rng(41)
+    files = {"a.ppm": b"P6\n# a comment\n5 3\n255\n" + bytes(rng.integers(0, 256, 45).astype(np.uint8)),
+             "b.pgm": b"P5 4 6 255\n" + bytes(rng.integers(0, 256, 24).astype(np.uint8)),
+             "c.ppm": b"P6\r\n2 2\r\n200\r" + bytes(rng.integers(0, 200, 12).astype(np.uint8))}
+    grt.config_reset(); grt.config_set(enable_mipmapping=0)
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+        got = grt.load_texture(tmp_path / name)[0]
+        if oracle.ref_lib() is not None and hasattr(oracle.ref_lib(), "ref_stbi_load_rgba"):
+            ref = oracle.ref_stbi_load(tmp_path / name)
+            assert ref is not None and np.array_equal(got, _srgb_to_linear_u8(ref)), name
+    assert np.array_equal(grt.load_texture(tmp_path / "b.pgm")[0][:, :, 0], grt.load_texture(tmp_path / "b.pgm")[0][:, :, 2])
+    for bad in (b"P6\n5 3\n65535\n" + bytes(90), b"P6\n5 3\n255\n" + bytes(10), b"P4\n8 1\n\xff"):
+        (tmp_path / "bad.ppm").write_bytes(bad)
+        with pytest.raises(RuntimeError):
+            grt.load_texture(tmp_path / "bad.ppm")
+    grt.config_reset()
