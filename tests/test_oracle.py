@@ -327,3 +327,43 @@ def test_spatial_split_and_collapsed_trees_trace_like_the_cwbvh(grt, oracle, tmp
         same_triangle = (got["p0"] == want["p0"]).all(axis=1)
         assert same_triangle.mean() > 0.995, bvh_type          # equal-t ties between overlapping slivers may resolve differently
     grt.config_reset()
+
+
+def _rectangle_form_factor(x0, x1, z0, z1, h):
+    """Form factor from a horizontal rectangle [x0, x1] x [z0, z1] at height h to the point below the origin
+    (parallel differential element): inclusion-exclusion over the closed form for a corner rectangle."""
+    def corner(x, z):
+        a, b = np.sqrt(h * h + x * x), np.sqrt(h * h + z * z)
+        return (x / a * np.arctan(z / a) + z / b * np.arctan(x / b)) / (2.0 * np.pi)
+    return corner(x1, z1) - corner(x0, z1) - corner(x1, z0) + corner(x0, z0)
+
+
+@pytest.mark.parametrize("toggles", [{}, {"enable_multiple_importance_sampling": 0}, {"enable_next_event_estimation": 0}],
+                         ids=["nee+mis", "nee", "bsdf-sampling"])
+def test_two_lights_of_different_power_size_and_instance_scale(grt, oracle, tmp_path, toggles):
+    """Pins the two-level light CDF and its pdf (Pathtracer.cpp:384-534 on the host, Pathtracer.cu:465-555 on the
+    device): mesh weight = luminance x area x scale^2, triangle picked by area, pdf = power d^2 / (cos total).
+    A unit-radiance 1x1 shape at height 1 and a three-times brighter file-loaded quad that is placed off-centre
+    through an instance transform with scale 0.5 must add up to L1 F1 + L2 F2 at the floor point under the
+    origin for every estimator; a weight that ignored the instance scale or the emission would bias NEE."""
+    (tmp_path / "quad.obj").write_text("v -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nf 1 2 3\nf 1 3 4\n")
+    (tmp_path / "s.xml").write_text(
+        '<scene version="0.5.0"><integrator type="path"><integer name="maxDepth" value="2"/></integrator>'
+        '<sensor type="perspective"><float name="fov" value="2"/><transform name="toWorld"><lookat origin="0.001, 0.5, 0" target="0, 0, 0" up="0, 0, 1"/></transform></sensor>'
+        '<shape type="rectangle"><transform name="toWorld"><rotate x="1" angle="-90"/><scale value="20"/></transform><bsdf type="diffuse"><rgb name="reflectance" value="1, 1, 1"/></bsdf></shape>'
+        '<shape type="rectangle"><transform name="toWorld"><rotate x="1" angle="90"/><scale value="0.5"/><translate y="1"/></transform><emitter type="area"><rgb name="radiance" value="1, 1, 1"/></emitter></shape>'
+        '<shape type="obj"><string name="filename" value="quad.obj"/><transform name="toWorld"><scale value="0.5"/><translate x="1.5" y="0.8" z="0.25"/></transform>'
+        '<emitter type="area"><rgb name="radiance" value="3, 3, 3"/></emitter></shape></scene>')
+    analytic = 1.0 * _rectangle_form_factor(-0.5, 0.5, -0.5, 0.5, 1.0) + 3.0 * _rectangle_form_factor(1.0, 2.0, -0.25, 0.75, 0.8)
+    grt.config_reset()
+    scene = grt.Scene(str(tmp_path / "s.xml"))
+    scene.set_sky_scale(0.0)
+    grt.config_set(num_bounces=2, enable_russian_roulette=0, **toggles)
+    pt = grt.Pathtracer(scene, 12, 12, device=-1); pt.update()
+    assert abs(scene.mesh_transform(2)[2] - 0.5) < 1e-6                        # the quad is an instance with scale 0.5, not baked
+    frame = oracle.Frame(oracle.SceneView(pt))
+    for s in range(769):
+        frame.render_sample(s)
+    mean = float(frame.final[:, :12, :3].mean())
+    assert abs(mean - analytic) < 0.012 * analytic, (mean, analytic)
+    pt.close(); scene.close(); grt.config_reset()
