@@ -367,3 +367,18 @@ def test_two_lights_of_different_power_size_and_instance_scale(grt, oracle, tmp_
     mean = float(frame.final[:, :12, :3].mean())
     assert abs(mean - analytic) < 0.012 * analytic, (mean, analytic)
     pt.close(); scene.close(); grt.config_reset()
+
+
+def test_russian_roulette_does_not_change_the_expectation(grt, oracle):
+    """Russian roulette (Pathtracer.cu:199-218) terminates paths with probability 1 - p and divides the survivors by
+    p: the mean image must not move (8 bounces, so that most paths reach the bounces where it is active)."""
+    means = {}
+    for label, cfg in (("rr", {}), ("no rr", dict(enable_russian_roulette=0))):
+        scene, pt = make_pathtracer(grt, "cornellbox", 20, 20, -1, num_bounces=8, **cfg)
+        frame = oracle.Frame(oracle.SceneView(pt))
+        for s in range(385):
+            frame.render_sample(s)
+        means[label] = float(frame.final[:, :20, :3].mean())
+        pt.close(); scene.close()
+    grt.config_reset()
+    assert abs(means["rr"] - means["no rr"]) < 0.02 * means["no rr"], means
