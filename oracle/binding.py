@@ -167,6 +167,48 @@ def ref_mipmap_downsample(filter_type, src, w_dst, h_dst):
     return dst
 
 
+class ReferenceFrame:
+    """The reference's own device code (Src/CUDA/Pathtracer.cu, compiled verbatim for the host CPU into oracle/_ref,
+    see oracle/ref/ref_cuda_harness.cpp) rendering the scene of a SceneView: same protocol as Frame."""
+
+    def __init__(self, view):
+        r = ref_lib()
+        if r is None or not hasattr(r, "ref_cuda_frame_create"):
+            raise RuntimeError("oracle/_ref was built without the CUDA-on-CPU harness")
+        r.ref_cuda_frame_create.restype = c_void_p
+        r.ref_cuda_frame_create.argtypes = [c_void_p]
+        r.ref_cuda_frame_free.argtypes = [c_void_p]
+        r.ref_cuda_render_sample.argtypes = [c_void_p, c_int, c_void_p]
+        r.ref_cuda_read_frame.argtypes = [c_void_p, c_void_p]
+        r.ref_cuda_read_aov.argtypes = [c_void_p, c_int, c_void_p]
+        self.view = view                       # keeps the staged arrays alive
+        self.handle = r.ref_cuda_frame_create(ctypes.addressof(view.scene))
+        s = view.scene
+        self.shape = (s.screen_height, s.screen_pitch, 4)
+
+    def render_sample(self, sample_index):
+        """One sample of the whole frame; returns {queue: per-bounce sizes} like the device counters."""
+        counters = np.zeros((6, 128), np.int32)
+        ref_lib().ref_cuda_render_sample(self.handle, sample_index, counters.ctypes.data)
+        return dict(zip(("trace", "diffuse", "plastic", "dielectric", "conductor", "shadow"), counters))
+
+    @property
+    def final(self):
+        out = np.zeros(self.shape, np.float32)
+        ref_lib().ref_cuda_read_frame(self.handle, out.ctypes.data)
+        return out
+
+    def accumulator(self, aov):
+        out = np.zeros(self.shape, np.float32)
+        if not ref_lib().ref_cuda_read_aov(self.handle, aov, out.ctypes.data):
+            raise KeyError("AOV %d is not enabled" % aov)
+        return out
+
+    def close(self):
+        if self.handle:
+            ref_lib().ref_cuda_frame_free(self.handle); self.handle = None
+
+
 def ref_geometry_shape(shape, transform16, p0=(0, 0, 0), p1=(0, 0, 1), radius=1.0, detail=-1):
     """Triangles (n, 24) of a primitive shape by the reference's own Geometry.cpp."""
     r = ref_lib()

@@ -382,3 +382,33 @@ def test_russian_roulette_does_not_change_the_expectation(grt, oracle):
         pt.close(); scene.close()
     grt.config_reset()
     assert abs(means["rr"] - means["no rr"]) < 0.02 * means["no rr"], means
+
+
+def _reference_frame(oracle, view):
+    if oracle.ref_lib() is None or not hasattr(oracle.ref_lib(), "ref_cuda_frame_create"):
+        pytest.skip("oracle/_ref not built with the reference's device code (no /root/reference on this machine)")
+    return oracle.ReferenceFrame(view)
+
+
+def test_oracle_equals_the_references_own_kernels_run_on_the_cpu(grt, oracle):
+    """THE pin of the restated device path: the reference's Pathtracer.cu (every kernel and header, compiled
+    verbatim for the host through oracle/ref/cuda_shim and executed one CUDA thread at a time by
+    oracle/ref/ref_cuda_harness.cpp) renders the Cornell box from the same staged arrays as the oracle.
+    Queue sizes per bounce must be identical and the frames agree to float noise: the two differ only in where
+    the compilers fuse multiply-adds."""
+    for config in (dict(num_bounces=5), dict(num_bounces=3, enable_next_event_estimation=0), dict(num_bounces=3, enable_multiple_importance_sampling=0),
+                   dict(num_bounces=6, enable_russian_roulette=0, reconstruction_filter=0), dict(num_bounces=4, reconstruction_filter=1)):
+        scene, pt = make_pathtracer(grt, "cornellbox", 64, 48, -1, **config)
+        view = oracle.SceneView(pt)
+        ours, theirs = oracle.Frame(view), _reference_frame(oracle, view)
+        nb = config["num_bounces"]
+        for s in range(3):
+            oc, rc = ours.render_sample(s), theirs.render_sample(s)
+            for queue in ("trace", "shadow", "diffuse"):
+                got, want = list(getattr(oc, queue)[:nb]), [int(v) for v in rc[queue][:nb]]
+                assert all(abs(a - b) <= 1 + 0.002 * b for a, b in zip(got, want)), (config, s, queue, got, want)
+            a, b = ours.final[:, :64, :3], theirs.final[:, :64, :3]
+            assert np.abs(a - b).sum() / b.sum() < 2e-5, (config, s)
+            assert (np.abs(a - b).max(axis=2) > 0.01 * (b.max(axis=2) + 1e-3)).mean() < 2e-3, (config, s)
+        theirs.close(); pt.close(); scene.close()
+    grt.config_reset()
