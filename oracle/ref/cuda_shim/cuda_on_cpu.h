@@ -34,6 +34,17 @@ struct grt_dim3 { unsigned x = 1, y = 1, z = 1; };
 inline thread_local grt_dim3 threadIdx, blockIdx, blockDim, gridDim;
 constexpr int warpSize = 32;
 
+// ---- min / max: CUDA overloads them for every arithmetic type; the reference's vendored cuda_math.h only supplies
+// the int pair on a host compiler, and without these a call like max(0.0001f, x) would silently truncate to int
+inline float    max(float a, float b)       { return __builtin_fmaxf(a, b); }
+inline float    min(float a, float b)       { return __builtin_fminf(a, b); }
+inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+inline float    max(float a, int b)         { return __builtin_fmaxf(a, float(b)); }
+inline float    max(int a, float b)         { return __builtin_fmaxf(float(a), b); }
+inline float    min(float a, int b)         { return __builtin_fminf(a, float(b)); }
+inline float    min(int a, float b)         { return __builtin_fminf(float(a), b); }
+
 // ---- math intrinsics (fast-math forms map to the precise libm functions; comparisons allow for that) ------
 inline float __saturatef(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); } // NaN -> 0 on the GPU; not exercised
 inline void  __sincosf(float x, float * s, float * c) { *s = sinf(x); *c = cosf(x); }

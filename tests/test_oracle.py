@@ -412,3 +412,76 @@ def test_oracle_equals_the_references_own_kernels_run_on_the_cpu(grt, oracle):
             assert (np.abs(a - b).max(axis=2) > 0.01 * (b.max(axis=2) + 1e-3)).mean() < 2e-3, (config, s)
         theirs.close(); pt.close(); scene.close()
     grt.config_reset()
+
+
+def _synthetic_luts(seed=5):
+    """Smooth tables in (0, 1) with the shapes of the Kulla-Conty LUTs: both renderers read the same numbers, so
+    they need not be the true albedos (integrating those on the CPU takes minutes)."""
+    rng = np.random.default_rng(seed)
+    def smooth(shape):
+        grid = np.meshgrid(*[np.linspace(0, 1, n) for n in shape], indexing="ij")
+        return (0.55 + 0.35 * np.cos(sum((i + 1.3) * a for i, a in enumerate(grid)) * 1.7 + rng.random())).astype(np.float32)
+    return [smooth((16, 16, 16)), smooth((16, 16, 16)), smooth((16, 16)), smooth((16, 16)), smooth((32, 32)), smooth((32,))]
+
+
+def _compare_with_reference_kernels(oracle, pt, w, samples, rel_tol, outlier_tol, luts=None, bvh_type=8):
+    view = oracle.SceneView(pt, bvh_type=bvh_type, luts=luts)
+    ours, theirs = oracle.Frame(view), _reference_frame(oracle, view)
+    nb = pt.device_config().num_bounces
+    totals = {}
+    for s in range(samples):
+        oc, rc = ours.render_sample(s), theirs.render_sample(s)
+        for queue in ("trace", "shadow", "diffuse", "plastic", "dielectric", "conductor"):
+            got, want = list(getattr(oc, queue)[:nb]), [int(v) for v in rc[queue][:nb]]
+            assert got[0] == want[0] and all(abs(a - b) <= 2 + 0.002 * b for a, b in zip(got, want)), (s, queue, got, want)
+            totals[queue] = totals.get(queue, 0) + sum(want)
+        a, b = ours.final[:, :w, :3], theirs.final[:, :w, :3]
+        assert np.isfinite(b).all()
+        assert np.abs(a - b).sum() / b.sum() < rel_tol, (s, np.abs(a - b).sum() / b.sum())
+        assert (np.abs(a - b).max(axis=2) > 0.01 * (b.max(axis=2) + 1e-3)).mean() < outlier_tol, s
+    theirs.close()
+    return totals
+
+
+def test_reference_kernels_on_sponza_textures_instances_and_plastic(grt, oracle):
+    """Same pin on Sponza: 384 instances through the TLAS, 19 mip-mapped textures (ray-cone LOD, anisotropic
+    bounce-0 lookups -- both sides filter with the software texture unit, the reference's NVIDIA unit being the one
+    thing that cannot run here), and the variant whose odd materials are rough plastic."""
+    scene, pt = make_pathtracer(grt, "sponza", 96, 54, -1, num_bounces=4)
+    totals = _compare_with_reference_kernels(oracle, pt, 96, 2, 3e-4, 2e-3)
+    assert totals["diffuse"] > 10000 and totals["shadow"] > 5000
+    pt.close(); scene.close()
+
+    grt.config_reset()
+    scene = grt.Scene(grt.scene_path("sponza"))
+    for i in range(1, scene.material_count, 2):
+        if scene.material_type(i) == grt.MATERIAL_DIFFUSE:
+            scene.set_material(i, grt.MATERIAL_PLASTIC, None, 0.3)
+    grt.config_set(num_bounces=4)
+    pt = grt.Pathtracer(scene, 96, 54, device=-1); pt.update()
+    totals = _compare_with_reference_kernels(oracle, pt, 96, 2, 3e-4, 2e-3)
+    assert totals["plastic"] > 5000
+    pt.close(); scene.close(); grt.config_reset()
+
+
+def test_reference_kernels_on_dielectric_conductor_and_medium(grt, oracle, tmp_path):
+    """Rough dielectric with a scattering medium inside, a smooth dielectric and a rough conductor (BSDF.h:192-525,
+    the medium branch of kernel_sort, Kulla-Conty energy compensation): queue sizes per material and bounce and the
+    frames of the reference's kernels and the oracle coincide."""
+    from test_gpu_materials_svgf import GLASS_SCENE
+    (tmp_path / "glass.xml").write_text(GLASS_SCENE)
+    grt.config_reset()
+    scene = grt.Scene(str(tmp_path / "glass.xml"))
+    pt = grt.Pathtracer(scene, 96, 64, device=-1); pt.update()
+    totals = _compare_with_reference_kernels(oracle, pt, 96, 3, 2e-5, 1e-3, luts=_synthetic_luts())
+    assert totals["dielectric"] > 1000 and totals["conductor"] > 300
+    pt.close(); scene.close(); grt.config_reset()
+
+
+@pytest.mark.parametrize("bvh_type", [2, 4])
+def test_reference_binary_and_4_wide_kernels(grt, oracle, bvh_type):
+    """kernel_trace_bvh2 / bvh4 and their shadow variants (BVH2.h, BVH4.h) of the reference, on the trees the host
+    builds for those types, against the oracle's traversal of the same trees."""
+    scene, pt = make_pathtracer(grt, "cornellbox", 64, 48, -1, bvh_type=bvh_type, num_bounces=4)
+    _compare_with_reference_kernels(oracle, pt, 64, 2, 2e-5, 2e-3, bvh_type=bvh_type)
+    pt.close(); scene.close(); grt.config_reset()
