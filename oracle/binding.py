@@ -198,6 +198,12 @@ class ReferenceFrame:
         ref_lib().ref_cuda_read_frame(self.handle, out.ctypes.data)
         return out
 
+    def history_length(self):
+        out = np.zeros(self.shape[:2], np.int32)
+        ref_lib().ref_cuda_read_history_length.argtypes = [c_void_p, c_void_p]
+        ref_lib().ref_cuda_read_history_length(self.handle, out.ctypes.data)
+        return out
+
     def accumulator(self, aov):
         out = np.zeros(self.shape, np.float32)
         if not ref_lib().ref_cuda_read_aov(self.handle, aov, out.ctypes.data):

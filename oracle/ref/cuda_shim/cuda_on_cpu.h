@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cassert>
 #include <atomic>
+#include <math.h>
+using std::isfinite; using std::isnan; using std::isinf;   // CUDA has them in the global namespace
 
 #include "crt/host_defines.h"
 #include "cudart/vector_types.h"   // the reference's vendored copies (Src/CUDA/cudart)
@@ -36,6 +38,11 @@ constexpr int warpSize = 32;
 
 // ---- min / max: CUDA overloads them for every arithmetic type; the reference's vendored cuda_math.h only supplies
 // the int pair on a host compiler, and without these a call like max(0.0001f, x) would silently truncate to int
+// (cuda_math.h is included with __CUDACC__ defined, so that its host fallbacks -- whose fminf / fmaxf return NaN
+// where CUDA's return the other operand -- stay out; libm's fminf / fmaxf have CUDA's semantics)
+inline int      max(int a, int b)           { return a > b ? a : b; }
+inline int      min(int a, int b)           { return a < b ? a : b; }
+inline float    rsqrtf(float x)             { return 1.0f / sqrtf(x); }
 inline float    max(float a, float b)       { return __builtin_fmaxf(a, b); }
 inline float    min(float a, float b)       { return __builtin_fminf(a, b); }
 inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }

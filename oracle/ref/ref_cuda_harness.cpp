@@ -24,7 +24,9 @@
 #define vmin_max         vmin_max_ptx
 #define vmax_min         vmax_min_ptx
 #define vmax_max         vmax_max_ptx
+#define __CUDACC__ 1   // keeps cuda_math.h's host fallbacks of fminf / fmaxf / min / max / rsqrtf out: see cuda_on_cpu.h
 #include "cudart/cuda_math.h"
+#undef __CUDACC__
 #include "Util.h"
 #undef sign_extend_s8x4
 #undef msb
@@ -91,7 +93,12 @@ extern "C" void grt_tex_fetch_3d(cudaTextureObject_t t, float s, float u, float 
 extern "C" void grt_tex_fetch_lod(cudaTextureObject_t t, float s, float u, float lod, float out[4]) { oracle_tex2d_lod(texture_of(t).material, s, u, lod, out); }
 extern "C" void grt_tex_fetch_grad(cudaTextureObject_t t, float s, float u, const float dx[2], const float dy[2], float out[4]) { oracle_tex2d_grad(texture_of(t).material, s, u, dx, dy, out); }
 extern "C" void grt_surf_read(cudaSurfaceObject_t s, int x_bytes, int y, int, void * dst, int bytes) {
+	// every read in the reference uses cudaBoundaryModeClamp: coordinates outside the surface read its border texel
 	const SurfaceObject & o = *reinterpret_cast<const SurfaceObject *>(s);
+	if (x_bytes < 0) x_bytes = 0;
+	if (x_bytes > o.pitch_bytes - bytes) x_bytes = o.pitch_bytes - bytes;
+	if (y < 0) y = 0;
+	if (y > o.height - 1) y = o.height - 1;
 	memcpy(dst, o.data + size_t(y) * o.pitch_bytes + x_bytes, size_t(bytes));
 }
 extern "C" void grt_surf_write(cudaSurfaceObject_t s, int x_bytes, int y, int, const void * src, int bytes) {
@@ -115,6 +122,7 @@ struct Frame {
 	TextureObject sky_object, lut_objects[6];
 	SurfaceObject accumulator_surface;
 	std::vector<float4> accumulator_image;
+	SurfaceObject gbuffer_surfaces[3];
 	std::vector<MaterialBuffer> material_buffers;
 	int batch_capacity = 0;
 	bool has_diffuse = false, has_plastic = false, has_dielectric = false, has_conductor = false, has_lights = false;
@@ -259,12 +267,33 @@ void * ref_cuda_frame_create(const oracle_scene * s) {
 	// AOVs (Integrator.cpp: init_aovs / aov_enable) and the display accumulator
 	for (int a = 0; a < int(AOVType::COUNT); a++) {
 		bool enabled = a == int(AOVType::RADIANCE) || (s->config.aov_mask & (1u << a));
+		if (s->config.enable_svgf && (a == int(AOVType::RADIANCE_DIRECT) || a == int(AOVType::RADIANCE_INDIRECT) || a == int(AOVType::ALBEDO))) enabled = true; // svgf_init
 		aovs[a].framebuffer = enabled ? alloc<float4>(f->pool, pixels) : nullptr;
 		aovs[a].accumulator = enabled ? alloc<float4>(f->pool, pixels) : nullptr;
 	}
 	f->accumulator_image.assign(pixels, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
 	f->accumulator_surface = { reinterpret_cast<unsigned char *>(f->accumulator_image.data()), int(s->screen_pitch * sizeof(float4)), s->screen_height };
 	accumulator.surface = reinterpret_cast<cudaSurfaceObject_t>(&f->accumulator_surface);
+
+	if (s->config.enable_svgf) { // Pathtracer::svgf_init (Pathtracer.cpp:316-357)
+		unsigned char * normal_and_depth = alloc<unsigned char>(f->pool, pixels * sizeof(float4));
+		unsigned char * ids              = alloc<unsigned char>(f->pool, pixels * sizeof(int2));
+		unsigned char * position_prev    = alloc<unsigned char>(f->pool, pixels * sizeof(float2));
+		f->gbuffer_surfaces[0] = { normal_and_depth, int(s->screen_pitch * sizeof(float4)), s->screen_height };
+		f->gbuffer_surfaces[1] = { ids,              int(s->screen_pitch * sizeof(int2)),   s->screen_height };
+		f->gbuffer_surfaces[2] = { position_prev,    int(s->screen_pitch * sizeof(float2)), s->screen_height };
+		gbuffer_normal_and_depth       .surface = reinterpret_cast<cudaSurfaceObject_t>(&f->gbuffer_surfaces[0]);
+		gbuffer_mesh_id_and_triangle_id.surface = reinterpret_cast<cudaSurfaceObject_t>(&f->gbuffer_surfaces[1]);
+		gbuffer_screen_position_prev   .surface = reinterpret_cast<cudaSurfaceObject_t>(&f->gbuffer_surfaces[2]);
+		frame_buffer_moment      = alloc<float4>(f->pool, pixels);
+		history_length           = alloc<int>   (f->pool, pixels);
+		history_direct           = alloc<float4>(f->pool, pixels);
+		history_indirect         = alloc<float4>(f->pool, pixels);
+		history_moment           = alloc<float4>(f->pool, pixels);
+		history_normal_and_depth = alloc<float4>(f->pool, pixels);
+		taa_frame_prev           = alloc<float4>(f->pool, pixels);
+		taa_frame_curr           = alloc<float4>(f->pool, pixels);
+	}
 
 	// wavefront buffers (Pathtracer.cpp:540-660): BATCH_SIZE entries each; two material types share one
 	// allocation, the second filling it from the back (PackedMaterialBuffer's low bit)
@@ -300,6 +329,10 @@ void ref_cuda_render_sample(void * frame, int sample_index, int * counters_out) 
 	int batch_size  = pixel_count < BATCH_SIZE ? pixel_count : BATCH_SIZE;
 	if (counters_out) memset(counters_out, 0, 6 * MAX_BOUNCES * sizeof(int));
 
+	static_assert(sizeof(SVGFData) == 128, "two row-major 4x4 matrices");
+	memcpy(&svgf_data.view_projection,      s->view_projection,      64); // uploaded by Pathtracer::update before the frame (Pathtracer.cpp:707-717)
+	memcpy(&svgf_data.view_projection_prev, s->view_projection_prev, 64);
+
 	int pixels_left = pixel_count;
 	while (pixels_left > 0) {
 		int pixel_offset = pixel_count - pixels_left;
@@ -333,7 +366,29 @@ void ref_cuda_render_sample(void * frame, int sample_index, int * counters_out) 
 		}
 		pixels_left -= batch_size;
 	}
-	launch_2d(s->screen_pitch, s->screen_height, kernel_accumulate, float(sample_index));
+	if (config.enable_svgf) { // Pathtracer.cpp:796-838
+		int w = s->screen_pitch, h = s->screen_height;
+		launch_2d(w, h, kernel_svgf_reproject, sample_index);
+		float4 * direct_in    = aovs[int(AOVType::RADIANCE_DIRECT)]  .framebuffer;
+		float4 * indirect_in  = aovs[int(AOVType::RADIANCE_INDIRECT)].framebuffer;
+		float4 * direct_out   = aovs[int(AOVType::RADIANCE_DIRECT)]  .accumulator;
+		float4 * indirect_out = aovs[int(AOVType::RADIANCE_INDIRECT)].accumulator;
+		if (config.enable_spatial_variance) {
+			launch_2d(w, h, kernel_svgf_variance, (const float4 *)direct_in, (const float4 *)indirect_in, direct_out, indirect_out);
+			std::swap(direct_in, direct_out); std::swap(indirect_in, indirect_out);
+		}
+		for (int i = 0; i < config.num_atrous_iterations; i++) {
+			launch_2d(w, h, kernel_svgf_atrous, (const float4 *)direct_in, (const float4 *)indirect_in, direct_out, indirect_out, 1 << i);
+			std::swap(direct_in, direct_out); std::swap(indirect_in, indirect_out);
+		}
+		launch_2d(w, h, kernel_svgf_finalize, (const float4 *)direct_in, (const float4 *)indirect_in);
+		if (config.enable_taa) {
+			launch_2d(w, h, kernel_taa, sample_index);
+			launch_2d(w, h, kernel_taa_finalize);
+		}
+	} else {
+		launch_2d(s->screen_pitch, s->screen_height, kernel_accumulate, float(sample_index));
+	}
 
 	// aovs_clear_to_zero (Integrator.cpp): the per-frame buffers start the next sample from zero
 	size_t pixels = size_t(s->screen_pitch) * s->screen_height;
@@ -342,6 +397,10 @@ void ref_cuda_render_sample(void * frame, int sample_index, int * counters_out) 
 
 // The displayed frame (the `accumulator` surface) and an AOV's accumulator: pitch * height float4
 void ref_cuda_read_frame(void * frame, float * dst) { Frame * f = static_cast<Frame *>(frame); memcpy(dst, f->accumulator_image.data(), f->accumulator_image.size() * sizeof(float4)); }
+void ref_cuda_read_history_length(void * frame, int * dst) {
+	Frame * f = static_cast<Frame *>(frame);
+	if (history_length) memcpy(dst, history_length, size_t(f->scene->screen_pitch) * f->scene->screen_height * sizeof(int));
+}
 int  ref_cuda_read_aov(void * frame, int aov, float * dst) {
 	Frame * f = static_cast<Frame *>(frame);
 	if (aov < 0 || aov >= int(AOVType::COUNT) || !aovs[aov].accumulator) return 0;

@@ -485,3 +485,29 @@ def test_reference_binary_and_4_wide_kernels(grt, oracle, bvh_type):
     scene, pt = make_pathtracer(grt, "cornellbox", 64, 48, -1, bvh_type=bvh_type, num_bounces=4)
     _compare_with_reference_kernels(oracle, pt, 64, 2, 2e-5, 2e-3, bvh_type=bvh_type)
     pt.close(); scene.close(); grt.config_reset()
+
+
+@pytest.mark.parametrize("taa", [1, 0])
+def test_reference_svgf_and_taa_kernels(grt, oracle, taa):
+    """SVGF (reproject, spatial variance, six a-trous iterations, finalize) and TAA of the reference (SVGF.h, TAA.h)
+    over five frames with a static camera, against the oracle's restatement: filtered frames and history lengths."""
+    scene, pt = make_pathtracer(grt, "cornellbox", 64, 48, -1, num_bounces=3, enable_svgf=1, enable_taa=taa)
+    view = oracle.SceneView(pt)
+    ours, theirs = oracle.Frame(view), _reference_frame(oracle, view)
+    for f in range(5):
+        if f:
+            pt.update()
+        vp = pt.view_projection()
+        for i in range(16):
+            view.scene.view_projection[i] = vp[0][i]
+            view.scene.view_projection_prev[i] = vp[1][i]
+        ours.render_sample(pt.sample_index); theirs.render_sample(pt.sample_index)
+        a, b = ours.final[:, :64, :3], theirs.final[:, :64, :3]
+        assert np.isfinite(b).all() and b.mean() > 0.01
+        # The edge-stopping weights are exp(-|dz| / (sigma_z |grad z . dp| + 1e-8)): on the Cornell walls that face the
+        # camera the depth gradient is zero up to rounding, so a last-bit difference in a depth (the two builds fuse
+        # multiply-adds differently) switches single taps on or off. The frames still have to agree to 0.25 % overall.
+        assert np.abs(a - b).sum() / b.sum() < 2.5e-3, (f, np.abs(a - b).sum() / b.sum())
+        assert (np.abs(a - b).max(axis=2) > 0.02 * (b.max(axis=2) + 1e-3)).mean() < 6e-2, f   # six a-trous passes spread each switched tap
+        assert np.array_equal(ours.buffers["hl"].reshape(48, -1)[:, :64], theirs.history_length()[:, :64]), f
+    theirs.close(); pt.close(); scene.close(); grt.config_reset()
