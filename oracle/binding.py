@@ -210,6 +210,30 @@ class ReferenceFrame:
             raise KeyError("AOV %d is not enabled" % aov)
         return out
 
+    def integrate_dielectric_cells(self, entering, first_cell, cell_count):
+        out = np.zeros(cell_count, np.float32)
+        f = ref_lib().ref_cuda_integrate_dielectric_cells; f.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
+        f(self.handle, 1 if entering else 0, first_cell, cell_count, out.ctypes.data)
+        return out
+
+    def integrate_conductor_cells(self, first_cell, cell_count):
+        out = np.zeros(cell_count, np.float32)
+        f = ref_lib().ref_cuda_integrate_conductor_cells; f.argtypes = [c_void_p, c_int, c_int, c_void_p]
+        f(self.handle, first_cell, cell_count, out.ctypes.data)
+        return out
+
+    @staticmethod
+    def average_dielectric(directional):
+        d = np.ascontiguousarray(directional, np.float32); out = np.zeros(256, np.float32)
+        f = ref_lib().ref_cuda_average_dielectric; f.argtypes = [c_void_p, c_void_p]; f(d.ctypes.data, out.ctypes.data)
+        return out
+
+    @staticmethod
+    def average_conductor(directional):
+        d = np.ascontiguousarray(directional, np.float32); out = np.zeros(32, np.float32)
+        f = ref_lib().ref_cuda_average_conductor; f.argtypes = [c_void_p, c_void_p]; f(d.ctypes.data, out.ctypes.data)
+        return out
+
     def close(self):
         if self.handle:
             ref_lib().ref_cuda_frame_free(self.handle); self.handle = None

@@ -69,7 +69,7 @@ struct TextureObject {
 	const float * data = nullptr;
 	int nx = 0, ny = 0, nz = 0;
 };
-struct SurfaceObject { unsigned char * data; int pitch_bytes, height; };
+struct SurfaceObject { unsigned char * data; int pitch_bytes, height; int depth = 1; };
 
 const TextureObject & texture_of(cudaTextureObject_t t) { return *reinterpret_cast<const TextureObject *>(t); }
 }
@@ -92,18 +92,20 @@ extern "C" void grt_tex_fetch_3d(cudaTextureObject_t t, float s, float u, float 
 }
 extern "C" void grt_tex_fetch_lod(cudaTextureObject_t t, float s, float u, float lod, float out[4]) { oracle_tex2d_lod(texture_of(t).material, s, u, lod, out); }
 extern "C" void grt_tex_fetch_grad(cudaTextureObject_t t, float s, float u, const float dx[2], const float dy[2], float out[4]) { oracle_tex2d_grad(texture_of(t).material, s, u, dx, dy, out); }
-extern "C" void grt_surf_read(cudaSurfaceObject_t s, int x_bytes, int y, int, void * dst, int bytes) {
+extern "C" void grt_surf_read(cudaSurfaceObject_t s, int x_bytes, int y, int z, void * dst, int bytes) {
 	// every read in the reference uses cudaBoundaryModeClamp: coordinates outside the surface read its border texel
 	const SurfaceObject & o = *reinterpret_cast<const SurfaceObject *>(s);
 	if (x_bytes < 0) x_bytes = 0;
 	if (x_bytes > o.pitch_bytes - bytes) x_bytes = o.pitch_bytes - bytes;
 	if (y < 0) y = 0;
 	if (y > o.height - 1) y = o.height - 1;
-	memcpy(dst, o.data + size_t(y) * o.pitch_bytes + x_bytes, size_t(bytes));
+	if (z < 0) z = 0;
+	if (z > o.depth - 1) z = o.depth - 1;
+	memcpy(dst, o.data + (size_t(z) * o.height + size_t(y)) * o.pitch_bytes + x_bytes, size_t(bytes));
 }
-extern "C" void grt_surf_write(cudaSurfaceObject_t s, int x_bytes, int y, int, const void * src, int bytes) {
+extern "C" void grt_surf_write(cudaSurfaceObject_t s, int x_bytes, int y, int z, const void * src, int bytes) {
 	const SurfaceObject & o = *reinterpret_cast<const SurfaceObject *>(s);
-	memcpy(o.data + size_t(y) * o.pitch_bytes + x_bytes, src, size_t(bytes));
+	memcpy(o.data + (size_t(z) * o.height + size_t(y)) * o.pitch_bytes + x_bytes, src, size_t(bytes));
 }
 
 // ---- one frame's worth of device state --------------------------------------------------------------------------
@@ -397,6 +399,35 @@ void ref_cuda_render_sample(void * frame, int sample_index, int * counters_out) 
 
 // The displayed frame (the `accumulator` surface) and an AOV's accumulator: pitch * height float4
 void ref_cuda_read_frame(void * frame, float * dst) { Frame * f = static_cast<Frame *>(frame); memcpy(dst, f->accumulator_image.data(), f->accumulator_image.size() * sizeof(float4)); }
+// Kulla-Conty table integration (KullaConty.h:83-240), cells [first, first + count) of the 16^3 dielectric table
+// (entering / leaving) or of the 32^2 conductor table, 100 000 samples each as in the reference; and the cosine-weighted
+// averages over the last axis. Needs a frame (the kernels draw from pmj_samples / blue_noise_textures).
+void ref_cuda_integrate_dielectric_cells(void *, int entering, int first, int count, float * out) {
+	std::vector<float> table(16 * 16 * 16, 0.0f);
+	SurfaceObject surface = { reinterpret_cast<unsigned char *>(table.data()), int(16 * sizeof(float)), 16, 16 };
+	Surface<float> lut; lut.surface = reinterpret_cast<cudaSurfaceObject_t>(&surface);
+	blockDim = grt_dim3(); gridDim = grt_dim3(); threadIdx = grt_dim3 { 0, 0, 0 }; blockIdx = grt_dim3 { 0, 0, 0 };
+	for (int cell = first; cell < first + count; cell++) { blockIdx.x = unsigned(cell); kernel_integrate_dielectric(entering != 0, lut); }
+	memcpy(out, table.data() + first, size_t(count) * sizeof(float));
+}
+void ref_cuda_integrate_conductor_cells(void *, int first, int count, float * out) {
+	std::vector<float> table(32 * 32, 0.0f);
+	blockDim = grt_dim3(); gridDim = grt_dim3(); threadIdx = grt_dim3 { 0, 0, 0 }; blockIdx = grt_dim3 { 0, 0, 0 };
+	for (int cell = first; cell < first + count; cell++) { blockIdx.x = unsigned(cell); kernel_integrate_conductor(table.data()); }
+	memcpy(out, table.data() + first, size_t(count) * sizeof(float));
+}
+void ref_cuda_average_dielectric(const float * directional_16x16x16, float * albedo_16x16) {
+	std::vector<float> in(directional_16x16x16, directional_16x16x16 + 4096);
+	SurfaceObject in_surface  = { reinterpret_cast<unsigned char *>(in.data()), int(16 * sizeof(float)), 16, 16 };
+	SurfaceObject out_surface = { reinterpret_cast<unsigned char *>(albedo_16x16), int(16 * sizeof(float)), 16, 1 };
+	Surface<float> lut_in, lut_out;
+	lut_in.surface = reinterpret_cast<cudaSurfaceObject_t>(&in_surface); lut_out.surface = reinterpret_cast<cudaSurfaceObject_t>(&out_surface);
+	launch_1d(256, kernel_average_dielectric, lut_in, lut_out);
+}
+void ref_cuda_average_conductor(const float * directional_32x32, float * albedo_32) {
+	launch_1d(32, kernel_average_conductor, directional_32x32, albedo_32);
+}
+
 void ref_cuda_read_history_length(void * frame, int * dst) {
 	Frame * f = static_cast<Frame *>(frame);
 	if (history_length) memcpy(dst, history_length, size_t(f->scene->screen_pitch) * f->scene->screen_height * sizeof(int));

@@ -511,3 +511,26 @@ def test_reference_svgf_and_taa_kernels(grt, oracle, taa):
         assert (np.abs(a - b).max(axis=2) > 0.02 * (b.max(axis=2) + 1e-3)).mean() < 6e-2, f   # six a-trous passes spread each switched tap
         assert np.array_equal(ours.buffers["hl"].reshape(48, -1)[:, :64], theirs.history_length()[:, :64]), f
     theirs.close(); pt.close(); scene.close(); grt.config_reset()
+
+
+def test_reference_kulla_conty_table_kernels(grt, oracle):
+    """kernel_integrate_dielectric / _conductor (100 000 samples per cell) and the two averaging kernels of the
+    reference (KullaConty.h:83-240) against oracle_luts.cpp: a spread of cells of each table, and the averages of
+    whole (synthetic) tables."""
+    scene, pt = make_pathtracer(grt, "cornellbox", 16, 16, -1)
+    view = oracle.SceneView(pt)
+    theirs = _reference_frame(oracle, view)
+    for entering in (True, False):
+        for first in (0, 273, 1911, 4090):
+            want = theirs.integrate_dielectric_cells(entering, first, 3)
+            got = view.integrate_dielectric_cells(entering, first, 3)
+            assert np.allclose(got, want, rtol=2e-5, atol=2e-6), (entering, first, got, want)
+            assert (want >= 0).all() and (want <= 1.0001).all()
+    for first in (0, 500, 1021):
+        want = theirs.integrate_conductor_cells(first, 3)
+        got = view.integrate_conductor_cells(first, 3)
+        assert np.allclose(got, want, rtol=2e-5, atol=2e-6), (first, got, want)
+    luts = _synthetic_luts()
+    assert np.allclose(oracle.average_dielectric(luts[0]), theirs.average_dielectric(luts[0]), rtol=1e-6, atol=1e-7)
+    assert np.allclose(oracle.average_conductor(luts[4]), theirs.average_conductor(luts[4]), rtol=1e-6, atol=1e-7)
+    theirs.close(); pt.close(); scene.close()
