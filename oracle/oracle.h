@@ -5,14 +5,19 @@
  * liboracle.so; the product (gpu-raytracer_amd/) never links or calls it.
  *
  * Parity status: the reference ships no tests or golden vectors for this path and its
- * device code (CUDA + PTX, NVRTC) cannot run here, so the oracle is pinned by
- *   (i)  the reference's own BVH builder compiled verbatim (oracle/_ref) for every byte of
- *        the node/triangle data the traversal consumes, and
- *   (ii) line-by-line restatement of CUDA/Raytracing/{BVH8,BVH2,Triangle,Mesh,BVH}.h,
- *        CUDA/{Camera,Sampling,Util,Buffers,AOV,Sky,Medium,RayCone,Material,BSDF,KullaConty}.h,
- *        CUDA/Pathtracer.cu and CUDA/SVGF/{SVGF,TAA}.h (each function cites its source).
- * Image-level output of the CUDA kernels themselves is therefore "parity unpinned"
- * (SURVEY.md 8c): no reference-rendered image exists to compare against.
+ * device code (CUDA + PTX, NVRTC) cannot run on a GPU here. The oracle is
+ *   (i)   fed by node / triangle data that the reference's own BVH builder, compiled verbatim
+ *         (oracle/_ref), reproduces byte for byte;
+ *   (ii)  a line-by-line restatement of CUDA/Raytracing/{BVH8,BVH2,BVH4,Triangle,Mesh,BVH}.h,
+ *         CUDA/{Camera,Sampling,Util,Buffers,AOV,Sky,Medium,RayCone,Material,BSDF,KullaConty}.h,
+ *         CUDA/Pathtracer.cu and CUDA/SVGF/{SVGF,TAA}.h (each function cites its source);
+ *   (iii) PINNED by those very sources: oracle/ref/ref_cuda_harness.cpp compiles
+ *         Src/CUDA/Pathtracer.cu and all its headers verbatim for the host CPU and runs the
+ *         reference's kernels thread by thread on the same inputs; tests/test_oracle.py
+ *         (test_*reference*) requires identical queue sizes and frames within float noise.
+ * Still "parity unpinned" (SURVEY.md 8c): NVIDIA's texture-unit filtering, which has no
+ * definition to execute -- both sides use the software rules of oracle_shading.h -- and the
+ * AO integrator (AO.cu), which is restated only.
  *
  * Arithmetic contract (shared with the HIP kernels so that traversal can be compared
  * bit for bit): IEEE fp32, no implicit contraction (-ffp-contract=off), explicit fmaf()
