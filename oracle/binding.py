@@ -239,6 +239,50 @@ class ReferenceFrame:
             ref_lib().ref_cuda_frame_free(self.handle); self.handle = None
 
 
+_ref_ao = None
+
+
+def ref_ao_lib():
+    """The reference's AO.cu compiled for the host (oracle/_ref/libref_ao.so), or None where it has not been built."""
+    global _ref_ao
+    path = os.path.join(os.path.dirname(REF_LIB_PATH), "libref_ao.so")
+    if _ref_ao is None and os.path.exists(path):
+        r = ctypes.CDLL(path)
+        r.ref_ao_frame_create.restype = c_void_p
+        r.ref_ao_frame_create.argtypes = [c_void_p]
+        r.ref_ao_frame_free.argtypes = [c_void_p]
+        r.ref_ao_render_sample.argtypes = [c_void_p, c_int, c_float, c_void_p]
+        r.ref_ao_read_frame.argtypes = [c_void_p, c_void_p]
+        _ref_ao = r
+    return _ref_ao
+
+
+class ReferenceAOFrame:
+    """The reference's ambient-occlusion kernels (Src/CUDA/AO.cu, verbatim, on the host CPU) rendering a SceneView."""
+
+    def __init__(self, view):
+        if ref_ao_lib() is None:
+            raise RuntimeError("oracle/_ref/libref_ao.so has not been built")
+        self.view = view
+        self.handle = ref_ao_lib().ref_ao_frame_create(ctypes.addressof(view.scene))
+        self.shape = (view.scene.screen_height, view.scene.screen_pitch, 4)
+
+    def render_ao_sample(self, sample_index, ao_radius=1.0):
+        counters = np.zeros(2, np.int32)
+        ref_ao_lib().ref_ao_render_sample(self.handle, sample_index, ao_radius, counters.ctypes.data)
+        return int(counters[0]), int(counters[1])
+
+    @property
+    def final(self):
+        out = np.zeros(self.shape, np.float32)
+        ref_ao_lib().ref_ao_read_frame(self.handle, out.ctypes.data)
+        return out
+
+    def close(self):
+        if self.handle:
+            ref_ao_lib().ref_ao_frame_free(self.handle); self.handle = None
+
+
 def ref_geometry_shape(shape, transform16, p0=(0, 0, 0), p1=(0, 0, 1), radius=1.0, detail=-1):
     """Triangles (n, 24) of a primitive shape by the reference's own Geometry.cpp."""
     r = ref_lib()

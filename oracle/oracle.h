@@ -16,8 +16,8 @@
  *         reference's kernels thread by thread on the same inputs; tests/test_oracle.py
  *         (test_*reference*) requires identical queue sizes and frames within float noise.
  * Still "parity unpinned" (SURVEY.md 8c): NVIDIA's texture-unit filtering, which has no
- * definition to execute -- both sides use the software rules of oracle_shading.h -- and the
- * AO integrator (AO.cu), which is restated only.
+ * definition to execute -- both sides use the software rules of oracle_shading.h.
+ * (The AO integrator, AO.cu, is pinned the same way through oracle/_ref/libref_ao.so.)
  *
  * Arithmetic contract (shared with the HIP kernels so that traversal can be compared
  * bit for bit): IEEE fp32, no implicit contraction (-ffp-contract=off), explicit fmaf()

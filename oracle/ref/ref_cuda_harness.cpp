@@ -16,30 +16,7 @@
 //    texture unit has no definition to run.
 //  * The launch sequence of Pathtracer::render (Renderer/Integrators/Pathtracer.cpp:738-855) is host code that
 //    cannot be compiled here (it needs the CUDA driver API); ref_cuda_render_sample below restates its few lines.
-#include "cuda_on_cpu.h"
-
-#define sign_extend_s8x4 sign_extend_s8x4_ptx
-#define msb              msb_ptx
-#define vmin_min         vmin_min_ptx
-#define vmin_max         vmin_max_ptx
-#define vmax_min         vmax_min_ptx
-#define vmax_max         vmax_max_ptx
-#define __CUDACC__ 1   // keeps cuda_math.h's host fallbacks of fminf / fmaxf / min / max / rsqrtf out: see cuda_on_cpu.h
-#include "cudart/cuda_math.h"
-#undef __CUDACC__
-#include "Util.h"
-#undef sign_extend_s8x4
-#undef msb
-#undef vmin_min
-#undef vmin_max
-#undef vmax_min
-#undef vmax_max
-inline unsigned sign_extend_s8x4(unsigned x) { unsigned r = 0; for (int i = 0; i < 4; i++) if (x & (0x80u << (8 * i))) r |= 0xffu << (8 * i); return r; }
-inline unsigned msb(unsigned x) { return x ? 31u - unsigned(__builtin_clz(x)) : 0xffffffffu; }
-inline float vmin_min(float a, float b, float c) { int x = __float_as_int(a), y = __float_as_int(b), z = __float_as_int(c); int m = x < y ? x : y; return __int_as_float(m < z ? m : z); }
-inline float vmin_max(float a, float b, float c) { int x = __float_as_int(a), y = __float_as_int(b), z = __float_as_int(c); int m = x < y ? x : y; return __int_as_float(m > z ? m : z); }
-inline float vmax_min(float a, float b, float c) { int x = __float_as_int(a), y = __float_as_int(b), z = __float_as_int(c); int m = x > y ? x : y; return __int_as_float(m < z ? m : z); }
-inline float vmax_max(float a, float b, float c) { int x = __float_as_int(a), y = __float_as_int(b), z = __float_as_int(c); int m = x > y ? x : y; return __int_as_float(m > z ? m : z); }
+#include "ref_cuda_common.h"
 
 #include "Pathtracer.cu"
 

@@ -534,3 +534,25 @@ def test_reference_kulla_conty_table_kernels(grt, oracle):
     assert np.allclose(oracle.average_dielectric(luts[0]), theirs.average_dielectric(luts[0]), rtol=1e-6, atol=1e-7)
     assert np.allclose(oracle.average_conductor(luts[4]), theirs.average_conductor(luts[4]), rtol=1e-6, atol=1e-7)
     theirs.close(); pt.close(); scene.close()
+
+
+@pytest.mark.parametrize("scene_name,w,h,radius", [("cornellbox", 64, 48, 0.5), ("sponza", 96, 54, 1.5)])
+def test_reference_ambient_occlusion_kernels(grt, oracle, scene_name, w, h, radius):
+    """The reference's AO integrator (Src/CUDA/AO.cu, verbatim, run on the CPU through oracle/_ref/libref_ao.so)
+    against the oracle's restatement: the same number of occlusion rays and the same 0 / 1 / fractional image."""
+    if oracle.ref_ao_lib() is None:
+        pytest.skip("oracle/_ref/libref_ao.so not built (no /root/reference on this machine)")
+    grt.config_reset()
+    scene = grt.Scene(grt.scene_path(scene_name))
+    ao = grt.AO(scene, w, h, device=-1, radius=radius); ao.update()
+    view = oracle.SceneView(ao)
+    ours, theirs = oracle.Frame(view), oracle.ReferenceAOFrame(view)
+    for s in range(4):
+        oc = ours.render_ao_sample(s, radius)
+        primary, occlusion = theirs.render_ao_sample(s, radius)
+        assert primary == w * h and abs(occlusion - oc.shadow[0]) <= 1 + 0.001 * occlusion, (s, occlusion, oc.shadow[0])
+        a, b = ours.final[:, :w, :3], theirs.final[:, :w, :3]
+        assert np.abs(a - b).sum() / max(b.sum(), 1e-6) < 2e-3, (s, np.abs(a - b).sum() / b.sum())
+        assert (np.abs(a - b).max(axis=2) > 1e-3).mean() < 3e-3, s
+    assert 0.05 < theirs.final[:, :w, 0].mean() < 0.99
+    theirs.close(); ao.close(); scene.close()
