@@ -308,6 +308,7 @@ void ref_cuda_render_sample(void * frame, int sample_index, int * counters_out) 
 	int batch_size  = pixel_count < BATCH_SIZE ? pixel_count : BATCH_SIZE;
 	if (counters_out) memset(counters_out, 0, 6 * MAX_BOUNCES * sizeof(int));
 
+	memcpy(&camera, &s->camera, sizeof(Camera)); // the camera constant is re-uploaded whenever it moved (Integrator.cpp:454-481)
 	static_assert(sizeof(SVGFData) == 128, "two row-major 4x4 matrices");
 	memcpy(&svgf_data.view_projection,      s->view_projection,      64); // uploaded by Pathtracer::update before the frame (Pathtracer.cpp:707-717)
 	memcpy(&svgf_data.view_projection_prev, s->view_projection_prev, 64);

@@ -556,3 +556,58 @@ def test_reference_ambient_occlusion_kernels(grt, oracle, scene_name, w, h, radi
         assert (np.abs(a - b).max(axis=2) > 1e-3).mean() < 3e-3, s
     assert 0.05 < theirs.final[:, :w, 0].mean() < 0.99
     theirs.close(); ao.close(); scene.close()
+
+
+def test_reference_kernels_thin_lens_hdr_sky_and_instances(grt, oracle, tmp_path):
+    """More of kernel_generate / kernel_sort through the reference's own code: a thin-lens camera (aperture sampling),
+    an HDR environment map with structure (sample_sky on misses at every bounce), and instanced file meshes with
+    rotation + uniform scale (object-space traversal, normal transforms, the plastic BSDF)."""
+    w, h = 32, 16
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgbe = np.zeros((h, w, 4), np.uint8)
+    rgbe[:, :, 0] = 100 + 100 * np.sin(xx / 5.0); rgbe[:, :, 1] = 120 + 80 * np.cos(yy / 3.0); rgbe[:, :, 2] = 60 + 3 * xx; rgbe[:, :, 3] = 128 + (yy < 6) * 2
+    rows = b"".join(bytes([2, 2, 0, w]) + b"".join(b"".join(bytes([1, int(v)]) for v in rgbe[y, :, c]) for c in range(4)) for y in range(h))
+    (tmp_path / "sky.hdr").write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w) + rows)
+    (tmp_path / "pyramid.obj").write_text("v -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nv 0 1.5 0\nf 1 2 5\nf 2 3 5\nf 3 4 5\nf 4 1 5\nf 1 3 2\nf 1 4 3\n")
+    rng = np.random.default_rng(1)
+    xml = ('<scene version="0.5.0"><integrator type="path"><integer name="maxDepth" value="4"/></integrator>'
+           '<sensor type="thinlens"><float name="fov" value="45"/><float name="apertureRadius" value="0.15"/><float name="focusDistance" value="4"/>'
+           '<transform name="toWorld"><lookat origin="0, 2.5, 7" target="0, 0.5, 0" up="0, 1, 0"/></transform></sensor>'
+           '<shape type="rectangle"><transform name="toWorld"><rotate x="1" angle="-90"/><scale value="6"/></transform><bsdf type="diffuse"><rgb name="reflectance" value="0.7, 0.6, 0.5"/></bsdf></shape>')
+    for i in range(8):
+        xml += ('<shape type="obj"><string name="filename" value="pyramid.obj"/><transform name="toWorld"><scale value="%.2f"/><rotate y="1" angle="%.1f"/><translate x="%.2f" y="0.01" z="%.2f"/></transform>'
+                % (rng.uniform(0.4, 1.2), rng.uniform(0, 360), rng.uniform(-4, 4), rng.uniform(-3, 2)))
+        xml += ('<bsdf type="roughplastic"><rgb name="diffuseReflectance" value="0.3, 0.5, 0.8"/><float name="alpha" value="0.2"/></bsdf></shape>' if i % 2 else
+                '<bsdf type="diffuse"><rgb name="reflectance" value="0.8, 0.3, 0.2"/></bsdf></shape>')
+    (tmp_path / "s.xml").write_text(xml + "</scene>")
+    grt.config_reset()
+    scene = grt.Scene(str(tmp_path / "s.xml"), sky=str(tmp_path / "sky.hdr"))
+    pt = grt.Pathtracer(scene, 64, 40, device=-1); pt.update()
+    assert pt.camera().aperture_radius > 0.1 and pt.sky()[1:3] == (32, 16)
+    totals = _compare_with_reference_kernels(oracle, pt, 64, 3, 2e-5, 1e-3)
+    assert totals["plastic"] > 200 and totals["shadow"] == 0               # lit by the sky alone
+    pt.close(); scene.close(); grt.config_reset()
+
+
+def test_reference_svgf_reprojection_with_a_moving_camera(grt, oracle):
+    """SVGF temporal reprojection under camera motion (kernel_svgf_reproject: previous screen positions from the
+    g-buffer, bilinear history taps, consistency tests, disocclusions): history lengths identical, frames within the
+    edge-stopping noise."""
+    scene, pt = make_pathtracer(grt, "cornellbox", 64, 48, -1, num_bounces=3, enable_svgf=1, enable_taa=1)
+    view = oracle.SceneView(pt)
+    ours, theirs = oracle.Frame(view), _reference_frame(oracle, view)
+    for f in range(4):
+        if f:
+            scene.set_camera((0.02 * f, 1.0 + 0.01 * f, 6.8), (0.0, 0.004 * f, 0.0, 1.0)); pt.update()
+            view.scene.camera = oracle.SceneView(pt).scene.camera
+        vp = pt.view_projection()
+        for i in range(16):
+            view.scene.view_projection[i] = vp[0][i]; view.scene.view_projection_prev[i] = vp[1][i]
+        ours.render_sample(pt.sample_index); theirs.render_sample(pt.sample_index)
+        a, b = ours.final[:, :64, :3], theirs.final[:, :64, :3]
+        assert np.abs(a - b).sum() / b.sum() < 6e-3, (f, np.abs(a - b).sum() / b.sum())
+        history = theirs.history_length()[:, :64]
+        assert np.array_equal(ours.buffers["hl"].reshape(48, -1)[:, :64], history), f
+        if f:
+            assert 0.8 * f < history.mean() <= f and (history == 0).any()      # most pixels reproject, some are disoccluded
+    theirs.close(); pt.close(); scene.close(); grt.config_reset()
