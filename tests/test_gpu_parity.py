@@ -648,3 +648,27 @@ def test_block_compressed_textures_render_like_the_oracle(grt, oracle):
         frames[compress] = pt.read_framebuffer()[:, :320, :3].copy()
         pt.close(); scene.close()
     assert not np.array_equal(frames[0], frames[1])
+
+
+@pytest.mark.gpu
+def test_gpu_frames_equal_the_references_own_kernels(grt, oracle):
+    """Closes the loop without the restated oracle in between: the HIP kernels on the MI355X against the reference's
+    Pathtracer.cu executed on the CPU (oracle/ref/ref_cuda_harness.cpp, prebuilt into oracle/_ref) on the same
+    staged arrays -- queue sizes per bounce and frames."""
+    if oracle.ref_lib() is None or not hasattr(oracle.ref_lib(), "ref_cuda_frame_create"):
+        pytest.skip("oracle/_ref was built without the reference's device code")
+    scene, pt = make_pathtracer(grt, "cornellbox", 96, 64, 0, num_bounces=5)
+    view = oracle.SceneView(pt)
+    theirs = oracle.ReferenceFrame(view)
+    for f in range(3):
+        if f:
+            pt.update()
+        pt.render()
+        c = pt.counters()
+        rc = theirs.render_sample(pt.sample_index)
+        for name in ("trace", "shadow", "diffuse"):
+            got, want = list(getattr(c, name)[:5]), [int(v) for v in rc[name][:5]]
+            assert got[0] == want[0] and all(abs(a - b) <= 2 + 0.002 * b for a, b in zip(got, want)), (f, name, got, want)
+        got, want = pt.read_framebuffer()[:, :96, :3], theirs.final[:, :96, :3]
+        assert np.abs(got - want).sum() / want.sum() < REL_L1_TOL, f
+    theirs.close(); pt.close(); scene.close()
