@@ -8,6 +8,8 @@ bvh_golden.json   ("variants": the same for the binary trees the device gets wit
                   builder (oracle/_ref/libref_bvh.so = /root/reference/Src/BVH compiled verbatim)
                   produces for every Cornell mesh, every Sponza mesh (one aggregate digest plus the
                   10 largest individually) and three seeded random triangle soups.
+reference_kernels_golden.npz  frames + queue sizes rendered by the reference's own Pathtracer.cu running on the CPU
+                  (oracle/ref/ref_cuda_harness.cpp): Cornell with and without NEE, textured Sponza.
 render_golden.npz Cornell 48x48, 2 samples, 4 bounces rendered by the CPU oracle (regression pin for
                   the oracle itself and a fixed target for the GPU parity test).
 """
@@ -88,7 +90,36 @@ def make_variants():
     return variants
 
 
+def make_reference_kernel_golden():
+    """reference_kernels_golden.npz: frames and per-bounce queue sizes produced by the REFERENCE'S OWN device code
+    (Src/CUDA/Pathtracer.cu compiled verbatim for the host, oracle/ref/ref_cuda_harness.cpp) -- the fixture that
+    pins the oracle where oracle/_ref is not available."""
+    out = {}
+    cases = (("cornell", dict(num_bounces=5), 64, 48, 3), ("cornell_no_nee", dict(num_bounces=4, enable_next_event_estimation=0), 64, 48, 2),
+             ("sponza", dict(num_bounces=3), 80, 45, 2))
+    for name, config, w, h, samples in cases:
+        grt.config_reset()
+        scene = grt.Scene(grt.scene_path("cornellbox" if name.startswith("cornell") else "sponza"))
+        grt.config_set(**config)
+        pt = grt.Pathtracer(scene, w, h, device=-1); pt.update()
+        view = oracle.SceneView(pt)
+        ref = oracle.ReferenceFrame(view)
+        queues = []
+        for s in range(samples):
+            rc = ref.render_sample(s)
+            queues.append([rc[k][:8] for k in ("trace", "shadow", "diffuse")])
+        out[name + "_image"] = ref.final[:, :w, :3].copy()
+        out[name + "_queues"] = np.array(queues, np.int32)
+        ref.close(); pt.close(); scene.close()
+    grt.config_reset()
+    np.savez_compressed(os.path.join(HERE, "reference_kernels_golden.npz"), **out)
+    print("wrote reference_kernels_golden.npz")
+
+
 def main():
+    if "--only-reference-kernels" in sys.argv:
+        make_reference_kernel_golden()
+        return
     if "--only-variants" in sys.argv:
         path = os.path.join(HERE, "bvh_golden.json")
         golden = json.load(open(path))
@@ -144,6 +175,7 @@ def main():
     hits, stats = view.trace(o, d)
     np.savez_compressed(os.path.join(HERE, "render_golden.npz"), image=frame.final[:, :48, :3].copy(), counters=np.array(counters, np.int32),
                         ray_origin=o, ray_direction=d, hits=hits, nodes=np.int64(stats.nodes), triangles=np.int64(stats.triangles))
+    make_reference_kernel_golden()
     print("wrote fixtures")
 
 

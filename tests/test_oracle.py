@@ -611,3 +611,26 @@ def test_reference_svgf_reprojection_with_a_moving_camera(grt, oracle):
         if f:
             assert 0.8 * f < history.mean() <= f and (history == 0).any()      # most pixels reproject, some are disoccluded
     theirs.close(); pt.close(); scene.close(); grt.config_reset()
+
+
+def test_oracle_matches_golden_frames_rendered_by_the_reference_kernels(grt, oracle):
+    """The committed fixture tests/golden/reference_kernels_golden.npz holds frames and queue sizes produced by the
+    reference's own Pathtracer.cu on the CPU (tests/golden/make_golden.py --only-reference-kernels): the oracle has to
+    reproduce them, also on a machine where oracle/_ref cannot be built."""
+    golden = np.load(os.path.join(os.path.dirname(GOLDEN), "reference_kernels_golden.npz"))
+    cases = (("cornell", "cornellbox", dict(num_bounces=5), 64, 48), ("cornell_no_nee", "cornellbox", dict(num_bounces=4, enable_next_event_estimation=0), 64, 48),
+             ("sponza", "sponza", dict(num_bounces=3), 80, 45))
+    for name, scene_name, config, w, h in cases:
+        scene, pt = make_pathtracer(grt, scene_name, w, h, -1, **config)
+        frame = oracle.Frame(oracle.SceneView(pt))
+        queues = golden[name + "_queues"]
+        for s in range(queues.shape[0]):
+            oc = frame.render_sample(s)
+            for k, queue in enumerate(("trace", "shadow", "diffuse")):
+                got, want = list(getattr(oc, queue)[:8]), queues[s, k].tolist()
+                assert all(abs(a - b) <= 2 + 0.002 * b for a, b in zip(got, want)), (name, s, queue, got, want)
+        want = golden[name + "_image"]
+        got = frame.final[:, :w, :3]
+        assert np.abs(got - want).sum() / want.sum() < 3e-4, name
+        pt.close(); scene.close()
+    grt.config_reset()
