@@ -634,3 +634,32 @@ def test_oracle_matches_golden_frames_rendered_by_the_reference_kernels(grt, ora
         assert np.abs(got - want).sum() / want.sum() < 3e-4, name
         pt.close(); scene.close()
     grt.config_reset()
+
+
+@pytest.mark.parametrize("toggles", [{}, {"enable_multiple_importance_sampling": 0}, {"enable_next_event_estimation": 0}, {"enable_mipmapping": 0}],
+                         ids=["default", "no-mis", "no-nee", "no-mipmaps"])
+def test_reference_kernels_on_a_scene_with_everything(grt, oracle, tmp_path, toggles):
+    """One scene through the reference's kernels and the oracle with every feature at once: a textured rough-plastic
+    floor (uv repeat, mip maps), two emitters of different power of which one is a rotated, scaled file mesh
+    (light_mesh_transform_indices), a rough dielectric holding a back-scattering medium, a named conductor, and a dim sky."""
+    from test_loaders import _png_bytes
+    rng = np.random.default_rng(2)
+    (tmp_path / "t.png").write_bytes(_png_bytes(rng.integers(0, 256, (32, 32, 3)), 2, 8))
+    (tmp_path / "quad.obj").write_text("v -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nvt 0 0\nvt 3 0\nvt 3 3\nvt 0 3\nf 1/1 2/2 3/3\nf 1/1 3/3 4/4\n")
+    (tmp_path / "s.xml").write_text(
+        '<scene version="0.5.0"><integrator type="path"><integer name="maxDepth" value="6"/></integrator>'
+        '<sensor type="perspective"><float name="fov" value="50"/><transform name="toWorld"><lookat origin="0, 2, 6" target="0, 0.7, 0" up="0, 1, 0"/></transform></sensor>'
+        '<shape type="obj"><string name="filename" value="quad.obj"/><transform name="toWorld"><scale value="5"/></transform><bsdf type="roughplastic"><texture type="bitmap" name="diffuseReflectance"><string name="filename" value="t.png"/></texture><float name="alpha" value="0.25"/></bsdf></shape>'
+        '<shape type="obj"><string name="filename" value="quad.obj"/><transform name="toWorld"><scale value="0.5"/><rotate x="1" angle="180"/><rotate z="1" angle="20"/><translate x="1.5" y="2.5" z="0.25"/></transform><emitter type="area"><rgb name="radiance" value="9, 8, 7"/></emitter></shape>'
+        '<shape type="rectangle"><transform name="toWorld"><rotate x="1" angle="90"/><scale value="0.4"/><translate x="-1.5" y="3"/></transform><emitter type="area"><rgb name="radiance" value="20, 5, 5"/></emitter></shape>'
+        '<shape type="sphere"><float name="radius" value="0.7"/><transform name="toWorld"><translate y="0.7"/></transform><bsdf type="roughdielectric"><float name="intIOR" value="1.5"/><float name="alpha" value="0.2"/></bsdf>'
+        '<medium type="homogeneous" name="interior"><rgb name="sigmaA" value="0.5, 0.2, 0.1"/><rgb name="sigmaS" value="2, 2.5, 3"/><phase type="hg"><float name="g" value="-0.4"/></phase></medium></shape>'
+        '<shape type="sphere"><float name="radius" value="0.4"/><transform name="toWorld"><translate x="-1.6" y="0.4" z="1"/></transform><bsdf type="roughconductor"><string name="material" value="Cu"/><float name="alpha" value="0.05"/></bsdf></shape></scene>')
+    grt.config_reset()
+    scene = grt.Scene(str(tmp_path / "s.xml")); scene.set_sky_scale(0.3)
+    grt.config_set(**toggles)
+    pt = grt.Pathtracer(scene, 72, 48, device=-1); pt.update()
+    totals = _compare_with_reference_kernels(oracle, pt, 72, 3, 1e-4, 2e-3, luts=_synthetic_luts())
+    assert totals["plastic"] > 3000 and totals["dielectric"] > 800 and totals["conductor"] > 200
+    assert (totals["shadow"] > 3000) == bool(toggles.get("enable_next_event_estimation", 1))
+    pt.close(); scene.close(); grt.config_reset()
