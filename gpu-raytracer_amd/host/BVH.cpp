@@ -161,10 +161,7 @@ int BVH8Converter::fill_cost_table(int node_index) {
 	Decision * row = &table[size_t(node_index) * 7];
 
 	if (node.is_leaf()) {
-		if (node.count != 1) {
-			fprintf(stderr, "ERROR: BVH8 conversion needs exactly one primitive per BVH2 leaf\n");
-			abort();
-		}
+		if (node.count != 1) throw std::runtime_error("BVH8 conversion needs exactly one primitive per BVH2 leaf");
 		float cost_leaf = node.aabb.surface_area() * float(node.count);
 		for (int i = 0; i < 7; i++) { row[i].kind = LEAF; row[i].cost = cost_leaf; }
 		return int(node.count);

@@ -150,6 +150,7 @@ bool BVHCache::try_to_load(const std::string & mesh_filename, const std::string 
 		const BVHNode2 & node = loaded.nodes[i];
 		const float * box = &node.aabb.min.x;
 		for (int k = 0; k < 6; k++) if (!std::isfinite(box[k])) return false;
+		if (node.is_leaf() && node.count != 1) return false; // caches hold the builders' raw trees: one reference per leaf
 		if (node.is_leaf() ? (node.first < 0 || size_t(node.first) + node.count > loaded.indices.size())
 		                   : (node.left <= int(i) || size_t(node.left) + 1 >= loaded.nodes.size())) return false;
 	}
