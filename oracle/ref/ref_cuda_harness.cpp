@@ -424,6 +424,7 @@ extern "C" void ref_cuda_primary_hits(void * frame, int sample_index, unsigned *
 	Frame * f = static_cast<Frame *>(frame);
 	const oracle_scene * s = f->scene;
 	int count = s->screen_width * s->screen_height;
+	if (count > BATCH_SIZE) count = BATCH_SIZE; // the wavefront buffers hold one batch
 	memset(&buffer_sizes, 0, sizeof(buffer_sizes));
 	buffer_sizes.trace[0] = count;
 	launch_1d(BATCH_SIZE, kernel_generate, sample_index, 0, count);
@@ -435,6 +436,7 @@ extern "C" void ref_cuda_primary_rays(void * frame, int sample_index, float * or
 	Frame * f = static_cast<Frame *>(frame);
 	const oracle_scene * s = f->scene;
 	int count = s->screen_width * s->screen_height;
+	if (count > BATCH_SIZE) count = BATCH_SIZE; // the wavefront buffers hold one batch
 	memset(&buffer_sizes, 0, sizeof(buffer_sizes));
 	buffer_sizes.trace[0] = count;
 	launch_1d(BATCH_SIZE, kernel_generate, sample_index, 0, count);
