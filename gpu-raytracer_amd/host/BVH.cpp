@@ -126,6 +126,7 @@ void SAHBuilder::build(const std::vector<Mesh> & meshes) {
 BVH2 BVH::create_sah_from_triangles(const std::vector<Triangle> & triangles) {
 	BVH2 bvh;
 	SAHBuilder(bvh, triangles.size()).build(triangles);
+	if (cpu_config.enable_bvh_optimization) BVHOptimizer::optimize(bvh); // reference: BVH.cpp:31-33
 	return bvh;
 }
 
@@ -133,6 +134,7 @@ BVH2 BVH::create_from_triangles(const std::vector<Triangle> & triangles) {
 	if (cpu_config.bvh_type != BVHType::SBVH) return create_sah_from_triangles(triangles);
 	BVH2 bvh;
 	SBVHBuilder(bvh, triangles.size()).build(triangles);
+	if (cpu_config.enable_bvh_optimization) BVHOptimizer::optimize(bvh);
 	return bvh;
 }
 

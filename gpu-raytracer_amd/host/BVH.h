@@ -199,6 +199,10 @@ struct SBVHBuilder {
 	void build(const std::vector<Triangle> & triangles);
 };
 
+namespace BVHOptimizer {
+	void optimize(BVH2 & bvh); // BVHOptimizer.cpp: insertion-based optimisation (Bittner et al. 2013), cpu_config.enable_bvh_optimization
+}
+
 namespace BVHCollapser {
 	void collapse(BVH2 & bvh); // SBVH.cpp
 }

@@ -71,7 +71,9 @@ struct CPUConfig {
 	// that may sit on a read-only asset tree only does so when asked to.
 	bool enable_bvh_cache        = false;
 	bool bvh_force_rebuild       = false; // ignore existing caches (they are still rewritten)
-	bool enable_bvh_optimization = false; // recorded in the cache header; the optimiser itself is not part of this path
+	bool enable_bvh_optimization = false; // BVHOptimizer::optimize on every binary tree after it is built (-O)
+	int  bvh_optimizer_max_time        = 60000; // milliseconds
+	int  bvh_optimizer_max_num_batches = 1000;
 
 	float sah_cost_node = 4.0f;   // BVH8 conversion and leaf collapse
 	float sah_cost_leaf = 1.0f;

@@ -132,6 +132,7 @@ void MeshData::prepare_device_bvh(BVHType type) {
 	if (type == BVHType::SBVH) {
 		if (sbvh.nodes.empty()) {
 			SBVHBuilder(sbvh, triangles.size()).build(triangles);
+			if (cpu_config.enable_bvh_optimization) BVHOptimizer::optimize(sbvh);
 			if (from_file && cpu_config.enable_bvh_cache && cpu_config.bvh_type == BVHType::SBVH) BVHCache::save(bvh_filename, triangles, sbvh);
 		}
 		device_bvh2 = sbvh;

@@ -52,6 +52,9 @@ int grt_config_set(const char * key, double value) {
 		cpu_config.mipmap_filter = MipmapFilterType(int(value));
 	}
 	else if (k == "enable_block_compression")            cpu_config.enable_block_compression = value != 0;
+	else if (k == "enable_bvh_optimization")             cpu_config.enable_bvh_optimization = value != 0;
+	else if (k == "bvh_optimizer_max_time")              cpu_config.bvh_optimizer_max_time = int(value);
+	else if (k == "bvh_optimizer_max_num_batches")       cpu_config.bvh_optimizer_max_num_batches = int(value);
 	else if (k == "enable_bvh_cache")                    cpu_config.enable_bvh_cache = value != 0;
 	else if (k == "bvh_force_rebuild")                   cpu_config.bvh_force_rebuild = value != 0;
 	else if (k == "sah_cost_node")                       cpu_config.sah_cost_node = float(value);

@@ -88,9 +88,9 @@ std::vector<Option> make_options(CommandLine & cl) {
 	o.push_back({ nullptr, "nee", "Enables or disables Next Event Estimation",        1, [](const char * v) { gpu_config.enable_next_event_estimation        = parse_bool(v); } });
 	o.push_back({ nullptr, "mis", "Enables or disables Multiple Importance Sampling", 1, [](const char * v) { gpu_config.enable_multiple_importance_sampling = parse_bool(v); } });
 	o.push_back({ nullptr, "force-rebuild", "BVH will not be loaded from disk but rebuilt from scratch", 0, [](const char *) { cpu_config.bvh_force_rebuild = true; } });
-	o.push_back({ "O", "optimize", "BVH optimization post-processing step (not available: must stay false)", 1, [](const char * v) {
-		if (parse_bool(v)) die("BVH optimization is not part of this build");
-	} });
+	o.push_back({ "O",  "optimize",    "Enables or disables BVH optimization post-processing step", 1, [](const char * v) { cpu_config.enable_bvh_optimization = parse_bool(v); } });
+	o.push_back({ "Ot", "opt-time",    "Sets time limit for BVH optimization (milliseconds, as the reference stores it)", 1, [](const char * v) { cpu_config.bvh_optimizer_max_time = parse_int(v, "--opt-time"); } });
+	o.push_back({ "Ob", "opt-batches", "Sets a limit on the maximum number of batches used in BVH optimization", 1, [](const char * v) { cpu_config.bvh_optimizer_max_num_batches = parse_int(v, "--opt-batches"); } });
 	o.push_back({ nullptr, "sah-node",   "Sets the SAH cost of an internal BVH node", 1, [](const char * v) { cpu_config.sah_cost_node = parse_float(v, "--sah-node"); } });
 	o.push_back({ nullptr, "sah-leaf",   "Sets the SAH cost of a leaf BVH node",      1, [](const char * v) { cpu_config.sah_cost_leaf = parse_float(v, "--sah-leaf"); } });
 	o.push_back({ nullptr, "sbvh-alpha", "Sets the SBVH alpha constant. An alpha of 1 results in a regular BVH, alpha of 0 results in full SBVH", 1, [](const char * v) { cpu_config.sbvh_alpha = parse_float(v, "--sbvh-alpha"); } });

@@ -333,6 +333,26 @@ def ref_build_binary_variant(tris24, sbvh, collapse, sbvh_alpha=10e-5):
     return out
 
 
+def ref_build_optimized(tris24, sbvh, max_batches):
+    """BVH::create_from_triangles with enable_bvh_optimization, limited to `max_batches` (+1) batches, and the BVH8
+    (SAH only) / BVH4 converted from the optimised tree."""
+    r = ref_lib()
+    t = np.ascontiguousarray(tris24, dtype=np.float32)
+    r.ref_bvh_build_optimized.restype = ctypes.c_void_p
+    r.ref_bvh_build_optimized.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    h = r.ref_bvh_build_optimized(t.ctypes.data, t.size // 24, int(sbvh), int(max_batches))
+    out = {}
+    out["bvh2_nodes"] = np.zeros(r.ref_bvh2_node_count(h) * 32, np.uint8); r.ref_bvh2_copy_nodes(h, out["bvh2_nodes"].ctypes.data)
+    out["bvh2_indices"] = np.zeros(r.ref_bvh2_index_count(h), np.int32); r.ref_bvh2_copy_indices(h, out["bvh2_indices"].ctypes.data)
+    out["bvh4_nodes"] = np.zeros(r.ref_bvh4_node_count(h) * 128, np.uint8); r.ref_bvh4_copy_nodes(h, out["bvh4_nodes"].ctypes.data)
+    if not sbvh:
+        out["bvh8_nodes"] = np.zeros(r.ref_bvh8_node_count(h) * 80, np.uint8); r.ref_bvh8_copy_nodes(h, out["bvh8_nodes"].ctypes.data)
+        out["bvh8_indices"] = np.zeros(r.ref_bvh8_index_count(h), np.int32); r.ref_bvh8_copy_indices(h, out["bvh8_indices"].ctypes.data)
+    out["ms_bvh2"] = r.ref_bvh_ms_bvh2(h)
+    r.ref_bvh_free(h)
+    return out
+
+
 class SceneView:
     """Keeps the numpy arrays alive that an OracleScene points into."""
 

@@ -107,6 +107,31 @@ void * ref_bvh_build_binary_variant(const float * tris24, int n, int sbvh, int c
 	return r;
 }
 
+// BVH::create_from_triangles with cpu_config.enable_bvh_optimization (BVH/BVH.cpp:31-33, BVH/BVHOptimizer.cpp) and the
+// device forms converted from the optimised tree. The optimiser seeds its random phase from time(): its output is a
+// function of the input only while it selects by measure, which max_batches <= 4 guarantees.
+void * ref_bvh_build_optimized(const float * tris24, int n, int sbvh, int max_batches) {
+	Array<Triangle> triangles(n);
+	memcpy((void *)triangles.data(), tris24, size_t(n) * sizeof(Triangle));
+
+	RefBVH * r = new RefBVH();
+	MuteStdout mute;
+	int saved_batches = cpu_config.bvh_optimizer_max_num_batches;
+	cpu_config.bvh_type = sbvh ? BVHType::SBVH : BVHType::BVH;
+	cpu_config.enable_bvh_optimization       = true;
+	cpu_config.bvh_optimizer_max_num_batches = max_batches;
+	double t0 = now_ms();
+	r->bvh2 = BVH::create_from_triangles(triangles);
+	double t1 = now_ms();
+	if (!sbvh) BVH8Converter(r->bvh8, r->bvh2).convert();
+	BVH4Converter(r->bvh4, r->bvh2).convert();
+	cpu_config.bvh_type = BVHType::BVH8;
+	cpu_config.enable_bvh_optimization       = false;
+	cpu_config.bvh_optimizer_max_num_batches = saved_batches;
+	r->ms_bvh2 = t1 - t0;
+	return r;
+}
+
 // aabbs6: n * 6 floats {min.xyz, max.xyz} = Mesh::aabb after Mesh::update().
 void * ref_bvh_build_meshes(const float * aabbs6, int n) {
 	Array<Mesh> meshes;

@@ -90,6 +90,23 @@ def make_variants():
     return variants
 
 
+OPTIMIZED_CASES = (("soup", 41, 300, 0, 4), ("soup", 42, 4000, 0, 2), ("slivers", 43, 500, 0, 4), ("slivers", 43, 500, 1, 3))
+
+
+def make_optimized():
+    """Digests of trees after the reference's BVHOptimizer (kind, seed, n, sbvh, max_batches): limited to its
+    deterministic measure-driven batches."""
+    out = {}
+    for kind, seed, n, sbvh, batches in OPTIMIZED_CASES:
+        tris = soup(seed, n) if kind == "soup" else slivers(seed, n)
+        ref = oracle.ref_build_optimized(tris, sbvh, batches)
+        plain = oracle.ref_build_binary_variant(tris, sbvh, 0)
+        assert not np.array_equal(ref["bvh2_nodes"], plain["bvh2_nodes"])
+        arrays = [ref["bvh2_nodes"], ref["bvh2_indices"], ref["bvh4_nodes"]] + ([] if sbvh else [ref["bvh8_nodes"], ref["bvh8_indices"]])
+        out["%s_%d_%d_%s_%d" % (kind, seed, n, "sbvh" if sbvh else "sah", batches)] = digest(*arrays)
+    return out
+
+
 def make_reference_kernel_golden():
     """reference_kernels_golden.npz: frames and per-bounce queue sizes produced by the REFERENCE'S OWN device code
     (Src/CUDA/Pathtracer.cu compiled verbatim for the host, oracle/ref/ref_cuda_harness.cpp) -- the fixture that
@@ -119,6 +136,13 @@ def make_reference_kernel_golden():
 def main():
     if "--only-reference-kernels" in sys.argv:
         make_reference_kernel_golden()
+        return
+    if "--only-optimized" in sys.argv:
+        path = os.path.join(HERE, "bvh_golden.json")
+        golden = json.load(open(path))
+        golden["optimized"] = make_optimized()
+        json.dump(golden, open(path, "w"), indent=1, sort_keys=True)
+        print("updated optimized")
         return
     if "--only-variants" in sys.argv:
         path = os.path.join(HERE, "bvh_golden.json")

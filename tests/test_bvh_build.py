@@ -56,7 +56,7 @@ def slivers(seed, n):
     return t
 
 
-def product_device_bvh(grt, tris24, sbvh, collapse, sbvh_alpha=None):
+def product_device_bvh(grt, tris24, sbvh, collapse, sbvh_alpha=None, **config):
     """The binary tree (and its BVH4 form) the host hands to the device for bvh_type = BVH / SBVH."""
     import ctypes
     lib = grt.host_lib()
@@ -64,6 +64,7 @@ def product_device_bvh(grt, tris24, sbvh, collapse, sbvh_alpha=None):
     grt.config_set(bvh_type=1 if sbvh else 2)
     if sbvh_alpha is not None:
         grt.config_set(sbvh_alpha=sbvh_alpha)
+    grt.config_set(**config)
     t = np.ascontiguousarray(tris24, np.float32)
     h = lib.grt_build_device_bvh(t.ctypes.data, t.size // 24, int(collapse))
     grt.config_reset()
@@ -165,6 +166,81 @@ def test_live_against_reference_builder(grt, oracle):
                 ref, built = oracle.ref_build_binary_variant(tris, sbvh, collapse), product_device_bvh(grt, tris, sbvh, collapse)
                 for key in ("bvh2_nodes", "bvh2_indices", "bvh4_nodes"):
                     assert np.array_equal(ref[key], built[key]), (sbvh, collapse, key)
+
+
+def optimized_build(grt, tris, sbvh, batches):
+    if sbvh:
+        return product_device_bvh(grt, tris, 1, 0, enable_bvh_optimization=1, bvh_optimizer_max_num_batches=batches)
+    grt.config_reset()
+    grt.config_set(enable_bvh_optimization=1, bvh_optimizer_max_num_batches=batches)
+    built = product_build(grt, tris)
+    grt.config_reset()
+    return built
+
+
+@pytest.mark.parametrize("key", sorted(GOLDEN["optimized"]))
+def test_optimized_trees_match_reference_digest(grt, key):
+    """BVHOptimizer::optimize (reference BVHOptimizer.cpp:225-417) while it selects nodes by measure -- the part of it
+    that does not depend on the wall clock -- and the device trees converted from its result."""
+    kind, seed, n, flavour, batches = key.split("_")
+    tris = soup(int(seed), int(n)) if kind == "soup" else slivers(int(seed), int(n))
+    built = optimized_build(grt, tris, flavour == "sbvh", int(batches))
+    arrays = [built["bvh2_nodes"], built["bvh2_indices"], built["bvh4_nodes"]] + ([] if flavour == "sbvh" else [built["bvh8_nodes"], built["bvh8_indices"]])
+    assert digest(*arrays) == GOLDEN["optimized"][key]
+
+
+def test_optimizer_live_against_reference(grt, oracle):
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    for tris, sbvh, batches in ((soup(51, 40), 0, 4), (soup(52, 1500), 0, 0), (soup(52, 1500), 0, 3), (slivers(53, 350), 1, 4), (soup(54, 9), 0, 4)):
+        ref, built = oracle.ref_build_optimized(tris, sbvh, batches), optimized_build(grt, tris, sbvh, batches)
+        for key in ("bvh2_nodes", "bvh2_indices", "bvh4_nodes") + (() if sbvh else ("bvh8_nodes", "bvh8_indices")):
+            assert np.array_equal(ref[key], built[key]), (sbvh, batches, key)
+
+
+def bvh2_sah_cost(nodes_bytes):
+    """bvh_sah_cost of BVHOptimizer.cpp:15-35 with the default costs (node 4, leaf 1)."""
+    raw = np.frombuffer(nodes_bytes.tobytes(), np.uint8).reshape(-1, 32)
+    box = raw[:, :24].copy().view(np.float32).astype(np.float64)
+    meta = raw[:, 24:32].copy().view(np.uint32)
+    count = meta[:, 1] & 0x3fffffff
+    d = box[:, 3:6] - box[:, 0:3]
+    area = 2 * (d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0])
+    keep = np.ones(len(raw), bool); keep[1] = False
+    leaf = keep & (count > 0)
+    return (4.0 * area[keep & ~leaf].sum() + (area[leaf] * count[leaf]).sum()) / area[0]
+
+
+def test_full_optimization_lowers_sah_cost_and_keeps_the_tree_valid(grt):
+    """Unlimited run (measure-driven and random batches until ten stall): every triangle still in exactly one leaf,
+    every inner box the union of its children's, children in even/odd pairs, and a cheaper tree."""
+    tris = soup(61, 2500)
+    plain = product_build(grt, tris)
+    built = optimized_build(grt, tris, False, 1000)
+    again = optimized_build(grt, tris, False, 1000)
+    assert np.array_equal(built["bvh2_nodes"], again["bvh2_nodes"])            # fixed seed: reproducible, unlike the reference
+    assert bvh2_sah_cost(built["bvh2_nodes"]) < 0.99 * bvh2_sah_cost(plain["bvh2_nodes"])   # (a uniform soup leaves a full sweep SAH build little to gain)
+    assert sorted(built["bvh2_indices"].tolist()) == list(range(2500)) and sorted(built["bvh8_indices"].tolist()) == list(range(2500))
+
+    raw = built["bvh2_nodes"].reshape(-1, 32)
+    box = raw[:, :24].copy().view(np.float32)
+    meta = raw[:, 24:32].copy().view(np.uint32)
+    left, count, axis = meta[:, 0], meta[:, 1] & 0x3fffffff, meta[:, 1] >> 30
+    seen_leaves, stack, visited = 0, [0], 0
+    while stack:
+        i = stack.pop(); visited += 1
+        if count[i]:
+            first = left[i]
+            corners = tris[built["bvh2_indices"][first:first + count[i]]][:, :9].reshape(-1, 3)
+            assert (corners >= box[i, :3] - 1e-4).all() and (corners <= box[i, 3:] + 1e-4).all()
+            seen_leaves += count[i]
+            continue
+        l, r = int(left[i]), int(left[i]) + 1
+        assert l % 2 == 0 and l >= 2
+        assert np.array_equal(box[i, :3], np.minimum(box[l, :3], box[r, :3])) and np.array_equal(box[i, 3:], np.maximum(box[l, 3:], box[r, 3:]))
+        assert int(axis[i]) < 3
+        stack += [l, r]
+    assert seen_leaves == 2500 and visited == len(raw) - 1
 
 
 def test_cwbvh_structural_invariants(grt):
