@@ -307,7 +307,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "Sponza (Crytek, 262 687 triangles, 384 instances) 1920x1080, samples 0..3 (4 spp), BVH8/CWBVH, diffuse + roughplastic(odd materials, alpha 0.3), NEE+MIS+RR, 10 bounces, constant white sky, mipmapping on, 19 diffuse textures at the reference's dimensions (1024x1024 RGBA8 + mips, ~106 MB; texels replicated 4x4 from the quarter-size maps that travel with the repo), the 5 maps missing upstream are the reference's 1x1 pink fallback",
+                "workload": "Sponza (Crytek, 262 687 triangles, 384 instances) 1920x1080, samples 0..3 (4 spp), BVH8/CWBVH, diffuse + roughplastic(odd materials, alpha 0.3), NEE+MIS+RR, 10 bounces, constant white sky, mipmapping on, 19 diffuse textures at the reference's dimensions (1024x1024 RGBA8 + mips, ~106 MB; texels replicated 4x4 from the quarter-size maps that travel with the repo), the 5 maps missing upstream are the reference's 1x1 fallback texel",
                 "step": "one sample per pixel for the whole frame; the 4 samples of a frame are submitted as one wavefront (rt_render_samples), the reference's 777 600-pixel batches (a VRAM bound) are not needed",
                 "rays_per_step": round(rays_per_step), "shadow_rays_per_step": round(shadow_4spp / SPP),
                 "mrays_s_including_shadow": round((rays_4spp + shadow_4spp) / SPP * args.steps / elapsed / 1e6, 1),

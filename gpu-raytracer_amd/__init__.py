@@ -324,6 +324,35 @@ class Scene:
         ptr = host_lib().grt_mesh_data_array(self.handle, index, name.encode(), byref(n))
         return _view(ptr, n.value, dtype)
 
+    def describe(self):
+        """One line per object the loaders produced (floats as bit patterns)."""
+        lib = host_lib()
+        lib.grt_scene_describe.restype = ctypes.c_size_t
+        lib.grt_scene_describe.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+        n = lib.grt_scene_describe(self.handle, None, 0)
+        buf = ctypes.create_string_buffer(n)
+        lib.grt_scene_describe(self.handle, buf, n)
+        return buf.value.decode(errors="replace")
+
+    def texture(self, index):
+        """-> dict(width, height, lod_width, lod_height, mip_offsets (texels), texels (RGBA8, all levels))"""
+        lib = host_lib()
+        lib.grt_scene_texture_info.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        lib.grt_scene_texture_data.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        info = (ctypes.c_int * 6)()
+        if lib.grt_scene_texture_info(self.handle, index, info) != 0:
+            raise RuntimeError(lib.grt_last_error().decode(errors="replace"))
+        texels = np.zeros((info[5], 4), np.uint8); offsets = np.zeros(info[2], np.int32)
+        lib.grt_scene_texture_data(self.handle, index, texels.ctypes.data, offsets.ctypes.data)
+        return dict(width=info[0], height=info[1], lod_width=info[3], lod_height=info[4], mip_offsets=offsets, texels=texels)
+
+    def sky(self):
+        lib = host_lib()
+        lib.grt_scene_sky.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        out = np.zeros((lib.grt_scene_sky(self.handle, None), 4), np.float32)
+        lib.grt_scene_sky(self.handle, out.ctypes.data)
+        return out
+
     def set_camera(self, position, rotation, fov=-1.0):
         pos = (c_float * 3)(*position)
         rot = (c_float * 4)(*rotation)

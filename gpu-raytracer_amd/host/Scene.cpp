@@ -248,9 +248,11 @@ void AssetManager::wait_until_loaded() {
 				try { loaded = TextureLoader::load(job.filename, &texture); } catch (const std::exception &) { /* e.g. out of memory on a hostile header: fall back */ }
 				if (!loaded) {
 					fprintf(stderr, "WARNING: Failed to load Texture '%s'!\n", job.filename.c_str());
-					// 1x1 pink fallback (reference: AssetManager.cpp:157-169)
+					// 1x1 fallback (reference: AssetManager.cpp:157-169). The reference means it to be pink but stores the
+					// colour as a float4 in a texture it then uploads as RGBA8: the one texel the device gets is the first
+					// four bytes of the float 1.0f. Same texel here, so that a scene with a missing map renders alike.
 					texture.width = texture.height = 1;
-					texture.texels = { 255, 0, 255, 255 };
+					texture.texels = { 0x00, 0x00, 0x80, 0x3f };
 					texture.mip_offsets = { 0 };
 				}
 			}

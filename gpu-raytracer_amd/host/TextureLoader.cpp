@@ -6,7 +6,7 @@
 // levels are what the shade kernel filters.
 // Decoders: TGA (every type and depth stb_image reads) and binary PPM (P6) here, PNG / BMP /
 // DXT-compressed DDS in ImageDecoders.cpp, JPEG in JPEGDecoder.cpp; stb_image is not linked (PSD, GIF,
-// PIC and Radiance-HDR textures are not read: such a texture gets the reference's pink 1x1 fallback).
+// PIC and Radiance-HDR textures are not read: such a texture gets the reference's 1x1 fallback).
 #include "Scene.h"
 #include "ImageDecoders.h"
 #include "BlockCompression.h"

@@ -144,6 +144,68 @@ int grt_scene_set_material(void * scene, int index, int type, const float * diff
 }
 int grt_scene_material_type(void * scene, int index) { return int(((Scene *)scene)->asset_manager.materials[index].type); }
 
+// A line-per-object listing of what the loaders produced (camera, meshes, materials, media, texture names, sky size),
+// floats as bit patterns: `pathtracer`-independent way to diff two loads of a scene. Returns the length needed.
+static void describe_floats(std::string & s, const char * key, const float * v, int n) {
+	char buf[16];
+	s += ' '; s += key; s += '=';
+	for (int i = 0; i < n; i++) { unsigned bits; memcpy(&bits, v + i, 4); snprintf(buf, sizeof buf, i ? ",%08x" : "%08x", bits); s += buf; }
+}
+static void describe_int(std::string & s, const char * key, int v) { s += ' '; s += key; s += '='; s += std::to_string(v); }
+static void describe_str(std::string & s, const char * key, const std::string & v) { s += ' '; s += key; s += "=\""; s += v; s += '"'; }
+size_t grt_scene_describe(void * scene_handle, char * out, size_t capacity) {
+	Scene & scene = *(Scene *)scene_handle;
+	std::string s;
+	s += "config"; describe_int(s, "width", cpu_config.initial_width); describe_int(s, "height", cpu_config.initial_height); describe_int(s, "num_bounces", gpu_config.num_bounces); s += '\n';
+	s += "camera"; describe_floats(s, "position", &scene.camera.position.x, 3); describe_floats(s, "rotation", &scene.camera.rotation.x, 4); describe_floats(s, "fov", &scene.camera.fov, 1);
+	describe_floats(s, "aperture_radius", &scene.camera.aperture_radius, 1); describe_floats(s, "focal_distance", &scene.camera.focal_distance, 1); s += '\n';
+	for (size_t i = 0; i < scene.meshes.size(); i++) {
+		const Mesh & m = scene.meshes[i];
+		s += "mesh " + std::to_string(i); describe_str(s, "name", m.name); describe_int(s, "mesh_data", m.mesh_data_handle.handle); describe_int(s, "material", m.material_handle.handle);
+		describe_floats(s, "position", &m.position.x, 3); describe_floats(s, "rotation", &m.rotation.x, 4); describe_floats(s, "scale", &m.scale, 1); s += '\n';
+	}
+	for (size_t i = 0; i < scene.asset_manager.mesh_datas.size(); i++) {
+		s += "mesh_data " + std::to_string(i); describe_int(s, "triangles", int(scene.asset_manager.mesh_datas[i].triangles.size())); s += '\n';
+	}
+	for (size_t i = 0; i < scene.asset_manager.materials.size(); i++) {
+		const Material & m = scene.asset_manager.materials[i];
+		s += "material " + std::to_string(i); describe_str(s, "name", m.name); describe_int(s, "type", int(m.type)); describe_floats(s, "emission", &m.emission.x, 3); describe_floats(s, "diffuse", &m.diffuse.x, 3);
+		describe_int(s, "texture", m.texture_handle.handle); describe_int(s, "medium", m.medium_handle.handle); describe_floats(s, "ior", &m.index_of_refraction, 1);
+		describe_floats(s, "eta", &m.eta.x, 3); describe_floats(s, "k", &m.k.x, 3); describe_floats(s, "linear_roughness", &m.linear_roughness, 1); s += '\n';
+	}
+	for (size_t i = 0; i < scene.asset_manager.media.size(); i++) {
+		const Medium & m = scene.asset_manager.media[i];
+		s += "medium " + std::to_string(i); describe_str(s, "name", m.name); describe_floats(s, "C", &m.C.x, 3); describe_floats(s, "mfp", &m.mfp.x, 3); describe_floats(s, "g", &m.g, 1); s += '\n';
+	}
+	for (size_t i = 0; i < scene.asset_manager.textures.size(); i++) {
+		s += "texture " + std::to_string(i); describe_str(s, "name", scene.asset_manager.textures[i].name); s += '\n';
+	}
+	s += "sky"; describe_int(s, "width", scene.sky.width); describe_int(s, "height", scene.sky.height); s += '\n';
+	if (out && capacity) { size_t n = std::min(capacity - 1, s.size()); memcpy(out, s.data(), n); out[n] = 0; }
+	return s.size() + 1;
+}
+// One texture of the scene as the device will get it. info: width, height, mip levels, lod_width, lod_height, texel count
+int grt_scene_texture_info(void * scene, int texture, int * info6) {
+	GRT_TRY
+		const Texture & t = ((Scene *)scene)->asset_manager.textures.at(texture);
+		info6[0] = t.width; info6[1] = t.height; info6[2] = t.mip_levels(); info6[3] = t.lod_width; info6[4] = t.lod_height; info6[5] = int(t.texels.size() / 4);
+		return 0;
+	GRT_CATCH(-1)
+}
+int grt_scene_texture_data(void * scene, int texture, unsigned char * rgba8, int * mip_offsets_in_texels) {
+	GRT_TRY
+		const Texture & t = ((Scene *)scene)->asset_manager.textures.at(texture);
+		memcpy(rgba8, t.texels.data(), t.texels.size());
+		for (int i = 0; i < t.mip_levels(); i++) mip_offsets_in_texels[i] = int(t.mip_offsets[i]);
+		return 0;
+	GRT_CATCH(-1)
+}
+int grt_scene_sky(void * scene, float * out_rgba) {
+	const Sky & sky = ((Scene *)scene)->sky;
+	if (out_rgba) memcpy(out_rgba, sky.data.data(), sky.data.size() * sizeof(Vector4));
+	return int(sky.data.size());
+}
+
 // Triangles / BLAS of one MeshData, for the builder parity tests
 int grt_scene_mesh_data_count(void * scene) { return int(((Scene *)scene)->asset_manager.mesh_datas.size()); }
 int grt_scene_wait_until_loaded(void * scene) {

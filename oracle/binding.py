@@ -333,6 +333,84 @@ def ref_build_binary_variant(tris24, sbvh, collapse, sbvh_alpha=10e-5):
     return out
 
 
+_ref_scene = None
+
+
+def ref_scene_lib():
+    """oracle/_ref/libref_scene.so: the reference's scene-loading side compiled verbatim (None where it was not built)."""
+    global _ref_scene
+    if _ref_scene is None:
+        path = os.path.join(_HERE, "_ref", "libref_scene.so")
+        if not os.path.exists(path):
+            return None
+        r = ctypes.CDLL(path)
+        r.ref_scene_load.restype = ctypes.c_void_p
+        r.ref_scene_load.argtypes = [ctypes.c_char_p, ctypes.c_char_p] + [ctypes.c_int] * 4
+        r.ref_scene_free.argtypes = [ctypes.c_void_p]
+        r.ref_scene_description.restype = ctypes.c_char_p
+        r.ref_scene_description.argtypes = [ctypes.c_void_p]
+        r.ref_scene_triangles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        r.ref_scene_texture_info.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        r.ref_scene_texture_data.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        r.ref_scene_mesh_transform.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        r.ref_scene_sky.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        r.ref_load_mesh_file.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_float, ctypes.c_void_p]
+        _ref_scene = r
+    return _ref_scene
+
+
+class ReferenceScene:
+    """Scene::Scene + AssetManager::wait_until_loaded of the reference for one scene file. It writes `.bvh` caches next
+    to the meshes it loads: point it at a scratch copy."""
+
+    def __init__(self, filename, sky="", bvh_type=3, enable_block_compression=True, mipmap_filter=0, enable_mipmapping=True):
+        self.lib = ref_scene_lib()
+        self.h = self.lib.ref_scene_load(filename.encode(), sky.encode(), bvh_type, int(enable_block_compression), mipmap_filter, int(enable_mipmapping))
+        self.description = self.lib.ref_scene_description(self.h).decode(errors="replace")
+
+    def close(self):
+        if self.h:
+            self.lib.ref_scene_free(self.h); self.h = None
+
+    def count(self, kind):
+        return sum(1 for line in self.description.splitlines() if line.startswith(kind + " "))
+
+    def triangles(self, mesh_data):
+        n = self.lib.ref_scene_triangles(self.h, mesh_data, None)
+        out = np.zeros((n, 24), np.float32)
+        self.lib.ref_scene_triangles(self.h, mesh_data, out.ctypes.data)
+        return out
+
+    def texture(self, index):
+        """-> dict(format 0..3 = BC1, BC2, BC3, RGBA; channels, width, height, mip_offsets (bytes), data)"""
+        info = (ctypes.c_int * 6)()
+        self.lib.ref_scene_texture_info(self.h, index, info)
+        data = np.zeros(info[5], np.uint8); offsets = np.zeros(info[4], np.int32)
+        self.lib.ref_scene_texture_data(self.h, index, data.ctypes.data, offsets.ctypes.data)
+        return dict(format=info[0], channels=info[1], width=info[2], height=info[3], mip_offsets=offsets, data=data)
+
+    def mesh_transform(self, mesh):
+        out = np.zeros((3, 16), np.float32)
+        self.lib.ref_scene_mesh_transform(self.h, mesh, out.ctypes.data)
+        return out
+
+    def sky(self):
+        n = self.lib.ref_scene_sky(self.h, None)
+        out = np.zeros((n, 4), np.float32)
+        self.lib.ref_scene_sky(self.h, out.ctypes.data)
+        return out
+
+
+def ref_load_mesh_file(kind, filename, arg=0.0):
+    """The reference's mesh loaders on their own. kind: "obj", "ply", "serialized" (arg = shape index), "hair" (arg = radius)."""
+    r = ref_scene_lib()
+    k = ("obj", "ply", "serialized", "hair").index(kind)
+    n = r.ref_load_mesh_file(k, filename.encode(), float(arg), None)
+    out = np.zeros((n, 24), np.float32)
+    r.ref_load_mesh_file(k, filename.encode(), float(arg), out.ctypes.data)
+    return out
+
+
 def ref_build_optimized(tris24, sbvh, max_batches):
     """BVH::create_from_triangles with enable_bvh_optimization, limited to `max_batches` (+1) batches, and the BVH8
     (SAH only) / BVH4 converted from the optimised tree."""

@@ -8,7 +8,10 @@
 #include <csignal>
 #include <cmath>
 #include <new>
-#define __debugbreak() raise(SIGTRAP)
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#define __debugbreak() (fflush(stdout), raise(SIGTRAP))
 #define __forceinline __attribute__((always_inline))
 typedef int errno_t;
 static inline errno_t fopen_s(FILE ** f, const char * name, const char * mode) { *f = fopen(name, mode); return *f ? 0 : errno; }

@@ -293,7 +293,7 @@ def test_sponza_texture_path_albedo_normal_position_aovs(grt, oracle):
     for aov in (grt.AOV_ALBEDO, grt.AOV_NORMAL, grt.AOV_POSITION):
         pt.aov_enable(aov)
     pt.update()
-    assert sum(1 for t in pt.textures() if t[0].size > 4) == 19   # the real maps are loaded, not the pink fallback
+    assert sum(1 for t in pt.textures() if t[0].size > 4) == 19   # the real maps are loaded, not the 1x1 fallback
     view = oracle.SceneView(pt)
     frame = oracle.Frame(view)
     pt.render()
