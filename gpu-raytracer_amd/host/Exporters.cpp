@@ -14,27 +14,28 @@ struct File {
 
 inline float clamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-// float -> IEEE half, round to nearest even; overflow to infinity, NaN stays NaN
+// float -> IEEE half the way the reference's tinyexr does it (tinyexr.h float_to_half_full): the first dropped bit
+// alone decides the rounding -- ties go away from zero, not to even --, float subnormals flush to zero, values beyond
+// the half range become infinity, every NaN becomes the quiet NaN 0x7e00
 uint16_t float_to_half(float value) {
 	uint32_t bits; memcpy(&bits, &value, 4);
 	uint32_t sign = (bits >> 16) & 0x8000u;
-	int32_t  exponent = int32_t((bits >> 23) & 0xff) - 127 + 15;
+	uint32_t biased = (bits >> 23) & 0xff;
 	uint32_t mantissa = bits & 0x7fffffu;
 
-	if (((bits >> 23) & 0xff) == 0xff) return uint16_t(sign | 0x7c00u | (mantissa ? 0x200u | (mantissa >> 13) : 0u));
+	if (biased == 0)    return uint16_t(sign);
+	if (biased == 0xff) return uint16_t(sign | 0x7c00u | (mantissa ? 0x200u : 0u));
+	int32_t exponent = int32_t(biased) - 127 + 15;
 	if (exponent >= 31) return uint16_t(sign | 0x7c00u);
 	if (exponent <= 0) {
-		if (exponent < -10) return uint16_t(sign); // below half the smallest subnormal
-		mantissa |= 0x800000u;                     // make the leading one explicit, then shift it into place
-		int shift = 14 - exponent;
-		uint32_t half = mantissa >> shift;
-		uint32_t rest = mantissa & ((1u << shift) - 1u), tie = 1u << (shift - 1);
-		if (rest > tie || (rest == tie && (half & 1u))) half++;
+		if (14 - exponent > 24) return uint16_t(sign); // nothing of the mantissa is left
+		mantissa |= 0x800000u;                         // make the leading one explicit, then shift it into place
+		uint32_t half = mantissa >> (14 - exponent);
+		if ((mantissa >> (13 - exponent)) & 1u) half++;
 		return uint16_t(sign | half);
 	}
 	uint32_t half = (uint32_t(exponent) << 10) | (mantissa >> 13);
-	uint32_t rest = mantissa & 0x1fffu;
-	if (rest > 0x1000u || (rest == 0x1000u && (half & 1u))) half++; // may carry into the exponent, which is the right result
+	if (mantissa & 0x1000u) half++; // may carry into the exponent, up to infinity
 	return uint16_t(sign | half);
 }
 

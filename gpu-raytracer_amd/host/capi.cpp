@@ -344,6 +344,15 @@ int grt_export_image(const char * filename, int pitch, int width, int height, co
 		return 0;
 	GRT_CATCH(-1)
 }
+// PPMExporter::save on its own: `rgb` is already in display space (no tone mapping)
+int grt_export_ppm_display(const char * filename, int pitch, int width, int height, const float * rgb) {
+	GRT_TRY
+		std::vector<Vector3> data(size_t(pitch) * height);
+		memcpy((void *)data.data(), rgb, data.size() * sizeof(Vector3));
+		if (!PPMExporter::save(filename, pitch, width, height, data)) throw std::runtime_error(std::string("failed to write '") + filename + "'");
+		return 0;
+	GRT_CATCH(-1)
+}
 int grt_pathtracer_read_framebuffer(void * pt, float * dst) {
 	GRT_TRY
 		std::vector<float> image = as_integrator(pt)->read_framebuffer();

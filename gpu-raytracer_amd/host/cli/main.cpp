@@ -32,6 +32,7 @@ struct CommandLine {
 	int  device = 0;
 	int  batch  = 4;
 	bool help   = false;
+	bool print_config = false;
 };
 
 [[noreturn]] void die(const std::string & message) {
@@ -108,6 +109,7 @@ std::vector<Option> make_options(CommandLine & cl) {
 		cl.batch = parse_int(v, "--batch");
 		if (cl.batch < 1 || cl.batch > 16) die("--batch must be between 1 and 16");
 	} });
+	o.push_back({ nullptr, "print-config", "Prints the configuration the command line amounts to and exits", 0, [&cl](const char *) { cl.print_config = true; } });
 	o.push_back({ "h", "help", "Displays this message", 0, [&cl](const char *) { cl.help = true; } });
 	return o;
 }
@@ -140,13 +142,27 @@ void parse_command_line(int argc, char ** argv, CommandLine & cl) {
 		}
 		if (i + match->argument_count >= argc) {
 			printf("Not enough arguments provided to option '%s'!\n", match->long_name);
-			return;
+			break; // the reference stops parsing here
 		}
 		match->apply(match->argument_count ? argv[i + 1] : nullptr);
 		i += match->argument_count;
 	}
 	if (cl.help) {
 		print_help(options);
+		exit(0);
+	}
+	if (cl.print_config) { // one line, floats as bit patterns; the form oracle/ref/ref_scene_harness.cpp writes for the reference's Args::parse
+		auto bits = [](float f) { unsigned u; memcpy(&u, &f, 4); return u; };
+		std::string scenes;
+		for (const std::string & s : cpu_config.scene_filenames) { if (!scenes.empty()) scenes += '|'; scenes += s; }
+		printf("integrator=%d width=%d height=%d num_bounces=%d samples=%d output=\"%s\" scenes=\"%s\" sky=\"%s\" bvh_type=%d nee=%d mis=%d force_rebuild=%d "
+		       "optimize=%d opt_time=%d opt_batches=%d sah_node=%08x sah_leaf=%08x sbvh_alpha=%08x mipmap=%d mip_filter=%d compress=%d\n",
+		       int(cpu_config.integrator), cpu_config.initial_width, cpu_config.initial_height, gpu_config.num_bounces, cpu_config.output_sample_index,
+		       cpu_config.output_filename.c_str(), scenes.c_str(), cpu_config.sky_filename.c_str(), int(cpu_config.bvh_type),
+		       int(gpu_config.enable_next_event_estimation), int(gpu_config.enable_multiple_importance_sampling), int(cpu_config.bvh_force_rebuild),
+		       int(cpu_config.enable_bvh_optimization), cpu_config.bvh_optimizer_max_time, cpu_config.bvh_optimizer_max_num_batches,
+		       bits(cpu_config.sah_cost_node), bits(cpu_config.sah_cost_leaf), bits(cpu_config.sbvh_alpha), int(gpu_config.enable_mipmapping),
+		       int(cpu_config.mipmap_filter), int(cpu_config.enable_block_compression));
 		exit(0);
 	}
 }

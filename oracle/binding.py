@@ -401,6 +401,26 @@ class ReferenceScene:
         return out
 
 
+def ref_export_image(filename, image, pitch=None):
+    """PPMExporter::save (.ppm, display-space values) / EXRExporter::save (.exr) of the reference; image: (h, w, 3) float32, row 0 at the bottom."""
+    r = ref_scene_lib()
+    h, w, _ = image.shape
+    pitch = pitch or w
+    buf = np.zeros((h, pitch, 3), np.float32); buf[:, :w] = image
+    r.ref_export_image.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    r.ref_export_image(0 if str(filename).endswith(".ppm") else 1, str(filename).encode(), pitch, w, h, buf.ctypes.data)
+
+
+def ref_args_parse(arguments):
+    """Args::parse of the reference on fresh configurations -> one line in the form of `pathtracer --print-config`."""
+    r = ref_scene_lib()
+    argv = (ctypes.c_char_p * (len(arguments) + 1))(b"pathtracer", *[a.encode() for a in arguments])
+    out = ctypes.create_string_buffer(4096)
+    r.ref_args_parse.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_char_p, ctypes.c_int]
+    r.ref_args_parse(len(arguments) + 1, argv, out, 4096)
+    return out.value.decode(errors="replace")
+
+
 def ref_load_mesh_file(kind, filename, arg=0.0):
     """The reference's mesh loaders on their own. kind: "obj", "ply", "serialized" (arg = shape index), "hair" (arg = radius)."""
     r = ref_scene_lib()

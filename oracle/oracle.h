@@ -6,8 +6,8 @@
  *
  * Parity status: the reference ships no tests or golden vectors for this path and its
  * device code (CUDA + PTX, NVRTC) cannot run on a GPU here. The oracle is
- *   (i)   fed by node / triangle data that the reference's own BVH builder, compiled verbatim
- *         (oracle/_ref), reproduces byte for byte;
+ *   (i)   fed by scene data that the reference's own loaders and BVH builders, compiled verbatim
+ *         (oracle/_ref/libref_scene.so, libref_bvh.so), reproduce bit for bit;
  *   (ii)  a line-by-line restatement of CUDA/Raytracing/{BVH8,BVH2,BVH4,Triangle,Mesh,BVH}.h,
  *         CUDA/{Camera,Sampling,Util,Buffers,AOV,Sky,Medium,RayCone,Material,BSDF,KullaConty}.h,
  *         CUDA/Pathtracer.cu and CUDA/SVGF/{SVGF,TAA}.h (each function cites its source);

@@ -148,6 +148,36 @@ EXPORT int ref_scene_sky(void * h, float * out) {
 	return int(sky.data.size());
 }
 
+// PPMExporter::save (kind 0, values already in display space) / EXRExporter::save (kind 1) of an RGB float image
+EXPORT void ref_export_image(int kind, const char * filename, int pitch, int width, int height, const float * rgb) {
+	MuteStdout mute;
+	Array<Vector3> data(size_t(pitch) * height);
+	memcpy((void *)data.data(), rgb, data.size() * sizeof(Vector3));
+	if (kind == 0) PPMExporter::save(String(filename), pitch, width, height, data);
+	else           EXRExporter::save(String(filename), pitch, width, height, data);
+}
+
+// Args::parse (Args.cpp:51-184) on fresh configurations -> the one-line form `pathtracer --print-config` writes
+EXPORT void ref_args_parse(int argc, char ** argv, char * out, int capacity) {
+	MuteStdout mute;
+	cpu_config = CPUConfig { };
+	gpu_config = GPUConfig { };
+	cpu_config.scene_filenames.clear();
+	Args::parse(argc, argv);
+	auto bits = [](float f) { unsigned u; memcpy(&u, &f, 4); return u; };
+	std::string scenes;
+	for (size_t i = 0; i < cpu_config.scene_filenames.size(); i++) { if (i) scenes += '|'; scenes.append(cpu_config.scene_filenames[i].data(), cpu_config.scene_filenames[i].size()); }
+	std::string output(cpu_config.output_filename.data(), cpu_config.output_filename.size()), sky(cpu_config.sky_filename.data(), cpu_config.sky_filename.size());
+	snprintf(out, capacity, "integrator=%d width=%d height=%d num_bounces=%d samples=%d output=\"%s\" scenes=\"%s\" sky=\"%s\" bvh_type=%d nee=%d mis=%d force_rebuild=%d "
+	         "optimize=%d opt_time=%d opt_batches=%d sah_node=%08x sah_leaf=%08x sbvh_alpha=%08x mipmap=%d mip_filter=%d compress=%d\n",
+	         int(cpu_config.integrator), cpu_config.initial_width, cpu_config.initial_height, gpu_config.num_bounces, cpu_config.output_sample_index,
+	         output.c_str(), scenes.c_str(), sky.c_str(), int(cpu_config.bvh_type),
+	         int(gpu_config.enable_next_event_estimation), int(gpu_config.enable_multiple_importance_sampling), int(cpu_config.bvh_force_rebuild),
+	         int(cpu_config.enable_bvh_optimization), cpu_config.bvh_optimizer_max_time, cpu_config.bvh_optimizer_max_num_batches,
+	         bits(cpu_config.sah_cost_node), bits(cpu_config.sah_cost_leaf), bits(cpu_config.sbvh_alpha), int(gpu_config.enable_mipmapping),
+	         int(cpu_config.mipmap_filter), int(cpu_config.enable_block_compression));
+}
+
 // The mesh loaders on their own: kind 0 OBJLoader::load, 1 PLYLoader::load, 2 SerializedLoader::load(shape_index = arg),
 // 3 MitshairLoader::load(radius = arg). Returns the triangle count; call with out24 = NULL first.
 EXPORT int ref_load_mesh_file(int kind, const char * filename, float arg, float * out24) {

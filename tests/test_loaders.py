@@ -301,9 +301,10 @@ def test_bvh_cache_files_follow_the_reference_format(grt, tmp_path):
     pt.close(); scene.close(); grt.config_reset()
 
 
-def _ply_bytes(fmt, positions, normals, uvs, faces, index_type="int", with_extras=False):
+def _ply_bytes(fmt, positions, normals, uvs, faces, index_type="int", with_extras=False, face_extras=None):
     """Serialises a mesh as PLY in one of the three encodings (an independent writer for the reader under test)."""
     import struct
+    face_extras = with_extras if face_extras is None else face_extras
     header = ["ply", "format %s 1.0" % fmt, "comment made by the test", "element vertex %d" % len(positions),
               "property float x", "property float y", "property float z"]
     if normals is not None:
@@ -313,12 +314,12 @@ def _ply_bytes(fmt, positions, normals, uvs, faces, index_type="int", with_extra
     if uvs is not None:
         header += ["property double s", "property double t"]
     header += ["element face %d" % len(faces), "property list uchar %s vertex_indices" % index_type]
-    if with_extras:
+    if face_extras:
         header += ["property short flags"]
     header += ["end_header"]
     out = ("\n".join(header) + "\n").encode()
     e = "<" if fmt == "binary_little_endian" else ">"
-    icode = {"int": "i", "uint": "I", "ushort": "H"}[index_type]
+    icode = {"int": "i", "uint": "I", "ushort": "H", "uchar": "B"}[index_type]
     for v in range(len(positions)):
         if fmt == "ascii":
             vals = list(positions[v]) + (list(normals[v]) if normals is not None else []) + ([200] if with_extras else []) + (list(uvs[v]) if uvs is not None else [])
@@ -330,10 +331,10 @@ def _ply_bytes(fmt, positions, normals, uvs, faces, index_type="int", with_extra
             if uvs is not None: out += struct.pack(e + "2d", *uvs[v])
     for f in faces:
         if fmt == "ascii":
-            out += ("%d %s%s\n" % (len(f), " ".join(map(str, f)), " 3" if with_extras else "")).encode()
+            out += ("%d %s%s\n" % (len(f), " ".join(map(str, f)), " 3" if face_extras else "")).encode()
         else:
             out += struct.pack("B", len(f)) + struct.pack(e + "%d%s" % (len(f), icode), *f)
-            if with_extras: out += struct.pack(e + "h", 3)
+            if face_extras: out += struct.pack(e + "h", 3)
     return out
 
 
@@ -451,7 +452,7 @@ def test_exporters_write_the_reference_file_formats(grt, tmp_path):
     channels, image = _parse_exr(tmp_path / "a.exr")
     assert channels == [("B", 1), ("G", 1), ("R", 1)]
     with np.errstate(over="ignore"):
-        want16 = img[::-1].astype(np.float16).astype(np.float32)      # numpy rounds to nearest even as well
+        want16 = img[::-1].astype(np.float16).astype(np.float32)      # (no ties in this image: tinyexr rounds those away from zero, numpy to even)
     for k, name in enumerate("RGB"):
         assert np.array_equal(image[name], want16[:, :, k]), name
     assert np.isinf(image["B"][h - 1, 0]) and image["R"][h - 1, 0] == -1.0

@@ -244,3 +244,185 @@ def test_sensor_variants_and_mip_filters_load_like_the_reference(grt, oracle, tm
         for block_compression in (1, 0):
             assert_same_scene(grt, oracle, xml, sky, enable_block_compression=block_compression, mipmap_filter=mipmap_filter)
     assert_same_scene(grt, oracle, xml, sky, enable_mipmapping=0)
+
+
+def test_bvh_caches_are_interchangeable_with_the_references(grt, oracle, tmp_path):
+    """`<mesh>.bvh` (BVHLoader.cpp:19-249): the files the reference writes carry the same header and the same payload --
+    triangles, BVHNode2s, indices -- as ours; it loads ours without rebuilding, and we load its."""
+    from test_loaders import _read_bvh_cache
+    if oracle.ref_scene_lib() is None:
+        pytest.skip("oracle/_ref/libref_scene.so not built (no /root/reference on this machine)")
+    rng = np.random.default_rng(8)
+    n = 400
+    p0 = rng.random((n, 3)) * 4; p1 = p0 + rng.random((n, 3)) * 3 - 1.5; p2 = p0 + rng.random((n, 3)) * 0.4
+
+    def write_obj(directory):
+        directory.mkdir()
+        with open(directory / "m.obj", "w") as f:
+            for a, b, c in zip(p0, p1, p2):
+                f.write("v %.6f %.6f %.6f\nv %.6f %.6f %.6f\nv %.6f %.6f %.6f\n" % (*a, *b, *c))
+            for i in range(n):
+                f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+        (directory / "s.xml").write_text('<scene version="0.5.0"><shape type="obj"><string name="filename" value="m.obj"/></shape></scene>')
+        return directory / "s.xml", str(directory / "m.obj") + ".bvh"
+
+    sky = write_sky(tmp_path / "sky.hdr")
+    for bvh_type, name in ((3, "bvh8"), (0, "sah"), (1, "sbvh")):          # the reference's BVHType order: BVH, SBVH, BVH4, BVH8
+        theirs_xml, theirs_cache = write_obj(tmp_path / ("theirs_" + name))
+        ours_xml, ours_cache = write_obj(tmp_path / ("ours_" + name))
+
+        ref = oracle.ReferenceScene(str(theirs_xml), sky=sky, bvh_type=bvh_type); ref.close()      # writes theirs
+        grt.config_reset(); grt.config_set(bvh_type=name, enable_bvh_cache=1)
+        scene = grt.Scene(str(ours_xml), sky=sky); pt = grt.Pathtracer(scene, 8, 8, device=-1)      # writes ours
+        built = {k: scene.mesh_data_array(0, k, dt).copy() for k, dt in (("triangles", np.float32), ("bvh2_nodes", np.uint8), ("bvh2_indices", np.int32))}
+        pt.close(); scene.close()
+
+        a, b = _read_bvh_cache(theirs_cache), _read_bvh_cache(ours_cache)
+        assert all(a[k] == b[k] for k in ("ident", "version", "bvh_type", "optimized", "cost_node", "cost_leaf")), name
+        assert all(np.array_equal(a[k], b[k]) for k in ("triangles", "nodes", "indices")), name
+        assert a["bvh_type"] == (1 if name == "sbvh" else 0)
+
+        # the reference accepts our file: it neither rebuilds nor rewrites it, and ends up with our triangles
+        before = (os.stat(ours_cache).st_mtime_ns, open(ours_cache, "rb").read())
+        ref = oracle.ReferenceScene(str(ours_xml), sky=sky, bvh_type=bvh_type)
+        assert np.array_equal(ref.triangles(0), b["triangles"]); ref.close()
+        assert (os.stat(ours_cache).st_mtime_ns, open(ours_cache, "rb").read()) == before
+
+        # and we accept the reference's: mark one coordinate in its file (recompressed here) and see it arrive
+        from test_loaders import _write_bvh_cache
+        marked = dict(a); marked["triangles"] = a["triangles"].copy(); marked["triangles"][7, 1] += 0.25
+        raw_reference_file = open(theirs_cache, "rb").read()
+        grt.config_reset(); grt.config_set(bvh_type=name, enable_bvh_cache=1)
+        scene = grt.Scene(str(theirs_xml), sky=sky); scene.wait_until_loaded()                     # reads the reference's own bytes
+        assert np.array_equal(scene.mesh_data_array(0, "triangles", np.float32).reshape(-1, 24), a["triangles"])
+        scene.close()
+        assert open(theirs_cache, "rb").read() == raw_reference_file                                # loaded, not rebuilt and saved again
+        _write_bvh_cache(theirs_cache, marked)
+        scene = grt.Scene(str(theirs_xml), sky=sky); scene.wait_until_loaded()
+        assert scene.mesh_data_array(0, "triangles", np.float32).reshape(-1, 24)[7, 1] == marked["triangles"][7, 1]
+        scene.close()
+    grt.config_reset()
+
+
+def test_exporters_write_the_same_files_as_the_references(grt, oracle, tmp_path):
+    """PPMExporter.cpp / EXRExporter.cpp (tinyexr with the reference's zero-initialised header): same bytes."""
+    import ctypes
+    if oracle.ref_scene_lib() is None:
+        pytest.skip("oracle/_ref/libref_scene.so not built (no /root/reference on this machine)")
+    rng = np.random.default_rng(12)
+    lib = grt.host_lib()
+    lib.grt_export_ppm_display.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    for h, w in ((5, 7), (1, 1), (33, 64), (130, 17)):
+        img = (rng.random((h, w, 3)) * 3 - 0.5).astype(np.float32)
+        img[0, 0] = (-1.0, 0.0, 70000.0)                  # negative, zero, beyond the half range
+        img[h - 1, w - 1] = (1e-8, 6.1e-5, 0.333)         # flushes to zero, the smallest normal half, an inexact value
+        oracle.ref_export_image(tmp_path / "ref.exr", img)
+        grt.export_image(tmp_path / "ours.exr", img)
+        assert open(tmp_path / "ref.exr", "rb").read() == open(tmp_path / "ours.exr", "rb").read(), (h, w)
+        oracle.ref_export_image(tmp_path / "ref.ppm", img)
+        assert lib.grt_export_ppm_display(str(tmp_path / "ours.ppm").encode(), w, w, h, np.ascontiguousarray(img).ctypes.data) == 0
+        assert open(tmp_path / "ref.ppm", "rb").read() == open(tmp_path / "ours.ppm", "rb").read(), (h, w)
+
+
+def test_command_lines_configure_like_the_references_argument_parser(grt, oracle):
+    """Args.cpp:51-184 against `pathtracer --print-config`: short and long names, `-b` meaning bounces (the reference
+    gives --bvh the same short name, after --bounce), bare arguments as scene files, boolean spellings, unknown options
+    skipped, the bounce count clamped. (-c and -S are always given: those two defaults differ, see DESIGN.md.)"""
+    import subprocess
+    if oracle.ref_scene_lib() is None:
+        pytest.skip("oracle/_ref/libref_scene.so not built (no /root/reference on this machine)")
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-raytracer_amd", "host", "pathtracer")
+    common = ["-c", "true", "-S", "sky.hdr"]
+    cases = [
+        ["a.xml"],
+        ["-s", "a.xml", "b.obj", "--scene", "c.ply"],
+        ["-W", "640", "-H", "360", "-b", "5", "-N", "16", "-o", "out.exr", "a.xml"],
+        ["--width", "33", "--height", "17", "--bounce", "1000", "--samples", "0", "--output", "x.ppm", "a.xml"],
+        ["--bounce", "-3", "a.xml"],
+        ["-I", "ao", "a.xml"], ["--integrator", "pathtracer", "a.xml"],
+        ["--bvh", "sah", "a.xml"], ["--bvh", "sbvh", "a.xml"], ["--bvh", "bvh4", "a.xml"], ["--bvh", "bvh8", "a.xml"],
+        ["--nee", "false", "--mis", "0", "a.xml"], ["--nee", "TRUE", "--mis", "False", "a.xml"], ["--nee", "maybe", "a.xml"],
+        ["--force-rebuild", "a.xml"],
+        ["-O", "true", "-Ot", "1500", "-Ob", "7", "a.xml"], ["--optimize", "1", "--opt-time", "20", "--opt-batches", "3", "a.xml"],
+        ["--sah-node", "2.5", "--sah-leaf", "0.75", "--sbvh-alpha", "0.001", "a.xml"], ["--sbvh-alpha", "1e-3", "a.xml"],
+        ["--mipmap", "false", "--mip-filter", "kaiser", "a.xml"], ["--mip-filter", "lanczos", "a.xml"], ["--mip-filter", "box", "a.xml"],
+        ["--frobnicate", "-x", "a.xml", "--width"],
+        ["-c", "false", "a.xml"], ["--compress", "0", "a.xml"],
+        ["-Ot", "5", "-O", "false", "a.xml", "-W", "12"],
+    ]
+    for arguments in cases:
+        arguments = common + arguments
+        ours = subprocess.run([cli, "--print-config", *arguments], capture_output=True, text=True, timeout=60)
+        assert ours.returncode == 0, (arguments, ours.stderr)
+        assert ours.stdout.splitlines()[-1] + "\n" == oracle.ref_args_parse(arguments), arguments
+
+
+def product_mesh_file(grt, path, xml=None):
+    grt.config_reset()
+    scene = grt.Scene(str(xml or path)); scene.wait_until_loaded()
+    tris = scene.mesh_data_array(0, "triangles", np.float32).reshape(-1, 24).copy()
+    scene.close()
+    return tris
+
+
+def test_mesh_file_loaders_equal_the_references(grt, oracle, tmp_path, monkeypatch):
+    """OBJLoader / PLYLoader / SerializedLoader / MitshairLoader on their own, on files that lean on their corners:
+    OBJ with negative and partial indices, polygons, missing normals, odd whitespace and comments; PLY in all three
+    encodings with and without normals, extra properties and short index types; serialized archives of both dictionary
+    widths, single and double precision; ascii and binary hair."""
+    if oracle.ref_scene_lib() is None:
+        pytest.skip("oracle/_ref/libref_scene.so not built (no /root/reference on this machine)")
+    monkeypatch.chdir(tmp_path)              # relative names: the ribbon angle of a hair file is seeded from its file name
+    rng = np.random.default_rng(31)
+
+    (tmp_path / "a.obj").write_text(
+        "# comment\n\nv 0 0 0\nv 1 0 0\nv   0 1 0  \nv 1 1 0.5\nv 2 1 0.25\nv -1.5e0 2 1\n"
+        "vt 0 0\nvt 1 0\nvt 0 1\nvt 0.25 0.75\nvn 0 0 1\nvn 0 1 0\nvn 1 0 0\n"
+        "o thing\ng part\nusemtl none\ns off\n"
+        "f 1/1/1 2/2/1 3/3/1\nf 2 4 3\nf -1 -2 -3 -4\nf 1//2 2//2 4//3 5//1 6//2\nf 1/1 2/2 4/4\nf 3/3/3 2/2/2 1/1/1\n")
+    n = 200
+    p = rng.random((n, 3, 3)) * 4
+    with open(tmp_path / "b.obj", "w") as f:
+        for t in p:
+            for v in t: f.write("v %.7g %.7g %.7g\n" % tuple(v))
+        for i in range(n): f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+    for name in ("a.obj", "b.obj"):
+        assert np.array_equal(oracle.ref_load_mesh_file("obj", name), product_mesh_file(grt, name), equal_nan=True), name
+
+    positions = np.round(rng.random((9, 3)) * 4 - 2, 3).astype(np.float32)
+    normals = rng.random((9, 3)).astype(np.float32); normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    uvs = np.round(rng.random((9, 2)), 3)
+    faces = [[0, 1, 2], [2, 3, 4, 5], [1, 6, 5, 4, 3], [6, 7, 8]]
+    for fmt in ("ascii", "binary_little_endian", "binary_big_endian"):
+        for variant, (with_normals, extras, index_type) in enumerate(((True, False, "int"), (False, True, "ushort" if fmt != "ascii" else "uint"), (True, True, "uchar" if fmt != "ascii" else "int"))):
+            name = "m_%s_%d.ply" % (fmt, variant)
+            # (extra properties on vertices only: the reference stops reading a face at the first property that is not the
+            # index list, which ends an ascii load with an error and silently desynchronises a binary one)
+            (tmp_path / name).write_bytes(_ply_bytes(fmt, positions, normals if with_normals else None, uvs, faces, index_type, extras, face_extras=False))
+            assert np.array_equal(oracle.ref_load_mesh_file("ply", name), product_mesh_file(grt, name), equal_nan=True), name
+
+    quad = dict(name="quad", positions=[[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], normals=[[0, 0, 1]] * 4, uvs=[[0, 0], [1, 0], [1, 1], [0, 1]],
+                colours=[[1, 0, 0]] * 4, faces=[[0, 1, 2], [0, 2, 3]])
+    fan = dict(name="fan", positions=np.round(rng.random((5, 3)) * 2, 3), faces=[[0, 1, 2], [0, 2, 3], [0, 3, 4]], face_normals=True)
+    soup_positions = rng.random((60, 3)) * 3
+    soup = dict(name="soup", positions=soup_positions, normals=rng.random((60, 3)) - 0.5, faces=[[3 * i, 3 * i + 1, 3 * i + 2] for i in range(20)])
+    for version in (3, 4):
+        for double in ((False, True) if version > 3 else (False,)):          # version 3 archives are single precision by definition
+            meshes = [dict(m, double=double) for m in (quad, fan, soup)]
+            name = "meshes_v%d_%d.serialized" % (version, double)
+            (tmp_path / name).write_bytes(_serialized_archive(meshes, version))
+            for index in range(3):
+                xml = tmp_path / "s.xml"
+                xml.write_text('<scene version="0.5.0"><shape type="serialized"><string name="filename" value="%s"/><integer name="shapeIndex" value="%d"/></shape></scene>' % (name, index))
+                assert np.array_equal(oracle.ref_load_mesh_file("serialized", name, index), product_mesh_file(grt, name, "s.xml"), equal_nan=True), (name, index)
+
+    strands = [np.cumsum(rng.random((k, 3)).astype(np.float32) * 0.3, axis=0) for k in (4, 1, 3, 2, 9)]
+    ascii_hair = "".join("".join("%.6g %.6g %.6g\n" % tuple(v) for v in s) + "\n" for s in strands).encode()
+    binary_hair = b"BINARY_HAIR" + struct.pack("<I", sum(len(s) for s in strands)) + b"".join(s.tobytes() + struct.pack("<f", np.inf) for s in strands)
+    for name, data in (("a.hair", ascii_hair), ("b.hair", binary_hair)):
+        (tmp_path / name).write_bytes(data)
+        for radius in (0.05, 0.5):
+            xml = tmp_path / "h.xml"
+            xml.write_text('<scene version="0.5.0"><shape type="hair"><string name="filename" value="%s"/><float name="radius" value="%g"/></shape></scene>' % (name, radius))
+            # ("./": the name as the Mitsuba loader composes it from the scene's directory, which is what seeds the ribbon angle)
+            assert np.array_equal(oracle.ref_load_mesh_file("hair", "./" + name, radius), product_mesh_file(grt, name, "h.xml"), equal_nan=True), (name, radius)
