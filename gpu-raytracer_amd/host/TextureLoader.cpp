@@ -273,6 +273,11 @@ bool TextureLoader::load(const std::string & filename, Texture * texture) {
 	// conversion, no re-filtering (reference: TextureLoader.cpp:19-106)
 	std::vector<std::vector<unsigned char>> dds_levels;
 	if (ImageDecoders::decode_dds(file, width, height, dds_levels)) {
+		// The reference walks the chain by halving the BLOCK counts and stops when one reaches zero (:92-104): levels
+		// narrower or lower than one full block of the previous halving -- the 2x2 and 1x1 tail -- are never used
+		size_t kept = 0;
+		for (int bw = (width + 3) / 4, bh = (height + 3) / 4; kept < dds_levels.size() && bw > 0 && bh > 0; bw /= 2, bh /= 2) kept++;
+		dds_levels.resize(std::max<size_t>(kept, 1));
 		if (!gpu_config.enable_mipmapping) dds_levels.resize(1);
 		texture->width  = width;
 		texture->height = height;

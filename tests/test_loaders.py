@@ -708,14 +708,13 @@ def test_png_bmp_and_dds_textures_decode(grt, tmp_path):
     assert len(header) == 128
     (tmp_path / "t.dds").write_bytes(header + blocks)
     levels = grt.load_texture(tmp_path / "t.dds")
-    assert [l.shape for l in levels] == [(4, 8, 4), (2, 4, 4)]
+    assert [l.shape for l in levels] == [(4, 8, 4)]      # the 4x2 level is stored but never used: the reference halves the block counts (2x1 -> 1x0) and stops at zero
     e0, e1 = expand(c0), expand(c1)
     four = [e0, e1, (2 * e0 + e1 + 1) // 3, (e0 + 2 * e1 + 1) // 3]
     three = [e1, e0, (e0 + e1) // 2, np.zeros(3, int)]
     for i in range(16):
         assert np.array_equal(levels[0][i // 4, i % 4, :3], four[idx0[i]]) and levels[0][i // 4, i % 4, 3] == 255
         assert np.array_equal(levels[0][i // 4, 4 + i % 4, :3], three[idx1[i]]) and levels[0][i // 4, 4 + i % 4, 3] == (0 if idx1[i] == 3 else 255)
-    assert (levels[1][:, :, :3] == e0).all()
     # DXT5: interpolated alpha; DXT3: explicit 4-bit alpha
     alpha_idx = rng.integers(0, 8, 16)
     a_bits = sum(int(v) << (3 * i) for i, v in enumerate(alpha_idx))

@@ -426,3 +426,26 @@ def test_mesh_file_loaders_equal_the_references(grt, oracle, tmp_path, monkeypat
             xml.write_text('<scene version="0.5.0"><shape type="hair"><string name="filename" value="%s"/><float name="radius" value="%g"/></shape></scene>' % (name, radius))
             # ("./": the name as the Mitsuba loader composes it from the scene's directory, which is what seeds the ribbon angle)
             assert np.array_equal(oracle.ref_load_mesh_file("hair", "./" + name, radius), product_mesh_file(grt, name, "h.xml"), equal_nan=True), (name, radius)
+
+
+def test_dds_textures_load_like_the_reference(grt, oracle, tmp_path):
+    """TextureLoader::load_dds (TextureLoader.cpp:19-106): DXT1 blocks used as stored; the chain ends where halving the
+    block counts reaches zero, whatever the file holds beyond that."""
+    rng = np.random.default_rng(17)
+    for name, (w, h) in (("a", (32, 16)), ("b", (64, 64)), ("c", (8, 8))):
+        levels, lw, lh = 0, w, h
+        blocks = b""
+        while True:
+            blocks += rng.integers(0, 256, ((lw + 3) // 4) * ((lh + 3) // 4) * 8, dtype=np.uint8).tobytes()
+            levels += 1
+            if lw == 1 and lh == 1: break
+            lw, lh = max(lw // 2, 1), max(lh // 2, 1)
+        header = b"DDS " + struct.pack("<IIIIIII", 124, 0x1007 | 0x20000, h, w, 0, 0, levels) + b"\0" * 44 + struct.pack("<II4sIIIII", 32, 4, b"DXT1", 0, 0, 0, 0, 0) + struct.pack("<IIIII", 0x1000, 0, 0, 0, 0)
+        (tmp_path / (name + ".dds")).write_bytes(header + blocks)
+    (tmp_path / "s.xml").write_text('<scene version="0.5.0">' + "".join(
+        '<shape type="rectangle"><bsdf type="diffuse"><texture name="reflectance" type="bitmap"><string name="filename" value="%s.dds"/></texture></bsdf></shape>' % n for n in "abc") + '</scene>')
+    assert_same_scene(grt, oracle, tmp_path / "s.xml", write_sky(tmp_path / "sky.hdr"))
+    grt.config_reset()
+    scene = grt.Scene(str(tmp_path / "s.xml")); scene.wait_until_loaded()
+    assert [len(scene.texture(i)["mip_offsets"]) for i in range(3)] == [3, 5, 2]
+    scene.close()
