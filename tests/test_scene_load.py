@@ -388,6 +388,8 @@ def test_mesh_file_loaders_equal_the_references(grt, oracle, tmp_path, monkeypat
         for i in range(n): f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
     for name in ("a.obj", "b.obj"):
         assert np.array_equal(oracle.ref_load_mesh_file("obj", name), product_mesh_file(grt, name), equal_nan=True), name
+    write_sky(tmp_path / "sky.hdr")
+    assert_same_scene(grt, oracle, "a.obj", "sky.hdr")        # a mesh file named as the scene (Scene.cpp:29-32): default camera and material
 
     positions = np.round(rng.random((9, 3)) * 4 - 2, 3).astype(np.float32)
     normals = rng.random((9, 3)).astype(np.float32); normals /= np.linalg.norm(normals, axis=1, keepdims=True)
@@ -400,6 +402,7 @@ def test_mesh_file_loaders_equal_the_references(grt, oracle, tmp_path, monkeypat
             # index list, which ends an ascii load with an error and silently desynchronises a binary one)
             (tmp_path / name).write_bytes(_ply_bytes(fmt, positions, normals if with_normals else None, uvs, faces, index_type, extras, face_extras=False))
             assert np.array_equal(oracle.ref_load_mesh_file("ply", name), product_mesh_file(grt, name), equal_nan=True), name
+    assert_same_scene(grt, oracle, "m_ascii_0.ply", "sky.hdr")
 
     quad = dict(name="quad", positions=[[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], normals=[[0, 0, 1]] * 4, uvs=[[0, 0], [1, 0], [1, 1], [0, 1]],
                 colours=[[1, 0, 0]] * 4, faces=[[0, 1, 2], [0, 2, 3]])
