@@ -222,6 +222,7 @@ struct Optimiser {
 		for (int j = 0; j < 2; j++) {
 			int pair = free_pair[j];
 			int target = find_insertion_point(moved[j].aabb);
+			if (target == INVALID) target = 0; // areas overflowed to infinity (coordinates beyond ~1e19): pair it with the root
 
 			bvh.nodes[pair]     = bvh.nodes[target];
 			bvh.nodes[pair + 1] = moved[j];
