@@ -539,12 +539,18 @@ __global__ void kernel_average_conductor(const float * lut_directional_albedo, f
 
 void rt_launch_integrate_luts(const RtParams & p, float * dielectric_dir_enter, float * dielectric_dir_leave, float * dielectric_enter, float * dielectric_leave,
                               float * conductor_dir, float * conductor, hipStream_t stream) {
+	// The cells draw their samples with random_sample(thread_index, ...), whose first step splits a *virtual* pixel
+	// index by the frame size (sample batches, rt_types.h). A cell index is not a path index: give the kernels the
+	// pre-resize split (one 2^30-pixel frame) so that cells never fold onto each other and the tables do not
+	// depend on the render resolution -- as in the reference, whose random<>() knows no such split.
+	RtParams q = p;
+	q.frame_pixels = 1u << 30; q.frame_pixels_magic = 5;
 	// 64-thread blocks: 4096 cells -> 64 workgroups, so the long sample loops spread over many CUs
-	hipLaunchKernelGGL(kernel_integrate_dielectric, dim3(4096 / 64), dim3(64), 0, stream, p, 1, dielectric_dir_enter);
-	hipLaunchKernelGGL(kernel_integrate_dielectric, dim3(4096 / 64), dim3(64), 0, stream, p, 0, dielectric_dir_leave);
+	hipLaunchKernelGGL(kernel_integrate_dielectric, dim3(4096 / 64), dim3(64), 0, stream, q, 1, dielectric_dir_enter);
+	hipLaunchKernelGGL(kernel_integrate_dielectric, dim3(4096 / 64), dim3(64), 0, stream, q, 0, dielectric_dir_leave);
 	hipLaunchKernelGGL(kernel_average_dielectric, dim3(1), dim3(256), 0, stream, dielectric_dir_enter, dielectric_enter);
 	hipLaunchKernelGGL(kernel_average_dielectric, dim3(1), dim3(256), 0, stream, dielectric_dir_leave, dielectric_leave);
-	hipLaunchKernelGGL(kernel_integrate_conductor, dim3(1024 / 64), dim3(64), 0, stream, p, conductor_dir);
+	hipLaunchKernelGGL(kernel_integrate_conductor, dim3(1024 / 64), dim3(64), 0, stream, q, conductor_dir);
 	hipLaunchKernelGGL(kernel_average_conductor, dim3(1), dim3(64), 0, stream, conductor_dir, conductor);
 }
 

@@ -46,14 +46,18 @@ struct Inflater {
 			if (z.avail_in == 0) {
 				z.next_in  = buffer;
 				z.avail_in = uInt(fread(buffer, 1, sizeof(buffer), file));
-				if (z.avail_in == 0) return false; // truncated file
+				// At the end of the file zlib may still hold output (a match that spans the last read, the
+				// end-of-block code in the final byte): keep calling inflate() and let IT report a truncated stream.
 			}
 			uInt chunk = uInt(remaining < (1u << 30) ? remaining : (1u << 30));
+			uInt had_in = z.avail_in;
 			z.avail_out = chunk;
 			int status = inflate(&z, Z_NO_FLUSH);
-			remaining -= chunk - z.avail_out;
+			size_t produced = chunk - z.avail_out;
+			remaining -= produced;
 			if (status == Z_STREAM_END) break;
-			if (status != Z_OK) return false;
+			if (status != Z_OK) return false;                                     // Z_BUF_ERROR: no progress possible = truncated
+			if (produced == 0 && had_in == 0 && z.avail_in == 0) return false;   // nothing in, nothing out
 		}
 		return remaining == 0;
 	}
@@ -143,18 +147,33 @@ bool BVHCache::try_to_load(const std::string & mesh_filename, const std::string 
 	}
 	// A cache is trusted for its content but not for memory safety: every index must stay in range.
 	for (int index : loaded.indices) if (index < 0 || index >= header.num_triangles) return false;
-	// ... every box must be finite, and children must come after their parent (as every builder emits them),
-	// which rules out cycles.
-	for (size_t i = 0; i < loaded.nodes.size(); i++) {
-		if (i == 1) continue; // the unused sibling of the root
-		const BVHNode2 & node = loaded.nodes[i];
-		const float * box = &node.aabb.min.x;
-		for (int k = 0; k < 6; k++) if (!std::isfinite(box[k])) return false;
-		if (node.is_leaf() && node.count != 1) return false; // caches hold the builders' raw trees: one reference per leaf
-		if (node.is_leaf() ? (node.first < 0 || size_t(node.first) + node.count > loaded.indices.size())
-		                   : (node.left <= int(i) || size_t(node.left) + 1 >= loaded.nodes.size())) return false;
-	}
+	// ... and the nodes must form a tree: walk it from the root with a visited bitmap. Every node may be reached
+	// at most once (no cycles, no shared subtrees), child pairs must lie inside the array, every box reached must
+	// be finite. The order of the nodes in the array is NOT constrained: the builders emit children after their
+	// parent, but BVHOptimizer re-inserts subtrees into freed slots in front of it (a third of Sponza's inner
+	// nodes after -O), and such caches -- ours and the reference's -- have to load.
 	if (loaded.nodes.size() < 2 || loaded.indices.empty()) return false;
+	{
+		std::vector<bool> visited(loaded.nodes.size(), false);
+		std::vector<int> stack; stack.push_back(0);
+		visited[0] = true;
+		while (!stack.empty()) {
+			const BVHNode2 & node = loaded.nodes[size_t(stack.back())]; stack.pop_back();
+			const float * box = &node.aabb.min.x;
+			for (int k = 0; k < 6; k++) if (!std::isfinite(box[k])) return false;
+			if (node.is_leaf()) {
+				if (node.count != 1) return false; // caches hold the builders' raw trees: one reference per leaf
+				if (node.first < 0 || size_t(node.first) + node.count > loaded.indices.size()) return false;
+				continue;
+			}
+			if (node.left < 2 || size_t(node.left) + 1 >= loaded.nodes.size()) return false; // slots 0 and 1: the root and its unused sibling
+			for (int child = node.left; child <= node.left + 1; child++) {
+				if (visited[size_t(child)]) return false;
+				visited[size_t(child)] = true;
+				stack.push_back(child);
+			}
+		}
+	}
 	*triangles = std::move(loaded_triangles);
 	*bvh       = std::move(loaded);
 	return true;

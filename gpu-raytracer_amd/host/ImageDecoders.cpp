@@ -215,12 +215,16 @@ bool ImageDecoders::decode_bmp(const std::vector<unsigned char> & file, int & wi
 		return (unsigned char)(max == 255 ? field : field * 255 / max);
 	};
 
-	const unsigned char * palette = nullptr;
+	// The palette is copied into a full 256-entry table: a pixel byte may name any entry, whatever biClrUsed says
+	// (entries the file does not define read as black instead of running past the buffer).
+	unsigned char palette[256 * 4] = { };
 	if (bits == 8) {
 		uint32_t colours = le32(&file[46]); if (colours == 0) colours = 256;
-		palette = &file[14 + header_size];
+		if (colours > 256) return false;
 		if (14 + size_t(header_size) + size_t(colours) * 4 > file.size()) return false;
+		memcpy(palette, &file[14 + header_size], size_t(colours) * 4);
 	}
+	if (size_t(data_offset) < 14 + size_t(header_size)) return false; // pixel data cannot start inside the headers
 	size_t row_bytes = ((size_t(w) * bits + 31) / 32) * 4;
 	if (size_t(data_offset) + row_bytes * h > file.size()) return false;
 

@@ -180,7 +180,11 @@ void Pathtracer::update(float delta) {
 		invalidated_mediums = false;
 	}
 
-	bool invalidated_light_mesh_weights = invalidated_scene;
+	// The per-mesh light tables (CDF, transform indices) are in TLAS order. With enable_scene_update the TLAS is
+	// rebuilt every frame (Integrator::update sets invalidated_scene only after this point), so the tables follow
+	// it every frame too. The reference captures the flag here as well but without this term (Pathtracer.cpp:694),
+	// i.e. after a TLAS reorder its NEE samples stale instance transforms: a reference flaw, not reproduced.
+	bool invalidated_light_mesh_weights = invalidated_scene || cpu_config.enable_scene_update;
 
 	if (gpu_config.enable_svgf) {
 		memcpy(&svgf_matrices[0],  scene.camera.view_projection.cells,      64);

@@ -29,6 +29,29 @@ def secondary_rays(view, o, d, hits, seed):
     return org[:, ok], dirs[:, ok]
 
 
+def test_gpu_frames_equal_the_references_own_kernels(grt, oracle):
+    """Closes the loop without the restated oracle in between: the HIP kernels on the MI355X against the reference's
+    Pathtracer.cu executed on the CPU (oracle/ref/ref_cuda_harness.cpp, prebuilt into oracle/_ref) on the same
+    staged arrays -- queue sizes per bounce and frames."""
+    if oracle.ref_lib() is None or not hasattr(oracle.ref_lib(), "ref_cuda_frame_create"):
+        pytest.skip("oracle/_ref was built without the reference's device code")
+    scene, pt = make_pathtracer(grt, "cornellbox", 96, 64, 0, num_bounces=5)
+    view = oracle.SceneView(pt)
+    theirs = oracle.ReferenceFrame(view)
+    for f in range(3):
+        if f:
+            pt.update()
+        pt.render()
+        c = pt.counters()
+        rc = theirs.render_sample(pt.sample_index)
+        for name in ("trace", "shadow", "diffuse"):
+            got, want = list(getattr(c, name)[:5]), [int(v) for v in rc[name][:5]]
+            assert got[0] == want[0] and all(abs(a - b) <= 2 + 0.002 * b for a, b in zip(got, want)), (f, name, got, want)
+        got, want = pt.read_framebuffer()[:, :96, :3], theirs.final[:, :96, :3]
+        assert np.abs(got - want).sum() / want.sum() < REL_L1_TOL, f
+    theirs.close(); pt.close(); scene.close()
+
+
 @pytest.mark.parametrize("scene_name,w,h", [("cornellbox", 256, 256), ("sponza", 640, 360)])
 def test_trace_hits_are_bit_exact(grt, oracle, scene_name, w, h):
     scene, pt = make_pathtracer(grt, scene_name, w, h, 0)
@@ -581,94 +604,3 @@ def test_trace_statistics_equal_the_oracle_counters(grt, oracle):
     assert abs(stats["shadow"]["nodes"] - oc.shadow_stats.nodes) <= 2e-3 * oc.shadow_stats.nodes
     assert abs(stats["closest"]["algorithmic_bytes"] - oc.trace_stats.algorithmic_bytes()) <= 1e-3 * oc.trace_stats.algorithmic_bytes()
     pt.close(); scene.close()
-
-
-@pytest.mark.gpu
-def test_command_line_render_and_screenshots_match_the_library(grt, tmp_path):
-    """host/pathtracer (Args.cpp + the headless part of Main.cpp:75-150) renders what the library
-    renders for the same options, and Integrator::save_image writes the frame the exporters' way."""
-    import subprocess
-    from test_loaders import CLI, _parse_exr
-    scene_file = grt.scene_path("cornellbox")
-    out = tmp_path / "cli.exr"
-    # -W / -H / -b are given, but what the scene file says (<film> size, maxDepth) is applied later and
-    # wins, as in the reference (MitsubaLoader.cpp:611-613, Main.cpp:109)
-    r = subprocess.run([CLI, "-s", scene_file, "-W", "96", "-H", "64", "-N", "5", "-b", "2", "--bvh", "bvh8", "-o", str(out)], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr + r.stdout
-    assert "Wrote" in r.stdout
-    _, cli = _parse_exr(out)
-
-    grt.config_reset()
-    scene = grt.Scene(scene_file)
-    w, h = int(grt.config_get("initial_width")), int(grt.config_get("initial_height"))
-    assert (w, h) == (1024, 1024) and cli["R"].shape == (h, w) and grt.config_get("num_bounces") > 2
-    pt = grt.Pathtracer(scene, w, h, device=0)
-    pt.update()
-    while True:
-        pt.render()
-        if pt.sample_index >= 5:
-            break
-        pt.update()
-    assert pt.sample_index == 5
-    pt.save_image(tmp_path / "lib.exr"); pt.save_image(tmp_path / "lib.ppm")
-    _, lib = _parse_exr(tmp_path / "lib.exr")
-    frame = pt.read_framebuffer()[:, :w, :3][::-1]
-    for k, name in enumerate("RGB"):
-        assert lib[name].shape == (h, w) and np.array_equal(lib[name], frame[:, :, k].astype(np.float16).astype(np.float32))
-        assert np.allclose(cli[name], lib[name], rtol=2e-3, atol=1e-4), name
-    raw = open(tmp_path / "lib.ppm", "rb").read()
-    header = b"P6\n %d\n %d\n 255\n" % (w, h)
-    assert raw.startswith(header) and len(raw) == len(header) + w * h * 3 and np.frombuffer(raw[len(header):], np.uint8).mean() > 20
-    pt.close(); scene.close()
-
-
-@pytest.mark.gpu
-def test_block_compressed_textures_render_like_the_oracle(grt, oracle):
-    """enable_block_compression: Sponza's power-of-two maps are BC1-quantised on the host and carry the
-    reference's block-count LOD size (rt_texture_desc::lod_width / lod_height), which shifts the bias of the
-    bounce > 0 texture lookups by -2. Bounce-0 albedo and a 3-bounce frame match the oracle, which is given
-    the same descriptors; and the frame differs from the uncompressed one (the switch does something)."""
-    frames = {}
-    for compress in (1, 0):
-        scene, pt = make_pathtracer(grt, "sponza", 320, 180, 0, num_bounces=3, enable_block_compression=compress)
-        if compress:
-            textures = pt.textures()
-            sizes = [pt.texture_lod_size(i) for i in range(len(textures))]
-            assert sum(1 for s in sizes if s != (0, 0)) == 19                                  # every real map (they are all powers of two)
-            assert all(s == ((0, 0) if t[1] == 1 else (t[1] // 4, t[2] // 4)) for s, t in zip(sizes, textures))   # e.g. 1024^2 texels -> 256^2 blocks
-            pt.aov_enable(grt.AOV_ALBEDO); pt.update()
-            view = oracle.SceneView(pt); frame = oracle.Frame(view)
-            pt.render(); frame.render_sample(pt.sample_index)
-            got, want = pt.read_aov(grt.AOV_ALBEDO)[:, :320, :3], frame.accumulator(grt.AOV_ALBEDO)[:, :320, :3]
-            assert (np.abs(got - want).max(axis=2) > 2e-3).mean() < 1e-3
-            got, want = pt.read_framebuffer()[:, :320, :3], frame.final[:, :320, :3]
-            assert np.abs(got - want).sum() / want.sum() < 1e-3
-        else:
-            pt.render()
-        frames[compress] = pt.read_framebuffer()[:, :320, :3].copy()
-        pt.close(); scene.close()
-    assert not np.array_equal(frames[0], frames[1])
-
-
-@pytest.mark.gpu
-def test_gpu_frames_equal_the_references_own_kernels(grt, oracle):
-    """Closes the loop without the restated oracle in between: the HIP kernels on the MI355X against the reference's
-    Pathtracer.cu executed on the CPU (oracle/ref/ref_cuda_harness.cpp, prebuilt into oracle/_ref) on the same
-    staged arrays -- queue sizes per bounce and frames."""
-    if oracle.ref_lib() is None or not hasattr(oracle.ref_lib(), "ref_cuda_frame_create"):
-        pytest.skip("oracle/_ref was built without the reference's device code")
-    scene, pt = make_pathtracer(grt, "cornellbox", 96, 64, 0, num_bounces=5)
-    view = oracle.SceneView(pt)
-    theirs = oracle.ReferenceFrame(view)
-    for f in range(3):
-        if f:
-            pt.update()
-        pt.render()
-        c = pt.counters()
-        rc = theirs.render_sample(pt.sample_index)
-        for name in ("trace", "shadow", "diffuse"):
-            got, want = list(getattr(c, name)[:5]), [int(v) for v in rc[name][:5]]
-            assert got[0] == want[0] and all(abs(a - b) <= 2 + 0.002 * b for a, b in zip(got, want)), (f, name, got, want)
-        got, want = pt.read_framebuffer()[:, :96, :3], theirs.final[:, :96, :3]
-        assert np.abs(got - want).sum() / want.sum() < REL_L1_TOL, f
-    theirs.close(); pt.close(); scene.close()

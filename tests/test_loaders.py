@@ -301,6 +301,75 @@ def test_bvh_cache_files_follow_the_reference_format(grt, tmp_path):
     pt.close(); scene.close(); grt.config_reset()
 
 
+def test_bvh_caches_of_optimized_trees_and_tiny_meshes_load_again(grt, tmp_path):
+    """Two ways a valid cache used to be refused and rebuilt on every load: (1) BVHOptimizer re-inserts subtrees into
+    freed node slots, so children may precede their parent in the array -- the loader must check that the nodes form
+    a tree, not their order; (2) a stream so short that zlib still holds output when the file is at its end (2
+    triangles inflate from one read). A marked cache proves that the second load really came from the file. A cache
+    whose nodes form a cycle, or share a subtree, is still rejected."""
+    rng = np.random.default_rng(5)
+    for name, n, config in (("opt", 400, dict(enable_bvh_optimization=1, bvh_optimizer_max_num_batches=3)), ("tiny", 2, dict())):
+        p0 = rng.random((n, 3)) * 4; p1 = p0 + rng.random((n, 3)) * 3 - 1.5; p2 = p0 + rng.random((n, 3)) * 0.4
+        obj = tmp_path / (name + ".obj")
+        with open(obj, "w") as f:
+            for a, b, c in zip(p0, p1, p2):
+                f.write("v %.6f %.6f %.6f\nv %.6f %.6f %.6f\nv %.6f %.6f %.6f\n" % (*a, *b, *c))
+            for i in range(n):
+                f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+        cache = str(obj) + ".bvh"
+
+        def load():
+            grt.config_reset(); grt.config_set(enable_bvh_cache=1, **config)
+            scene = grt.Scene(str(obj)); scene.wait_until_loaded()
+            out = {k: scene.mesh_data_array(0, k, dt).copy() for k, dt in (("triangles", np.float32), ("bvh2_nodes", np.uint8), ("bvh2_indices", np.int32))}
+            scene.close()
+            return out
+
+        built = load()
+        c = _read_bvh_cache(cache)
+        assert bool(c["optimized"]) == (name == "opt") and np.array_equal(c["nodes"], built["bvh2_nodes"])
+        nodes = c["nodes"].view(np.int32).reshape(-1, 8)          # 6 floats of box, left_or_first, count | axis << 30
+        inner = np.nonzero((nodes[:, 7] & 0x3fffffff) == 0)[0]
+        inner = inner[inner != 1]
+        if name == "opt":
+            assert (nodes[inner, 6] < inner).any()                    # the optimizer did put children in front of parents
+        marked = dict(c); marked["triangles"] = c["triangles"].copy(); marked["triangles"][1, 0] += 0.25
+        _write_bvh_cache(cache, marked)
+        again = load()
+        assert again["triangles"].reshape(-1, 24)[1, 0] == marked["triangles"][1, 0], name   # came from the cache
+        assert np.array_equal(again["bvh2_nodes"], built["bvh2_nodes"]) and np.array_equal(again["bvh2_indices"], built["bvh2_indices"])
+        if name == "opt":
+            # not a tree: an inner node pointing back at the root's children (cycle / shared subtree) -> rebuilt
+            bad = dict(marked); bad_nodes = nodes.copy(); bad_nodes[inner[-1], 6] = nodes[0, 6]
+            bad["nodes"] = bad_nodes.view(np.uint8).ravel()
+            _write_bvh_cache(cache, bad)
+            rebuilt = load()
+            assert np.array_equal(rebuilt["triangles"], built["triangles"]) and np.array_equal(rebuilt["bvh2_nodes"], built["bvh2_nodes"])
+    grt.config_reset()
+
+
+def test_bmp_palette_indices_beyond_the_declared_colours_stay_in_bounds(grt, tmp_path):
+    """An 8-bit BMP whose pixels name palette entries the file does not hold (biClrUsed = 2, index 255) used to read
+    past the buffer; such entries are black now, and pixel data that claims to start inside the headers is refused."""
+    import struct
+    def bmp(colours_used, data_offset, pixel):
+        palette = bytes([10, 20, 30, 0, 40, 50, 60, 0])[:4 * colours_used]
+        header = struct.pack("<IiiHHIIiiII", 40, 1, 1, 1, 8, 0, 4, 2835, 2835, colours_used, 0)
+        body = header + palette
+        pixels = bytes([pixel, 0, 0, 0])
+        offset = 14 + len(body) if data_offset is None else data_offset
+        return b"BM" + struct.pack("<IHHI", 14 + len(body) + 4, 0, 0, offset) + body + pixels
+    for name, data, expect in (("ok.bmp", bmp(2, None, 1), (60, 50, 40, 255)), ("beyond.bmp", bmp(2, None, 255), (0, 0, 0, 255)), ("inside.bmp", bmp(2, 0, 1), None)):
+        path = tmp_path / name
+        open(path, "wb").write(data)
+        if expect is None:
+            with pytest.raises(RuntimeError, match="cannot decode"):
+                grt.load_texture(path)
+        else:
+            level0 = grt.load_texture(path)[0]
+            assert level0.shape == (1, 1, 4) and np.array_equal(level0, _srgb_to_linear_u8(np.array(expect, np.uint8).reshape(1, 1, 4))), name
+
+
 def _ply_bytes(fmt, positions, normals, uvs, faces, index_type="int", with_extras=False, face_extras=None):
     """Serialises a mesh as PLY in one of the three encodings (an independent writer for the reader under test)."""
     import struct
