@@ -118,6 +118,15 @@ def main():
     ap.add_argument("--samples-in-flight", type=int, default=0, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     import torch
     import torch.distributed as dist
     import gpu_raytracer_amd as grt
@@ -129,8 +138,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     # debug only: BENCH_DIST_BACKEND=gloo BENCH_SHARE_GPU=1 runs the N-rank flow (rendezvous, tile split,
     # stream hand-over, reductions) with every rank on GPU 0 and the gather staged through the host
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
@@ -163,6 +170,7 @@ def main():
     gathered = torch.zeros((split_world * split.local_pixels, 4), dtype=torch.float32, device=device)
     import ctypes
     lib.rt_pack_pixels.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.rt_unpack_pixels.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.rt_synchronize.argtypes = [ctypes.c_void_p]
     lib.rt_stream_wait_for_context.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.rt_context_wait_for_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -197,6 +205,11 @@ def main():
                     gathered.copy_(host)
                 else:
                     gathered[:split.local_pixels].copy_(packed)   # --emulate-world: stand-in for the collective
+                # ... and the gathered tiles are scattered into the final framebuffer of this rank (every rank ends
+                # up with the whole frame), stream-ordered after the collective
+                if world > 1:
+                    check(lib.rt_context_wait_for_stream(ctx, torch_stream))
+                    check(lib.rt_unpack_pixels(ctx, gathered.data_ptr(), split.tile_pixels, split_world, split.tiles_per_rank))
 
     def counters():
         c = pt.counters()
@@ -312,7 +325,7 @@ def main():
                 "rays_per_step": round(rays_per_step), "shadow_rays_per_step": round(shadow_4spp / SPP),
                 "mrays_s_including_shadow": round((rays_4spp + shadow_4spp) / SPP * args.steps / elapsed / 1e6, 1),
                 "ms_per_4spp_frame": round(elapsed / args.steps * SPP * 1e3, 3),
-                "emulated_world": args.emulate_world,
+                "emulated_world": args.emulate_world, "ranks": (dist.get_world_size() if world > 1 else 1),
                 "parallelism": "tile-split x%d + one RCCL all-gather of the accumulated float4 frame per %d-spp frame" % (world, SPP) if world > 1 else "single GPU",
                 "samples_per_submission": args.batch, "submissions_in_flight": args.samples_in_flight,
                 "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},

@@ -249,10 +249,19 @@ def config_set(**kwargs):
             raise KeyError(lib.grt_last_error().decode(errors="replace"))
 
 
-def load_texture(filename):
+def load_texture(filename, block_compression=False):
     """Decodes an image file the way the scene loader does (TGA / PPM / PNG / BMP: sRGB -> linear RGBA8 +
-    box-filtered mips; DDS: stored DXT levels as they are). Returns a list of (height, width, 4) uint8 levels."""
+    box-filtered mips; DDS: stored DXT levels as they are). Returns a list of (height, width, 4) uint8 levels.
+    block_compression: False = the decoded levels; True = what survives BC1 (power-of-two textures only, the
+    scene loader's default); None = whatever `enable_block_compression` says."""
     lib = host_lib()
+    if block_compression is not None:
+        previous = config_get("enable_block_compression")
+        config_set(enable_block_compression=int(bool(block_compression)))
+        try:
+            return load_texture(filename, None)
+        finally:
+            config_set(enable_block_compression=previous)
     lib.grt_texture_load.restype = c_void_p
     lib.grt_texture_load.argtypes = [c_char_p]
     lib.grt_texture_data.restype = c_void_p

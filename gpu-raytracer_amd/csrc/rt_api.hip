@@ -15,6 +15,12 @@
 
 static thread_local std::string g_global_error;
 
+// HIP multiplexes its streams onto 4 hardware queues unless told otherwise; a context keeps up to
+// 2 x (submissions in flight) streams busy and loses their overlap silently when they share queues
+// (profiles/r01_small_range_concurrency.txt). The variable is read when the HIP runtime initialises, i.e. at
+// the first HIP call of the process: set the default when this library is loaded, never override the user's.
+__attribute__((constructor)) static void grt_default_environment() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+
 // Everything one sample per pixel owns while it is in flight. Up to RT_MAX_SAMPLE_SLOTS samples
 // are rendered concurrently (rt_set_samples_in_flight): consecutive rt_render_sample calls take the
 // slots round-robin, each on its own stream, and only the accumulate step is ordered between them.
@@ -486,13 +492,18 @@ int rt_upload_textures(rt_context * ctx, const rt_texture_desc * descs, size_t c
 	for (size_t i = 0; i < count; i++) {
 		const rt_texture_desc & d = descs[i];
 		RT_REQUIRE(ctx, d.texels && d.width > 0 && d.height > 0 && d.mip_levels > 0, "rt_upload_textures: invalid texture descriptor");
-		size_t texels = 0;
-		for (int l = 0; l < d.mip_levels; l++) { int w = d.width >> l; if (w < 1) w = 1; int h = d.height >> l; if (h < 1) h = 1; texels += size_t(w) * h; }
+		RT_REQUIRE(ctx, d.format == RT_TEXTURE_RGBA8 || d.format == RT_TEXTURE_BC1, "rt_upload_textures: unknown texture format");
+		size_t bytes = 0;
+		for (int l = 0; l < d.mip_levels; l++) {
+			int w = d.width >> l; if (w < 1) w = 1; int h = d.height >> l; if (h < 1) h = 1;
+			bytes += d.format == RT_TEXTURE_BC1 ? size_t((w + 3) / 4) * ((h + 3) / 4) * 8 : size_t(w) * h * 4;
+		}
 		void * dev = nullptr;
-		int s = upload(ctx, &dev, d.texels, texels * 4); if (s) return s;
+		int s = upload(ctx, &dev, d.texels, bytes); if (s) return s;
 		ctx->texture_data.push_back(dev);
 		table[i].texels = (const uchar4 *)dev;
 		table[i].width = d.width; table[i].height = d.height; table[i].mip_levels = d.mip_levels;
+		table[i].format = d.format; table[i].pad = 0;
 		int lod_width  = d.lod_width  > 0 ? d.lod_width  : d.width;
 		int lod_height = d.lod_height > 0 ? d.lod_height : d.height;
 		table[i].lod_bias = 0.5f * log2f(float(lod_width * lod_height)); // Integrator.cpp:95

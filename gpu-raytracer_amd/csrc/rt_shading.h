@@ -186,13 +186,47 @@ RT_DEV int wrap_index(int i, int n) { int r = i % n; return r < 0 ? r + n : r; }
 RT_DEV float lerpf(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
 RT_DEV f4 lerp4(f4 a, f4 b, float t) { return mk4(lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)); }
 
+// One texel of a BC1 block (the texture unit's decode, done here: CDNA compute has none). D3D rules, the same
+// integer arithmetic as the host's BlockCompression::decode_bc1_block: end points expand by bit replication,
+// c0 > c1: the two thirds rounded to nearest, else the half (rounded down) and transparent black.
+RT_DEV uchar4 bc1_texel(uint2 block, int x_in_block, int y_in_block) {
+	unsigned c0 = block.x & 0xffffu, c1 = block.x >> 16;
+	unsigned index = (block.y >> (2 * (y_in_block * 4 + x_in_block))) & 3u;
+	unsigned r0 = c0 >> 11, g0 = (c0 >> 5) & 63u, b0 = c0 & 31u;
+	unsigned r1 = c1 >> 11, g1 = (c1 >> 5) & 63u, b1 = c1 & 31u;
+	r0 = (r0 << 3) | (r0 >> 2); g0 = (g0 << 2) | (g0 >> 4); b0 = (b0 << 3) | (b0 >> 2);
+	r1 = (r1 << 3) | (r1 >> 2); g1 = (g1 << 2) | (g1 >> 4); b1 = (b1 << 3) | (b1 >> 2);
+	if (index == 0u) return make_uchar4((unsigned char)r0, (unsigned char)g0, (unsigned char)b0, 255);
+	if (index == 1u) return make_uchar4((unsigned char)r1, (unsigned char)g1, (unsigned char)b1, 255);
+	if (c0 > c1) { // (2 a + b + 1) / 3 with a the nearer end point
+		unsigned ra = index == 2u ? r0 : r1, rb = index == 2u ? r1 : r0;
+		unsigned ga = index == 2u ? g0 : g1, gb = index == 2u ? g1 : g0;
+		unsigned ba = index == 2u ? b0 : b1, bb = index == 2u ? b1 : b0;
+		return make_uchar4((unsigned char)((2u * ra + rb + 1u) / 3u), (unsigned char)((2u * ga + gb + 1u) / 3u), (unsigned char)((2u * ba + bb + 1u) / 3u), 255);
+	}
+	if (index == 2u) return make_uchar4((unsigned char)((r0 + r1) / 2u), (unsigned char)((g0 + g1) / 2u), (unsigned char)((b0 + b1) / 2u), 255);
+	return make_uchar4(0, 0, 0, 0);
+}
+
+// level_offset: in texels (RGBA8) or in blocks (BC1)
 RT_DEV f4 texture_texel(const RtTexture & tex, size_t level_offset, int w, int h, int x, int y) {
-	uchar4 c = tex.texels[level_offset + size_t(wrap_index(x, w)) + size_t(wrap_index(y, h)) * w];
+	x = wrap_index(x, w); y = wrap_index(y, h);
+	uchar4 c;
+	if (tex.format == RT_TEXTURE_BC1) {
+		int blocks_per_row = (w + 3) >> 2;
+		uint2 block = ((const uint2 *)tex.texels)[level_offset + size_t(x >> 2) + size_t(y >> 2) * blocks_per_row];
+		c = bc1_texel(block, x & 3, y & 3);
+	} else {
+		c = tex.texels[level_offset + size_t(x) + size_t(y) * w];
+	}
 	return mk4(float(c.x) * (1.0f / 255.0f), float(c.y) * (1.0f / 255.0f), float(c.z) * (1.0f / 255.0f), float(c.w) * (1.0f / 255.0f));
 }
 RT_DEV f4 texture_bilinear(const RtTexture & tex, int level, float s, float t) {
 	size_t offset = 0;
-	for (int l = 0; l < level; l++) { int lw = max(tex.width >> l, 1), lh = max(tex.height >> l, 1); offset += size_t(lw) * lh; }
+	for (int l = 0; l < level; l++) {
+		int lw = max(tex.width >> l, 1), lh = max(tex.height >> l, 1);
+		offset += tex.format == RT_TEXTURE_BC1 ? size_t((lw + 3) >> 2) * ((lh + 3) >> 2) : size_t(lw) * lh;
+	}
 	int w = max(tex.width >> level, 1), h = max(tex.height >> level, 1);
 	float x = s * float(w) - 0.5f, y = t * float(h) - 0.5f;
 	float x0f = floorf(x), y0f = floorf(y);

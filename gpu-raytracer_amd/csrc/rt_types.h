@@ -59,9 +59,11 @@ struct RtBufferSizes { // Pathtracer.cu:103-114
 };
 
 struct RtTexture {
-	const uchar4 * texels;   // linear RGBA8, mip levels back to back
+	const uchar4 * texels;   // linear RGBA8, mip levels back to back; or BC1 blocks (uint2 each), see `format`
 	int   width, height, mip_levels;
 	float lod_bias;          // 0.5 * log2(width * height)   (Integrator.cpp:95)
+	int   format;            // RT_TEXTURE_RGBA8 / RT_TEXTURE_BC1
+	int   pad;
 };
 
 struct RtAOV { float4 * framebuffer, * accumulator; };

@@ -215,7 +215,7 @@ void BlockCompression::compress_bc1_block(const unsigned char rgba[64], unsigned
 	dst[4] = (unsigned char)mask;  dst[5] = (unsigned char)(mask >> 8); dst[6] = (unsigned char)(mask >> 16); dst[7] = (unsigned char)(mask >> 24);
 }
 
-void BlockCompression::quantise_level_bc1(unsigned char * rgba, int width, int height) {
+void BlockCompression::quantise_level_bc1(unsigned char * rgba, int width, int height, std::vector<unsigned char> * blocks) {
 	for (int by = 0; by < (height + 3) / 4; by++) {
 		for (int bx = 0; bx < (width + 3) / 4; bx++) {
 			unsigned char block[64] = { }; // texels beyond the level's edge stay zero, as in the reference
@@ -225,6 +225,7 @@ void BlockCompression::quantise_level_bc1(unsigned char * rgba, int width, int h
 			}
 			unsigned char compressed[8], decoded[16][4];
 			compress_bc1_block(block, compressed);
+			if (blocks) blocks->insert(blocks->end(), compressed, compressed + 8);
 			decode_bc1_block(compressed, decoded);
 			for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) {
 				int x = bx * 4 + i, y = by * 4 + j;

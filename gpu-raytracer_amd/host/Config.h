@@ -64,7 +64,7 @@ struct CPUConfig {
 	MipmapFilterType mipmap_filter = MipmapFilterType::BOX;
 	// BC1-quantise power-of-two textures like the reference does by default (BlockCompression.cpp). Off by
 	// default here until the textured GPU parity tests have been re-run with it.
-	bool enable_block_compression = false;
+	bool enable_block_compression = true;  // the reference's default (Config.h:55): every power-of-two texture is stored as BC1
 	BVHType bvh_type = BVHType::BVH8;
 
 	// "<mesh file>.bvh" caches (BVHCache.h). The reference always reads and writes them; a library

@@ -56,6 +56,11 @@ void Integrator::init_materials() {
 			descs[i].mip_levels = textures[i].mip_levels();
 			descs[i].lod_width  = textures[i].lod_width;
 			descs[i].lod_height = textures[i].lod_height;
+			descs[i].format     = RT_TEXTURE_RGBA8;
+			if (!textures[i].bc1_blocks.empty()) { // block-compressed: the device keeps the 8-byte blocks and decodes per texel
+				descs[i].texels = textures[i].bc1_blocks.data();
+				descs[i].format = RT_TEXTURE_BC1;
+			}
 		}
 		check(rt_upload_textures(ctx, descs.data(), descs.size()));
 	}

@@ -15,6 +15,10 @@ struct Texture {
 	// Size that enters the LOD bias; 0 = width / height. Block counts for a BC1-compressed texture, as in
 	// the reference (TextureLoader.cpp:256-258 overwrite width / height, Integrator.cpp:95 reads them).
 	int lod_width = 0, lod_height = 0;
+	// BC1 blocks (8 bytes per 4x4 texels, rows of blocks, all kept levels back to back) of a block-compressed
+	// texture: what the device stores and decodes in its texel fetch. `texels` then holds the decoded levels --
+	// the same values, for the host-side consumers (exporters, the parity checker).
+	std::vector<unsigned char> bc1_blocks;
 
 	int mip_levels() const { return int(mip_offsets.size()); }
 };

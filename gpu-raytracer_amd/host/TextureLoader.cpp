@@ -361,7 +361,7 @@ bool TextureLoader::load(const std::string & filename, Texture * texture) {
 			texture->mip_offsets.resize(kept_levels);
 		}
 		for (size_t l = 0; l < texture->mip_offsets.size(); l++) {
-			BlockCompression::quantise_level_bc1(&texture->texels[texture->mip_offsets[l] * 4], std::max(width >> l, 1), std::max(height >> l, 1));
+			BlockCompression::quantise_level_bc1(&texture->texels[texture->mip_offsets[l] * 4], std::max(width >> l, 1), std::max(height >> l, 1), &texture->bc1_blocks);
 		}
 		texture->lod_width  = blocks_w;
 		texture->lod_height = blocks_h;

@@ -102,7 +102,7 @@ std::vector<Option> make_options(CommandLine & cl) {
 		else if (strcmp(v, "kaiser")  == 0) cpu_config.mipmap_filter = MipmapFilterType::KAISER;
 		else die(std::string("'") + v + "' is not a recognized Mipmap Filter!");
 	} });
-	o.push_back({ "c", "compress",  "Enables or disables texture block compression (BC1 quantisation; default false here, true in the reference)", 1, [](const char * v) { cpu_config.enable_block_compression = parse_bool(v); } });
+	o.push_back({ "c", "compress",  "Enables or disables texture block compression (BC1, decoded in the shade kernels; default true, as in the reference)", 1, [](const char * v) { cpu_config.enable_block_compression = parse_bool(v); } });
 	o.push_back({ nullptr, "device",    "HIP device ordinal to render on", 1, [&cl](const char * v) { cl.device = parse_int(v, "--device"); } });
 	o.push_back({ nullptr, "bvh-cache", "Enables or disables reading and writing <mesh>.bvh cache files", 1, [](const char * v) { cpu_config.enable_bvh_cache = parse_bool(v); } });
 	o.push_back({ nullptr, "batch",     "Samples per submission to the device (1..16)", 1, [&cl](const char * v) {

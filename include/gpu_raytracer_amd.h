@@ -92,6 +92,8 @@ typedef struct rt_camera {
 	float focal_distance;
 } rt_camera;
 
+enum { RT_TEXTURE_RGBA8 = 0, RT_TEXTURE_BC1 = 1 };
+
 /* One mip-mapped RGBA8 texture in LINEAR light, i.e. what the reference hands to
  * cuMipmappedArray before optional BC1 compression (Assets/TextureLoader.cpp:145-206).
  * CDNA compute parts have no texture units, so wrap addressing and bi/tri-linear
@@ -104,6 +106,12 @@ typedef struct rt_texture_desc {
 	 * overwrites Texture::width/height with the BLOCK counts when it BC1-compresses a texture
 	 * (TextureLoader.cpp:256-258), so compressed textures carry a bias that is 2 lower.                  */
 	int32_t         lod_width, lod_height;
+	/* RT_TEXTURE_RGBA8: `texels` as described above. RT_TEXTURE_BC1: `texels` points at the BC1 blocks the reference
+	 * hands to its texture unit (TextureLoader.cpp:208-262): 8 bytes per 4x4 texels, ((w+3)/4) x ((h+3)/4) blocks per
+	 * level in row-major order, levels back to back; the shade kernels decode a block per texel fetch (D3D rules:
+	 * bit-replicated end points, thirds rounded to nearest, 3-colour + transparent mode when c0 <= c1).            */
+	int32_t         format;
+	int32_t         reserved;
 } rt_texture_desc;
 
 /* Per-stage counters of the last rt_render_sample, replaces the read-back of

@@ -72,6 +72,7 @@ void svgf_reproject(const oracle_scene & s, oracle_frame & f) { // SVGF.h:130-28
 	Img im(s);
 	const rt_gpu_config & cfg = s.config;
 	float * fb_direct = f.framebuffer[RT_AOV_RADIANCE_DIRECT], * fb_indirect = f.framebuffer[RT_AOV_RADIANCE_INDIRECT];
+	#pragma omp parallel for schedule(static) // every pixel writes its own outputs only, from buffers no stage writes
 	for (int y = 0; y < s.screen_height; y++) for (int x = 0; x < s.screen_width; x++) {
 		int pixel_index = im.idx(x, y);
 		float4 direct = ld4(fb_direct, pixel_index), indirect = ld4(fb_indirect, pixel_index);
@@ -164,6 +165,7 @@ void svgf_reproject(const oracle_scene & s, oracle_frame & f) { // SVGF.h:130-28
 void svgf_variance(const oracle_scene & s, oracle_frame & f, const float * d_in, const float * i_in, float * d_out, float * i_out) { // SVGF.h:284-410
 	Img im(s);
 	const rt_gpu_config & cfg = s.config;
+	#pragma omp parallel for schedule(static) // every pixel writes its own outputs only, from buffers no stage writes
 	for (int y = 0; y < s.screen_height; y++) for (int x = 0; x < s.screen_pitch; x++) { // note: pitch, not width
 		int pixel_index = im.idx(x, y);
 		int history = f.history_length[pixel_index];
@@ -218,6 +220,7 @@ void svgf_variance(const oracle_scene & s, oracle_frame & f, const float * d_in,
 void svgf_atrous(const oracle_scene & s, oracle_frame & f, const float * d_in, const float * i_in, float * d_out, float * i_out, int step_size) { // SVGF.h:416-554
 	Img im(s);
 	const rt_gpu_config & cfg = s.config;
+	#pragma omp parallel for schedule(static) // every pixel writes its own outputs only, from buffers no stage writes
 	for (int y = 0; y < s.screen_height; y++) for (int x = 0; x < s.screen_width; x++) {
 		int pixel_index = im.idx(x, y);
 
@@ -277,6 +280,7 @@ void svgf_atrous(const oracle_scene & s, oracle_frame & f, const float * d_in, c
 
 void svgf_finalize(const oracle_scene & s, oracle_frame & f, const float * colour_direct, const float * colour_indirect) { // SVGF.h:559-609
 	const rt_gpu_config & cfg = s.config;
+	#pragma omp parallel for schedule(static) // every pixel writes its own outputs only, from buffers no stage writes
 	for (int y = 0; y < s.screen_height; y++) for (int x = 0; x < s.screen_width; x++) {
 		int pixel_index = x + y * s.screen_pitch;
 		float4 direct = ld4(colour_direct, pixel_index), indirect = ld4(colour_indirect, pixel_index);
@@ -305,6 +309,7 @@ inline float3 clamp3(float3 v, float3 lo, float3 hi) { return make_float3(clampf
 void taa(const oracle_scene & s, oracle_frame & f, int sample_index) { // TAA.h:10-151
 	std::vector<float> out(size_t(s.screen_pitch) * s.screen_height * 4);
 	memcpy(out.data(), f.final_image, out.size() * sizeof(float));
+	#pragma omp parallel for schedule(static) // every pixel writes its own outputs only, from buffers no stage writes
 	for (int y = 0; y < s.screen_height; y++) for (int x = 0; x < s.screen_width; x++) {
 		int pixel_index = x + y * s.screen_pitch;
 		float4 colour = ld4(f.taa_frame_curr, pixel_index);
@@ -357,6 +362,7 @@ void taa(const oracle_scene & s, oracle_frame & f, int sample_index) { // TAA.h:
 }
 
 void taa_finalize(const oracle_scene & s, oracle_frame & f) { // TAA.h:153-172
+	#pragma omp parallel for schedule(static) // every pixel writes its own outputs only, from buffers no stage writes
 	for (int y = 0; y < s.screen_height; y++) for (int x = 0; x < s.screen_width; x++) {
 		int pixel_index = x + y * s.screen_pitch;
 		float4 colour = ld4(f.final_image, pixel_index);

@@ -40,9 +40,11 @@ def fresh_config(grt):
 
 def make_pathtracer(grt, scene_name, width, height, device, **config):
     grt.config_reset()
+    if config:
+        grt.config_set(**config)   # before the load: switches the loaders read (textures, BVH type, caches)
     scene = grt.Scene(grt.scene_path(scene_name))
     if config:
-        grt.config_set(**config)
+        grt.config_set(**config)   # and after it: the scene file's own film size / maxDepth must not win
     pt = grt.Pathtracer(scene, width, height, device=device)
     pt.update()
     return scene, pt

@@ -1,0 +1,153 @@
+"""Parity at the sizes that are benchmarked: BASELINE.json's configurations at 1920x1080 against the CPU oracle.
+
+The other GPU tests compare small frames; these run what bench.py and tools/config_suite.py time -- the same
+scene builders, frame size, bounce count, sample batching and submissions in flight -- and compare the result with
+the oracle rendering the same samples one at a time (a 1080p oracle sample is a few seconds on the GPU box's cores).
+Collected first (file name order), so that a regression of the benchmarked path is the first thing `pytest -x` shows.
+
+Tolerances: queue sizes per bounce within 0.2 % + 2 rays (paths whose roulette / pdf comparison sits within an ulp of
+its threshold, where glibc's and the device's sinf / cosf / logf differ); frames within REL_L1_TOL relative L1 and at
+most OUTLIER_FRACTION_TOL of the pixels off by more than 1 %; SVGF frames within 1e-3 / 1 % (the edge-stopping
+weights amplify last-bit depth differences)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import make_pathtracer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+W, H = 1920, 1080
+REL_L1_TOL = 1e-4
+OUTLIER_FRACTION_TOL = 2e-3
+QUEUES = ("trace", "shadow", "diffuse", "plastic", "dielectric", "conductor")
+
+
+def queues_of(counters, nb):
+    return {name: np.array(list(getattr(counters, name)[:nb]), np.int64) for name in QUEUES}
+
+
+def assert_queues_agree(got, want, label, rel=0.002, slack=2):
+    for name in QUEUES:
+        assert got[name][0] == want[name][0], (label, name, got[name][0], want[name][0])
+        assert (np.abs(got[name] - want[name]) <= slack + rel * want[name]).all(), (label, name, got[name].tolist(), want[name].tolist())
+
+
+def assert_frames_agree(got, want, label, rel_tol=REL_L1_TOL, outlier_tol=OUTLIER_FRACTION_TOL, outlier_step=0.01):
+    assert np.isfinite(got).all(), label
+    rel = np.abs(got - want).sum() / want.sum()
+    outliers = (np.abs(got - want).max(axis=2) > outlier_step * (want.max(axis=2) + 1e-3)).mean()
+    assert rel < rel_tol and outliers < outlier_tol, (label, rel, outliers)
+
+
+def test_benchmarked_sponza_frame_matches_the_oracle(grt, oracle):
+    """BASELINE config 2 exactly as bench.py submits it: Sponza with the plastic variant, 1920x1080, 10 bounces,
+    the 4 samples of a frame as ONE submission (rt_render_samples(0, 4), virtual pixel indices, 8 M-ray launches),
+    three such frames in flight. The oracle renders samples 0..3 one after the other."""
+    import bench
+    scene = bench.build_scene(grt)
+    pt = grt.Pathtracer(scene, W, H, device=0); pt.update()
+    nb = pt.device_config().num_bounces
+    assert nb == bench.NUM_BOUNCES == 10
+    lib = grt.device_lib()
+    lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    grt.set_samples_in_flight(pt.ctx, 3)
+    for _ in range(3):   # three 4-spp frames back to back: each restarts the accumulation at sample 0
+        assert lib.rt_render_samples(pt.ctx, 0, bench.SPP) == 0, lib.rt_last_error(pt.ctx)
+    got_queues = queues_of(pt.counters(), nb)     # the last submission: its 4 samples summed per bounce
+    got = pt.read_framebuffer()[:, :W, :3].copy()
+
+    frame = oracle.Frame(oracle.SceneView(pt))
+    want_queues = {name: np.zeros(nb, np.int64) for name in QUEUES}
+    for s in range(bench.SPP):
+        oc = queues_of(frame.render_sample(s), nb)
+        for name in QUEUES:
+            want_queues[name] += oc[name]
+    assert want_queues["trace"][0] == bench.SPP * W * H and want_queues["plastic"].sum() > 0
+    assert_queues_agree(got_queues, want_queues, "bench frame")
+    assert_frames_agree(got, frame.final[:, :W, :3], "bench frame")
+    pt.close(); scene.close()
+
+
+def test_sponza_svgf_taa_with_a_moving_camera_at_full_size(grt, oracle):
+    """BASELINE config 3: Sponza 1920x1080 with SVGF (6 a-trous iterations) + TAA, one sample per filtered frame,
+    five frames while the camera translates and turns (temporal reprojection from the previous frame's g-buffers,
+    disocclusions at the columns, history lengths). Frames are submitted with 3 in flight, as config_suite times them;
+    the oracle filters the same five frames."""
+    import bench
+    scene = bench.build_scene(grt)
+    grt.config_set(enable_svgf=1, enable_taa=1, num_atrous_iterations=6)
+    pt = grt.Pathtracer(scene, W, H, device=0); pt.update()
+    grt.set_samples_in_flight(pt.ctx, 3)
+    view = oracle.SceneView(pt)
+    frame = oracle.Frame(view)
+    for f in range(5):
+        if f:
+            position, rotation, _ = scene.get_camera()
+            turned = np.array([rotation[0], rotation[1], rotation[2], rotation[3] - 0.004]); turned /= np.linalg.norm(turned)
+            scene.set_camera((position[0] + 0.05, position[1] + 0.02, position[2] + 0.04), tuple(float(v) for v in turned))
+            pt.update()
+            view.scene.camera = oracle.SceneView(pt).scene.camera
+        vp = pt.view_projection()
+        for i in range(16):
+            view.scene.view_projection[i] = vp[0][i]; view.scene.view_projection_prev[i] = vp[1][i]
+        pt.render()
+        frame.render_sample(pt.sample_index)
+        got, want = pt.read_framebuffer()[:, :W, :3], frame.final[:, :W, :3]
+        assert_frames_agree(got, want, "svgf frame %d" % f, rel_tol=1e-3, outlier_tol=1e-2, outlier_step=0.02)
+    history = frame.buffers["hl"].reshape(H, -1)[:, :W]
+    assert 3.0 < history.mean() <= 4.0 and (history == 0).any()   # most pixels reprojected four times, some disoccluded
+    pt.close(); scene.close()
+
+
+def test_config_4_and_5_stand_ins_match_the_oracle_at_full_size(grt, oracle, tmp_path):
+    """The scenes tools/config_suite.py times for BASELINE configs 4 and 5 (SURVEY.md 8d stand-ins), at 1920x1080
+    with reduced sample counts: 441 rotated / scaled instances of a 102 400-triangle mesh (TLAS / BLAS with
+    non-identity transforms, diffuse + plastic), and the rough-dielectric + medium + conductor scene."""
+    import config_suite
+    lib = grt.device_lib()
+    lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    # config 4
+    grt.config_reset()
+    scene = grt.Scene(config_suite.instancing_scene(str(tmp_path / "instancing")))
+    grt.config_set(num_bounces=10)
+    pt = grt.Pathtracer(scene, W, H, device=0); pt.update()
+    assert lib.rt_render_samples(pt.ctx, 0, 2) == 0, lib.rt_last_error(pt.ctx)
+    got_queues = queues_of(pt.counters(), 10)
+    got = pt.read_framebuffer()[:, :W, :3].copy()
+    frame = oracle.Frame(oracle.SceneView(pt))
+    want_queues = {name: np.zeros(10, np.int64) for name in QUEUES}
+    for s in range(2):
+        oc = queues_of(frame.render_sample(s), 10)
+        for name in QUEUES:
+            want_queues[name] += oc[name]
+    assert want_queues["plastic"].sum() > 0 and want_queues["diffuse"].sum() > 0
+    assert_queues_agree(got_queues, want_queues, "config 4")
+    assert_frames_agree(got, frame.final[:, :W, :3], "config 4")
+    pt.close(); scene.close()
+    # config 5
+    grt.config_reset()
+    scene = grt.Scene(config_suite.glass_scene(str(tmp_path / "glass")))
+    pt = grt.Pathtracer(scene, W, H, device=0); pt.update()
+    nb = pt.device_config().num_bounces
+    luts = grt.read_luts(pt.ctx)
+    assert lib.rt_render_samples(pt.ctx, 0, 2) == 0, lib.rt_last_error(pt.ctx)
+    got_queues = queues_of(pt.counters(), nb)
+    got = pt.read_framebuffer()[:, :W, :3].copy()
+    frame = oracle.Frame(oracle.SceneView(pt, luts=luts))
+    want_queues = {name: np.zeros(nb, np.int64) for name in QUEUES}
+    for s in range(2):
+        oc = queues_of(frame.render_sample(s), nb)
+        for name in QUEUES:
+            want_queues[name] += oc[name]
+    assert want_queues["dielectric"].sum() > 0 and want_queues["conductor"].sum() > 0
+    assert_queues_agree(got_queues, want_queues, "config 5", rel=0.004, slack=3)
+    assert_frames_agree(got, frame.final[:, :W, :3], "config 5", rel_tol=5e-4, outlier_tol=5e-3, outlier_step=0.02)
+    pt.close(); scene.close()
+    grt.config_reset()

@@ -604,3 +604,23 @@ def test_trace_statistics_equal_the_oracle_counters(grt, oracle):
     assert abs(stats["shadow"]["nodes"] - oc.shadow_stats.nodes) <= 2e-3 * oc.shadow_stats.nodes
     assert abs(stats["closest"]["algorithmic_bytes"] - oc.trace_stats.algorithmic_bytes()) <= 1e-3 * oc.trace_stats.algorithmic_bytes()
     pt.close(); scene.close()
+
+
+def test_bench_spawns_its_own_ranks_for_a_tile_split_run(grt):
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver starts it) re-executes itself under
+    torch.distributed.run. Both ranks share GPU 0 here and gather through gloo (BENCH_SHARE_GPU / BENCH_DIST_BACKEND:
+    one GPU on the test box); tile split, pack, all-gather, unpack and the max-over-ranks timing all run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 8 and out["value"] > 0 and out["config"]["ranks"] == 2
+    assert out["config"]["rays_per_step"] > 1920 * 1080      # both ranks' rays are in the total

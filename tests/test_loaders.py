@@ -1141,9 +1141,8 @@ def test_block_compressed_textures_follow_the_reference_pipeline(grt, oracle, tm
     (tmp_path / "odd.png").write_bytes(_png_bytes(img[:30, :60], 2, 8))
     grt.config_reset()
     plain = grt.load_texture(tmp_path / "pow2.png")
-    grt.config_set(enable_block_compression=1)
-    packed = grt.load_texture(tmp_path / "pow2.png")
-    odd = grt.load_texture(tmp_path / "odd.png")
+    packed = grt.load_texture(tmp_path / "pow2.png", block_compression=None)   # the default configuration compresses
+    odd = grt.load_texture(tmp_path / "odd.png", block_compression=True)
     grt.config_reset()
     assert [l.shape[:2] for l in plain] == [(32, 64), (16, 32), (8, 16), (4, 8), (2, 4), (1, 2), (1, 1)]
     assert [l.shape[:2] for l in packed] == [(32, 64), (16, 32), (8, 16), (4, 8), (2, 4)]      # 16x8 blocks ... 1x1 block

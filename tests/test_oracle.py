@@ -618,8 +618,9 @@ def test_oracle_matches_golden_frames_rendered_by_the_reference_kernels(grt, ora
     reference's own Pathtracer.cu on the CPU (tests/golden/make_golden.py --only-reference-kernels): the oracle has to
     reproduce them, also on a machine where oracle/_ref cannot be built."""
     golden = np.load(os.path.join(os.path.dirname(GOLDEN), "reference_kernels_golden.npz"))
+    # (the Sponza fixture was rendered from uncompressed textures; BC1 textures against the reference's kernels: test_reference_*)
     cases = (("cornell", "cornellbox", dict(num_bounces=5), 64, 48), ("cornell_no_nee", "cornellbox", dict(num_bounces=4, enable_next_event_estimation=0), 64, 48),
-             ("sponza", "sponza", dict(num_bounces=3), 80, 45))
+             ("sponza", "sponza", dict(num_bounces=3, enable_block_compression=0), 80, 45))
     for name, scene_name, config, w, h in cases:
         scene, pt = make_pathtracer(grt, scene_name, w, h, -1, **config)
         frame = oracle.Frame(oracle.SceneView(pt))
