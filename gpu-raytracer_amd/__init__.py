@@ -653,3 +653,67 @@ def set_samples_in_flight(ctx, count):
 def set_profiling(ctx, enable):
     """False/0 off; True/1 per-stage events (serialised); 2 events around the trace launches only."""
     _dev_check(ctx, device_lib().rt_set_profiling(ctx, int(enable)))
+
+
+SCHEDULER_MERGED, SCHEDULER_SLOTS = 0, 1
+
+
+def set_scheduler(ctx, scheduler):
+    """'merged' (default): consecutive submissions feed one wavefront; 'slots': one launch chain per submission,
+    several in flight on their own streams (rt_set_scheduler)."""
+    if isinstance(scheduler, str):
+        scheduler = {"merged": SCHEDULER_MERGED, "slots": SCHEDULER_SLOTS}[scheduler]
+    lib = device_lib()
+    lib.rt_set_scheduler.argtypes = [c_void_p, c_int]
+    _dev_check(ctx, lib.rt_set_scheduler(ctx, int(scheduler)))
+
+
+def set_frame_pipelining(ctx, enable):
+    lib = device_lib()
+    lib.rt_set_frame_pipelining.argtypes = [c_void_p, c_int]
+    _dev_check(ctx, lib.rt_set_frame_pipelining(ctx, 1 if enable else 0))
+
+
+def advance(ctx):
+    """One iteration of the merged wavefront without new samples (no-op when nothing is in flight)."""
+    lib = device_lib()
+    lib.rt_advance.argtypes = [c_void_p]
+    _dev_check(ctx, lib.rt_advance(ctx))
+
+
+def submissions_completed(ctx):
+    lib = device_lib()
+    lib.rt_submissions_completed.argtypes = [c_void_p, c_void_p]
+    n = ctypes.c_uint64(0)
+    _dev_check(ctx, lib.rt_submissions_completed(ctx, byref(n)))
+    return int(n.value)
+
+
+def launch_timings(ctx, kind=0):
+    """Durations (ms) of the traversal launches timed by set_profiling(ctx, 2) since the last call."""
+    lib = device_lib()
+    lib.rt_get_launch_timings.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p]
+    n = c_int(0)
+    _dev_check(ctx, lib.rt_get_launch_timings(ctx, int(kind), None, 0, byref(n)))
+    out = np.zeros(max(n.value, 1), np.float32)
+    _dev_check(ctx, lib.rt_get_launch_timings(ctx, int(kind), out.ctypes.data, n.value, byref(n)))
+    return out[:n.value]
+
+
+def trace_statistics_history(ctx):
+    """(rows, 10) uint64: the trace statistics after each iteration of the merged wavefront (cumulative)."""
+    lib = device_lib()
+    lib.rt_get_trace_statistics_history.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
+    n = c_int(0)
+    _dev_check(ctx, lib.rt_get_trace_statistics_history(ctx, None, 0, byref(n)))
+    out = np.zeros((max(n.value, 1), 10), np.uint64)
+    _dev_check(ctx, lib.rt_get_trace_statistics_history(ctx, out.ctypes.data, n.value, byref(n)))
+    return out[:n.value]
+
+
+def algorithmic_bytes(row10):
+    """SURVEY.md 8d bytes of ten trace-statistics counters {closest: nodes, triangles, transformed, identity, rays; shadow: same}."""
+    r = [int(v) for v in row10]
+    closest = 40 * r[4] + 80 * r[0] + 48 * r[1] + 52 * r[2] + 4 * r[3]
+    shadow = 28 * r[9] + 80 * r[5] + 48 * r[6] + 52 * r[7] + 4 * r[8]
+    return closest, shadow

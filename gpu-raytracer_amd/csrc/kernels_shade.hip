@@ -84,6 +84,45 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate(RtParams p, in
 	}
 }
 
+// Merged wavefront: the primary rays of a new submission join the trace queue of the current iteration behind
+// whatever the previous iteration's sort / shade kernels appended (kernel_stream_advance adds the count afterwards).
+// Sample s of the submission renders into sample slot slot_base + s.
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate_stream(RtParams p, int sample_index, int pixel_offset, int pixel_count, int slot_base) {
+	const int ray_count = pixel_count * p.batch_samples;
+	const RtTraceBuffer & out = p.trace[p.stream_iteration & 1];
+	const int base = p.stream->trace_count[p.stream_iteration & 1];
+	for (int index = blockIdx.x * blockDim.x + threadIdx.x; index < ray_count; index += gridDim.x * blockDim.x) {
+		int sample_in_batch = index / pixel_count;
+		int index_offset = rt_map_pixel(p, index - sample_in_batch * pixel_count + pixel_offset);
+		int x = index_offset % p.screen_width;
+		int y = index_offset / p.screen_width;
+		int pixel_index = x + y * p.screen_pitch;
+		unsigned slot = unsigned(slot_base + sample_in_batch);
+		unsigned virtual_pixel = slot * p.frame_pixels + unsigned(pixel_index);
+
+		f3 origin, direction;
+		camera_generate_ray(p, int(virtual_pixel), sample_index + sample_in_batch - int(slot), x, y, origin, direction); // random_sample adds the slot back
+
+		store3(out.origin,    base + index, origin);
+		store3(out.direction, base + index, direction);
+		out.pixel_index_and_flags[base + index] = virtual_pixel;
+	}
+}
+
+// Bookkeeping between the iterations of the merged wavefront, one thread: the generated rays are counted in, the
+// queues this iteration appends to start empty, the cursors of its trace launch are reset, and the host gets the
+// size of the wavefront (it bounds what is in flight with it before admitting the next submission).
+__global__ void kernel_stream_advance(RtStreamControl * control, int iteration, int generated, volatile int * progress) {
+	const int q = iteration & 1;
+	int total = control->trace_count[q] + generated;
+	control->trace_count[q] = total;
+	control->trace_count[q ^ 1] = 0;
+	for (int m = 0; m < 4; m++) control->material_count[m] = 0;
+	control->shadow_count[q] = 0;
+	control->cursor[q][0] = 0; control->cursor[q][1] = 0;
+	if (progress) { progress[1] = total; __threadfence_system(); progress[0] = iteration; }
+}
+
 __global__ void kernel_random(RtParams p, int dimension, const unsigned * pixel_indices, int count, unsigned bounce, unsigned sample_index, float2 * out) {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= count) return;
@@ -189,12 +228,53 @@ RT_DEV void material_queue_store(const RtParams & p, int slot, int index_out, in
 	if (bounce > 0) store3(q.throughput, index_out, throughput);
 }
 
-__global__ void __launch_bounds__(RT_SORT_BLOCK) kernel_sort(RtParams p, int bounce, int sample_index) {
-	const int ray_count = p.sizes->trace[bounce];
-	const RtTraceBuffer & in  = p.trace[bounce & 1];
-	const RtTraceBuffer & out = p.trace[(bounce + 1) & 1];
+// ---- per-submission statistics of the merged wavefront ------------------------------------------------------
+// Rays per (submission, queue kind, bounce), what rt_get_counters reports. A workgroup tallies in LDS -- per wave one
+// LDS add for every distinct submission among its lanes (queues are mostly sorted by submission, so usually one) --
+// and flushes its non-zero cells with one global add each when it is done.
+struct StreamStatsLDS { int count[RT_STREAM_SUBMISSIONS][RT_STAT_KINDS]; };
+
+RT_DEV void stream_stats_clear(StreamStatsLDS & lds) {
+	for (int i = threadIdx.x; i < RT_STREAM_SUBMISSIONS * RT_STAT_KINDS; i += blockDim.x) (&lds.count[0][0])[i] = 0;
+	__syncthreads();
+}
+// called in converged or diverged flow by any subset of lanes: lanes with `counted` add one to (submission, kind)
+RT_DEV void stream_stats_add(StreamStatsLDS & lds, bool counted, int submission, int kind) {
+	unsigned long long remaining = __ballot(counted);
+	while (remaining) {
+		int leader = __ffsll((long long)remaining) - 1;
+		int s = __shfl(submission, leader);
+		unsigned long long same = __ballot(counted && submission == s) & remaining;
+		if (int(lane_id()) == leader) atomicAdd(&lds.count[s][kind], __popcll(same));
+		remaining &= ~same;
+	}
+}
+RT_DEV void stream_stats_flush(const RtParams & p, StreamStatsLDS & lds) {
+	__syncthreads();
+	for (int i = threadIdx.x; i < RT_STREAM_SUBMISSIONS * RT_STAT_KINDS; i += blockDim.x) {
+		int n = (&lds.count[0][0])[i];
+		if (n == 0) continue;
+		int submission = i / RT_STAT_KINDS, kind = i % RT_STAT_KINDS;
+		int bounce = p.stream_iteration - p.stream_table->submission_birth[submission];
+		if (bounce >= 0 && bounce < RT_MAX_BOUNCES) atomicAdd(&p.stream->stats[submission][kind][bounce], n);
+	}
+}
+
+// MERGED: the launch processes the trace queue of iteration p.stream_iteration, whose entries are at different
+// bounces and belong to different samples (rt_stream_path_info); the launch arguments are ignored.
+template<bool MERGED>
+RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_index) {
+	const int q = MERGED ? (p.stream_iteration & 1) : (launch_bounce & 1);
+	const int ray_count = MERGED ? p.stream->trace_count[q] : p.sizes->trace[launch_bounce];
+	const RtTraceBuffer & in  = p.trace[q];
+	const RtTraceBuffer & out = p.trace[q ^ 1];
 	__shared__ BlockAppendLDS<4, RT_SORT_BLOCK / RT_WAVE_SIZE> append_lds;
-	int * const material_counters[4] = { &p.sizes->diffuse[bounce], &p.sizes->plastic[bounce], &p.sizes->dielectric[bounce], &p.sizes->conductor[bounce] };
+	__shared__ StreamStatsLDS stats_lds;
+	int * const material_counters[4] = {
+		MERGED ? &p.stream->material_count[0] : &p.sizes->diffuse[launch_bounce],    MERGED ? &p.stream->material_count[1] : &p.sizes->plastic[launch_bounce],
+		MERGED ? &p.stream->material_count[2] : &p.sizes->dielectric[launch_bounce], MERGED ? &p.stream->material_count[3] : &p.sizes->conductor[launch_bounce] };
+	int * const next_trace_counter = MERGED ? &p.stream->trace_count[q ^ 1] : &p.sizes->trace[launch_bounce + 1];
+	if (MERGED) stream_stats_clear(stats_lds);
 
 	// every thread of the workgroup makes the same number of rounds (block_aggregated_append has barriers)
 	for (int first = blockIdx.x * blockDim.x; first < ray_count; first += gridDim.x * blockDim.x) {
@@ -203,18 +283,24 @@ __global__ void __launch_bounds__(RT_SORT_BLOCK) kernel_sort(RtParams p, int bou
 		float ray_cone_angle = 0.0f, ray_cone_width = 0.0f;
 		int pixel_index = 0, medium_id = RT_INVALID;
 		f3 throughput = mk3(1.0f);
+		int bounce = launch_bounce, sample_index = launch_sample_index, submission = 0;
 
 		// classify one ray: the material queue it continues in, or -1 (missed, hit a light, scattered, terminated)
 		auto classify = [&]() -> int {
 		if (index >= ray_count) return -1;
+		unsigned pixel_index_and_flags = in.pixel_index_and_flags[index];
+		pixel_index = int(pixel_index_and_flags & ~RT_FLAGS_ALL);
+		bool first_of_submission = true;
+		if (MERGED) {
+			RtPathInfo info = rt_stream_path_info(p, unsigned(pixel_index));
+			bounce = info.bounce; sample_index = int(info.sample_index_for_rng); submission = info.submission; first_of_submission = info.first_of_submission;
+		}
 		ray_direction = load3(in.direction, index);
 		packed_hit = in.hits[index];
 		HitInfo hit = unpack_hit(packed_hit);
 
 		if (bounce > 0 && p.config.enable_mipmapping) { ray_cone_angle = in.cone_angle[index]; ray_cone_width = in.cone_width[index]; }
 
-		unsigned pixel_index_and_flags = in.pixel_index_and_flags[index];
-		pixel_index = int(pixel_index_and_flags & ~RT_FLAGS_ALL);
 		int x = pixel_index % p.screen_pitch;
 		int y = pixel_index / p.screen_pitch;
 
@@ -251,7 +337,7 @@ __global__ void __launch_bounds__(RT_SORT_BLOCK) kernel_sort(RtParams p, int bou
 					f3 direction_out = sample_henyey_greenstein(-ray_direction, medium.g, rand_phase.x, rand_phase.y);
 					f3 origin_out = load3(in.origin, index) + scatter_distance * ray_direction;
 
-					int index_out = wave_aggregated_append(&p.sizes->trace[bounce + 1]);
+					int index_out = wave_aggregated_append(next_trace_counter);
 					store3(out.origin,    index_out, origin_out);
 					store3(out.direction, index_out, direction_out);
 					out.medium[index_out] = medium_id;
@@ -278,7 +364,7 @@ __global__ void __launch_bounds__(RT_SORT_BLOCK) kernel_sort(RtParams p, int bou
 			return -1;
 		}
 
-		if (bounce == 0 && p.pixel_query_pixel == pixel_index) { // Pathtracer.cu:345-348 (sample 0 of a batch: virtual == real index)
+		if (bounce == 0 && first_of_submission && p.pixel_query_pixel == (MERGED ? int(unsigned(pixel_index) % p.frame_pixels) : pixel_index)) { // Pathtracer.cu:345-348 (sample 0 of a batch: virtual == real index)
 			p.pixel_query_out[0] = hit.mesh_id;
 			p.pixel_query_out[1] = hit.triangle_id;
 		}
@@ -337,10 +423,19 @@ __global__ void __launch_bounds__(RT_SORT_BLOCK) kernel_sort(RtParams p, int bou
 		};
 
 		int slot = classify();
+		if (MERGED) {
+			stream_stats_add(stats_lds, index < ray_count, submission, RT_STAT_TRACE);
+			#pragma unroll
+			for (int m = 0; m < 4; m++) stream_stats_add(stats_lds, slot == m, submission, RT_STAT_DIFFUSE + m);
+		}
 		int index_out = block_aggregated_append(slot, material_counters, append_lds);
 		if (slot >= 0) material_queue_store(p, slot, index_out, bounce, ray_direction, medium_id, ray_cone_angle, ray_cone_width, packed_hit, pixel_index, throughput);
 	}
+	if (MERGED) stream_stats_flush(p, stats_lds);
 }
+
+__global__ void __launch_bounds__(RT_SORT_BLOCK) kernel_sort(RtParams p, int bounce, int sample_index) { sort_rays<false>(p, bounce, sample_index); }
+__global__ void __launch_bounds__(RT_SORT_BLOCK) kernel_sort_stream(RtParams p) { sort_rays<true>(p, 0, 0); }
 
 // ---- BSDFs (CUDA/BSDF.h) ----------------------------------------------------------------------------------
 
@@ -700,15 +795,22 @@ RT_DEV f2 ray_cone_ellipse_axis_to_gradient(const TriangleFull & tri, float doub
 }
 RT_DEV float ray_cone_get_lod(f3 ray_direction, f3 geometric_normal, float cone_width) { return fabsf(cone_width / dot(ray_direction, geometric_normal)); }
 
-template<typename BSDF, int SLOT>
-RT_DEV void shade_material(const RtParams & p, int bounce, int sample_index, int buffer_size) {
+// MERGED: the queue holds the surface hits of every submission in flight (see sort_rays); bounce and sample come
+// from the slot table, the launch arguments are ignored.
+template<typename BSDF, int SLOT, bool MERGED>
+RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sample_index) {
 	const RtMaterialBuffer & q = p.material[SLOT];
-	const RtTraceBuffer & out = p.trace[(bounce + 1) & 1];
+	const int iq = MERGED ? (p.stream_iteration & 1) : (launch_bounce & 1);
+	const RtTraceBuffer & out = p.trace[iq ^ 1];
+	const int buffer_size = MERGED ? p.stream->material_count[SLOT]
+	                               : (SLOT == 0 ? p.sizes->diffuse[launch_bounce] : SLOT == 1 ? p.sizes->plastic[launch_bounce] : SLOT == 2 ? p.sizes->dielectric[launch_bounce] : p.sizes->conductor[launch_bounce]);
 
 	__shared__ BlockAppendLDS<1, RT_SHADE_BLOCK / RT_WAVE_SIZE> append_lds;
-	int * const shadow_counter[1] = { &p.sizes->shadow[bounce] };
-	int * const trace_counter[1]  = { &p.sizes->trace[bounce + 1] };
+	__shared__ StreamStatsLDS stats_lds;
+	int * const shadow_counter[1] = { MERGED ? &p.stream->shadow_count[iq]      : &p.sizes->shadow[launch_bounce] };
+	int * const trace_counter[1]  = { MERGED ? &p.stream->trace_count[iq ^ 1]   : &p.sizes->trace[launch_bounce + 1] };
 	const bool nee_enabled = p.config.enable_next_event_estimation && p.lights_total_weight > 0.0f; // uniform
+	if (MERGED) stream_stats_clear(stats_lds);
 
 	// every thread of the workgroup makes the same number of rounds (block_aggregated_append has barriers)
 	for (int first = blockIdx.x * blockDim.x; first < buffer_size; first += gridDim.x * blockDim.x) {
@@ -719,14 +821,19 @@ RT_DEV void shade_material(const RtParams & p, int bounce, int sample_index, int
 		f3 throughput = mk3(1.0f), hit_point = mk3(0.0f), geometric_normal = mk3(0.0f);
 		float cone_angle = 0.0f, cone_width = 0.0f;
 		ShadowRay shadow; bool has_shadow_ray = false;
+		int bounce = launch_bounce, sample_index = launch_sample_index, submission = 0;
 
 		auto set_up_surface = [&]() -> bool { // false: the path ends here
 		if (index >= buffer_size) return false;
+		unsigned pixel_index_and_flags = q.pixel_index_and_flags[index];
+		pixel_index = int(pixel_index_and_flags & ~RT_FLAGS_ALL);
+		if (MERGED) {
+			RtPathInfo info = rt_stream_path_info(p, unsigned(pixel_index));
+			bounce = info.bounce; sample_index = int(info.sample_index_for_rng); submission = info.submission;
+		}
 		f3 ray_direction = load3(q.direction, index);
 		HitInfo hit = unpack_hit(q.hits[index]);
 
-		unsigned pixel_index_and_flags = q.pixel_index_and_flags[index];
-		pixel_index = int(pixel_index_and_flags & ~RT_FLAGS_ALL);
 		bool inside_medium = pixel_index_and_flags & RT_FLAG_INSIDE_MEDIUM;
 		medium_id = inside_medium ? q.medium[index] : RT_INVALID;
 
@@ -814,12 +921,15 @@ RT_DEV void shade_material(const RtParams & p, int bounce, int sample_index, int
 		bool alive = set_up_surface();
 
 		if (nee_enabled) {
+			if (MERGED) stream_stats_add(stats_lds, has_shadow_ray, submission, RT_STAT_SHADOW);
 			int shadow_ray_index = block_aggregated_append(has_shadow_ray ? 0 : -1, shadow_counter, append_lds);
 			if (has_shadow_ray) {
 				store3(p.shadow.origin,    shadow_ray_index, shadow.origin);
 				store3(p.shadow.direction, shadow_ray_index, shadow.direction);
 				p.shadow.max_distance[shadow_ray_index] = shadow.max_distance;
-				p.shadow.illumination_and_pixel_index[shadow_ray_index] = make_float4(shadow.illumination.x, shadow.illumination.y, shadow.illumination.z, __int_as_float(pixel_index));
+				// merged wavefront: the trace launch that consumes the ray cannot know its bounce from a launch argument
+				unsigned pixel_word = unsigned(pixel_index) | (MERGED && bounce == 0 ? RT_SHADOW_FLAG_BOUNCE_0 : 0u);
+				p.shadow.illumination_and_pixel_index[shadow_ray_index] = make_float4(shadow.illumination.x, shadow.illumination.y, shadow.illumination.z, __uint_as_float(pixel_word));
 			}
 		}
 
@@ -843,12 +953,17 @@ RT_DEV void shade_material(const RtParams & p, int bounce, int sample_index, int
 		store3(out.throughput, index_out, throughput);
 		if (allow_nee) out.last_pdf[index_out] = pdf;
 	}
+	if (MERGED) stream_stats_flush(p, stats_lds);
 }
 
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_diffuse(RtParams p, int bounce, int sample_index)    { shade_material<BSDFDiffuse,    0>(p, bounce, sample_index, p.sizes->diffuse   [bounce]); }
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_plastic(RtParams p, int bounce, int sample_index)    { shade_material<BSDFPlastic,    1>(p, bounce, sample_index, p.sizes->plastic   [bounce]); }
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_dielectric(RtParams p, int bounce, int sample_index) { shade_material<BSDFDielectric, 2>(p, bounce, sample_index, p.sizes->dielectric[bounce]); }
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_conductor(RtParams p, int bounce, int sample_index)  { shade_material<BSDFConductor,  3>(p, bounce, sample_index, p.sizes->conductor [bounce]); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_diffuse(RtParams p, int bounce, int sample_index)    { shade_material<BSDFDiffuse,    0, false>(p, bounce, sample_index); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_plastic(RtParams p, int bounce, int sample_index)    { shade_material<BSDFPlastic,    1, false>(p, bounce, sample_index); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_dielectric(RtParams p, int bounce, int sample_index) { shade_material<BSDFDielectric, 2, false>(p, bounce, sample_index); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_conductor(RtParams p, int bounce, int sample_index)  { shade_material<BSDFConductor,  3, false>(p, bounce, sample_index); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_diffuse_stream(RtParams p)    { shade_material<BSDFDiffuse,    0, true>(p, 0, 0); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_plastic_stream(RtParams p)    { shade_material<BSDFPlastic,    1, true>(p, 0, 0); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_dielectric_stream(RtParams p) { shade_material<BSDFDielectric, 2, true>(p, 0, 0); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_conductor_stream(RtParams p)  { shade_material<BSDFConductor,  3, true>(p, 0, 0); }
 
 // ---- ambient occlusion (CUDA/AO.cu:103-159) -------------------------------------------------------
 // One cosine-weighted occlusion ray of length ao_radius per primary hit; the AO shadow kernel sets
@@ -929,6 +1044,24 @@ void rt_launch_material(const RtParams & p, int material_slot, int bounce, int s
 		case 1: hipLaunchKernelGGL(kernel_material_plastic,    grid, block, 0, stream, p, bounce, sample_index); break;
 		case 2: hipLaunchKernelGGL(kernel_material_dielectric, grid, block, 0, stream, p, bounce, sample_index); break;
 		case 3: hipLaunchKernelGGL(kernel_material_conductor,  grid, block, 0, stream, p, bounce, sample_index); break;
+	}
+}
+void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, int slot_base, hipStream_t stream) {
+	hipLaunchKernelGGL(kernel_generate_stream, dim3(streaming_grid(pixel_count * p.batch_samples)), dim3(RT_SHADE_BLOCK), 0, stream, p, sample_index, pixel_offset, pixel_count, slot_base);
+}
+void rt_launch_stream_advance(RtStreamControl * control, int iteration, int generated, int * progress, hipStream_t stream) {
+	hipLaunchKernelGGL(kernel_stream_advance, dim3(1), dim3(1), 0, stream, control, iteration, generated, (volatile int *)progress);
+}
+void rt_launch_sort_stream(const RtParams & p, hipStream_t stream) {
+	hipLaunchKernelGGL(kernel_sort_stream, dim3(2048 * RT_SHADE_BLOCK / RT_SORT_BLOCK), dim3(RT_SORT_BLOCK), 0, stream, p);
+}
+void rt_launch_material_stream(const RtParams & p, int material_slot, hipStream_t stream) {
+	dim3 grid(2048), block(RT_SHADE_BLOCK);
+	switch (material_slot) {
+		case 0: hipLaunchKernelGGL(kernel_material_diffuse_stream,    grid, block, 0, stream, p); break;
+		case 1: hipLaunchKernelGGL(kernel_material_plastic_stream,    grid, block, 0, stream, p); break;
+		case 2: hipLaunchKernelGGL(kernel_material_dielectric_stream, grid, block, 0, stream, p); break;
+		case 3: hipLaunchKernelGGL(kernel_material_conductor_stream,  grid, block, 0, stream, p); break;
 	}
 }
 void rt_launch_ambient_occlusion(const RtParams & p, int sample_index, float ao_radius, hipStream_t stream) {

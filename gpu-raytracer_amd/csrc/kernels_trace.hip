@@ -632,6 +632,28 @@ struct ShadowQueueSource {
 	}
 };
 
+// Merged wavefront: the shadow queue holds rays emitted at different bounces; the one distinction the miss lambda makes
+// (bounce 0 sets RADIANCE_DIRECT, later bounces add to RADIANCE_INDIRECT) travels as a flag in the pixel word.
+struct ShadowStreamSource {
+	RtShadowBuffer buffer;
+	RtAOV radiance, direct, indirect;
+	RT_DEV void load(int i, Ray3 & ray, float & max_distance) const { ray.origin = load3(buffer.origin, i); ray.direction = load3(buffer.direction, i); max_distance = buffer.max_distance[i]; }
+	RT_DEV void finish(int i, const HitRecord &, bool occluded) const {
+		if (occluded) return;
+		float4 ip = buffer.illumination_and_pixel_index[i];
+		unsigned pixel_word = __float_as_uint(ip.w);
+		int pixel_index = int(pixel_word & ~RT_SHADOW_FLAG_BOUNCE_0);
+		float4 value = make_float4(ip.x, ip.y, ip.z, 0.0f);
+		if (radiance.framebuffer) { float4 c = radiance.framebuffer[pixel_index]; radiance.framebuffer[pixel_index] = make_float4(c.x + value.x, c.y + value.y, c.z + value.z, c.w + value.w); }
+		if (pixel_word & RT_SHADOW_FLAG_BOUNCE_0) {
+			if (direct.framebuffer) direct.framebuffer[pixel_index] = value;
+		} else if (indirect.framebuffer) {
+			float4 c = indirect.framebuffer[pixel_index];
+			indirect.framebuffer[pixel_index] = make_float4(c.x + value.x, c.y + value.y, c.z + value.z, c.w + value.w);
+		}
+	}
+};
+
 // AO integrator: an occlusion ray that escapes sets RADIANCE to 1 (CUDA/AO.cu:77-101)
 struct ShadowAOSource {
 	RtShadowBuffer buffer;
@@ -1036,6 +1058,27 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_
 #endif
 }
 
+// The ONE traversal launch of an iteration of the merged wavefront: the closest-hit rays of the iteration (primary rays of
+// the newest submission and the continuation rays of all others) and then, by the same persistent waves as they run out of
+// those, the shadow rays the previous iteration's shade kernels emitted. Both queues are complete when the launch starts,
+// both results are needed by the same next kernel (sort), so there is nothing to gain from two launches that would only
+// compete for the wave slots -- and a wave that finds the closest-hit queue drained goes straight on to shadow rays instead
+// of idling through the other waves' tails.
+template<bool COUNT>
+RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
+	const int q = p.stream_iteration & 1;
+	{
+		ClosestHitSource src { p.trace[q].origin, p.trace[q].direction, p.trace[q].hits };
+		RT_TRACE_ENGINE<false, COUNT>(p, src, p.stream->trace_count[q], &p.stream->cursor[q][0], stats);
+	}
+	{
+		ShadowStreamSource src { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT] };
+		RT_TRACE_ENGINE<true, COUNT>(p, src, p.stream->shadow_count[q ^ 1], &p.stream->cursor[q][1], COUNT ? stats + 5 : nullptr);
+	}
+}
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8(RtParams p) { trace_stream<false>(p, nullptr); }
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_counting(RtParams p, unsigned long long * stats) { trace_stream<true>(p, stats); }
+
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {
 	ClosestHitSource src { origin, direction, hits };
 	RT_TRACE_ENGINE<false, false>(p, src, ray_count, retired);
@@ -1104,6 +1147,15 @@ void rt_launch_trace_shadow_ao(const RtParams & p, hipStream_t stream) {
 	}
 	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8_ao);
 	hipLaunchKernelGGL(kernel_trace_shadow_bvh8_ao, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p);
+}
+void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, hipStream_t stream) {
+	if (stats) {
+		static int grid_counting = trace_grid_size((const void *)kernel_trace_stream_bvh8_counting);
+		hipLaunchKernelGGL(kernel_trace_stream_bvh8_counting, dim3(grid_counting), dim3(RT_TRACE_BLOCK), 0, stream, p, stats);
+		return;
+	}
+	static int grid = trace_grid_size((const void *)kernel_trace_stream_bvh8);
+	hipLaunchKernelGGL(kernel_trace_stream_bvh8, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p);
 }
 void rt_launch_trace_counting(const RtParams & p, int bounce, unsigned long long * stats, hipStream_t stream) {
 	static int grid = trace_grid_size((const void *)kernel_trace_bvh8_counting);

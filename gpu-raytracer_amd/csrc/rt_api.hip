@@ -6,10 +6,12 @@
 // wavefront launch loop of Pathtracer::render, Pathtracer.cpp:738-855).
 #include "rt_types.h"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -69,6 +71,54 @@ struct SceneRing {
 	int current = -1;
 };
 
+// ---- merged wavefront (RT_SCHEDULER_MERGED; the idea is described at RtStreamSlot in rt_types.h) -------------------
+// Host side: ONE stream, one set of queues sized for `capacity` rays. A submission (one rt_render_samples call) gets a
+// run of sample slots, generates its primary rays into the current trace queue and advances the wavefront by one
+// iteration; it is complete -- accumulated into the shared accumulators, in submission order -- after the iteration in
+// which it reaches its last bounce. What bounds the queues: every path in flight occupies at most one entry of a
+// queue, paths only die, so (wavefront size reported by an earlier iteration) + (rays generated since) bounds the
+// entries any queue can receive; the host stays RT_STREAM_RUN_AHEAD iterations ahead of the device at most, reads the
+// reported sizes from pinned memory without blocking, and runs iterations without new samples while a new
+// submission would not fit.
+#define RT_STREAM_PROGRESS_RING   64
+#define RT_STREAM_RUN_AHEAD       4
+#define RT_STREAM_TABLE_SNAPSHOTS 8
+#define RT_STREAM_HISTORY_ROWS    4096
+#define RT_STREAM_STATS_ROW       (RT_STAT_KINDS * RT_MAX_BOUNCES)   // ints per submission
+
+struct StreamSubmission {
+	int first_sample, sample_count, slot_base, ring, birth, last, paths;
+	int range_offset, range_count, tile_pixels, tile_first, tile_stride;
+};
+
+struct PathStream {
+	bool created = false;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev_idle = nullptr;         // after the last completion enqueued so far: what main-stream consumers wait for
+	RtTraceBuffer trace[2]; RtMaterialBuffer material[4]; RtShadowBuffer shadow;
+	bool queues_allocated = false; size_t capacity = 0;
+	RtStreamControl * control = nullptr;
+	RtStreamTable * table_device = nullptr;
+	RtStreamTable table_host;             // what the device table will hold once the copies enqueued so far have run
+	RtStreamTable * table_staging = nullptr; hipEvent_t table_copied[RT_STREAM_TABLE_SNAPSHOTS] = { }; int table_next = 0;
+	void * spill = nullptr;
+	void * aov_framebuffer[RT_AOV_COUNT] = { }; int frame_slots = 0;   // per-sample frames, one per sample slot
+	bool slot_used[RT_STREAM_SAMPLE_SLOTS] = { };
+	int next_slot = 0, next_ring = 0;
+	int iteration = 0;                    // the next iteration to enqueue
+	int base_iteration = 0;               // nothing generated before it is still in flight
+	std::deque<StreamSubmission> in_flight;
+	int * progress = nullptr;             // pinned [RING][2] = { iteration, wavefront size }, written by kernel_stream_advance
+	hipEvent_t iteration_done[RT_STREAM_PROGRESS_RING] = { };
+	int generated[RT_STREAM_PROGRESS_RING] = { };
+	int known_iteration = -1; long long known_size = 0;
+	unsigned long long submissions_completed = 0;
+	int * stats_host = nullptr;           // pinned [RT_STREAM_SUBMISSIONS][RT_STREAM_STATS_ROW]
+	hipEvent_t ev_begin[RT_STREAM_SUBMISSIONS] = { }, ev_end[RT_STREAM_SUBMISSIONS] = { };
+	int last_completed_ring = -1;
+	unsigned long long * history = nullptr; int history_rows = 0;   // pinned [ROWS][10]: trace statistics after each iteration
+};
+
 struct rt_context {
 	int device = 0;
 	hipStream_t stream = nullptr;      // "main": uploads, read-backs, pack/unpack, kernel-level entry points
@@ -76,6 +126,10 @@ struct rt_context {
 	std::string error;
 
 	SampleSlot slots[RT_MAX_SAMPLE_SLOTS];
+	PathStream path_stream;
+	int scheduler = RT_SCHEDULER_MERGED;
+	bool last_render_merged = false;
+	bool frame_pipelining = false;     // rt_pack_pixels / rt_unpack_pixels follow the completed submissions only (rt_set_frame_pipelining)
 	int samples_in_flight = 3;
 	bool overlap_shadows = true;
 	unsigned render_counter = 0;
@@ -156,8 +210,16 @@ static int upload(rt_context * ctx, void ** slot, const void * src, size_t bytes
 	return RT_OK;
 }
 
-// Wait for everything the context has in flight: every sample slot (and its side stream), then main.
+// Wait for everything the context has in flight: the merged wavefront (run to completion first), every sample
+// slot (and its side stream), then main.
+static hipError_t stream_flush(rt_context * ctx);
+static void stream_destroy(rt_context * ctx);
+static void stream_release_frames(rt_context * ctx);
 static hipError_t quiesce(rt_context * ctx) {
+	if (ctx->path_stream.created) {
+		hipError_t e = stream_flush(ctx);                            if (e != hipSuccess) return e;
+		e = hipStreamSynchronize(ctx->path_stream.stream);           if (e != hipSuccess) return e;
+	}
 	for (SampleSlot & slot : ctx->slots) if (slot.created) {
 		hipError_t e = hipStreamSynchronize(slot.side);   if (e != hipSuccess) return e;
 		e = hipStreamSynchronize(slot.stream);            if (e != hipSuccess) return e;
@@ -167,6 +229,10 @@ static hipError_t quiesce(rt_context * ctx) {
 
 // Main-stream work that reads or writes frame results is ordered after every sample already submitted.
 static hipError_t main_waits_for_samples(rt_context * ctx) {
+	if (ctx->path_stream.created) {
+		if (!ctx->frame_pipelining) { hipError_t e = stream_flush(ctx); if (e != hipSuccess) return e; }
+		hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->path_stream.ev_idle, 0); if (e != hipSuccess) return e;
+	}
 	for (SampleSlot & slot : ctx->slots) if (slot.created) {
 		hipError_t e = hipStreamWaitEvent(ctx->stream, slot.ev_done, 0); if (e != hipSuccess) return e;
 	}
@@ -229,6 +295,8 @@ static RtParams slot_params(const rt_context * ctx, const SampleSlot & slot, int
 // ring_commit() then starts the copy. `which` selects the slot field that remembers the version in use.
 static int ring_begin(rt_context * ctx, SceneRing & ring, size_t bytes, int SampleSlot::* which, void ** staging) {
 	if (bytes == 0) bytes = 16;
+	// a launch of the merged wavefront traces the rays of every submission in flight against ONE scene version
+	if (ctx->path_stream.created) RT_HIP(ctx, stream_flush(ctx));
 	if (bytes > ring.capacity) { // first use, or the scene outgrew the ring: start over (the only case that drains)
 		RT_HIP(ctx, quiesce(ctx));
 		size_t capacity = bytes + bytes / 2 + 256; // a TLAS changes its node count a little from frame to frame
@@ -266,6 +334,8 @@ static bool bvh_nodes_present(const rt_context * ctx) {
 	return ctx->bvh_width == 8 ? p.bvh8_nodes != nullptr : (ctx->bvh_width == 4 ? p.bvh4_nodes != nullptr : p.bvh2_nodes != nullptr);
 }
 
+enum { STAGE_GENERATE = 0, STAGE_TRACE, STAGE_SORT, STAGE_SHADE, STAGE_SHADOW, STAGE_POST, STAGE_END };
+
 extern "C" {
 
 const char * rt_version(void) { return "gpu-raytracer_amd 0.1 (gfx950, HIP)"; }
@@ -292,6 +362,7 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 	RT_HIP(ctx, hipEventRecord(ctx->ev_scene, ctx->stream));
 	if (const char * e = getenv("GRT_SAMPLES_IN_FLIGHT")) { int n = atoi(e); if (n >= 1 && n <= RT_MAX_SAMPLE_SLOTS) ctx->samples_in_flight = n; }
 	if (const char * e = getenv("GRT_OVERLAP_SHADOWS")) ctx->overlap_shadows = atoi(e) != 0;
+	if (const char * e = getenv("GRT_SCHEDULER")) ctx->scheduler = strcmp(e, "slots") == 0 ? RT_SCHEDULER_SLOTS : RT_SCHEDULER_MERGED;
 
 	int s = ensure_slot(ctx, 0); if (s) return s;
 	s = device_alloc(ctx, (void **)&ctx->explicit_retired, 8 * sizeof(int)); if (s) return s;
@@ -317,6 +388,7 @@ void rt_destroy(rt_context * ctx) {
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	(void)quiesce(ctx);
+	stream_destroy(ctx);
 	for (void * p : ctx->owned) (void)hipFree(p);
 	for (hipEvent_t e : ctx->stage_events) (void)hipEventDestroy(e);
 	for (hipEvent_t e : ctx->span_events) (void)hipEventDestroy(e);
@@ -629,6 +701,7 @@ static int sync_aovs(rt_context * ctx) {
 		bool allocated = ctx->aov_buffers[i][0] != nullptr;
 		if (enabled && !allocated && bytes) {
 			RT_HIP(ctx, quiesce(ctx));
+			stream_release_frames(ctx);
 			for (int k = 0; k < 2; k++) { // [0]: slot 0's per-sample frame buffer(s), [1]: the accumulator
 				size_t n = k == 0 ? bytes * ctx->slots[0].aov_samples : bytes;
 				int s = device_alloc(ctx, &ctx->aov_buffers[i][k], n); if (s) return s;
@@ -640,6 +713,7 @@ static int sync_aovs(rt_context * ctx) {
 			}
 		} else if (!enabled && allocated) {
 			RT_HIP(ctx, quiesce(ctx));
+			stream_release_frames(ctx);
 			for (int k = 0; k < 2; k++) { device_free(ctx, ctx->aov_buffers[i][k]); ctx->aov_buffers[i][k] = nullptr; }
 			for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) { device_free(ctx, ctx->slots[k].aov_framebuffer[i]); ctx->slots[k].aov_framebuffer[i] = nullptr; }
 		}
@@ -710,6 +784,7 @@ int rt_resize(rt_context * ctx, int width, int height) {
 	int pitch = (width + 31) / 32 * 32; // Math::round_up(width, WARP_SIZE), Pathtracer.cpp:258
 	ctx->params.screen_width = width; ctx->params.screen_height = height; ctx->params.screen_pitch = pitch;
 	ctx->frame_pixels = size_t(pitch) * height;
+	stream_release_frames(ctx);
 
 	for (int i = 0; i < RT_AOV_COUNT; i++) for (int k = 0; k < 2; k++) { device_free(ctx, ctx->aov_buffers[i][k]); ctx->aov_buffers[i][k] = nullptr; }
 	for (int i = 0; i < RT_AOV_COUNT; i++) for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) { device_free(ctx, ctx->slots[k].aov_framebuffer[i]); ctx->slots[k].aov_framebuffer[i] = nullptr; }
@@ -746,6 +821,7 @@ int rt_set_config(rt_context * ctx, const rt_gpu_config * config) {
 	RT_REQUIRE(ctx, config->num_bounces >= 0 && config->num_bounces <= RT_MAX_BOUNCES, "rt_set_config: num_bounces out of range");
 	RT_REQUIRE(ctx, config->num_atrous_iterations >= 0 && config->num_atrous_iterations <= RT_MAX_ATROUS_ITERATIONS, "rt_set_config: num_atrous_iterations out of range");
 	(void)hipSetDevice(ctx->device);
+	if (ctx->path_stream.created && memcmp(&ctx->params.config, config, sizeof(*config)) != 0) RT_HIP(ctx, stream_flush(ctx)); // the submissions in flight were made under the old settings
 	ctx->params.config = *config;
 	ctx->params.config.aov_mask |= 1u << RT_AOV_RADIANCE;
 	if (config->enable_svgf) ctx->params.config.aov_mask |= (1u << RT_AOV_RADIANCE_DIRECT) | (1u << RT_AOV_RADIANCE_INDIRECT) | (1u << RT_AOV_ALBEDO);
@@ -836,6 +912,58 @@ int rt_set_profiling(rt_context * ctx, int enable) {
 	ctx->launch_timing = enable == 2;
 	ctx->timing_counter = 0;
 	ctx->span_used = 0;
+	ctx->stage_used = 0;
+	return RT_OK;
+}
+
+int rt_get_launch_timings(rt_context * ctx, int kind, float * out_ms, int capacity, int * out_count) {
+	RT_REQUIRE(ctx, ctx && out_count && (out_ms || capacity == 0) && (kind == 0 || kind == 1), "rt_get_launch_timings: invalid argument");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	int n = 0;
+	for (size_t i = 0; i + 1 < ctx->span_used; i += 2) {
+		if ((ctx->span_kinds[i] == STAGE_TRACE ? 0 : 1) != kind) continue;
+		float d = 0.0f;
+		if (hipEventElapsedTime(&d, ctx->span_events[i], ctx->span_events[i + 1]) != hipSuccess) continue;
+		if (n < capacity) out_ms[n] = d;
+		n++;
+	}
+	*out_count = n;
+	if (n <= capacity) { // everything delivered: start over (a call with too small a buffer only reports the count)
+		size_t kept = 0;
+		for (size_t i = 0; i + 1 < ctx->span_used; i += 2) if ((ctx->span_kinds[i] == STAGE_TRACE ? 0 : 1) != kind) {
+			std::swap(ctx->span_events[kept], ctx->span_events[i]); std::swap(ctx->span_events[kept + 1], ctx->span_events[i + 1]);
+			ctx->span_kinds[kept] = ctx->span_kinds[i]; ctx->span_kinds[kept + 1] = ctx->span_kinds[i + 1];
+			kept += 2;
+		}
+		ctx->span_used = kept;
+	}
+	return RT_OK;
+}
+
+int rt_set_scheduler(rt_context * ctx, int scheduler) {
+	RT_REQUIRE(ctx, ctx && (scheduler == RT_SCHEDULER_MERGED || scheduler == RT_SCHEDULER_SLOTS), "rt_set_scheduler: unknown scheduler");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	ctx->scheduler = scheduler;
+	return RT_OK;
+}
+
+int rt_set_frame_pipelining(rt_context * ctx, int enable) {
+	RT_REQUIRE(ctx, ctx, "rt_set_frame_pipelining: NULL context");
+	ctx->frame_pipelining = enable != 0;
+	return RT_OK;
+}
+
+int rt_get_trace_statistics_history(rt_context * ctx, uint64_t * out_rows10, int capacity_rows, int * out_rows) {
+	RT_REQUIRE(ctx, ctx && out_rows && (out_rows10 || capacity_rows == 0), "rt_get_trace_statistics_history: invalid argument");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	const PathStream & s = ctx->path_stream;
+	int rows = s.created ? s.history_rows : 0;
+	*out_rows = rows;
+	if (rows > capacity_rows) rows = capacity_rows;
+	if (rows > 0) memcpy(out_rows10, s.history, size_t(rows) * 10 * sizeof(uint64_t));
 	return RT_OK;
 }
 
@@ -859,7 +987,6 @@ static int ensure_luts(rt_context * ctx) {
 	return RT_OK;
 }
 
-enum { STAGE_GENERATE = 0, STAGE_TRACE, STAGE_SORT, STAGE_SHADE, STAGE_SHADOW, STAGE_POST, STAGE_END };
 
 static void stage_mark(rt_context * ctx, int kind, hipStream_t stream) {
 	if (!ctx->profiling) return;
@@ -887,6 +1014,291 @@ __global__ void kernel_accumulate_counters(const RtBufferSizes * sizes, int * to
 	totals[5 * RT_MAX_BOUNCES + b] += sizes->conductor[b];
 }
 
+
+} // extern "C" -- the merged-wavefront scheduler below is internal
+
+// ---- merged wavefront: host side ---------------------------------------------------------------------------------
+
+static int stream_create(rt_context * ctx) {
+	PathStream & s = ctx->path_stream;
+	if (s.created) return RT_OK;
+	memset(s.trace, 0, sizeof(s.trace)); memset(s.material, 0, sizeof(s.material)); memset(&s.shadow, 0, sizeof(s.shadow));
+	RT_HIP(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+	RT_HIP(ctx, hipEventCreateWithFlags(&s.ev_idle, hipEventDisableTiming));
+	RT_HIP(ctx, hipEventRecord(s.ev_idle, s.stream));
+	int status = device_alloc(ctx, (void **)&s.control, sizeof(RtStreamControl)); if (status) return status;
+	RT_HIP(ctx, hipMemset(s.control, 0, sizeof(RtStreamControl)));
+	status = device_alloc(ctx, (void **)&s.table_device, sizeof(RtStreamTable)); if (status) return status;
+	RT_HIP(ctx, hipMemset(s.table_device, 0, sizeof(RtStreamTable)));
+	memset(&s.table_host, 0, sizeof(s.table_host));
+	RT_HIP(ctx, hipHostMalloc((void **)&s.table_staging, sizeof(RtStreamTable) * RT_STREAM_TABLE_SNAPSHOTS));
+	for (hipEvent_t & e : s.table_copied) { RT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); RT_HIP(ctx, hipEventRecord(e, s.stream)); }
+	// one spill area: the closest-hit and the shadow part of the fused launch run one after the other in the same waves
+	status = device_alloc(ctx, &s.spill, size_t(24) * 8 * 256 * 8 * 256); if (status) return status;
+	RT_HIP(ctx, hipHostMalloc((void **)&s.progress, sizeof(int) * 2 * RT_STREAM_PROGRESS_RING));
+	for (int i = 0; i < 2 * RT_STREAM_PROGRESS_RING; i++) s.progress[i] = -1;
+	for (hipEvent_t & e : s.iteration_done) { RT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); RT_HIP(ctx, hipEventRecord(e, s.stream)); }
+	RT_HIP(ctx, hipHostMalloc((void **)&s.stats_host, sizeof(int) * RT_STREAM_SUBMISSIONS * RT_STREAM_STATS_ROW));
+	memset(s.stats_host, 0, sizeof(int) * RT_STREAM_SUBMISSIONS * RT_STREAM_STATS_ROW);
+	for (int i = 0; i < RT_STREAM_SUBMISSIONS; i++) { RT_HIP(ctx, hipEventCreate(&s.ev_begin[i])); RT_HIP(ctx, hipEventCreate(&s.ev_end[i])); }
+	RT_HIP(ctx, hipHostMalloc((void **)&s.history, sizeof(unsigned long long) * 10 * RT_STREAM_HISTORY_ROWS));
+	s.created = true;
+	return RT_OK;
+}
+
+static void stream_destroy(rt_context * ctx) {
+	PathStream & s = ctx->path_stream;
+	if (!s.stream) return;
+	if (s.table_staging) (void)hipHostFree(s.table_staging);
+	if (s.progress)      (void)hipHostFree(s.progress);
+	if (s.stats_host)    (void)hipHostFree(s.stats_host);
+	if (s.history)       (void)hipHostFree(s.history);
+	for (hipEvent_t e : s.table_copied)   if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : s.iteration_done) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : s.ev_begin)       if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : s.ev_end)         if (e) (void)hipEventDestroy(e);
+	if (s.ev_idle) (void)hipEventDestroy(s.ev_idle);
+	(void)hipStreamDestroy(s.stream);
+	s.stream = nullptr; s.created = false;
+}
+
+// The per-sample frames of the sample slots (they are freed with the frame resources: rt_resize, AOV changes).
+static void stream_release_frames(rt_context * ctx) {
+	PathStream & s = ctx->path_stream;
+	for (void * & fb : s.aov_framebuffer) { device_free(ctx, fb); fb = nullptr; }
+	s.frame_slots = 0;
+}
+
+static int stream_ensure_frames(rt_context * ctx, int wanted_slots) {
+	PathStream & s = ctx->path_stream;
+	int limit = int(std::min<size_t>(RT_STREAM_SAMPLE_SLOTS, ((size_t(1) << 30) - 1) / ctx->frame_pixels));
+	int slots = std::min(limit, std::max(wanted_slots, 8));
+	bool complete = s.frame_slots >= slots;
+	for (int i = 0; i < RT_AOV_COUNT; i++) if ((ctx->aov_buffers[i][0] != nullptr) != (s.aov_framebuffer[i] != nullptr)) complete = false;
+	if (complete) return RT_OK;
+	RT_HIP(ctx, quiesce(ctx));
+	slots = std::max(slots, s.frame_slots);
+	stream_release_frames(ctx);
+	size_t bytes = ctx->frame_pixels * 16 * size_t(slots);
+	for (int i = 0; i < RT_AOV_COUNT; i++) if (ctx->aov_buffers[i][0]) {
+		int status = device_alloc(ctx, &s.aov_framebuffer[i], bytes); if (status) return status;
+		RT_HIP(ctx, hipMemset(s.aov_framebuffer[i], 0, bytes));
+	}
+	s.frame_slots = slots;
+	for (bool & used : s.slot_used) used = false;
+	s.next_slot = 0;
+	return RT_OK;
+}
+
+static int stream_ensure_queues(rt_context * ctx, size_t entries) {
+	PathStream & s = ctx->path_stream;
+	if (s.queues_allocated && s.capacity >= entries) return RT_OK;
+	RT_HIP(ctx, quiesce(ctx));
+	auto free3 = [&](RtVec3SoA & v) { device_free(ctx, v.x); device_free(ctx, v.y); device_free(ctx, v.z); };
+	if (s.queues_allocated) {
+		for (RtTraceBuffer & t : s.trace) { free3(t.origin); free3(t.direction); device_free(ctx, t.hits); device_free(ctx, t.cone_angle); device_free(ctx, t.cone_width); device_free(ctx, t.medium); device_free(ctx, t.pixel_index_and_flags); free3(t.throughput); device_free(ctx, t.last_pdf); }
+		for (RtMaterialBuffer & m : s.material) { free3(m.direction); device_free(ctx, m.hits); device_free(ctx, m.cone_angle); device_free(ctx, m.cone_width); device_free(ctx, m.medium); device_free(ctx, m.pixel_index_and_flags); free3(m.throughput); }
+		free3(s.shadow.origin); free3(s.shadow.direction); device_free(ctx, s.shadow.max_distance); device_free(ctx, s.shadow.illumination_and_pixel_index);
+		s.queues_allocated = false;
+	}
+	size_t n = entries;
+	int status;
+	for (RtTraceBuffer & t : s.trace) {
+		if ((status = alloc_vec3(ctx, t.origin, n))) return status;
+		if ((status = alloc_vec3(ctx, t.direction, n))) return status;
+		if ((status = device_alloc(ctx, (void **)&t.hits, n * 16))) return status;
+		if ((status = device_alloc(ctx, (void **)&t.cone_angle, n * 4))) return status;
+		if ((status = device_alloc(ctx, (void **)&t.cone_width, n * 4))) return status;
+		if ((status = device_alloc(ctx, (void **)&t.medium, n * 4))) return status;
+		if ((status = device_alloc(ctx, (void **)&t.pixel_index_and_flags, n * 4))) return status;
+		if ((status = alloc_vec3(ctx, t.throughput, n))) return status;
+		if ((status = device_alloc(ctx, (void **)&t.last_pdf, n * 4))) return status;
+	}
+	for (RtMaterialBuffer & m : s.material) {
+		if ((status = alloc_vec3(ctx, m.direction, n))) return status;
+		if ((status = device_alloc(ctx, (void **)&m.hits, n * 16))) return status;
+		if ((status = device_alloc(ctx, (void **)&m.cone_angle, n * 4))) return status;
+		if ((status = device_alloc(ctx, (void **)&m.cone_width, n * 4))) return status;
+		if ((status = device_alloc(ctx, (void **)&m.medium, n * 4))) return status;
+		if ((status = device_alloc(ctx, (void **)&m.pixel_index_and_flags, n * 4))) return status;
+		if ((status = alloc_vec3(ctx, m.throughput, n))) return status;
+	}
+	if ((status = alloc_vec3(ctx, s.shadow.origin, n))) return status;
+	if ((status = alloc_vec3(ctx, s.shadow.direction, n))) return status;
+	if ((status = device_alloc(ctx, (void **)&s.shadow.max_distance, n * 4))) return status;
+	if ((status = device_alloc(ctx, (void **)&s.shadow.illumination_and_pixel_index, n * 16))) return status;
+	s.queues_allocated = true;
+	s.capacity = n;
+	return RT_OK;
+}
+
+// The parameter block of iteration `iteration`: the context's block with the stream's queues, control block and
+// per-sample frames patched in.
+static RtParams stream_params(const rt_context * ctx, int iteration) {
+	const PathStream & s = ctx->path_stream;
+	RtParams p = ctx->params;
+	memcpy(p.trace, s.trace, sizeof(p.trace)); memcpy(p.material, s.material, sizeof(p.material)); p.shadow = s.shadow;
+	p.sizes = nullptr; p.xcd_counters = nullptr; p.stack_spill = (uint2 *)s.spill;
+	p.stream = s.control; p.stream_table = s.table_device; p.stream_iteration = iteration;
+	for (int i = 0; i < RT_AOV_COUNT; i++) p.aovs[i].framebuffer = (float4 *)s.aov_framebuffer[i];
+	p.batch_samples = 1;
+	return p;
+}
+
+// Reads the wavefront sizes the device has reported so far (pinned memory, no synchronisation).
+static void stream_update_known(PathStream & s) {
+	for (int k = std::max(s.known_iteration + 1, s.iteration - RT_STREAM_PROGRESS_RING + 1); k < s.iteration; k++) {
+		volatile int * entry = s.progress + 2 * (k % RT_STREAM_PROGRESS_RING);
+		if (entry[0] != k) break;
+		s.known_iteration = k; s.known_size = entry[1];
+	}
+}
+
+// Upper bound of the paths in flight when the next iteration starts (before anything it generates).
+static long long stream_bound(PathStream & s) {
+	stream_update_known(s);
+	int from = s.base_iteration; long long bound = 0;
+	if (s.known_iteration >= s.base_iteration) { from = s.known_iteration + 1; bound = s.known_size; }
+	for (int k = from; k < s.iteration; k++) bound += s.generated[k % RT_STREAM_PROGRESS_RING];
+	return bound;
+}
+
+static int stream_complete(rt_context * ctx, const StreamSubmission & sub, const RtParams & p) {
+	PathStream & s = ctx->path_stream;
+	hipStream_t st = s.stream;
+	// the accumulate step follows the main-stream work submitted so far (rt_pack_pixels of an earlier frame reads,
+	// rt_unpack_pixels writes the image)
+	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
+	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
+	RtParams pa = p;
+	pa.batch_samples = sub.sample_count;
+	pa.tile_pixels = sub.tile_pixels; pa.tile_first = sub.tile_first; pa.tile_stride = sub.tile_stride;
+	for (int i = 0; i < RT_AOV_COUNT; i++) if (pa.aovs[i].framebuffer) pa.aovs[i].framebuffer += size_t(sub.slot_base) * ctx->frame_pixels;
+	stage_mark(ctx, STAGE_POST, st);
+	rt_launch_accumulate(pa, float(sub.first_sample), sub.range_offset, sub.range_count, st);
+	stage_mark(ctx, STAGE_END, st);
+	for (int i = 0; i < RT_AOV_COUNT; i++) if (pa.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(pa.aovs[i].framebuffer, 0, ctx->frame_pixels * 16 * size_t(sub.sample_count), st)); // aovs_clear_to_zero
+	RT_HIP(ctx, hipMemcpyAsync(s.stats_host + size_t(sub.ring) * RT_STREAM_STATS_ROW, &s.control->stats[sub.ring][0][0], sizeof(int) * RT_STREAM_STATS_ROW, hipMemcpyDeviceToHost, st));
+	RT_HIP(ctx, hipEventRecord(s.ev_end[sub.ring], st));
+	RT_HIP(ctx, hipEventRecord(s.ev_idle, st));
+	for (int k = 0; k < sub.sample_count; k++) s.slot_used[sub.slot_base + k] = false;
+	s.last_completed_ring = sub.ring;
+	s.submissions_completed++;
+	return RT_OK;
+}
+
+// One iteration of the wavefront: [generate the rays of `fresh`] -> advance -> fused trace -> sort -> shade, then the
+// accumulate step of every submission that has just passed its last bounce.
+static int stream_enqueue_iteration(rt_context * ctx, const StreamSubmission * fresh) {
+	PathStream & s = ctx->path_stream;
+	const int i = s.iteration;
+	hipStream_t st = s.stream;
+	if (i - RT_STREAM_RUN_AHEAD >= 0) RT_HIP(ctx, hipEventSynchronize(s.iteration_done[(i - RT_STREAM_RUN_AHEAD) % RT_STREAM_PROGRESS_RING]));
+	RtParams p = stream_params(ctx, i);
+	if (fresh) {
+		RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));  // asynchronous scene uploads (they flush the wavefront first)
+		RtParams pg = p;
+		pg.batch_samples = fresh->sample_count;
+		pg.tile_pixels = fresh->tile_pixels; pg.tile_first = fresh->tile_first; pg.tile_stride = fresh->tile_stride;
+		RT_HIP(ctx, hipEventRecord(s.ev_begin[fresh->ring], st));
+		stage_mark(ctx, STAGE_GENERATE, st);
+		rt_launch_generate_stream(pg, fresh->first_sample, fresh->range_offset, fresh->range_count, fresh->slot_base, st);
+	}
+	rt_launch_stream_advance(s.control, i, fresh ? fresh->paths : 0, s.progress + 2 * (i % RT_STREAM_PROGRESS_RING), st);
+	s.generated[i % RT_STREAM_PROGRESS_RING] = fresh ? fresh->paths : 0;
+	RT_HIP(ctx, hipEventRecord(s.iteration_done[i % RT_STREAM_PROGRESS_RING], st));
+	stage_mark(ctx, STAGE_TRACE, st);
+	span_mark(ctx, STAGE_TRACE, st);
+	rt_launch_trace_stream(p, ctx->trace_statistics ? ctx->trace_stats : nullptr, st);
+	span_mark(ctx, STAGE_TRACE, st);
+	if (ctx->trace_statistics && s.history_rows < RT_STREAM_HISTORY_ROWS)
+		RT_HIP(ctx, hipMemcpyAsync(s.history + size_t(10) * s.history_rows++, ctx->trace_stats, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+	stage_mark(ctx, STAGE_SORT, st);
+	rt_launch_sort_stream(p, st);
+	stage_mark(ctx, STAGE_SHADE, st);
+	for (int m = 0; m < 4; m++) if (ctx->has_material[m]) rt_launch_material_stream(p, m, st);
+	stage_mark(ctx, STAGE_END, st);
+	s.iteration = i + 1;
+	while (!s.in_flight.empty() && s.in_flight.front().last <= i) {
+		int status = stream_complete(ctx, s.in_flight.front(), p); if (status) return status;
+		s.in_flight.pop_front();
+	}
+	if (s.in_flight.empty()) s.base_iteration = s.iteration;
+	RT_HIP(ctx, hipGetLastError());
+	return RT_OK;
+}
+
+// Runs the wavefront until nothing is in flight (the calls that read results or change state need that).
+static hipError_t stream_flush(rt_context * ctx) {
+	PathStream & s = ctx->path_stream;
+	while (s.created && !s.in_flight.empty()) if (stream_enqueue_iteration(ctx, nullptr) != RT_OK) return hipErrorUnknown;
+	return hipSuccess;
+}
+
+// rt_render_samples under RT_SCHEDULER_MERGED
+static int stream_submit(rt_context * ctx, int sample_index, int sample_count, int range_offset, int range_count) {
+	int status = stream_create(ctx); if (status) return status;
+	PathStream & s = ctx->path_stream;
+	const int num_bounces = ctx->params.config.num_bounces;
+	status = stream_ensure_frames(ctx, sample_count * (num_bounces + 1)); if (status) return status;
+	if (sample_count > s.frame_slots) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_samples: %d samples of a %zu pixel frame exceed the %d sample slots of the merged wavefront", sample_count, ctx->frame_pixels, s.frame_slots);
+	const long long paths = (long long)range_count * sample_count;
+	if (paths <= 0) return RT_OK;
+	static const double factor = getenv("GRT_STREAM_CAPACITY_FACTOR") ? atof(getenv("GRT_STREAM_CAPACITY_FACTOR")) : 4.0;
+	if (size_t(paths) > s.capacity || !s.queues_allocated) { status = stream_ensure_queues(ctx, size_t(double(paths) * (factor < 1.0 ? 1.0 : factor)) + 1024); if (status) return status; }
+
+	// admission: sample slots, a statistics ring entry, and room in the queues
+	int slot_base = -1;
+	for (;;) {
+		bool ring_free = s.in_flight.size() < RT_STREAM_SUBMISSIONS - 1;
+		slot_base = -1;
+		for (int start = 0; start + sample_count <= s.frame_slots && slot_base < 0; start++) {
+			int candidate = (s.next_slot + start) % s.frame_slots;
+			if (candidate + sample_count > s.frame_slots) continue;
+			bool free_run = true;
+			for (int k = 0; k < sample_count; k++) if (s.slot_used[candidate + k]) { free_run = false; break; }
+			if (free_run) slot_base = candidate;
+		}
+		bool fits = stream_bound(s) + paths <= (long long)s.capacity;
+		if (ring_free && slot_base >= 0 && fits) break;
+		if (!fits && s.known_iteration < s.iteration - 1 && s.iteration > s.base_iteration) { // the bound is stale: let the device catch up
+			RT_HIP(ctx, hipEventSynchronize(s.iteration_done[(s.iteration - 1) % RT_STREAM_PROGRESS_RING]));
+			continue;
+		}
+		if (s.in_flight.empty()) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_samples: the merged wavefront cannot take %lld paths (capacity %zu, %d sample slots)", paths, s.capacity, s.frame_slots);
+		status = stream_enqueue_iteration(ctx, nullptr); if (status) return status;   // advance without new samples: paths die, submissions complete
+	}
+
+	StreamSubmission sub;
+	sub.first_sample = sample_index; sub.sample_count = sample_count; sub.slot_base = slot_base;
+	sub.ring = s.next_ring; s.next_ring = (s.next_ring + 1) % RT_STREAM_SUBMISSIONS;
+	sub.birth = s.iteration; sub.last = s.iteration + num_bounces - 1; sub.paths = int(paths);
+	sub.range_offset = range_offset; sub.range_count = range_count;
+	sub.tile_pixels = ctx->params.tile_pixels; sub.tile_first = ctx->params.tile_first; sub.tile_stride = ctx->params.tile_stride;
+	for (int k = 0; k < sample_count; k++) {
+		s.slot_used[slot_base + k] = true;
+		s.table_host.slots[slot_base + k] = { sample_index + k, sub.birth, sub.ring, k };
+	}
+	s.next_slot = (slot_base + sample_count) % s.frame_slots;
+	s.table_host.submission_birth[sub.ring] = sub.birth;
+	// the table travels in stream order: the kernels of earlier iterations have run when it lands, and they never
+	// look at the entries of free slots
+	int snapshot = s.table_next; s.table_next = (s.table_next + 1) % RT_STREAM_TABLE_SNAPSHOTS;
+	RT_HIP(ctx, hipEventSynchronize(s.table_copied[snapshot]));
+	s.table_staging[snapshot] = s.table_host;
+	RT_HIP(ctx, hipMemcpyAsync(s.table_device, &s.table_staging[snapshot], sizeof(RtStreamTable), hipMemcpyHostToDevice, s.stream));
+	RT_HIP(ctx, hipEventRecord(s.table_copied[snapshot], s.stream));
+	RT_HIP(ctx, hipMemsetAsync(&s.control->stats[sub.ring][0][0], 0, sizeof(int) * RT_STREAM_STATS_ROW, s.stream));
+	if (ctx->trace_statistics && s.in_flight.empty()) { // statistics are per run of the wavefront
+		RT_HIP(ctx, hipMemsetAsync(ctx->trace_stats, 0, 10 * sizeof(unsigned long long), s.stream));
+		s.history_rows = 0;
+	}
+	s.in_flight.push_back(sub);
+	return stream_enqueue_iteration(ctx, &s.in_flight.back());
+}
+
+extern "C" {
+
 int rt_render_sample(rt_context * ctx, int sample_index) { return rt_render_samples(ctx, sample_index, 1); }
 
 int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
@@ -903,6 +1315,27 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	if (ctx->bvh_width != 8 && ctx->trace_statistics) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: trace statistics exist for the CWBVH kernels only");
 	// Slot choice: round-robin over the samples in flight. Profiling / statistics passes use one slot,
 	// serialised. SVGF frames pipeline like plain samples: only their filter stage is ordered.
+	// Scheduler (see rt_set_scheduler): the merged wavefront where its kernels exist
+	const bool merged = ctx->scheduler == RT_SCHEDULER_MERGED && !ctx->params.config.enable_svgf && ctx->params.config.num_bounces > 0 && ctx->bvh_width == 8
+	                    && !(ctx->batch_size_request > 0); // explicit pixel batches (a VRAM bound of the reference) are a slot-scheduler feature
+	if (merged != ctx->last_render_merged) { RT_HIP(ctx, quiesce(ctx)); ctx->last_render_merged = merged; }
+	if (merged) {
+		if (ctx->has_material[2] || ctx->has_material[3]) { int ls = ensure_luts(ctx); if (ls) return ls; }
+		if (size_t(sample_count) * ctx->frame_pixels >= (1u << 30)) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_samples: %d samples of a %zu pixel frame exceed the 30-bit path index", sample_count, ctx->frame_pixels);
+		const RtParams & cp = ctx->params;
+		int frame = cp.screen_width * cp.screen_height;
+		int offset = ctx->pixel_offset, count = ctx->pixel_count < 0 ? frame - offset : ctx->pixel_count;
+		if (cp.tile_pixels > 0) { // tile mode: local pixels 0..count-1 are mapped to this context's tiles by rt_map_pixel
+			int tiles_total = (frame + cp.tile_pixels - 1) / cp.tile_pixels;
+			int owned = cp.tile_first < tiles_total ? (tiles_total - cp.tile_first + cp.tile_stride - 1) / cp.tile_stride : 0;
+			offset = 0; count = owned * cp.tile_pixels;
+			int last_tile = cp.tile_first + (owned - 1) * cp.tile_stride;
+			if (owned > 0 && last_tile == tiles_total - 1) count -= tiles_total * cp.tile_pixels - frame; // clipped last tile
+		}
+		if (cp.tile_pixels == 0 && offset + count > frame) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_sample: pixel range [%d,%d) exceeds the %d pixel frame", offset, offset + count, frame);
+		ctx->time_this_sample = ctx->launch_timing;
+		return stream_submit(ctx, sample_index, sample_count, offset, count);
+	}
 	bool exclusive = ctx->profiling || ctx->trace_statistics;
 	int slot_index = exclusive ? 0 : int(ctx->render_counter++ % unsigned(ctx->samples_in_flight));
 	int s = ensure_slot(ctx, slot_index); if (s) return s;
@@ -933,7 +1366,7 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	memcpy(p.trace, slot.trace, sizeof(p.trace)); memcpy(p.material, slot.material, sizeof(p.material)); p.shadow = slot.shadow; // (re)allocated just now
 	p_shadow = p; p_shadow.stack_spill = (uint2 *)slot.spill[1];
 
-	ctx->time_this_sample = ctx->launch_timing && (ctx->timing_counter++ % RT_LAUNCH_TIMING_STRIDE) == 0;
+	ctx->time_this_sample = ctx->launch_timing;
 	hipStream_t st = slot.stream;
 	// The wavefront part depends on nothing the main stream does asynchronously (uploads and the LUT
 	// integration synchronise); only the accumulate step below has to follow the main-stream work
@@ -1119,6 +1552,20 @@ int rt_set_samples_in_flight(rt_context * ctx, int count) {
 	return RT_OK;
 }
 
+int rt_advance(rt_context * ctx) {
+	RT_REQUIRE(ctx, ctx, "rt_advance: NULL context");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->path_stream.created || ctx->path_stream.in_flight.empty()) return RT_OK;
+	ctx->time_this_sample = ctx->launch_timing;
+	return stream_enqueue_iteration(ctx, nullptr);
+}
+
+int rt_submissions_completed(rt_context * ctx, uint64_t * out_count) {
+	RT_REQUIRE(ctx, ctx && out_count, "rt_submissions_completed: NULL argument");
+	*out_count = ctx->path_stream.submissions_completed;
+	return RT_OK;
+}
+
 int rt_synchronize(rt_context * ctx) {
 	RT_REQUIRE(ctx, ctx, "rt_synchronize: NULL context");
 	(void)hipSetDevice(ctx->device);
@@ -1131,22 +1578,33 @@ int rt_get_counters(rt_context * ctx, rt_counters * out) {
 	(void)hipSetDevice(ctx->device);
 	RT_HIP(ctx, quiesce(ctx));
 	rt_counters c; memset(&c, 0, sizeof(c));
-	const SampleSlot & slot = ctx->slots[ctx->last_slot < 0 ? 0 : ctx->last_slot];
-	const int * totals = (const int *)slot.pinned_counters;
-	memcpy(c.trace,      totals + 0 * RT_MAX_BOUNCES, sizeof(c.trace));
-	memcpy(c.shadow,     totals + 1 * RT_MAX_BOUNCES, sizeof(c.shadow));
-	memcpy(c.diffuse,    totals + 2 * RT_MAX_BOUNCES, sizeof(c.diffuse));
-	memcpy(c.plastic,    totals + 3 * RT_MAX_BOUNCES, sizeof(c.plastic));
-	memcpy(c.dielectric, totals + 4 * RT_MAX_BOUNCES, sizeof(c.dielectric));
-	memcpy(c.conductor,  totals + 5 * RT_MAX_BOUNCES, sizeof(c.conductor));
 	float ms = 0.0f;
-	if (hipEventElapsedTime(&ms, slot.ev_frame_start, slot.ev_frame_end) == hipSuccess) c.ms_total = ms;
-	if (ctx->launch_timing) { // sums over every launch since the mode was enabled / the last call
+	if (ctx->last_render_merged && ctx->path_stream.last_completed_ring >= 0) { // the last submission the merged wavefront completed
+		const PathStream & s = ctx->path_stream;
+		const int * row = s.stats_host + size_t(s.last_completed_ring) * RT_STREAM_STATS_ROW;
+		memcpy(c.trace,      row + RT_STAT_TRACE      * RT_MAX_BOUNCES, sizeof(c.trace));
+		memcpy(c.shadow,     row + RT_STAT_SHADOW     * RT_MAX_BOUNCES, sizeof(c.shadow));
+		memcpy(c.diffuse,    row + RT_STAT_DIFFUSE    * RT_MAX_BOUNCES, sizeof(c.diffuse));
+		memcpy(c.plastic,    row + RT_STAT_PLASTIC    * RT_MAX_BOUNCES, sizeof(c.plastic));
+		memcpy(c.dielectric, row + RT_STAT_DIELECTRIC * RT_MAX_BOUNCES, sizeof(c.dielectric));
+		memcpy(c.conductor,  row + RT_STAT_CONDUCTOR  * RT_MAX_BOUNCES, sizeof(c.conductor));
+		if (hipEventElapsedTime(&ms, s.ev_begin[s.last_completed_ring], s.ev_end[s.last_completed_ring]) == hipSuccess) c.ms_total = ms;
+	} else {
+		const SampleSlot & slot = ctx->slots[ctx->last_slot < 0 ? 0 : ctx->last_slot];
+		const int * totals = (const int *)slot.pinned_counters;
+		memcpy(c.trace,      totals + 0 * RT_MAX_BOUNCES, sizeof(c.trace));
+		memcpy(c.shadow,     totals + 1 * RT_MAX_BOUNCES, sizeof(c.shadow));
+		memcpy(c.diffuse,    totals + 2 * RT_MAX_BOUNCES, sizeof(c.diffuse));
+		memcpy(c.plastic,    totals + 3 * RT_MAX_BOUNCES, sizeof(c.plastic));
+		memcpy(c.dielectric, totals + 4 * RT_MAX_BOUNCES, sizeof(c.dielectric));
+		memcpy(c.conductor,  totals + 5 * RT_MAX_BOUNCES, sizeof(c.conductor));
+		if (hipEventElapsedTime(&ms, slot.ev_frame_start, slot.ev_frame_end) == hipSuccess) c.ms_total = ms;
+	}
+	if (ctx->launch_timing) { // sums over every launch since the mode was enabled (rt_get_launch_timings returns each and starts over)
 		for (size_t i = 0; i + 1 < ctx->span_used; i += 2) {
 			float d = 0.0f;
 			if (hipEventElapsedTime(&d, ctx->span_events[i], ctx->span_events[i + 1]) == hipSuccess) (ctx->span_kinds[i] == STAGE_TRACE ? c.ms_trace : c.ms_shadow) += d;
 		}
-		ctx->span_used = 0;
 	}
 	if (ctx->profiling) {
 		float * bucket[STAGE_END] = { &c.ms_generate, &c.ms_trace, &c.ms_sort, &c.ms_shade, &c.ms_shadow, &c.ms_post };
@@ -1159,6 +1617,7 @@ int rt_get_counters(rt_context * ctx, rt_counters * out) {
 				if (print_stages) fprintf(stderr, "[grt] stage %-8s %8.4f ms\n", stage_names[ctx->stage_kinds[i]], d);
 			}
 		}
+		if (ctx->last_render_merged) ctx->stage_used = 0; // the merged wavefront's stage events add up over its iterations until they are read
 	}
 	ctx->last_counters = c;
 	*out = c;

@@ -58,6 +58,34 @@ struct RtBufferSizes { // Pathtracer.cu:103-114
 	int rays_retired_shadow[RT_MAX_BOUNCES];
 };
 
+// ---- merged wavefront (rt_api.hip, "PathStream") -----------------------------------------------------------
+// Instead of one launch chain per submission (generate -> (trace, sort, shade, shadow) x bounces), whose launches
+// shrink bounce by bounce until they no longer fill the GPU, consecutive submissions feed ONE wavefront: iteration
+// i traces / sorts / shades the rays of every submission in flight -- the primary rays of the newest next to bounce
+// 1 of the one before, bounce 2 of the one before that ... -- so every launch has the size of a whole sample and
+// there are no per-submission tails. A queue entry does not store its bounce: its virtual pixel index names a SAMPLE
+// SLOT (v = slot * frame_pixels + pixel; the slot's per-sample AOV frame lives at the same offset), and the slot table
+// says which sample that is and in which iteration it was generated; bounce = iteration - birth.
+#define RT_STREAM_SAMPLE_SLOTS 64     // samples in flight (each owns one frame of the per-sample AOV buffers)
+#define RT_STREAM_SUBMISSIONS  32     // ring of submissions whose per-bounce statistics are kept
+enum { RT_STAT_TRACE = 0, RT_STAT_SHADOW, RT_STAT_DIFFUSE, RT_STAT_PLASTIC, RT_STAT_DIELECTRIC, RT_STAT_CONDUCTOR, RT_STAT_KINDS };
+
+struct RtStreamSlot { int sample_index, birth_iteration, submission, index_in_submission; }; // one int4 per sample slot
+
+struct RtStreamTable {                 // written by the host per submission (asynchronous copy in stream order)
+	RtStreamSlot slots[RT_STREAM_SAMPLE_SLOTS];
+	int submission_birth[RT_STREAM_SUBMISSIONS];
+};
+
+struct RtStreamControl {               // queue sizes and ray-claim cursors; [iteration & 1] where two launches overlap in time
+	int trace_count[2];                // rays in trace queue [i & 1]: appended by sort / shade of i - 1 and generate of i
+	int material_count[4];
+	int shadow_count[2];               // shadow rays emitted by the shade kernels of iteration i, traced by the launch of i + 1
+	int cursor[2][2];                  // [i & 1][closest, shadow] cursors of the fused trace launch
+	int pad[4];
+	int stats[RT_STREAM_SUBMISSIONS][RT_STAT_KINDS][RT_MAX_BOUNCES]; // rays per submission, queue kind and bounce
+};
+
 struct RtTexture {
 	const uchar4 * texels;   // linear RGBA8, mip levels back to back; or BC1 blocks (uint2 each), see `format`
 	int   width, height, mip_levels;
@@ -132,7 +160,11 @@ struct RtParams {
 	RtMaterialBuffer material[4];   // diffuse, plastic, dielectric, conductor
 	RtShadowBuffer   shadow;
 	RtBufferSizes  * sizes;
-	int   * xcd_counters;               // [RT_MAX_BOUNCES][2 (closest, shadow)][8 XCDs] ray-fetch cursors
+	// merged wavefront only (null / 0 otherwise)
+	RtStreamControl     * stream;
+	const RtStreamTable * stream_table;
+	int stream_iteration;
+	int * xcd_counters;               // [RT_MAX_BOUNCES][2 (closest, shadow)][8 XCDs] ray-fetch cursors
 	uint2 * stack_spill;                // traversal stack entries beyond the LDS part, [entry][grid lane]
 	// outputs
 	RtAOV    aovs[RT_AOV_COUNT];
@@ -163,13 +195,35 @@ __device__ __forceinline__ unsigned rt_split_virtual_pixel(const RtParams & p, u
 	return v - s * p.frame_pixels;
 }
 
+// merged wavefront: slot, sample and bounce of a queue entry (see RtStreamSlot). `sample_index_for_rng` is what
+// random_sample() expects from its callers: it adds the slot number it splits off the virtual index itself.
+struct RtPathInfo { int bounce, submission; unsigned sample_index_for_rng; bool first_of_submission; };
+__device__ __forceinline__ RtPathInfo rt_stream_path_info(const RtParams & p, unsigned virtual_pixel) {
+	unsigned slot;
+	rt_split_virtual_pixel(p, virtual_pixel, slot);
+	RtStreamSlot e = p.stream_table->slots[slot];
+	RtPathInfo info;
+	info.bounce = p.stream_iteration - e.birth_iteration;
+	info.submission = e.submission;
+	info.sample_index_for_rng = unsigned(e.sample_index) - slot;
+	info.first_of_submission = e.index_in_submission == 0;
+	return info;
+}
+
 #define RT_FLAG_ALLOW_NEE     (1u << 31)
 #define RT_FLAG_INSIDE_MEDIUM (1u << 30)
 #define RT_FLAGS_ALL          (RT_FLAG_ALLOW_NEE | RT_FLAG_INSIDE_MEDIUM)
+#define RT_SHADOW_FLAG_BOUNCE_0 (1u << 30)   // merged wavefront: pixel word of a shadow ray emitted at bounce 0
 
 // Launch helpers implemented in the kernel translation units
 void rt_launch_generate(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, hipStream_t stream);
 void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream);
+// merged wavefront (the iteration is p.stream_iteration); stats: null, or 10 x u64 as for the counting variants below
+void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, int slot_base, hipStream_t stream);
+void rt_launch_stream_advance(RtStreamControl * control, int iteration, int generated, int * progress, hipStream_t stream);
+void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, hipStream_t stream);
+void rt_launch_sort_stream(const RtParams & p, hipStream_t stream);
+void rt_launch_material_stream(const RtParams & p, int material_slot, hipStream_t stream);
 void rt_launch_trace_shadow(const RtParams & p, int bounce, hipStream_t stream);
 void rt_launch_ambient_occlusion(const RtParams & p, int sample_index, float ao_radius, hipStream_t stream);
 void rt_launch_trace_shadow_ao(const RtParams & p, hipStream_t stream);

@@ -256,6 +256,12 @@ void Integrator::update(float delta) {
 		invalidated_camera = true;
 	}
 
+	if (ctx && cpu_config.enable_scene_update != scheduler_for_scene_updates) {
+		// A scene that uploads a new TLAS every frame keeps several frames in flight only under the slot scheduler
+		// (each chain reads the scene version it was submitted with); everything else feeds the merged wavefront.
+		scheduler_for_scene_updates = cpu_config.enable_scene_update;
+		check(rt_set_scheduler(ctx, scheduler_for_scene_updates ? RT_SCHEDULER_SLOTS : RT_SCHEDULER_MERGED));
+	}
 	if (cpu_config.enable_scene_update) {
 		scene.update(delta);
 		invalidated_scene = true;

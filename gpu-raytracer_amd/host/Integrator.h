@@ -59,6 +59,7 @@ struct Integrator {
 
 	PixelQuery pixel_query = { INVALID, INVALID, INVALID };
 	enum struct PixelQueryStatus { INACTIVE, PENDING, OUTPUT_READY } pixel_query_status = PixelQueryStatus::INACTIVE; // Integrator.h:75-79
+	bool scheduler_for_scene_updates = false; // the device context schedules for per-frame scene uploads (rt_set_scheduler)
 
 	// ---- host staging of everything the device consumes (filled by init_* / build_tlas) ----
 	std::vector<DeviceTriangle> aggregated_triangles;

@@ -247,6 +247,29 @@ int rt_render_sample(rt_context * ctx, int sample_index);
  * bit-identical to count calls of rt_render_sample (tests/test_gpu_parity.py). Not for SVGF.
  * rt_get_counters reports the batch totals.                                               */
 int rt_render_samples(rt_context * ctx, int sample_index, int sample_count);
+
+/* How consecutive rt_render_sample(s) calls are scheduled on the device.
+ * RT_SCHEDULER_MERGED (default): the calls feed ONE wavefront. Each call ("submission") adds its primary rays to the
+ *   wavefront and advances it by one iteration (trace, sort, shade of every submission in flight: the new one is at
+ *   bounce 0, the one before at bounce 1, ...), so every launch has the size of a whole sample and a submission is
+ *   complete num_bounces - 1 calls later; reads and rt_synchronize run the remaining iterations. Same arithmetic per
+ *   path, per-sample frame buffers folded in submission order: images are bit-identical to RT_SCHEDULER_SLOTS.
+ *   (The reference runs the chain of one sample at a time, Pathtracer.cpp:738-855: its deep bounces are launches of a
+ *   few thousand rays.) SVGF frames, the binary / 4-wide BVH kernels and num_bounces = 0 always use the slot scheduler.
+ * RT_SCHEDULER_SLOTS: one launch chain per submission, up to rt_set_samples_in_flight chains concurrently on their own
+ *   streams, each reading the scene version (TLAS, instances, lights) that was current when it was submitted: the
+ *   choice for scenes that upload a new TLAS every frame.                                                           */
+enum { RT_SCHEDULER_MERGED = 0, RT_SCHEDULER_SLOTS = 1 };
+int rt_set_scheduler(rt_context * ctx, int scheduler);
+/* Merged scheduler: one more iteration of the wavefront without new samples (no-op when nothing is in flight), and the
+ * number of submissions whose accumulate step has been enqueued so far -- a frame loop that hands every completed
+ * frame to a collective calls rt_advance / rt_render_samples and packs the frame when the count moves
+ * (bench.py); rt_pack_pixels and the reads on their own complete everything first.                       */
+int rt_advance(rt_context * ctx);
+/* enable = 1: rt_pack_pixels / rt_unpack_pixels are ordered after the submissions COMPLETED so far instead of first
+ * completing everything in flight, so that later frames keep filling the wavefront while an earlier one is exchanged. */
+int rt_set_frame_pipelining(rt_context * ctx, int enable);
+int rt_submissions_completed(rt_context * ctx, uint64_t * out_count);
 /* Replaces the `pixel_query` global (Integrator.h:266-277, Integrator.cpp:483-495, Pathtracer.cu:345-348):
  * the mesh (TLAS-order id) and triangle that the primary ray of pixel `pixel_index` = x + y * pitch hits
  * in the next sample rendered (-1 disarms it). rt_get_pixel_query waits and returns -1, -1 for a miss. */
@@ -263,18 +286,24 @@ int rt_synchronize(rt_context * ctx);
  * instrumentation of the reference (Pathtracer.cpp:751-843, Device/CUDAEvent.h:31-53).
  * enable = 1: events around every stage; samples are rendered one at a time with the shadow rays
  *             on the main chain, so the stage times are those of each kernel running alone.
- * enable = 2: events only around the closest-hit / shadow trace launches of every 3rd sample
- *             (the 1st, 4th, 7th ... rt_render_sample call after enabling), on the stream each is
- *             launched on; concurrency (side stream, samples in flight) stays as in production.
+ * enable = 2: events around EVERY traversal launch, on the stream each is launched on; concurrency
+ *             (merged wavefront, or side stream and samples in flight) stays as in production.
  *             rt_get_counters then returns in ms_trace / ms_shadow the SUM over those launches
- *             since the mode was enabled or counters were last read.                          */
+ *             since the mode was enabled or counters were last read, rt_get_launch_timings each. */
 int rt_set_profiling(rt_context * ctx, int enable);
+/* rt_set_profiling(ctx, 2): HIP events around every traversal launch, each on the stream it runs on. Durations in
+ * milliseconds of the launches since the mode was enabled (or since the last call), in submission order:
+ * kind 0 = closest-hit / fused traversal launches, 1 = separate shadow launches (slot scheduler).          */
+int rt_get_launch_timings(rt_context * ctx, int kind, float * out_ms, int capacity, int * out_count);
 /* Work statistics of the trace kernels: when enabled, rt_render_sample runs counting variants
  * of kernel_trace(_shadow)_bvh8 (slower: per-ray atomics) and rt_get_trace_statistics returns,
  * for the last sample, 10 x u64 {closest-hit: BVH8 nodes fetched, triangles tested, transformed
  * instance entries, identity instance entries, rays; then the same five for shadow rays}.
  * These are the N_node / N_tri / N_inst of the algorithmic-bytes roofline.     */
 int rt_set_trace_statistics(rt_context * ctx, int enable);
+/* Merged scheduler with statistics on: the ten counters after each iteration (cumulative), oldest first; per-launch
+ * work = difference of consecutive rows.                                                                  */
+int rt_get_trace_statistics_history(rt_context * ctx, uint64_t * out_rows10, int capacity_rows, int * out_rows);
 int rt_get_trace_statistics(rt_context * ctx, uint64_t * out10);
 /* Counters of the most recent completed rt_render_sample (synchronous).                    */
 int rt_get_counters(rt_context * ctx, rt_counters * out);

@@ -624,3 +624,88 @@ def test_bench_spawns_its_own_ranks_for_a_tile_split_run(grt):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 8 and out["value"] > 0 and out["config"]["ranks"] == 2
     assert out["config"]["rays_per_step"] > 1920 * 1080      # both ranks' rays are in the total
+
+
+def _render_plan(grt, scene_name, w, h, scheduler, plan, config, prepare=None, aovs=()):
+    """Submits `plan` = [(first sample, count), ...] back to back (nothing is read in between) and returns the
+    accumulated image, the AOV accumulators, the counters of the last submission and the completion count."""
+    import ctypes
+    scene, pt = make_pathtracer(grt, scene_name, w, h, 0, **config)
+    for aov in aovs:
+        pt.aov_enable(aov)
+    if aovs:
+        pt.update()
+    lib = grt.device_lib()
+    lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    grt.set_scheduler(pt.ctx, scheduler)
+    if prepare:
+        prepare(lib, pt)
+    completed = []
+    for first, count in plan:
+        assert lib.rt_render_samples(pt.ctx, first, count) == 0, lib.rt_last_error(pt.ctx)
+        completed.append(grt.submissions_completed(pt.ctx))
+    image = pt.read_framebuffer().copy()
+    extra = [pt.read_aov(aov).copy() for aov in aovs]
+    c = pt.counters()
+    nb = pt.device_config().num_bounces
+    queues = [list(getattr(c, name)[:nb]) for name in ("trace", "shadow", "diffuse", "plastic", "dielectric", "conductor")]
+    done = grt.submissions_completed(pt.ctx)
+    pt.close(); scene.close()
+    return image, extra, queues, completed, done
+
+
+def test_merged_wavefront_equals_the_slot_scheduler(grt):
+    """RT_SCHEDULER_MERGED: consecutive submissions feed one wavefront (every launch carries the rays of all submissions
+    in flight, each at its own bounce). Per path nothing changes, so images, AOVs and the per-bounce queue sizes of a
+    submission are bit-identical to the slot scheduler's -- with submissions of different sizes back to back, whole
+    frames restarted at sample 0, a pixel range, a tile split, and more submissions than the wavefront admits at once."""
+    import ctypes
+    cases = [
+        ("cornellbox", 320, 240, [(0, 1), (1, 4), (5, 2), (7, 3), (10, 1), (11, 1), (12, 4)], dict(num_bounces=5), None, ()),
+        ("sponza", 640, 360, [(0, 4), (0, 4), (0, 4)], dict(num_bounces=6), None, (grt.AOV_ALBEDO, grt.AOV_NORMAL, grt.AOV_POSITION)),
+        ("cornellbox", 200, 150, [(s, 1) for s in range(40)], dict(num_bounces=12), None, ()),   # 40 submissions, 12 in flight
+    ]
+    def tiles(lib, pt):
+        lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3
+        assert lib.rt_set_pixel_tiles(pt.ctx, 640 * 8, 1, 4) == 0
+    def pixel_range(lib, pt):
+        assert lib.rt_set_pixel_range(pt.ctx, 640 * 100 + 17, 640 * 120 + 5) == 0
+    cases.append(("sponza", 640, 360, [(0, 2), (2, 2), (4, 4)], dict(num_bounces=4), tiles, ()))
+    cases.append(("sponza", 640, 360, [(0, 3), (3, 1)], dict(num_bounces=4), pixel_range, ()))
+    for scene_name, w, h, plan, config, prepare, aovs in cases:
+        merged = _render_plan(grt, scene_name, w, h, "merged", plan, config, prepare, aovs)
+        slots = _render_plan(grt, scene_name, w, h, "slots", plan, config, prepare, aovs)
+        label = (scene_name, plan[:3])
+        assert np.array_equal(merged[0], slots[0]) and merged[0][..., :3].max() > 0.0, label
+        for a, b in zip(merged[1], slots[1]):
+            assert np.array_equal(a, b), label
+        assert merged[2] == slots[2], (label, merged[2], slots[2])
+        # a submission is complete num_bounces - 1 submissions after it was made; reading completes the rest
+        nb = config["num_bounces"]
+        assert all(done >= max(0, k + 2 - nb) for k, done in enumerate(merged[3])) and merged[3] == sorted(merged[3]), (label, merged[3])
+        assert merged[4] == len(plan), label
+
+
+def test_merged_wavefront_advances_without_new_samples(grt):
+    """rt_advance runs one iteration without new samples: a frame loop learns from rt_submissions_completed when a frame
+    may be packed. With frame pipelining on, rt_pack_pixels follows the completed submissions only."""
+    import ctypes
+    scene, pt = make_pathtracer(grt, "cornellbox", 160, 120, 0, num_bounces=6)
+    lib = grt.device_lib()
+    lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    assert lib.rt_render_samples(pt.ctx, 0, 2) == 0 and lib.rt_render_samples(pt.ctx, 2, 2) == 0
+    assert grt.submissions_completed(pt.ctx) == 0
+    for k in range(4):
+        grt.advance(pt.ctx)
+    assert grt.submissions_completed(pt.ctx) == 1      # born at iteration 0, last bounce at iteration 5
+    grt.advance(pt.ctx)
+    assert grt.submissions_completed(pt.ctx) == 2
+    grt.advance(pt.ctx)                                 # nothing in flight: a no-op
+    assert grt.submissions_completed(pt.ctx) == 2
+    four = pt.read_framebuffer().copy()
+    pt.close(); scene.close()
+    scene, pt = make_pathtracer(grt, "cornellbox", 160, 120, 0, num_bounces=6)
+    for s in range(4):
+        assert lib.rt_render_samples(pt.ctx, s, 1) == 0
+    assert np.array_equal(pt.read_framebuffer(), four)
+    pt.close(); scene.close()
