@@ -44,6 +44,19 @@ if ROOT not in sys.path:
 WIDTH, HEIGHT = 1920, 1080
 NUM_BOUNCES = 10
 SPP = 4
+# The fixed Sponza points of view of the reference's perf harness (Util/PerfTest.h:30-40: position, rotation quaternion);
+# its harness times 32 frames at each and reports the average per POV.
+SPONZA_POVS = [
+    ((18.739738, 10.332139, -10.229103), (0.000000, 0.801883, 0.000000, 0.597480)),
+    ((31.355043, 31.696985, 13.222142), (0.000000, 0.387925, 0.000000, -0.921690)),
+    ((70.257584, 8.347624, 49.902672), (0.000000, -0.576111, 0.000000, -0.817371)),
+    ((24.349691, 51.417969, -10.351927), (0.000000, -0.985181, 0.000000, 0.171514)),
+    ((24.349691, 51.417969, -10.351927), (0.000000, -0.245309, 0.000000, -0.969444)),
+    ((-15.957721, 62.806641, -43.916168), (0.000000, -0.803925, 0.000000, 0.594729)),
+    ((-52.839905, 38.513454, -8.991060), (0.202261, -0.729369, -0.606600, -0.243197)),
+    ((-92.179306, 74.721153, 12.197323), (0.009840, 0.621556, 0.007809, -0.783262)),
+    ((-129.707321, 17.916590, 43.054050), (0.011467, 0.408287, 0.005129, -0.912762)),
+]
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3-6.6 TB/s is achievable
 
 
@@ -94,16 +107,25 @@ def cpu_baseline(grt, pt, scene):
         "nodes_per_ray": [round(stats_primary.nodes / stats_primary.rays, 2), round(stats_secondary.nodes / stats_secondary.rays, 2)],
         "triangles_per_ray": [round(stats_primary.triangles / stats_primary.rays, 2), round(stats_secondary.triangles / stats_secondary.rays, 2)],
     }
+    out["effective_parallelism"] = round(oracle.effective_parallelism(threads), 1)   # of `threads` logical CPUs
+    out["note"] = "the oracle's per-ray work is ~1 us; at %d threads the OpenMP fork/join and the dynamic schedule dominate, so this is a stated baseline, not a tuned CPU tracer" % threads
     if oracle.ref_lib() is not None:  # the reference's own CPU path: BVH2 + BVH8 build of all 383 Sponza meshes
         scene.wait_until_loaded()
-        t0 = time.perf_counter()
-        ms2 = ms8 = 0.0
-        for m in range(scene.mesh_data_count):
-            ref = oracle.ref_build(scene.mesh_data_array(m, "triangles", np.float32))
-            ms2 += ref["ms_bvh2"]; ms8 += ref["ms_bvh8"]
-        out["reference_bvh_build"] = {"kind": "reference", "cores": 1, "ms_sah_bvh2": round(ms2, 1), "ms_bvh8_convert": round(ms8, 1),
-                                      "ms_wall": round((time.perf_counter() - t0) * 1e3, 1), "meshes": scene.mesh_data_count,
-                                      "product_builder_ms_parallel": round(scene.bvh_build_ms, 1)}
+        meshes = [scene.mesh_data_array(m, "triangles", np.float32).reshape(-1, 24) for m in range(scene.mesh_data_count)]
+        build = {"kind": "reference", "meshes": len(meshes), "triangles": int(sum(m.shape[0] for m in meshes)),
+                 "schedule": "one job per mesh on a pool of hardware_concurrency workers, as AssetManager.cpp:57 does",
+                 "product_builder_ms_parallel": round(scene.bvh_build_ms, 1)}
+        many = oracle.ref_build_many(meshes, threads)
+        if many is not None:
+            one = oracle.ref_build_many(meshes, 1)
+            build.update({"cores": threads, "ms_wall": round(many[0], 1), "ms_wall_1_thread": round(one[0], 1), "bvh2_nodes": many[1], "bvh8_nodes": many[2]})
+        else:   # an oracle/_ref built before the pooled entry point existed: mesh after mesh on one core
+            ms2 = ms8 = 0.0
+            for m in meshes:
+                ref = oracle.ref_build(m)
+                ms2 += ref["ms_bvh2"]; ms8 += ref["ms_bvh8"]
+            build.update({"cores": 1, "ms_sah_bvh2": round(ms2, 1), "ms_bvh8_convert": round(ms8, 1), "ms_wall": round(ms2 + ms8, 1)})
+        out["reference_bvh_build"] = build
     return out
 
 
@@ -113,6 +135,7 @@ def main():
     ap.add_argument("--steps", type=int, default=32)   # PerfTest BUFFER_SIZE = 32 frames (Util/PerfTest.h:9)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-povs", action="store_true", help="skip the sweep over the reference's 9 fixed Sponza points of view (N = 1 only)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: render only rank 0's tiles of an N-GPU split on one GPU (no collective), to exercise the N > 1 code path")
     ap.add_argument("--batch", type=int, default=SPP, help="samples per pixel per submission (rt_render_samples), 1..%d" % SPP)
     ap.add_argument("--samples-in-flight", type=int, default=0, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
@@ -156,14 +179,17 @@ def main():
     pt.update()
     lib = grt.device_lib()
     ctx = pt.ctx
-    if args.samples_in_flight <= 0:   # measured optima (profiles/r01_sample_batching.txt): the smaller a rank's share, the more submissions
-        split_n = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
-        args.samples_in_flight = 3 if split_n == 1 else (4 if split_n == 2 else 8)
-    grt.set_samples_in_flight(ctx, args.samples_in_flight)
+    scheduler = os.environ.get("BENCH_SCHEDULER", "merged")     # "slots": the per-submission launch chains, for comparison
+    grt.set_scheduler(ctx, scheduler)
     split_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
+    if args.samples_in_flight <= 0:   # slot scheduler only (profiles/r01_sample_batching.txt): the smaller a rank's share, the more submissions
+        args.samples_in_flight = 3 if split_world == 1 else (4 if split_world == 2 else 8)
+    grt.set_samples_in_flight(ctx, args.samples_in_flight)
     split = parallel.TileSplit(rank, split_world, WIDTH, HEIGHT)
-    pitch = pt.pitch
     device = torch.device("cuda", local_rank)
+    merged = scheduler == "merged"
+    if merged and split_world > 1:
+        grt.set_frame_pipelining(ctx, True)   # pack / unpack follow the frames completed so far; later frames keep the wavefront full
 
     # this rank's tiles, rendered as scan-order pixel ranges; the gather buffers live in torch
     packed = torch.zeros((split.local_pixels, 4), dtype=torch.float32, device=device)
@@ -174,91 +200,115 @@ def main():
     lib.rt_synchronize.argtypes = [ctypes.c_void_p]
     lib.rt_stream_wait_for_context.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.rt_context_wait_for_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 
     def check(status):
         if status != 0:
             raise RuntimeError(lib.rt_last_error(ctx).decode())
 
-    def render_step(sample_index, frame_complete=False, count=1):
-        """`count` consecutive samples for this rank's share of the frame, as one submission (the
-        library keeps `samples_in_flight` submissions running concurrently); with N > 1 the
-        accumulated frame is gathered once it is complete, i.e. after its last sample -- every rank
-        accumulates its own tiles, so nothing has to be exchanged between the samples of a frame."""
-        if split_world == 1:
-            check(lib.rt_set_pixel_range(ctx, 0, WIDTH * HEIGHT))
-            check(lib.rt_render_samples(ctx, sample_index, count))
+    if split_world == 1:
+        check(lib.rt_set_pixel_range(ctx, 0, WIDTH * HEIGHT))
+    else:
+        check(lib.rt_set_pixel_tiles(ctx, split.tile_pixels, rank, split_world))
+
+    def exchange_frame():
+        """The one data-path collective: this rank's accumulated tiles -> every rank's final framebuffer. Stream-ordered in
+        both directions, the host does not block: pack after the previous all_gather has read `packed`, all_gather after
+        the pack, unpack after the all_gather; later frames are already being traced meanwhile."""
+        if split_world == 1 or os.environ.get("BENCH_NO_GATHER"):
+            return
+        torch_stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.rt_context_wait_for_stream(ctx, torch_stream))
+        check(lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, split_world, split.tiles_per_rank))
+        check(lib.rt_stream_wait_for_context(ctx, torch_stream))
+        if world > 1 and backend == "nccl":
+            dist.all_gather_into_tensor(gathered, packed)
+        elif world > 1:
+            host = torch.empty(gathered.shape, dtype=gathered.dtype)
+            dist.all_gather_into_tensor(host, packed.cpu())
+            gathered.copy_(host)
         else:
-            check(lib.rt_set_pixel_tiles(ctx, split.tile_pixels, rank, split_world))
-            check(lib.rt_render_samples(ctx, sample_index, count))
-            if frame_complete and not os.environ.get("BENCH_NO_GATHER"):
-                # stream-ordered, the host does not block: pack after the previous all_gather has read
-                # `packed`, all_gather after the pack; the next frames are already being traced meanwhile
-                torch_stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-                check(lib.rt_context_wait_for_stream(ctx, torch_stream))
-                check(lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, split_world, split.tiles_per_rank))
-                check(lib.rt_stream_wait_for_context(ctx, torch_stream))
-                if world > 1 and backend == "nccl":
-                    dist.all_gather_into_tensor(gathered, packed)
-                elif world > 1:
-                    host = torch.empty(gathered.shape, dtype=gathered.dtype)
-                    dist.all_gather_into_tensor(host, packed.cpu())
-                    gathered.copy_(host)
-                else:
-                    gathered[:split.local_pixels].copy_(packed)   # --emulate-world: stand-in for the collective
-                # ... and the gathered tiles are scattered into the final framebuffer of this rank (every rank ends
-                # up with the whole frame), stream-ordered after the collective
-                if world > 1:
-                    check(lib.rt_context_wait_for_stream(ctx, torch_stream))
-                    check(lib.rt_unpack_pixels(ctx, gathered.data_ptr(), split.tile_pixels, split_world, split.tiles_per_rank))
+            gathered[:split.local_pixels].copy_(packed)   # --emulate-world: stand-in for the collective
+        if world > 1:   # the gathered tiles become the final framebuffer of this rank (every rank ends up with the whole frame)
+            check(lib.rt_context_wait_for_stream(ctx, torch_stream))
+            check(lib.rt_unpack_pixels(ctx, gathered.data_ptr(), split.tile_pixels, split_world, split.tiles_per_rank))
 
-    def counters():
-        c = pt.counters()
-        return c, sum(c.trace[:NUM_BOUNCES]), sum(c.shadow[:NUM_BOUNCES])
-
-    lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-
-    # ---- warm-up (untimed) ---------------------------------------------------------------------
     def submissions(steps):
-        """[(first sample index, count)] covering exactly `steps` samples, frame by frame."""
+        """[(first sample index, count, completes a frame)] covering exactly `steps` samples, frame by frame."""
         out, k = [], 0
         while k < steps:
             first = k % SPP
             count = min(SPP - first, steps - k, args.batch)
-            out.append((first, count)); k += count
+            k += count
+            out.append((first, count, first + count == SPP or k == steps))
         return out
 
-    # untimed priming: every submission slot allocates its queues / streams on first use (GBs of hipMalloc)
-    for _ in range(args.samples_in_flight):
-        render_step(0, frame_complete=True, count=min(args.batch, SPP))
-    check(lib.rt_synchronize(ctx))
-    for first, count in submissions(args.warmup):
-        render_step(first, frame_complete=True, count=count)
+    def run(plan):
+        """Submits the plan; a frame is exchanged as soon as its last submission is complete. Under the merged scheduler a
+        submission completes num_bounces - 1 iterations after it was made (rt_submissions_completed tells), so the loop
+        ends by advancing the wavefront without new samples; under the slot scheduler the exchange is simply ordered
+        behind the submission."""
+        if not merged:
+            for first, count, frame_complete in plan:
+                check(lib.rt_render_samples(ctx, first, count))
+                if frame_complete:
+                    exchange_frame()
+            return
+        base = grt.submissions_completed(ctx)
+        handled = 0
+        def drain_completions():
+            nonlocal handled
+            done = grt.submissions_completed(ctx) - base
+            while handled < done:
+                if plan[handled][2]:
+                    exchange_frame()
+                handled += 1
+        for first, count, _ in plan:
+            check(lib.rt_render_samples(ctx, first, count))
+            drain_completions()
+        while handled < len(plan):
+            grt.advance(ctx)
+            drain_completions()
+
+    # ---- untimed priming + warm-up: queues, sample frames and streams are allocated on first use (GBs of hipMalloc)
+    run(submissions(max(args.warmup, SPP)))
     check(lib.rt_synchronize(ctx))
 
-    # ---- untimed statistics pass: rays per sample and the work counters of the trace kernels ---
-    rays_per_sample, shadow_per_sample, alg_bytes_per_sample, trace_rays_stat = [], [], [], []
+    # ---- untimed statistics pass: rays per sample and the work counters of the trace kernels ------
+    rays_per_sample, shadow_per_sample, alg_closest_per_sample, alg_shadow_per_sample, trace_rays_stat = [], [], [], [], []
     grt.set_trace_statistics(ctx, True)
     for s in range(SPP):
-        render_step(s)
-        _, closest, shadow = counters()
+        check(lib.rt_render_samples(ctx, s, 1))
+        c = pt.counters()
         stats = grt.get_trace_statistics(ctx)
-        rays_per_sample.append(closest); shadow_per_sample.append(shadow)
-        alg_bytes_per_sample.append(stats["closest"]["algorithmic_bytes"])
+        rays_per_sample.append(sum(c.trace[:NUM_BOUNCES])); shadow_per_sample.append(sum(c.shadow[:NUM_BOUNCES]))
+        alg_closest_per_sample.append(stats["closest"]["algorithmic_bytes"]); alg_shadow_per_sample.append(stats["shadow"]["algorithmic_bytes"])
         trace_rays_stat.append(stats)
+    # ... and, for the merged scheduler, of every traversal launch of the plan that is about to be timed
+    plan = submissions(args.steps)
+    launch_bytes = None
+    if merged:
+        run(plan)
+        history = grt.trace_statistics_history(ctx).astype(np.int64)
+        rows = np.vstack([np.zeros((1, 10), np.int64), history])
+        per_launch = rows[1:] - rows[:-1]
+        launch_bytes = np.array([sum(grt.algorithmic_bytes(r)) for r in per_launch], np.float64)
+        launch_closest_bytes = np.array([grt.algorithmic_bytes(r)[0] for r in per_launch], np.float64)
+        launch_rays = per_launch[:, 4] + per_launch[:, 9]
     grt.set_trace_statistics(ctx, False)
 
-    # ---- profiled pass (HIP events per stage, on the tracer's stream): kernel time of the trace launches
+    # ---- profiled pass (HIP events per stage): kernel time of the stages of one 4-spp frame, nothing else in flight
     grt.set_profiling(ctx, True)
-    trace_ms, stage_ms = [], {}
-    alone_subs = submissions(SPP)
+    stage_ms = {}
     for rep in range(2):
-        for first, count in alone_subs:
-            render_step(first, count=count)
-            c, _, _ = counters()
-            if rep == 1:
-                trace_ms.append(c.ms_trace)
-                for k in ("ms_generate", "ms_trace", "ms_sort", "ms_shade", "ms_shadow", "ms_post"):
-                    stage_ms[k] = stage_ms.get(k, 0.0) + getattr(c, k) / SPP
+        for first, count, _ in submissions(SPP):
+            check(lib.rt_render_samples(ctx, first, count))
+        c = pt.counters()
+        if rep == 1:
+            for k in ("ms_generate", "ms_trace", "ms_sort", "ms_shade", "ms_shadow", "ms_post"):
+                stage_ms[k] = getattr(c, k) / SPP
+    alone_trace_ms = stage_ms["ms_trace"] * SPP
     grt.set_profiling(ctx, False)
 
     # ---- timed region: exactly K steps -------------------------------------------------------------
@@ -266,74 +316,110 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     check(lib.rt_synchronize(ctx))
-    # HIP events around every trace launch of the timed region, each on the stream the launch runs on
-    # (mode 2: no serialisation -- the side stream and the samples in flight stay as in production)
+    # HIP events around EVERY traversal launch of the timed region, each on the stream the launch runs on
     grt.set_profiling(ctx, 0 if os.environ.get("BENCH_NO_LAUNCH_TIMING") else 2)
     t0 = time.perf_counter()
-    plan = submissions(args.steps)
-    for i, (first, count) in enumerate(plan):
-        render_step(first, frame_complete=(first + count == SPP or i == len(plan) - 1), count=count)
+    run(plan)
     check(lib.rt_synchronize(ctx))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    timed_counters = pt.counters()
-    timed_subs = [plan[i] for i in range(0, len(plan), 3)]       # mode 2 times every 3rd submission (events are not free)
-    timed_trace_ms = timed_counters.ms_trace                     # sum over their closest-hit launches
-    timed_alg_bytes = sum(alg_bytes_per_sample[first + j] for first, count in timed_subs for j in range(count))
+    launch_ms = grt.launch_timings(ctx, 0).astype(np.float64)
+    shadow_launch_ms = grt.launch_timings(ctx, 1).astype(np.float64)
     grt.set_profiling(ctx, False)
 
-    local = torch.tensor([elapsed, float(sum(rays_per_sample)), float(sum(shadow_per_sample)), float(sum(alg_bytes_per_sample)), float(sum(trace_ms))], dtype=torch.float64, device=device)
+    rays_plan = float(sum(rays_per_sample[(first + j) % SPP] for first, count, _ in plan for j in range(count)))
+    shadow_plan = float(sum(shadow_per_sample[(first + j) % SPP] for first, count, _ in plan for j in range(count)))
+    local = torch.tensor([elapsed, rays_plan, shadow_plan], dtype=torch.float64, device=device)
     if world > 1:
         mx = local.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = local.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0]); rays_4spp = float(sm[1]); shadow_4spp = float(sm[2])
-    else:
-        rays_4spp, shadow_4spp = float(local[1]), float(local[2])
+        elapsed = float(mx[0]); rays_plan = float(sm[1]); shadow_plan = float(sm[2])
 
     if rank == 0:
-        rays_per_step = rays_4spp / SPP
-        total_rays = rays_per_step * args.steps
-        value = total_rays / elapsed / 1e6
-        launches_per_sample = NUM_BOUNCES  # closest-hit trace launches per submission (one per bounce)
-        achieved = timed_alg_bytes / (max(timed_trace_ms, 1e-9) * 1e-3) / 1e9  # rank 0's launches of the timed region
-        achieved_alone = sum(alg_bytes_per_sample) / (sum(trace_ms) * 1e-3) / 1e9
-        roofline = {
-            "bound": "hbm", "kernel": "kernel_trace_bvh8", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "algorithmic_bytes_per_launch": round(timed_alg_bytes / len(timed_subs) / launches_per_sample),
-            "samples_per_launch": args.batch,
-            "avg_launch_ms": round(timed_trace_ms / len(timed_subs) / launches_per_sample, 4), "launches_per_step": round(launches_per_sample * len(plan) / args.steps, 2),
-            "avg_launch_ms_running_alone": round(sum(trace_ms) / len(alone_subs) / launches_per_sample, 4), "frac_running_alone": round(achieved_alone / HBM_PEAK_GBPS, 4),
-            "bytes_per_ray": round(sum(alg_bytes_per_sample) / max(sum(rays_per_sample), 1), 1),
+        value = rays_plan / elapsed / 1e6
+        alg_closest_plan = float(sum(alg_closest_per_sample[(first + j) % SPP] for first, count, _ in plan for j in range(count)))
+        alg_shadow_plan = float(sum(alg_shadow_per_sample[(first + j) % SPP] for first, count, _ in plan for j in range(count)))
+        def spread(values):
+            v = np.sort(np.asarray(values, np.float64))
+            return {"min": round(float(v[0]), 4), "median": round(float(v[len(v) // 2]), 4), "max": round(float(v[-1]), 4)} if len(v) else None
+        roofline = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None}
+        if merged and len(launch_ms) == len(launch_bytes):
+            # the dominant kernel: ONE fused traversal launch per iteration (closest-hit rays of every submission in flight +
+            # the shadow rays of the previous iteration); bytes per launch from the counting variant of the same launches
+            achieved = launch_bytes.sum() / (launch_ms.sum() * 1e-3) / 1e9
+            big = launch_rays >= 0.5 * launch_rays.max()        # the steady-state launches (fill and drain iterations excluded)
+            per_launch_gbps = launch_bytes / np.maximum(launch_ms, 1e-6) / 1e6
+            roofline.update({
+                "kernel": "kernel_trace_stream_bvh8", "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "launches": int(len(launch_ms)), "algorithmic_bytes_per_launch": round(float(launch_bytes.mean())), "avg_launch_ms": round(float(launch_ms.mean()), 4),
+                "launch_ms": spread(launch_ms), "launch_gbps": spread(per_launch_gbps),
+                "steady_state": {"launches": int(big.sum()), "achieved": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9), 1),
+                                 "frac": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9 / HBM_PEAK_GBPS), 4),
+                                 "launch_gbps": spread(per_launch_gbps[big]), "rays_per_launch": int(launch_rays[big].mean())},
+                "closest_hit_share_of_bytes": round(float(launch_closest_bytes.sum() / launch_bytes.sum()), 3),
+                "time_share_of_step": round(float(launch_ms.sum() / (elapsed * 1e3)), 3),
+                "note": "achieved = sum of the algorithmic bytes (SURVEY 8d; counted by the counting variant on the same launches) of ALL traversal launches of the timed region / sum of their HIP-event durations; one launch at a time is resident (single stream), so a duration is the kernel's own. steady_state = launches with at least half the rays of the largest. Working set (2.6 MB nodes + 12.6 MB triangle positions) is L2 / Infinity-Cache resident: algorithmic bytes >> DRAM traffic",
+            })
+        else:
+            total_ms = float(launch_ms.sum()) if len(launch_ms) else float("nan")
+            achieved = alg_closest_plan / (total_ms * 1e-3) / 1e9
+            roofline.update({"kernel": "kernel_trace_bvh8", "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4), "launches": int(len(launch_ms)),
+                             "launch_ms": spread(launch_ms), "shadow_kernel": {"kernel": "kernel_trace_shadow_bvh8", "launches": int(len(shadow_launch_ms)), "launch_ms": spread(shadow_launch_ms),
+                             "achieved": round(alg_shadow_plan / (max(float(shadow_launch_ms.sum()), 1e-9) * 1e-3) / 1e9, 1)},
+                             "note": "slot scheduler: launches of different submissions queue behind each other, the event durations include that wait"})
+        roofline.update({
+            "traversal_share": {"algorithmic_gbps_over_the_whole_step": round((alg_closest_plan + alg_shadow_plan) / elapsed / 1e9, 1),
+                                "frac": round((alg_closest_plan + alg_shadow_plan) / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
+                                "note": "all traversal bytes (closest + shadow) / wall time of the timed region: a lower bound that charges every other kernel to the traversal"},
+            "bytes_per_ray": round(sum(alg_closest_per_sample) / max(sum(rays_per_sample), 1), 1),
+            "bytes_per_shadow_ray": round(sum(alg_shadow_per_sample) / max(sum(shadow_per_sample), 1), 1),
             "nodes_per_ray": round(sum(s["closest"]["nodes"] for s in trace_rays_stat) / max(sum(rays_per_sample), 1), 2),
             "triangles_per_ray": round(sum(s["closest"]["triangles"] for s in trace_rays_stat) / max(sum(rays_per_sample), 1), 2),
+            "nodes_per_shadow_ray": round(sum(s["shadow"]["nodes"] for s in trace_rays_stat) / max(sum(shadow_per_sample), 1), 2),
+            "triangles_per_shadow_ray": round(sum(s["shadow"]["triangles"] for s in trace_rays_stat) / max(sum(shadow_per_sample), 1), 2),
+            "frame_alone_trace_ms_per_step": round(alone_trace_ms / SPP, 4),
             "measured_stream_read_gbps": round(grt.measure_stream_bandwidth(ctx, 1 << 30, 5), 1),
-            "note": "achieved = algorithmic bytes of the timed region's trace launches / sum of their HIP-event durations while they share the GPU with the shadow launch and the other sample in flight (what rocprofv3 --kernel-trace sees); *_running_alone = the same launches in a serialised pass. Working set (2.6 MB nodes + 12.6 MB triangle positions) is L2/Infinity-Cache resident; algorithmic bytes >> DRAM traffic",
-        }
-        traffic_file = os.path.join(ROOT, "profiles", "pmc_trace_traffic.json")
-        if os.path.exists(traffic_file):
-            roofline["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
+        })
         result = {
             "metric": "Mrays/s (primary+secondary) + ms/frame, Sponza 1920x1080 4spp BVH8", "value": round(value, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "Sponza (Crytek, 262 687 triangles, 384 instances) 1920x1080, samples 0..3 (4 spp), BVH8/CWBVH, diffuse + roughplastic(odd materials, alpha 0.3), NEE+MIS+RR, 10 bounces, constant white sky, mipmapping on, 19 diffuse textures at the reference's dimensions (1024x1024 RGBA8 + mips, ~106 MB; texels replicated 4x4 from the quarter-size maps that travel with the repo), the 5 maps missing upstream are the reference's 1x1 fallback texel",
-                "step": "one sample per pixel for the whole frame; the 4 samples of a frame are submitted as one wavefront (rt_render_samples), the reference's 777 600-pixel batches (a VRAM bound) are not needed",
-                "rays_per_step": round(rays_per_step), "shadow_rays_per_step": round(shadow_4spp / SPP),
-                "mrays_s_including_shadow": round((rays_4spp + shadow_4spp) / SPP * args.steps / elapsed / 1e6, 1),
+                "workload": "Sponza (Crytek, 262 687 triangles, 384 instances) 1920x1080, samples 0..3 (4 spp), BVH8/CWBVH, diffuse + roughplastic(odd materials, alpha 0.3), NEE+MIS+RR, 10 bounces, constant white sky, mipmapping on, 19 diffuse textures at the reference's dimensions (1024x1024 + mips, BC1 block-compressed as the reference does by default, decoded in the shade kernels; texels replicated 4x4 from the quarter-size maps that travel with the repo), the 5 maps missing upstream are the reference's 1x1 fallback texel",
+                "step": "one sample per pixel for the whole frame; the 4 samples of a frame are one submission (rt_render_samples); consecutive submissions feed one merged wavefront, every launch carries the rays of all submissions in flight",
+                "scheduler": scheduler,
+                "rays_per_step": round(rays_plan / args.steps), "shadow_rays_per_step": round(shadow_plan / args.steps),
+                "mrays_s_including_shadow": round((rays_plan + shadow_plan) / elapsed / 1e6, 1),
                 "ms_per_4spp_frame": round(elapsed / args.steps * SPP * 1e3, 3),
                 "emulated_world": args.emulate_world, "ranks": (dist.get_world_size() if world > 1 else 1),
-                "parallelism": "tile-split x%d + one RCCL all-gather of the accumulated float4 frame per %d-spp frame" % (world, SPP) if world > 1 else "single GPU",
-                "samples_per_submission": args.batch, "submissions_in_flight": args.samples_in_flight,
-                "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
+                "parallelism": "tile-split x%d + one RCCL all-gather of the accumulated float4 frame per %d-spp frame, unpacked into every rank's framebuffer" % (world, SPP) if world > 1 else "single GPU",
+                "samples_per_submission": args.batch, "submissions_in_flight": ("num_bounces (merged wavefront)" if merged else args.samples_in_flight),
+                "stage_ms_per_step_one_frame_alone": {k: round(v, 3) for k, v in stage_ms.items()},
             },
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(grt, pt, scene)
+        if world == 1 and split_world == 1 and not args.no_povs:
+            # the reference's perf harness (Util/PerfTest.h): the same frame loop at its 9 fixed points of view
+            povs = []
+            for position, rotation in SPONZA_POVS:
+                scene.set_camera(position, rotation); pt.update()
+                run(submissions(2 * SPP)); check(lib.rt_synchronize(ctx))     # untimed: first frames from the new camera
+                grt.set_trace_statistics(ctx, False)
+                pov_plan = submissions(4 * SPP)
+                t0 = time.perf_counter()
+                run(pov_plan)
+                check(lib.rt_synchronize(ctx))
+                ms = (time.perf_counter() - t0) / (4 * SPP) * 1e3
+                check(lib.rt_render_samples(ctx, 0, 1)); c = pt.counters()
+                povs.append({"ms_per_step": round(ms, 3), "rays_per_step": int(sum(c.trace[:NUM_BOUNCES])), "mrays_s": round(sum(c.trace[:NUM_BOUNCES]) / ms / 1e3, 1)})
+            ms_all = np.array([p["ms_per_step"] for p in povs]); mr_all = np.array([p["mrays_s"] for p in povs])
+            result["povs"] = {"source": "Util/PerfTest.h:30-40 (povs_sponza), 16 steps each", "per_pov": povs,
+                              "ms_per_step_avg": round(float(ms_all.mean()), 3), "ms_per_step_stddev": round(float(ms_all.std()), 3),
+                              "mrays_s_avg": round(float(mr_all.mean()), 1), "mrays_s_stddev": round(float(mr_all.std()), 1)}
         print(json.dumps(result))
 
     pt.close()

@@ -1483,6 +1483,7 @@ int rt_render_ao_sample(rt_context * ctx, int sample_index, float ao_radius) {
 	int range_count  = ctx->pixel_count < 0 ? frame_pixels - range_offset : ctx->pixel_count;
 	if (range_offset + range_count > frame_pixels) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_ao_sample: pixel range [%d,%d) exceeds the %d pixel frame", range_offset, range_offset + range_count, frame_pixels);
 
+	if (ctx->last_render_merged) { RT_HIP(ctx, quiesce(ctx)); ctx->last_render_merged = false; } // this integrator runs on slot 0
 	int s = ensure_slot(ctx, 0); if (s) return s;
 	int batch_limit = int(wanted_batch_size(ctx));
 	int batch_size  = range_count < batch_limit ? range_count : batch_limit;

@@ -159,6 +159,33 @@ def ref_build(tris24):
     return out
 
 
+def ref_build_many(meshes, threads):
+    """The reference's load-time BVH schedule: one job per mesh (SAH BVH2 + BVH8 conversion, the reference's own code) on
+    `threads` workers, as AssetManager's thread pool runs it (Assets/AssetManager.cpp:57).
+    meshes: list of (n, 24) float32 triangle arrays. Returns (wall ms, BVH2 nodes, BVH8 nodes), or None where oracle/_ref
+    was built without it."""
+    r = ref_lib()
+    if r is None or not hasattr(r, "ref_bvh_build_many"):
+        return None
+    arrays = [np.ascontiguousarray(m, dtype=np.float32) for m in meshes]
+    pointers = (ctypes.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+    counts = (ctypes.c_int * len(arrays))(*[a.size // 24 for a in arrays])
+    totals = (ctypes.c_longlong * 2)()
+    r.ref_bvh_build_many.restype = ctypes.c_double
+    r.ref_bvh_build_many.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    wall = r.ref_bvh_build_many(pointers, counts, len(arrays), int(threads), totals)
+    return float(wall), int(totals[0]), int(totals[1])
+
+
+def effective_parallelism(threads, seconds_per_run=0.25):
+    """threads x (time of a fixed spin loop on one thread) / (time of `threads` such loops at once): how many cores the
+    process really gets (BASELINE.md 3 asks for it next to the core count)."""
+    l = lib()
+    l.oracle_effective_parallelism.restype = ctypes.c_double
+    l.oracle_effective_parallelism.argtypes = [ctypes.c_int, ctypes.c_double]
+    return float(l.oracle_effective_parallelism(int(threads), float(seconds_per_run)))
+
+
 def ref_mipmap_downsample(filter_type, src, w_dst, h_dst):
     """One mip step by the reference's own Mipmap::downsample; src (h, w, 4) float32 -> (h_dst, w_dst, 4)."""
     src = np.ascontiguousarray(src, np.float32)

@@ -23,6 +23,8 @@
 
 #include <vector>
 #include <chrono>
+#include <atomic>
+#include <thread>
 #include <unistd.h>
 #include <fcntl.h>
 
@@ -82,6 +84,35 @@ void * ref_bvh_build_triangles(const float * tris24, int n) {
 	r->ms_bvh2 = t1 - t0;
 	r->ms_bvh8 = t2 - t1;
 	return r;
+}
+
+// The reference's load-time schedule for the CPU baseline of bench.py: AssetManager (Assets/AssetManager.cpp:57) owns a
+// thread pool of hardware_concurrency workers and gives it ONE JOB PER MESH; a job builds the SAH BVH2 of its mesh
+// (BVH::create_from_triangles) and converts it to the 8-wide tree (BVH8Converter). Same code, same granularity; the
+// pool itself is replaced by `threads` std::threads pulling mesh indices from an atomic counter (Util/ThreadPool.cpp
+// loses wake-ups on jobs this short). Returns the wall-clock milliseconds; totals = { BVH2 nodes, BVH8 nodes }.
+double ref_bvh_build_many(const float * const * tris24, const int * counts, int meshes, int threads, long long * totals) {
+	cpu_config.bvh_type = BVHType::BVH8;
+	if (threads < 1) threads = 1;
+	std::vector<RefBVH> results; results.resize(size_t(meshes));
+	std::atomic<int> next(0);
+	MuteStdout mute;
+	double t0 = now_ms();
+	auto worker = [&]() {
+		for (int m = next.fetch_add(1); m < meshes; m = next.fetch_add(1)) {
+			Array<Triangle> triangles(counts[m]);
+			memcpy((void *)triangles.data(), tris24[m], size_t(counts[m]) * sizeof(Triangle));
+			results[size_t(m)].bvh2 = BVH::create_from_triangles(triangles);
+			BVH8Converter(results[size_t(m)].bvh8, results[size_t(m)].bvh2).convert();
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+	worker();
+	for (std::thread & t : pool) t.join();
+	double wall = now_ms() - t0;
+	if (totals) { totals[0] = totals[1] = 0; for (const RefBVH & r : results) { totals[0] += (long long)r.bvh2.nodes.size(); totals[1] += (long long)r.bvh8.nodes.size(); } }
+	return wall;
 }
 
 // The binary tree the reference hands to the device for bvh_type = BVH (sbvh = 0) or SBVH
