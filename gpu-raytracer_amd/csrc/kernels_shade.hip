@@ -713,6 +713,7 @@ struct BSDFConductor : BSDFCommon {
 RT_DEV int sample_light(const RtParams & p, float u1, float u2, int & transform_id) { // Sampling.h:180-190
 	int light_mesh_id = binary_search(p.light_mesh_cumulative_probability, 0, p.light_mesh_count - 1, u1);
 	transform_id = p.light_mesh_transform_indices[light_mesh_id];
+	if (p.mesh_position) transform_id = p.mesh_position[transform_id]; // device-built TLAS: the host only knows scene indices
 	int2 span = p.light_mesh_triangle_span[light_mesh_id];
 	int light_triangle_id = binary_search(p.light_triangle_cumulative_probability, span.x, span.y, u2);
 	return p.light_triangle_indices[light_triangle_id];

@@ -144,6 +144,7 @@ struct rt_context {
 	size_t bvh8_node_count = 0, bvh2_node_count = 0, triangle_count = 0;
 	size_t mesh_count = 0;
 	SceneRing tlas_ring, instance_ring, light_ring;
+	int * device_tlas_order = nullptr, * device_tlas_node_count = nullptr; // current TLAS built by rt_build_tlas (else null)
 	hipEvent_t ev_scene = nullptr;  // the last asynchronous scene upload on the main stream
 	void * material_types = nullptr, * materials = nullptr, * media = nullptr;
 	bool has_material[4] = { false, false, false, false };
@@ -519,6 +520,95 @@ int rt_upload_instances(rt_context * ctx, const int32_t * root_indices, const in
 	ctx->params.mesh_transforms       = (const float4 *)(base + offset[2]);
 	ctx->params.mesh_transforms_inv   = (const float4 *)(base + offset[3]);
 	ctx->params.mesh_transforms_prev  = (const float4 *)(base + offset[4]);
+	ctx->params.mesh_position = nullptr;   // the host supplies everything in TLAS order
+	ctx->device_tlas_order = nullptr; ctx->device_tlas_node_count = nullptr;
+	return RT_OK;
+}
+
+// ---- TLAS build on the device (kernels_build.hip) ---------------------------------------------------------------
+} // extern "C"
+#include "rt_tlas_build.h"
+struct TlasBuildArgs;
+void rt_launch_build_tlas(const TlasBuildArgs & args, hipStream_t stream);
+struct TlasBuildArgs { // must match kernels_build.hip
+	int count;
+	const int * root_indices; const int * material_ids;
+	const float4 * transforms, * transforms_inv, * transforms_prev;
+	const float * local_boxes;
+	uint32_t * nodes; int * out_root_indices, * out_material_ids;
+	float4 * out_transforms, * out_transforms_inv, * out_transforms_prev;
+	int * order; int * position; int * node_count;
+	TlasBox * boxes; int * queue; int * runs; int * bases; TlasBox * child_boxes;
+};
+extern "C" {
+
+int rt_build_tlas(rt_context * ctx, const int32_t * root_indices, const int32_t * material_ids,
+                  const float * transforms, const float * transforms_inv, const float * transforms_prev,
+                  const float * local_boxes, size_t mesh_count) {
+	RT_REQUIRE(ctx, ctx && root_indices && material_ids && transforms && transforms_inv && transforms_prev && local_boxes, "rt_build_tlas: NULL argument");
+	RT_REQUIRE(ctx, mesh_count >= 1 && mesh_count <= RT_TLAS_BUILD_MAX, "rt_build_tlas: 1 .. 4096 instances (larger scenes build the TLAS on the host: rt_upload_tlas)");
+	RT_REQUIRE(ctx, ctx->bvh_width == 8 && ctx->bvh8_nodes && 2 * mesh_count <= ctx->bvh8_node_count, "rt_build_tlas: CWBVH geometry with 2 * mesh_count reserved node slots must be uploaded first");
+	(void)hipSetDevice(ctx->device);
+	const size_t n = mesh_count, padded = (n + 3) / 4 * 4;
+	// one allocation per version: outputs | inputs | scratch (every region 16-byte aligned)
+	size_t offset[24]; size_t at = 0; int regions = 0;
+	auto region = [&](size_t bytes) { offset[regions++] = at; at += (bytes + 15) / 16 * 16; };
+	region(padded * 4); region(padded * 4); region(n * 48); region(n * 48); region(n * 48);   // 0..4 out: roots, materials, transforms, inverse, previous
+	region(padded * 4); region(padded * 4); region(16);                                      // 5..7 out: position, order, node count
+	const size_t inputs_begin = at;
+	region(padded * 4); region(padded * 4); region(n * 48); region(n * 48); region(n * 48); region(n * 24); // 8..13 in
+	const size_t inputs_end = at;
+	region(n * 24); region(n * 24); region(n * 48); region(n * 8); region(n * 192);            // 14..18 scratch: boxes, queues, runs, bases, child boxes
+	void * staging = nullptr;
+	int s = ring_begin(ctx, ctx->instance_ring, at, &SampleSlot::instance_version, &staging); if (s) return s;
+	const void * src[6] = { root_indices, material_ids, transforms, transforms_inv, transforms_prev, local_boxes };
+	const size_t bytes[6] = { n * 4, n * 4, n * 48, n * 48, n * 48, n * 24 };
+	for (int i = 0; i < 6; i++) memcpy((char *)staging + offset[8 + i], src[i], bytes[i]);
+	char * base = (char *)ctx->instance_ring.device[ctx->instance_ring.current];
+	RT_HIP(ctx, hipMemcpyAsync(base + inputs_begin, (char *)staging + inputs_begin, inputs_end - inputs_begin, hipMemcpyHostToDevice, ctx->stream));
+	void * tlas_staging = nullptr;
+	s = ring_begin(ctx, ctx->tlas_ring, 2 * n * 80, &SampleSlot::tlas_version, &tlas_staging); if (s) return s;
+	void * tlas_device = ctx->tlas_ring.device[ctx->tlas_ring.current];
+
+	TlasBuildArgs a;
+	a.count = int(n);
+	a.root_indices = (const int *)(base + offset[8]); a.material_ids = (const int *)(base + offset[9]);
+	a.transforms = (const float4 *)(base + offset[10]); a.transforms_inv = (const float4 *)(base + offset[11]); a.transforms_prev = (const float4 *)(base + offset[12]);
+	a.local_boxes = (const float *)(base + offset[13]);
+	a.nodes = (uint32_t *)tlas_device;
+	a.out_root_indices = (int *)(base + offset[0]); a.out_material_ids = (int *)(base + offset[1]);
+	a.out_transforms = (float4 *)(base + offset[2]); a.out_transforms_inv = (float4 *)(base + offset[3]); a.out_transforms_prev = (float4 *)(base + offset[4]);
+	a.position = (int *)(base + offset[5]); a.order = (int *)(base + offset[6]); a.node_count = (int *)(base + offset[7]);
+	a.boxes = (TlasBox *)(base + offset[14]); a.queue = (int *)(base + offset[15]); a.runs = (int *)(base + offset[16]); a.bases = (int *)(base + offset[17]); a.child_boxes = (TlasBox *)(base + offset[18]);
+	rt_launch_build_tlas(a, ctx->stream);
+	RT_HIP(ctx, hipGetLastError());
+	RT_HIP(ctx, hipEventRecord(ctx->instance_ring.copied[ctx->instance_ring.current], ctx->stream));
+	RT_HIP(ctx, hipEventRecord(ctx->tlas_ring.copied[ctx->tlas_ring.current], ctx->stream));
+	RT_HIP(ctx, hipEventRecord(ctx->ev_scene, ctx->stream));
+
+	ctx->mesh_count = n;
+	ctx->params.tlas_nodes = (const float4 *)tlas_device;
+	ctx->params.tlas_node_count = int(2 * n);     // the node slots reserved for the TLAS; BLAS nodes start behind them
+	ctx->params.mesh_bvh_root_indices = a.out_root_indices;
+	ctx->params.mesh_material_ids     = a.out_material_ids;
+	ctx->params.mesh_transforms       = a.out_transforms;
+	ctx->params.mesh_transforms_inv   = a.out_transforms_inv;
+	ctx->params.mesh_transforms_prev  = a.out_transforms_prev;
+	ctx->params.mesh_position         = a.position;
+	ctx->device_tlas_order = a.order; ctx->device_tlas_node_count = a.node_count;
+	return RT_OK;
+}
+
+int rt_read_tlas(rt_context * ctx, int32_t * order, void * nodes, size_t node_capacity, int32_t * node_count) {
+	RT_REQUIRE(ctx, ctx, "rt_read_tlas: NULL context");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->device_tlas_order) return fail(ctx, RT_ERROR_NOT_READY, "rt_read_tlas: the current TLAS was not built on the device (rt_build_tlas)");
+	RT_HIP(ctx, quiesce(ctx));
+	int count = 0;
+	RT_HIP(ctx, hipMemcpy(&count, ctx->device_tlas_node_count, sizeof(int), hipMemcpyDeviceToHost));
+	if (node_count) *node_count = count;
+	if (order) RT_HIP(ctx, hipMemcpy(order, ctx->device_tlas_order, ctx->mesh_count * sizeof(int), hipMemcpyDeviceToHost));
+	if (nodes) RT_HIP(ctx, hipMemcpy(nodes, ctx->params.tlas_nodes, std::min(node_capacity, size_t(count)) * 80, hipMemcpyDeviceToHost));
 	return RT_OK;
 }
 

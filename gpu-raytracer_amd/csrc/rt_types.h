@@ -114,6 +114,9 @@ struct RtParams {
 	const int    * mesh_bvh_root_indices;
 	const int    * mesh_material_ids;
 	const float4 * mesh_transforms, * mesh_transforms_inv, * mesh_transforms_prev;
+	// TLAS built on the device (rt_build_tlas): scene index of an instance -> its position in TLAS order, for tables that
+	// name instances by scene index (light_mesh_transform_indices); null when the host supplied everything in TLAS order
+	const int    * mesh_position;
 	// materials
 	const uint8_t * material_types;
 	const float4  * materials;  // 2 float4 per material

@@ -163,6 +163,21 @@ int rt_upload_geometry_bvh4(rt_context * ctx, const void * triangles, size_t tri
 int rt_upload_tlas_bvh4(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count);
 /* Selects the trace kernels (kernel_trace_bvh2 / bvh4 / bvh8 of the reference, Pathtracer.cpp:115-135). */
 int rt_set_bvh_type(rt_context * ctx, int bvh_width /* 2, 4 or 8 */);
+
+/* Per-frame TLAS build ON THE DEVICE: replaces, for scenes whose instances move, the host work of Integrator::build_tlas
+ * (Integrator.cpp:399-430: SAH build over the instance boxes, CWBVH conversion, re-ordering of the per-instance tables)
+ * and rt_upload_tlas + rt_upload_instances. Everything is given in SCENE order (one entry per instance, any order the
+ * host likes, the same every frame): root_indices / material_ids / transforms / transforms_inv / transforms_prev as for
+ * rt_upload_instances, local_boxes = 6 floats per instance, the object-space min and max of its BLAS. One kernel launch
+ * (asynchronous, a new version of the scene ring like the uploads) sorts the instances along a Morton curve, builds the
+ * 8-wide compressed TLAS over them in node slots [0, 2 * mesh_count) and gathers the tables into TLAS order. CWBVH
+ * kernels only; 1 <= mesh_count <= 4096. With a device-built TLAS rt_upload_lights takes SCENE indices in
+ * light_mesh_transform_indices. rt_read_tlas copies the result back (tests, pixel-query translation):
+ * order[position] = scene index, the nodes actually used (80 bytes each) and their count; any pointer may be NULL. */
+int rt_build_tlas(rt_context * ctx, const int32_t * root_indices, const int32_t * material_ids,
+                  const float * transforms, const float * transforms_inv, const float * transforms_prev,
+                  const float * local_boxes, size_t mesh_count);
+int rt_read_tlas(rt_context * ctx, int32_t * order, void * nodes, size_t node_capacity, int32_t * node_count);
 /* Replaces mesh_bvh_root_indices / mesh_material_ids / mesh_transforms{,_inv,_prev}
  * (Integrator.cpp:412-429). Index = TLAS-order mesh id. Matrices are 12 floats, row-major
  * 3x4.  MSB of root_indices[i] = "identity transform" (Integrator.cpp:415).              */
