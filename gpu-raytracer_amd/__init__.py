@@ -403,6 +403,8 @@ _ARRAY_DTYPES = {
     "light_triangle_indices": np.int32, "light_triangle_cumulative_probability": np.float32,
     "light_mesh_cumulative_probability": np.float32, "light_mesh_triangle_span": np.int32,
     "light_mesh_transform_indices": np.int32, "sky": np.float32, "camera": np.uint8, "svgf_matrices": np.float32,
+    "scene_order_roots": np.int32, "scene_order_materials": np.int32, "scene_order_transforms": np.float32,
+    "scene_order_transforms_inv": np.float32, "scene_order_transforms_prev": np.float32, "scene_order_boxes": np.float32,
 }
 
 

@@ -191,10 +191,62 @@ void Integrator::init_rng() {
 
 // Per-frame TLAS over the mesh AABBs; every per-instance table is written in TLAS
 // leaf order, which is what `mesh_id` means on the device (reference: Integrator.cpp:399-430).
+bool Integrator::wants_device_tlas() const {
+	if (!ctx || cpu_config.bvh_type != BVHType::BVH8 || scene.meshes.empty() || scene.meshes.size() > 4096) return false;
+	return cpu_config.device_tlas > 0 || (cpu_config.device_tlas < 0 && cpu_config.enable_scene_update);
+}
+
+// The device-built TLAS as host arrays (TLAS nodes in the aggregated node array, the instance tables in TLAS order,
+// tlas.indices): what pixel queries and the parity checker read. One synchronous read-back, only when asked for.
+void Integrator::sync_host_view_of_device_tlas() {
+	if (!tlas_on_device || !tlas_host_view_stale) return;
+	size_t mesh_count = scene.meshes.size();
+	tlas.indices.resize(mesh_count);
+	tlas.nodes.assign(2 * mesh_count, BVHNode8());
+	int node_count = 0;
+	check(rt_read_tlas(ctx, tlas.indices.data(), tlas.nodes.data(), tlas.nodes.size(), &node_count));
+	tlas.nodes.resize(size_t(node_count));
+	memcpy(aggregated_bvh_nodes_8.data(), tlas.nodes.data(), tlas.nodes.size() * sizeof(BVHNode8));
+	for (size_t i = 0; i < mesh_count; i++) {
+		int src = tlas.indices[i];
+		mesh_bvh_root_indices[i] = scene_order_roots[src];
+		mesh_material_ids[i]     = scene_order_materials[src];
+		mesh_transforms[i] = scene_order_transforms[src]; mesh_transforms_inv[i] = scene_order_transforms_inv[src]; mesh_transforms_prev[i] = scene_order_transforms_prev[src];
+	}
+	tlas_host_view_stale = false;
+}
+
+// What rt_build_tlas takes: one entry per instance in scene order
+void Integrator::fill_scene_order_tables() {
+	size_t mesh_count = scene.meshes.size();
+	scene_order_roots.resize(mesh_count); scene_order_materials.resize(mesh_count); scene_order_boxes.resize(6 * mesh_count);
+	scene_order_transforms.resize(mesh_count); scene_order_transforms_inv.resize(mesh_count); scene_order_transforms_prev.resize(mesh_count);
+	for (size_t i = 0; i < mesh_count; i++) {
+		const Mesh & mesh = scene.meshes[i];
+		scene_order_roots[i]     = mesh_data_bvh_offsets[mesh.mesh_data_handle.handle] | (int(mesh.has_identity_transform()) << 31);
+		scene_order_materials[i] = mesh.material_handle.handle;
+		memcpy(scene_order_transforms     [i].cells, mesh.transform     .cells, sizeof(Matrix3x4));
+		memcpy(scene_order_transforms_inv [i].cells, mesh.transform_inv .cells, sizeof(Matrix3x4));
+		memcpy(scene_order_transforms_prev[i].cells, mesh.transform_prev.cells, sizeof(Matrix3x4));
+		memcpy(&scene_order_boxes[6 * i],     &mesh.aabb_untransformed.min.x, 12);
+		memcpy(&scene_order_boxes[6 * i + 3], &mesh.aabb_untransformed.max.x, 12);
+	}
+}
+
 void Integrator::build_tlas() {
+	size_t mesh_count = scene.meshes.size();
+	if (wants_device_tlas()) {
+		// Everything in scene order; the device sorts, builds and re-orders (replaces the SAH build, the CWBVH conversion and
+		// the table shuffle below: Integrator.cpp:399-430 of the reference)
+		fill_scene_order_tables();
+		check(rt_build_tlas(ctx, scene_order_roots.data(), scene_order_materials.data(), scene_order_transforms[0].cells, scene_order_transforms_inv[0].cells,
+		                    scene_order_transforms_prev[0].cells, scene_order_boxes.data(), mesh_count));
+		tlas_on_device = true; tlas_host_view_stale = true;
+		return;
+	}
+	tlas_on_device = false;
 	tlas_builder->build(scene.meshes);
 
-	size_t mesh_count = scene.meshes.size();
 	bool use_bvh8 = cpu_config.bvh_type == BVHType::BVH8;
 	const std::vector<int> * leaf_order;
 	if (cpu_config.bvh_type == BVHType::BVH4) {
@@ -272,6 +324,7 @@ void Integrator::update(float delta) {
 
 	if (pixel_query_status == PixelQueryStatus::OUTPUT_READY) { // reference: Integrator.cpp:483-495
 		if (ctx) check(rt_get_pixel_query(ctx, &pixel_query.mesh_id, &pixel_query.triangle_id));
+		sync_host_view_of_device_tlas();
 		if (pixel_query.mesh_id != INVALID) pixel_query.mesh_id = tlas.indices[pixel_query.mesh_id]; // TLAS order -> scene mesh index
 		pixel_query.pixel_index = INVALID;
 		if (ctx) check(rt_set_pixel_query(ctx, INVALID));

@@ -59,7 +59,16 @@ struct Integrator {
 
 	PixelQuery pixel_query = { INVALID, INVALID, INVALID };
 	enum struct PixelQueryStatus { INACTIVE, PENDING, OUTPUT_READY } pixel_query_status = PixelQueryStatus::INACTIVE; // Integrator.h:75-79
-	bool scheduler_for_scene_updates = false; // the device context schedules for per-frame scene uploads (rt_set_scheduler)
+	bool scheduler_for_scene_updates = false;
+	// The current TLAS was built by the device (rt_build_tlas): the host holds no TLAS nodes, `tlas.indices` and the
+	// TLAS-ordered instance tables are fetched from the device when something on the host needs them (pixel queries,
+	// the parity checker's view of the scene).
+	bool tlas_on_device = false, tlas_host_view_stale = false;
+	bool wants_device_tlas() const;
+	void sync_host_view_of_device_tlas();
+	void fill_scene_order_tables();
+	std::vector<int> scene_order_roots, scene_order_materials; std::vector<float> scene_order_boxes;
+	std::vector<Matrix3x4> scene_order_transforms, scene_order_transforms_inv, scene_order_transforms_prev; // the device context schedules for per-frame scene uploads (rt_set_scheduler)
 
 	// ---- host staging of everything the device consumes (filled by init_* / build_tlas) ----
 	std::vector<DeviceTriangle> aggregated_triangles;

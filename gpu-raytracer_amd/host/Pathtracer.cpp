@@ -88,9 +88,11 @@ void Pathtracer::calc_light_mesh_weights() {
 	light_mesh_triangle_span.clear();
 	light_mesh_transform_indices.clear();
 
+	// Order of the light meshes in the CDF: TLAS order, as in the reference -- unless the TLAS is built on the device, whose
+	// order the host does not know; then scene order, with scene indices as transform indices (the device maps them)
 	double total = 0.0;
 	for (size_t i = 0; i < scene.meshes.size(); i++) {
-		const Mesh & mesh = scene.meshes[tlas.indices[i]];
+		const Mesh & mesh = scene.meshes[tlas_on_device ? int(i) : tlas.indices[i]];
 		if (mesh.light.weight > 0.0f) {
 			total += double(mesh.light.weight * mesh.scale * mesh.scale);
 			light_mesh_cumulative_probability.push_back(float(total));

@@ -61,6 +61,7 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "sah_cost_leaf")                       cpu_config.sah_cost_leaf = float(value);
 	else if (k == "sbvh_alpha")                          cpu_config.sbvh_alpha = float(value);
 	else if (k == "enable_scene_update")                 cpu_config.enable_scene_update = value != 0;
+	else if (k == "device_tlas")                         cpu_config.device_tlas = int(value);
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
 	else if (k == "initial_height")                      cpu_config.initial_height = int(value);
 	else { g_host_error = "unknown config key '" + k + "'"; return -1; }
@@ -365,6 +366,19 @@ int grt_pathtracer_read_framebuffer(void * pt, float * dst) {
 const void * grt_pathtracer_array(void * pt, const char * name, size_t * bytes) {
 	Integrator * p = as_integrator(pt);
 	std::string n(name);
+	if (p->tlas_on_device) { // the views below show what the device built
+		p->sync_host_view_of_device_tlas();
+		if (n == "light_mesh_transform_indices") if (Pathtracer * pt_only = dynamic_cast<Pathtracer *>(p)) {
+			// the device gets scene indices and maps them itself; a reader of the TLAS-ordered tables wants positions
+			static thread_local std::vector<int> positions;
+			std::vector<int> position_of(p->tlas.indices.size());
+			for (size_t i = 0; i < p->tlas.indices.size(); i++) position_of[size_t(p->tlas.indices[i])] = int(i);
+			positions.clear();
+			for (int scene_index : pt_only->light_mesh_transform_indices) positions.push_back(position_of[size_t(scene_index)]);
+			*bytes = positions.size() * sizeof(int);
+			return positions.data();
+		}
+	}
 	if (n == "triangles")             RET(p->aggregated_triangles)
 	if (n == "bvh8_nodes")            RET(p->aggregated_bvh_nodes_8)
 	if (n == "bvh2_nodes")            RET(p->aggregated_bvh_nodes_2)
@@ -378,6 +392,15 @@ const void * grt_pathtracer_array(void * pt, const char * name, size_t * bytes) 
 	if (n == "material_types")        RET(p->material_types)
 	if (n == "materials")             RET(p->materials)
 	if (n == "media")                 RET(p->media)
+	if (n.rfind("scene_order_", 0) == 0) { // the inputs of rt_build_tlas, filled on demand (the parity tests build from them on the CPU)
+		if (!p->tlas_on_device) p->fill_scene_order_tables();
+		if (n == "scene_order_roots")           RET(p->scene_order_roots)
+		if (n == "scene_order_materials")       RET(p->scene_order_materials)
+		if (n == "scene_order_transforms")      RET(p->scene_order_transforms)
+		if (n == "scene_order_transforms_inv")  RET(p->scene_order_transforms_inv)
+		if (n == "scene_order_transforms_prev") RET(p->scene_order_transforms_prev)
+		if (n == "scene_order_boxes")           RET(p->scene_order_boxes)
+	}
 	if (n == "tlas_indices")          RET(p->tlas.indices)
 	if (n == "tlas_nodes")            RET(p->tlas.nodes)
 	if (n == "tlas_raw_nodes")        RET(p->tlas_raw.nodes)

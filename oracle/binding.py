@@ -177,6 +177,19 @@ def ref_build_many(meshes, threads):
     return float(wall), int(totals[0]), int(totals[1])
 
 
+def tlas_build(transforms, local_boxes):
+    """CPU restatement of the device TLAS build (oracle_tlas.cpp): (n, 12) instance matrices and (n, 6) object-space boxes
+    in scene order -> (nodes as (count, 80) uint8, order[position] = scene index)."""
+    t = np.ascontiguousarray(transforms, np.float32).reshape(-1, 12); b = np.ascontiguousarray(local_boxes, np.float32).reshape(-1, 6)
+    n = t.shape[0]
+    nodes = np.zeros((2 * n, 80), np.uint8); order = np.zeros(n, np.int32)
+    l = lib()
+    l.oracle_tlas_build.restype = ctypes.c_int
+    l.oracle_tlas_build.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    count = l.oracle_tlas_build(t.ctypes.data, b.ctypes.data, n, nodes.ctypes.data, order.ctypes.data)
+    return nodes[:count], order
+
+
 def effective_parallelism(threads, seconds_per_run=0.25):
     """threads x (time of a fixed spin loop on one thread) / (time of `threads` such loops at once): how many cores the
     process really gets (BASELINE.md 3 asks for it next to the core count)."""

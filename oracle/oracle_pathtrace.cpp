@@ -1021,7 +1021,11 @@ void oracle_render_sample(const oracle_scene * scene, oracle_frame * frame, int 
                           int range_offset, int range_count, oracle_counters * counters, int threads) {
 	const oracle_scene & s = *scene;
 	if (threads <= 0) threads = omp_get_max_threads();
-	g_oracle_threads = threads;
+	g_oracle_threads = threads < 32 ? threads : 32;   // chunks of the sort / shade kernels: joining many small pieces costs more than it saves
+	if (const char * e = getenv("ORACLE_CHUNKS")) g_oracle_threads = atoi(e) > 0 ? atoi(e) : 1;
+	const bool profile = getenv("ORACLE_PROFILE") != nullptr;
+	double t_trace = 0.0, t_sort = 0.0, t_shade = 0.0, t_shadow = 0.0, t_rest = 0.0, t_mark = omp_get_wtime();
+	auto lap = [&](double & bucket) { double now = omp_get_wtime(); bucket += now - t_mark; t_mark = now; };
 	Context c(s, *frame);
 	Wavefront w;
 	oracle_counters local; memset(&local, 0, sizeof(local));
@@ -1076,11 +1080,13 @@ void oracle_render_sample(const oracle_scene * scene, oracle_frame * frame, int 
 				#pragma omp critical
 				{ local.trace_stats.nodes += st.nodes; local.trace_stats.triangles += st.triangles; local.trace_stats.instances_transformed += st.instances_transformed; local.trace_stats.instances_identity += st.instances_identity; local.trace_stats.rays += st.rays; }
 			}
+			lap(t_trace);
 
 			{	// kernel_sort: the input queue is read in place, outputs are appended chunk by chunk
 				const std::vector<TraceRay> & in = w.trace[bounce & 1];
 				run_in_chunks(in.size(), w, [&](size_t begin, size_t end, Wavefront & piece) { kernel_sort(c, in, begin, end, piece, bounce, sample_index); });
 			}
+			lap(t_sort);
 			local.diffuse[bounce] += int(w.material[0].size()); local.plastic[bounce] += int(w.material[1].size());
 			local.dielectric[bounce] += int(w.material[2].size()); local.conductor[bounce] += int(w.material[3].size());
 
@@ -1089,6 +1095,7 @@ void oracle_render_sample(const oracle_scene * scene, oracle_frame * frame, int 
 			if (has[2]) { const std::vector<MaterialRay> queue = w.material[2]; run_in_chunks(queue.size(), w, [&](size_t begin, size_t end, Wavefront & piece) { shade_material<BSDFDielectric>(c, piece, queue, begin, end, bounce, sample_index); }); }
 			if (has[3]) { const std::vector<MaterialRay> queue = w.material[3]; run_in_chunks(queue.size(), w, [&](size_t begin, size_t end, Wavefront & piece) { shade_material<BSDFConductor>(c, piece, queue, begin, end, bounce, sample_index); }); }
 
+			lap(t_shade);
 			if (has_lights && s.config.enable_next_event_estimation) { // kernel_trace_shadow_bvhN + miss lambda (Pathtracer.cu:183-196)
 				local.shadow[bounce] += int(w.shadow.size());
 				std::vector<uint8_t> occluded(w.shadow.size());
@@ -1108,6 +1115,7 @@ void oracle_render_sample(const oracle_scene * scene, oracle_frame * frame, int 
 					else             c.aov_add(RT_AOV_RADIANCE_INDIRECT, sr.pixel_index, make_float4(sr.illumination));
 				}
 			}
+			lap(t_shadow);
 		}
 		pixels_left -= batch_size;
 	}
@@ -1120,6 +1128,8 @@ void oracle_render_sample(const oracle_scene * scene, oracle_frame * frame, int 
 		if (frame->framebuffer[a]) memset(frame->framebuffer[a], 0, size_t(s.screen_pitch) * s.screen_height * 4 * sizeof(float));
 	}
 	if (counters) *counters = local;
+	lap(t_rest);
+	if (profile) fprintf(stderr, "[oracle] sample %d: trace %.2f s, sort %.2f s, shade %.2f s, shadow %.2f s, generate + accumulate / filter %.2f s (%d threads, %d chunks)\n", sample_index, t_trace, t_sort, t_shade, t_shadow, t_rest, threads, g_oracle_threads);
 }
 
 } // extern "C"

