@@ -575,6 +575,53 @@ __global__ void __launch_bounds__(256) kernel_unpack_pixels(RtParams p, const fl
 	}
 }
 
+// SVGF under the tile split: what the filter stage of a frame reads of THIS frame's path tracing -- the
+// per-frame DIRECT / INDIRECT / ALBEDO buffers and the three g-buffers -- travels as 5 float4 per pixel (80 B): every rank
+// packs its tiles, one all-gather, every rank scatters all tiles and then filters the whole frame (its histories are
+// complete: it filtered every earlier frame too).
+__global__ void __launch_bounds__(256) kernel_pack_svgf(RtParams p, float4 * dst, int tile_pixels, int tile_first, int tile_stride, int count) {
+	int frame_pixels = p.screen_width * p.screen_height;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+		int g = ((i / tile_pixels) * tile_stride + tile_first) * tile_pixels + i % tile_pixels;
+		float4 v[5];
+		for (int k = 0; k < 5; k++) v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (g < frame_pixels) {
+			int idx = g % p.screen_width + (g / p.screen_width) * p.screen_pitch;
+			v[0] = p.aovs[RT_AOV_RADIANCE_DIRECT].framebuffer[idx];
+			v[1] = p.aovs[RT_AOV_RADIANCE_INDIRECT].framebuffer[idx];
+			v[2] = p.aovs[RT_AOV_ALBEDO].framebuffer[idx];
+			v[3] = p.gbuffer_normal_and_depth[idx];
+			int2 ids = p.gbuffer_mesh_id_and_triangle_id[idx]; float2 prev = p.gbuffer_screen_position_prev[idx];
+			v[4] = make_float4(__int_as_float(ids.x), __int_as_float(ids.y), prev.x, prev.y);
+		}
+		for (int k = 0; k < 5; k++) dst[size_t(5) * i + k] = v[k];
+	}
+}
+__global__ void __launch_bounds__(256) kernel_unpack_svgf(RtParams p, const float4 * src, int tile_pixels, int world, int tiles_per_rank) {
+	int frame_pixels = p.screen_width * p.screen_height;
+	for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < frame_pixels; g += gridDim.x * blockDim.x) {
+		int tile = g / tile_pixels;
+		int owner = tile % world, slot = tile / world;
+		const float4 * v = src + size_t(5) * (size_t(owner * tiles_per_rank + slot) * tile_pixels + g % tile_pixels);
+		int idx = g % p.screen_width + (g / p.screen_width) * p.screen_pitch;
+		p.aovs[RT_AOV_RADIANCE_DIRECT].framebuffer[idx]   = v[0];
+		p.aovs[RT_AOV_RADIANCE_INDIRECT].framebuffer[idx] = v[1];
+		p.aovs[RT_AOV_ALBEDO].framebuffer[idx]            = v[2];
+		p.gbuffer_normal_and_depth[idx] = v[3];
+		float4 w = v[4];
+		p.gbuffer_mesh_id_and_triangle_id[idx] = make_int2(__float_as_int(w.x), __float_as_int(w.y));
+		p.gbuffer_screen_position_prev[idx]    = make_float2(w.z, w.w);
+	}
+}
+void rt_launch_pack_svgf(const RtParams & p, float4 * dst, int tile_pixels, int tile_first, int tile_stride, int tiles, hipStream_t stream) {
+	int count = tiles * tile_pixels;
+	int blocks = (count + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+	hipLaunchKernelGGL(kernel_pack_svgf, dim3(blocks), dim3(256), 0, stream, p, dst, tile_pixels, tile_first, tile_stride, count);
+}
+void rt_launch_unpack_svgf(const RtParams & p, const float4 * src, int tile_pixels, int world, int tiles_per_rank, hipStream_t stream) {
+	hipLaunchKernelGGL(kernel_unpack_svgf, dim3(4096), dim3(256), 0, stream, p, src, tile_pixels, world, tiles_per_rank);
+}
+
 void rt_launch_pack_pixels(const RtParams & p, float4 * dst, int tile_pixels, int tile_first, int tile_stride, int tiles, hipStream_t stream) {
 	int count = tiles * tile_pixels;
 	int blocks = (count + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;

@@ -139,6 +139,7 @@ struct rt_context {
 	unsigned long long * stream_history = nullptr; int stream_history_rows = 0;   // pinned [ROWS][10]: trace statistics after each traversal launch
 	int scheduler = RT_SCHEDULER_MERGED;
 	bool last_render_merged = false;
+	bool defer_filter = false;         // rt_render_sample_unfiltered: an SVGF frame stops before its filter stage (tile split)
 	bool frame_pipelining = false;     // rt_pack_pixels / rt_unpack_pixels follow the completed submissions only (rt_set_frame_pipelining)
 	int samples_in_flight = 3;
 	bool overlap_shadows = true;
@@ -964,6 +965,53 @@ int rt_unpack_pixels(rt_context * ctx, const void * src_device, int tile_pixels,
 	return RT_OK;
 }
 
+// ---- SVGF frames under the tile split ---------------------------------------------------------------
+int rt_render_sample_unfiltered(rt_context * ctx, int sample_index) {
+	RT_REQUIRE(ctx, ctx, "rt_render_sample_unfiltered: NULL context");
+	if (!ctx->params.config.enable_svgf) return fail(ctx, RT_ERROR_INVALID_ARG, "rt_render_sample_unfiltered: SVGF is not enabled");
+	ctx->defer_filter = true;
+	int status = rt_render_samples(ctx, sample_index, 1);
+	ctx->defer_filter = false;
+	return status;
+}
+
+int rt_pack_svgf_inputs(rt_context * ctx, void * dst_device, int tile_pixels, int first_tile, int tile_stride, int tiles) {
+	RT_REQUIRE(ctx, ctx && dst_device && tile_pixels > 0 && tile_stride > 0 && tiles >= 0, "rt_pack_svgf_inputs: invalid argument");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->svgf_allocated) return fail(ctx, RT_ERROR_NOT_READY, "rt_pack_svgf_inputs: SVGF is not enabled");
+	RT_HIP(ctx, main_waits_for_samples(ctx));
+	rt_launch_pack_svgf(slot_params(ctx, ctx->slots[0], 0), (float4 *)dst_device, tile_pixels, first_tile, tile_stride, tiles, ctx->stream);
+	RT_HIP(ctx, hipGetLastError());
+	return RT_OK;
+}
+
+int rt_unpack_svgf_inputs(rt_context * ctx, const void * src_device, int tile_pixels, int world, int tiles_per_rank) {
+	RT_REQUIRE(ctx, ctx && src_device && tile_pixels > 0 && world > 0 && tiles_per_rank > 0, "rt_unpack_svgf_inputs: invalid argument");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->svgf_allocated) return fail(ctx, RT_ERROR_NOT_READY, "rt_unpack_svgf_inputs: SVGF is not enabled");
+	RT_HIP(ctx, main_waits_for_samples(ctx));
+	rt_launch_unpack_svgf(slot_params(ctx, ctx->slots[0], 0), (const float4 *)src_device, tile_pixels, world, tiles_per_rank, ctx->stream);
+	RT_HIP(ctx, hipGetLastError());
+	return RT_OK;
+}
+
+int rt_filter_frame(rt_context * ctx, int sample_index) {
+	RT_REQUIRE(ctx, ctx, "rt_filter_frame: NULL context");
+	(void)hipSetDevice(ctx->device);
+	if (!ctx->params.config.enable_svgf || !ctx->svgf_allocated) return fail(ctx, RT_ERROR_NOT_READY, "rt_filter_frame: SVGF is not enabled");
+	SampleSlot & slot = ctx->slots[0];
+	RtParams p = slot_params(ctx, slot, 0);
+	p.batch_samples = 1;
+	hipStream_t st = slot.stream;
+	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));      // after the scatter of the gathered tiles (main stream)
+	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
+	rt_launch_svgf_taa(p, sample_index, st);
+	for (int i = 0; i < RT_AOV_COUNT; i++) if (p.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(p.aovs[i].framebuffer, 0, ctx->frame_pixels * 16, st)); // aovs_clear_to_zero
+	RT_HIP(ctx, hipEventRecord(slot.ev_done, st));
+	RT_HIP(ctx, hipGetLastError());
+	return RT_OK;
+}
+
 int rt_stream_wait_for_context(rt_context * ctx, void * stream) {
 	RT_REQUIRE(ctx, ctx, "rt_stream_wait_for_context: NULL context");
 	(void)hipSetDevice(ctx->device);
@@ -1460,7 +1508,7 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 		ctx->time_this_sample = ctx->launch_timing;
 		return stream_submit(ctx, sample_index, sample_count, offset, count);
 	}
-	bool exclusive = ctx->profiling || ctx->trace_statistics;
+	bool exclusive = ctx->profiling || ctx->trace_statistics || ctx->defer_filter;
 	int slot_index = exclusive ? 0 : int(ctx->render_counter++ % unsigned(ctx->samples_in_flight));
 	int s = ensure_slot(ctx, slot_index); if (s) return s;
 	if (ctx->has_material[2] || ctx->has_material[3]) { s = ensure_luts(ctx); if (s) return s; }
@@ -1573,12 +1621,14 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
 	if (ctx->last_slot >= 0 && ctx->last_slot != slot_index) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[ctx->last_slot].ev_done, 0));
 	stage_mark(ctx, STAGE_POST, st);
-	if (p.config.enable_svgf) rt_launch_svgf_taa(p, sample_index, st);
+	const bool deferred = p.config.enable_svgf && ctx->defer_filter; // rt_filter_frame does the rest once the ranks have exchanged their tiles
+	if (deferred) { }
+	else if (p.config.enable_svgf) rt_launch_svgf_taa(p, sample_index, st);
 	else rt_launch_accumulate(p, float(sample_index), range_offset, range_count, st);
 	stage_mark(ctx, STAGE_END, st);
 
 	// aovs_clear_to_zero (Integrator.cpp:379-385)
-	for (int i = 0; i < RT_AOV_COUNT; i++) if (p.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(p.aovs[i].framebuffer, 0, ctx->frame_pixels * 16 * sample_count, st));
+	if (!deferred) for (int i = 0; i < RT_AOV_COUNT; i++) if (p.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(p.aovs[i].framebuffer, 0, ctx->frame_pixels * 16 * sample_count, st));
 
 	RT_HIP(ctx, hipMemcpyAsync(slot.pinned_counters, slot.counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int), hipMemcpyDeviceToHost, st));
 	RT_HIP(ctx, hipEventRecord(slot.ev_frame_end, st));

@@ -239,6 +239,8 @@ void rt_launch_integrate_luts(const RtParams & p, float * dielectric_dir_enter, 
                               float * conductor_dir, float * conductor, hipStream_t stream);
 void rt_launch_pack_pixels(const RtParams & p, float4 * dst, int tile_pixels, int tile_first, int tile_stride, int tiles, hipStream_t stream);
 void rt_launch_unpack_pixels(const RtParams & p, const float4 * src, int tile_pixels, int world, int tiles_per_rank, hipStream_t stream);
+void rt_launch_pack_svgf(const RtParams & p, float4 * dst, int tile_pixels, int tile_first, int tile_stride, int tiles, hipStream_t stream);
+void rt_launch_unpack_svgf(const RtParams & p, const float4 * src, int tile_pixels, int world, int tiles_per_rank, hipStream_t stream);
 void rt_launch_stream_read(const float4 * src, size_t count, float * sink, hipStream_t stream);
 // Counting variants: stats = 10 x u64 {closest: nodes, triangles, inst_xform, inst_ident, rays; shadow: same}
 void rt_launch_trace_counting(const RtParams & p, int bounce, unsigned long long * stats, hipStream_t stream);

@@ -84,3 +84,53 @@ class TileSplit:
         else:
             dist.all_gather_into_tensor(out, packed.contiguous())
         return out
+
+
+class SvgfTileSplit(TileSplit):
+    """SVGF / TAA frames under the tile split (BASELINE config 3 on N GPUs). The filter stage needs
+    neighbourhoods of +-(3 + 2^5) pixels and reprojects from anywhere in the previous frame, so every rank filters the whole
+    frame -- redundantly, but without a second exchange: per frame a rank path-traces its own tiles, ONE all-gather moves what
+    the filter reads of this frame (DIRECT / INDIRECT / ALBEDO and the three g-buffers: 5 float4 = 80 B per pixel, 166 MB at
+    1080p), and every rank runs reproject / variance / a-trous / finalize / TAA on the full frame."""
+
+    FLOATS_PER_PIXEL = 20
+
+    def __init__(self, rank, world_size, width, height, tile_rows=TILE_ROWS):
+        super().__init__(rank, world_size, width, height, tile_rows)
+        self._buffers = None
+
+    def render_frame(self, grt, ctx, sample_index, gather=None):
+        """One filtered frame on the device context `ctx` (tiles already set with rt_set_pixel_tiles). `gather(packed) ->
+        gathered` defaults to torch.distributed.all_gather_into_tensor; it is ordered on torch's current stream."""
+        import ctypes
+        import torch
+        lib = grt.device_lib()
+        for name, args in (("rt_render_sample_unfiltered", [ctypes.c_void_p, ctypes.c_int]), ("rt_filter_frame", [ctypes.c_void_p, ctypes.c_int]),
+                           ("rt_pack_svgf_inputs", [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4), ("rt_unpack_svgf_inputs", [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 3),
+                           ("rt_stream_wait_for_context", [ctypes.c_void_p, ctypes.c_void_p]), ("rt_context_wait_for_stream", [ctypes.c_void_p, ctypes.c_void_p])):
+            getattr(lib, name).argtypes = args
+
+        def check(status):
+            if status != 0:
+                raise RuntimeError(lib.rt_last_error(ctx).decode())
+
+        if self._buffers is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+            self._buffers = (torch.zeros((self.local_pixels, self.FLOATS_PER_PIXEL), dtype=torch.float32, device=device),
+                             torch.zeros((self.world_size * self.local_pixels, self.FLOATS_PER_PIXEL), dtype=torch.float32, device=device))
+        packed, gathered = self._buffers
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.rt_render_sample_unfiltered(ctx, sample_index))
+        check(lib.rt_context_wait_for_stream(ctx, stream))      # the previous frame's collective has read `packed`
+        check(lib.rt_pack_svgf_inputs(ctx, packed.data_ptr(), self.tile_pixels, self.rank, self.world_size, self.tiles_per_rank))
+        check(lib.rt_stream_wait_for_context(ctx, stream))
+        if gather is not None:
+            gathered = gather(packed)
+        elif self.world_size == 1:
+            gathered.copy_(packed)
+        else:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(gathered, packed)
+        check(lib.rt_context_wait_for_stream(ctx, stream))
+        check(lib.rt_unpack_svgf_inputs(ctx, gathered.data_ptr(), self.tile_pixels, self.world_size, self.tiles_per_rank))
+        check(lib.rt_filter_frame(ctx, sample_index))

@@ -233,6 +233,17 @@ int rt_unpack_pixels(rt_context * ctx, const void * src_device, int tile_pixels,
  *       enqueued on its transfer stream so far (rt_pack_pixels, rt_unpack_pixels);
  *   rt_context_wait_for_stream: the context's transfer stream waits for everything enqueued on
  *       `stream` so far (e.g. the collective that still reads the buffer the next pack writes). */
+/* SVGF / TAA frames under the tile split (config 3 on N GPUs). The filter stage needs neighbourhoods of +-(3 + 2^5) pixels
+ * and reprojects from anywhere in the previous frame, so every rank filters the WHOLE frame, redundantly: a rank path-traces
+ * its own tiles (rt_render_sample_unfiltered: like rt_render_sample, stopping before the filter stage), the ranks exchange
+ * what the filter reads of this frame -- the per-frame DIRECT / INDIRECT / ALBEDO buffers and the three g-buffers, packed
+ * as 5 float4 per pixel by rt_pack_svgf_inputs (same tile arguments as rt_pack_pixels), one all-gather,
+ * rt_unpack_svgf_inputs -- and rt_filter_frame runs reproject / variance / a-trous / finalize / TAA on every rank
+ * (Pathtracer.cpp:798-838). Bit-identical to one context rendering the whole frame (tests/test_gpu_materials_svgf.py). */
+int rt_render_sample_unfiltered(rt_context * ctx, int sample_index);
+int rt_pack_svgf_inputs(rt_context * ctx, void * dst_device, int tile_pixels, int first_tile, int tile_stride, int tiles);
+int rt_unpack_svgf_inputs(rt_context * ctx, const void * src_device, int tile_pixels, int world, int tiles_per_rank);
+int rt_filter_frame(rt_context * ctx, int sample_index);
 int rt_stream_wait_for_context(rt_context * ctx, void * stream);
 int rt_context_wait_for_stream(rt_context * ctx, void * stream);
 

@@ -16,6 +16,7 @@ REF_LIB_PATH = os.path.join(_HERE, "_ref", "libref_bvh.so")
 
 RT_MAX_BOUNCES = 128
 RT_AOV_COUNT = 6
+RT_AOV_RADIANCE, RT_AOV_RADIANCE_DIRECT, RT_AOV_RADIANCE_INDIRECT, RT_AOV_ALBEDO, RT_AOV_NORMAL, RT_AOV_POSITION = range(6)
 
 
 class GPUConfig(Structure):
@@ -100,6 +101,8 @@ def lib():
         l.oracle_generate.argtypes = [POINTER(OracleScene), c_int, c_int, c_int] + [c_void_p] * 7
         l.oracle_random.argtypes = [POINTER(OracleScene), c_int, c_void_p, c_size_t, c_uint32, c_uint32, c_void_p]
         l.oracle_render_sample.argtypes = [POINTER(OracleScene), POINTER(OracleFrame), c_int, c_int, c_int, POINTER(OracleCounters), c_int]
+        l.oracle_render_sample_unfiltered.argtypes = [POINTER(OracleScene), POINTER(OracleFrame), c_int, c_int, c_int, POINTER(OracleCounters), c_int]
+        l.oracle_filter_frame.argtypes = [POINTER(OracleScene), POINTER(OracleFrame), c_int]
         l.oracle_render_ao_sample.argtypes = [POINTER(OracleScene), POINTER(OracleFrame), c_int, c_float, c_int, c_int, POINTER(OracleCounters), c_int]
         l.oracle_integrate_dielectric_cells.argtypes = [POINTER(OracleScene), c_int, c_int, c_int, c_int, c_void_p, c_int]
         l.oracle_integrate_conductor_cells.argtypes = [POINTER(OracleScene), c_int, c_int, c_int, c_void_p, c_int]
@@ -630,6 +633,24 @@ class Frame:
         counters = OracleCounters()
         lib().oracle_render_sample(byref(s), byref(self.f), sample_index, pixel_offset, pixel_count, byref(counters), threads)
         return counters
+
+    def render_sample_unfiltered(self, sample_index, pixel_offset=0, pixel_count=None, threads=0):
+        """SVGF frame, first half: path-trace a pixel range into the per-frame AOVs and g-buffers; no filter, nothing cleared."""
+        s = self.view.scene
+        if pixel_count is None:
+            pixel_count = s.screen_width * s.screen_height - pixel_offset
+        counters = OracleCounters()
+        lib().oracle_render_sample_unfiltered(byref(s), byref(self.f), sample_index, pixel_offset, pixel_count, byref(counters), threads)
+        return counters
+
+    def filter_frame(self, sample_index):
+        """SVGF frame, second half: reproject / variance / a-trous / finalize / TAA over the whole frame, then clear the AOVs."""
+        lib().oracle_filter_frame(byref(self.view.scene), byref(self.f), sample_index)
+
+    def svgf_inputs(self):
+        """The arrays an SVGF frame's filter reads that the path tracing of THIS frame wrote: name -> (pitch * height, C) array."""
+        return {"direct": self.buffers["fb%d" % RT_AOV_RADIANCE_DIRECT], "indirect": self.buffers["fb%d" % RT_AOV_RADIANCE_INDIRECT], "albedo": self.buffers["fb%d" % RT_AOV_ALBEDO],
+                "normal_and_depth": self.buffers["gnd"], "mesh_and_triangle": self.buffers["gid"], "screen_position_prev": self.buffers["gsp"]}
 
     def render_ao_sample(self, sample_index, ao_radius=1.0, pixel_offset=0, pixel_count=None, threads=0):
         """AO::render (Integrators/AO.cpp:148-200) for one sample."""

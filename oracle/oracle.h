@@ -147,6 +147,11 @@ void oracle_random(const oracle_scene * scene, int dimension, const uint32_t * p
  * (Pathtracer.cpp:738-855): batches, bounces, accumulate or SVGF/TAA. */
 void oracle_render_sample(const oracle_scene * scene, oracle_frame * frame, int sample_index,
                           int pixel_offset, int pixel_count, oracle_counters * counters, int threads);
+/* The two halves of an SVGF frame under the multi-GPU tile split: path tracing of a pixel range that leaves the per-frame
+ * AOVs and g-buffers in place, and the filter stage over the whole frame (+ aovs_clear_to_zero). */
+void oracle_render_sample_unfiltered(const oracle_scene * scene, oracle_frame * frame, int sample_index,
+                                     int pixel_offset, int pixel_count, oracle_counters * counters, int threads);
+void oracle_filter_frame(const oracle_scene * scene, oracle_frame * frame, int sample_index);
 /* AO::render for one sample (Integrators/AO.cpp:148-200, CUDA/AO.cu): primary hit -> one cosine-
  * weighted occlusion ray of length ao_radius -> RADIANCE = 1 where it escapes; NORMAL / POSITION AOVs. */
 void oracle_render_ao_sample(const oracle_scene * scene, oracle_frame * frame, int sample_index, float ao_radius,

@@ -1017,8 +1017,26 @@ void oracle_render_ao_sample(const oracle_scene * scene, oracle_frame * frame, i
 	if (counters) *counters = local;
 }
 
+static void render_sample_impl(const oracle_scene * scene, oracle_frame * frame, int sample_index, int range_offset, int range_count, oracle_counters * counters, int threads, bool finish);
+
 void oracle_render_sample(const oracle_scene * scene, oracle_frame * frame, int sample_index,
                           int range_offset, int range_count, oracle_counters * counters, int threads) {
+	render_sample_impl(scene, frame, sample_index, range_offset, range_count, counters, threads, true);
+}
+
+// The two halves of an SVGF frame for the multi-GPU tile split: every rank path-traces its own pixels and
+// leaves the per-frame AOVs and g-buffers in place; once the ranks have exchanged them, each filters the whole frame.
+void oracle_render_sample_unfiltered(const oracle_scene * scene, oracle_frame * frame, int sample_index,
+                                     int range_offset, int range_count, oracle_counters * counters, int threads) {
+	render_sample_impl(scene, frame, sample_index, range_offset, range_count, counters, threads, false);
+}
+void oracle_filter_frame(const oracle_scene * scene, oracle_frame * frame, int sample_index) {
+	oracle_svgf_taa(*scene, *frame, sample_index);
+	for (int a = 0; a < RT_AOV_COUNT; a++) if (frame->framebuffer[a]) memset(frame->framebuffer[a], 0, size_t(scene->screen_pitch) * scene->screen_height * 4 * sizeof(float));
+}
+
+static void render_sample_impl(const oracle_scene * scene, oracle_frame * frame, int sample_index,
+                               int range_offset, int range_count, oracle_counters * counters, int threads, bool finish) {
 	const oracle_scene & s = *scene;
 	if (threads <= 0) threads = omp_get_max_threads();
 	g_oracle_threads = threads < 32 ? threads : 32;   // chunks of the sort / shade kernels: joining many small pieces costs more than it saves
@@ -1120,12 +1138,14 @@ void oracle_render_sample(const oracle_scene * scene, oracle_frame * frame, int 
 		pixels_left -= batch_size;
 	}
 
-	if (s.config.enable_svgf) oracle_svgf_taa(s, *frame, sample_index);
-	else kernel_accumulate(c, float(sample_index), range_offset, range_count);
+	if (finish) {
+		if (s.config.enable_svgf) oracle_svgf_taa(s, *frame, sample_index);
+		else kernel_accumulate(c, float(sample_index), range_offset, range_count);
 
-	// aovs_clear_to_zero (Integrator.cpp:379-385): framebuffers are zeroed for the next frame
-	for (int a = 0; a < RT_AOV_COUNT; a++) {
-		if (frame->framebuffer[a]) memset(frame->framebuffer[a], 0, size_t(s.screen_pitch) * s.screen_height * 4 * sizeof(float));
+		// aovs_clear_to_zero (Integrator.cpp:379-385): framebuffers are zeroed for the next frame
+		for (int a = 0; a < RT_AOV_COUNT; a++) {
+			if (frame->framebuffer[a]) memset(frame->framebuffer[a], 0, size_t(s.screen_pitch) * s.screen_height * 4 * sizeof(float));
+		}
 	}
 	if (counters) *counters = local;
 	lap(t_rest);

@@ -145,3 +145,73 @@ def test_white_furnace_conductor_and_dielectric(grt, tmp_path, bsdf, lo, hi):
     assert lo <= img.mean() <= hi, img.mean()
     assert np.isfinite(img).all()
     pt.close(); scene.close()
+
+
+def test_svgf_frames_under_the_tile_split_equal_the_single_context_frames(grt):
+    """BASELINE config 3 on N GPUs: every rank path-traces its tiles, the per-frame AOVs and g-buffers are
+    exchanged, every rank filters the whole frame. Two contexts on this one GPU play two ranks (the all-gather is a
+    concatenation of their packed tiles); five frames with a moving camera are bit-identical, on both ranks, to one
+    context rendering whole frames -- temporal histories, disocclusions and TAA included."""
+    import ctypes
+    import importlib
+    import torch
+    parallel = importlib.import_module("gpu_raytracer_amd.parallel")
+    W, H, world = 256, 144, 2
+    lib = grt.device_lib()
+    lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+
+    def camera_of(frame):
+        return (0.05 * frame, 1.0 + 0.02 * frame, 6.8 - 0.03 * frame), (0.0, 0.004 * frame, 0.0, 1.0)
+
+    scene, pt = make_pathtracer(grt, "cornellbox", W, H, 0, num_bounces=4, enable_svgf=1, enable_taa=1)
+    want = []
+    for f in range(5):
+        if f:
+            scene.set_camera(*camera_of(f)); pt.update()
+        pt.render()
+        want.append(pt.read_framebuffer().copy())
+    pt.close(); scene.close()
+
+    ranks = []
+    for rank in range(world):
+        scene, pt = make_pathtracer(grt, "cornellbox", W, H, 0, num_bounces=4, enable_svgf=1, enable_taa=1)
+        split = parallel.SvgfTileSplit(rank, world, W, H)
+        assert lib.rt_set_pixel_tiles(pt.ctx, split.tile_pixels, rank, world) == 0
+        ranks.append((scene, pt, split))
+    packed_by_rank = {}
+    for f in range(5):
+        # each "rank" renders and packs; the stand-in collective hands every rank the concatenation once all have packed
+        for scene, pt, split in ranks:
+            if f:
+                scene.set_camera(*camera_of(f)); pt.update()
+        sample_index = ranks[0][1].sample_index
+        # pass 1: render + pack on every rank, pass 2: scatter the gathered tiles and filter
+        for rank, (scene, pt, split) in enumerate(ranks):
+            lib.rt_render_sample_unfiltered.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            lib.rt_pack_svgf_inputs.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4
+            packed = torch.zeros((split.local_pixels, split.FLOATS_PER_PIXEL), device="cuda")
+            torch.cuda.synchronize()
+            assert lib.rt_render_sample_unfiltered(pt.ctx, sample_index) == 0, lib.rt_last_error(pt.ctx)
+            assert lib.rt_pack_svgf_inputs(pt.ctx, packed.data_ptr(), split.tile_pixels, rank, world, split.tiles_per_rank) == 0
+            assert lib.rt_synchronize(pt.ctx) == 0
+            packed_by_rank[rank] = packed
+        gathered = torch.cat([packed_by_rank[r] for r in range(world)])
+        torch.cuda.synchronize()
+        for rank, (scene, pt, split) in enumerate(ranks):
+            lib.rt_unpack_svgf_inputs.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 3
+            lib.rt_filter_frame.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            assert lib.rt_unpack_svgf_inputs(pt.ctx, gathered.data_ptr(), split.tile_pixels, world, split.tiles_per_rank) == 0
+            assert lib.rt_filter_frame(pt.ctx, sample_index) == 0
+            assert np.array_equal(pt.read_framebuffer(), want[f]), (f, rank)
+    for scene, pt, split in ranks:
+        pt.close(); scene.close()
+    # and through the helper the frame loop of a rank uses (one rank: the gather is a copy)
+    scene, pt = make_pathtracer(grt, "cornellbox", W, H, 0, num_bounces=4, enable_svgf=1, enable_taa=1)
+    split = parallel.SvgfTileSplit(0, 1, W, H)
+    assert lib.rt_set_pixel_tiles(pt.ctx, split.tile_pixels, 0, 1) == 0
+    for f in range(5):
+        if f:
+            scene.set_camera(*camera_of(f)); pt.update()
+        split.render_frame(grt, pt.ctx, pt.sample_index)
+        assert np.array_equal(pt.read_framebuffer(), want[f]), f
+    pt.close(); scene.close()
