@@ -129,12 +129,58 @@ def cpu_baseline(grt, pt, scene):
     return out
 
 
+def pmc_section(args, rays_per_step, launch_ms, plan):
+    """roofline.traffic and the counters the scope table asks for next to the fraction, from rocprofv3 --pmc
+    passes over this very command (tools/pmc_pass.py). Everything is per traversal launch of the timed region, like `achieved`."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_pass
+    passes = pmc_pass.run_passes(args.steps, args.warmup)
+    kernels = passes["kernels"]
+    out = {"pmc_errors": passes["errors"]} if passes["errors"] else {}
+    trace = kernels.get("kernel_trace_stream_bvh8")
+    if not trace:
+        return dict(out, traffic=None)
+    # what the child rendered with the non-counting traversal kernel: warm-up, the two profiled frames, the timed plan
+    steps_rendered = max(args.warmup, SPP) + 2 * SPP + args.steps
+    launches_timed = max(len(launch_ms), 1)
+    scale = args.steps / steps_rendered / launches_timed     # sums over the child -> per launch of the timed region
+    read_probe, generate = kernels.get("kernel_stream_read"), kernels.get("kernel_generate_stream")
+    fetch_factor = write_factor = None
+    if "FETCH_SIZE" in trace and read_probe and read_probe.get("FETCH_SIZE", [0, 0])[1] > 0:
+        fetch_factor = (read_probe["FETCH_SIZE"][0] * float(1 << 30)) / (read_probe["FETCH_SIZE"][1] * 1024.0)   # known bytes / counted bytes
+    if "WRITE_SIZE" in trace and generate and generate.get("WRITE_SIZE", [0, 0])[1] > 0:
+        primary_rays = WIDTH * HEIGHT * steps_rendered
+        write_factor = (28.0 * primary_rays) / (generate["WRITE_SIZE"][1] * 1024.0)
+    if fetch_factor and write_factor:
+        read_bytes = trace["FETCH_SIZE"][1] * 1024.0 * fetch_factor * scale
+        written_bytes = trace["WRITE_SIZE"][1] * 1024.0 * write_factor * scale
+        out["traffic"] = round(read_bytes + written_bytes)
+        out["traffic_detail"] = {"hbm_read_bytes_per_launch": round(read_bytes), "hbm_written_bytes_per_launch": round(written_bytes),
+                                 "fetch_size_calibration": round(fetch_factor, 3), "write_size_calibration": round(write_factor, 3),
+                                 "hbm_gbps_during_traversal": round((read_bytes + written_bytes) / (float(np.mean(launch_ms)) * 1e-3) / 1e9, 1) if len(launch_ms) else None,
+                                 "note": "L2 memory-side requests (Infinity-Cache hits included) of all traversal launches of a rocprofv3 --pmc re-run of this command, scaled to one launch of the timed region; FETCH_SIZE / WRITE_SIZE calibrated in that run on kernel_stream_read (1 GiB) and kernel_generate_stream (28 B per primary ray)"}
+    else:
+        out["traffic"] = None
+    if "SQ_INSTS_VALU" in trace and "SQ_THREAD_CYCLES_VALU" in trace and trace["SQ_INSTS_VALU"][1] > 0:
+        c = {k: v[1] for k, v in trace.items()}
+        counters = {"valu_lane_utilisation": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 3)}
+        if c.get("SQ_WAVE_CYCLES"):
+            counters["wave_cycles_waiting"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)
+            counters["wave_cycles_issuing_valu"] = round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"], 3)
+        if c.get("GRBM_GUI_ACTIVE"):   # VALUBusy of the gfx9 derived-counter definition: 4 x SQ_ACTIVE_INST_VALU / SIMDs / GPU-active cycles
+            counters["valu_busy"] = round(4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (256 * 4) / c["GRBM_GUI_ACTIVE"], 3)
+        counters["valu_thread_instructions_per_ray"] = round(c["SQ_THREAD_CYCLES_VALU"] * scale * launches_timed / args.steps / max(rays_per_step, 1.0), 1)
+        out["counters"] = counters
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)   # PerfTest BUFFER_SIZE = 32 frames (Util/PerfTest.h:9)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the hardware-counter passes (rocprofv3 --pmc re-runs of this benchmark: HBM traffic, VALU busy; N = 1 only)")
     ap.add_argument("--no-povs", action="store_true", help="skip the sweep over the reference's 9 fixed Sponza points of view (N = 1 only)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: render only rank 0's tiles of an N-GPU split on one GPU (no collective), to exercise the N > 1 code path")
     ap.add_argument("--batch", type=int, default=SPP, help="samples per pixel per submission (rt_render_samples), 1..%d" % SPP)
@@ -177,6 +223,7 @@ def main():
     scene = build_scene(grt)
     pt = grt.Pathtracer(scene, WIDTH, HEIGHT, device=local_rank)
     pt.update()
+    closed = False
     lib = grt.device_lib()
     ctx = pt.ctx
     scheduler = os.environ.get("BENCH_SCHEDULER", "merged")     # "slots": the per-submission launch chains, for comparison
@@ -420,10 +467,15 @@ def main():
             result["povs"] = {"source": "Util/PerfTest.h:30-40 (povs_sponza), 16 steps each", "per_pov": povs,
                               "ms_per_step_avg": round(float(ms_all.mean()), 3), "ms_per_step_stddev": round(float(ms_all.std()), 3),
                               "mrays_s_avg": round(float(mr_all.mean()), 1), "mrays_s_stddev": round(float(mr_all.std()), 1)}
+        if world == 1 and split_world == 1 and merged and not args.no_pmc and not os.environ.get("BENCH_PMC_CHILD"):
+            # hardware counters of the same command (separate rocprofv3 --pmc passes); this process lets go of the GPU first
+            pt.close(); scene.close(); closed = True
+            result["roofline"].update(pmc_section(args, rays_plan / args.steps, launch_ms, plan))
         print(json.dumps(result))
 
-    pt.close()
-    scene.close()
+    if not closed:
+        pt.close()
+        scene.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -37,7 +37,7 @@ struct TlasBuildArgs {
 	int      * position;             // scene index -> position
 	int      * node_count;
 	// scratch (global): boxes[count], queues 2 x count x {node, lo, hi}, per level-node records
-	TlasBox  * boxes;
+	TlasBox  * boxes, * sorted_boxes;
 	int      * queue;                // [2][count][3]
 	int      * runs;                 // [count][12]: begin[9], children, inner children, leaf children
 	int      * bases;                // [count][2]: first child node index, first leaf position
@@ -88,6 +88,10 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) kernel_build_tlas(TlasBuildA
 		}
 	}
 
+	// the boxes once more in sorted order: the runs of step 3c read consecutive memory instead of chasing the keys
+	for (int i = tid; i < n; i += RT_BUILD_THREADS) a.sorted_boxes[i] = a.boxes[int(keys[i] & 0xffffffffull)];
+	__syncthreads();
+
 	// ---- 3: breadth-first build
 	int * queue[2] = { a.queue, a.queue + 3 * size_t(n) };
 	if (tid == 0) { level_count = 1; nodes_used = 1; leaves_used = 0; queue[0][0] = 0; queue[0][1] = 0; queue[0][2] = n; }
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) kernel_build_tlas(TlasBuildA
 			const int * r = a.runs + 12 * size_t(k);
 			if (c >= r[9]) continue;
 			TlasBox box; tlas_box_empty(box);
-			for (int i = r[c]; i < r[c + 1]; i++) tlas_box_grow(box, a.boxes[int(keys[i] & 0xffffffffull)]);
+			for (int i = r[c]; i < r[c + 1]; i++) tlas_box_grow(box, a.sorted_boxes[i]);
 			a.child_boxes[8 * size_t(k) + c] = box;
 		}
 		__syncthreads();

@@ -87,7 +87,6 @@ struct SceneRing {
 #define RT_STREAM_STATS_ROW       (RT_STAT_KINDS * RT_MAX_BOUNCES)   // ints per submission
 
 struct StreamSubmission {
-	unsigned long long sequence;          // order of submission over both pipelines = order of the accumulate steps
 	int first_sample, sample_count, slot_base, ring, birth, last, paths;
 	int range_offset, range_count, tile_pixels, tile_first, tile_stride;
 };
@@ -126,16 +125,11 @@ struct rt_context {
 	std::string error;
 
 	SampleSlot slots[RT_MAX_SAMPLE_SLOTS];
-	// Two wavefronts ("pipelines") take the submissions in turns. Their traversal launches are serialised by a token (an
-	// event chain): one such launch fills the machine, two at once would only queue behind each other -- but while one
-	// pipeline traces, the sort / shade kernels of the OTHER run beside it (memory-latency-bound kernels next to a
-	// VALU-bound one), which a single chain cannot do: its sort needs its own trace to be finished.
-	PathStream path_streams[2];
-	int stream_pipelines = 2;           // 1: a single wavefront (GRT_STREAM_PIPELINES)
-	int stream_turn = 0;                // the pipeline that takes the next submission
-	unsigned long long stream_sequence = 0;
-	hipEvent_t ev_trace_token = nullptr, ev_accumulated = nullptr;
-	int last_completed_pipeline = -1;
+	// (Two such wavefronts taking the submissions in turns, their traversal launches serialised by an event chain so that
+	// one pipeline's sort / shade kernels would run beside the other's traversal, were built and measured: 3.23 ms per step
+	// against 3.02 ms with one -- the persistent traversal launch holds every wave slot of the machine until its queue is
+	// drained, nothing can start beside it. Removed; profiles/r02_two_pipelines_*.)
+	PathStream path_stream;
 	unsigned long long * stream_history = nullptr; int stream_history_rows = 0;   // pinned [ROWS][10]: trace statistics after each traversal launch
 	int scheduler = RT_SCHEDULER_MERGED;
 	bool last_render_merged = false;
@@ -228,9 +222,9 @@ static hipError_t stream_flush(rt_context * ctx);
 static void stream_destroy(rt_context * ctx);
 static void stream_release_frames(rt_context * ctx);
 static hipError_t quiesce(rt_context * ctx) {
-	{
-		hipError_t e = stream_flush(ctx); if (e != hipSuccess) return e;
-		for (PathStream & s : ctx->path_streams) if (s.created) { e = hipStreamSynchronize(s.stream); if (e != hipSuccess) return e; }
+	if (ctx->path_stream.created) {
+		hipError_t e = stream_flush(ctx);                            if (e != hipSuccess) return e;
+		e = hipStreamSynchronize(ctx->path_stream.stream);           if (e != hipSuccess) return e;
 	}
 	for (SampleSlot & slot : ctx->slots) if (slot.created) {
 		hipError_t e = hipStreamSynchronize(slot.side);   if (e != hipSuccess) return e;
@@ -241,8 +235,10 @@ static hipError_t quiesce(rt_context * ctx) {
 
 // Main-stream work that reads or writes frame results is ordered after every sample already submitted.
 static hipError_t main_waits_for_samples(rt_context * ctx) {
-	if (!ctx->frame_pipelining) { hipError_t e = stream_flush(ctx); if (e != hipSuccess) return e; }
-	for (PathStream & s : ctx->path_streams) if (s.created) { hipError_t e = hipStreamWaitEvent(ctx->stream, s.ev_idle, 0); if (e != hipSuccess) return e; }
+	if (ctx->path_stream.created) {
+		if (!ctx->frame_pipelining) { hipError_t e = stream_flush(ctx); if (e != hipSuccess) return e; }
+		hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->path_stream.ev_idle, 0); if (e != hipSuccess) return e;
+	}
 	for (SampleSlot & slot : ctx->slots) if (slot.created) {
 		hipError_t e = hipStreamWaitEvent(ctx->stream, slot.ev_done, 0); if (e != hipSuccess) return e;
 	}
@@ -306,7 +302,7 @@ static RtParams slot_params(const rt_context * ctx, const SampleSlot & slot, int
 static int ring_begin(rt_context * ctx, SceneRing & ring, size_t bytes, int SampleSlot::* which, void ** staging) {
 	if (bytes == 0) bytes = 16;
 	// a launch of the merged wavefront traces the rays of every submission in flight against ONE scene version
-	RT_HIP(ctx, stream_flush(ctx));
+	if (ctx->path_stream.created) RT_HIP(ctx, stream_flush(ctx));
 	if (bytes > ring.capacity) { // first use, or the scene outgrew the ring: start over (the only case that drains)
 		RT_HIP(ctx, quiesce(ctx));
 		size_t capacity = bytes + bytes / 2 + 256; // a TLAS changes its node count a little from frame to frame
@@ -373,7 +369,6 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 	if (const char * e = getenv("GRT_SAMPLES_IN_FLIGHT")) { int n = atoi(e); if (n >= 1 && n <= RT_MAX_SAMPLE_SLOTS) ctx->samples_in_flight = n; }
 	if (const char * e = getenv("GRT_OVERLAP_SHADOWS")) ctx->overlap_shadows = atoi(e) != 0;
 	if (const char * e = getenv("GRT_SCHEDULER")) ctx->scheduler = strcmp(e, "slots") == 0 ? RT_SCHEDULER_SLOTS : RT_SCHEDULER_MERGED;
-	if (const char * e = getenv("GRT_STREAM_PIPELINES")) ctx->stream_pipelines = atoi(e) == 1 ? 1 : 2;
 
 	int s = ensure_slot(ctx, 0); if (s) return s;
 	s = device_alloc(ctx, (void **)&ctx->explicit_retired, 8 * sizeof(int)); if (s) return s;
@@ -548,7 +543,7 @@ struct TlasBuildArgs { // must match kernels_build.hip
 	uint32_t * nodes; int * out_root_indices, * out_material_ids;
 	float4 * out_transforms, * out_transforms_inv, * out_transforms_prev;
 	int * order; int * position; int * node_count;
-	TlasBox * boxes; int * queue; int * runs; int * bases; TlasBox * child_boxes;
+	TlasBox * boxes, * sorted_boxes; int * queue; int * runs; int * bases; TlasBox * child_boxes;
 };
 extern "C" {
 
@@ -568,7 +563,7 @@ int rt_build_tlas(rt_context * ctx, const int32_t * root_indices, const int32_t 
 	const size_t inputs_begin = at;
 	region(padded * 4); region(padded * 4); region(n * 48); region(n * 48); region(n * 48); region(n * 24); // 8..13 in
 	const size_t inputs_end = at;
-	region(n * 24); region(n * 24); region(n * 48); region(n * 8); region(n * 192);            // 14..18 scratch: boxes, queues, runs, bases, child boxes
+	region(n * 24); region(n * 24); region(n * 48); region(n * 8); region(n * 192); region(n * 24); // 14..19 scratch: boxes, queues, runs, bases, child boxes, boxes in sorted order
 	void * staging = nullptr;
 	int s = ring_begin(ctx, ctx->instance_ring, at, &SampleSlot::instance_version, &staging); if (s) return s;
 	const void * src[6] = { root_indices, material_ids, transforms, transforms_inv, transforms_prev, local_boxes };
@@ -589,7 +584,7 @@ int rt_build_tlas(rt_context * ctx, const int32_t * root_indices, const int32_t 
 	a.out_root_indices = (int *)(base + offset[0]); a.out_material_ids = (int *)(base + offset[1]);
 	a.out_transforms = (float4 *)(base + offset[2]); a.out_transforms_inv = (float4 *)(base + offset[3]); a.out_transforms_prev = (float4 *)(base + offset[4]);
 	a.position = (int *)(base + offset[5]); a.order = (int *)(base + offset[6]); a.node_count = (int *)(base + offset[7]);
-	a.boxes = (TlasBox *)(base + offset[14]); a.queue = (int *)(base + offset[15]); a.runs = (int *)(base + offset[16]); a.bases = (int *)(base + offset[17]); a.child_boxes = (TlasBox *)(base + offset[18]);
+	a.boxes = (TlasBox *)(base + offset[14]); a.queue = (int *)(base + offset[15]); a.runs = (int *)(base + offset[16]); a.bases = (int *)(base + offset[17]); a.child_boxes = (TlasBox *)(base + offset[18]); a.sorted_boxes = (TlasBox *)(base + offset[19]);
 	rt_launch_build_tlas(a, ctx->stream);
 	RT_HIP(ctx, hipGetLastError());
 	RT_HIP(ctx, hipEventRecord(ctx->instance_ring.copied[ctx->instance_ring.current], ctx->stream));
@@ -921,7 +916,7 @@ int rt_set_config(rt_context * ctx, const rt_gpu_config * config) {
 	RT_REQUIRE(ctx, config->num_bounces >= 0 && config->num_bounces <= RT_MAX_BOUNCES, "rt_set_config: num_bounces out of range");
 	RT_REQUIRE(ctx, config->num_atrous_iterations >= 0 && config->num_atrous_iterations <= RT_MAX_ATROUS_ITERATIONS, "rt_set_config: num_atrous_iterations out of range");
 	(void)hipSetDevice(ctx->device);
-	if (memcmp(&ctx->params.config, config, sizeof(*config)) != 0) RT_HIP(ctx, stream_flush(ctx)); // the submissions in flight were made under the old settings
+	if (ctx->path_stream.created && memcmp(&ctx->params.config, config, sizeof(*config)) != 0) RT_HIP(ctx, stream_flush(ctx)); // the submissions in flight were made under the old settings
 	ctx->params.config = *config;
 	ctx->params.config.aov_mask |= 1u << RT_AOV_RADIANCE;
 	if (config->enable_svgf) ctx->params.config.aov_mask |= (1u << RT_AOV_RADIANCE_DIRECT) | (1u << RT_AOV_RADIANCE_INDIRECT) | (1u << RT_AOV_ALBEDO);
@@ -1165,13 +1160,10 @@ __global__ void kernel_accumulate_counters(const RtBufferSizes * sizes, int * to
 
 // ---- merged wavefront: host side ---------------------------------------------------------------------------------
 
-static int stream_create(rt_context * ctx, PathStream & s) {
+static int stream_create(rt_context * ctx) {
+	PathStream & s = ctx->path_stream;
 	if (s.created) return RT_OK;
-	if (!ctx->ev_trace_token) {
-		RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_trace_token, hipEventDisableTiming)); RT_HIP(ctx, hipEventRecord(ctx->ev_trace_token, ctx->stream));
-		RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_accumulated, hipEventDisableTiming)); RT_HIP(ctx, hipEventRecord(ctx->ev_accumulated, ctx->stream));
-		RT_HIP(ctx, hipHostMalloc((void **)&ctx->stream_history, sizeof(unsigned long long) * 10 * RT_STREAM_HISTORY_ROWS));
-	}
+	if (!ctx->stream_history) RT_HIP(ctx, hipHostMalloc((void **)&ctx->stream_history, sizeof(unsigned long long) * 10 * RT_STREAM_HISTORY_ROWS));
 	memset(s.trace, 0, sizeof(s.trace)); memset(s.material, 0, sizeof(s.material)); memset(&s.shadow, 0, sizeof(s.shadow));
 	RT_HIP(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
 	RT_HIP(ctx, hipEventCreateWithFlags(&s.ev_idle, hipEventDisableTiming));
@@ -1195,7 +1187,9 @@ static int stream_create(rt_context * ctx, PathStream & s) {
 	return RT_OK;
 }
 
-static void stream_destroy_one(PathStream & s) {
+static void stream_destroy(rt_context * ctx) {
+	PathStream & s = ctx->path_stream;
+	if (ctx->stream_history) { (void)hipHostFree(ctx->stream_history); ctx->stream_history = nullptr; }
 	if (!s.stream) return;
 	if (s.table_staging) (void)hipHostFree(s.table_staging);
 	if (s.progress)      (void)hipHostFree(s.progress);
@@ -1208,22 +1202,17 @@ static void stream_destroy_one(PathStream & s) {
 	(void)hipStreamDestroy(s.stream);
 	s.stream = nullptr; s.created = false;
 }
-static void stream_destroy(rt_context * ctx) {
-	for (PathStream & s : ctx->path_streams) stream_destroy_one(s);
-	if (ctx->stream_history) { (void)hipHostFree(ctx->stream_history); ctx->stream_history = nullptr; }
-	if (ctx->ev_trace_token) { (void)hipEventDestroy(ctx->ev_trace_token); ctx->ev_trace_token = nullptr; }
-	if (ctx->ev_accumulated) { (void)hipEventDestroy(ctx->ev_accumulated); ctx->ev_accumulated = nullptr; }
-}
+
 
 // The per-sample frames of the sample slots (they are freed with the frame resources: rt_resize, AOV changes).
 static void stream_release_frames(rt_context * ctx) {
-	for (PathStream & s : ctx->path_streams) {
-		for (void * & fb : s.aov_framebuffer) { device_free(ctx, fb); fb = nullptr; }
-		s.frame_slots = 0;
-	}
+	PathStream & s = ctx->path_stream;
+	for (void * & fb : s.aov_framebuffer) { device_free(ctx, fb); fb = nullptr; }
+	s.frame_slots = 0;
 }
 
-static int stream_ensure_frames(rt_context * ctx, PathStream & s, int wanted_slots) {
+static int stream_ensure_frames(rt_context * ctx, int wanted_slots) {
+	PathStream & s = ctx->path_stream;
 	int limit = int(std::min<size_t>(RT_STREAM_SAMPLE_SLOTS, ((size_t(1) << 30) - 1) / ctx->frame_pixels));
 	int slots = std::min(limit, std::max(wanted_slots, 8));
 	bool complete = s.frame_slots >= slots;
@@ -1243,7 +1232,8 @@ static int stream_ensure_frames(rt_context * ctx, PathStream & s, int wanted_slo
 	return RT_OK;
 }
 
-static int stream_ensure_queues(rt_context * ctx, PathStream & s, size_t entries) {
+static int stream_ensure_queues(rt_context * ctx, size_t entries) {
+	PathStream & s = ctx->path_stream;
 	if (s.queues_allocated && s.capacity >= entries) return RT_OK;
 	RT_HIP(ctx, quiesce(ctx));
 	auto free3 = [&](RtVec3SoA & v) { device_free(ctx, v.x); device_free(ctx, v.y); device_free(ctx, v.z); };
@@ -1286,7 +1276,8 @@ static int stream_ensure_queues(rt_context * ctx, PathStream & s, size_t entries
 
 // The parameter block of iteration `iteration`: the context's block with the stream's queues, control block and
 // per-sample frames patched in.
-static RtParams stream_params(const rt_context * ctx, const PathStream & s, int iteration) {
+static RtParams stream_params(const rt_context * ctx, int iteration) {
+	const PathStream & s = ctx->path_stream;
 	RtParams p = ctx->params;
 	memcpy(p.trace, s.trace, sizeof(p.trace)); memcpy(p.material, s.material, sizeof(p.material)); p.shadow = s.shadow;
 	p.sizes = nullptr; p.xcd_counters = nullptr; p.stack_spill = (uint2 *)s.spill;
@@ -1314,15 +1305,9 @@ static long long stream_bound(PathStream & s) {
 	return bound;
 }
 
-static int stream_enqueue_iteration(rt_context * ctx, PathStream & s, const StreamSubmission * fresh);
-static int stream_complete(rt_context * ctx, PathStream & s, const StreamSubmission & sub, const RtParams & p) {
+static int stream_complete(rt_context * ctx, const StreamSubmission & sub, const RtParams & p) {
+	PathStream & s = ctx->path_stream;
 	hipStream_t st = s.stream;
-	// accumulate steps run in submission order over both pipelines: an earlier submission of the other pipeline goes first
-	PathStream & other = ctx->path_streams[&s == &ctx->path_streams[0] ? 1 : 0];
-	while (other.created && !other.in_flight.empty() && other.in_flight.front().sequence < sub.sequence) {
-		int status = stream_enqueue_iteration(ctx, other, nullptr); if (status) return status;
-	}
-	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_accumulated, 0));
 	// the accumulate step follows the main-stream work submitted so far (rt_pack_pixels of an earlier frame reads,
 	// rt_unpack_pixels writes the image)
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
@@ -1338,8 +1323,6 @@ static int stream_complete(rt_context * ctx, PathStream & s, const StreamSubmiss
 	RT_HIP(ctx, hipMemcpyAsync(s.stats_host + size_t(sub.ring) * RT_STREAM_STATS_ROW, &s.control->stats[sub.ring][0][0], sizeof(int) * RT_STREAM_STATS_ROW, hipMemcpyDeviceToHost, st));
 	RT_HIP(ctx, hipEventRecord(s.ev_end[sub.ring], st));
 	RT_HIP(ctx, hipEventRecord(s.ev_idle, st));
-	RT_HIP(ctx, hipEventRecord(ctx->ev_accumulated, st));
-	ctx->last_completed_pipeline = int(&s - &ctx->path_streams[0]);
 	for (int k = 0; k < sub.sample_count; k++) s.slot_used[sub.slot_base + k] = false;
 	s.last_completed_ring = sub.ring;
 	s.submissions_completed++;
@@ -1348,11 +1331,12 @@ static int stream_complete(rt_context * ctx, PathStream & s, const StreamSubmiss
 
 // One iteration of the wavefront: [generate the rays of `fresh`] -> advance -> fused trace -> sort -> shade, then the
 // accumulate step of every submission that has just passed its last bounce.
-static int stream_enqueue_iteration(rt_context * ctx, PathStream & s, const StreamSubmission * fresh) {
+static int stream_enqueue_iteration(rt_context * ctx, const StreamSubmission * fresh) {
+	PathStream & s = ctx->path_stream;
 	const int i = s.iteration;
 	hipStream_t st = s.stream;
 	if (i - RT_STREAM_RUN_AHEAD >= 0) RT_HIP(ctx, hipEventSynchronize(s.iteration_done[(i - RT_STREAM_RUN_AHEAD) % RT_STREAM_PROGRESS_RING]));
-	RtParams p = stream_params(ctx, s, i);
+	RtParams p = stream_params(ctx, i);
 	if (fresh) {
 		RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));  // asynchronous scene uploads (they flush the wavefront first)
 		RtParams pg = p;
@@ -1365,14 +1349,12 @@ static int stream_enqueue_iteration(rt_context * ctx, PathStream & s, const Stre
 	rt_launch_stream_advance(s.control, i, fresh ? fresh->paths : 0, s.progress + 2 * (i % RT_STREAM_PROGRESS_RING), st);
 	s.generated[i % RT_STREAM_PROGRESS_RING] = fresh ? fresh->paths : 0;
 	RT_HIP(ctx, hipEventRecord(s.iteration_done[i % RT_STREAM_PROGRESS_RING], st));
-	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_trace_token, 0));   // one traversal launch at a time over both pipelines
 	stage_mark(ctx, STAGE_TRACE, st);
 	span_mark(ctx, STAGE_TRACE, st);
 	rt_launch_trace_stream(p, ctx->trace_statistics ? ctx->trace_stats : nullptr, st);
 	span_mark(ctx, STAGE_TRACE, st);
 	if (ctx->trace_statistics && ctx->stream_history_rows < RT_STREAM_HISTORY_ROWS)
 		RT_HIP(ctx, hipMemcpyAsync(ctx->stream_history + size_t(10) * ctx->stream_history_rows++, ctx->trace_stats, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-	RT_HIP(ctx, hipEventRecord(ctx->ev_trace_token, st));
 	stage_mark(ctx, STAGE_SORT, st);
 	rt_launch_sort_stream(p, st);
 	stage_mark(ctx, STAGE_SHADE, st);
@@ -1380,7 +1362,7 @@ static int stream_enqueue_iteration(rt_context * ctx, PathStream & s, const Stre
 	stage_mark(ctx, STAGE_END, st);
 	s.iteration = i + 1;
 	while (!s.in_flight.empty() && s.in_flight.front().last <= i) {
-		int status = stream_complete(ctx, s, s.in_flight.front(), p); if (status) return status;
+		int status = stream_complete(ctx, s.in_flight.front(), p); if (status) return status;
 		s.in_flight.pop_front();
 	}
 	if (s.in_flight.empty()) s.base_iteration = s.iteration;
@@ -1389,33 +1371,23 @@ static int stream_enqueue_iteration(rt_context * ctx, PathStream & s, const Stre
 }
 
 // Runs the wavefront until nothing is in flight (the calls that read results or change state need that).
-// The pipeline whose oldest submission is the oldest overall (null: nothing in flight)
-static PathStream * stream_oldest(rt_context * ctx) {
-	PathStream * oldest = nullptr;
-	for (PathStream & s : ctx->path_streams) if (s.created && !s.in_flight.empty() && (!oldest || s.in_flight.front().sequence < oldest->in_flight.front().sequence)) oldest = &s;
-	return oldest;
-}
 static hipError_t stream_flush(rt_context * ctx) {
-	while (PathStream * s = stream_oldest(ctx)) if (stream_enqueue_iteration(ctx, *s, nullptr) != RT_OK) return hipErrorUnknown;
+	PathStream & s = ctx->path_stream;
+	while (s.created && !s.in_flight.empty()) if (stream_enqueue_iteration(ctx, nullptr) != RT_OK) return hipErrorUnknown;
 	return hipSuccess;
 }
 
 // rt_render_samples under RT_SCHEDULER_MERGED
 static int stream_submit(rt_context * ctx, int sample_index, int sample_count, int range_offset, int range_count) {
-	// per-stage profiling measures one chain: a single pipeline while it is on
-	const int pipelines = ctx->profiling ? 1 : ctx->stream_pipelines;
-	if (pipelines == 1 && ctx->path_streams[1].created && !ctx->path_streams[1].in_flight.empty()) RT_HIP(ctx, stream_flush(ctx));
-	if (ctx->stream_turn >= pipelines) ctx->stream_turn = 0;
-	PathStream & s = ctx->path_streams[ctx->stream_turn];
-	ctx->stream_turn = (ctx->stream_turn + 1) % pipelines;
-	int status = stream_create(ctx, s); if (status) return status;
+	int status = stream_create(ctx); if (status) return status;
+	PathStream & s = ctx->path_stream;
 	const int num_bounces = ctx->params.config.num_bounces;
-	status = stream_ensure_frames(ctx, s, sample_count * (num_bounces + 1)); if (status) return status;
+	status = stream_ensure_frames(ctx, sample_count * (num_bounces + 1)); if (status) return status;
 	if (sample_count > s.frame_slots) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_samples: %d samples of a %zu pixel frame exceed the %d sample slots of the merged wavefront", sample_count, ctx->frame_pixels, s.frame_slots);
 	const long long paths = (long long)range_count * sample_count;
 	if (paths <= 0) return RT_OK;
 	static const double factor = getenv("GRT_STREAM_CAPACITY_FACTOR") ? atof(getenv("GRT_STREAM_CAPACITY_FACTOR")) : 4.0;
-	if (size_t(paths) > s.capacity || !s.queues_allocated) { status = stream_ensure_queues(ctx, s, size_t(double(paths) * (factor < 1.0 ? 1.0 : factor)) + 1024); if (status) return status; }
+	if (size_t(paths) > s.capacity || !s.queues_allocated) { status = stream_ensure_queues(ctx, size_t(double(paths) * (factor < 1.0 ? 1.0 : factor)) + 1024); if (status) return status; }
 
 	// admission: sample slots, a statistics ring entry, and room in the queues
 	int slot_base = -1;
@@ -1436,11 +1408,10 @@ static int stream_submit(rt_context * ctx, int sample_index, int sample_count, i
 			continue;
 		}
 		if (s.in_flight.empty()) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_samples: the merged wavefront cannot take %lld paths (capacity %zu, %d sample slots)", paths, s.capacity, s.frame_slots);
-		status = stream_enqueue_iteration(ctx, s, nullptr); if (status) return status;   // advance without new samples: paths die, submissions complete
+		status = stream_enqueue_iteration(ctx, nullptr); if (status) return status;   // advance without new samples: paths die, submissions complete
 	}
 
 	StreamSubmission sub;
-	sub.sequence = ctx->stream_sequence++;
 	sub.first_sample = sample_index; sub.sample_count = sample_count; sub.slot_base = slot_base;
 	sub.ring = s.next_ring; s.next_ring = (s.next_ring + 1) % RT_STREAM_SUBMISSIONS;
 	sub.birth = s.iteration; sub.last = s.iteration + num_bounces - 1; sub.paths = int(paths);
@@ -1460,13 +1431,12 @@ static int stream_submit(rt_context * ctx, int sample_index, int sample_count, i
 	RT_HIP(ctx, hipMemcpyAsync(s.table_device, &s.table_staging[snapshot], sizeof(RtStreamTable), hipMemcpyHostToDevice, s.stream));
 	RT_HIP(ctx, hipEventRecord(s.table_copied[snapshot], s.stream));
 	RT_HIP(ctx, hipMemsetAsync(&s.control->stats[sub.ring][0][0], 0, sizeof(int) * RT_STREAM_STATS_ROW, s.stream));
-	if (ctx->trace_statistics && !stream_oldest(ctx)) { // statistics are per run of the wavefront
-		RT_HIP(ctx, hipStreamWaitEvent(s.stream, ctx->ev_trace_token, 0));
+	if (ctx->trace_statistics && s.in_flight.empty()) { // statistics are per run of the wavefront
 		RT_HIP(ctx, hipMemsetAsync(ctx->trace_stats, 0, 10 * sizeof(unsigned long long), s.stream));
 		ctx->stream_history_rows = 0;
 	}
 	s.in_flight.push_back(sub);
-	return stream_enqueue_iteration(ctx, s, &s.in_flight.back());
+	return stream_enqueue_iteration(ctx, &s.in_flight.back());
 }
 
 extern "C" {
@@ -1730,15 +1700,14 @@ int rt_set_samples_in_flight(rt_context * ctx, int count) {
 int rt_advance(rt_context * ctx) {
 	RT_REQUIRE(ctx, ctx, "rt_advance: NULL context");
 	(void)hipSetDevice(ctx->device);
-	PathStream * s = stream_oldest(ctx);
-	if (!s) return RT_OK;
+	if (!ctx->path_stream.created || ctx->path_stream.in_flight.empty()) return RT_OK;
 	ctx->time_this_sample = ctx->launch_timing;
-	return stream_enqueue_iteration(ctx, *s, nullptr);
+	return stream_enqueue_iteration(ctx, nullptr);
 }
 
 int rt_submissions_completed(rt_context * ctx, uint64_t * out_count) {
 	RT_REQUIRE(ctx, ctx && out_count, "rt_submissions_completed: NULL argument");
-	*out_count = ctx->path_streams[0].submissions_completed + ctx->path_streams[1].submissions_completed;
+	*out_count = ctx->path_stream.submissions_completed;
 	return RT_OK;
 }
 
@@ -1755,8 +1724,8 @@ int rt_get_counters(rt_context * ctx, rt_counters * out) {
 	RT_HIP(ctx, quiesce(ctx));
 	rt_counters c; memset(&c, 0, sizeof(c));
 	float ms = 0.0f;
-	if (ctx->last_render_merged && ctx->last_completed_pipeline >= 0) { // the last submission the merged wavefront completed
-		const PathStream & s = ctx->path_streams[ctx->last_completed_pipeline];
+	if (ctx->last_render_merged && ctx->path_stream.last_completed_ring >= 0) { // the last submission the merged wavefront completed
+		const PathStream & s = ctx->path_stream;
 		const int * row = s.stats_host + size_t(s.last_completed_ring) * RT_STREAM_STATS_ROW;
 		memcpy(c.trace,      row + RT_STAT_TRACE      * RT_MAX_BOUNCES, sizeof(c.trace));
 		memcpy(c.shadow,     row + RT_STAT_SHADOW     * RT_MAX_BOUNCES, sizeof(c.shadow));
