@@ -167,8 +167,10 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
         if c.get("SQ_WAVE_CYCLES"):
             counters["wave_cycles_waiting"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)
             counters["wave_cycles_issuing_valu"] = round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"], 3)
-        if c.get("GRBM_GUI_ACTIVE"):   # VALUBusy of the gfx9 derived-counter definition: 4 x SQ_ACTIVE_INST_VALU / SIMDs / GPU-active cycles
-            counters["valu_busy"] = round(4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (256 * 4) / c["GRBM_GUI_ACTIVE"], 3)
+        if c.get("_duration_ns"):   # VALU issue per SIMD: SQ_ACTIVE_INST_VALU (quad-cycles, MI355X_MICROARCH.md) x 4 / (1024 SIMDs x kernel cycles at 2.4 GHz)
+            counters["valu_busy"] = round(4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024.0 * c["_duration_ns"] * 2.4), 3)
+            counters["valu_busy_definition"] = "4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles of the traversal launches in the counter pass, 2.4 GHz)"
+            counters["waves_resident_per_simd"] = round(4.0 * c.get("SQ_WAVE_CYCLES", 0.0) / (1024.0 * c["_duration_ns"] * 2.4), 2)
         counters["valu_thread_instructions_per_ray"] = round(c["SQ_THREAD_CYCLES_VALU"] * scale * launches_timed / args.steps / max(rays_per_step, 1.0), 1)
         out["counters"] = counters
     return out

@@ -50,10 +50,11 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) kernel_build_tlas(TlasBuildA
 	__shared__ TlasBox scene;
 	__shared__ int level_count, next_count, nodes_used, leaves_used;
 	const int tid = threadIdx.x, n = a.count;
+	const int threads = int(blockDim.x);   // 256 for small scenes (cheaper barriers), RT_BUILD_THREADS beyond
 
 	// ---- 1: instance boxes, scene box
 	TlasBox mine; tlas_box_empty(mine);
-	for (int i = tid; i < n; i += RT_BUILD_THREADS) {
+	for (int i = tid; i < n; i += threads) {
 		TlasBox box = tlas_world_box((const float *)(a.transforms + 3 * size_t(i)), a.local_boxes + 6 * size_t(i), a.local_boxes + 6 * size_t(i) + 3);
 		a.boxes[i] = box;
 		tlas_box_grow(mine, box);
@@ -66,17 +67,17 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) kernel_build_tlas(TlasBuildA
 	__syncthreads();
 	if (tid == 0) {
 		tlas_box_empty(scene);
-		for (int w = 0; w < RT_BUILD_THREADS / RT_WAVE_SIZE; w++) for (int d = 0; d < 3; d++) { scene.min[d] = fminf(scene.min[d], reduce[w][d]); scene.max[d] = fmaxf(scene.max[d], reduce[w][3 + d]); }
+		for (int w = 0; w < threads / RT_WAVE_SIZE; w++) for (int d = 0; d < 3; d++) { scene.min[d] = fminf(scene.min[d], reduce[w][d]); scene.max[d] = fmaxf(scene.max[d], reduce[w][3 + d]); }
 	}
 	__syncthreads();
 
 	// ---- 2: Morton keys, bitonic sort (padded with the largest key to a power of two)
 	int padded = 1; while (padded < n) padded <<= 1;
-	for (int i = tid; i < padded; i += RT_BUILD_THREADS) keys[i] = i < n ? (uint64_t(tlas_morton(a.boxes[i], scene)) << 32) | uint64_t(i) : ~0ull;
+	for (int i = tid; i < padded; i += threads) keys[i] = i < n ? (uint64_t(tlas_morton(a.boxes[i], scene)) << 32) | uint64_t(i) : ~0ull;
 	__syncthreads();
 	for (int size = 2; size <= padded; size <<= 1) {
 		for (int stride = size >> 1; stride > 0; stride >>= 1) {
-			for (int i = tid; i < padded; i += RT_BUILD_THREADS) {
+			for (int i = tid; i < padded; i += threads) {
 				int partner = i ^ stride;
 				if (partner > i) {
 					bool ascending = (i & size) == 0;
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) kernel_build_tlas(TlasBuildA
 	}
 
 	// the boxes once more in sorted order: the runs of step 3c read consecutive memory instead of chasing the keys
-	for (int i = tid; i < n; i += RT_BUILD_THREADS) a.sorted_boxes[i] = a.boxes[int(keys[i] & 0xffffffffull)];
+	for (int i = tid; i < n; i += threads) a.sorted_boxes[i] = a.boxes[int(keys[i] & 0xffffffffull)];
 	__syncthreads();
 
 	// ---- 3: breadth-first build
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) kernel_build_tlas(TlasBuildA
 		const int * in = queue[level & 1]; int * out = queue[(level + 1) & 1];
 		const int count = level_count;
 		// a) child runs
-		for (int k = tid; k < count; k += RT_BUILD_THREADS) {
+		for (int k = tid; k < count; k += threads) {
 			int begin[9];
 			int children = tlas_child_runs(keys, in[3 * k + 1], in[3 * k + 2], begin);
 			int inner = 0;
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) kernel_build_tlas(TlasBuildA
 			nodes_used = node_base; leaves_used = leaf_base;
 		}
 		// c) child boxes
-		for (int t = tid; t < 8 * count; t += RT_BUILD_THREADS) {
+		for (int t = tid; t < 8 * count; t += threads) {
 			int k = t >> 3, c = t & 7;
 			const int * r = a.runs + 12 * size_t(k);
 			if (c >= r[9]) continue;
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) kernel_build_tlas(TlasBuildA
 		}
 		__syncthreads();
 		// d) slots, node, leaf order, next level
-		for (int k = tid; k < count; k += RT_BUILD_THREADS) {
+		for (int k = tid; k < count; k += threads) {
 			const int * r = a.runs + 12 * size_t(k);
 			const int children = r[9];
 			TlasBox node; tlas_box_empty(node);
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) kernel_build_tlas(TlasBuildA
 
 	// ---- 4: the per-instance tables in TLAS order
 	if (tid == 0) *a.node_count = nodes_used;
-	for (int pos = tid; pos < n; pos += RT_BUILD_THREADS) {
+	for (int pos = tid; pos < n; pos += threads) {
 		int src = a.order[pos];
 		a.position[src] = pos;
 		a.out_root_indices[pos] = a.root_indices[src];
@@ -183,5 +184,5 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) kernel_build_tlas(TlasBuildA
 }
 
 void rt_launch_build_tlas(const TlasBuildArgs & args, hipStream_t stream) {
-	hipLaunchKernelGGL(kernel_build_tlas, dim3(1), dim3(RT_BUILD_THREADS), 0, stream, args);
+	hipLaunchKernelGGL(kernel_build_tlas, dim3(1), dim3(args.count <= 1024 ? 256 : RT_BUILD_THREADS), 0, stream, args);
 }

@@ -254,6 +254,35 @@ RT_DEV bool triangle_test_loaded(float4 part_0, float4 part_1, float4 part_2, in
 	return false;
 }
 
+// The same test with the ray kind decided per lane (the mixed engine of the merged wavefront); with a compile-time
+// constant `shadow` it folds to triangle_test_loaded<SHADOW>.
+RT_DEV bool triangle_test_kind(bool shadow, float4 part_0, float4 part_1, float4 part_2, int mesh_id, int triangle_id, const Ray3 & ray, float max_distance, HitRecord & hit) {
+	f3 p0 = mk3(part_0.x, part_0.y, part_0.z);
+	f3 e1 = mk3(part_0.w, part_1.x, part_1.y);
+	f3 e2 = mk3(part_1.z, part_1.w, part_2.x);
+
+	f3 h = cross_fma(ray.direction, e2);
+	float a = dot_fma(e1, h);
+	float f = 1.0f / a;
+	f3 s = ray.origin - p0;
+	float u = f * dot_fma(s, h);
+	if (u >= 0.0f && u <= 1.0f) {
+		f3 q = cross_fma(s, e1);
+		float v = f * dot_fma(ray.direction, q);
+		if (v >= 0.0f && u + v <= 1.0f) {
+			float t = f * dot_fma(e2, q);
+			if (shadow) {
+				if (t > 0.0f && t < max_distance) return true;
+			} else if (t > 0.0f && t < hit.t) {
+				hit.t = t; hit.u = u; hit.v = v;
+				hit.mesh_id = mesh_id;
+				hit.triangle_id = triangle_id;
+			}
+		}
+	}
+	return false;
+}
+
 template<bool SHADOW>
 RT_DEV bool triangle_test(const float4 * __restrict__ triangle_positions, int mesh_id, int triangle_id, const Ray3 & ray, float max_distance, HitRecord & hit) {
 	// traversal reads the positions-only copy (48 B stride): half the cache footprint of the
@@ -309,8 +338,24 @@ __shared__ int   shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4]; // per wave: ne
 // COUNT adds per-ray work counters (nodes fetched, triangles tested, instance entries) that are
 // flushed with atomics when a ray retires; it exists to MEASURE the algorithmic bytes of a launch
 // (rt_set_trace_statistics) and is never used in a timed frame.
-template<bool SHADOW, bool COUNT, bool NARROW, typename Source>
-RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr) {
+// MODE: RT_TRACE_CLOSEST / RT_TRACE_SHADOW (one queue, the kind is a compile-time constant), or RT_TRACE_MIXED -- the fused
+// launch of the merged wavefront: the closest-hit queue first, then the shadow queue (ray_count_2, cursor_2), with the kind
+// of a ray a PER-LANE value: a lane that finds the closest-hit queue drained takes a shadow ray at once instead of idling
+// until the longest closest-hit ray of its wave is done (two engine calls one after the other did that: every wave ended
+// its first phase at a few lanes' occupancy). The source of a mixed launch takes the kind as first argument.
+enum { RT_TRACE_CLOSEST = 0, RT_TRACE_SHADOW = 1, RT_TRACE_MIXED = 2 };
+template<int MODE, typename Source> RT_DEV void source_load(const Source & src, bool shadow, int i, Ray3 & ray, float & max_distance) {
+	if constexpr (MODE == RT_TRACE_MIXED) src.load(shadow, i, ray, max_distance); else src.load(i, ray, max_distance);
+}
+template<int MODE, typename Source> RT_DEV void source_finish(const Source & src, bool shadow, int i, const HitRecord & hit, bool occluded) {
+	if constexpr (MODE == RT_TRACE_MIXED) src.finish(shadow, i, hit, occluded); else src.finish(i, hit, occluded);
+}
+
+template<int MODE, bool COUNT, bool NARROW, typename Source>
+RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr, int ray_count_2 = 0, int * cursor_2 = nullptr) {
+	constexpr bool SHADOW = MODE == RT_TRACE_SHADOW;   // the kind of every ray, unless MODE == RT_TRACE_MIXED: then lane_shadow
+	bool lane_shadow = SHADOW;
+	#define RT_IS_SHADOW (MODE == RT_TRACE_MIXED ? lane_shadow : SHADOW)
 	const float4 * __restrict__ nodes     = p.bvh8_nodes;
 	const float4 * __restrict__ triangles = p.triangle_positions;
 
@@ -328,20 +373,26 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 	// Rays per cursor atomic: up to 128 for big launches, 64 for small ones so that every wave gets work
 	// (narrow mode: 8, one ray per 8-lane group).
 	const int waves_in_grid = int(gridDim.x) * (RT_TRACE_BLOCK / RT_WAVE_SIZE);
-	const int ray_block = NARROW ? 8 : max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (ray_count / (2 * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
+	const int rays_total = ray_count + (MODE == RT_TRACE_MIXED ? ray_count_2 : 0);
+	const int ray_block = NARROW ? 8 : max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (rays_total / (2 * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
 	// Only as many waves as there are blocks take part; the rest of the (machine-sized) persistent
 	// grid leaves without touching the shared cursor.
-	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * unsigned(ray_block) >= unsigned(ray_count)) return;
+	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * unsigned(ray_block) >= unsigned(rays_total)) return;
 	// volatile: the words are written by one lane and read by OTHER lanes of the same wave with no
 	// barrier in between; without it the compiler forwards a lane's own last view of them.
 	typedef volatile __attribute__((address_space(3))) int LdsFetchWord; // typed: ds_read/ds_write, not FLAT
 	LdsFetchWord * fetch_state = (LdsFetchWord *)&shared_fetch[wave][0];
-	if (lane == 0) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[2] = 0; }
+	if (lane == 0) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[2] = 0; fetch_state[3] = 0; }
 	// Called (converged) by the lanes that need a ray; returns its index or -1 once the launch is drained.
 	// Narrow mode: whole groups call it, every lane of a group gets the group's ray.
+	// Mixed launches: fetch_state[3] says which queue the wave is claiming from (0: closest hit, 1: shadow); a wave moves on
+	// to the shadow queue when a claim on the first comes back empty, and the lanes served in one round all get that kind.
 	auto fetch_ray = [&]() -> int {
 		while (true) {
 			if (fetch_state[2]) return -1;
+			const bool second_queue = MODE == RT_TRACE_MIXED && fetch_state[3] != 0;
+			const int queue_count = second_queue ? ray_count_2 : ray_count;
+			int * const queue_cursor = second_queue ? cursor_2 : xcd_counters;
 			unsigned long long want = __ballot(1);
 			unsigned long long askers = NARROW ? (want & 0x0101010101010101ull) : want; // one per ray wanted
 			int n_want = __popcll(askers);
@@ -351,18 +402,21 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			int next = fetch_state[0], end = fetch_state[1];
 			if (next >= end) { // the same for every lane of the ballot: claim the next block
 				int base = 0;
-				if (elected) base = atomicAdd(xcd_counters, ray_block);
+				if (elected) base = atomicAdd(queue_cursor, ray_block);
 				base = __builtin_amdgcn_readfirstlane(base);
-				next = min(base, ray_count);
-				end  = min(base + ray_block, ray_count);
+				next = min(base, queue_count);
+				end  = min(base + ray_block, queue_count);
 			}
 			int give = min(n_want, end - next);
 			if (elected) {
 				fetch_state[0] = next + give;
 				fetch_state[1] = end;
-				if (next >= end) fetch_state[2] = 1;
+				if (next >= end) { // this queue is drained
+					if (MODE == RT_TRACE_MIXED && !second_queue) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[3] = 1; }
+					else fetch_state[2] = 1;
+				}
 			}
-			if (int(rank) < give) return next + int(rank);
+			if (int(rank) < give) { if (MODE == RT_TRACE_MIXED) lane_shadow = second_queue; return next + int(rank); }
 			// the block did not cover every lane: the rest goes round again (and claims a new block)
 		}
 	};
@@ -392,7 +446,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			ray_index = fetch_ray();
 			if (ray_index < 0) return;
 
-			src.load(ray_index, ray, max_distance);
+			source_load<MODE>(src, RT_IS_SHADOW, ray_index, ray, max_distance);
 			inv_dir  = reciprocal(ray.direction);
 			oct_inv4 = ray_get_octant_inv4(ray.direction);
 
@@ -424,8 +478,8 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 #ifdef RT_PHASE_STATS
 					if (COUNT && !SHADOW) { phase_node_lanes++; if (RT_PHASE_LEADER()) phase_node_execs++; }
 #endif
-					unsigned hitmask = NARROW ? group8_or(bvh8_node_intersect_child(ray, inv_dir, oct_inv4, SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, group_child))
-					                          : bvh8_node_intersect(ray, inv_dir, oct_inv4, SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
+					unsigned hitmask = NARROW ? group8_or(bvh8_node_intersect_child(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, group_child))
+					                          : bvh8_node_intersect(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
 					unsigned imask = extract_byte(__float_as_uint(n0.w), 3);
 
 					current_group .x = __float_as_uint(n1.x);
@@ -491,9 +545,9 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 						if (my_bit >= 0) {
 							my_triangle = int(triangle_group.x) + my_bit;
 							const float4 * tri = triangles + size_t(my_triangle) * 3;
-							valid = triangle_test_values(tri[0], tri[1], tri[2].x, ray, t, u, v) && t < (SHADOW ? max_distance : hit.t);
+							valid = triangle_test_values(tri[0], tri[1], tri[2].x, ray, t, u, v) && t < (RT_IS_SHADOW ? max_distance : hit.t);
 						}
-						if (SHADOW) {
+						if (RT_IS_SHADOW) {   // (a group's lanes share one ray, so the kind is uniform within the group)
 							if ((__ballot(valid) >> group_base) & 0xffull) occluded = true;
 						} else {
 							// the sequential loop keeps the smallest t and, among equal t, the triangle tested first
@@ -529,7 +583,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					for (int k = 0; k < RT_TRI_BATCH; k++) {
 						if (tri_id[k] != RT_INVALID && !occluded) {
 							if (COUNT) count_triangles++;
-							if (triangle_test_loaded<SHADOW>(tri_a[k], tri_b[k], make_float4(tri_c[k], 0.0f, 0.0f, 0.0f), mesh_id, tri_id[k], ray, max_distance, hit)) occluded = true;
+							if (triangle_test_kind(RT_IS_SHADOW, tri_a[k], tri_b[k], make_float4(tri_c[k], 0.0f, 0.0f, 0.0f), mesh_id, tri_id[k], ray, max_distance, hit)) occluded = true;
 						}
 					}
 				}
@@ -537,10 +591,11 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 
 					}
 			bool traversal_done = triangle_group.y == 0 && (current_group.y & 0xff000000u) == 0 && stack.size == 0;
-			if (COUNT && ((SHADOW && occluded) || traversal_done)) {
-				atomicAdd(&stats[0], (unsigned long long)count_nodes);     atomicAdd(&stats[1], (unsigned long long)count_triangles);
-				atomicAdd(&stats[2], (unsigned long long)count_inst_xform); atomicAdd(&stats[3], (unsigned long long)count_inst_ident);
-				atomicAdd(&stats[4], 1ull);
+			if (COUNT && ((RT_IS_SHADOW && occluded) || traversal_done)) {
+				unsigned long long * bucket = stats + (MODE == RT_TRACE_MIXED && lane_shadow ? 5 : 0);   // mixed launches: {closest x5, shadow x5}
+				atomicAdd(&bucket[0], (unsigned long long)count_nodes);     atomicAdd(&bucket[1], (unsigned long long)count_triangles);
+				atomicAdd(&bucket[2], (unsigned long long)count_inst_xform); atomicAdd(&bucket[3], (unsigned long long)count_inst_ident);
+				atomicAdd(&bucket[4], 1ull);
 				count_nodes = count_triangles = count_inst_xform = count_inst_ident = 0;
 #ifdef RT_PHASE_STATS
 				if (!SHADOW) {
@@ -550,8 +605,8 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 				}
 #endif
 			}
-			if (SHADOW && occluded) {
-				if (!NARROW || group_child == 0) src.finish(ray_index, hit, true);
+			if (RT_IS_SHADOW && occluded) {
+				if (!NARROW || group_child == 0) source_finish<MODE>(src, true, ray_index, hit, true);
 				stack.size = 0;
 				current_group.y = 0;
 				triangle_group.y = 0;
@@ -560,7 +615,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 
 			if (triangle_group.y == 0 && (current_group.y & 0xff000000u) == 0) {
 				if (stack.size == 0) {
-					if (!NARROW || group_child == 0) src.finish(ray_index, hit, false);
+					if (!NARROW || group_child == 0) source_finish<MODE>(src, RT_IS_SHADOW, ray_index, hit, false);
 					current_group.y = 0;
 					break;
 				}
@@ -568,7 +623,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					tlas_stack_size = RT_INVALID;
 					if (!mesh_has_identity_transform) {
 						float unused;
-						src.load(ray_index, ray, unused); // world-space ray again (kept in memory, not in registers)
+						source_load<MODE>(src, RT_IS_SHADOW, ray_index, ray, unused); // world-space ray again (kept in memory, not in registers)
 						inv_dir  = reciprocal(ray.direction);
 						oct_inv4 = ray_get_octant_inv4(ray.direction);
 					}
@@ -579,10 +634,14 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			iterations_lost += RT_WAVE_SIZE - __popcll(__ballot(1)) - RT_N_D;
 		} while (iterations_lost < RT_N_W);
 	}
+	#undef RT_IS_SHADOW
 }
 
 
 #define RT_TRACE_LAUNCH_WAVES RT_TRACE_WAVES_PER_SIMD
+#ifndef RT_MIXED_MAX_RAYS
+#define RT_MIXED_MAX_RAYS (10 * 1024 * 1024)   // fused launches up to this many rays mix closest-hit and shadow rays within a wave
+#endif
 #ifndef RT_NARROW_MAX_RAYS
 #define RT_NARROW_MAX_RAYS 16384   // incoherent launches up to this many rays run 8 lanes per ray (measured cross-over ~20 k rays)
 #endif
@@ -591,8 +650,8 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 // `coherent`: primary rays keep one ray per lane at any count (neighbouring lanes walk the same nodes).
 template<bool SHADOW, bool COUNT, typename Source>
 RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_count, int * cursor, unsigned long long * stats = nullptr, bool coherent = false) {
-	if (!COUNT && !coherent && ray_count <= RT_NARROW_MAX_RAYS) bvh8_trace_engine<SHADOW, false, true>(p, src, ray_count, cursor);
-	else bvh8_trace_engine<SHADOW, COUNT, false>(p, src, ray_count, cursor, stats);
+	if (!COUNT && !coherent && ray_count <= RT_NARROW_MAX_RAYS) bvh8_trace_engine<SHADOW ? RT_TRACE_SHADOW : RT_TRACE_CLOSEST, false, true>(p, src, ray_count, cursor);
+	else bvh8_trace_engine<SHADOW ? RT_TRACE_SHADOW : RT_TRACE_CLOSEST, COUNT, false>(p, src, ray_count, cursor, stats);
 }
 #define RT_TRACE_ENGINE bvh8_trace_persistent
 
@@ -1064,16 +1123,32 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_
 // both results are needed by the same next kernel (sort), so there is nothing to gain from two launches that would only
 // compete for the wave slots -- and a wave that finds the closest-hit queue drained goes straight on to shadow rays instead
 // of idling through the other waves' tails.
+struct MixedStreamSource {
+	ClosestHitSource closest; ShadowStreamSource shadow;
+	RT_DEV void load(bool is_shadow, int i, Ray3 & ray, float & max_distance) const { if (is_shadow) shadow.load(i, ray, max_distance); else closest.load(i, ray, max_distance); }
+	RT_DEV void finish(bool is_shadow, int i, const HitRecord & hit, bool occluded) const { if (is_shadow) shadow.finish(i, hit, occluded); else closest.finish(i, hit, occluded); }
+};
 template<bool COUNT>
 RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	const int q = p.stream_iteration & 1;
-	{
-		ClosestHitSource src { p.trace[q].origin, p.trace[q].direction, p.trace[q].hits };
-		RT_TRACE_ENGINE<false, COUNT>(p, src, p.stream->trace_count[q], &p.stream->cursor[q][0], stats);
-	}
-	{
-		ShadowStreamSource src { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT] };
-		RT_TRACE_ENGINE<true, COUNT>(p, src, p.stream->shadow_count[q ^ 1], &p.stream->cursor[q][1], COUNT ? stats + 5 : nullptr);
+	MixedStreamSource src { { p.trace[q].origin, p.trace[q].direction, p.trace[q].hits },
+	                        { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT] } };
+	const int closest_count = p.stream->trace_count[q], shadow_count = p.stream->shadow_count[q ^ 1];
+	// Which engine (the counts are only known on the device; the choice is uniform over the launch):
+	//   * few rays (the fill and drain iterations of the wavefront): 8 lanes per ray, see the narrow mode;
+	//   * up to RT_MIXED_MAX_RAYS: mixed kinds -- a lane that finds the closest-hit queue drained takes a shadow ray at once.
+	//     On an eighth of a 1080p frame (3.3 M rays per launch) that is +11 % (0.60 -> 0.67 of the roofline): every wave
+	//     used to end its closest-hit phase at a few lanes' occupancy;
+	//   * beyond: the two kinds one after the other. Mixing costs ~4 % of the issue slots (the kind is a per-lane value
+	//     where it was a compile-time constant) and a 25 M-ray launch has little to gain from it (0.87 -> 0.83 when mixed).
+	//   profiles/r02_mixed_engine.txt
+	if (!COUNT && closest_count + shadow_count <= RT_NARROW_MAX_RAYS)
+		bvh8_trace_engine<RT_TRACE_MIXED, false, true>(p, src, closest_count, &p.stream->cursor[q][0], nullptr, shadow_count, &p.stream->cursor[q][1]);
+	else if (COUNT || closest_count + shadow_count <= RT_MIXED_MAX_RAYS)
+		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
+	else {
+		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
+		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
 	}
 }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8(RtParams p) { trace_stream<false>(p, nullptr); }

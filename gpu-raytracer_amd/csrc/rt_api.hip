@@ -45,7 +45,6 @@ struct SampleSlot {
 	RtBufferSizes * pinned_counters = nullptr;
 	void * aov_framebuffer[RT_AOV_COUNT] = { };  // slots 1..: per-sample frame buffers (slot 0 uses ctx->aov_buffers[i][0])
 	int aov_samples = 1;                         // samples per batch the frame buffers of this slot are sized for
-	int tlas_version = -1, instance_version = -1, light_version = -1; // scene-ring versions the last submission of this slot reads
 	// SVGF g-buffers (normal+depth, mesh+triangle id, previous screen position) are written by the
 	// bounce-0 kernels of a frame and read by its filter stage: one set per slot lets frame n+1 be
 	// traced while frame n is filtered. Pixels that miss all geometry keep the value of the last
@@ -69,6 +68,11 @@ struct SceneRing {
 	size_t capacity = 0;   // bytes allocated per version (grows only)
 	size_t bytes = 0;      // bytes of the current version
 	int current = -1;
+	// Sample slots that have submitted work reading a version since it was last written. (A slot used to remember only the
+	// version of its LAST submission: with the host several frames ahead of the device, an older submission still queued
+	// on the same slot lost its claim and the ring wrapped around onto the version it was about to read -- found with 1 500
+	// moving instances and 48 frames, tools/animation_bench.py: a TLAS overwritten under a running traversal.)
+	unsigned users[RT_SCENE_VERSIONS] = { };
 };
 
 // ---- merged wavefront (RT_SCHEDULER_MERGED; the idea is described at RtStreamSlot in rt_types.h) -------------------
@@ -299,7 +303,7 @@ static RtParams slot_params(const rt_context * ctx, const SampleSlot & slot, int
 
 // Next version of a scene ring, sized `bytes`: returns its pinned staging buffer for the caller to fill;
 // ring_commit() then starts the copy. `which` selects the slot field that remembers the version in use.
-static int ring_begin(rt_context * ctx, SceneRing & ring, size_t bytes, int SampleSlot::* which, void ** staging) {
+static int ring_begin(rt_context * ctx, SceneRing & ring, size_t bytes, void ** staging) {
 	if (bytes == 0) bytes = 16;
 	// a launch of the merged wavefront traces the rays of every submission in flight against ONE scene version
 	if (ctx->path_stream.created) RT_HIP(ctx, stream_flush(ctx));
@@ -315,11 +319,13 @@ static int ring_begin(rt_context * ctx, SceneRing & ring, size_t bytes, int Samp
 		}
 		ring.capacity = capacity;
 		ring.current = -1;
-		for (SampleSlot & slot : ctx->slots) slot.*which = -1;
+		for (unsigned & users : ring.users) users = 0;
 	}
 	ring.bytes = bytes;
 	int v = (ring.current + 1) % RT_SCENE_VERSIONS;
-	for (SampleSlot & slot : ctx->slots) if (slot.created && slot.*which == v) { RT_HIP(ctx, hipEventSynchronize(slot.ev_done)); slot.*which = -1; }
+	// every submission that reads version v has passed its slot's ev_done by the time the slot's LATEST record of it completes
+	for (int k = 0; k < RT_MAX_SAMPLE_SLOTS; k++) if ((ring.users[v] >> k) & 1u) RT_HIP(ctx, hipEventSynchronize(ctx->slots[k].ev_done));
+	ring.users[v] = 0;
 	if (ring.current >= 0) RT_HIP(ctx, hipEventSynchronize(ring.copied[v])); // its previous staging copy (recorded when it was last filled)
 	*staging = ring.pinned[v];
 	ring.current = v;
@@ -442,7 +448,7 @@ int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle
 // TLAS of the selected BVH type: node_bytes = 80 (CWBVH), 32 (binary) or 128 (4-wide)
 static int upload_tlas_version(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count, size_t node_bytes) {
 	void * staging = nullptr;
-	int s = ring_begin(ctx, ctx->tlas_ring, tlas_node_count * node_bytes, &SampleSlot::tlas_version, &staging); if (s) return s;
+	int s = ring_begin(ctx, ctx->tlas_ring, tlas_node_count * node_bytes, &staging); if (s) return s;
 	memcpy(staging, tlas_nodes, tlas_node_count * node_bytes);
 	s = ring_commit(ctx, ctx->tlas_ring); if (s) return s;
 	ctx->params.tlas_nodes = (const float4 *)ctx->tlas_ring.device[ctx->tlas_ring.current];
@@ -515,7 +521,7 @@ int rt_upload_instances(rt_context * ctx, const int32_t * root_indices, const in
 	const void * src[5] = { root_indices, material_ids, transforms, transforms_inv, transforms_prev };
 	size_t bytes[5] = { mesh_count * 4, mesh_count * 4, mesh_count * 48, mesh_count * 48, mesh_count * 48 };
 	void * staging = nullptr;
-	int s = ring_begin(ctx, ctx->instance_ring, offset[5], &SampleSlot::instance_version, &staging); if (s) return s;
+	int s = ring_begin(ctx, ctx->instance_ring, offset[5], &staging); if (s) return s;
 	for (int i = 0; i < 5; i++) memcpy((char *)staging + offset[i], src[i], bytes[i]);
 	s = ring_commit(ctx, ctx->instance_ring); if (s) return s;
 	const char * base = (const char *)ctx->instance_ring.device[ctx->instance_ring.current];
@@ -565,14 +571,14 @@ int rt_build_tlas(rt_context * ctx, const int32_t * root_indices, const int32_t 
 	const size_t inputs_end = at;
 	region(n * 24); region(n * 24); region(n * 48); region(n * 8); region(n * 192); region(n * 24); // 14..19 scratch: boxes, queues, runs, bases, child boxes, boxes in sorted order
 	void * staging = nullptr;
-	int s = ring_begin(ctx, ctx->instance_ring, at, &SampleSlot::instance_version, &staging); if (s) return s;
+	int s = ring_begin(ctx, ctx->instance_ring, at, &staging); if (s) return s;
 	const void * src[6] = { root_indices, material_ids, transforms, transforms_inv, transforms_prev, local_boxes };
 	const size_t bytes[6] = { n * 4, n * 4, n * 48, n * 48, n * 48, n * 24 };
 	for (int i = 0; i < 6; i++) memcpy((char *)staging + offset[8 + i], src[i], bytes[i]);
 	char * base = (char *)ctx->instance_ring.device[ctx->instance_ring.current];
 	RT_HIP(ctx, hipMemcpyAsync(base + inputs_begin, (char *)staging + inputs_begin, inputs_end - inputs_begin, hipMemcpyHostToDevice, ctx->stream));
 	void * tlas_staging = nullptr;
-	s = ring_begin(ctx, ctx->tlas_ring, 2 * n * 80, &SampleSlot::tlas_version, &tlas_staging); if (s) return s;
+	s = ring_begin(ctx, ctx->tlas_ring, 2 * n * 80, &tlas_staging); if (s) return s;
 	void * tlas_device = ctx->tlas_ring.device[ctx->tlas_ring.current];
 
 	TlasBuildArgs a;
@@ -692,7 +698,7 @@ int rt_upload_lights(rt_context * ctx,
 	size_t offset[6] = { 0 };
 	for (int i = 0; i < 5; i++) offset[i + 1] = offset[i] + ((src[i] ? bytes[i] : 0) + 15) / 16 * 16;
 	void * staging = nullptr;
-	int s = ring_begin(ctx, ctx->light_ring, offset[5], &SampleSlot::light_version, &staging); if (s) return s;
+	int s = ring_begin(ctx, ctx->light_ring, offset[5], &staging); if (s) return s;
 	for (int i = 0; i < 5; i++) if (src[i] && bytes[i]) memcpy((char *)staging + offset[i], src[i], bytes[i]);
 	s = ring_commit(ctx, ctx->light_ring); if (s) return s;
 	const char * base = (const char *)ctx->light_ring.device[ctx->light_ring.current];
@@ -1516,7 +1522,7 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
 	// ... and it reads the scene version that is current now (asynchronous TLAS / instance uploads)
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));
-	slot.tlas_version = ctx->tlas_ring.current; slot.instance_version = ctx->instance_ring.current; slot.light_version = ctx->light_ring.current;
+	for (SceneRing * ring : { &ctx->tlas_ring, &ctx->instance_ring, &ctx->light_ring }) if (ring->current >= 0) ring->users[ring->current] |= 1u << slot_index;
 	if (exclusive) for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[k].ev_done, 0));
 
 	ctx->stage_used = 0;
@@ -1640,7 +1646,7 @@ int rt_render_ao_sample(rt_context * ctx, int sample_index, float ao_radius) {
 	hipStream_t st = slot.stream;
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
-	slot.tlas_version = ctx->tlas_ring.current; slot.instance_version = ctx->instance_ring.current; slot.light_version = ctx->light_ring.current;
+	for (SceneRing * ring : { &ctx->tlas_ring, &ctx->instance_ring, &ctx->light_ring }) if (ring->current >= 0) ring->users[ring->current] |= 1u;
 	for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[k].ev_done, 0));
 
 	RT_HIP(ctx, hipEventRecord(slot.ev_frame_start, st));

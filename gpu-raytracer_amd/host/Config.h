@@ -59,8 +59,8 @@ struct CPUConfig {
 
 	bool enable_scene_update = false;
 	// Where the TLAS is built: 0 = on the host (SAH + CWBVH conversion, byte-identical to the reference's), 1 = on the device
-	// (rt_build_tlas: one kernel launch, CWBVH only, up to 4096 instances), -1 = on the device exactly when the scene is
-	// rebuilt every frame (enable_scene_update), where the host build is the only CPU work inside the frame loop
+	// (rt_build_tlas: one kernel launch, CWBVH only, up to 4096 instances), -1 = on the device when the scene is rebuilt
+	// every frame (enable_scene_update) and has at least 1024 instances: there the host build is the CPU work inside the frame loop
 	int  device_tlas = -1;
 
 	IntegratorType integrator = IntegratorType::PATHTRACER; // read by the command-line front end

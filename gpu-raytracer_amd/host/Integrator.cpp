@@ -193,7 +193,11 @@ void Integrator::init_rng() {
 // leaf order, which is what `mesh_id` means on the device (reference: Integrator.cpp:399-430).
 bool Integrator::wants_device_tlas() const {
 	if (!ctx || cpu_config.bvh_type != BVHType::BVH8 || scene.meshes.empty() || scene.meshes.size() > 4096) return false;
-	return cpu_config.device_tlas > 0 || (cpu_config.device_tlas < 0 && cpu_config.enable_scene_update);
+	// auto: scenes that rebuild every frame AND are large enough for the host build to matter -- at 441 instances the host's
+	// SAH + CWBVH build is 0.05 ms and overlaps the GPU while the one-workgroup kernel has to find a free CU beside the
+	// persistent traversal launches (frames 3.40 -> 3.72 ms); at 4 000 instances the host's share of a frame drops from
+	// 3.5 to 1.1 ms at equal frame time (profiles/r02_animated_scene*.txt)
+	return cpu_config.device_tlas > 0 || (cpu_config.device_tlas < 0 && cpu_config.enable_scene_update && scene.meshes.size() >= 1024);
 }
 
 // The device-built TLAS as host arrays (TLAS nodes in the aggregated node array, the instance tables in TLAS order,

@@ -166,7 +166,7 @@ def test_animated_instances_do_not_drain_the_pipeline_or_mix_scene_versions(grt,
         scene = grt.Scene(str(tmp_path / "s.xml"))
         pt = grt.Pathtracer(scene, w, h, device=0); pt.update()
         grt.set_samples_in_flight(pt.ctx, in_flight)
-        for frame in range(6):
+        for frame in range(40):      # more frames than the scene ring has versions (12): it wraps around under frames in flight
             move(scene, frame); pt.invalidate("scene"); pt.update()
             assert lib.rt_render_sample(pt.ctx, frame) == 0
         images.append(pt.read_framebuffer().copy())

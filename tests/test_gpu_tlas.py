@@ -60,8 +60,8 @@ def test_device_tlas_equals_its_restatement_and_traces_like_the_host_tlas(grt, o
 
 
 def test_frames_with_a_device_tlas_match_the_oracle_while_instances_move(grt, oracle, tmp_path):
-    """enable_scene_update: every frame the instances move and Integrator::build_tlas runs -- on the device (device_tlas = -1
-    picks it for such scenes). (a) each frame against the oracle, which reads the device-built TLAS back; the light tables
+    """enable_scene_update: every frame the instances move and Integrator::build_tlas runs -- on the device (device_tlas = 1;
+    the default -1 picks it for such scenes from 1024 instances on). (a) each frame against the oracle, which reads the device-built TLAS back; the light tables
     name instances by scene index and the device maps them; (b) six frames accumulated with 1 and with 3 frames in flight
     (slot scheduler: every chain reads the TLAS version it was submitted with) are bit-identical."""
     path = instanced_scene_file(str(tmp_path / "s"), count=40)
@@ -74,7 +74,7 @@ def test_frames_with_a_device_tlas_match_the_oracle_while_instances_move(grt, or
             a = 0.35 * frame + 0.2 * m
             scene.set_mesh_transform(m, [pos[0] + 0.6 * np.sin(a), pos[1], pos[2] + 0.6 * np.cos(a)], [0.0, float(np.sin(a / 2)), 0.0, float(np.cos(a / 2))], scale)
 
-    grt.config_reset(); grt.config_set(num_bounces=3, enable_scene_update=1)
+    grt.config_reset(); grt.config_set(num_bounces=3, enable_scene_update=1, device_tlas=1)
     scene = grt.Scene(path)
     base = [scene.mesh_transform(m) for m in range(scene.mesh_count)]
     pt = grt.Pathtracer(scene, w, h, device=0); pt.update()
@@ -93,11 +93,11 @@ def test_frames_with_a_device_tlas_match_the_oracle_while_instances_move(grt, or
 
     images = []
     for in_flight in (1, 3):
-        grt.config_reset(); grt.config_set(num_bounces=3, enable_scene_update=1)
+        grt.config_reset(); grt.config_set(num_bounces=3, enable_scene_update=1, device_tlas=1)
         scene = grt.Scene(path)
         pt = grt.Pathtracer(scene, w, h, device=0); pt.update()
         grt.set_samples_in_flight(pt.ctx, in_flight)
-        for frame in range(6):
+        for frame in range(40):      # more frames than the scene ring has versions (12)
             move(scene, base, frame); pt.update()
             assert lib.rt_render_sample(pt.ctx, frame) == 0
         images.append(pt.read_framebuffer().copy())

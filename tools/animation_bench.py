@@ -16,8 +16,17 @@ import gpu_raytracer_amd as grt  # noqa: E402
 import config_suite  # noqa: E402
 
 
+def big_scene(directory, count):
+    """`count` instances of a small mesh (the TLAS build is what is being timed, not the BLAS)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_tlas import instanced_scene_file
+    return instanced_scene_file(directory, count=count, seed=11)
+
+
 def main():
-    path = config_suite.instancing_scene(os.path.join(ROOT, "assets", "_cache", "configs", "instancing"))
+    count = int(os.environ.get("ANIM_INSTANCES", "0"))
+    path = big_scene(os.path.join(ROOT, "assets", "_cache", "configs", "instances_%d" % count), count) if count else config_suite.instancing_scene(os.path.join(ROOT, "assets", "_cache", "configs", "instancing"))
+    print("scene: %s" % ("%d instances of a 256-triangle mesh" % count if count else "441 instances x 102 400 triangles"), flush=True)
     for label, device_tlas, in_flight, drain in (("host TLAS, 1 frame in flight, drained around uploads (reference protocol)", 0, 1, True), ("host TLAS, 1 frame in flight", 0, 1, False),
                                                  ("host TLAS, 3 frames in flight", 0, 3, False), ("DEVICE TLAS (rt_build_tlas), 1 frame in flight", 1, 1, False), ("DEVICE TLAS (rt_build_tlas), 3 frames in flight", 1, 3, False)):
         grt.config_reset(); grt.config_set(num_bounces=10, device_tlas=device_tlas)
@@ -28,7 +37,7 @@ def main():
         base = [scene.mesh_transform(m) for m in range(scene.mesh_count)]
 
         def animate(frame):
-            for m in range(2 + frame % 11, scene.mesh_count, 11):
+            for m in range(3 + frame % 11, scene.mesh_count, 11):
                 pos, _, scale = base[m]
                 a = 0.1 * frame + m
                 scene.set_mesh_transform(m, [pos[0], pos[1] + 0.3 * np.sin(a), pos[2]], [0.0, float(np.sin(a / 2)), 0.0, float(np.cos(a / 2))], scale)

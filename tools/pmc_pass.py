@@ -30,6 +30,14 @@ def summarise(db_path):
     rows = cur.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name").fetchall()
     for kernel, counter, n, total in rows:
         out.setdefault(kernel.split("(")[0], {})[counter] = [int(n), float(total)]
+    try:   # the time the dispatches of a kernel took in this pass (for rates per cycle), from the kernel trace of the same run
+        cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+        name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+        for kernel, n, ns in cur.execute("select %s, count(*), sum(end - start) from kernels group by %s" % (name_col, name_col)).fetchall():
+            if kernel.split("(")[0] in out:
+                out[kernel.split("(")[0]]["_duration_ns"] = [int(n), float(ns)]
+    except Exception:
+        pass
     return out
 
 
