@@ -75,7 +75,9 @@ def cpu_baseline(grt, pt, scene):
     """CPU leg (rank 0, N = 1 only): bounded sample, ~10-30 s of host work."""
     from oracle import binding as oracle  # checker only: never on the product path
     view = oracle.SceneView(pt)
-    threads = os.cpu_count() or 1
+    # threads: all logical CPUs up to 32 -- the container of a GPU box sees 256 logical CPUs but gets about 16 cores' worth
+    # (effective_parallelism below); the traversal loop peaks at 16-32 threads there (8 Mrays/s) and falls to 3.5 Mrays/s at 256
+    threads = min(os.cpu_count() or 1, 32)
     n = grt.RT_BATCH_SIZE
     o, d, _ = view.generate(0, 0, n)
     t0 = time.perf_counter()
@@ -107,18 +109,20 @@ def cpu_baseline(grt, pt, scene):
         "nodes_per_ray": [round(stats_primary.nodes / stats_primary.rays, 2), round(stats_secondary.nodes / stats_secondary.rays, 2)],
         "triangles_per_ray": [round(stats_primary.triangles / stats_primary.rays, 2), round(stats_secondary.triangles / stats_secondary.rays, 2)],
     }
-    out["effective_parallelism"] = round(oracle.effective_parallelism(threads), 1)   # of `threads` logical CPUs
-    out["note"] = "the oracle's per-ray work is ~1 us; at %d threads the OpenMP fork/join and the dynamic schedule dominate, so this is a stated baseline, not a tuned CPU tracer" % threads
+    logical = os.cpu_count() or 1
+    out["logical_cpus"] = logical
+    out["effective_parallelism"] = round(oracle.effective_parallelism(logical), 1)   # a spin loop on every logical CPU against one
+    out["note"] = "a port of the reference's device traversal run ray by ray under OpenMP: a stated baseline, not a tuned CPU tracer" 
     if oracle.ref_lib() is not None:  # the reference's own CPU path: BVH2 + BVH8 build of all 383 Sponza meshes
         scene.wait_until_loaded()
         meshes = [scene.mesh_data_array(m, "triangles", np.float32).reshape(-1, 24) for m in range(scene.mesh_data_count)]
         build = {"kind": "reference", "meshes": len(meshes), "triangles": int(sum(m.shape[0] for m in meshes)),
                  "schedule": "one job per mesh on a pool of hardware_concurrency workers, as AssetManager.cpp:57 does",
                  "product_builder_ms_parallel": round(scene.bvh_build_ms, 1)}
-        many = oracle.ref_build_many(meshes, threads)
+        many = oracle.ref_build_many(meshes, logical)   # hardware_concurrency() workers, as the reference's thread pool
         if many is not None:
             one = oracle.ref_build_many(meshes, 1)
-            build.update({"cores": threads, "ms_wall": round(many[0], 1), "ms_wall_1_thread": round(one[0], 1), "bvh2_nodes": many[1], "bvh8_nodes": many[2]})
+            build.update({"cores": logical, "ms_wall": round(many[0], 1), "ms_wall_1_thread": round(one[0], 1), "bvh2_nodes": many[1], "bvh8_nodes": many[2]})
         else:   # an oracle/_ref built before the pooled entry point existed: mesh after mesh on one core
             ms2 = ms8 = 0.0
             for m in meshes:
@@ -137,7 +141,10 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
     passes = pmc_pass.run_passes(args.steps, args.warmup)
     kernels = passes["kernels"]
     out = {"pmc_errors": passes["errors"]} if passes["errors"] else {}
-    trace = kernels.get("kernel_trace_stream_bvh8")
+    trace = {}   # the traversal launch exists in two compilations (5 and 4 waves per SIMD, picked by wavefront size): both count
+    for name in ("kernel_trace_stream_bvh8", "kernel_trace_stream_bvh8_small"):
+        for counter, (n, total) in kernels.get(name, {}).items():
+            e = trace.setdefault(counter, [0, 0.0]); e[0] += n; e[1] += total
     if not trace:
         return dict(out, traffic=None)
     # what the child rendered with the non-counting traversal kernel: warm-up, the two profiled frames, the timed plan
@@ -401,7 +408,7 @@ def main():
             big = launch_rays >= 0.5 * launch_rays.max()        # the steady-state launches (fill and drain iterations excluded)
             per_launch_gbps = launch_bytes / np.maximum(launch_ms, 1e-6) / 1e6
             roofline.update({
-                "kernel": "kernel_trace_stream_bvh8", "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "kernel": "kernel_trace_stream_bvh8 (+ its 4-waves-per-SIMD compilation kernel_trace_stream_bvh8_small for wavefronts below 6 M rays)", "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "launches": int(len(launch_ms)), "algorithmic_bytes_per_launch": round(float(launch_bytes.mean())), "avg_launch_ms": round(float(launch_ms.mean()), 4),
                 "launch_ms": spread(launch_ms), "launch_gbps": spread(per_launch_gbps),
                 "steady_state": {"launches": int(big.sum()), "achieved": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9), 1),

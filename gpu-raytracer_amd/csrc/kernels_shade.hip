@@ -12,6 +12,11 @@
 #include "rt_shading.h"
 
 #define RT_SHADE_BLOCK 256
+#ifndef RT_SHADE_WAVES
+// The material kernels wait on scattered triangle / texture / light-table reads; left alone the compiler uses 129-140 VGPRs
+// (3 waves per SIMD). Asking for 4 waves caps them at 128 registers: one more wave to hide the latency behind.
+#define RT_SHADE_WAVES 4
+#endif
 #ifndef RT_SORT_BLOCK
 #define RT_SORT_BLOCK 512   // kernel_sort: 8 waves share one atomic per material queue
 #endif
@@ -957,14 +962,14 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 	if (MERGED) stream_stats_flush(p, stats_lds);
 }
 
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_diffuse(RtParams p, int bounce, int sample_index)    { shade_material<BSDFDiffuse,    0, false>(p, bounce, sample_index); }
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_plastic(RtParams p, int bounce, int sample_index)    { shade_material<BSDFPlastic,    1, false>(p, bounce, sample_index); }
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_dielectric(RtParams p, int bounce, int sample_index) { shade_material<BSDFDielectric, 2, false>(p, bounce, sample_index); }
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_conductor(RtParams p, int bounce, int sample_index)  { shade_material<BSDFConductor,  3, false>(p, bounce, sample_index); }
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_diffuse_stream(RtParams p)    { shade_material<BSDFDiffuse,    0, true>(p, 0, 0); }
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_plastic_stream(RtParams p)    { shade_material<BSDFPlastic,    1, true>(p, 0, 0); }
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_dielectric_stream(RtParams p) { shade_material<BSDFDielectric, 2, true>(p, 0, 0); }
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_material_conductor_stream(RtParams p)  { shade_material<BSDFConductor,  3, true>(p, 0, 0); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_diffuse(RtParams p, int bounce, int sample_index)    { shade_material<BSDFDiffuse,    0, false>(p, bounce, sample_index); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_plastic(RtParams p, int bounce, int sample_index)    { shade_material<BSDFPlastic,    1, false>(p, bounce, sample_index); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_dielectric(RtParams p, int bounce, int sample_index) { shade_material<BSDFDielectric, 2, false>(p, bounce, sample_index); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_conductor(RtParams p, int bounce, int sample_index)  { shade_material<BSDFConductor,  3, false>(p, bounce, sample_index); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_diffuse_stream(RtParams p)    { shade_material<BSDFDiffuse,    0, true>(p, 0, 0); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_plastic_stream(RtParams p)    { shade_material<BSDFPlastic,    1, true>(p, 0, 0); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_dielectric_stream(RtParams p) { shade_material<BSDFDielectric, 2, true>(p, 0, 0); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_conductor_stream(RtParams p)  { shade_material<BSDFConductor,  3, true>(p, 0, 0); }
 
 // ---- ambient occlusion (CUDA/AO.cu:103-159) -------------------------------------------------------
 // One cosine-weighted occlusion ray of length ao_radius per primary hit; the AO shadow kernel sets

@@ -73,6 +73,7 @@ struct SceneRing {
 	// on the same slot lost its claim and the ring wrapped around onto the version it was about to read -- found with 1 500
 	// moving instances and 48 frames, tools/animation_bench.py: a TLAS overwritten under a running traversal.)
 	unsigned users[RT_SCENE_VERSIONS] = { };
+	hipEvent_t last_use[RT_SCENE_VERSIONS][RT_MAX_SAMPLE_SLOTS] = { }; // end of the slot's latest submission that reads the version
 };
 
 // ---- merged wavefront (RT_SCHEDULER_MERGED; the idea is described at RtStreamSlot in rt_types.h) -------------------
@@ -88,6 +89,7 @@ struct SceneRing {
 #define RT_STREAM_RUN_AHEAD       4
 #define RT_STREAM_TABLE_SNAPSHOTS 8
 #define RT_STREAM_HISTORY_ROWS    4096
+#define RT_STREAM_SMALL_WAVEFRONT  (6ll * 1024 * 1024)   // closest-hit rays: below it the traversal launch compiled for 4 waves per SIMD
 #define RT_STREAM_STATS_ROW       (RT_STAT_KINDS * RT_MAX_BOUNCES)   // ints per submission
 
 struct StreamSubmission {
@@ -323,8 +325,9 @@ static int ring_begin(rt_context * ctx, SceneRing & ring, size_t bytes, void ** 
 	}
 	ring.bytes = bytes;
 	int v = (ring.current + 1) % RT_SCENE_VERSIONS;
-	// every submission that reads version v has passed its slot's ev_done by the time the slot's LATEST record of it completes
-	for (int k = 0; k < RT_MAX_SAMPLE_SLOTS; k++) if ((ring.users[v] >> k) & 1u) RT_HIP(ctx, hipEventSynchronize(ctx->slots[k].ev_done));
+	// wait for the submissions that read version v -- for them only: a slot's ev_done is re-recorded by every later
+	// submission, waiting on it would stall the host behind the frame it has just submitted
+	for (int k = 0; k < RT_MAX_SAMPLE_SLOTS; k++) if ((ring.users[v] >> k) & 1u) RT_HIP(ctx, hipEventSynchronize(ring.last_use[v][k]));
 	ring.users[v] = 0;
 	if (ring.current >= 0) RT_HIP(ctx, hipEventSynchronize(ring.copied[v])); // its previous staging copy (recorded when it was last filled)
 	*staging = ring.pinned[v];
@@ -337,6 +340,18 @@ static int ring_commit(rt_context * ctx, SceneRing & ring) {
 	RT_HIP(ctx, hipMemcpyAsync(ring.device[v], ring.pinned[v], ring.bytes, hipMemcpyHostToDevice, ctx->stream));
 	RT_HIP(ctx, hipEventRecord(ring.copied[v], ctx->stream));
 	RT_HIP(ctx, hipEventRecord(ctx->ev_scene, ctx->stream));
+	return RT_OK;
+}
+
+// A submission on sample slot `slot_index` (stream `st`, everything enqueued) read the current version of every scene ring
+static int mark_scene_versions_in_use(rt_context * ctx, int slot_index, hipStream_t st) {
+	for (SceneRing * ring : { &ctx->tlas_ring, &ctx->instance_ring, &ctx->light_ring }) {
+		if (ring->current < 0) continue;
+		hipEvent_t & e = ring->last_use[ring->current][slot_index];
+		if (!e) RT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		RT_HIP(ctx, hipEventRecord(e, st));
+		ring->users[ring->current] |= 1u << slot_index;
+	}
 	return RT_OK;
 }
 
@@ -416,6 +431,7 @@ void rt_destroy(rt_context * ctx) {
 	for (SceneRing * ring : { &ctx->tlas_ring, &ctx->instance_ring, &ctx->light_ring }) for (int v = 0; v < RT_SCENE_VERSIONS; v++) {
 		if (ring->pinned[v]) (void)hipHostFree(ring->pinned[v]);
 		if (ring->copied[v]) (void)hipEventDestroy(ring->copied[v]);
+		for (hipEvent_t e : ring->last_use[v]) if (e) (void)hipEventDestroy(e);
 	}
 	(void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -1343,6 +1359,7 @@ static int stream_enqueue_iteration(rt_context * ctx, const StreamSubmission * f
 	hipStream_t st = s.stream;
 	if (i - RT_STREAM_RUN_AHEAD >= 0) RT_HIP(ctx, hipEventSynchronize(s.iteration_done[(i - RT_STREAM_RUN_AHEAD) % RT_STREAM_PROGRESS_RING]));
 	RtParams p = stream_params(ctx, i);
+	const long long wavefront_bound = stream_bound(s) + (fresh ? fresh->paths : 0);
 	if (fresh) {
 		RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));  // asynchronous scene uploads (they flush the wavefront first)
 		RtParams pg = p;
@@ -1357,7 +1374,9 @@ static int stream_enqueue_iteration(rt_context * ctx, const StreamSubmission * f
 	RT_HIP(ctx, hipEventRecord(s.iteration_done[i % RT_STREAM_PROGRESS_RING], st));
 	stage_mark(ctx, STAGE_TRACE, st);
 	span_mark(ctx, STAGE_TRACE, st);
-	rt_launch_trace_stream(p, ctx->trace_statistics ? ctx->trace_stats : nullptr, st);
+	// the variant of the traversal launch: by the host's bound on the closest-hit rays of this iteration (stream_bound)
+	const bool small_wavefront = wavefront_bound < RT_STREAM_SMALL_WAVEFRONT;
+	rt_launch_trace_stream(p, ctx->trace_statistics ? ctx->trace_stats : nullptr, small_wavefront, st);
 	span_mark(ctx, STAGE_TRACE, st);
 	if (ctx->trace_statistics && ctx->stream_history_rows < RT_STREAM_HISTORY_ROWS)
 		RT_HIP(ctx, hipMemcpyAsync(ctx->stream_history + size_t(10) * ctx->stream_history_rows++, ctx->trace_stats, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1522,7 +1541,7 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
 	// ... and it reads the scene version that is current now (asynchronous TLAS / instance uploads)
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));
-	for (SceneRing * ring : { &ctx->tlas_ring, &ctx->instance_ring, &ctx->light_ring }) if (ring->current >= 0) ring->users[ring->current] |= 1u << slot_index;
+
 	if (exclusive) for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[k].ev_done, 0));
 
 	ctx->stage_used = 0;
@@ -1609,6 +1628,7 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	RT_HIP(ctx, hipMemcpyAsync(slot.pinned_counters, slot.counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int), hipMemcpyDeviceToHost, st));
 	RT_HIP(ctx, hipEventRecord(slot.ev_frame_end, st));
 	RT_HIP(ctx, hipEventRecord(slot.ev_done, st));
+	{ int status = mark_scene_versions_in_use(ctx, slot_index, st); if (status) return status; }
 	ctx->last_slot = slot_index;
 	RT_HIP(ctx, hipGetLastError());
 	return RT_OK;
@@ -1646,7 +1666,7 @@ int rt_render_ao_sample(rt_context * ctx, int sample_index, float ao_radius) {
 	hipStream_t st = slot.stream;
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
-	for (SceneRing * ring : { &ctx->tlas_ring, &ctx->instance_ring, &ctx->light_ring }) if (ring->current >= 0) ring->users[ring->current] |= 1u;
+
 	for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[k].ev_done, 0));
 
 	RT_HIP(ctx, hipEventRecord(slot.ev_frame_start, st));
@@ -1671,6 +1691,7 @@ int rt_render_ao_sample(rt_context * ctx, int sample_index, float ao_radius) {
 	RT_HIP(ctx, hipMemcpyAsync(slot.pinned_counters, slot.counter_totals, 6 * RT_MAX_BOUNCES * sizeof(int), hipMemcpyDeviceToHost, st));
 	RT_HIP(ctx, hipEventRecord(slot.ev_frame_end, st));
 	RT_HIP(ctx, hipEventRecord(slot.ev_done, st));
+	{ int status = mark_scene_versions_in_use(ctx, 0, st); if (status) return status; }
 	ctx->last_slot = 0;
 	RT_HIP(ctx, hipGetLastError());
 	return RT_OK;

@@ -137,6 +137,10 @@ void oracle_trace(const oracle_scene * scene, const float * ox, const float * oy
 void oracle_trace_shadow(const oracle_scene * scene, const float * ox, const float * oy, const float * oz,
                          const float * dx, const float * dy, const float * dz, const float * max_distance,
                          size_t ray_count, uint8_t * occluded, oracle_trace_stats * stats, int threads);
+/* Threads a call with threads <= 0 uses: ORACLE_THREADS, else min(omp_get_max_threads(), 32). (A GPU box shows 256 logical
+ * CPUs to the container and gives it about 16 cores' worth: the traversal loop peaks at 16-32 threads, 8 Mrays/s, and
+ * falls to 3.5 Mrays/s at 256.) */
+int oracle_default_threads(void);
 /* kernel_generate (Pathtracer.cu:122-139) */
 void oracle_generate(const oracle_scene * scene, int sample_index, int pixel_offset, int pixel_count,
                      float * ox, float * oy, float * oz, float * dx, float * dy, float * dz, uint32_t * pixel_index_and_flags);

@@ -32,3 +32,11 @@ extern "C" double oracle_effective_parallelism(int threads, double seconds_per_r
 	double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	return wall > 0.0 ? double(threads) * t1 / wall : 0.0;
 }
+
+#include <cstdlib>
+#include <omp.h>
+extern "C" int oracle_default_threads(void) {
+	if (const char * e = getenv("ORACLE_THREADS")) { int n = atoi(e); if (n > 0) return n; }
+	int n = omp_get_max_threads();
+	return n < 32 ? n : 32;
+}

@@ -12,7 +12,7 @@ static inline float online_average(float avg, float sample, int n) { // Util.h:1
 extern "C" {
 
 void oracle_integrate_dielectric_cells(const oracle_scene * scene, int entering, int num_samples, int first_cell, int cell_count, float * out, int threads) {
-	if (threads <= 0) threads = omp_get_max_threads();
+	if (threads <= 0) threads = oracle_default_threads();
 	#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
 	for (int k = 0; k < cell_count; k++) {
 		int thread_index = first_cell + k;
@@ -50,7 +50,7 @@ void oracle_integrate_dielectric_cells(const oracle_scene * scene, int entering,
 }
 
 void oracle_integrate_conductor_cells(const oracle_scene * scene, int num_samples, int first_cell, int cell_count, float * out, int threads) {
-	if (threads <= 0) threads = omp_get_max_threads();
+	if (threads <= 0) threads = oracle_default_threads();
 	#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
 	for (int k = 0; k < cell_count; k++) {
 		int thread_index = first_cell + k;

@@ -921,7 +921,7 @@ void oracle_random(const oracle_scene * scene, int dimension, const uint32_t * p
 void oracle_render_ao_sample(const oracle_scene * scene, oracle_frame * frame, int sample_index, float ao_radius,
                              int range_offset, int range_count, oracle_counters * counters, int threads) {
 	const oracle_scene & s = *scene;
-	if (threads <= 0) threads = omp_get_max_threads();
+	if (threads <= 0) threads = oracle_default_threads();
 	Context c(s, *frame);
 	oracle_counters local; memset(&local, 0, sizeof(local));
 
@@ -1038,7 +1038,7 @@ void oracle_filter_frame(const oracle_scene * scene, oracle_frame * frame, int s
 static void render_sample_impl(const oracle_scene * scene, oracle_frame * frame, int sample_index,
                                int range_offset, int range_count, oracle_counters * counters, int threads, bool finish) {
 	const oracle_scene & s = *scene;
-	if (threads <= 0) threads = omp_get_max_threads();
+	if (threads <= 0) threads = oracle_default_threads();
 	g_oracle_threads = threads < 32 ? threads : 32;   // chunks of the sort / shade kernels: joining many small pieces costs more than it saves
 	if (const char * e = getenv("ORACLE_CHUNKS")) g_oracle_threads = atoi(e) > 0 ? atoi(e) : 1;
 	const bool profile = getenv("ORACLE_PROFILE") != nullptr;

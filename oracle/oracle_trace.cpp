@@ -479,7 +479,7 @@ const char * oracle_version(void) { return "gpu-raytracer oracle 0.1 (CPU restat
 void oracle_trace(const oracle_scene * scene, const float * ox, const float * oy, const float * oz,
                   const float * dx, const float * dy, const float * dz, size_t ray_count,
                   uint32_t * hits, oracle_trace_stats * stats, int threads) {
-	if (threads <= 0) threads = omp_get_max_threads();
+	if (threads <= 0) threads = oracle_default_threads();
 	oracle_trace_stats total = { 0, 0, 0, 0, 0 };
 	#pragma omp parallel num_threads(threads)
 	{
@@ -497,7 +497,7 @@ void oracle_trace(const oracle_scene * scene, const float * ox, const float * oy
 void oracle_trace_shadow(const oracle_scene * scene, const float * ox, const float * oy, const float * oz,
                          const float * dx, const float * dy, const float * dz, const float * max_distance,
                          size_t ray_count, uint8_t * occluded, oracle_trace_stats * stats, int threads) {
-	if (threads <= 0) threads = omp_get_max_threads();
+	if (threads <= 0) threads = oracle_default_threads();
 	oracle_trace_stats total = { 0, 0, 0, 0, 0 };
 	#pragma omp parallel num_threads(threads)
 	{
