@@ -141,10 +141,7 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
     passes = pmc_pass.run_passes(args.steps, args.warmup)
     kernels = passes["kernels"]
     out = {"pmc_errors": passes["errors"]} if passes["errors"] else {}
-    trace = {}   # the traversal launch exists in two compilations (5 and 4 waves per SIMD, picked by wavefront size): both count
-    for name in ("kernel_trace_stream_bvh8", "kernel_trace_stream_bvh8_small"):
-        for counter, (n, total) in kernels.get(name, {}).items():
-            e = trace.setdefault(counter, [0, 0.0]); e[0] += n; e[1] += total
+    trace = kernels.get("kernel_trace_stream_bvh8")
     if not trace:
         return dict(out, traffic=None)
     # what the child rendered with the non-counting traversal kernel: warm-up, the two profiled frames, the timed plan
@@ -408,7 +405,7 @@ def main():
             big = launch_rays >= 0.5 * launch_rays.max()        # the steady-state launches (fill and drain iterations excluded)
             per_launch_gbps = launch_bytes / np.maximum(launch_ms, 1e-6) / 1e6
             roofline.update({
-                "kernel": "kernel_trace_stream_bvh8 (+ its 4-waves-per-SIMD compilation kernel_trace_stream_bvh8_small for wavefronts below 6 M rays)", "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "kernel": "kernel_trace_stream_bvh8", "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "launches": int(len(launch_ms)), "algorithmic_bytes_per_launch": round(float(launch_bytes.mean())), "avg_launch_ms": round(float(launch_ms.mean()), 4),
                 "launch_ms": spread(launch_ms), "launch_gbps": spread(per_launch_gbps),
                 "steady_state": {"launches": int(big.sum()), "achieved": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9), 1),

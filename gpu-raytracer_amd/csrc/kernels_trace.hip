@@ -1153,9 +1153,6 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8(RtParams p) { trace_stream<false>(p, nullptr); }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_counting(RtParams p, unsigned long long * stats) { trace_stream<true>(p, stats); }
-// The same launch compiled for 4 waves per SIMD (up to 128 VGPRs): the host picks it for wavefronts of a few million rays --
-// an eighth of a 1080p frame runs 4.5 % faster with it, a whole frame 7 % slower (profiles/r02_trace_variants.txt).
-__global__ void __launch_bounds__(RT_TRACE_BLOCK, 4) kernel_trace_stream_bvh8_small(RtParams p) { trace_stream<false>(p, nullptr); }
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {
 	ClosestHitSource src { origin, direction, hits };
@@ -1226,12 +1223,7 @@ void rt_launch_trace_shadow_ao(const RtParams & p, hipStream_t stream) {
 	static int grid = trace_grid_size((const void *)kernel_trace_shadow_bvh8_ao);
 	hipLaunchKernelGGL(kernel_trace_shadow_bvh8_ao, dim3(grid), dim3(RT_TRACE_BLOCK), 0, stream, p);
 }
-void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, bool small_wavefront, hipStream_t stream) {
-	if (small_wavefront && !stats) {
-		static int grid_small = trace_grid_size((const void *)kernel_trace_stream_bvh8_small);
-		hipLaunchKernelGGL(kernel_trace_stream_bvh8_small, dim3(grid_small), dim3(RT_TRACE_BLOCK), 0, stream, p);
-		return;
-	}
+void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, hipStream_t stream) {
 	if (stats) {
 		static int grid_counting = trace_grid_size((const void *)kernel_trace_stream_bvh8_counting);
 		hipLaunchKernelGGL(kernel_trace_stream_bvh8_counting, dim3(grid_counting), dim3(RT_TRACE_BLOCK), 0, stream, p, stats);

@@ -89,7 +89,6 @@ struct SceneRing {
 #define RT_STREAM_RUN_AHEAD       4
 #define RT_STREAM_TABLE_SNAPSHOTS 8
 #define RT_STREAM_HISTORY_ROWS    4096
-#define RT_STREAM_SMALL_WAVEFRONT  (6ll * 1024 * 1024)   // closest-hit rays: below it the traversal launch compiled for 4 waves per SIMD
 #define RT_STREAM_STATS_ROW       (RT_STAT_KINDS * RT_MAX_BOUNCES)   // ints per submission
 
 struct StreamSubmission {
@@ -1359,7 +1358,6 @@ static int stream_enqueue_iteration(rt_context * ctx, const StreamSubmission * f
 	hipStream_t st = s.stream;
 	if (i - RT_STREAM_RUN_AHEAD >= 0) RT_HIP(ctx, hipEventSynchronize(s.iteration_done[(i - RT_STREAM_RUN_AHEAD) % RT_STREAM_PROGRESS_RING]));
 	RtParams p = stream_params(ctx, i);
-	const long long wavefront_bound = stream_bound(s) + (fresh ? fresh->paths : 0);
 	if (fresh) {
 		RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));  // asynchronous scene uploads (they flush the wavefront first)
 		RtParams pg = p;
@@ -1374,9 +1372,7 @@ static int stream_enqueue_iteration(rt_context * ctx, const StreamSubmission * f
 	RT_HIP(ctx, hipEventRecord(s.iteration_done[i % RT_STREAM_PROGRESS_RING], st));
 	stage_mark(ctx, STAGE_TRACE, st);
 	span_mark(ctx, STAGE_TRACE, st);
-	// the variant of the traversal launch: by the host's bound on the closest-hit rays of this iteration (stream_bound)
-	const bool small_wavefront = wavefront_bound < RT_STREAM_SMALL_WAVEFRONT;
-	rt_launch_trace_stream(p, ctx->trace_statistics ? ctx->trace_stats : nullptr, small_wavefront, st);
+	rt_launch_trace_stream(p, ctx->trace_statistics ? ctx->trace_stats : nullptr, st);
 	span_mark(ctx, STAGE_TRACE, st);
 	if (ctx->trace_statistics && ctx->stream_history_rows < RT_STREAM_HISTORY_ROWS)
 		RT_HIP(ctx, hipMemcpyAsync(ctx->stream_history + size_t(10) * ctx->stream_history_rows++, ctx->trace_stats, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
