@@ -30,7 +30,6 @@ __attribute__((constructor)) static void grt_default_environment() { setenv("GPU
 // and whose persistent trace launches each end in a tail; a second sample's kernels fill those holes.
 #define RT_MAX_SAMPLE_SLOTS 8
 #define RT_MAX_BATCH_SAMPLES 16
-#define RT_LAUNCH_TIMING_STRIDE 3   // profiling mode 2 times the trace launches of every 3rd sample (events between launches cost ~3 % when on every sample)
 struct SampleSlot {
 	bool created = false;
 	hipStream_t stream = nullptr;      // the sample's launch chain
@@ -178,8 +177,8 @@ struct rt_context {
 
 	rt_counters last_counters;
 	bool profiling = false;          // mode 1: per-stage events, one sample at a time
-	bool launch_timing = false;      // mode 2: events around the trace launches of every RT_LAUNCH_TIMING_STRIDE-th sample, concurrency untouched
-	bool time_this_sample = false; unsigned timing_counter = 0;
+	bool launch_timing = false;      // mode 2: events around every traversal launch, concurrency untouched
+	bool time_this_sample = false;
 	std::vector<hipEvent_t> span_events; std::vector<int> span_kinds; size_t span_used = 0; // mode 2: [begin, end] pairs
 	bool trace_statistics = false;
 	unsigned long long * trace_stats = nullptr;    // device, 10 x u64
@@ -1073,7 +1072,6 @@ int rt_set_profiling(rt_context * ctx, int enable) {
 	RT_HIP(ctx, quiesce(ctx));
 	ctx->profiling = enable == 1;
 	ctx->launch_timing = enable == 2;
-	ctx->timing_counter = 0;
 	ctx->span_used = 0;
 	ctx->stage_used = 0;
 	return RT_OK;
