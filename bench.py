@@ -449,6 +449,8 @@ def main():
                 "emulated_world": args.emulate_world, "ranks": (dist.get_world_size() if world > 1 else 1),
                 "parallelism": "tile-split x%d + one RCCL all-gather of the accumulated float4 frame per %d-spp frame, unpacked into every rank's framebuffer" % (world, SPP) if world > 1 else "single GPU",
                 "samples_per_submission": args.batch, "submissions_in_flight": ("num_bounces (merged wavefront)" if merged else args.samples_in_flight),
+                # rt_set_frame_pipelining: the submissions of a tile split are small, up to 8 of them share one iteration of the wavefront
+                "submissions_per_iteration": (min(8, -(-WIDTH * HEIGHT * SPP // max(1, split.local_pixels * args.batch))) if (merged and split_world > 1) else 1),
                 "stage_ms_per_step_one_frame_alone": {k: round(v, 3) for k, v in stage_ms.items()},
             },
             "roofline": roofline,

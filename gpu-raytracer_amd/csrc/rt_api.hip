@@ -84,6 +84,14 @@ struct SceneRing {
 // entries any queue can receive; the host stays RT_STREAM_RUN_AHEAD iterations ahead of the device at most, reads the
 // reported sizes from pinned memory without blocking, and runs iterations without new samples while a new
 // submission would not fit.
+// Small submissions (the tiles of one rank of a multi-GPU split: 1/8 of a frame) would make small iterations again --
+// launches that do not fill the machine, fixed costs per iteration that no longer disappear behind the rays. When the
+// application pipelines frames (rt_set_frame_pipelining) a submission therefore generates its rays at once but the
+// iteration is only enqueued when RT_STREAM_BATCH_PATHS paths have been generated for it (or RT_STREAM_MAX_BATCH
+// submissions), so the iterations of a 1/8 split carry 8 frames and are as large as those of a whole frame. Anything that
+// needs progress -- rt_advance, every call that flushes, a change of camera -- enqueues the iteration with what is there.
+#define RT_STREAM_BATCH_PATHS     (1920 * 1080 * 4)
+#define RT_STREAM_MAX_BATCH       8
 #define RT_STREAM_PROGRESS_RING   64
 #define RT_STREAM_RUN_AHEAD       4
 #define RT_STREAM_TABLE_SNAPSHOTS 8
@@ -112,6 +120,7 @@ struct PathStream {
 	int iteration = 0;                    // the next iteration to enqueue
 	int base_iteration = 0;               // nothing generated before it is still in flight
 	std::deque<StreamSubmission> in_flight;
+	int pending = 0; long long pending_paths = 0;   // the newest submissions: rays generated, iteration not enqueued yet
 	int * progress = nullptr;             // pinned [RING][2] = { iteration, wavefront size }, written by kernel_stream_advance
 	hipEvent_t iteration_done[RT_STREAM_PROGRESS_RING] = { };
 	int generated[RT_STREAM_PROGRESS_RING] = { };
@@ -223,6 +232,7 @@ static int upload(rt_context * ctx, void ** slot, const void * src, size_t bytes
 // Wait for everything the context has in flight: the merged wavefront (run to completion first), every sample
 // slot (and its side stream), then main.
 static hipError_t stream_flush(rt_context * ctx);
+static int stream_launch_pending(rt_context * ctx);
 static void stream_destroy(rt_context * ctx);
 static void stream_release_frames(rt_context * ctx);
 static hipError_t quiesce(rt_context * ctx) {
@@ -920,6 +930,7 @@ int rt_resize(rt_context * ctx, int width, int height) {
 
 int rt_set_camera(rt_context * ctx, const rt_camera * camera) {
 	RT_REQUIRE(ctx, ctx && camera, "rt_set_camera: NULL argument");
+	if (memcmp(&ctx->params.camera, camera, sizeof(*camera)) != 0) { int status = stream_launch_pending(ctx); if (status) return status; } // bounce 0 is shaded with the camera
 	ctx->params.camera = *camera;
 	return RT_OK;
 }
@@ -1047,6 +1058,7 @@ int rt_set_trace_statistics(rt_context * ctx, int enable) {
 	RT_REQUIRE(ctx, ctx, "rt_set_trace_statistics: NULL context");
 	(void)hipSetDevice(ctx->device);
 	if (enable && !ctx->trace_stats) { int s = device_alloc(ctx, (void **)&ctx->trace_stats, 10 * sizeof(unsigned long long)); if (s) return s; }
+	{ int s = stream_launch_pending(ctx); if (s) return s; }
 	ctx->trace_statistics = enable != 0;
 	return RT_OK;
 }
@@ -1324,49 +1336,84 @@ static long long stream_bound(PathStream & s) {
 	return bound;
 }
 
-static int stream_complete(rt_context * ctx, const StreamSubmission & sub, const RtParams & p) {
+// The submissions that have passed their last bounce with iteration i (consecutive, in submission order; with batched
+// admission up to RT_STREAM_MAX_BATCH of them): folded into the accumulators, their sample slots cleared and released.
+static int stream_complete(rt_context * ctx, const StreamSubmission * subs, int count, const RtParams & p) {
 	PathStream & s = ctx->path_stream;
 	hipStream_t st = s.stream;
 	// the accumulate step follows the main-stream work submitted so far (rt_pack_pixels of an earlier frame reads,
 	// rt_unpack_pixels writes the image)
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
-	RtParams pa = p;
-	pa.batch_samples = sub.sample_count;
-	pa.tile_pixels = sub.tile_pixels; pa.tile_first = sub.tile_first; pa.tile_stride = sub.tile_stride;
-	for (int i = 0; i < RT_AOV_COUNT; i++) if (pa.aovs[i].framebuffer) pa.aovs[i].framebuffer += size_t(sub.slot_base) * ctx->frame_pixels;
 	stage_mark(ctx, STAGE_POST, st);
-	rt_launch_accumulate(pa, float(sub.first_sample), sub.range_offset, sub.range_count, st);
+	for (int first = 0; first < count; ) {
+		// one launch for a run of submissions over the same pixels
+		const StreamSubmission & head = subs[first];
+		RtAccumulateGroup group; group.count = 0;
+		int k = first;
+		for (; k < count && group.count < RT_ACCUMULATE_GROUP; k++) {
+			const StreamSubmission & sub = subs[k];
+			if (sub.range_offset != head.range_offset || sub.range_count != head.range_count || sub.tile_pixels != head.tile_pixels || sub.tile_first != head.tile_first || sub.tile_stride != head.tile_stride) break;
+			group.first_sample[group.count] = sub.first_sample; group.sample_count[group.count] = sub.sample_count; group.slot_base[group.count] = sub.slot_base;
+			group.count++;
+		}
+		RtParams pa = p;
+		pa.tile_pixels = head.tile_pixels; pa.tile_first = head.tile_first; pa.tile_stride = head.tile_stride;
+		rt_launch_accumulate_group(pa, group, head.range_offset, head.range_count, st);
+		first = k;
+	}
 	stage_mark(ctx, STAGE_END, st);
-	for (int i = 0; i < RT_AOV_COUNT; i++) if (pa.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(pa.aovs[i].framebuffer, 0, ctx->frame_pixels * 16 * size_t(sub.sample_count), st)); // aovs_clear_to_zero
-	RT_HIP(ctx, hipMemcpyAsync(s.stats_host + size_t(sub.ring) * RT_STREAM_STATS_ROW, &s.control->stats[sub.ring][0][0], sizeof(int) * RT_STREAM_STATS_ROW, hipMemcpyDeviceToHost, st));
-	RT_HIP(ctx, hipEventRecord(s.ev_end[sub.ring], st));
+	for (int k = 0; k < count; k++) {
+		const StreamSubmission & sub = subs[k];
+		// the AOVs the accumulate kernel does not fold (DIRECT / INDIRECT exist for the filter only) are cleared the plain way
+		for (int i : { RT_AOV_RADIANCE_DIRECT, RT_AOV_RADIANCE_INDIRECT }) if (p.aovs[i].framebuffer)
+			RT_HIP(ctx, hipMemsetAsync(p.aovs[i].framebuffer + size_t(sub.slot_base) * ctx->frame_pixels, 0, ctx->frame_pixels * 16 * size_t(sub.sample_count), st)); // aovs_clear_to_zero
+	}
+	for (int k = 0; k < count; ) { // statistics rows: consecutive ring entries travel in one copy
+		int run = 1;
+		while (k + run < count && subs[k + run].ring == subs[k].ring + run) run++;
+		RT_HIP(ctx, hipMemcpyAsync(s.stats_host + size_t(subs[k].ring) * RT_STREAM_STATS_ROW, &s.control->stats[subs[k].ring][0][0], sizeof(int) * RT_STREAM_STATS_ROW * size_t(run), hipMemcpyDeviceToHost, st));
+		k += run;
+	}
+	for (int k = 0; k < count; k++) {
+		const StreamSubmission & sub = subs[k];
+		RT_HIP(ctx, hipEventRecord(s.ev_end[sub.ring], st));
+		for (int j = 0; j < sub.sample_count; j++) s.slot_used[sub.slot_base + j] = false;
+		s.last_completed_ring = sub.ring;
+		s.submissions_completed++;
+	}
 	RT_HIP(ctx, hipEventRecord(s.ev_idle, st));
-	for (int k = 0; k < sub.sample_count; k++) s.slot_used[sub.slot_base + k] = false;
-	s.last_completed_ring = sub.ring;
-	s.submissions_completed++;
 	return RT_OK;
 }
 
-// One iteration of the wavefront: [generate the rays of `fresh`] -> advance -> fused trace -> sort -> shade, then the
-// accumulate step of every submission that has just passed its last bounce.
-static int stream_enqueue_iteration(rt_context * ctx, const StreamSubmission * fresh) {
+// The primary rays of a new submission: appended to the trace queue of the iteration that is enqueued next, behind the
+// rays of the submissions already waiting for it.
+static int stream_generate(rt_context * ctx, const StreamSubmission & sub) {
+	PathStream & s = ctx->path_stream;
+	hipStream_t st = s.stream;
+	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));  // asynchronous scene uploads (they flush the wavefront first)
+	RtParams pg = stream_params(ctx, s.iteration);
+	pg.batch_samples = sub.sample_count;
+	pg.tile_pixels = sub.tile_pixels; pg.tile_first = sub.tile_first; pg.tile_stride = sub.tile_stride;
+	RT_HIP(ctx, hipEventRecord(s.ev_begin[sub.ring], st));
+	stage_mark(ctx, STAGE_GENERATE, st);
+	rt_launch_generate_stream(pg, sub.first_sample, sub.range_offset, sub.range_count, sub.slot_base, int(s.pending_paths), st);
+	s.pending++; s.pending_paths += sub.paths;
+	return RT_OK;
+}
+
+// One iteration of the wavefront: advance (counts the rays generated since the last one in) -> fused trace -> sort ->
+// shade, then the accumulate step of every submission that has just passed its last bounce.
+static int stream_enqueue_iteration(rt_context * ctx) {
 	PathStream & s = ctx->path_stream;
 	const int i = s.iteration;
 	hipStream_t st = s.stream;
 	if (i - RT_STREAM_RUN_AHEAD >= 0) RT_HIP(ctx, hipEventSynchronize(s.iteration_done[(i - RT_STREAM_RUN_AHEAD) % RT_STREAM_PROGRESS_RING]));
 	RtParams p = stream_params(ctx, i);
-	if (fresh) {
-		RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));  // asynchronous scene uploads (they flush the wavefront first)
-		RtParams pg = p;
-		pg.batch_samples = fresh->sample_count;
-		pg.tile_pixels = fresh->tile_pixels; pg.tile_first = fresh->tile_first; pg.tile_stride = fresh->tile_stride;
-		RT_HIP(ctx, hipEventRecord(s.ev_begin[fresh->ring], st));
-		stage_mark(ctx, STAGE_GENERATE, st);
-		rt_launch_generate_stream(pg, fresh->first_sample, fresh->range_offset, fresh->range_count, fresh->slot_base, st);
-	}
-	rt_launch_stream_advance(s.control, i, fresh ? fresh->paths : 0, s.progress + 2 * (i % RT_STREAM_PROGRESS_RING), st);
-	s.generated[i % RT_STREAM_PROGRESS_RING] = fresh ? fresh->paths : 0;
+	const int generated = int(s.pending_paths);
+	s.pending = 0; s.pending_paths = 0;
+	rt_launch_stream_advance(s.control, i, generated, s.progress + 2 * (i % RT_STREAM_PROGRESS_RING), st);
+	s.generated[i % RT_STREAM_PROGRESS_RING] = generated;
 	RT_HIP(ctx, hipEventRecord(s.iteration_done[i % RT_STREAM_PROGRESS_RING], st));
 	stage_mark(ctx, STAGE_TRACE, st);
 	span_mark(ctx, STAGE_TRACE, st);
@@ -1380,19 +1427,31 @@ static int stream_enqueue_iteration(rt_context * ctx, const StreamSubmission * f
 	for (int m = 0; m < 4; m++) if (ctx->has_material[m]) rt_launch_material_stream(p, m, st);
 	stage_mark(ctx, STAGE_END, st);
 	s.iteration = i + 1;
+	StreamSubmission done[RT_STREAM_MAX_BATCH]; int done_count = 0;
 	while (!s.in_flight.empty() && s.in_flight.front().last <= i) {
-		int status = stream_complete(ctx, s.in_flight.front(), p); if (status) return status;
+		done[done_count++] = s.in_flight.front();
 		s.in_flight.pop_front();
+		if (done_count == RT_STREAM_MAX_BATCH || s.in_flight.empty() || s.in_flight.front().last > i) {
+			int status = stream_complete(ctx, done, done_count, p); if (status) return status;
+			done_count = 0;
+		}
 	}
 	if (s.in_flight.empty()) s.base_iteration = s.iteration;
 	RT_HIP(ctx, hipGetLastError());
 	return RT_OK;
 }
 
+// Submissions that wait for company get their iteration now (before a setting they were made under changes).
+static int stream_launch_pending(rt_context * ctx) {
+	if (!ctx->path_stream.created || ctx->path_stream.pending == 0) return RT_OK;
+	(void)hipSetDevice(ctx->device);
+	return stream_enqueue_iteration(ctx);
+}
+
 // Runs the wavefront until nothing is in flight (the calls that read results or change state need that).
 static hipError_t stream_flush(rt_context * ctx) {
 	PathStream & s = ctx->path_stream;
-	while (s.created && !s.in_flight.empty()) if (stream_enqueue_iteration(ctx, nullptr) != RT_OK) return hipErrorUnknown;
+	while (s.created && !s.in_flight.empty()) if (stream_enqueue_iteration(ctx) != RT_OK) return hipErrorUnknown;
 	return hipSuccess;
 }
 
@@ -1401,12 +1460,14 @@ static int stream_submit(rt_context * ctx, int sample_index, int sample_count, i
 	int status = stream_create(ctx); if (status) return status;
 	PathStream & s = ctx->path_stream;
 	const int num_bounces = ctx->params.config.num_bounces;
-	status = stream_ensure_frames(ctx, sample_count * (num_bounces + 1)); if (status) return status;
-	if (sample_count > s.frame_slots) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_samples: %d samples of a %zu pixel frame exceed the %d sample slots of the merged wavefront", sample_count, ctx->frame_pixels, s.frame_slots);
 	const long long paths = (long long)range_count * sample_count;
 	if (paths <= 0) return RT_OK;
+	// submissions per iteration: one, unless the application pipelines frames and they are small
+	const int batch = ctx->frame_pipelining ? int(std::min<long long>(RT_STREAM_MAX_BATCH, (RT_STREAM_BATCH_PATHS + paths - 1) / paths)) : 1;
+	status = stream_ensure_frames(ctx, sample_count * (num_bounces + 1) * batch); if (status) return status;
+	if (sample_count > s.frame_slots) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_samples: %d samples of a %zu pixel frame exceed the %d sample slots of the merged wavefront", sample_count, ctx->frame_pixels, s.frame_slots);
 	static const double factor = getenv("GRT_STREAM_CAPACITY_FACTOR") ? atof(getenv("GRT_STREAM_CAPACITY_FACTOR")) : 4.0;
-	if (size_t(paths) > s.capacity || !s.queues_allocated) { status = stream_ensure_queues(ctx, size_t(double(paths) * (factor < 1.0 ? 1.0 : factor)) + 1024); if (status) return status; }
+	if (size_t(paths * batch) > s.capacity || !s.queues_allocated) { status = stream_ensure_queues(ctx, size_t(double(paths * batch) * (factor < 1.0 ? 1.0 : factor)) + 1024); if (status) return status; }
 
 	// admission: sample slots, a statistics ring entry, and room in the queues
 	int slot_base = -1;
@@ -1427,7 +1488,7 @@ static int stream_submit(rt_context * ctx, int sample_index, int sample_count, i
 			continue;
 		}
 		if (s.in_flight.empty()) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_samples: the merged wavefront cannot take %lld paths (capacity %zu, %d sample slots)", paths, s.capacity, s.frame_slots);
-		status = stream_enqueue_iteration(ctx, nullptr); if (status) return status;   // advance without new samples: paths die, submissions complete
+		status = stream_enqueue_iteration(ctx); if (status) return status;   // advance (with the submissions waiting, if any): paths die, submissions complete
 	}
 
 	StreamSubmission sub;
@@ -1455,7 +1516,9 @@ static int stream_submit(rt_context * ctx, int sample_index, int sample_count, i
 		ctx->stream_history_rows = 0;
 	}
 	s.in_flight.push_back(sub);
-	return stream_enqueue_iteration(ctx, &s.in_flight.back());
+	status = stream_generate(ctx, sub); if (status) return status;
+	if (s.pending < batch && s.pending_paths < RT_STREAM_BATCH_PATHS) return RT_OK;   // wait for more of the same size
+	return stream_enqueue_iteration(ctx);
 }
 
 extern "C" {
@@ -1723,7 +1786,7 @@ int rt_advance(rt_context * ctx) {
 	(void)hipSetDevice(ctx->device);
 	if (!ctx->path_stream.created || ctx->path_stream.in_flight.empty()) return RT_OK;
 	ctx->time_this_sample = ctx->launch_timing;
-	return stream_enqueue_iteration(ctx, nullptr);
+	return stream_enqueue_iteration(ctx);
 }
 
 int rt_submissions_completed(rt_context * ctx, uint64_t * out_count) {

@@ -66,8 +66,8 @@ struct RtBufferSizes { // Pathtracer.cu:103-114
 // there are no per-submission tails. A queue entry does not store its bounce: its virtual pixel index names a SAMPLE
 // SLOT (v = slot * frame_pixels + pixel; the slot's per-sample AOV frame lives at the same offset), and the slot table
 // says which sample that is and in which iteration it was generated; bounce = iteration - birth.
-#define RT_STREAM_SAMPLE_SLOTS 64     // samples in flight (each owns one frame of the per-sample AOV buffers)
-#define RT_STREAM_SUBMISSIONS  32     // ring of submissions whose per-bounce statistics are kept
+#define RT_STREAM_SAMPLE_SLOTS 512    // samples in flight (each owns one frame of the per-sample AOV buffers)
+#define RT_STREAM_SUBMISSIONS  128    // ring of submissions whose per-bounce statistics are kept
 enum { RT_STAT_TRACE = 0, RT_STAT_SHADOW, RT_STAT_DIFFUSE, RT_STAT_PLASTIC, RT_STAT_DIELECTRIC, RT_STAT_CONDUCTOR, RT_STAT_KINDS };
 
 struct RtStreamSlot { int sample_index, birth_iteration, submission, index_in_submission; }; // one int4 per sample slot
@@ -222,7 +222,7 @@ __device__ __forceinline__ RtPathInfo rt_stream_path_info(const RtParams & p, un
 void rt_launch_generate(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, hipStream_t stream);
 void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream);
 // merged wavefront (the iteration is p.stream_iteration); stats: null, or 10 x u64 as for the counting variants below
-void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, int slot_base, hipStream_t stream);
+void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, int slot_base, int queue_offset, hipStream_t stream);
 void rt_launch_stream_advance(RtStreamControl * control, int iteration, int generated, int * progress, hipStream_t stream);
 void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, hipStream_t stream);
 void rt_launch_sort_stream(const RtParams & p, hipStream_t stream);
@@ -233,6 +233,9 @@ void rt_launch_trace_shadow_ao(const RtParams & p, hipStream_t stream);
 void rt_launch_sort(const RtParams & p, int bounce, int sample_index, hipStream_t stream);
 void rt_launch_material(const RtParams & p, int material_slot, int bounce, int sample_index, hipStream_t stream);
 void rt_launch_accumulate(const RtParams & p, float frames_accumulated, int pixel_offset, int pixel_count, hipStream_t stream);
+#define RT_ACCUMULATE_GROUP 8
+struct RtAccumulateGroup { int count; int first_sample[RT_ACCUMULATE_GROUP], sample_count[RT_ACCUMULATE_GROUP], slot_base[RT_ACCUMULATE_GROUP]; };
+void rt_launch_accumulate_group(const RtParams & p, const RtAccumulateGroup & group, int pixel_offset, int pixel_count, hipStream_t stream);
 void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream);
 void rt_launch_random(const RtParams & p, int dimension, const unsigned * pixel_indices, int count, unsigned bounce, unsigned sample_index, float2 * out, hipStream_t stream);
 void rt_launch_integrate_luts(const RtParams & p, float * dielectric_dir_enter, float * dielectric_dir_leave, float * dielectric_enter, float * dielectric_leave,

@@ -292,8 +292,14 @@ int rt_set_scheduler(rt_context * ctx, int scheduler);
  * frame to a collective calls rt_advance / rt_render_samples and packs the frame when the count moves
  * (bench.py); rt_pack_pixels and the reads on their own complete everything first.                       */
 int rt_advance(rt_context * ctx);
-/* enable = 1: rt_pack_pixels / rt_unpack_pixels are ordered after the submissions COMPLETED so far instead of first
- * completing everything in flight, so that later frames keep filling the wavefront while an earlier one is exchanged. */
+/* enable = 1: the application keeps several frames in flight.
+ *  - rt_pack_pixels / rt_unpack_pixels are ordered after the submissions COMPLETED so far instead of first completing
+ *    everything in flight, so that later frames keep filling the wavefront while an earlier one is exchanged;
+ *  - small submissions share iterations: a submission generates its primary rays at once, but the iteration that traces
+ *    them is only enqueued when 1920 x 1080 x 4 paths are waiting for it (or 8 submissions), so that the launches of one
+ *    rank of an N-GPU tile split are as large as those of a whole frame. Whatever needs progress enqueues the iteration
+ *    with the submissions that are there: rt_advance, a camera change, every call that completes the work in flight
+ *    (reads, uploads, rt_synchronize). rt_submissions_completed only reports.                                          */
 int rt_set_frame_pipelining(rt_context * ctx, int enable);
 int rt_submissions_completed(rt_context * ctx, uint64_t * out_count);
 /* Replaces the `pixel_query` global (Integrator.h:266-277, Integrator.cpp:483-495, Pathtracer.cu:345-348):

@@ -685,6 +685,58 @@ def test_merged_wavefront_equals_the_slot_scheduler(grt):
         assert merged[4] == len(plan), label
 
 
+def test_small_pipelined_submissions_share_an_iteration(grt):
+    """The tiles of one rank of an 8-way split are 1/8 of a frame: with frame pipelining on, such submissions generate
+    their rays at once but wait for company, so that the iterations stay as large as those of a whole frame
+    (RT_STREAM_BATCH_PATHS). Nothing completes until the iteration is enqueued -- by the submission that fills the batch,
+    by rt_advance, by a camera change or by any call that flushes -- and the image and the per-bounce ray counts are those
+    of the same submissions made one per iteration."""
+    import ctypes
+    W, H, BOUNCES, FRAMES = 192, 128, 5, 11
+    lib = grt.device_lib()
+    lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3
+
+    def render(pipelining):
+        scene, pt = make_pathtracer(grt, "cornellbox", W, H, 0, num_bounces=BOUNCES)
+        assert lib.rt_set_pixel_tiles(pt.ctx, W * 8, 1, 8) == 0      # rank 1 of 8: tiles 1, 9 of 16
+        grt.set_frame_pipelining(pt.ctx, pipelining)
+        completed, counters = [], None
+        for f in range(FRAMES):
+            assert lib.rt_render_samples(pt.ctx, 2 * f, 2) == 0
+            completed.append(grt.submissions_completed(pt.ctx))
+        if pipelining:
+            # 8 submissions per iteration: #0-7 entered iteration 0 together, #8-10 still wait for theirs
+            assert completed == [0] * FRAMES
+            for k in range(BOUNCES - 1):
+                grt.advance(pt.ctx)
+            assert grt.submissions_completed(pt.ctx) == 8          # iterations 0..4 done: the first batch is complete
+            grt.advance(pt.ctx)
+            assert grt.submissions_completed(pt.ctx) == FRAMES     # #8-10 entered iteration 1
+        counters = pt.counters()
+        image = pt.read_framebuffer().copy()
+        trace = list(counters.trace[:BOUNCES]), list(counters.shadow[:BOUNCES])
+        pt.close(); scene.close()
+        return image, trace
+
+    batched, batched_counts = render(True)
+    single, single_counts = render(False)
+    assert np.array_equal(batched, single)
+    assert batched_counts == single_counts
+    assert np.abs(batched[8:16, :W]).max() > 0 and np.abs(batched[0:8, :W]).max() == 0   # only this rank's tiles
+
+    # a camera change enqueues the waiting submissions first: they are shaded with the camera they were generated with
+    scene, pt = make_pathtracer(grt, "cornellbox", W, H, 0, num_bounces=BOUNCES)
+    assert lib.rt_set_pixel_tiles(pt.ctx, W * 8, 1, 8) == 0
+    grt.set_frame_pipelining(pt.ctx, True)
+    assert lib.rt_render_samples(pt.ctx, 0, 2) == 0
+    scene.set_camera((0.2, 1.0, 6.5), (0.0, 0.0, 0.0, 1.0)); pt.update()   # -> iteration 0
+    for k in range(BOUNCES - 1):                                            # iterations 1..4
+        grt.advance(pt.ctx)
+    assert grt.submissions_completed(pt.ctx) == 1
+    pt.close(); scene.close()
+
+
 def test_merged_wavefront_advances_without_new_samples(grt):
     """rt_advance runs one iteration without new samples: a frame loop learns from rt_submissions_completed when a frame
     may be packed. With frame pipelining on, rt_pack_pixels follows the completed submissions only."""

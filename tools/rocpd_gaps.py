@@ -2,7 +2,8 @@
 """GPU occupancy over time from a rocprofv3 kernel trace (rocpd database): how much of the wall time between the first and
 the last kernel of the busiest stretch had at least one kernel resident, the idle time between dependent launches, and per
 kernel name the time it was the ONLY kernel resident. Usage: tools/rocpd_gaps.py <results.db> [last_fraction]
-(last_fraction: analyse only the last part of the trace, default 0.35 -- the timed region of bench.py comes last)."""
+(last_fraction: analyse only the last part of the trace, default 0.35 -- the timed region of bench.py comes last; a value
+above 1 is taken as milliseconds before the end of the last kernel)."""
 import sqlite3
 import sys
 
@@ -17,7 +18,7 @@ def main():
     if not rows:
         print("no kernels"); return
     t_first, t_last = rows[0][1], max(r[2] for r in rows)
-    cut = t_last - (t_last - t_first) * frac
+    cut = t_last - (t_last - t_first) * frac if frac <= 1.0 else t_last - frac * 1e6
     rows = [r for r in rows if r[1] >= cut]
     t0, t1 = rows[0][1], max(r[2] for r in rows)
     busy, gaps, covered_until = 0, [], t0
@@ -27,7 +28,7 @@ def main():
         if end > covered_until:
             busy += end - covered_until; covered_until = end
     wall = t1 - t0
-    print("analysed: last %.0f %% of the trace, %d kernels, %.3f ms wall" % (frac * 100, len(rows), wall / 1e6))
+    print("analysed: last %s of the trace, %d kernels, %.3f ms wall" % ("%.0f %%" % (frac * 100) if frac <= 1.0 else "%.1f ms" % frac, len(rows), wall / 1e6))
     print("GPU had a kernel resident %.1f %% of that time; %d idle gaps, %.3f ms in total, median %.1f us, max %.1f us"
           % (100.0 * busy / wall, len(gaps), sum(gaps) / 1e6, (sorted(gaps)[len(gaps) // 2] / 1e3) if gaps else 0.0, (max(gaps) / 1e3) if gaps else 0.0))
     per = {}
