@@ -34,7 +34,9 @@ RT_DEV HitInfo unpack_hit(uint4 h) { // Buffers.h:34-48
 
 // ---- kernel_generate ----------------------------------------------------------------------------
 
-RT_DEV void camera_generate_ray(const RtParams & p, int pixel_index, int sample_index, int x, int y, f3 & origin, f3 & direction) {
+// `taa_index`: the sample index that picks the TAA jitter (the merged wavefront passes a sample index shifted by the slot,
+// which random_sample undoes).
+RT_DEV void camera_generate_ray(const RtParams & p, int pixel_index, int sample_index, int x, int y, f3 & origin, f3 & direction, int taa_index) {
 	f2 rand_filter   = random_sample(p, DIM_FILTER,   unsigned(pixel_index), 0, unsigned(sample_index));
 	f2 rand_aperture = random_sample(p, DIM_APERTURE, unsigned(pixel_index), 0, unsigned(sample_index));
 
@@ -42,8 +44,8 @@ RT_DEV void camera_generate_ray(const RtParams & p, int pixel_index, int sample_
 	if (p.config.enable_svgf) {
 		const float taa_halton_x[4] = { 0.3f, 0.7f, 0.2f, 0.8f };
 		const float taa_halton_y[4] = { 0.2f, 0.8f, 0.7f, 0.3f };
-		jitter.x = taa_halton_x[sample_index & 3];
-		jitter.y = taa_halton_y[sample_index & 3];
+		jitter.x = taa_halton_x[taa_index & 3];
+		jitter.y = taa_halton_y[taa_index & 3];
 	} else if (p.config.reconstruction_filter == RT_FILTER_BOX) {
 		jitter = rand_filter;
 	} else if (p.config.reconstruction_filter == RT_FILTER_TENT) {
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate(RtParams p, in
 		unsigned virtual_pixel = unsigned(sample_in_batch) * p.frame_pixels + unsigned(pixel_index);
 
 		f3 origin, direction;
-		camera_generate_ray(p, int(virtual_pixel), sample_index, x, y, origin, direction);
+		camera_generate_ray(p, int(virtual_pixel), sample_index, x, y, origin, direction, sample_index + sample_in_batch);
 
 		store3(p.trace[0].origin,    index, origin);
 		store3(p.trace[0].direction, index, direction);
@@ -107,7 +109,7 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate_stream(RtParam
 		unsigned virtual_pixel = slot * p.frame_pixels + unsigned(pixel_index);
 
 		f3 origin, direction;
-		camera_generate_ray(p, int(virtual_pixel), sample_index + sample_in_batch - int(slot), x, y, origin, direction); // random_sample adds the slot back
+		camera_generate_ray(p, int(virtual_pixel), sample_index + sample_in_batch - int(slot), x, y, origin, direction, sample_index + sample_in_batch); // random_sample adds the slot back
 
 		store3(out.origin,    base + index, origin);
 		store3(out.direction, base + index, direction);

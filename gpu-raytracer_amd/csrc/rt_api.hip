@@ -115,6 +115,8 @@ struct PathStream {
 	RtStreamTable * table_staging = nullptr; hipEvent_t table_copied[RT_STREAM_TABLE_SNAPSHOTS] = { }; int table_next = 0;
 	void * spill = nullptr;
 	void * aov_framebuffer[RT_AOV_COUNT] = { }; int frame_slots = 0;   // per-sample frames, one per sample slot
+	void * gbuffers[3] = { };             // SVGF: one g-buffer set (float4, int2, float2 per pixel) per sample slot
+	int last_gbuffer_slot = -1;           // the set of the frame submitted last, if that was a frame of this wavefront
 	bool slot_used[RT_STREAM_SAMPLE_SLOTS] = { };
 	int next_slot = 0, next_ring = 0;
 	int iteration = 0;                    // the next iteration to enqueue
@@ -884,6 +886,8 @@ static int sync_svgf(rt_context * ctx) {
 		RT_HIP(ctx, quiesce(ctx));
 		for (int i = 0; i < 12; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
 		for (SampleSlot & slot : ctx->slots) for (int i = 0; i < 3; i++) { device_free(ctx, slot.gbuffers[i]); slot.gbuffers[i] = nullptr; }
+		ctx->path_stream.last_gbuffer_slot = -1;
+		for (void * & g : ctx->path_stream.gbuffers) { device_free(ctx, g); g = nullptr; }
 	}
 	ctx->svgf_allocated = want;
 	RtParams & p = ctx->params;
@@ -909,6 +913,7 @@ int rt_resize(rt_context * ctx, int width, int height) {
 	int pitch = (width + 31) / 32 * 32; // Math::round_up(width, WARP_SIZE), Pathtracer.cpp:258
 	ctx->params.screen_width = width; ctx->params.screen_height = height; ctx->params.screen_pitch = pitch;
 	ctx->frame_pixels = size_t(pitch) * height;
+	ctx->path_stream.last_gbuffer_slot = -1; // the filter's histories start over with the new size
 	stream_release_frames(ctx);
 
 	for (int i = 0; i < RT_AOV_COUNT; i++) for (int k = 0; k < 2; k++) { device_free(ctx, ctx->aov_buffers[i][k]); ctx->aov_buffers[i][k] = nullptr; }
@@ -1235,10 +1240,26 @@ static void stream_destroy(rt_context * ctx) {
 }
 
 
+// SVGF: a frame starts from a copy of the g-buffers of the frame before it (the reference has ONE set that every frame
+// overwrites where its primary rays hit something). Before the sets of the sample slots are freed or re-allocated the
+// latest one moves to the set of slot 0 of the slot scheduler, where the next frame of either scheduler finds it.
+static const size_t stream_gbuffer_elem[3] = { 16, 8, 8 };
+static void stream_save_gbuffers(rt_context * ctx) {
+	PathStream & s = ctx->path_stream;
+	if (s.last_gbuffer_slot >= 0 && s.gbuffers[0] && ctx->svgf_buffers[0]) {
+		(void)hipDeviceSynchronize();
+		for (int i = 0; i < 3; i++) (void)hipMemcpy(ctx->svgf_buffers[i], (char *)s.gbuffers[i] + ctx->frame_pixels * stream_gbuffer_elem[i] * size_t(s.last_gbuffer_slot), ctx->frame_pixels * stream_gbuffer_elem[i], hipMemcpyDeviceToDevice);
+		ctx->last_slot = 0;
+	}
+	s.last_gbuffer_slot = -1;
+}
+
 // The per-sample frames of the sample slots (they are freed with the frame resources: rt_resize, AOV changes).
 static void stream_release_frames(rt_context * ctx) {
 	PathStream & s = ctx->path_stream;
 	for (void * & fb : s.aov_framebuffer) { device_free(ctx, fb); fb = nullptr; }
+	stream_save_gbuffers(ctx);
+	for (void * & g : s.gbuffers) { device_free(ctx, g); g = nullptr; }
 	s.frame_slots = 0;
 }
 
@@ -1248,14 +1269,21 @@ static int stream_ensure_frames(rt_context * ctx, int wanted_slots) {
 	int slots = std::min(limit, std::max(wanted_slots, 8));
 	bool complete = s.frame_slots >= slots;
 	for (int i = 0; i < RT_AOV_COUNT; i++) if ((ctx->aov_buffers[i][0] != nullptr) != (s.aov_framebuffer[i] != nullptr)) complete = false;
+	if (ctx->svgf_allocated != (s.gbuffers[0] != nullptr)) complete = false;
 	if (complete) return RT_OK;
 	RT_HIP(ctx, quiesce(ctx));
 	slots = std::max(slots, s.frame_slots);
+	stream_save_gbuffers(ctx);
+	for (void * & g : s.gbuffers) { device_free(ctx, g); g = nullptr; }
 	for (void * & fb : s.aov_framebuffer) { device_free(ctx, fb); fb = nullptr; }
 	size_t bytes = ctx->frame_pixels * 16 * size_t(slots);
 	for (int i = 0; i < RT_AOV_COUNT; i++) if (ctx->aov_buffers[i][0]) {
 		int status = device_alloc(ctx, &s.aov_framebuffer[i], bytes); if (status) return status;
 		RT_HIP(ctx, hipMemset(s.aov_framebuffer[i], 0, bytes));
+	}
+	if (ctx->svgf_allocated) for (int i = 0; i < 3; i++) {
+		int status = device_alloc(ctx, &s.gbuffers[i], ctx->frame_pixels * stream_gbuffer_elem[i] * size_t(slots)); if (status) return status;
+		RT_HIP(ctx, hipMemset(s.gbuffers[i], 0, ctx->frame_pixels * stream_gbuffer_elem[i] * size_t(slots)));
 	}
 	s.frame_slots = slots;
 	for (bool & used : s.slot_used) used = false;
@@ -1314,6 +1342,9 @@ static RtParams stream_params(const rt_context * ctx, int iteration) {
 	p.sizes = nullptr; p.xcd_counters = nullptr; p.stack_spill = (uint2 *)s.spill;
 	p.stream = s.control; p.stream_table = s.table_device; p.stream_iteration = iteration;
 	for (int i = 0; i < RT_AOV_COUNT; i++) p.aovs[i].framebuffer = (float4 *)s.aov_framebuffer[i];
+	if (s.gbuffers[0]) { // x + y * pitch of a VIRTUAL pixel is the virtual pixel: the shade kernels write the set of the path's slot
+		p.gbuffer_normal_and_depth = (float4 *)s.gbuffers[0]; p.gbuffer_mesh_id_and_triangle_id = (int2 *)s.gbuffers[1]; p.gbuffer_screen_position_prev = (float2 *)s.gbuffers[2];
+	}
 	p.batch_samples = 1;
 	return p;
 }
@@ -1346,6 +1377,16 @@ static int stream_complete(rt_context * ctx, const StreamSubmission * subs, int 
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
 	stage_mark(ctx, STAGE_POST, st);
+	if (p.config.enable_svgf) { // one filtered frame per submission: reproject / variance / a-trous / finalize / TAA on its own sample frames and g-buffers
+		for (int k = 0; k < count; k++) {
+			const StreamSubmission & sub = subs[k];
+			RtParams pf = p;
+			for (int i = 0; i < RT_AOV_COUNT; i++) if (pf.aovs[i].framebuffer) pf.aovs[i].framebuffer += size_t(sub.slot_base) * ctx->frame_pixels;
+			pf.gbuffer_normal_and_depth += size_t(sub.slot_base) * ctx->frame_pixels; pf.gbuffer_mesh_id_and_triangle_id += size_t(sub.slot_base) * ctx->frame_pixels; pf.gbuffer_screen_position_prev += size_t(sub.slot_base) * ctx->frame_pixels;
+			rt_launch_svgf_taa(pf, sub.first_sample, st);
+			for (int i = 0; i < RT_AOV_COUNT; i++) if (pf.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(pf.aovs[i].framebuffer, 0, ctx->frame_pixels * 16 * size_t(sub.sample_count), st)); // aovs_clear_to_zero
+		}
+	} else
 	for (int first = 0; first < count; ) {
 		// one launch for a run of submissions over the same pixels
 		const StreamSubmission & head = subs[first];
@@ -1363,7 +1404,7 @@ static int stream_complete(rt_context * ctx, const StreamSubmission * subs, int 
 		first = k;
 	}
 	stage_mark(ctx, STAGE_END, st);
-	for (int k = 0; k < count; k++) {
+	if (!p.config.enable_svgf) for (int k = 0; k < count; k++) {
 		const StreamSubmission & sub = subs[k];
 		// the AOVs the accumulate kernel does not fold (DIRECT / INDIRECT exist for the filter only) are cleared the plain way
 		for (int i : { RT_AOV_RADIANCE_DIRECT, RT_AOV_RADIANCE_INDIRECT }) if (p.aovs[i].framebuffer)
@@ -1463,7 +1504,8 @@ static int stream_submit(rt_context * ctx, int sample_index, int sample_count, i
 	const long long paths = (long long)range_count * sample_count;
 	if (paths <= 0) return RT_OK;
 	// submissions per iteration: one, unless the application pipelines frames and they are small
-	const int batch = ctx->frame_pipelining ? int(std::min<long long>(RT_STREAM_MAX_BATCH, (RT_STREAM_BATCH_PATHS + paths - 1) / paths)) : 1;
+	// (SVGF frames: never, a frame inherits the g-buffers its predecessor's bounce 0 has written)
+	const int batch = (ctx->frame_pipelining && !ctx->params.config.enable_svgf) ? int(std::min<long long>(RT_STREAM_MAX_BATCH, (RT_STREAM_BATCH_PATHS + paths - 1) / paths)) : 1;
 	status = stream_ensure_frames(ctx, sample_count * (num_bounces + 1) * batch); if (status) return status;
 	if (sample_count > s.frame_slots) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_samples: %d samples of a %zu pixel frame exceed the %d sample slots of the merged wavefront", sample_count, ctx->frame_pixels, s.frame_slots);
 	static const double factor = getenv("GRT_STREAM_CAPACITY_FACTOR") ? atof(getenv("GRT_STREAM_CAPACITY_FACTOR")) : 4.0;
@@ -1516,6 +1558,16 @@ static int stream_submit(rt_context * ctx, int sample_index, int sample_count, i
 		ctx->stream_history_rows = 0;
 	}
 	s.in_flight.push_back(sub);
+	if (ctx->params.config.enable_svgf && s.gbuffers[0]) { // the frame starts from the g-buffers of the frame before it
+		const void * from[3];
+		for (int i = 0; i < 3; i++) {
+			if (s.last_gbuffer_slot >= 0) from[i] = (char *)s.gbuffers[i] + ctx->frame_pixels * stream_gbuffer_elem[i] * size_t(s.last_gbuffer_slot);
+			else from[i] = (ctx->last_slot > 0 && ctx->slots[ctx->last_slot].gbuffers[i]) ? ctx->slots[ctx->last_slot].gbuffers[i] : ctx->svgf_buffers[i]; // (the slot scheduler is drained)
+			void * to = (char *)s.gbuffers[i] + ctx->frame_pixels * stream_gbuffer_elem[i] * size_t(slot_base);
+			if (from[i] && from[i] != to) RT_HIP(ctx, hipMemcpyAsync(to, from[i], ctx->frame_pixels * stream_gbuffer_elem[i], hipMemcpyDeviceToDevice, s.stream));
+		}
+		s.last_gbuffer_slot = slot_base;
+	}
 	status = stream_generate(ctx, sub); if (status) return status;
 	if (s.pending < batch && s.pending_paths < RT_STREAM_BATCH_PATHS) return RT_OK;   // wait for more of the same size
 	return stream_enqueue_iteration(ctx);
@@ -1538,10 +1590,12 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	if (ctx->frame_pixels == 0)          return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: rt_resize was not called");
 	if (ctx->bvh_width != 8 && ctx->trace_statistics) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_sample: trace statistics exist for the CWBVH kernels only");
 	// Slot choice: round-robin over the samples in flight. Profiling / statistics passes use one slot,
-	// serialised. SVGF frames pipeline like plain samples: only their filter stage is ordered.
+	// serialised. SVGF frames pipeline like plain samples under either scheduler: only their filter stage is ordered.
 	// Scheduler (see rt_set_scheduler): the merged wavefront where its kernels exist
-	const bool merged = ctx->scheduler == RT_SCHEDULER_MERGED && !ctx->params.config.enable_svgf && ctx->params.config.num_bounces > 0 && ctx->bvh_width == 8
+	const bool merged = ctx->scheduler == RT_SCHEDULER_MERGED && ctx->params.config.num_bounces > 0 && ctx->bvh_width == 8
+	                    && !(ctx->params.config.enable_svgf && ctx->defer_filter) // the tile split of SVGF frames exchanges the filter's inputs per frame
 	                    && !(ctx->batch_size_request > 0); // explicit pixel batches (a VRAM bound of the reference) are a slot-scheduler feature
+	if (ctx->params.config.enable_svgf && sample_count != 1) return fail(ctx, RT_ERROR_INVALID_ARG, "rt_render_samples: SVGF frames are rendered one sample at a time");
 	if (merged != ctx->last_render_merged) { RT_HIP(ctx, quiesce(ctx)); ctx->last_render_merged = merged; }
 	if (merged) {
 		if (ctx->has_material[2] || ctx->has_material[3]) { int ls = ensure_luts(ctx); if (ls) return ls; }
@@ -1565,7 +1619,6 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	int s = ensure_slot(ctx, slot_index); if (s) return s;
 	if (ctx->has_material[2] || ctx->has_material[3]) { s = ensure_luts(ctx); if (s) return s; }
 	SampleSlot & slot = ctx->slots[slot_index];
-	if (ctx->params.config.enable_svgf && sample_count != 1) return fail(ctx, RT_ERROR_INVALID_ARG, "rt_render_samples: SVGF frames are rendered one sample at a time");
 	if (size_t(sample_count) * ctx->frame_pixels >= (1u << 30)) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_samples: %d samples of a %zu pixel frame exceed the 30-bit path index", sample_count, ctx->frame_pixels);
 	s = ensure_aov_batch(ctx, slot_index, sample_count); if (s) return s;
 	RtParams p = slot_params(ctx, slot, slot_index);
@@ -1604,12 +1657,15 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	ctx->stage_used = 0;
 	RT_HIP(ctx, hipEventRecord(slot.ev_frame_start, st));
 	const bool svgf = p.config.enable_svgf != 0;
+	if (svgf && ctx->path_stream.last_gbuffer_slot >= 0) { // the previous frame went through the merged wavefront (which is drained by now)
+		stream_save_gbuffers(ctx);                            // ... into the set of slot 0 (a blocking copy)
+	}
 	if (svgf && ctx->last_slot >= 0 && ctx->last_slot != slot_index) { // inherit the g-buffers of the previous frame
 		SampleSlot & prev = ctx->slots[ctx->last_slot];
 		void * from[3] = { ctx->last_slot == 0 ? ctx->svgf_buffers[0] : prev.gbuffers[0], ctx->last_slot == 0 ? ctx->svgf_buffers[1] : prev.gbuffers[1], ctx->last_slot == 0 ? ctx->svgf_buffers[2] : prev.gbuffers[2] };
 		void * to[3]   = { p.gbuffer_normal_and_depth, p.gbuffer_mesh_id_and_triangle_id, p.gbuffer_screen_position_prev };
 		const size_t elem[3] = { 16, 8, 8 };
-		RT_HIP(ctx, hipStreamWaitEvent(st, prev.ev_gbuffers, 0));
+		if (prev.created) RT_HIP(ctx, hipStreamWaitEvent(st, prev.ev_gbuffers, 0));
 		for (int i = 0; i < 3; i++) if (from[i] && to[i] && from[i] != to[i]) RT_HIP(ctx, hipMemcpyAsync(to[i], from[i], ctx->frame_pixels * elem[i], hipMemcpyDeviceToDevice, st));
 	}
 

@@ -281,7 +281,9 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count);
  *   complete num_bounces - 1 calls later; reads and rt_synchronize run the remaining iterations. Same arithmetic per
  *   path, per-sample frame buffers folded in submission order: images are bit-identical to RT_SCHEDULER_SLOTS.
  *   (The reference runs the chain of one sample at a time, Pathtracer.cpp:738-855: its deep bounces are launches of a
- *   few thousand rays.) SVGF frames, the binary / 4-wide BVH kernels and num_bounces = 0 always use the slot scheduler.
+ *   few thousand rays.) SVGF frames go through it as well: every sample slot has its own g-buffer set, a frame is
+ *   filtered when it has passed its last bounce, frames in submission order. The binary / 4-wide BVH kernels,
+ *   num_bounces = 0, explicit pixel batches and the SVGF tile split always use the slot scheduler.
  * RT_SCHEDULER_SLOTS: one launch chain per submission, up to rt_set_samples_in_flight chains concurrently on their own
  *   streams, each reading the scene version (TLAS, instances, lights) that was current when it was submitted: the
  *   choice for scenes that upload a new TLAS every frame.                                                           */

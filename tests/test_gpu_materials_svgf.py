@@ -109,20 +109,28 @@ def test_svgf_taa_pipeline_matches_oracle(grt, oracle, taa):
 
 
 def test_svgf_frames_pipeline_without_changing_the_image(grt):
-    """SVGF frames in flight (per-slot g-buffers, the filter stage ordered by events): six frames
-    submitted back to back with 1 and with 3 frames in flight give bit-identical filtered images,
-    also where rays miss all geometry (those pixels keep the g-buffer of the last frame that hit)."""
-    images = []
-    for in_flight in (1, 3):
+    """SVGF frames in flight: six frames submitted back to back give bit-identical filtered images under the slot
+    scheduler with 1 and with 3 frames in flight (per-slot g-buffers, the filter stage ordered by events), in the merged
+    wavefront (per-sample-slot g-buffers, the filter stage of a frame when it has passed its last bounce), and when the
+    scheduler changes in the middle of the sequence (the g-buffers of the last frame are handed over) -- also where rays
+    miss all geometry (those pixels keep the g-buffer of the last frame that hit)."""
+    images = {}
+    for label, schedule in (("slots, 1 in flight", ["slots"] * 6), ("slots, 3 in flight", ["slots"] * 6), ("merged", ["merged"] * 6),
+                            ("merged then slots", ["merged"] * 3 + ["slots"] * 3), ("slots then merged", ["slots"] * 2 + ["merged"] * 4)):
         scene, pt = make_pathtracer(grt, "cornellbox", 200, 150, 0, num_bounces=4, enable_svgf=1, enable_taa=1)
-        grt.set_samples_in_flight(pt.ctx, in_flight)
-        for f in range(6):
+        grt.set_samples_in_flight(pt.ctx, 1 if "1 in flight" in label else 3)
+        for f, scheduler in enumerate(schedule):
             if f:
                 pt.update()
+            if f == 0 or scheduler != schedule[f - 1]:
+                grt.set_scheduler(pt.ctx, scheduler)   # (completes what is in flight)
             pt.render()
-        images.append(pt.read_framebuffer().copy())
+        images[label] = pt.read_framebuffer().copy()
         pt.close(); scene.close()
-    assert np.array_equal(images[0], images[1]) and np.isfinite(images[0]).all() and images[0][..., :3].max() > 0.0
+    first = images["slots, 1 in flight"]
+    assert np.isfinite(first).all() and first[..., :3].max() > 0.0
+    for label, image in images.items():
+        assert np.array_equal(image, first), label
 
 
 @pytest.mark.parametrize("bsdf,lo,hi", [

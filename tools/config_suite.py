@@ -93,7 +93,7 @@ def measure(pt, samples, batch, label, svgf=False):
     rays /= min(samples, 4); shadow /= min(samples, 4)
     grt.set_trace_statistics(ctx, False)
     frame(); lib.rt_synchronize(ctx)
-    reps = 6
+    reps = 16 if svgf else 6   # SVGF: 64 filtered frames, so that the 9 iterations that drain the wavefront do not dominate
     t0 = time.perf_counter()
     for _ in range(reps):
         frame()
@@ -106,12 +106,17 @@ def measure(pt, samples, batch, label, svgf=False):
 
 def main():
     cache = os.path.join(ROOT, "assets", "_cache", "configs")
-    # config 3
-    scene = bench.build_scene(grt)
-    grt.config_set(enable_svgf=1, enable_taa=1, num_atrous_iterations=6)
-    pt = grt.Pathtracer(scene, W, H, device=0); pt.update()
-    measure(pt, 4, 1, "config 3  Sponza + SVGF/TAA (1 sample per filtered frame)", svgf=True)
-    pt.close(); scene.close()
+    only = os.environ.get("CONFIG_ONLY", "")
+    # config 3 (under both schedulers: the merged wavefront is the default, the per-frame launch chains are round 1's)
+    for scheduler in ("merged", "slots"):
+        scene = bench.build_scene(grt)
+        grt.config_set(enable_svgf=1, enable_taa=1, num_atrous_iterations=6)
+        pt = grt.Pathtracer(scene, W, H, device=0); pt.update()
+        grt.set_scheduler(pt.ctx, scheduler)
+        measure(pt, 4, 1, "config 3  Sponza + SVGF/TAA (1 sample per filtered frame), %s scheduler" % scheduler, svgf=True)
+        pt.close(); scene.close()
+    if only == "3":
+        return
     # config 4
     grt.config_reset()
     t0 = time.perf_counter()
