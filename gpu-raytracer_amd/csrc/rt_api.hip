@@ -1523,7 +1523,7 @@ static int stream_submit(rt_context * ctx, int sample_index, int sample_count, i
 			for (int k = 0; k < sample_count; k++) if (s.slot_used[candidate + k]) { free_run = false; break; }
 			if (free_run) slot_base = candidate;
 		}
-		bool fits = stream_bound(s) + paths <= (long long)s.capacity;
+		bool fits = stream_bound(s) + s.pending_paths + paths <= (long long)s.capacity;   // (with the submissions already waiting for the next iteration)
 		if (ring_free && slot_base >= 0 && fits) break;
 		if (!fits && s.known_iteration < s.iteration - 1 && s.iteration > s.base_iteration) { // the bound is stale: let the device catch up
 			RT_HIP(ctx, hipEventSynchronize(s.iteration_done[(s.iteration - 1) % RT_STREAM_PROGRESS_RING]));
@@ -1727,7 +1727,7 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 
 	// The accumulate step folds this sample into the shared accumulators: strictly in sample order.
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
-	if (ctx->last_slot >= 0 && ctx->last_slot != slot_index) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[ctx->last_slot].ev_done, 0));
+	if (ctx->last_slot >= 0 && ctx->last_slot != slot_index && ctx->slots[ctx->last_slot].created) RT_HIP(ctx, hipStreamWaitEvent(st, ctx->slots[ctx->last_slot].ev_done, 0));
 	stage_mark(ctx, STAGE_POST, st);
 	const bool deferred = p.config.enable_svgf && ctx->defer_filter; // rt_filter_frame does the rest once the ranks have exchanged their tiles
 	if (deferred) { }
