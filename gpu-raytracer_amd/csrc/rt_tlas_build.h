@@ -90,17 +90,18 @@ RT_HD int tlas_split(const uint64_t * keys, int lo, int hi) {
 }
 
 // Up to eight child runs of [lo, hi): the largest run is cut until there are eight or only single instances are left.
-// Returns the number of runs; run c is [begin[c], begin[c + 1]).
+// Returns the number of runs; run c is [begin[c], begin[c + 1]). (Every index into begin[] is a loop counter of a loop with
+// constant bounds: unrolled on the device the array lives in registers, not in scratch memory.)
 RT_HD int tlas_child_runs(const uint64_t * keys, int lo, int hi, int begin[9]) {
 	int count = 1;
 	begin[0] = lo; begin[1] = hi;
-	while (count < 8) {
-		int widest = -1, width = 1;
-		for (int c = 0; c < count; c++) if (begin[c + 1] - begin[c] > width) { width = begin[c + 1] - begin[c]; widest = c; }
+	for (int c = 2; c < 9; c++) begin[c] = hi;
+	for (int round = 0; round < 7; round++) {
+		int widest = -1, width = 1, widest_lo = 0, widest_hi = 0;
+		for (int c = 0; c < 8; c++) if (c < count && begin[c + 1] - begin[c] > width) { width = begin[c + 1] - begin[c]; widest = c; widest_lo = begin[c]; widest_hi = begin[c + 1]; }
 		if (widest < 0) break;
-		int cut = tlas_split(keys, begin[widest], begin[widest + 1]);
-		for (int c = count; c > widest; c--) begin[c + 1] = begin[c];
-		begin[widest + 1] = cut;
+		int cut = tlas_split(keys, widest_lo, widest_hi);
+		for (int c = 8; c >= 1; c--) { if (c > widest + 1) begin[c] = begin[c - 1]; else if (c == widest + 1) begin[c] = cut; }
 		count++;
 	}
 	return count;
