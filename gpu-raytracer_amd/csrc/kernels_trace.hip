@@ -351,7 +351,10 @@ template<int MODE, typename Source> RT_DEV void source_finish(const Source & src
 	if constexpr (MODE == RT_TRACE_MIXED) src.finish(shadow, i, hit, occluded); else src.finish(i, hit, occluded);
 }
 
-template<int MODE, bool COUNT, bool NARROW, typename Source>
+// UNIFIED: the TLAS nodes have been copied into the slots [0, tlas_node_count) that the BLAS node array reserves for them
+// (the merged wavefront does that whenever the TLAS changes, rt_api.hip: stream_sync_tlas), so a node is fetched from ONE
+// base address: no compare / select of two 64-bit bases and no scalar load of the TLAS size in every round.
+template<int MODE, bool COUNT, bool NARROW, bool UNIFIED = false, typename Source>
 RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr, int ray_count_2 = 0, int * cursor_2 = nullptr) {
 	constexpr bool SHADOW = MODE == RT_TRACE_SHADOW;   // the kind of every ray, unless MODE == RT_TRACE_MIXED: then lane_shadow
 	bool lane_shadow = SHADOW;
@@ -456,7 +459,9 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 		}
 
 		int iterations_lost = 0;
+		bool running = true;   // a lane that has finished its ray idles (masked) until the wave refills
 		do {
+			if (running) {
 			// ---- node phase: lanes with no triangle work pending advance their traversal by one step
 			if (triangle_group.y == 0) {
 				if (current_group.y & 0xff000000u) {
@@ -472,7 +477,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					unsigned relative_index = __popc(hits_imask & ~(0xffffffffu << slot_index));
 					unsigned child_node_index = child_index_base + relative_index;
 
-					const float4 * node = (child_node_index < unsigned(p.tlas_node_count) ? p.tlas_nodes : nodes) + size_t(child_node_index) * 5;
+					const float4 * node = (!UNIFIED && child_node_index < unsigned(p.tlas_node_count) ? p.tlas_nodes : nodes) + size_t(child_node_index) * 5;
 					float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
 					if (COUNT) count_nodes++;
 #ifdef RT_PHASE_STATS
@@ -610,15 +615,15 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 				stack.size = 0;
 				current_group.y = 0;
 				triangle_group.y = 0;
-				break;
+				running = false;
 			}
 
-			if (triangle_group.y == 0 && (current_group.y & 0xff000000u) == 0) {
+			if (running && triangle_group.y == 0 && (current_group.y & 0xff000000u) == 0) {
 				if (stack.size == 0) {
 					if (!NARROW || group_child == 0) source_finish<MODE>(src, RT_IS_SHADOW, ray_index, hit, false);
 					current_group.y = 0;
-					break;
-				}
+					running = false;
+				} else {
 				if (stack.size == tlas_stack_size) {
 					tlas_stack_size = RT_INVALID;
 					if (!mesh_has_identity_transform) {
@@ -629,9 +634,11 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					}
 				}
 				current_group = stack.pop();
+				}
+			}
 			}
 
-			iterations_lost += RT_WAVE_SIZE - __popcll(__ballot(1)) - RT_N_D;
+			iterations_lost += RT_WAVE_SIZE - __popcll(__ballot(running)) - RT_N_D;
 		} while (iterations_lost < RT_N_W);
 	}
 	#undef RT_IS_SHADOW
@@ -1143,12 +1150,12 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	//     where it was a compile-time constant) and a 25 M-ray launch has little to gain from it (0.87 -> 0.83 when mixed).
 	//   profiles/r02_mixed_engine.txt
 	if (!COUNT && closest_count + shadow_count <= RT_NARROW_MAX_RAYS)
-		bvh8_trace_engine<RT_TRACE_MIXED, false, true>(p, src, closest_count, &p.stream->cursor[q][0], nullptr, shadow_count, &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_MIXED, false, true, true>(p, src, closest_count, &p.stream->cursor[q][0], nullptr, shadow_count, &p.stream->cursor[q][1]);
 	else if (COUNT || closest_count + shadow_count <= RT_MIXED_MAX_RAYS)
-		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
 	else {
-		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
-		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
+		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
 	}
 }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8(RtParams p) { trace_stream<false>(p, nullptr); }

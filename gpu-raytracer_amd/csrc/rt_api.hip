@@ -160,6 +160,7 @@ struct rt_context {
 
 	// named allocations that get replaced on re-upload
 	void * triangles = nullptr, * triangle_positions = nullptr, * bvh8_nodes = nullptr, * bvh2_nodes = nullptr, * bvh4_nodes = nullptr;
+	unsigned long long tlas_version = 0, tlas_version_in_nodes = ~0ull;   // the merged wavefront traces a copy of the TLAS inside the BLAS node array (stream_sync_tlas)
 	size_t bvh4_node_count = 0;
 	size_t bvh8_node_count = 0, bvh2_node_count = 0, triangle_count = 0;
 	size_t mesh_count = 0;
@@ -466,6 +467,7 @@ int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle
 	s = upload(ctx, &ctx->bvh8_nodes, bvh8_nodes, node_count * 80); if (s) return s;
 	s = upload_triangle_positions(ctx, triangles, triangle_count); if (s) return s;
 	ctx->triangle_count = triangle_count; ctx->bvh8_node_count = node_count;
+	ctx->tlas_version_in_nodes = ~0ull;
 	ctx->params.triangles  = (const float4 *)ctx->triangles;
 	ctx->params.bvh8_nodes = (const float4 *)ctx->bvh8_nodes;
 	return RT_OK;
@@ -479,6 +481,7 @@ static int upload_tlas_version(rt_context * ctx, const void * tlas_nodes, size_t
 	s = ring_commit(ctx, ctx->tlas_ring); if (s) return s;
 	ctx->params.tlas_nodes = (const float4 *)ctx->tlas_ring.device[ctx->tlas_ring.current];
 	ctx->params.tlas_node_count = int(tlas_node_count);
+	ctx->tlas_version++;
 	return RT_OK;
 }
 
@@ -626,6 +629,7 @@ int rt_build_tlas(rt_context * ctx, const int32_t * root_indices, const int32_t 
 	ctx->mesh_count = n;
 	ctx->params.tlas_nodes = (const float4 *)tlas_device;
 	ctx->params.tlas_node_count = int(2 * n);     // the node slots reserved for the TLAS; BLAS nodes start behind them
+	ctx->tlas_version++;
 	ctx->params.mesh_bvh_root_indices = a.out_root_indices;
 	ctx->params.mesh_material_ids     = a.out_material_ids;
 	ctx->params.mesh_transforms       = a.out_transforms;
@@ -1427,6 +1431,21 @@ static int stream_complete(rt_context * ctx, const StreamSubmission * subs, int 
 	return RT_OK;
 }
 
+// The fused traversal launch fetches every node from ONE array: the TLAS (which lives in a ring of versions, for the
+// per-submission chains that keep frames of different scene versions in flight) is copied into the slots [0, node count)
+// that the BLAS node array reserves for it -- node indices below the TLAS size never name BLAS nodes. Nothing of the merged
+// wavefront is in flight when the TLAS changes (every upload completes it first), and the other kernels never read those slots.
+static int stream_sync_tlas(rt_context * ctx) {
+	if (ctx->tlas_version_in_nodes == ctx->tlas_version) return RT_OK;
+	if (!ctx->params.tlas_nodes || ctx->params.tlas_node_count <= 0) { ctx->tlas_version_in_nodes = ctx->tlas_version; return RT_OK; }   // one BVH, no TLAS: node 0 is its root
+	if (!ctx->bvh8_nodes || size_t(ctx->params.tlas_node_count) > ctx->bvh8_node_count) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_samples: the TLAS does not fit the node slots the geometry reserves for it");
+	hipStream_t st = ctx->path_stream.stream;
+	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));
+	RT_HIP(ctx, hipMemcpyAsync(ctx->bvh8_nodes, ctx->params.tlas_nodes, size_t(ctx->params.tlas_node_count) * 80, hipMemcpyDeviceToDevice, st));
+	ctx->tlas_version_in_nodes = ctx->tlas_version;
+	return RT_OK;
+}
+
 // The primary rays of a new submission: appended to the trace queue of the iteration that is enqueued next, behind the
 // rays of the submissions already waiting for it.
 static int stream_generate(rt_context * ctx, const StreamSubmission & sub) {
@@ -1568,6 +1587,7 @@ static int stream_submit(rt_context * ctx, int sample_index, int sample_count, i
 		}
 		s.last_gbuffer_slot = slot_base;
 	}
+	status = stream_sync_tlas(ctx); if (status) return status;
 	status = stream_generate(ctx, sub); if (status) return status;
 	if (s.pending < batch && s.pending_paths < RT_STREAM_BATCH_PATHS) return RT_OK;   // wait for more of the same size
 	return stream_enqueue_iteration(ctx);
