@@ -332,6 +332,11 @@ struct TraversalStack {
 // engine inside one kernel share ONE allocation.
 __shared__ uint2 shared_stack[(RT_TRACE_BLOCK / RT_WAVE_SIZE) * RT_LDS_STACK * RT_WAVE_SIZE];
 __shared__ int   shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4]; // per wave: next, end, drained
+// The fused launch of the merged wavefront: BLAS root (| identity flag) of every instance of a small scene. A ray enters ~8
+// instances on Sponza, and the root index was a dependent global load (TLAS leaf -> root index -> root node) with a full
+// wait behind it in the middle of a round; from LDS it costs a fraction of that latency.
+#define RT_ROOTS_IN_LDS 1024
+__shared__ int   shared_roots[RT_ROOTS_IN_LDS];
 
 // The common traversal engine. RaySource supplies rays and consumes results so that the same
 // code serves the wavefront queues and the stand-alone entry points.
@@ -511,7 +516,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 				tlas_stack_size = stack.size;
 				triangle_group.y = 0;
 
-				unsigned root = unsigned(p.mesh_bvh_root_indices[mesh_id]);
+				unsigned root = unsigned(UNIFIED && p.mesh_count <= RT_ROOTS_IN_LDS ? shared_roots[mesh_id] : p.mesh_bvh_root_indices[mesh_id]);
 				mesh_has_identity_transform = (root >> 31) != 0;
 				if (!mesh_has_identity_transform) {
 					const float4 * m = p.mesh_transforms_inv + size_t(mesh_id) * 3;
@@ -1141,6 +1146,10 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	MixedStreamSource src { { p.trace[q].origin, p.trace[q].direction, p.trace[q].hits },
 	                        { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT] } };
 	const int closest_count = p.stream->trace_count[q], shadow_count = p.stream->shadow_count[q ^ 1];
+	if (p.mesh_count <= RT_ROOTS_IN_LDS) {   // (uniform over the launch; before any wave leaves the kernel)
+		for (int i = threadIdx.x; i < p.mesh_count; i += RT_TRACE_BLOCK) shared_roots[i] = p.mesh_bvh_root_indices[i];
+		__syncthreads();
+	}
 	// Which engine (the counts are only known on the device; the choice is uniform over the launch):
 	//   * few rays (the fill and drain iterations of the wavefront): 8 lanes per ray, see the narrow mode;
 	//   * up to RT_MIXED_MAX_RAYS: mixed kinds -- a lane that finds the closest-hit queue drained takes a shadow ray at once.

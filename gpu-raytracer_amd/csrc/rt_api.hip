@@ -554,7 +554,7 @@ int rt_upload_instances(rt_context * ctx, const int32_t * root_indices, const in
 	for (int i = 0; i < 5; i++) memcpy((char *)staging + offset[i], src[i], bytes[i]);
 	s = ring_commit(ctx, ctx->instance_ring); if (s) return s;
 	const char * base = (const char *)ctx->instance_ring.device[ctx->instance_ring.current];
-	ctx->mesh_count = mesh_count;
+	ctx->mesh_count = mesh_count; ctx->params.mesh_count = int(mesh_count);
 	ctx->params.mesh_bvh_root_indices = (const int *)(base + offset[0]);
 	ctx->params.mesh_material_ids     = (const int *)(base + offset[1]);
 	ctx->params.mesh_transforms       = (const float4 *)(base + offset[2]);
@@ -626,7 +626,7 @@ int rt_build_tlas(rt_context * ctx, const int32_t * root_indices, const int32_t 
 	RT_HIP(ctx, hipEventRecord(ctx->tlas_ring.copied[ctx->tlas_ring.current], ctx->stream));
 	RT_HIP(ctx, hipEventRecord(ctx->ev_scene, ctx->stream));
 
-	ctx->mesh_count = n;
+	ctx->mesh_count = n; ctx->params.mesh_count = int(n);
 	ctx->params.tlas_nodes = (const float4 *)tlas_device;
 	ctx->params.tlas_node_count = int(2 * n);     // the node slots reserved for the TLAS; BLAS nodes start behind them
 	ctx->tlas_version++;
