@@ -447,9 +447,17 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 	#define RT_PHASE_LEADER() (__builtin_amdgcn_mbcnt_hi(unsigned(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(__ballot(1)), 0u)) == 0)
 #endif
 
+	// A finished ray hands over its result at the next refill, together with the other lanes that finished since the last
+	// one: inside the loop the hand-over ran in almost every round for 2-3 of 64 lanes, and its stores sat in front of the
+	// next round's loads (one counter for both on this chip: a wait for a load is a wait for every store before it).
+	int result_pending = 0;   // 1: finished (closest hit or a shadow ray that reached its light), 2: shadow ray occluded
 	while (true) {
 		bool inactive = stack.size == 0 && current_group.y == 0 && triangle_group.y == 0;
 
+		if (result_pending) {
+			if (!NARROW || group_child == 0) source_finish<MODE>(src, RT_IS_SHADOW, ray_index, hit, result_pending == 2);
+			result_pending = 0;
+		}
 		if (inactive) {
 			ray_index = fetch_ray();
 			if (ray_index < 0) return;
@@ -616,7 +624,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 #endif
 			}
 			if (RT_IS_SHADOW && occluded) {
-				if (!NARROW || group_child == 0) source_finish<MODE>(src, true, ray_index, hit, true);
+				result_pending = 2;
 				stack.size = 0;
 				current_group.y = 0;
 				triangle_group.y = 0;
@@ -625,7 +633,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 
 			if (running && triangle_group.y == 0 && (current_group.y & 0xff000000u) == 0) {
 				if (stack.size == 0) {
-					if (!NARROW || group_child == 0) source_finish<MODE>(src, RT_IS_SHADOW, ray_index, hit, false);
+					result_pending = 1;
 					current_group.y = 0;
 					running = false;
 				} else {
