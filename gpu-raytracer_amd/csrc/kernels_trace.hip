@@ -31,14 +31,15 @@
 #include <cstdlib>
 
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK   12   // stack entries per lane kept in LDS (6 KB per wave; 20 waves per CU = 120 KB of 160 KB)
+#define RT_LDS_STACK   10   // stack entries per lane kept in LDS (5 KB per wave; 24 waves per CU = 120 KB of 160 KB)
 #endif
 #define RT_STACK_SIZE  32   // total entries per lane (reference: BVH_STACK_SIZE, Common.h:103)
 #define RT_TRACE_BLOCK 256  // 4 waves per workgroup
 #ifndef RT_TRACE_WAVES_PER_SIMD
-// Measured on MI355X (profiles/r01_trace_variants.txt): 5 waves/SIMD (<= 96 VGPRs, no spills) beats 6 and
-// 8 (64 VGPRs, 13 dwords of scratch spills in the loop); throughput is not limited by the wave count.
-#define RT_TRACE_WAVES_PER_SIMD 5
+// Round 1 (profiles/r01_trace_variants.txt): 5 waves/SIMD (<= 96 VGPRs, no spills) beat 6 and 8. Round 2, with the loop
+// ~50 instructions shorter and its dependent loads cut (profiles/r02_traversal_loop.txt): 6 waves/SIMD (80 VGPRs, 20 dwords
+// spilled, 3 scratch accesses per round) is 2.2 % faster per step than 5, 7 (72 VGPRs, 49 dwords) 2.7 % slower than 6.
+#define RT_TRACE_WAVES_PER_SIMD 6
 #endif
 // (Per-XCD chunks of the ray range -- L2 affinity via HW_REG_XCC_ID -- were tried and measured slower
 // than one shared cursor: 1.84 vs 2.01 Grays/s at 8M incoherent rays; see profiles/r01_trace_variants.txt.)
