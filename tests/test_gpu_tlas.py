@@ -104,3 +104,28 @@ def test_frames_with_a_device_tlas_match_the_oracle_while_instances_move(grt, or
         pt.close(); scene.close()
     assert np.array_equal(images[0], images[1]) and images[0][..., :3].max() > 0.0
     grt.config_reset()
+
+
+def test_merged_wavefront_on_a_scene_with_more_instances_than_its_lds_root_table(grt, tmp_path):
+    """The fused traversal launch keeps the BLAS roots of up to 1 024 instances in LDS and fetches every node -- TLAS nodes
+    included -- from the BLAS node array, into whose reserved slots the TLAS is copied. Beyond 1 024 instances the roots
+    come from global memory: frames of a 1 203-instance scene (host TLAS and device TLAS) are bit-identical under the
+    merged wavefront and under the per-submission chains, whose kernels read the TLAS from its own buffer."""
+    import ctypes
+    path = instanced_scene_file(str(tmp_path / "s"), count=1200)
+    lib = grt.device_lib()
+    lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    for device_tlas in (0, 1):
+        images = []
+        for scheduler in ("merged", "slots"):
+            grt.config_reset(); grt.config_set(device_tlas=device_tlas, num_bounces=4)
+            scene = grt.Scene(path)
+            pt = grt.Pathtracer(scene, 160, 100, device=0); pt.update()
+            assert scene.mesh_count > 1024
+            grt.set_scheduler(pt.ctx, scheduler)
+            for first in (0, 2, 4):
+                assert lib.rt_render_samples(pt.ctx, first, 2) == 0
+            images.append(pt.read_framebuffer().copy())
+            pt.close(); scene.close()
+        assert np.array_equal(images[0], images[1]) and images[0][..., :3].max() > 0, device_tlas
+    grt.config_reset()
