@@ -1061,11 +1061,18 @@ void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_o
 void rt_launch_stream_advance(RtStreamControl * control, int iteration, int generated, int * progress, hipStream_t stream) {
 	hipLaunchKernelGGL(kernel_stream_advance, dim3(1), dim3(1), 0, stream, control, iteration, generated, (volatile int *)progress);
 }
+#ifndef RT_STREAM_SHADE_GRID
+#define RT_STREAM_SHADE_GRID 8192   // workgroups of the grid-stride shade launches of the merged wavefront: 2 048 (two rounds of
+                                    // resident workgroups) left 2.7 of 4 waves per SIMD resident on average; 8 192: shade stage -9 %, step -2.4 %
+#endif
+#ifndef RT_STREAM_SORT_GRID
+#define RT_STREAM_SORT_GRID 2048    // ... and of its sort launch (in units of RT_SHADE_BLOCK threads)
+#endif
 void rt_launch_sort_stream(const RtParams & p, hipStream_t stream) {
-	hipLaunchKernelGGL(kernel_sort_stream, dim3(2048 * RT_SHADE_BLOCK / RT_SORT_BLOCK), dim3(RT_SORT_BLOCK), 0, stream, p);
+	hipLaunchKernelGGL(kernel_sort_stream, dim3(RT_STREAM_SORT_GRID * RT_SHADE_BLOCK / RT_SORT_BLOCK), dim3(RT_SORT_BLOCK), 0, stream, p);
 }
 void rt_launch_material_stream(const RtParams & p, int material_slot, hipStream_t stream) {
-	dim3 grid(2048), block(RT_SHADE_BLOCK);
+	dim3 grid(RT_STREAM_SHADE_GRID), block(RT_SHADE_BLOCK);
 	switch (material_slot) {
 		case 0: hipLaunchKernelGGL(kernel_material_diffuse_stream,    grid, block, 0, stream, p); break;
 		case 1: hipLaunchKernelGGL(kernel_material_plastic_stream,    grid, block, 0, stream, p); break;
