@@ -479,6 +479,13 @@ def main():
             # hardware counters of the same command (separate rocprofv3 --pmc passes); this process lets go of the GPU first
             pt.close(); scene.close(); closed = True
             result["roofline"].update(pmc_section(args, rays_plan / args.steps, launch_ms, plan))
+            r = result["roofline"]
+            if r.get("traffic") and r.get("algorithmic_bytes_per_launch"):
+                # how much of what the traversal reads is served by the caches (L1 + L2 + Infinity Cache together): the
+                # algorithmic bytes are a lower bound of its requests, the memory-side traffic is what got past the caches
+                r["cache_hit_fraction_lower_bound"] = round(1.0 - r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
+                r["bound_in_practice"] = ("VALU issue and the dependent chain of each ray: vector ALUs busy %.2f at a lane utilisation of %.2f; the memory side moves %.0f %% of the algorithmic bytes, which is why frac can exceed 1 (DESIGN.md 4.1, profiles/r02_valu_experiments.txt)"
+                                          % (r.get("counters", {}).get("valu_busy", float("nan")), r.get("counters", {}).get("valu_lane_utilisation", float("nan")), 100.0 * r["traffic"] / r["algorithmic_bytes_per_launch"]))
         print(json.dumps(result))
 
     if not closed:
