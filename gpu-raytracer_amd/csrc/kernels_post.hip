@@ -120,14 +120,41 @@ RT_DEV bool is_tap_consistent(const RtParams & p, int x, int y, f3 normal, float
 	return dot(normal, prev_normal) > 0.95f && fabsf(depth - prev.z) < 2.0f;
 }
 
+// The edge-stopping weights of the variance and a-trous filters (SVGF.h:268-282):
+//     w = max(0, n . n')^sigma_n * exp(-|l - l'| * denom - |z - z'| / (sigma_z |grad z . delta| + eps))
+// 8 resp. 48 taps per pixel, two weights (direct, indirect) per tap. Written with powf / expf of the device library (full
+// range, correctly-rounded-ish: ~200 + 2 x 30 VALU instructions per tap) the six a-trous passes of a 1080p frame cost 0.7 ms
+// of VALU time for 0.2 ms of memory traffic. Both weights are ONE power of two each:
+//     w = exp2(sigma_n * log2(n . n') - (|l - l'| * denom + ln_w_z) * log2(e))
+// on the hardware's v_log_f32 / v_exp_f32 / v_rcp_f32 (1 ulp each). A weight is accurate to ~1e-5 relative (the exponent's
+// absolute error is sigma_n = 128 times 2^-24), far inside what the filter's tests allow (images within 1e-3 of the oracle's,
+// tests/test_gpu_materials_svgf.py) -- and the oracle's own libm differs from the reference's --use_fast_math intrinsics
+// by more. Nothing that decides a threshold (reprojection consistency, history lengths) goes through here.
+RT_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+RT_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+RT_DEV float fast_rcp(float x)  { return __builtin_amdgcn_rcpf(x); }
+
 RT_DEV f2 edge_stopping_weights(const RtParams & p, int delta_x, int delta_y, f2 center_depth_gradient, float center_depth, float depth,
 		f3 center_normal, f3 normal, float cl_direct, float cl_indirect, float l_direct, float l_indirect, float denom_direct, float denom_indirect) {
+	const float log2_e = 1.44269504088896340736f;
 	float d = center_depth_gradient.x * float(delta_x) + center_depth_gradient.y * float(delta_y);
-	float ln_w_z = fabsf(center_depth - depth) / (p.config.sigma_z * fabsf(d) + RT_SVGF_EPSILON);
-	float w_n = powf(fmaxf(0.0f, dot(center_normal, normal)), p.config.sigma_n);
-	float w_l_direct   = w_n * expf(-fabsf(cl_direct   - l_direct)   * denom_direct   - ln_w_z);
-	float w_l_indirect = w_n * expf(-fabsf(cl_indirect - l_indirect) * denom_indirect - ln_w_z);
+	float ln_w_z = fabsf(center_depth - depth) * fast_rcp(p.config.sigma_z * fabsf(d) + RT_SVGF_EPSILON);
+	float n_dot_n = fmaxf(0.0f, dot(center_normal, normal));
+	// pow(0, sigma_n) = 0 for sigma_n > 0 and 1 for sigma_n = 0; log2(0) = -inf does the first, the second needs the select
+	float log2_w_n = (n_dot_n > 0.0f || p.config.sigma_n > 0.0f) ? p.config.sigma_n * fast_log2(n_dot_n) : 0.0f;
+	float w_l_direct   = fast_exp2(log2_w_n - (fabsf(cl_direct   - l_direct)   * denom_direct   + ln_w_z) * log2_e);
+	float w_l_indirect = fast_exp2(log2_w_n - (fabsf(cl_indirect - l_indirect) * denom_indirect + ln_w_z) * log2_e);
 	return mk2(w_l_direct, w_l_indirect);
+}
+
+// Normal of a g-buffer texel for the filters' weights: the same decoding with v_rsq_f32 (1 ulp) for the normalisation.
+RT_DEV f3 oct_decode_normal_fast(f2 f) {
+	f = mk2(f.x * 2.0f - 1.0f, f.y * 2.0f - 1.0f);
+	f3 n = mk3(f.x, f.y, 1.0f - fabsf(f.x) - fabsf(f.y));
+	float t = saturate(-n.z);
+	n.x += n.x >= 0.0f ? -t : t;
+	n.y += n.y >= 0.0f ? -t : t;
+	return n * __builtin_amdgcn_rsqf(dot(n, n));
 }
 
 __global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p) {
@@ -243,7 +270,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 	float cl_d = luminance(cd.x, cd.y, cd.z), cl_i = luminance(ci.x, ci.y, ci.z);
 
 	float4 cnd = p.gbuffer_normal_and_depth[pixel_index];
-	f3 center_normal = oct_decode_normal(mk2(cnd.x, cnd.y));
+	f3 center_normal = oct_decode_normal_fast(mk2(cnd.x, cnd.y));
 	float center_depth = cnd.z;
 	int xr = min(x + 1, p.screen_pitch - 1), yd = min(y + 1, p.screen_height - 1);
 	f2 grad = mk2(p.gbuffer_normal_and_depth[xr + y * p.screen_pitch].z - center_depth,
@@ -266,7 +293,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 			f4 td = ld4(d_in, tap_index), ti = ld4(i_in, tap_index), moment = ld4(p.frame_buffer_moment, tap_index);
 			float l_d = luminance(td.x, td.y, td.z), l_i = luminance(ti.x, ti.y, ti.z);
 			float4 nd = p.gbuffer_normal_and_depth[tap_index];
-			f3 normal = oct_decode_normal(mk2(nd.x, nd.y));
+			f3 normal = oct_decode_normal_fast(mk2(nd.x, nd.y));
 			f2 w = edge_stopping_weights(p, i, j, grad, center_depth, nd.z, center_normal, normal, cl_d, cl_i, l_d, l_i, luminance_denom, luminance_denom);
 			sw_d += w.x; sw_i += w.y;
 			sc_d += w.x * td;
@@ -308,7 +335,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const floa
 	float cl_d = luminance(cd.x, cd.y, cd.z), cl_i = luminance(ci.x, ci.y, ci.z);
 
 	float4 cnd = p.gbuffer_normal_and_depth[pixel_index];
-	f3 center_normal = oct_decode_normal(mk2(cnd.x, cnd.y));
+	f3 center_normal = oct_decode_normal_fast(mk2(cnd.x, cnd.y));
 	float center_depth = cnd.z;
 	if (center_depth == 0.0f) return; // sky: outputs intentionally not written (SVGF.h:462)
 
@@ -329,7 +356,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const floa
 			f4 td = ld4(d_in, tap_index), ti = ld4(i_in, tap_index);
 			float l_d = luminance(td.x, td.y, td.z), l_i = luminance(ti.x, ti.y, ti.z);
 			float4 nd = p.gbuffer_normal_and_depth[tap_index];
-			f3 normal = oct_decode_normal(mk2(nd.x, nd.y));
+			f3 normal = oct_decode_normal_fast(mk2(nd.x, nd.y));
 			f2 w = edge_stopping_weights(p, i * step_size, j * step_size, grad, center_depth, nd.z, center_normal, normal, cl_d, cl_i, l_d, l_i, denom_d, denom_i);
 			sw_d += w.x; sw_i += w.y;
 			sc_d += mk4(w.x, w.x, w.x, w.x * w.x) * td;

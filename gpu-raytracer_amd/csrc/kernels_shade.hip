@@ -17,6 +17,14 @@
 // (3 waves per SIMD). Asking for 4 waves caps them at 128 registers: one more wave to hide the latency behind.
 #define RT_SHADE_WAVES 4
 #endif
+#ifndef RT_OCTANT_BUCKETS
+#define RT_OCTANT_BUCKETS 1   // a shade workgroup appends its rays ordered by direction octant (rt_math.h: block_bucketed_append)
+#endif
+#if RT_OCTANT_BUCKETS
+#define RT_RAY_BUCKET(d) direction_octant(d)
+#else
+#define RT_RAY_BUCKET(d) 0u
+#endif
 #ifndef RT_SORT_BLOCK
 #define RT_SORT_BLOCK 512   // kernel_sort: 8 waves share one atomic per material queue
 #endif
@@ -814,10 +822,10 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 	const int buffer_size = MERGED ? p.stream->material_count[SLOT]
 	                               : (SLOT == 0 ? p.sizes->diffuse[launch_bounce] : SLOT == 1 ? p.sizes->plastic[launch_bounce] : SLOT == 2 ? p.sizes->dielectric[launch_bounce] : p.sizes->conductor[launch_bounce]);
 
-	__shared__ BlockAppendLDS<1, RT_SHADE_BLOCK / RT_WAVE_SIZE> append_lds;
+	__shared__ BlockBucketLDS<RT_SHADE_BLOCK / RT_WAVE_SIZE> append_lds;
 	__shared__ StreamStatsLDS stats_lds;
-	int * const shadow_counter[1] = { MERGED ? &p.stream->shadow_count[iq]      : &p.sizes->shadow[launch_bounce] };
-	int * const trace_counter[1]  = { MERGED ? &p.stream->trace_count[iq ^ 1]   : &p.sizes->trace[launch_bounce + 1] };
+	int * const shadow_counter = MERGED ? &p.stream->shadow_count[iq]    : &p.sizes->shadow[launch_bounce];
+	int * const trace_counter  = MERGED ? &p.stream->trace_count[iq ^ 1] : &p.sizes->trace[launch_bounce + 1];
 	const bool nee_enabled = p.config.enable_next_event_estimation && p.lights_total_weight > 0.0f; // uniform
 	if (MERGED) stream_stats_clear(stats_lds);
 
@@ -931,7 +939,8 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 
 		if (nee_enabled) {
 			if (MERGED) stream_stats_add(stats_lds, has_shadow_ray, submission, RT_STAT_SHADOW);
-			int shadow_ray_index = block_aggregated_append(has_shadow_ray ? 0 : -1, shadow_counter, append_lds);
+			// (both ray queues: the workgroup's rays ordered by direction octant, see block_bucketed_append)
+			int shadow_ray_index = block_bucketed_append(has_shadow_ray, RT_RAY_BUCKET(shadow.direction), shadow_counter, append_lds);
 			if (has_shadow_ray) {
 				store3(p.shadow.origin,    shadow_ray_index, shadow.origin);
 				store3(p.shadow.direction, shadow_ray_index, shadow.direction);
@@ -945,7 +954,7 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 		f3 direction_out = mk3(0.0f); float pdf = 0.0f;
 		bool continues = alive && bsdf.sample(p, throughput, medium_id, direction_out, pdf);
 
-		int index_out = block_aggregated_append(continues ? 0 : -1, trace_counter, append_lds);
+		int index_out = block_bucketed_append(continues, RT_RAY_BUCKET(direction_out), trace_counter, append_lds);
 		if (!continues) continue;
 
 		f3 origin_out = ray_origin_epsilon_offset(hit_point, direction_out, geometric_normal);
