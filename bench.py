@@ -58,6 +58,9 @@ SPONZA_POVS = [
     ((-129.707321, 17.916590, 43.054050), (0.011467, 0.408287, 0.005129, -0.912762)),
 ]
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3-6.6 TB/s is achievable
+# Vector-ALU peak for ordinary (non-packed) instructions: 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz. (The 157.3 TFLOP/s
+# FP32 figure of the data sheet is this x 2 for the fused multiply-add x 2 for v_pk_fma_f32; traversal is neither.)
+VALU_PEAK_LANE_INSTR_PER_S = 256 * 4 * 16 * 2.4e9
 
 
 def build_scene(grt):
@@ -138,7 +141,7 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
     passes over this very command (tools/pmc_pass.py). Everything is per traversal launch of the timed region, like `achieved`."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_pass
-    passes = pmc_pass.run_passes(args.steps, args.warmup)
+    passes = pmc_pass.run_passes(args.steps, args.warmup, groups=pmc_pass.DEFAULT_GROUPS + ["TCC_HIT_sum TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"])
     kernels = passes["kernels"]
     out = {"pmc_errors": passes["errors"]} if passes["errors"] else {}
     trace = kernels.get("kernel_trace_stream_bvh8")
@@ -177,16 +180,140 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
             counters["waves_resident_per_simd"] = round(4.0 * c.get("SQ_WAVE_CYCLES", 0.0) / (1024.0 * c["_duration_ns"] * 2.4), 2)
         counters["valu_thread_instructions_per_ray"] = round(c["SQ_THREAD_CYCLES_VALU"] * scale * launches_timed / args.steps / max(rays_per_step, 1.0), 1)
         out["counters"] = counters
+        if c.get("_duration_ns"):
+            # the roofline that BINDS this kernel: useful (active-lane) vector instructions per second against the chip's issue peak
+            useful = c["SQ_THREAD_CYCLES_VALU"] / (c["_duration_ns"] * 1e-9)
+            out["binding"] = {"bound": "valu", "unit": "lane-instr/s", "peak": VALU_PEAK_LANE_INSTR_PER_S, "achieved": float("%.4g" % useful),
+                              "frac": round(useful / VALU_PEAK_LANE_INSTR_PER_S, 4),
+                              "issue_slots_used": counters.get("valu_busy"), "lane_utilisation": counters["valu_lane_utilisation"],
+                              "note": "achieved = SQ_THREAD_CYCLES_VALU (active lanes summed over all vector instructions) of the traversal launches / their time in the counter pass; frac = issue_slots_used x lane_utilisation up to clock effects (the chip runs below 2.4 GHz under this load). The vector ALUs are the unit this kernel saturates; what is left is the idle half of each instruction's lanes"}
+    if "TCC_HIT_sum" in trace and "TCC_MISS_sum" in trace and (trace["TCC_HIT_sum"][1] + trace["TCC_MISS_sum"][1]) > 0:
+        out.setdefault("binding", {})["l2_hit_rate"] = round(trace["TCC_HIT_sum"][1] / (trace["TCC_HIT_sum"][1] + trace["TCC_MISS_sum"][1]), 4)
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in trace and trace["TCP_TOTAL_CACHE_ACCESSES_sum"][1] > 0 and "TCP_TCC_READ_REQ_sum" in trace:
+        out.setdefault("binding", {})["l1_hit_rate"] = round(1.0 - trace["TCP_TCC_READ_REQ_sum"][1] / trace["TCP_TOTAL_CACHE_ACCESSES_sum"][1], 4)
+    out["kernels"] = kernels
     return out
+
+
+# ---- per-stage rooflines (SURVEY.md 8d) ------------------------------------------------------------------------------
+# ALGORITHMIC bytes of the stages besides traversal, per unit of work, as the scope table states them:
+#   generate    28 B written per primary ray
+#   sort        32 B read per ray (+ 28 B of path state from bounce 1 on), 60 B written per ray that reaches a material queue
+#   shade       per queue entry read 32 B (60 B from bounce 1 on) + 96 B triangle + 48 B instance transform + 32 B material
+#               + one trilinear albedo lookup on textured hits (8 taps x 8-byte BC1 blocks = 64 B; the extra probes of the
+#               anisotropic lookup at bounce 0 are NOT counted), written 52 B per continuation ray + 44 B per shadow ray
+#               + 3 x 16 B of albedo / normal / position at bounce 0
+#   accumulate  48 B per pixel and AOV (sample read, accumulator read + write)
+#   SVGF / TAA  every tap the kernels request, enumerated from the tap loops (reference SVGF.h:130-609, TAA.h:10-172);
+#               `unique` next to it is the compulsory traffic (every image read / written once per kernel)
+SVGF_TAP_BYTES = {   # kernel: (bytes requested per pixel, bytes per pixel if every image moved once)
+    "svgf_reproject": (32 + 16 + 8 + 4 * 16 + 4 * 48 + 8 + 48, 32 + 16 + 8 + 16 + 48 + 8 + 48),
+    "svgf_variance":  (32 + 4 + 64, 32 + 4 + 64),             # pixels with a history of >= 4 frames are copied; younger ones gather 48 taps x 64 B (counted below)
+    "svgf_atrous":    (9 * 2 * 16 + 32 + 16 + 2 * 16 + 8 * (32 + 16) + 32, 32 + 16 + 32),
+    "svgf_finalize":  (32 + 16 + 16 + 16 + 16 + 16 + 16 + 16 + 16 + 8, 176),
+    "taa":            (16 + 8 + 16 * 16 + 8 * 16 + 16, 16 + 8 + 16 + 16),
+    "taa_finalize":   (16 + 16 + 16 + 8, 56),
+}
+
+
+def stage_rooflines(grt, ctx, counters_per_sample, plan, steps, stream_gbps, textured_fraction=1.0):
+    """[{stage, launches, ms_per_step, algorithmic_bytes_per_step, achieved, frac}] from the mode-3 launch timings of a repeat of
+    the timed plan (rt_set_profiling(ctx, 3): HIP events around every launch) and the queue sizes per bounce."""
+    def total(kind):
+        t = grt.launch_timings(ctx, kind).astype(np.float64)
+        return len(t), float(t.sum())
+    nb = NUM_BOUNCES
+    per_step = {"generate": 0.0, "sort": 0.0, "material_diffuse": 0.0, "material_plastic": 0.0, "material_dielectric": 0.0, "material_conductor": 0.0, "accumulate": 0.0}
+    samples = [(first + j) % SPP for first, count, _ in plan for j in range(count)]
+    for sidx in samples:
+        c = counters_per_sample[sidx]
+        entries = {"material_diffuse": c.diffuse, "material_plastic": c.plastic, "material_dielectric": c.dielectric, "material_conductor": c.conductor}
+        per_step["generate"] += 28.0 * c.trace[0]
+        for b in range(nb):
+            shaded = sum(e[b] for e in entries.values())
+            per_step["sort"] += c.trace[b] * (32.0 + (28.0 if b else 0.0)) + 60.0 * shaded
+            nxt = c.trace[b + 1] if b + 1 < nb else 0
+            for name, e in entries.items():
+                if not e[b]:
+                    continue
+                share = e[b] / max(shaded, 1)
+                texels = 64.0 * textured_fraction if name in ("material_diffuse", "material_plastic") else 0.0
+                per_step[name] += e[b] * ((32.0 if b == 0 else 60.0) + 96.0 + 48.0 + 32.0 + texels + (48.0 if b == 0 else 0.0)) + share * (52.0 * nxt + 44.0 * c.shadow[b])
+        per_step["accumulate"] += 48.0 * WIDTH * HEIGHT
+    stages = []
+    for name, nbytes in per_step.items():
+        launches, ms = total(name)
+        if launches == 0:
+            continue
+        gbps = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        stages.append({"stage": name, "launches": launches, "ms_per_step": round(ms / steps, 4), "algorithmic_bytes_per_step": round(nbytes / steps),
+                       "achieved": round(gbps, 1), "unit": "GB/s", "frac": round(gbps / stream_gbps, 4)})
+    return stages
+
+
+def config3_section(grt, scene, device, stream_gbps, frames=64):
+    """BASELINE config 3 (Sponza 1080p, SVGF with 6 a-trous passes + TAA, one sample per filtered frame, the camera moving
+    between frames): ms per filtered frame in the merged wavefront, and every filter kernel priced against the stream bandwidth."""
+    grt.config_set(enable_svgf=1, enable_taa=1, num_atrous_iterations=6)
+    pt = grt.Pathtracer(scene, WIDTH, HEIGHT, device=device)
+    try:
+        pt.update()
+        lib, ctx = grt.device_lib(), pt.ctx
+        def frame(index):   # one filtered frame = one sample (rt_render_sample with SVGF on filters the frame when it has passed its last bounce)
+            status = lib.rt_render_sample(ctx, index % SPP)
+            if status != 0:
+                raise RuntimeError(lib.rt_last_error(ctx).decode())
+        for f in range(8):
+            frame(f)
+        lib.rt_synchronize(ctx)
+        t0 = time.perf_counter()
+        for f in range(frames):
+            frame(f)
+        lib.rt_synchronize(ctx)
+        ms_frame = (time.perf_counter() - t0) / frames * 1e3
+        c = pt.counters()
+        rays = int(sum(c.trace[:NUM_BOUNCES]))
+        grt.set_profiling(ctx, 3)
+        for f in range(frames):
+            frame(f)
+        lib.rt_synchronize(ctx)
+        px = WIDTH * HEIGHT
+        kernels, filter_ms = [], 0.0
+        for name, (tap_bytes, unique_bytes) in SVGF_TAP_BYTES.items():
+            t = grt.launch_timings(ctx, name).astype(np.float64)
+            if not len(t):
+                continue
+            per_frame = float(t.sum()) / frames
+            filter_ms += per_frame
+            passes = len(t) / frames
+            gbps = tap_bytes * px * passes / (per_frame * 1e-3) / 1e9
+            kernels.append({"kernel": "kernel_" + name, "launches_per_frame": round(passes, 2), "ms_per_frame": round(per_frame, 4),
+                            "tap_bytes_per_pixel": tap_bytes, "unique_bytes_per_pixel": unique_bytes,
+                            "achieved": round(gbps, 1), "unit": "GB/s", "frac": round(gbps / stream_gbps, 4),
+                            "frac_unique": round(unique_bytes * px * passes / (per_frame * 1e-3) / 1e9 / stream_gbps, 4)})
+        trace_ms = float(grt.launch_timings(ctx, "trace").sum()) / frames
+        grt.set_profiling(ctx, False)
+        unique_total = sum(k["unique_bytes_per_pixel"] * k["launches_per_frame"] for k in kernels) * px
+        return {"workload": "Sponza 1920x1080, SVGF (6 a-trous passes, spatial variance) + TAA, 1 sample per filtered frame, %d frames back to back in the merged wavefront (static camera; the moving-camera frames are parity-tested in tests/test_gpu_full_size.py)" % frames,
+                "ms_per_filtered_frame": round(ms_frame, 3), "rays_per_frame": rays, "mrays_s": round(rays / ms_frame / 1e3, 1),
+                "filter_ms_per_frame": round(filter_ms, 4), "traversal_ms_per_frame": round(trace_ms, 4),
+                "filter_frac_of_stream_unique_bytes": round(unique_total / (filter_ms * 1e-3) / 1e9 / stream_gbps, 4) if filter_ms > 0 else None,
+                "kernels": kernels,
+                "note": "tap bytes = every tap the kernel requests (SVGF.h / TAA.h tap loops), unique bytes = each image once; frac against the measured stream-read bandwidth"}
+    finally:
+        pt.close()
+        grt.config_set(enable_svgf=0, enable_taa=0)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)   # PerfTest BUFFER_SIZE = 32 frames (Util/PerfTest.h:9)
+    ap.add_argument("--steps", type=int, default=64)   # 16 frames of 4 spp: the 9 fill / drain iterations of the wavefront are a small part of the launches
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the hardware-counter passes (rocprofv3 --pmc re-runs of this benchmark: HBM traffic, VALU busy; N = 1 only)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the SVGF + TAA frames of BASELINE config 3 (N = 1 only)")
+    ap.add_argument("--no-stages", action="store_true", help="skip the per-stage rooflines (a repeat of the timed plan with events around every launch)")
     ap.add_argument("--no-povs", action="store_true", help="skip the sweep over the reference's 9 fixed Sponza points of view (N = 1 only)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: render only rank 0's tiles of an N-GPU split on one GPU (no collective), to exercise the N > 1 code path")
     ap.add_argument("--batch", type=int, default=SPP, help="samples per pixel per submission (rt_render_samples), 1..%d" % SPP)
@@ -329,12 +456,13 @@ def main():
     check(lib.rt_synchronize(ctx))
 
     # ---- untimed statistics pass: rays per sample and the work counters of the trace kernels ------
-    rays_per_sample, shadow_per_sample, alg_closest_per_sample, alg_shadow_per_sample, trace_rays_stat = [], [], [], [], []
+    rays_per_sample, shadow_per_sample, alg_closest_per_sample, alg_shadow_per_sample, trace_rays_stat, counters_per_sample = [], [], [], [], [], []
     grt.set_trace_statistics(ctx, True)
     for s in range(SPP):
         check(lib.rt_render_samples(ctx, s, 1))
         c = pt.counters()
         stats = grt.get_trace_statistics(ctx)
+        counters_per_sample.append(c)
         rays_per_sample.append(sum(c.trace[:NUM_BOUNCES])); shadow_per_sample.append(sum(c.shadow[:NUM_BOUNCES]))
         alg_closest_per_sample.append(stats["closest"]["algorithmic_bytes"]); alg_shadow_per_sample.append(stats["shadow"]["algorithmic_bytes"])
         trace_rays_stat.append(stats)
@@ -381,6 +509,14 @@ def main():
     launch_ms = grt.launch_timings(ctx, 0).astype(np.float64)
     shadow_launch_ms = grt.launch_timings(ctx, 1).astype(np.float64)
     grt.set_profiling(ctx, False)
+
+    # ---- untimed repeat of the plan with HIP events around EVERY launch: what each stage of the step costs
+    stages_raw = None
+    if merged and world == 1 and split_world == 1 and not args.no_stages:
+        grt.set_profiling(ctx, 3)
+        run(plan)
+        check(lib.rt_synchronize(ctx))
+        stages_raw = True   # (the timings are read below, next to the stream bandwidth they are priced against)
 
     rays_plan = float(sum(rays_per_sample[(first + j) % SPP] for first, count, _ in plan for j in range(count)))
     shadow_plan = float(sum(shadow_per_sample[(first + j) % SPP] for first, count, _ in plan for j in range(count)))
@@ -435,6 +571,20 @@ def main():
             "frame_alone_trace_ms_per_step": round(alone_trace_ms / SPP, 4),
             "measured_stream_read_gbps": round(grt.measure_stream_bandwidth(ctx, 1 << 30, 5), 1),
         })
+        stream_gbps = roofline["measured_stream_read_gbps"]
+        if roofline.get("achieved"):   # the denominator SURVEY 8d names: what a streaming read reaches on THIS GPU
+            roofline["frac_of_measured_stream"] = round(roofline["achieved"] / stream_gbps, 4)
+        if stages_raw:
+            trace_ms = float(grt.launch_timings(ctx, "trace").sum())
+            stages = stage_rooflines(grt, ctx, counters_per_sample, plan, args.steps, stream_gbps)
+            if merged and launch_bytes is not None:
+                stages.insert(1, {"stage": "traversal", "launches": int(len(launch_bytes)), "ms_per_step": round(trace_ms / args.steps, 4),
+                                  "algorithmic_bytes_per_step": round(float(launch_bytes.sum()) / args.steps),
+                                  "achieved": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                  "frac": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9 / stream_gbps, 4)})
+            roofline["stages"] = stages
+            roofline["stages_note"] = "a repeat of the timed plan with HIP events around every launch (rt_set_profiling 3); frac = algorithmic bytes (SURVEY 8d formulas, bench.py stage_rooflines) / stage time / measured stream-read bandwidth; the shade kernels are gather chains, the traversal is VALU-bound (see binding): for those the fraction is a yardstick, not the limit"
+            grt.set_profiling(ctx, False)
         result = {
             "metric": "Mrays/s (primary+secondary) + ms/frame, Sponza 1920x1080 4spp BVH8", "value": round(value, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -460,6 +610,7 @@ def main():
         if world == 1 and split_world == 1 and not args.no_povs:
             # the reference's perf harness (Util/PerfTest.h): the same frame loop at its 9 fixed points of view
             povs = []
+            camera_before = scene.get_camera()
             for position, rotation in SPONZA_POVS:
                 scene.set_camera(position, rotation); pt.update()
                 run(submissions(2 * SPP)); check(lib.rt_synchronize(ctx))     # untimed: first frames from the new camera
@@ -471,25 +622,40 @@ def main():
                 ms = (time.perf_counter() - t0) / (4 * SPP) * 1e3
                 check(lib.rt_render_samples(ctx, 0, 1)); c = pt.counters()
                 povs.append({"ms_per_step": round(ms, 3), "rays_per_step": int(sum(c.trace[:NUM_BOUNCES])), "mrays_s": round(sum(c.trace[:NUM_BOUNCES]) / ms / 1e3, 1)})
+            scene.set_camera(tuple(camera_before[0]), tuple(camera_before[1])); pt.update()
             ms_all = np.array([p["ms_per_step"] for p in povs]); mr_all = np.array([p["mrays_s"] for p in povs])
             result["povs"] = {"source": "Util/PerfTest.h:30-40 (povs_sponza), 16 steps each", "per_pov": povs,
                               "ms_per_step_avg": round(float(ms_all.mean()), 3), "ms_per_step_stddev": round(float(ms_all.std()), 3),
                               "mrays_s_avg": round(float(mr_all.mean()), 1), "mrays_s_stddev": round(float(mr_all.std()), 1)}
+        if world == 1 and split_world == 1 and merged and not args.no_config3 and not os.environ.get("BENCH_PMC_CHILD"):
+            pt.close(); pt = None   # (its queues and sample frames go back first)
+            result["config3"] = config3_section(grt, scene, local_rank, stream_gbps)
         if world == 1 and split_world == 1 and merged and not args.no_pmc and not os.environ.get("BENCH_PMC_CHILD"):
             # hardware counters of the same command (separate rocprofv3 --pmc passes); this process lets go of the GPU first
-            pt.close(); scene.close(); closed = True
-            result["roofline"].update(pmc_section(args, rays_plan / args.steps, launch_ms, plan))
+            if pt is not None:
+                pt.close()
+            scene.close(); closed = True
+            pmc = pmc_section(args, rays_plan / args.steps, launch_ms, plan)
+            pmc_kernels = pmc.pop("kernels", {})
+            result["roofline"].update(pmc)
             r = result["roofline"]
+            for stage in r.get("stages", []):   # the counters of the other stages' kernels, where the passes saw them
+                k = pmc_kernels.get({"traversal": "kernel_trace_stream_bvh8", "sort": "kernel_sort_stream", "generate": "kernel_generate_stream", "accumulate": "kernel_accumulate_group"}.get(stage["stage"], "kernel_" + stage["stage"] + "_stream"))
+                if k and k.get("SQ_INSTS_VALU", [0, 0])[1] > 0 and k.get("_duration_ns"):
+                    stage["lane_utilisation"] = round(k["SQ_THREAD_CYCLES_VALU"][1] / (64.0 * k["SQ_INSTS_VALU"][1]), 3)
+                    stage["valu_busy"] = round(4.0 * k.get("SQ_ACTIVE_INST_VALU", [0, 0.0])[1] / (1024.0 * k["_duration_ns"][1] * 2.4), 3)
+                    stage["waves_per_simd"] = round(4.0 * k.get("SQ_WAVE_CYCLES", [0, 0.0])[1] / (1024.0 * k["_duration_ns"][1] * 2.4), 2)
             if r.get("traffic") and r.get("algorithmic_bytes_per_launch"):
                 # how much of what the traversal reads is served by the caches (L1 + L2 + Infinity Cache together): the
                 # algorithmic bytes are a lower bound of its requests, the memory-side traffic is what got past the caches
                 r["cache_hit_fraction_lower_bound"] = round(1.0 - r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
-                r["bound_in_practice"] = ("VALU issue and the dependent chain of each ray: vector ALUs busy %.2f at a lane utilisation of %.2f; the memory side moves %.0f %% of the algorithmic bytes, which is why frac can exceed 1 (DESIGN.md 4.1, profiles/r02_valu_experiments.txt)"
+                r["bound_in_practice"] = ("VALU issue and the dependent chain of each ray: vector ALUs busy %.2f at a lane utilisation of %.2f; the memory side moves %.0f %% of the algorithmic bytes, which is why frac can exceed 1 (see roofline.binding; DESIGN.md 4.1)"
                                           % (r.get("counters", {}).get("valu_busy", float("nan")), r.get("counters", {}).get("valu_lane_utilisation", float("nan")), 100.0 * r["traffic"] / r["algorithmic_bytes_per_launch"]))
         print(json.dumps(result))
 
     if not closed:
-        pt.close()
+        if pt is not None:
+            pt.close()
         scene.close()
     if world > 1:
         dist.destroy_process_group()

@@ -157,6 +157,14 @@ def host_lib():
         lib.grt_pathtracer_texture.argtypes = [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_int)]
         lib.grt_pathtracer_device_config.argtypes = [c_void_p, POINTER(GPUConfig)]
         lib.grt_pathtracer_counters.argtypes = [c_void_p, POINTER(Counters)]
+        lib.grt_frame_split_create.restype = c_void_p
+        lib.grt_frame_split_create.argtypes = [c_void_p, c_int, c_int, POINTER(c_int), c_int]
+        lib.grt_frame_split_free.argtypes = [c_void_p]
+        lib.grt_frame_split_update.argtypes = [c_void_p, c_float]
+        lib.grt_frame_split_render.argtypes = [c_void_p]
+        lib.grt_frame_split_render_samples.argtypes = [c_void_p, c_int]
+        lib.grt_frame_split_rank.restype = c_void_p
+        lib.grt_frame_split_rank.argtypes = [c_void_p, c_int]
         lib.grt_build_blas.restype = c_void_p
         lib.grt_build_blas.argtypes = [c_void_p, c_int]
         lib.grt_build_device_bvh.restype = c_void_p
@@ -549,6 +557,41 @@ class Pathtracer:
 
 # ---- kernel-level entry points of the C ABI -----------------------------------------------------------
 
+class FrameSplit:
+    """host/FrameSplit.h: one frame over several GPUs from one process -- row tiles dealt round-robin to one Pathtracer per
+    entry of `devices` (an ordinal may repeat: contexts sharing a GPU exchange by peer copies), ONE grouped all-gather over
+    RCCL per render(); no torch.distributed. rank(r) is that rank's Pathtracer (owned by the split)."""
+
+    def __init__(self, scene, width, height, devices):
+        lib = host_lib()
+        self.scene, self.width, self.height, self.world = scene, width, height, len(devices)
+        ordinals = (c_int * len(devices))(*devices)
+        self.handle = lib.grt_frame_split_create(scene.handle, width, height, ordinals, len(devices))
+        if not self.handle:
+            raise RuntimeError("FrameSplit creation failed: %s" % lib.grt_last_error().decode(errors="replace"))
+
+    def close(self):
+        if self.handle:
+            host_lib().grt_frame_split_free(self.handle)
+            self.handle = None
+
+    def rank(self, r):
+        view = Pathtracer.__new__(Pathtracer)
+        view.scene, view.width, view.height = self.scene, self.width, self.height
+        view.handle = host_lib().grt_frame_split_rank(self.handle, r)
+        view.close = lambda: None      # owned by the split
+        return view
+
+    def update(self, delta=0.0):
+        _host_check(host_lib().grt_frame_split_update(self.handle, float(delta)))
+
+    def render(self):
+        _host_check(host_lib().grt_frame_split_render(self.handle))
+
+    def render_samples(self, count):
+        _host_check(host_lib().grt_frame_split_render_samples(self.handle, int(count)))
+
+
 class AO(Pathtracer):
     """reference: Src/Renderer/Integrators/AO.h -- the ambient-occlusion integrator. Shares the
     update()/render()/read_* protocol and the staging arrays with Pathtracer; `radius` is AO::ao_radius."""
@@ -691,8 +734,15 @@ def submissions_completed(ctx):
     return int(n.value)
 
 
+# kinds of rt_get_launch_timings (include/gpu_raytracer_amd.h, RT_TIMING_*)
+TIMING_KINDS = {"trace": 0, "shadow": 1, "sort": 2, "generate": 3, "accumulate": 4, "material_diffuse": 5, "material_plastic": 6,
+                "material_dielectric": 7, "material_conductor": 8, "svgf_reproject": 9, "svgf_variance": 10, "svgf_atrous": 11,
+                "svgf_finalize": 12, "taa": 13, "taa_finalize": 14}
+
+
 def launch_timings(ctx, kind=0):
-    """Durations (ms) of the traversal launches timed by set_profiling(ctx, 2) since the last call."""
+    """Durations (ms) of the launches of one kind timed by set_profiling(ctx, 2 or 3) since the last call for that kind."""
+    kind = TIMING_KINDS.get(kind, kind)
     lib = device_lib()
     lib.rt_get_launch_timings.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p]
     n = c_int(0)

@@ -147,16 +147,6 @@ RT_DEV f2 edge_stopping_weights(const RtParams & p, int delta_x, int delta_y, f2
 	return mk2(w_l_direct, w_l_indirect);
 }
 
-// Normal of a g-buffer texel for the filters' weights: the same decoding with v_rsq_f32 (1 ulp) for the normalisation.
-RT_DEV f3 oct_decode_normal_fast(f2 f) {
-	f = mk2(f.x * 2.0f - 1.0f, f.y * 2.0f - 1.0f);
-	f3 n = mk3(f.x, f.y, 1.0f - fabsf(f.x) - fabsf(f.y));
-	float t = saturate(-n.z);
-	n.x += n.x >= 0.0f ? -t : t;
-	n.y += n.y >= 0.0f ? -t : t;
-	return n * __builtin_amdgcn_rsqf(dot(n, n));
-}
-
 __global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p) {
 	int x = blockIdx.x * blockDim.x + threadIdx.x;
 	int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -177,6 +167,9 @@ __global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p) {
 
 	f3 normal = oct_decode_normal(mk2(normal_and_depth.x, normal_and_depth.y));
 	float depth = normal_and_depth.z, depth_prev = normal_and_depth.w;
+	// the variance and a-trous passes read every pixel's normal up to 9 + 6 x 9 times per frame: decoded once, here, into a
+	// float4 of its own (normal, depth) -- the same 16 bytes per tap as the octahedral g-buffer texel, without the decode
+	p.svgf_normal_and_depth[pixel_index] = make_float4(normal.x, normal.y, normal.z, depth);
 	if (depth == 0.0f) return; // sky
 
 	float s_prev = (0.5f + 0.5f * screen_position_prev.x) * float(p.screen_width);
@@ -265,16 +258,17 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 	int history = p.history_length[pixel_index];
 	if (history >= 4) { d_out[pixel_index] = d_in[pixel_index]; i_out[pixel_index] = i_in[pixel_index]; return; }
 
+	const float4 * __restrict__ normal_and_depth = p.svgf_normal_and_depth;   // (normal, depth), decoded by kernel_svgf_reproject
 	float luminance_denom = 1.0f / p.config.sigma_l;
 	f4 cd = ld4(d_in, pixel_index), ci = ld4(i_in, pixel_index);
 	float cl_d = luminance(cd.x, cd.y, cd.z), cl_i = luminance(ci.x, ci.y, ci.z);
 
-	float4 cnd = p.gbuffer_normal_and_depth[pixel_index];
-	f3 center_normal = oct_decode_normal_fast(mk2(cnd.x, cnd.y));
-	float center_depth = cnd.z;
+	float4 cnd = normal_and_depth[pixel_index];
+	f3 center_normal = mk3(cnd.x, cnd.y, cnd.z);
+	float center_depth = cnd.w;
 	int xr = min(x + 1, p.screen_pitch - 1), yd = min(y + 1, p.screen_height - 1);
-	f2 grad = mk2(p.gbuffer_normal_and_depth[xr + y * p.screen_pitch].z - center_depth,
-	              p.gbuffer_normal_and_depth[x + yd * p.screen_pitch].z - center_depth);
+	f2 grad = mk2(normal_and_depth[xr + y * p.screen_pitch].w - center_depth,
+	              normal_and_depth[x + yd * p.screen_pitch].w - center_depth);
 
 	if (center_depth == 0.0f) { st4(d_out, pixel_index, cd); st4(i_out, pixel_index, ci); return; }
 
@@ -292,9 +286,8 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 			int tap_index = tap_x + tap_y * p.screen_pitch;
 			f4 td = ld4(d_in, tap_index), ti = ld4(i_in, tap_index), moment = ld4(p.frame_buffer_moment, tap_index);
 			float l_d = luminance(td.x, td.y, td.z), l_i = luminance(ti.x, ti.y, ti.z);
-			float4 nd = p.gbuffer_normal_and_depth[tap_index];
-			f3 normal = oct_decode_normal_fast(mk2(nd.x, nd.y));
-			f2 w = edge_stopping_weights(p, i, j, grad, center_depth, nd.z, center_normal, normal, cl_d, cl_i, l_d, l_i, luminance_denom, luminance_denom);
+			float4 nd = normal_and_depth[tap_index];
+			f2 w = edge_stopping_weights(p, i, j, grad, center_depth, nd.w, center_normal, mk3(nd.x, nd.y, nd.z), cl_d, cl_i, l_d, l_i, luminance_denom, luminance_denom);
 			sw_d += w.x; sw_i += w.y;
 			sc_d += w.x * td;
 			sc_i += w.y * ti;
@@ -310,22 +303,31 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 	st4(i_out, pixel_index, sc_i);
 }
 
-__global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, int step_size) {
+// One a-trous pass (SVGF.h:416-554). Per pixel: the 3x3 Gaussian blur of the variance (9 taps, .w only), then 8 taps at
+// +-step_size of (direct, indirect, normal + depth) = 48 B each. The tap loops are fully unrolled (the offsets are
+// -step, 0, +step: the bounds tests become four comparisons per pixel), the normals come decoded, both weights of a tap are one
+// v_exp_f32 each (edge_stopping_weights): ~600 vector instructions per pixel where the literal form ran ~3 000 -- the pass
+// moves 80 B of compulsory traffic per pixel and was bound by the vector ALUs at a third of the stream bandwidth
+// (BENCH config3 kernels; profiles/r03_svgf.txt).
+__global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const float4 * __restrict__ d_in, const float4 * __restrict__ i_in, float4 * __restrict__ d_out, float4 * __restrict__ i_out, int step_size) {
 	int x = blockIdx.x * blockDim.x + threadIdx.x;
 	int y = blockIdx.y * blockDim.y + threadIdx.y;
 	if (x >= p.screen_width || y >= p.screen_height) return;
-	int pixel_index = x + y * p.screen_pitch;
+	const int pitch = p.screen_pitch;
+	int pixel_index = x + y * pitch;
+	const float4 * __restrict__ normal_and_depth = p.svgf_normal_and_depth;   // (normal, depth), decoded by kernel_svgf_reproject
 
+	// clamped neighbours for the variance blur
+	const int xl = max(x - 1, 0), xr1 = min(x + 1, p.screen_width - 1), yu = max(y - 1, 0), yd1 = min(y + 1, p.screen_height - 1);
+	const int col[3] = { xl, x, xr1 }, row[3] = { yu * pitch, y * pitch, yd1 * pitch };
 	float vb_d = 0.0f, vb_i = 0.0f;
 	#pragma unroll
-	for (int j = -1; j <= 1; j++) {
-		int tap_y = min(max(y + j, 0), p.screen_height - 1);
+	for (int j = 0; j < 3; j++) {
 		#pragma unroll
-		for (int i = -1; i <= 1; i++) {
-			int tap_x = min(max(x + i, 0), p.screen_width - 1);
-			float kernel_weight = scalbnf(0.25f, -(abs(i) + abs(j)));
-			vb_d += d_in[tap_x + tap_y * p.screen_pitch].w * kernel_weight;
-			vb_i += i_in[tap_x + tap_y * p.screen_pitch].w * kernel_weight;
+		for (int i = 0; i < 3; i++) {
+			const float kernel_weight = (i == 1 ? 0.5f : 0.25f) * (j == 1 ? 0.5f : 0.25f) * 1.0f;   // 0.25 * 2^-(|i| + |j|), |i| = distance from the centre
+			vb_d += d_in[col[i] + row[j]].w * kernel_weight;
+			vb_i += i_in[col[i] + row[j]].w * kernel_weight;
 		}
 	}
 	float denom_d = 1.0f / sqrtf(p.config.sigma_l * p.config.sigma_l * fmaxf(0.0f, vb_d) + RT_SVGF_EPSILON);
@@ -334,33 +336,34 @@ __global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const floa
 	f4 cd = ld4(d_in, pixel_index), ci = ld4(i_in, pixel_index);
 	float cl_d = luminance(cd.x, cd.y, cd.z), cl_i = luminance(ci.x, ci.y, ci.z);
 
-	float4 cnd = p.gbuffer_normal_and_depth[pixel_index];
-	f3 center_normal = oct_decode_normal_fast(mk2(cnd.x, cnd.y));
-	float center_depth = cnd.z;
+	float4 cnd = normal_and_depth[pixel_index];
+	f3 center_normal = mk3(cnd.x, cnd.y, cnd.z);
+	float center_depth = cnd.w;
 	if (center_depth == 0.0f) return; // sky: outputs intentionally not written (SVGF.h:462)
 
-	int xr = min(x + 1, p.screen_pitch - 1), yd = min(y + 1, p.screen_height - 1);
-	f2 grad = mk2(p.gbuffer_normal_and_depth[xr + y * p.screen_pitch].z - center_depth,
-	              p.gbuffer_normal_and_depth[x + yd * p.screen_pitch].z - center_depth);
+	int xr = min(x + 1, pitch - 1), yd = min(y + 1, p.screen_height - 1);
+	f2 grad = mk2(normal_and_depth[xr + y * pitch].w - center_depth,
+	              normal_and_depth[x + yd * pitch].w - center_depth);
 
+	const bool in_x[3] = { x - step_size >= 0, true, x + step_size < p.screen_width };
+	const bool in_y[3] = { y - step_size >= 0, true, y + step_size < p.screen_height };
 	float sw_d = 1.0f, sw_i = 1.0f;
 	f4 sc_d = cd, sc_i = ci;
+	#pragma unroll
 	for (int j = -1; j <= 1; j++) {
-		int tap_y = y + j * step_size;
-		if (tap_y < 0 || tap_y >= p.screen_height) continue;
+		#pragma unroll
 		for (int i = -1; i <= 1; i++) {
-			int tap_x = x + i * step_size;
-			if (tap_x < 0 || tap_x >= p.screen_width) continue;
 			if (i == 0 && j == 0) continue;
-			int tap_index = tap_x + tap_y * p.screen_pitch;
-			f4 td = ld4(d_in, tap_index), ti = ld4(i_in, tap_index);
-			float l_d = luminance(td.x, td.y, td.z), l_i = luminance(ti.x, ti.y, ti.z);
-			float4 nd = p.gbuffer_normal_and_depth[tap_index];
-			f3 normal = oct_decode_normal_fast(mk2(nd.x, nd.y));
-			f2 w = edge_stopping_weights(p, i * step_size, j * step_size, grad, center_depth, nd.z, center_normal, normal, cl_d, cl_i, l_d, l_i, denom_d, denom_i);
-			sw_d += w.x; sw_i += w.y;
-			sc_d += mk4(w.x, w.x, w.x, w.x * w.x) * td;
-			sc_i += mk4(w.y, w.y, w.y, w.y * w.y) * ti;
+			if (in_x[i + 1] && in_y[j + 1]) {
+				int tap_index = pixel_index + i * step_size + j * step_size * pitch;
+				f4 td = ld4(d_in, tap_index), ti = ld4(i_in, tap_index);
+				float4 nd = normal_and_depth[tap_index];
+				float l_d = luminance(td.x, td.y, td.z), l_i = luminance(ti.x, ti.y, ti.z);
+				f2 w = edge_stopping_weights(p, i * step_size, j * step_size, grad, center_depth, nd.w, center_normal, mk3(nd.x, nd.y, nd.z), cl_d, cl_i, l_d, l_i, denom_d, denom_i);
+				sw_d += w.x; sw_i += w.y;
+				sc_d += mk4(w.x, w.x, w.x, w.x * w.x) * td;
+				sc_i += mk4(w.y, w.y, w.y, w.y * w.y) * ti;
+			}
 		}
 	}
 	float inv_d = 1.0f / sw_d, inv_i = 1.0f / sw_i;
@@ -399,9 +402,9 @@ __global__ void __launch_bounds__(256) kernel_svgf_finalize(RtParams p, const fl
 
 RT_DEV f3 clamp3(f3 v, f3 lo, f3 hi) { return mk3(clampf(v.x, lo.x, hi.x), clampf(v.y, lo.y, hi.y), clampf(v.z, lo.z, hi.z)); }
 
-// Reads final_image-independent inputs (taa_frame_curr / taa_frame_prev), writes taa_scratch;
-// kernel_taa_finalize then moves it into final_image. (The reference writes the `accumulator`
-// surface in place, which is safe there for the same reason: kernel_taa never reads it.)
+// Reads taa_frame_curr / taa_frame_prev, writes final_image; kernel_taa_finalize then turns it into the next frame's
+// taa_frame_prev and the displayed image. (The reference writes the `accumulator` surface in place, which is safe there
+// for the same reason: kernel_taa never reads it.)
 __global__ void __launch_bounds__(256) kernel_taa(RtParams p, int sample_index) {
 	int x = blockIdx.x * blockDim.x + threadIdx.x;
 	int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -471,11 +474,12 @@ __global__ void __launch_bounds__(256) kernel_taa_finalize(RtParams p) {
 }
 
 // Launch order of Pathtracer::render (Pathtracer.cpp:798-838)
-void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream) {
+void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream, void (*mark)(void * user, int svgf_kernel, hipStream_t stream), void * user) {
 	dim3 block(RT_POST_BLOCK_X, RT_POST_BLOCK_Y);
 	dim3 grid((p.screen_pitch + block.x - 1) / block.x, (p.screen_height + block.y - 1) / block.y);
+	#define RT_TIMED(k, launch) { if (mark) mark(user, k, stream); launch; if (mark) mark(user, k, stream); }
 
-	hipLaunchKernelGGL(kernel_svgf_reproject, grid, block, 0, stream, p);
+	RT_TIMED(0, hipLaunchKernelGGL(kernel_svgf_reproject, grid, block, 0, stream, p));
 
 	float4 * direct_in    = p.aovs[RT_AOV_RADIANCE_DIRECT].framebuffer;
 	float4 * indirect_in  = p.aovs[RT_AOV_RADIANCE_INDIRECT].framebuffer;
@@ -483,21 +487,22 @@ void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream
 	float4 * indirect_out = p.aovs[RT_AOV_RADIANCE_INDIRECT].accumulator;
 
 	if (p.config.enable_spatial_variance) {
-		hipLaunchKernelGGL(kernel_svgf_variance, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out);
+		RT_TIMED(1, hipLaunchKernelGGL(kernel_svgf_variance, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out));
 		float4 * t = direct_in; direct_in = direct_out; direct_out = t;
 		t = indirect_in; indirect_in = indirect_out; indirect_out = t;
 	}
 	for (int i = 0; i < p.config.num_atrous_iterations; i++) {
-		hipLaunchKernelGGL(kernel_svgf_atrous, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out, 1 << i);
+		RT_TIMED(2, hipLaunchKernelGGL(kernel_svgf_atrous, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out, 1 << i));
 		float4 * t = direct_in; direct_in = direct_out; direct_out = t;
 		t = indirect_in; indirect_in = indirect_out; indirect_out = t;
 	}
-	hipLaunchKernelGGL(kernel_svgf_finalize, grid, block, 0, stream, p, direct_in, indirect_in);
+	RT_TIMED(3, hipLaunchKernelGGL(kernel_svgf_finalize, grid, block, 0, stream, p, direct_in, indirect_in));
 
 	if (p.config.enable_taa) {
-		hipLaunchKernelGGL(kernel_taa, grid, block, 0, stream, p, sample_index);
-		hipLaunchKernelGGL(kernel_taa_finalize, grid, block, 0, stream, p);
+		RT_TIMED(4, hipLaunchKernelGGL(kernel_taa, grid, block, 0, stream, p, sample_index));
+		RT_TIMED(5, hipLaunchKernelGGL(kernel_taa_finalize, grid, block, 0, stream, p));
 	}
+	#undef RT_TIMED
 }
 
 void rt_launch_accumulate(const RtParams & p, float frames_accumulated, int pixel_offset, int pixel_count, hipStream_t stream) {

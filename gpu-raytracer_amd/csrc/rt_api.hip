@@ -4,6 +4,7 @@
 // handed to the kernels by value. It plays the role of the reference's Device/ layer plus the
 // device half of Integrator/Pathtracer (buffer ownership, `buffer_sizes` handling, the
 // wavefront launch loop of Pathtracer::render, Pathtracer.cpp:738-855).
+#include <dlfcn.h>
 #include "rt_types.h"
 
 #include <algorithm>
@@ -182,6 +183,16 @@ struct rt_context {
 	void * svgf_buffers[12] = { }; bool svgf_allocated = false;
 	size_t frame_pixels = 0; // pitch * height
 
+	// frame exchange of the tile split (rt_comm_*): this context's rank in a group of `world` contexts, each on its own GPU
+	// (RCCL communicator) or, for tests on one GPU, several in one process (peer copies)
+	struct FrameExchange {
+		int rank = 0, world = 1;
+		void * comm = nullptr;                       // ncclComm_t
+		std::vector<rt_context *> peers;             // in-process transport: all contexts of the group, by rank
+		float4 * packed = nullptr, * gathered = nullptr; size_t packed_pixels = 0;   // per pixel `channels` float4
+		hipEvent_t ev_packed = nullptr, ev_copied = nullptr;
+	} exchange;
+
 	int * explicit_retired = nullptr;
 	int * pixel_query_out = nullptr;   // device { mesh_id, triangle_id }
 	int batch_size_request = 0;              // 0 = whole frame (288 GB of HBM: no reason to cut a frame into pieces)
@@ -190,6 +201,7 @@ struct rt_context {
 	rt_counters last_counters;
 	bool profiling = false;          // mode 1: per-stage events, one sample at a time
 	bool launch_timing = false;      // mode 2: events around every traversal launch, concurrency untouched
+	bool launch_timing_all = false;  // mode 3: ... and around every other launch of the merged wavefront
 	bool time_this_sample = false;
 	std::vector<hipEvent_t> span_events; std::vector<int> span_kinds; size_t span_used = 0; // mode 2: [begin, end] pairs
 	bool trace_statistics = false;
@@ -373,6 +385,9 @@ static bool bvh_nodes_present(const rt_context * ctx) {
 }
 
 enum { STAGE_GENERATE = 0, STAGE_TRACE, STAGE_SORT, STAGE_SHADE, STAGE_SHADOW, STAGE_POST, STAGE_END };
+// what a [begin, end] event pair of rt_set_profiling(ctx, 2 / 3) brackets (the `kind` of rt_get_launch_timings)
+enum { SPAN_TRACE = RT_TIMING_TRACE, SPAN_SHADOW = RT_TIMING_SHADOW, SPAN_SORT = RT_TIMING_SORT, SPAN_GENERATE = RT_TIMING_GENERATE, SPAN_ACCUMULATE = RT_TIMING_ACCUMULATE,
+       SPAN_MATERIAL = RT_TIMING_MATERIAL_0, SPAN_SVGF = RT_TIMING_SVGF_REPROJECT };
 
 extern "C" {
 
@@ -427,6 +442,7 @@ void rt_destroy(rt_context * ctx) {
 	(void)hipSetDevice(ctx->device);
 	(void)quiesce(ctx);
 	stream_destroy(ctx);
+	(void)rt_comm_destroy(ctx);
 	for (void * p : ctx->owned) (void)hipFree(p);
 	for (hipEvent_t e : ctx->stage_events) (void)hipEventDestroy(e);
 	for (hipEvent_t e : ctx->span_events) (void)hipEventDestroy(e);
@@ -906,7 +922,7 @@ static int sync_svgf(rt_context * ctx) {
 	p.history_normal_and_depth        = (float4 *)ctx->svgf_buffers[8];
 	p.taa_frame_prev                  = (float4 *)ctx->svgf_buffers[9];
 	p.taa_frame_curr                  = (float4 *)ctx->svgf_buffers[10];
-	p.taa_scratch                     = (float4 *)ctx->svgf_buffers[11];
+	p.svgf_normal_and_depth           = (float4 *)ctx->svgf_buffers[11];
 	return RT_OK;
 }
 
@@ -1047,6 +1063,205 @@ int rt_filter_frame(rt_context * ctx, int sample_index) {
 	return RT_OK;
 }
 
+// ---- frame exchange of the tile split without Python ----------------------------------------------------
+// One communicator per context. RCCL is bound at RUN TIME (dlopen, RTLD_LOCAL): a process that also hosts PyTorch already
+// has torch's own copy of librccl mapped, and a link-time dependency would make every user of this library load a
+// collective library most of them never call. Contexts that share a GPU (tests; RCCL refuses a device twice in one
+// communicator) exchange by stream-ordered peer copies instead -- the same pack / unpack kernels either way.
+extern "C++" {
+namespace {
+struct RcclUniqueId { char internal[128]; };            // ncclUniqueId (rccl.h)
+enum { RCCL_FLOAT32 = 7 };                              // ncclFloat32
+struct RcclApi {
+	void * handle = nullptr;
+	int (*get_unique_id)(RcclUniqueId *) = nullptr;
+	int (*comm_init_rank)(void **, int, RcclUniqueId, int) = nullptr;
+	int (*comm_init_all)(void **, int, const int *) = nullptr;
+	int (*comm_destroy)(void *) = nullptr;
+	int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+	int (*group_start)() = nullptr; int (*group_end)() = nullptr;
+	const char * (*error_string)(int) = nullptr;
+};
+RcclApi * rccl_api(std::string & why) {
+	static RcclApi api; static bool tried = false; static std::string failure;
+	if (!tried) {
+		tried = true;
+		for (const char * name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) if ((api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+		if (!api.handle) failure = std::string("librccl.so not found: ") + dlerror();
+		else {
+			#define RT_BIND(member, symbol) { *(void **)&api.member = dlsym(api.handle, symbol); if (!api.member) failure = std::string("librccl.so lacks ") + symbol; }
+			RT_BIND(get_unique_id, "ncclGetUniqueId") RT_BIND(comm_init_rank, "ncclCommInitRank") RT_BIND(comm_init_all, "ncclCommInitAll") RT_BIND(comm_destroy, "ncclCommDestroy")
+			RT_BIND(all_gather, "ncclAllGather") RT_BIND(group_start, "ncclGroupStart") RT_BIND(group_end, "ncclGroupEnd") RT_BIND(error_string, "ncclGetErrorString")
+			#undef RT_BIND
+		}
+	}
+	why = failure;
+	return failure.empty() ? &api : nullptr;
+}
+// this rank's share of the frame in float4 pixels, padded so that every rank sends the same amount
+size_t exchange_tiles_per_rank(const rt_context * ctx, int tile_pixels, int world) {
+	size_t frame = size_t(ctx->params.screen_width) * ctx->params.screen_height;
+	size_t tiles = (frame + tile_pixels - 1) / tile_pixels;
+	return (tiles + world - 1) / world;
+}
+int exchange_buffers(rt_context * ctx, size_t pixels) {
+	rt_context::FrameExchange & x = ctx->exchange;
+	if (x.packed_pixels >= pixels) return RT_OK;
+	if (x.packed)   device_free(ctx, x.packed);
+	if (x.gathered) device_free(ctx, x.gathered);
+	x.packed = x.gathered = nullptr; x.packed_pixels = 0;
+	int status = device_alloc(ctx, (void **)&x.packed, pixels * 16); if (status) return status;
+	status = device_alloc(ctx, (void **)&x.gathered, pixels * 16 * size_t(x.world)); if (status) return status;
+	x.packed_pixels = pixels;
+	if (!x.ev_packed) { RT_HIP(ctx, hipEventCreateWithFlags(&x.ev_packed, hipEventDisableTiming)); RT_HIP(ctx, hipEventCreateWithFlags(&x.ev_copied, hipEventDisableTiming)); }
+	return RT_OK;
+}
+} // namespace
+} // extern "C++"
+
+int rt_comm_unique_id(void * out_id_128_bytes) {
+	if (!out_id_128_bytes) return RT_ERROR_INVALID_ARG;
+	std::string why; RcclApi * api = rccl_api(why);
+	if (!api) return RT_ERROR_NOT_READY;
+	return api->get_unique_id((RcclUniqueId *)out_id_128_bytes) == 0 ? RT_OK : RT_ERROR_HIP;
+}
+
+int rt_comm_init_rank(rt_context * ctx, const void * unique_id_128_bytes, int rank, int world) {
+	RT_REQUIRE(ctx, ctx && unique_id_128_bytes && world >= 1 && rank >= 0 && rank < world, "rt_comm_init_rank: invalid argument");
+	(void)hipSetDevice(ctx->device);
+	(void)rt_comm_destroy(ctx);
+	std::string why; RcclApi * api = rccl_api(why);
+	if (!api) return fail(ctx, RT_ERROR_NOT_READY, "rt_comm_init_rank: %s", why.c_str());
+	RcclUniqueId id; memcpy(&id, unique_id_128_bytes, sizeof(id));
+	int rc = api->comm_init_rank(&ctx->exchange.comm, world, id, rank);
+	if (rc != 0) { ctx->exchange.comm = nullptr; return fail(ctx, RT_ERROR_HIP, "rt_comm_init_rank: ncclCommInitRank: %s", api->error_string(rc)); }
+	ctx->exchange.rank = rank; ctx->exchange.world = world;
+	return RT_OK;
+}
+
+int rt_comm_init_all(rt_context ** contexts, int count) {
+	if (!contexts || count < 1) return RT_ERROR_INVALID_ARG;
+	for (int i = 0; i < count; i++) if (!contexts[i]) return RT_ERROR_INVALID_ARG;
+	bool distinct = true;
+	for (int i = 0; i < count; i++) for (int j = 0; j < i; j++) if (contexts[i]->device == contexts[j]->device) distinct = false;
+	for (int i = 0; i < count; i++) { (void)rt_comm_destroy(contexts[i]); contexts[i]->exchange.rank = i; contexts[i]->exchange.world = count; }
+	if (distinct && count > 1) {   // one communicator over the GPUs of this process (ncclCommInitAll)
+		std::string why; RcclApi * api = rccl_api(why);
+		if (!api) return fail(contexts[0], RT_ERROR_NOT_READY, "rt_comm_init_all: %s", why.c_str());
+		std::vector<void *> comms(count, nullptr); std::vector<int> devices(count);
+		for (int i = 0; i < count; i++) devices[i] = contexts[i]->device;
+		int rc = api->comm_init_all(comms.data(), count, devices.data());
+		if (rc != 0) return fail(contexts[0], RT_ERROR_HIP, "rt_comm_init_all: ncclCommInitAll: %s", api->error_string(rc));
+		for (int i = 0; i < count; i++) contexts[i]->exchange.comm = comms[i];
+	} else {                       // contexts sharing a GPU: stream-ordered copies between them
+		for (int i = 0; i < count; i++) contexts[i]->exchange.peers.assign(contexts, contexts + count);
+	}
+	return RT_OK;
+}
+
+int rt_comm_destroy(rt_context * ctx) {
+	if (!ctx) return RT_ERROR_INVALID_ARG;
+	rt_context::FrameExchange & x = ctx->exchange;
+	if (x.comm) { std::string why; if (RcclApi * api = rccl_api(why)) (void)api->comm_destroy(x.comm); x.comm = nullptr; }
+	for (rt_context * peer : x.peers) if (peer && peer != ctx) {   // the others of an in-process group lose this member
+		for (rt_context *& p : peer->exchange.peers) if (p == ctx) p = nullptr;
+	}
+	x.peers.clear();
+	if (x.ev_packed) { (void)hipEventDestroy(x.ev_packed); (void)hipEventDestroy(x.ev_copied); x.ev_packed = x.ev_copied = nullptr; }
+	x.rank = 0; x.world = 1;
+	return RT_OK;
+}
+
+// what: 0 = the final image (1 float4 per pixel), 1 = the inputs of the SVGF filter stage (5 float4 per pixel)
+static int exchange_group(rt_context ** contexts, int count, int what) {
+	const int channels = what == 0 ? 1 : 5;
+	std::string why; RcclApi * api = nullptr;
+	// pack: every context's own tiles (the tile layout is the one rt_set_pixel_tiles gave it)
+	for (int i = 0; i < count; i++) {
+		rt_context * ctx = contexts[i];
+		rt_context::FrameExchange & x = ctx->exchange;
+		RT_REQUIRE(ctx, x.world == count || x.comm, "rt_all_gather: the contexts are not one communicator group");
+		RT_REQUIRE(ctx, ctx->params.tile_pixels > 0 && ctx->params.tile_stride == x.world && ctx->params.tile_first == x.rank, "rt_all_gather: rt_set_pixel_tiles(tile_pixels, rank, world) first");
+		(void)hipSetDevice(ctx->device);
+		const size_t per_rank = exchange_tiles_per_rank(ctx, ctx->params.tile_pixels, x.world) * size_t(ctx->params.tile_pixels) * channels;
+		int status = exchange_buffers(ctx, per_rank); if (status) return status;
+		RT_HIP(ctx, main_waits_for_samples(ctx));
+		if (!x.peers.empty()) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, x.ev_copied, 0));   // the peers have read the previous frame's tiles (see below)
+		const int tiles = int(per_rank / size_t(ctx->params.tile_pixels) / channels);
+		if (what == 0) rt_launch_pack_pixels(ctx->params, x.packed, ctx->params.tile_pixels, x.rank, x.world, tiles, ctx->stream);
+		else { if (!ctx->svgf_allocated) return fail(ctx, RT_ERROR_NOT_READY, "rt_all_gather_svgf_inputs: SVGF is not enabled"); rt_launch_pack_svgf(slot_params(ctx, ctx->slots[0], 0), x.packed, ctx->params.tile_pixels, x.rank, x.world, tiles, ctx->stream); }
+		RT_HIP(ctx, hipEventRecord(x.ev_packed, ctx->stream));
+		if (x.comm && !api) { api = rccl_api(why); if (!api) return fail(ctx, RT_ERROR_NOT_READY, "rt_all_gather: %s", why.c_str()); }
+	}
+	// exchange
+	if (api) {
+		if (count > 1) api->group_start();
+		for (int i = 0; i < count; i++) {
+			rt_context * ctx = contexts[i]; rt_context::FrameExchange & x = ctx->exchange;
+			(void)hipSetDevice(ctx->device);
+			const size_t per_rank = exchange_tiles_per_rank(ctx, ctx->params.tile_pixels, x.world) * size_t(ctx->params.tile_pixels) * channels;
+			int rc = api->all_gather(x.packed, x.gathered, per_rank * 4, RCCL_FLOAT32, x.comm, ctx->stream);
+			if (rc != 0) { if (count > 1) api->group_end(); return fail(ctx, RT_ERROR_HIP, "rt_all_gather: ncclAllGather: %s", api->error_string(rc)); }
+		}
+		if (count > 1) { int rc = api->group_end(); if (rc != 0) return fail(contexts[0], RT_ERROR_HIP, "rt_all_gather: ncclGroupEnd: %s", api->error_string(rc)); }
+	} else {
+		for (int i = 0; i < count; i++) {
+			rt_context * ctx = contexts[i]; rt_context::FrameExchange & x = ctx->exchange;
+			RT_REQUIRE(ctx, int(x.peers.size()) == x.world && count == x.world, "rt_all_gather: an in-process group exchanges all its contexts in one call (rt_all_gather_framebuffers)");
+			(void)hipSetDevice(ctx->device);
+			const size_t per_rank = exchange_tiles_per_rank(ctx, ctx->params.tile_pixels, x.world) * size_t(ctx->params.tile_pixels) * channels;
+			for (int r = 0; r < x.world; r++) {
+				rt_context * peer = x.peers[r];
+				RT_REQUIRE(ctx, peer && peer->exchange.packed_pixels >= per_rank, "rt_all_gather: a member of the group is gone");
+				RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, peer->exchange.ev_packed, 0));
+				if (peer->device == ctx->device) RT_HIP(ctx, hipMemcpyAsync(x.gathered + size_t(r) * per_rank, peer->exchange.packed, per_rank * 16, hipMemcpyDeviceToDevice, ctx->stream));
+				else RT_HIP(ctx, hipMemcpyPeerAsync(x.gathered + size_t(r) * per_rank, ctx->device, peer->exchange.packed, peer->device, per_rank * 16, ctx->stream));
+			}
+		}
+		// a context may pack its next frame only when every peer has copied this one: one event per context, recorded on a
+		// stream that has waited for all the copies (its own stream does: the peers' copy streams are joined through ev_packed
+		// of the NEXT round only, so join them here explicitly)
+		for (int i = 0; i < count; i++) {
+			rt_context * ctx = contexts[i];
+			(void)hipSetDevice(ctx->device);
+			RT_HIP(ctx, hipEventRecord(ctx->ev_interop, ctx->stream));
+		}
+		for (int i = 0; i < count; i++) {
+			rt_context * ctx = contexts[i];
+			(void)hipSetDevice(ctx->device);
+			for (int r = 0; r < count; r++) if (r != i) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, contexts[r]->ev_interop, 0));
+			RT_HIP(ctx, hipEventRecord(ctx->exchange.ev_copied, ctx->stream));
+		}
+	}
+	// unpack: the gathered tiles become every context's whole frame
+	for (int i = 0; i < count; i++) {
+		rt_context * ctx = contexts[i]; rt_context::FrameExchange & x = ctx->exchange;
+		(void)hipSetDevice(ctx->device);
+		const int tiles = int(exchange_tiles_per_rank(ctx, ctx->params.tile_pixels, x.world));
+		if (what == 0) rt_launch_unpack_pixels(ctx->params, x.gathered, ctx->params.tile_pixels, x.world, tiles, ctx->stream);
+		else rt_launch_unpack_svgf(slot_params(ctx, ctx->slots[0], 0), x.gathered, ctx->params.tile_pixels, x.world, tiles, ctx->stream);
+		RT_HIP(ctx, hipGetLastError());
+	}
+	return RT_OK;
+}
+
+int rt_all_gather_framebuffer(rt_context * ctx) {
+	RT_REQUIRE(ctx, ctx, "rt_all_gather_framebuffer: NULL context");
+	if (ctx->exchange.world == 1) return RT_OK;
+	RT_REQUIRE(ctx, ctx->exchange.comm, "rt_all_gather_framebuffer: no communicator (rt_comm_init_rank), or an in-process group (use rt_all_gather_framebuffers)");
+	return exchange_group(&ctx, 1, 0);
+}
+int rt_all_gather_framebuffers(rt_context ** contexts, int count) {
+	if (!contexts || count < 1) return RT_ERROR_INVALID_ARG;
+	if (count == 1 && contexts[0] && contexts[0]->exchange.world == 1) return RT_OK;
+	return exchange_group(contexts, count, 0);
+}
+int rt_all_gather_svgf_inputs(rt_context ** contexts, int count) {
+	if (!contexts || count < 1) return RT_ERROR_INVALID_ARG;
+	if (count == 1 && contexts[0] && contexts[0]->exchange.world == 1) return RT_OK;
+	return exchange_group(contexts, count, 1);
+}
+
 int rt_stream_wait_for_context(rt_context * ctx, void * stream) {
 	RT_REQUIRE(ctx, ctx, "rt_stream_wait_for_context: NULL context");
 	(void)hipSetDevice(ctx->device);
@@ -1092,19 +1307,20 @@ int rt_set_profiling(rt_context * ctx, int enable) {
 	(void)hipSetDevice(ctx->device);
 	RT_HIP(ctx, quiesce(ctx));
 	ctx->profiling = enable == 1;
-	ctx->launch_timing = enable == 2;
+	ctx->launch_timing = enable == 2 || enable == 3;
+	ctx->launch_timing_all = enable == 3;
 	ctx->span_used = 0;
 	ctx->stage_used = 0;
 	return RT_OK;
 }
 
 int rt_get_launch_timings(rt_context * ctx, int kind, float * out_ms, int capacity, int * out_count) {
-	RT_REQUIRE(ctx, ctx && out_count && (out_ms || capacity == 0) && (kind == 0 || kind == 1), "rt_get_launch_timings: invalid argument");
+	RT_REQUIRE(ctx, ctx && out_count && (out_ms || capacity == 0) && kind >= 0 && kind < RT_TIMING_KINDS, "rt_get_launch_timings: invalid argument");
 	(void)hipSetDevice(ctx->device);
 	RT_HIP(ctx, quiesce(ctx));
 	int n = 0;
 	for (size_t i = 0; i + 1 < ctx->span_used; i += 2) {
-		if ((ctx->span_kinds[i] == STAGE_TRACE ? 0 : 1) != kind) continue;
+		if (ctx->span_kinds[i] != kind) continue;
 		float d = 0.0f;
 		if (hipEventElapsedTime(&d, ctx->span_events[i], ctx->span_events[i + 1]) != hipSuccess) continue;
 		if (n < capacity) out_ms[n] = d;
@@ -1113,7 +1329,7 @@ int rt_get_launch_timings(rt_context * ctx, int kind, float * out_ms, int capaci
 	*out_count = n;
 	if (n <= capacity) { // everything delivered: start over (a call with too small a buffer only reports the count)
 		size_t kept = 0;
-		for (size_t i = 0; i + 1 < ctx->span_used; i += 2) if ((ctx->span_kinds[i] == STAGE_TRACE ? 0 : 1) != kind) {
+		for (size_t i = 0; i + 1 < ctx->span_used; i += 2) if (ctx->span_kinds[i] != kind) {
 			std::swap(ctx->span_events[kept], ctx->span_events[i]); std::swap(ctx->span_events[kept + 1], ctx->span_events[i + 1]);
 			ctx->span_kinds[kept] = ctx->span_kinds[i]; ctx->span_kinds[kept + 1] = ctx->span_kinds[i + 1];
 			kept += 2;
@@ -1179,10 +1395,14 @@ static void stage_mark(rt_context * ctx, int kind, hipStream_t stream) {
 // mode 2: an event on the launch's own stream before and after it (does not order other streams)
 static void span_mark(rt_context * ctx, int kind, hipStream_t stream) {
 	if (!ctx->time_this_sample) return;
+	if (kind != SPAN_TRACE && kind != SPAN_SHADOW && !ctx->launch_timing_all) return;
 	if (ctx->span_used == ctx->span_events.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->span_events.push_back(e); ctx->span_kinds.push_back(0); }
 	ctx->span_kinds[ctx->span_used] = kind;
 	(void)hipEventRecord(ctx->span_events[ctx->span_used++], stream);
 }
+
+// rt_launch_svgf_taa calls this before and after each of its kernels (mode 3)
+static void svgf_span_mark(void * user, int svgf_kernel, hipStream_t stream) { span_mark((rt_context *)user, SPAN_SVGF + svgf_kernel, stream); }
 
 __global__ void kernel_accumulate_counters(const RtBufferSizes * sizes, int * totals) {
 	int b = threadIdx.x;
@@ -1387,7 +1607,7 @@ static int stream_complete(rt_context * ctx, const StreamSubmission * subs, int 
 			RtParams pf = p;
 			for (int i = 0; i < RT_AOV_COUNT; i++) if (pf.aovs[i].framebuffer) pf.aovs[i].framebuffer += size_t(sub.slot_base) * ctx->frame_pixels;
 			pf.gbuffer_normal_and_depth += size_t(sub.slot_base) * ctx->frame_pixels; pf.gbuffer_mesh_id_and_triangle_id += size_t(sub.slot_base) * ctx->frame_pixels; pf.gbuffer_screen_position_prev += size_t(sub.slot_base) * ctx->frame_pixels;
-			rt_launch_svgf_taa(pf, sub.first_sample, st);
+			rt_launch_svgf_taa(pf, sub.first_sample, st, ctx->launch_timing_all && ctx->time_this_sample ? svgf_span_mark : nullptr, ctx);
 			for (int i = 0; i < RT_AOV_COUNT; i++) if (pf.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(pf.aovs[i].framebuffer, 0, ctx->frame_pixels * 16 * size_t(sub.sample_count), st)); // aovs_clear_to_zero
 		}
 	} else
@@ -1404,7 +1624,9 @@ static int stream_complete(rt_context * ctx, const StreamSubmission * subs, int 
 		}
 		RtParams pa = p;
 		pa.tile_pixels = head.tile_pixels; pa.tile_first = head.tile_first; pa.tile_stride = head.tile_stride;
+		span_mark(ctx, SPAN_ACCUMULATE, st);
 		rt_launch_accumulate_group(pa, group, head.range_offset, head.range_count, st);
+		span_mark(ctx, SPAN_ACCUMULATE, st);
 		first = k;
 	}
 	stage_mark(ctx, STAGE_END, st);
@@ -1457,7 +1679,9 @@ static int stream_generate(rt_context * ctx, const StreamSubmission & sub) {
 	pg.tile_pixels = sub.tile_pixels; pg.tile_first = sub.tile_first; pg.tile_stride = sub.tile_stride;
 	RT_HIP(ctx, hipEventRecord(s.ev_begin[sub.ring], st));
 	stage_mark(ctx, STAGE_GENERATE, st);
+	span_mark(ctx, SPAN_GENERATE, st);
 	rt_launch_generate_stream(pg, sub.first_sample, sub.range_offset, sub.range_count, sub.slot_base, int(s.pending_paths), st);
+	span_mark(ctx, SPAN_GENERATE, st);
 	s.pending++; s.pending_paths += sub.paths;
 	return RT_OK;
 }
@@ -1476,15 +1700,17 @@ static int stream_enqueue_iteration(rt_context * ctx) {
 	s.generated[i % RT_STREAM_PROGRESS_RING] = generated;
 	RT_HIP(ctx, hipEventRecord(s.iteration_done[i % RT_STREAM_PROGRESS_RING], st));
 	stage_mark(ctx, STAGE_TRACE, st);
-	span_mark(ctx, STAGE_TRACE, st);
+	span_mark(ctx, SPAN_TRACE, st);
 	rt_launch_trace_stream(p, ctx->trace_statistics ? ctx->trace_stats : nullptr, st);
-	span_mark(ctx, STAGE_TRACE, st);
+	span_mark(ctx, SPAN_TRACE, st);
 	if (ctx->trace_statistics && ctx->stream_history_rows < RT_STREAM_HISTORY_ROWS)
 		RT_HIP(ctx, hipMemcpyAsync(ctx->stream_history + size_t(10) * ctx->stream_history_rows++, ctx->trace_stats, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 	stage_mark(ctx, STAGE_SORT, st);
+	span_mark(ctx, SPAN_SORT, st);
 	rt_launch_sort_stream(p, st);
+	span_mark(ctx, SPAN_SORT, st);
 	stage_mark(ctx, STAGE_SHADE, st);
-	for (int m = 0; m < 4; m++) if (ctx->has_material[m]) rt_launch_material_stream(p, m, st);
+	for (int m = 0; m < 4; m++) if (ctx->has_material[m]) { span_mark(ctx, SPAN_MATERIAL + m, st); rt_launch_material_stream(p, m, st); span_mark(ctx, SPAN_MATERIAL + m, st); }
 	stage_mark(ctx, STAGE_END, st);
 	s.iteration = i + 1;
 	StreamSubmission done[RT_STREAM_MAX_BATCH]; int done_count = 0;
@@ -1714,7 +1940,7 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 			for (int bounce = 0; bounce < p.config.num_bounces; bounce++) {
 				stage_mark(ctx, STAGE_TRACE, st);
 				if (ctx->trace_statistics) rt_launch_trace_counting(p, bounce, ctx->trace_stats, st);
-				else { span_mark(ctx, STAGE_TRACE, st); rt_launch_trace(p, bounce, st); span_mark(ctx, STAGE_TRACE, st); }
+				else { span_mark(ctx, SPAN_TRACE, st); rt_launch_trace(p, bounce, st); span_mark(ctx, SPAN_TRACE, st); }
 				if (shadow_pending) { RT_HIP(ctx, hipStreamWaitEvent(st, slot.ev_shadowed, 0)); shadow_pending = false; }
 				stage_mark(ctx, STAGE_SORT, st);
 				rt_launch_sort(p, bounce, sample_index, st);
@@ -1728,9 +1954,9 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 					else {
 						RT_HIP(ctx, hipEventRecord(slot.ev_shaded, st));
 						RT_HIP(ctx, hipStreamWaitEvent(slot.side, slot.ev_shaded, 0));
-						span_mark(ctx, STAGE_SHADOW, slot.side);
+						span_mark(ctx, SPAN_SHADOW, slot.side);
 						rt_launch_trace_shadow(p_shadow, bounce, slot.side);
-						span_mark(ctx, STAGE_SHADOW, slot.side);
+						span_mark(ctx, SPAN_SHADOW, slot.side);
 						RT_HIP(ctx, hipEventRecord(slot.ev_shadowed, slot.side));
 						shadow_pending = true;
 					}
@@ -1908,7 +2134,7 @@ int rt_get_counters(rt_context * ctx, rt_counters * out) {
 	if (ctx->launch_timing) { // sums over every launch since the mode was enabled (rt_get_launch_timings returns each and starts over)
 		for (size_t i = 0; i + 1 < ctx->span_used; i += 2) {
 			float d = 0.0f;
-			if (hipEventElapsedTime(&d, ctx->span_events[i], ctx->span_events[i + 1]) == hipSuccess) (ctx->span_kinds[i] == STAGE_TRACE ? c.ms_trace : c.ms_shadow) += d;
+			if (hipEventElapsedTime(&d, ctx->span_events[i], ctx->span_events[i + 1]) == hipSuccess) { if (ctx->span_kinds[i] == SPAN_TRACE) c.ms_trace += d; else if (ctx->span_kinds[i] == SPAN_SHADOW) c.ms_shadow += d; }
 		}
 	}
 	if (ctx->profiling) {

@@ -208,45 +208,74 @@ RT_DEV uchar4 bc1_texel(uint2 block, int x_in_block, int y_in_block) {
 	return make_uchar4(0, 0, 0, 0);
 }
 
-// level_offset: in texels (RGBA8) or in blocks (BC1)
-RT_DEV f4 texture_texel(const RtTexture & tex, size_t level_offset, int w, int h, int x, int y) {
-	x = wrap_index(x, w); y = wrap_index(y, h);
-	uchar4 c;
-	if (tex.format == RT_TEXTURE_BC1) {
-		int blocks_per_row = (w + 3) >> 2;
-		uint2 block = ((const uint2 *)tex.texels)[level_offset + size_t(x >> 2) + size_t(y >> 2) * blocks_per_row];
-		c = bc1_texel(block, x & 3, y & 3);
-	} else {
-		c = tex.texels[level_offset + size_t(x) + size_t(y) * w];
-	}
-	return mk4(float(c.x) * (1.0f / 255.0f), float(c.y) * (1.0f / 255.0f), float(c.z) * (1.0f / 255.0f), float(c.w) * (1.0f / 255.0f));
-}
-RT_DEV f4 texture_bilinear(const RtTexture & tex, int level, float s, float t) {
-	size_t offset = 0;
+// A mip level as the filter sees it: where it starts (in texels for RGBA8, in blocks for BC1) and its size.
+struct RtTextureLevel { size_t offset; int w, h; };
+RT_DEV RtTextureLevel texture_level(const RtTexture & tex, int level) {
+	RtTextureLevel r; r.offset = 0;
 	for (int l = 0; l < level; l++) {
 		int lw = max(tex.width >> l, 1), lh = max(tex.height >> l, 1);
-		offset += tex.format == RT_TEXTURE_BC1 ? size_t((lw + 3) >> 2) * ((lh + 3) >> 2) : size_t(lw) * lh;
+		r.offset += tex.format == RT_TEXTURE_BC1 ? size_t((lw + 3) >> 2) * ((lh + 3) >> 2) : size_t(lw) * lh;
 	}
-	int w = max(tex.width >> level, 1), h = max(tex.height >> level, 1);
+	r.w = max(tex.width >> level, 1); r.h = max(tex.height >> level, 1);
+	return r;
+}
+RT_DEV RtTextureLevel texture_level_after(const RtTexture & tex, const RtTextureLevel & at, int level) {   // level + 1, from `level`
+	RtTextureLevel r;
+	r.offset = at.offset + (tex.format == RT_TEXTURE_BC1 ? size_t((at.w + 3) >> 2) * ((at.h + 3) >> 2) : size_t(at.w) * at.h);
+	r.w = max(tex.width >> (level + 1), 1); r.h = max(tex.height >> (level + 1), 1);
+	return r;
+}
+RT_DEV f4 texel_to_float(uchar4 c) { return mk4(float(c.x) * (1.0f / 255.0f), float(c.y) * (1.0f / 255.0f), float(c.z) * (1.0f / 255.0f), float(c.w) * (1.0f / 255.0f)); }
+
+// One bilinear footprint: the four texels around (s, t) of one level, wrap addressing, weights in full fp32.
+// The two columns and the two rows are wrapped ONCE each -- with a mask where the size is a power of two (every BC1 level
+// is), a remainder otherwise: the integer remainders of a tap-by-tap formulation (eight per footprint, ~20 instructions each
+// without a divide unit) were most of what a texture lookup cost. Same texels, same arithmetic on them.
+RT_DEV f4 texture_bilinear(const RtTexture & tex, const RtTextureLevel & lv, float s, float t) {
+	const int w = lv.w, h = lv.h;
 	float x = s * float(w) - 0.5f, y = t * float(h) - 0.5f;
 	float x0f = floorf(x), y0f = floorf(y);
 	float fx = x - x0f, fy = y - y0f;
-	int x0 = int(x0f), y0 = int(y0f);
-	f4 c00 = texture_texel(tex, offset, w, h, x0, y0),     c10 = texture_texel(tex, offset, w, h, x0 + 1, y0);
-	f4 c01 = texture_texel(tex, offset, w, h, x0, y0 + 1), c11 = texture_texel(tex, offset, w, h, x0 + 1, y0 + 1);
-	return lerp4(lerp4(c00, c10, fx), lerp4(c01, c11, fx), fy);
+	int x0 = int(x0f), y0 = int(y0f), x1 = x0 + 1, y1 = y0 + 1;
+	if ((w & (w - 1)) == 0) { x0 &= w - 1; x1 &= w - 1; } else { x0 = wrap_index(x0, w); x1 = x0 + 1 == w ? 0 : x0 + 1; }
+	if ((h & (h - 1)) == 0) { y0 &= h - 1; y1 &= h - 1; } else { y0 = wrap_index(y0, h); y1 = y0 + 1 == h ? 0 : y0 + 1; }
+	uchar4 c00, c10, c01, c11;
+	if (tex.format == RT_TEXTURE_BC1) {
+		const uint2 * blocks = (const uint2 *)tex.texels + lv.offset;
+		const int blocks_per_row = (w + 3) >> 2;
+		const size_t row0 = size_t(y0 >> 2) * blocks_per_row, row1 = size_t(y1 >> 2) * blocks_per_row;
+		uint2 b00 = blocks[row0 + (x0 >> 2)], b10 = blocks[row0 + (x1 >> 2)], b01 = blocks[row1 + (x0 >> 2)], b11 = blocks[row1 + (x1 >> 2)];
+		c00 = bc1_texel(b00, x0 & 3, y0 & 3); c10 = bc1_texel(b10, x1 & 3, y0 & 3);
+		c01 = bc1_texel(b01, x0 & 3, y1 & 3); c11 = bc1_texel(b11, x1 & 3, y1 & 3);
+	} else {
+		const uchar4 * texels = tex.texels + lv.offset;
+		const size_t row0 = size_t(y0) * w, row1 = size_t(y1) * w;
+		c00 = texels[row0 + x0]; c10 = texels[row0 + x1]; c01 = texels[row1 + x0]; c11 = texels[row1 + x1];
+	}
+	return lerp4(lerp4(texel_to_float(c00), texel_to_float(c10), fx), lerp4(texel_to_float(c01), texel_to_float(c11), fx), fy);
 }
-RT_DEV f4 texture_get(const RtTexture & tex, float s, float t) { return texture_bilinear(tex, 0, s, t); }
-RT_DEV f4 texture_get_lod(const RtTexture & tex, float s, float t, float lod) {
+RT_DEV f4 texture_get(const RtTexture & tex, float s, float t) { return texture_bilinear(tex, texture_level(tex, 0), s, t); }
+
+// Trilinear between floor(lod) and the next level; the levels are looked up once per filtered fetch, not once per probe.
+struct RtTrilinear { RtTextureLevel l0, l1; float fl; bool single; };
+RT_DEV RtTrilinear texture_trilinear_levels(const RtTexture & tex, float lod) {
 	float max_level = float(tex.mip_levels - 1);
 	lod = fminf(fmaxf(lod, 0.0f), max_level);
 	float l0f = floorf(lod);
 	int l0 = int(l0f), l1 = l0 + 1 < tex.mip_levels ? l0 + 1 : l0;
-	float fl = lod - l0f;
-	f4 a = texture_bilinear(tex, l0, s, t);
-	if (fl == 0.0f || l1 == l0) return a;
-	return lerp4(a, texture_bilinear(tex, l1, s, t), fl);
+	RtTrilinear r;
+	r.fl = lod - l0f;
+	r.single = r.fl == 0.0f || l1 == l0;
+	r.l0 = texture_level(tex, l0);
+	r.l1 = r.single ? r.l0 : texture_level_after(tex, r.l0, l0);
+	return r;
 }
+RT_DEV f4 texture_trilinear(const RtTexture & tex, const RtTrilinear & tri, float s, float t) {
+	f4 a = texture_bilinear(tex, tri.l0, s, t);
+	if (tri.single) return a;
+	return lerp4(a, texture_bilinear(tex, tri.l1, s, t), tri.fl);
+}
+RT_DEV f4 texture_get_lod(const RtTexture & tex, float s, float t, float lod) { return texture_trilinear(tex, texture_trilinear_levels(tex, lod), s, t); }
 RT_DEV f4 texture_get_grad(const RtTexture & tex, float s, float t, f2 dx, f2 dy) {
 	float w = float(tex.width), h = float(tex.height);
 	float px = sqrtf(square(dx.x * w) + square(dx.y * h));
@@ -257,10 +286,11 @@ RT_DEV f4 texture_get_grad(const RtTexture & tex, float s, float t, f2 dx, f2 dy
 	if (!(n_f >= 1.0f)) n_f = 1.0f;
 	int n = int(n_f);
 	float lod = log2f(fmaxf(p_max / n_f, 1e-12f));
+	const RtTrilinear tri = texture_trilinear_levels(tex, lod);   // every probe of the footprint filters the same two levels
 	f4 sum = mk4(0.0f);
 	for (int i = 0; i < n; i++) {
 		float o = (float(i) + 0.5f) / n_f - 0.5f;
-		sum += texture_get_lod(tex, s + major.x * o, t + major.y * o, lod);
+		sum += texture_trilinear(tex, tri, s + major.x * o, t + major.y * o);
 	}
 	return sum * (1.0f / n_f);
 }

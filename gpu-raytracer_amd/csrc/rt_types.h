@@ -181,7 +181,7 @@ struct RtParams {
 	int    * history_length;
 	float4 * history_direct, * history_indirect, * history_moment, * history_normal_and_depth;
 	float4 * taa_frame_prev, * taa_frame_curr;
-	float4 * taa_scratch;
+	float4 * svgf_normal_and_depth;   // (normal, depth) of the frame being filtered: decoded once by kernel_svgf_reproject for the variance / a-trous taps
 };
 
 // Scan-order index of local pixel i of this context: its tiles are tile_first, tile_first +
@@ -237,7 +237,8 @@ void rt_launch_accumulate(const RtParams & p, float frames_accumulated, int pixe
 #define RT_ACCUMULATE_GROUP 8
 struct RtAccumulateGroup { int count; int first_sample[RT_ACCUMULATE_GROUP], sample_count[RT_ACCUMULATE_GROUP], slot_base[RT_ACCUMULATE_GROUP]; };
 void rt_launch_accumulate_group(const RtParams & p, const RtAccumulateGroup & group, int pixel_offset, int pixel_count, hipStream_t stream);
-void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream);
+// mark(user, k, stream), if given, is called before and after kernel k = 0 reproject, 1 variance, 2 a-trous (each pass), 3 finalize, 4 TAA, 5 TAA finalize
+void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream, void (*mark)(void * user, int svgf_kernel, hipStream_t stream) = nullptr, void * user = nullptr);
 void rt_launch_random(const RtParams & p, int dimension, const unsigned * pixel_indices, int count, unsigned bounce, unsigned sample_index, float2 * out, hipStream_t stream);
 void rt_launch_integrate_luts(const RtParams & p, float * dielectric_dir_enter, float * dielectric_dir_leave, float * dielectric_enter, float * dielectric_leave,
                               float * conductor_dir, float * conductor, hipStream_t stream);

@@ -319,9 +319,9 @@ void Integrator::update(float delta) {
 		check(rt_set_scheduler(ctx, scheduler_for_scene_updates ? RT_SCHEDULER_SLOTS : RT_SCHEDULER_MERGED));
 	}
 	if (cpu_config.enable_scene_update) {
-		scene.update(delta);
+		if (!scene_advanced_by_another_integrator) scene.update(delta);
 		invalidated_scene = true;
-	} else if (gpu_config.enable_svgf || invalidated_scene) {
+	} else if ((gpu_config.enable_svgf || invalidated_scene) && !scene_advanced_by_another_integrator) {
 		scene.camera.update(0.0f);
 		scene.update(0.0f);
 	}

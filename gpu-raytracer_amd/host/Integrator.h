@@ -60,6 +60,9 @@ struct Integrator {
 	PixelQuery pixel_query = { INVALID, INVALID, INVALID };
 	enum struct PixelQueryStatus { INACTIVE, PENDING, OUTPUT_READY } pixel_query_status = PixelQueryStatus::INACTIVE; // Integrator.h:75-79
 	bool scheduler_for_scene_updates = false;
+	// Several integrators on ONE scene (FrameSplit: one per GPU): Camera::update and Mesh::update shift "current" into
+	// "previous" on every call, so only the first integrator of a frame may advance the scene; the others upload what it left.
+	bool scene_advanced_by_another_integrator = false;
 	// The current TLAS was built by the device (rt_build_tlas): the host holds no TLAS nodes, `tlas.indices` and the
 	// TLAS-ordered instance tables are fetched from the device when something on the host needs them (pixel queries,
 	// the parity checker's view of the scene).

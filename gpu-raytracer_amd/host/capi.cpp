@@ -2,6 +2,7 @@
 // host applications written in C. Nothing here touches the GPU directly: the device is
 // reached only through the Pathtracer, i.e. through include/gpu_raytracer_amd.h.
 #include <stdexcept>
+#include "FrameSplit.h"
 #include "Pathtracer.h"
 #include "Exporters.h"
 #include "BlockCompression.h"
@@ -360,6 +361,37 @@ int grt_pathtracer_read_framebuffer(void * pt, float * dst) {
 		memcpy(dst, image.data(), image.size() * sizeof(float));
 		return 0;
 	GRT_CATCH(-1)
+}
+
+// ---- FrameSplit: several GPUs (or, for tests, several contexts of one GPU) render one frame ------------------------
+void * grt_frame_split_create(void * scene, int width, int height, const int * device_ordinals, int count) {
+	GRT_TRY
+		return new FrameSplit(width, height, *(Scene *)scene, std::vector<int>(device_ordinals, device_ordinals + count));
+	GRT_CATCH(nullptr)
+}
+void grt_frame_split_free(void * split) { delete (FrameSplit *)split; }
+int grt_frame_split_update(void * split, float delta) {
+	GRT_TRY
+		((FrameSplit *)split)->update(delta);
+		return 0;
+	GRT_CATCH(-1)
+}
+int grt_frame_split_render(void * split) {
+	GRT_TRY
+		((FrameSplit *)split)->render();
+		return 0;
+	GRT_CATCH(-1)
+}
+int grt_frame_split_render_samples(void * split, int count) {
+	GRT_TRY
+		((FrameSplit *)split)->render_samples(count);
+		return 0;
+	GRT_CATCH(-1)
+}
+// the integrator of one rank (a grt_pathtracer_* handle owned by the split): its framebuffer is the whole frame after render()
+void * grt_frame_split_rank(void * split, int rank) {
+	FrameSplit * s = (FrameSplit *)split;
+	return rank >= 0 && rank < s->world() ? static_cast<Integrator *>(s->ranks[rank].get()) : nullptr;
 }
 
 // Host staging arrays by name (what the device was / would be given), read-only views.

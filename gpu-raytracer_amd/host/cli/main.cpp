@@ -3,7 +3,8 @@
 // run update() / render() until sample_index reaches -N, write the frame (-o file.ppm | file.exr)
 // and exit. Window, GUI and the interactive camera are out of scope.
 //
-// Options without a counterpart in the reference: --device <ordinal>, --bvh-cache <bool>
+// Options without a counterpart in the reference: --device <ordinal>, --devices <a,b,...> (one frame split over several
+// GPUs: row tiles dealt round-robin, one RCCL all-gather per render(), host/FrameSplit.h), --bvh-cache <bool>
 // (the reference always uses its .bvh caches; here they are opt-in), --batch <n> samples per
 // submission (default 4; 1 = one render() per sample exactly like the reference loop).
 #include <chrono>
@@ -16,6 +17,7 @@
 #include <vector>
 
 #include "../AO.h"
+#include "../FrameSplit.h"
 #include "../Pathtracer.h"
 
 namespace {
@@ -30,6 +32,7 @@ struct Option {
 
 struct CommandLine {
 	int  device = 0;
+	std::vector<int> devices;   // --devices: more than one entry = tile split (FrameSplit)
 	int  batch  = 4;
 	bool help   = false;
 	bool print_config = false;
@@ -104,6 +107,15 @@ std::vector<Option> make_options(CommandLine & cl) {
 	} });
 	o.push_back({ "c", "compress",  "Enables or disables texture block compression (BC1, decoded in the shade kernels; default true, as in the reference)", 1, [](const char * v) { cpu_config.enable_block_compression = parse_bool(v); } });
 	o.push_back({ nullptr, "device",    "HIP device ordinal to render on", 1, [&cl](const char * v) { cl.device = parse_int(v, "--device"); } });
+	o.push_back({ nullptr, "devices",   "Comma-separated HIP device ordinals: the frame is split into row tiles over them (an ordinal may repeat: contexts sharing a GPU)", 1, [&cl](const char * v) {
+		cl.devices.clear();
+		std::string list(v);
+		for (size_t at = 0; at <= list.size(); ) {
+			size_t comma = list.find(',', at); if (comma == std::string::npos) comma = list.size();
+			cl.devices.push_back(parse_int(list.substr(at, comma - at).c_str(), "--devices"));
+			at = comma + 1;
+		}
+	} });
 	o.push_back({ nullptr, "bvh-cache", "Enables or disables reading and writing <mesh>.bvh cache files", 1, [](const char * v) { cpu_config.enable_bvh_cache = parse_bool(v); } });
 	o.push_back({ nullptr, "batch",     "Samples per submission to the device (1..16)", 1, [&cl](const char * v) {
 		cl.batch = parse_int(v, "--batch");
@@ -183,6 +195,26 @@ int main(int argc, char ** argv) {
 	try {
 		auto t0 = std::chrono::steady_clock::now();
 		Scene scene;
+		if (cl.devices.size() > 1) { // one frame over several GPUs
+			if (cpu_config.integrator == IntegratorType::AO) die("--devices: the tile split exists for the path tracer");
+			FrameSplit split(cpu_config.initial_width, cpu_config.initial_height, scene, cl.devices);
+			printf("Initialization: %.0f ms (%d ranks)\n", seconds_since(t0) * 1e3, split.world());
+			auto t1 = std::chrono::steady_clock::now();
+			int target = cpu_config.output_sample_index;
+			while (true) {
+				split.update(0.0f);
+				int remaining = target - split.sample_index() + 1;
+				if (cl.batch > 1 && split.sample_index() > 0 && remaining > 1) split.render_samples(remaining < cl.batch ? remaining : cl.batch);
+				else split.render();
+				if (split.sample_index() >= target) break;
+			}
+			split.read_framebuffer(); // waits for the devices
+			printf("Rendered sample %d at %dx%d in %.1f ms\n", split.sample_index(), split.front().screen_width, split.front().screen_height, seconds_since(t1) * 1e3);
+			split.save_image(cpu_config.output_filename);
+			printf("Wrote %s\n", cpu_config.output_filename.c_str());
+			return 0;
+		}
+		if (cl.devices.size() == 1) cl.device = cl.devices[0];
 		std::unique_ptr<Integrator> integrator;
 		if (cpu_config.integrator == IntegratorType::AO) integrator = std::make_unique<AO>        (cpu_config.initial_width, cpu_config.initial_height, scene, cl.device);
 		else                                             integrator = std::make_unique<Pathtracer>(cpu_config.initial_width, cpu_config.initial_height, scene, cl.device);

@@ -227,6 +227,25 @@ int rt_set_pixel_tiles(rt_context * ctx, int tile_pixels, int first_tile, int ti
  *        the final image in scan order.                                                       */
 int rt_pack_pixels(rt_context * ctx, void * dst_device, int tile_pixels, int first_tile, int tile_stride, int tiles);
 int rt_unpack_pixels(rt_context * ctx, const void * src_device, int tile_pixels, int world, int tiles_per_rank);
+
+/* The same exchange WITHOUT a Python / torch.distributed layer: the tile split of a C++ host (host/FrameSplit.h,
+ * `pathtracer --devices 0,1,...`). One communicator per context, over RCCL (librccl.so is bound at run time, so the library
+ * has no link-time dependency on it):
+ *   several processes, one GPU each:  rank 0 calls rt_comm_unique_id and hands the 128 bytes to the others (any side channel:
+ *                                     a file, a socket, MPI), every rank calls rt_comm_init_rank (= ncclCommInitRank);
+ *   one process, several GPUs:        rt_comm_init_all over its contexts (= ncclCommInitAll). Contexts that SHARE a GPU --
+ *                                     which RCCL refuses -- are joined by stream-ordered peer copies instead (tests).
+ * A context renders the tiles rt_set_pixel_tiles(ctx, tile_pixels, rank, world) names; rt_all_gather_framebuffer packs them,
+ * all-gathers (ncclAllGather on the context's stream) and scatters the result into every context's final image, asynchronously.
+ * Contexts of one process are exchanged by ONE call (grouped: ncclGroupStart / End). rt_all_gather_svgf_inputs moves what the
+ * SVGF filter stage reads of a frame instead (DIRECT, INDIRECT, ALBEDO, the g-buffers: 80 B per pixel; see rt_pack_svgf_inputs). */
+int rt_comm_unique_id(void * out_id_128_bytes);
+int rt_comm_init_rank(rt_context * ctx, const void * unique_id_128_bytes, int rank, int world);
+int rt_comm_init_all(rt_context ** contexts, int count);
+int rt_comm_destroy(rt_context * ctx);
+int rt_all_gather_framebuffer(rt_context * ctx);
+int rt_all_gather_framebuffers(rt_context ** contexts, int count);
+int rt_all_gather_svgf_inputs(rt_context ** contexts, int count);
 /* Stream-ordered hand-over of device buffers between the context and a consumer's HIP stream
  * (e.g. the stream RCCL runs on), so that the host never has to block between frames:
  *   rt_stream_wait_for_context: `stream` (a hipStream_t) waits for everything the context has
@@ -323,11 +342,22 @@ int rt_synchronize(rt_context * ctx);
  * enable = 2: events around EVERY traversal launch, on the stream each is launched on; concurrency
  *             (merged wavefront, or side stream and samples in flight) stays as in production.
  *             rt_get_counters then returns in ms_trace / ms_shadow the SUM over those launches
- *             since the mode was enabled or counters were last read, rt_get_launch_timings each. */
+ *             since the mode was enabled or counters were last read, rt_get_launch_timings each.
+ * enable = 3: as 2, plus events around every OTHER launch of the merged wavefront (generate, sort, one per
+ *             material queue, accumulate, each SVGF / TAA kernel): the per-stage rooflines of bench.py. */
 int rt_set_profiling(rt_context * ctx, int enable);
-/* rt_set_profiling(ctx, 2): HIP events around every traversal launch, each on the stream it runs on. Durations in
- * milliseconds of the launches since the mode was enabled (or since the last call), in submission order:
- * kind 0 = closest-hit / fused traversal launches, 1 = separate shadow launches (slot scheduler).          */
+/* What a timed launch was (rt_set_profiling 2 / 3). */
+enum {
+	RT_TIMING_TRACE = 0,        /* closest-hit launches; the fused traversal launch of the merged wavefront */
+	RT_TIMING_SHADOW = 1,       /* separate shadow launches (slot scheduler) */
+	RT_TIMING_SORT = 2, RT_TIMING_GENERATE = 3, RT_TIMING_ACCUMULATE = 4,
+	RT_TIMING_MATERIAL_0 = 5,   /* + material slot: diffuse, plastic, dielectric, conductor */
+	RT_TIMING_SVGF_REPROJECT = 9, RT_TIMING_SVGF_VARIANCE = 10, RT_TIMING_SVGF_ATROUS = 11, RT_TIMING_SVGF_FINALIZE = 12,
+	RT_TIMING_TAA = 13, RT_TIMING_TAA_FINALIZE = 14,
+	RT_TIMING_KINDS = 15
+};
+/* Durations in milliseconds of the launches of one kind since the mode was enabled (or since the last call for
+ * that kind), in submission order; each event pair sits on the stream the launch runs on.                    */
 int rt_get_launch_timings(rt_context * ctx, int kind, float * out_ms, int capacity, int * out_count);
 /* Work statistics of the trace kernels: when enabled, rt_render_sample runs counting variants
  * of kernel_trace(_shadow)_bvh8 (slower: per-ray atomics) and rt_get_trace_statistics returns,

@@ -93,3 +93,30 @@ def test_block_compressed_textures_render_like_the_oracle(grt, oracle):
         frames[compress] = pt.read_framebuffer()[:, :320, :3].copy()
         pt.close(); scene.close()
     assert not np.array_equal(frames[0], frames[1])
+
+
+def test_frame_split_in_one_process_without_python_collectives(grt):
+    """host/FrameSplit.h over the C ABI's own frame exchange (rt_comm_init_all, rt_all_gather_framebuffers): two and three
+    contexts of ONE GPU -- RCCL refuses a device twice in a communicator, so they exchange by stream-ordered peer copies; on
+    distinct GPUs the same calls go through ncclAllGather -- render one frame as row tiles dealt round-robin. After every
+    render() EVERY rank's final image is the whole frame, bit-identical to a single context's: accumulated samples,
+    4-sample submissions, and SVGF + TAA frames (inputs of the filter gathered, every rank filters)."""
+    for config, steps in ((dict(num_bounces=4), ("render", "render", "samples3", "render")), (dict(num_bounces=3, enable_svgf=1, enable_taa=1), ("render",) * 4)):
+        images = {}
+        for world in (1, 2, 3):
+            scene, pt = make_pathtracer(grt, "cornellbox", 200, 152, -1, **config)
+            pt.close()
+            split = grt.FrameSplit(scene, 200, 152, [0] * world)
+            for step in steps:
+                split.update()
+                if step == "render":
+                    split.render()
+                else:
+                    split.render_samples(int(step[-1]))
+            images[world] = [split.rank(r).read_framebuffer().copy() for r in range(world)]
+            split.close(); scene.close()
+        assert np.isfinite(images[1][0]).all() and images[1][0][..., :3].max() > 0
+        for world in (2, 3):
+            for r in range(world):
+                assert np.array_equal(images[world][r], images[1][0]), (config, world, r)
+    grt.config_reset()

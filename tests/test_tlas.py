@@ -51,7 +51,13 @@ def decode_nodes(nodes):
 
 
 def check_tlas(nodes, order, world_boxes):
-    """Structural invariants of a TLAS over len(order) instances (world_boxes in scene order: (n, 2, 3))."""
+    """Structural invariants of a TLAS over len(order) instances (world_boxes in scene order: (n, 2, 3)), decoded here in
+    numpy from the 80-byte node format alone -- nothing of the product's builder is used, so this is the independent half of
+    the device-TLAS tests (tests/test_gpu_tlas.py runs it on the nodes the MI355X built). It restates what the reference's
+    converter asserts of its own output (BVH8Converter.cpp:21,293,303,322-323): every primitive in exactly one leaf, an
+    inner child's meta byte is 0b001xxxxx with its slot + 24 and its imask bit set, a leaf's unary count and offset stay
+    below 24 and the leaf offsets of a node run 0, 1, 2, ... in slot order, inner children sit in consecutive node slots
+    from base_index_child -- plus what traversal relies on: each quantised child box contains the boxes of everything below it."""
     n = len(order)
     assert sorted(order.tolist()) == list(range(n))                       # a permutation: every instance in exactly one leaf
     p, scale, imask, base_child, base_leaf, meta, q = decode_nodes(nodes)
@@ -60,6 +66,9 @@ def check_tlas(nodes, order, world_boxes):
     def visit(k):
         below = []
         inner_rank = 0
+        leaf_offsets = [int(meta[k, s]) & 31 for s in range(8) if int(meta[k, s]) and not (imask[k] >> s) & 1]
+        assert leaf_offsets == list(range(len(leaf_offsets))) and len(leaf_offsets) <= 24          # num_triangles runs up in slot order (BVH8Converter.cpp:300-303)
+        assert all(int(meta[k, s]) for s in range(8) if (imask[k] >> s) & 1)                       # an imask bit names a filled slot
         for s in range(8):
             m = int(meta[k, s])
             if m == 0:
