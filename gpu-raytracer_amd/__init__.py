@@ -68,7 +68,13 @@ def device_lib():
     if _device is None:
         if not os.path.exists(DEVICE_LIB_PATH):
             raise DeviceLibraryMissing("%s is missing -- run `python __graft_entry__.py` (build()) first" % DEVICE_LIB_PATH)
+        # HIP reads this at the first HIP call of the process; the per-submission scheduler runs up to 18 streams.
+        # The library itself leaves the environment alone; a process that initialised HIP earlier (torch imported and used
+        # first) keeps HIP's default of 4 queues and the context says so when it matters.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
         lib = ctypes.CDLL(DEVICE_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        if hasattr(lib, "rt_abi_version") and lib.rt_abi_version() != 3:
+            raise DeviceLibraryMissing("%s has ABI version %d, this front end was written for 3 -- rebuild (python __graft_entry__.py)" % (DEVICE_LIB_PATH, lib.rt_abi_version()))
         lib.rt_last_error.restype = c_char_p
         lib.rt_last_error.argtypes = [c_void_p]
         lib.rt_version.restype = c_char_p

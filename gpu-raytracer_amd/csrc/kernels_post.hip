@@ -12,6 +12,25 @@
 #define RT_POST_BLOCK_X 64
 #define RT_POST_BLOCK_Y 4
 
+// Pixel of this thread in the image-space kernels below (SVGF, TAA): tiles of 64 x 4 pixels, dealt to the workgroups so
+// that the tiles one XCD works on are NEIGHBOURS. Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md: observed, for speed
+// only) and every XCD has its own 4 MiB L2: with tile = workgroup index, horizontally adjacent tiles land on eight
+// different L2s, every XCD pulls the whole frame through the fabric, and a stencil's taps -- nine rows of three images in
+// an a-trous pass -- are fetched up to nine times from the Infinity Cache instead of once (measured: 0.078 ms per pass for
+// 0.17 GB of compulsory traffic). Here XCD k takes the k-th eighth of the row-major tile sequence, in order: a band of
+// ~135 rows at 1080p, swept top to bottom, whose taps stay in the band's own L2 lines.
+// The launch is one-dimensional and padded to a multiple of 8 workgroups; returns false for a padding workgroup.
+RT_DEV bool post_tile_pixel(const RtParams & p, int & x, int & y) {
+	const unsigned tiles_x = (unsigned(p.screen_pitch) + RT_POST_BLOCK_X - 1) / RT_POST_BLOCK_X;
+	const unsigned tiles_y = (unsigned(p.screen_height) + RT_POST_BLOCK_Y - 1) / RT_POST_BLOCK_Y;
+	const unsigned tiles = tiles_x * tiles_y, per_xcd = gridDim.x / 8u;
+	const unsigned tile = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+	if (tile >= tiles) return false;
+	x = int(tile % tiles_x) * RT_POST_BLOCK_X + int(threadIdx.x);
+	y = int(tile / tiles_x) * RT_POST_BLOCK_Y + int(threadIdx.y);
+	return true;
+}
+
 RT_DEV f4 ld4(const float4 * p, int i) { return mk4(p[i]); }
 RT_DEV void st4(float4 * p, int i, f4 v) { p[i] = to_float4(v); }
 
@@ -148,8 +167,8 @@ RT_DEV f2 edge_stopping_weights(const RtParams & p, int delta_x, int delta_y, f2
 }
 
 __global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p) {
-	int x = blockIdx.x * blockDim.x + threadIdx.x;
-	int y = blockIdx.y * blockDim.y + threadIdx.y;
+	int x, y;
+	if (!post_tile_pixel(p, x, y)) return;
 	if (x >= p.screen_width || y >= p.screen_height) return;
 	int pixel_index = x + y * p.screen_pitch;
 
@@ -250,8 +269,8 @@ __global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p) {
 }
 
 __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out) {
-	int x = blockIdx.x * blockDim.x + threadIdx.x;
-	int y = blockIdx.y * blockDim.y + threadIdx.y;
+	int x, y;
+	if (!post_tile_pixel(p, x, y)) return;
 	if (x >= p.screen_pitch || y >= p.screen_height) return; // pitch, as in the reference (SVGF.h:293)
 	int pixel_index = x + y * p.screen_pitch;
 
@@ -310,8 +329,8 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 // moves 80 B of compulsory traffic per pixel and was bound by the vector ALUs at a third of the stream bandwidth
 // (BENCH config3 kernels; profiles/r03_svgf.txt).
 __global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const float4 * __restrict__ d_in, const float4 * __restrict__ i_in, float4 * __restrict__ d_out, float4 * __restrict__ i_out, int step_size) {
-	int x = blockIdx.x * blockDim.x + threadIdx.x;
-	int y = blockIdx.y * blockDim.y + threadIdx.y;
+	int x, y;
+	if (!post_tile_pixel(p, x, y)) return;
 	if (x >= p.screen_width || y >= p.screen_height) return;
 	const int pitch = p.screen_pitch;
 	int pixel_index = x + y * pitch;
@@ -375,8 +394,8 @@ __global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const floa
 }
 
 __global__ void __launch_bounds__(256) kernel_svgf_finalize(RtParams p, const float4 * colour_direct, const float4 * colour_indirect) {
-	int x = blockIdx.x * blockDim.x + threadIdx.x;
-	int y = blockIdx.y * blockDim.y + threadIdx.y;
+	int x, y;
+	if (!post_tile_pixel(p, x, y)) return;
 	if (x >= p.screen_width || y >= p.screen_height) return;
 	int pixel_index = x + y * p.screen_pitch;
 
@@ -406,8 +425,8 @@ RT_DEV f3 clamp3(f3 v, f3 lo, f3 hi) { return mk3(clampf(v.x, lo.x, hi.x), clamp
 // taa_frame_prev and the displayed image. (The reference writes the `accumulator` surface in place, which is safe there
 // for the same reason: kernel_taa never reads it.)
 __global__ void __launch_bounds__(256) kernel_taa(RtParams p, int sample_index) {
-	int x = blockIdx.x * blockDim.x + threadIdx.x;
-	int y = blockIdx.y * blockDim.y + threadIdx.y;
+	int x, y;
+	if (!post_tile_pixel(p, x, y)) return;
 	if (x >= p.screen_width || y >= p.screen_height) return;
 	int pixel_index = x + y * p.screen_pitch;
 
@@ -460,8 +479,8 @@ __global__ void __launch_bounds__(256) kernel_taa(RtParams p, int sample_index) 
 }
 
 __global__ void __launch_bounds__(256) kernel_taa_finalize(RtParams p) {
-	int x = blockIdx.x * blockDim.x + threadIdx.x;
-	int y = blockIdx.y * blockDim.y + threadIdx.y;
+	int x, y;
+	if (!post_tile_pixel(p, x, y)) return;
 	if (x >= p.screen_width || y >= p.screen_height) return;
 	int pixel_index = x + y * p.screen_pitch;
 
@@ -476,7 +495,8 @@ __global__ void __launch_bounds__(256) kernel_taa_finalize(RtParams p) {
 // Launch order of Pathtracer::render (Pathtracer.cpp:798-838)
 void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream, void (*mark)(void * user, int svgf_kernel, hipStream_t stream), void * user) {
 	dim3 block(RT_POST_BLOCK_X, RT_POST_BLOCK_Y);
-	dim3 grid((p.screen_pitch + block.x - 1) / block.x, (p.screen_height + block.y - 1) / block.y);
+	const unsigned tiles = ((p.screen_pitch + block.x - 1) / block.x) * ((p.screen_height + block.y - 1) / block.y);
+	dim3 grid((tiles + 7) / 8 * 8);   // post_tile_pixel: XCD k sweeps the k-th eighth of the tiles
 	#define RT_TIMED(k, launch) { if (mark) mark(user, k, stream); launch; if (mark) mark(user, k, stream); }
 
 	RT_TIMED(0, hipLaunchKernelGGL(kernel_svgf_reproject, grid, block, 0, stream, p));

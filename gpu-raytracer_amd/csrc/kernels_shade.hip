@@ -28,6 +28,9 @@
 #ifndef RT_SORT_BLOCK
 #define RT_SORT_BLOCK 512   // kernel_sort: 8 waves share one atomic per material queue
 #endif
+#ifndef RT_SORT_WAVES
+#define RT_SORT_WAVES 2    // minimum waves per SIMD asked of the sort kernels' register allocation (2 = one 512-thread workgroup per CU: no cap)
+#endif
 
 struct HitInfo { float t, u, v; int mesh_id, triangle_id; };
 
@@ -450,8 +453,8 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 	if (MERGED) stream_stats_flush(p, stats_lds);
 }
 
-__global__ void __launch_bounds__(RT_SORT_BLOCK) kernel_sort(RtParams p, int bounce, int sample_index) { sort_rays<false>(p, bounce, sample_index); }
-__global__ void __launch_bounds__(RT_SORT_BLOCK) kernel_sort_stream(RtParams p) { sort_rays<true>(p, 0, 0); }
+__global__ void __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES) kernel_sort(RtParams p, int bounce, int sample_index) { sort_rays<false>(p, bounce, sample_index); }
+__global__ void __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES) kernel_sort_stream(RtParams p) { sort_rays<true>(p, 0, 0); }
 
 // ---- BSDFs (CUDA/BSDF.h) ----------------------------------------------------------------------------------
 

@@ -50,6 +50,9 @@
 #ifndef RT_FETCH_BLOCK_MAX
 #define RT_FETCH_BLOCK_MAX 128   // rays claimed per cursor atomic; measured 64..1024, see profiles/r01_trace_fetch_block.txt
 #endif
+#ifndef RT_TRI_HOLD
+#define RT_TRI_HOLD 0        // see the triangle phase; 0 = every round (tools/wave_sim: 8 / 16 save ~1.5 % of the issue slots, measured: see profiles/r03_traversal_variants.txt)
+#endif
 #ifndef RT_N_D
 #define RT_N_D 4            // dynamic fetch: tolerated idle lanes per iteration (N_d = 4 of 32 in the reference)
 #define RT_N_W 16           // dynamic fetch: lost lane-iterations before refilling  (N_w = 16 of 32); swept 0/1 .. 24/64, profiles/r01_trace_fetch_block.txt
@@ -548,6 +551,14 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			bool occluded = false;
 			{
 				bool has_triangles = triangle_group.y != 0 && tlas_stack_size != RT_INVALID;
+#if RT_TRI_HOLD > 0
+				// experiment: the triangle phase of a round runs only when at least RT_TRI_HOLD lanes have triangles waiting, or no
+				// running lane of the wave can do anything else (its lanes are at ~20 % of the wave in an ordinary round)
+				if (!NARROW) {
+					const int waiting = __popcll(__ballot(has_triangles)), others = __popcll(__ballot(!has_triangles));
+					if (waiting < RT_TRI_HOLD && others > 0) has_triangles = false;
+				}
+#endif
 				if (has_triangles) {
 #ifdef RT_PHASE_STATS
 					if (COUNT && !SHADOW) { phase_tri_lanes++; if (RT_PHASE_LEADER()) phase_tri_rounds++; }

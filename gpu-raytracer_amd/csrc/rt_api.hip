@@ -18,11 +18,23 @@
 
 static thread_local std::string g_global_error;
 
-// HIP multiplexes its streams onto 4 hardware queues unless told otherwise; a context keeps up to
-// 2 x (submissions in flight) streams busy and loses their overlap silently when they share queues
-// (profiles/r01_small_range_concurrency.txt). The variable is read when the HIP runtime initialises, i.e. at
-// the first HIP call of the process: set the default when this library is loaded, never override the user's.
-__attribute__((constructor)) static void grt_default_environment() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+// HIP multiplexes its streams onto 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and the variable is read when
+// the HIP runtime initialises, i.e. at the first HIP call of the PROCESS. The per-submission scheduler keeps up to 2 x
+// (submissions in flight) streams busy and loses their overlap silently when they share queues
+// (profiles/r01_small_range_concurrency.txt). A library has no business editing its host's environment (and cannot know
+// whether HIP is already up -- PyTorch imported first, say): the applications that ship with it set the variable before
+// their first HIP call (bench.py, the Python front end, the command-line renderer), INTEGRATION.md tells embedders to, and
+// a context says so once when it is asked for more concurrent streams than the process has queues for.
+static void warn_if_streams_share_queues(int streams_needed) {
+	static bool warned = false;
+	if (warned) return;
+	const char * value = getenv("GPU_MAX_HW_QUEUES");
+	const int queues = value ? atoi(value) : 4;
+	if (queues >= streams_needed) return;
+	warned = true;
+	fprintf(stderr, "[grt] %d streams in flight but GPU_MAX_HW_QUEUES=%s: HIP will multiplex them onto %d hardware queues and serialise their kernels; "
+	                "export GPU_MAX_HW_QUEUES=24 before the process makes its first HIP call\n", streams_needed, value ? value : "(unset, 4)", queues);
+}
 
 // Everything one sample per pixel owns while it is in flight. Up to RT_MAX_SAMPLE_SLOTS samples
 // are rendered concurrently (rt_set_samples_in_flight): consecutive rt_render_sample calls take the
@@ -161,6 +173,8 @@ struct rt_context {
 
 	// named allocations that get replaced on re-upload
 	void * triangles = nullptr, * triangle_positions = nullptr, * bvh8_nodes = nullptr, * bvh2_nodes = nullptr, * bvh4_nodes = nullptr;
+	size_t tlas_node_bytes = 80;        // what the current TLAS version was uploaded as (80 CWBVH, 32 binary, 128 4-wide)
+	int lowest_blas_root = 0x7fffffff;  // over the instances uploaded last: the node slots below it are free for the TLAS copy of the merged wavefront
 	unsigned long long tlas_version = 0, tlas_version_in_nodes = ~0ull;   // the merged wavefront traces a copy of the TLAS inside the BLAS node array (stream_sync_tlas)
 	size_t bvh4_node_count = 0;
 	size_t bvh8_node_count = 0, bvh2_node_count = 0, triangle_count = 0;
@@ -277,6 +291,7 @@ static hipError_t main_waits_for_samples(rt_context * ctx) {
 static int ensure_slot(rt_context * ctx, int index) {
 	SampleSlot & slot = ctx->slots[index];
 	if (slot.created) return RT_OK;
+	if (index > 0) warn_if_streams_share_queues(2 * (index + 1) + 2);   // two streams per slot, the main stream, the merged wavefront's
 	memset(slot.trace, 0, sizeof(slot.trace)); memset(slot.material, 0, sizeof(slot.material)); memset(&slot.shadow, 0, sizeof(slot.shadow));
 	RT_HIP(ctx, hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
 	RT_HIP(ctx, hipStreamCreateWithFlags(&slot.side,   hipStreamNonBlocking));
@@ -331,7 +346,14 @@ static RtParams slot_params(const rt_context * ctx, const SampleSlot & slot, int
 static int ring_begin(rt_context * ctx, SceneRing & ring, size_t bytes, void ** staging) {
 	if (bytes == 0) bytes = 16;
 	// a launch of the merged wavefront traces the rays of every submission in flight against ONE scene version
-	if (ctx->path_stream.created) RT_HIP(ctx, stream_flush(ctx));
+	if (ctx->path_stream.created) {
+		RT_HIP(ctx, stream_flush(ctx));
+		// ... and the copy into the next version (main stream) runs after everything the wavefront has enqueued: its kernels read
+		// ring versions too, and nothing else orders the two streams (the flush only ENQUEUES the remaining iterations). Without
+		// this wait a version was safe from being overwritten under a running iteration only because RT_SCENE_VERSIONS (12)
+		// exceeds what RT_STREAM_RUN_AHEAD (4) lets the host get ahead.
+		RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->path_stream.ev_idle, 0));
+	}
 	if (bytes > ring.capacity) { // first use, or the scene outgrew the ring: start over (the only case that drains)
 		RT_HIP(ctx, quiesce(ctx));
 		size_t capacity = bytes + bytes / 2 + 256; // a TLAS changes its node count a little from frame to frame
@@ -391,7 +413,8 @@ enum { SPAN_TRACE = RT_TIMING_TRACE, SPAN_SHADOW = RT_TIMING_SHADOW, SPAN_SORT =
 
 extern "C" {
 
-const char * rt_version(void) { return "gpu-raytracer_amd 0.1 (gfx950, HIP)"; }
+const char * rt_version(void) { return "gpu-raytracer_amd 0.3 (gfx950, HIP; ABI 3)"; }
+int rt_abi_version(void) { return RT_ABI_VERSION; }
 
 const char * rt_last_error(const rt_context * ctx) { return ctx ? ctx->error.c_str() : g_global_error.c_str(); }
 
@@ -497,6 +520,7 @@ static int upload_tlas_version(rt_context * ctx, const void * tlas_nodes, size_t
 	s = ring_commit(ctx, ctx->tlas_ring); if (s) return s;
 	ctx->params.tlas_nodes = (const float4 *)ctx->tlas_ring.device[ctx->tlas_ring.current];
 	ctx->params.tlas_node_count = int(tlas_node_count);
+	ctx->tlas_node_bytes = node_bytes;
 	ctx->tlas_version++;
 	return RT_OK;
 }
@@ -569,6 +593,8 @@ int rt_upload_instances(rt_context * ctx, const int32_t * root_indices, const in
 	int s = ring_begin(ctx, ctx->instance_ring, offset[5], &staging); if (s) return s;
 	for (int i = 0; i < 5; i++) memcpy((char *)staging + offset[i], src[i], bytes[i]);
 	s = ring_commit(ctx, ctx->instance_ring); if (s) return s;
+	ctx->lowest_blas_root = 0x7fffffff;
+	for (size_t i = 0; i < mesh_count; i++) ctx->lowest_blas_root = std::min(ctx->lowest_blas_root, int(root_indices[i] & 0x7fffffff));
 	const char * base = (const char *)ctx->instance_ring.device[ctx->instance_ring.current];
 	ctx->mesh_count = mesh_count; ctx->params.mesh_count = int(mesh_count);
 	ctx->params.mesh_bvh_root_indices = (const int *)(base + offset[0]);
@@ -1661,6 +1687,11 @@ static int stream_sync_tlas(rt_context * ctx) {
 	if (ctx->tlas_version_in_nodes == ctx->tlas_version) return RT_OK;
 	if (!ctx->params.tlas_nodes || ctx->params.tlas_node_count <= 0) { ctx->tlas_version_in_nodes = ctx->tlas_version; return RT_OK; }   // one BVH, no TLAS: node 0 is its root
 	if (!ctx->bvh8_nodes || size_t(ctx->params.tlas_node_count) > ctx->bvh8_node_count) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_samples: the TLAS does not fit the node slots the geometry reserves for it");
+	// the copy below overwrites node slots [0, tlas_node_count): they must be CWBVH nodes and must not hold BLAS nodes (the host
+	// classes reserve 2 x meshes slots in front of the first BLAS; a C-API caller with another layout gets an error, not a
+	// silently corrupted BVH -- the per-submission scheduler, which reads the TLAS from its own buffer, renders such layouts)
+	if (ctx->tlas_node_bytes != 80) return fail(ctx, RT_ERROR_INVALID_ARG, "rt_render_samples: the merged wavefront needs the TLAS as 80-byte CWBVH nodes (rt_upload_tlas); select RT_SCHEDULER_SLOTS for other BVH types");
+	if (ctx->params.tlas_node_count > ctx->lowest_blas_root) return fail(ctx, RT_ERROR_INVALID_ARG, "rt_render_samples: a BLAS root (node %d) lies inside the %d node slots the merged wavefront copies the TLAS into; reserve them in front of the BLAS nodes or select RT_SCHEDULER_SLOTS", ctx->lowest_blas_root, ctx->params.tlas_node_count);
 	hipStream_t st = ctx->path_stream.stream;
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));
 	RT_HIP(ctx, hipMemcpyAsync(ctx->bvh8_nodes, ctx->params.tlas_nodes, size_t(ctx->params.tlas_node_count) * 80, hipMemcpyDeviceToDevice, st));
@@ -1761,9 +1792,9 @@ static int stream_submit(rt_context * ctx, int sample_index, int sample_count, i
 	for (;;) {
 		bool ring_free = s.in_flight.size() < RT_STREAM_SUBMISSIONS - 1;
 		slot_base = -1;
-		for (int start = 0; start + sample_count <= s.frame_slots && slot_base < 0; start++) {
-			int candidate = (s.next_slot + start) % s.frame_slots;
-			if (candidate + sample_count > s.frame_slots) continue;
+		const int legal_bases = s.frame_slots - sample_count + 1;   // every base 0 .. frame_slots - sample_count is tried, starting at next_slot (round robin)
+		for (int start = 0; start < legal_bases && slot_base < 0; start++) {
+			int candidate = ((s.next_slot < legal_bases ? s.next_slot : 0) + start) % legal_bases;
 			bool free_run = true;
 			for (int k = 0; k < sample_count; k++) if (s.slot_used[candidate + k]) { free_run = false; break; }
 			if (free_run) slot_base = candidate;

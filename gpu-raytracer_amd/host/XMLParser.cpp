@@ -56,72 +56,86 @@ Matrix4 XMLAttribute::as_matrix4() const {
 
 XMLParser::XMLParser(const std::string & filename) : source(read_text_file(filename)), parser(source, filename) { }
 
+// The document is read by ONE loop over its tags with an explicit stack of the elements that are still open (no recursion:
+// a scene file nested a few thousand levels deep is a malformed file, not a stack overflow). A tag is one of
+//   <name attr="v" ...>    opens an element: pushed      <name ... />  or  <?name ... ?>   a complete element
+//   </name>                closes the innermost open element, whose name it must repeat
+// Comments may stand wherever white space may. No entities, no CDATA, no text content (Mitsuba scene files have none).
+namespace {
+
+struct TagScanner {
+	Parser & in;
+
+	void blank() { parser_skip_xml_whitespace(in); }
+	bool at_end() const { return in.reached_end(); }
+
+	// characters up to (not including) the first one `stop` accepts
+	template<typename Stop> std::string until(Stop stop) {
+		const char * from = in.cur;
+		while (!in.reached_end() && !stop(*in.cur)) in.advance();
+		return std::string(from, in.cur);
+	}
+
+	XMLAttribute attribute() {
+		XMLAttribute a;
+		a.name = until([](char c) { return c == '='; });
+		while (!a.name.empty() && (is_whitespace(a.name.back()) || is_newline(a.name.back()))) a.name.pop_back();
+		in.expect('=');
+		(void)until([](char c) { return c == '"' || c == '\''; });
+		if (in.reached_end()) in.fail("an attribute value must be quoted");
+		const char quote = *in.cur;
+		in.advance();
+		a.value = until([quote](char c) { return c == quote; });
+		in.expect(quote);
+		return a;
+	}
+};
+
+} // namespace
+
 XMLNode XMLParser::parse_root() {
 	XMLNode root;
 	root.location = parser.filename;
-	while (!parser.reached_end()) {
-		parser_skip_xml_whitespace(parser);
-		if (parser.reached_end()) break;
-		root.children.push_back(parse_tag());
-		parser_skip_xml_whitespace(parser);
-	}
-	return root;
-}
+	TagScanner scan { parser };
+	std::vector<XMLNode> open;   // the elements whose closing tag has not been seen yet, outermost first
 
-XMLNode XMLParser::parse_tag() {
-	XMLNode node;
-	if (parser.reached_end()) return node;
+	auto finished = [&](XMLNode && element) {
+		(open.empty() ? root : open.back()).children.push_back(std::move(element));
+	};
 
-	parser.expect('<');
-	node.location = parser.filename + ":" + std::to_string(parser.line);
-	node.is_question_mark = parser.match('?');
-
-	const char * tag_start = parser.cur;
-	while (!parser.reached_end() && !is_whitespace(*parser.cur) && !is_newline(*parser.cur) && *parser.cur != '>' && *parser.cur != '/') parser.advance();
-	node.tag.assign(tag_start, parser.cur);
-	if (node.tag.empty()) parser.fail("empty open tag");
-
-	parser_skip_xml_whitespace(parser);
-
-	// Attributes, until '>' (children follow) or '/>' / '?>' (inline tag)
 	while (true) {
-		if (parser.reached_end()) parser.fail("unterminated tag <" + node.tag + ">");
-		if (parser.match('>')) break;
-		if (parser.match('/') || (node.is_question_mark && parser.match('?'))) { parser.expect('>'); return node; }
+		scan.blank();
+		if (scan.at_end()) {
+			if (!open.empty()) parser.fail("missing closing tag for <" + open.back().tag + ">");
+			return root;
+		}
+		if (parser.match("</")) {   // closes the innermost element
+			std::string name = scan.until([](char c) { return c == '>'; });
+			parser.expect('>');
+			if (open.empty()) parser.fail("closing tag '" + name + "' without an open element");
+			if (name != open.back().tag) parser.fail("non matching closing tag '" + name + "' for node '" + open.back().tag + "'");
+			XMLNode element = std::move(open.back());
+			open.pop_back();
+			finished(std::move(element));
+			continue;
+		}
 
-		XMLAttribute attribute;
-		const char * name_start = parser.cur;
-		while (!parser.reached_end() && *parser.cur != '=') parser.advance();
-		attribute.name.assign(name_start, parser.cur);
-		while (!attribute.name.empty() && (is_whitespace(attribute.name.back()) || is_newline(attribute.name.back()))) attribute.name.pop_back();
+		parser.expect('<');
+		XMLNode element;
+		element.location = parser.filename + ":" + std::to_string(parser.line);
+		element.is_question_mark = parser.match('?');
+		element.tag = scan.until([](char c) { return is_whitespace(c) || is_newline(c) || c == '>' || c == '/'; });
+		if (element.tag.empty()) parser.fail("empty open tag");
 
-		parser.expect('=');
-		while (!parser.reached_end() && *parser.cur != '"' && *parser.cur != '\'') parser.advance();
-		char quote;
-		if      (parser.match('"'))  quote = '"';
-		else if (parser.match('\'')) quote = '\'';
-		else parser.fail("an attribute value must be quoted");
-
-		const char * value_start = parser.cur;
-		while (!parser.reached_end() && *parser.cur != quote) parser.advance();
-		attribute.value.assign(value_start, parser.cur);
-		parser.expect(quote);
-		parser_skip_xml_whitespace(parser);
-
-		node.attributes.push_back(std::move(attribute));
+		bool complete = false;      // <name ... /> or <?name ... ?>
+		while (true) {
+			scan.blank();
+			if (scan.at_end()) parser.fail("unterminated tag <" + element.tag + ">");
+			if (parser.match('>')) break;
+			if (parser.match('/') || (element.is_question_mark && parser.match('?'))) { parser.expect('>'); complete = true; break; }
+			element.attributes.push_back(scan.attribute());
+		}
+		if (complete) finished(std::move(element));
+		else open.push_back(std::move(element));
 	}
-
-	parser_skip_xml_whitespace(parser);
-	while (!parser.match("</")) {
-		if (parser.reached_end()) parser.fail("missing closing tag for <" + node.tag + ">");
-		node.children.push_back(parse_tag());
-		parser_skip_xml_whitespace(parser);
-	}
-
-	const char * closing_start = parser.cur;
-	while (!parser.reached_end() && *parser.cur != '>') parser.advance();
-	std::string closing(closing_start, parser.cur);
-	parser.expect('>');
-	if (closing != node.tag) parser.fail("non matching closing tag '" + closing + "' for node '" + node.tag + "'");
-	return node;
 }

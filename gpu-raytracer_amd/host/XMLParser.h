@@ -69,10 +69,7 @@ struct XMLParser {
 	Parser parser;
 
 	explicit XMLParser(const std::string & filename);
-	XMLNode parse_root();
-
-private:
-	XMLNode parse_tag();
+	XMLNode parse_root();   // the whole document: a nameless node whose children are the top-level elements
 };
 
 std::string read_text_file(const std::string & filename);

@@ -186,6 +186,7 @@ double seconds_since(std::chrono::steady_clock::time_point t0) {
 } // namespace
 
 int main(int argc, char ** argv) {
+	setenv("GPU_MAX_HW_QUEUES", "24", 0);   // before the first HIP call: HIP multiplexes its streams onto 4 hardware queues otherwise (rt_api.hip)
 	CommandLine cl;
 	parse_command_line(argc, argv, cl);
 

@@ -135,6 +135,14 @@ int          rt_create (int device_ordinal, rt_context ** out_ctx);
 void         rt_destroy(rt_context * ctx);
 const char * rt_last_error(const rt_context * ctx);      /* ctx may be NULL: last global error */
 const char * rt_version(void);
+/* Layout version of the structs that cross this boundary. Bumped whenever one changes size or meaning, so that a client
+ * built against an older header fails its start-up check instead of passing arrays with the wrong stride:
+ *   1  round 1
+ *   2  rt_texture_desc grew `format`, `lod_width`, `lod_height` (32 -> 40 bytes; rt_upload_textures rejects unknown formats)
+ *   3  RT_TIMING_* kinds of rt_get_launch_timings, rt_comm_* / rt_all_gather_* entry points (additions only)
+ * Check `rt_abi_version() == RT_ABI_VERSION` once after loading the library.                                          */
+#define RT_ABI_VERSION 3
+int rt_abi_version(void);
 
 /* ---- scene upload ------------------------------------------------------------------- */
 /* Replaces globals `triangles` and `bvh8_nodes` (Integrator.cpp:153-154,268-269).
