@@ -151,6 +151,8 @@ def host_lib():
         lib.grt_pathtracer_aov_enable.argtypes = [c_void_p, c_int, c_int]
         lib.grt_pathtracer_context.restype = c_void_p
         lib.grt_pathtracer_context.argtypes = [c_void_p]
+        lib.grt_pathtracer_device_blas_build_ms.restype = c_float
+        lib.grt_pathtracer_device_blas_build_ms.argtypes = [c_void_p]
         lib.grt_pathtracer_lights_total_weight.restype = c_float
         lib.grt_pathtracer_lights_total_weight.argtypes = [c_void_p]
         lib.grt_pathtracer_read_aov.argtypes = [c_void_p, c_int, c_int, c_void_p]
@@ -455,6 +457,11 @@ class Pathtracer:
     @property
     def pitch(self):
         return host_lib().grt_pathtracer_screen_pitch(self.handle)
+
+    @property
+    def device_blas_build_ms(self):
+        """config device_blas = 1: what the BLAS build took on the device (0 when the host built the trees)."""
+        return float(host_lib().grt_pathtracer_device_blas_build_ms(self.handle))
 
     @property
     def lights_total_weight(self):

@@ -189,7 +189,9 @@ __global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p) {
 	// the variance and a-trous passes read every pixel's normal up to 9 + 6 x 9 times per frame: decoded once, here, into a
 	// float4 of its own (normal, depth) -- the same 16 bytes per tap as the octahedral g-buffer texel, without the decode
 	p.svgf_normal_and_depth[pixel_index] = make_float4(normal.x, normal.y, normal.z, depth);
-	if (depth == 0.0f) return; // sky
+	// ... and the variance pair (direct.w, indirect.w) of every pixel once more in a float2 image of its own: the a-trous passes
+	// blur it over 3 x 3 neighbours, and a .w picked out of two float4 images costs the cache as much as the float4s
+	if (depth == 0.0f) { p.svgf_variance[0][pixel_index] = make_float2(direct.w, indirect.w); return; } // sky
 
 	float s_prev = (0.5f + 0.5f * screen_position_prev.x) * float(p.screen_width);
 	float t_prev = (0.5f + 0.5f * screen_position_prev.y) * float(p.screen_height);
@@ -266,16 +268,17 @@ __global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p) {
 	st4(fb_direct, pixel_index, direct);
 	st4(fb_indirect, pixel_index, indirect);
 	st4(p.frame_buffer_moment, pixel_index, moment);
+	p.svgf_variance[0][pixel_index] = make_float2(direct.w, indirect.w);
 }
 
-__global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out) {
+__global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, float2 * variance_out) {
 	int x, y;
 	if (!post_tile_pixel(p, x, y)) return;
 	if (x >= p.screen_pitch || y >= p.screen_height) return; // pitch, as in the reference (SVGF.h:293)
 	int pixel_index = x + y * p.screen_pitch;
 
 	int history = p.history_length[pixel_index];
-	if (history >= 4) { d_out[pixel_index] = d_in[pixel_index]; i_out[pixel_index] = i_in[pixel_index]; return; }
+	if (history >= 4) { float4 d = d_in[pixel_index], i = i_in[pixel_index]; d_out[pixel_index] = d; i_out[pixel_index] = i; variance_out[pixel_index] = make_float2(d.w, i.w); return; }
 
 	const float4 * __restrict__ normal_and_depth = p.svgf_normal_and_depth;   // (normal, depth), decoded by kernel_svgf_reproject
 	float luminance_denom = 1.0f / p.config.sigma_l;
@@ -289,7 +292,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 	f2 grad = mk2(normal_and_depth[xr + y * p.screen_pitch].w - center_depth,
 	              normal_and_depth[x + yd * p.screen_pitch].w - center_depth);
 
-	if (center_depth == 0.0f) { st4(d_out, pixel_index, cd); st4(i_out, pixel_index, ci); return; }
+	if (center_depth == 0.0f) { st4(d_out, pixel_index, cd); st4(i_out, pixel_index, ci); variance_out[pixel_index] = make_float2(cd.w, ci.w); return; }
 
 	float sw_d = 1.0f, sw_i = 1.0f;
 	f4 sc_d = cd, sc_i = ci;
@@ -320,6 +323,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 	sc_i.w = fmaxf(0.0f, sum_moment.w - sum_moment.y * sum_moment.y);
 	st4(d_out, pixel_index, sc_d);
 	st4(i_out, pixel_index, sc_i);
+	variance_out[pixel_index] = make_float2(sc_d.w, sc_i.w);
 }
 
 // One a-trous pass (SVGF.h:416-554). Per pixel: the 3x3 Gaussian blur of the variance (9 taps, .w only), then 8 taps at
@@ -328,7 +332,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 // v_exp_f32 each (edge_stopping_weights): ~600 vector instructions per pixel where the literal form ran ~3 000 -- the pass
 // moves 80 B of compulsory traffic per pixel and was bound by the vector ALUs at a third of the stream bandwidth
 // (BENCH config3 kernels; profiles/r03_svgf.txt).
-__global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const float4 * __restrict__ d_in, const float4 * __restrict__ i_in, float4 * __restrict__ d_out, float4 * __restrict__ i_out, int step_size) {
+__global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const float4 * __restrict__ d_in, const float4 * __restrict__ i_in, float4 * __restrict__ d_out, float4 * __restrict__ i_out, const float2 * __restrict__ variance_in, float2 * __restrict__ variance_out, int step_size) {
 	int x, y;
 	if (!post_tile_pixel(p, x, y)) return;
 	if (x >= p.screen_width || y >= p.screen_height) return;
@@ -345,8 +349,9 @@ __global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const floa
 		#pragma unroll
 		for (int i = 0; i < 3; i++) {
 			const float kernel_weight = (i == 1 ? 0.5f : 0.25f) * (j == 1 ? 0.5f : 0.25f) * 1.0f;   // 0.25 * 2^-(|i| + |j|), |i| = distance from the centre
-			vb_d += d_in[col[i] + row[j]].w * kernel_weight;
-			vb_i += i_in[col[i] + row[j]].w * kernel_weight;
+			const float2 variance = variance_in[col[i] + row[j]];   // (d_in[..].w, i_in[..].w), see kernel_svgf_reproject
+			vb_d += variance.x * kernel_weight;
+			vb_i += variance.y * kernel_weight;
 		}
 	}
 	float denom_d = 1.0f / sqrtf(p.config.sigma_l * p.config.sigma_l * fmaxf(0.0f, vb_d) + RT_SVGF_EPSILON);
@@ -390,6 +395,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const floa
 	sc_d.w *= inv_d; sc_i.w *= inv_i;
 	st4(d_out, pixel_index, sc_d);
 	st4(i_out, pixel_index, sc_i);
+	variance_out[pixel_index] = make_float2(sc_d.w, sc_i.w);
 	if (step_size == (1 << RT_FEEDBACK_ITERATION)) { st4(p.history_direct, pixel_index, sc_d); st4(p.history_indirect, pixel_index, sc_i); }
 }
 
@@ -506,15 +512,20 @@ void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream
 	float4 * direct_out   = p.aovs[RT_AOV_RADIANCE_DIRECT].accumulator;
 	float4 * indirect_out = p.aovs[RT_AOV_RADIANCE_INDIRECT].accumulator;
 
+	// svgf_variance[0] mirrors the .w of the two framebuffers, [1] that of the two accumulators -- pixel for pixel, the ones a pass
+	// leaves unwritten (sky) included: every kernel that writes a (direct, indirect) pair writes the pair's variances as well
+	float2 * variance_in = p.svgf_variance[0], * variance_out = p.svgf_variance[1];
 	if (p.config.enable_spatial_variance) {
-		RT_TIMED(1, hipLaunchKernelGGL(kernel_svgf_variance, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out));
+		RT_TIMED(1, hipLaunchKernelGGL(kernel_svgf_variance, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out, variance_out));
 		float4 * t = direct_in; direct_in = direct_out; direct_out = t;
 		t = indirect_in; indirect_in = indirect_out; indirect_out = t;
+		float2 * v = variance_in; variance_in = variance_out; variance_out = v;
 	}
 	for (int i = 0; i < p.config.num_atrous_iterations; i++) {
-		RT_TIMED(2, hipLaunchKernelGGL(kernel_svgf_atrous, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out, 1 << i));
+		RT_TIMED(2, hipLaunchKernelGGL(kernel_svgf_atrous, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out, variance_in, variance_out, 1 << i));
 		float4 * t = direct_in; direct_in = direct_out; direct_out = t;
 		t = indirect_in; indirect_in = indirect_out; indirect_out = t;
+		float2 * v = variance_in; variance_in = variance_out; variance_out = v;
 	}
 	RT_TIMED(3, hipLaunchKernelGGL(kernel_svgf_finalize, grid, block, 0, stream, p, direct_in, indirect_in));
 

@@ -4,8 +4,10 @@
 // handed to the kernels by value. It plays the role of the reference's Device/ layer plus the
 // device half of Integrator/Pathtracer (buffer ownership, `buffer_sizes` handling, the
 // wavefront launch loop of Pathtracer::render, Pathtracer.cpp:738-855).
+#include "rt_tlas_build.h"
 #include <dlfcn.h>
 #include "rt_types.h"
+#include "rt_tlas_build.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -194,7 +196,7 @@ struct rt_context {
 	// frame resources
 	void * aov_buffers[RT_AOV_COUNT][2] = { };
 	void * final_image = nullptr;
-	void * svgf_buffers[12] = { }; bool svgf_allocated = false;
+	void * svgf_buffers[14] = { }; bool svgf_allocated = false;
 	size_t frame_pixels = 0; // pitch * height
 
 	// frame exchange of the tile split (rt_comm_*): this context's rank in a group of `world` contexts, each on its own GPU
@@ -512,6 +514,97 @@ int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle
 	return RT_OK;
 }
 
+// ---- BLAS build on the device (kernels_blas.hip) ---------------------------------------------------------------------
+} // extern "C"
+struct BlasBuildArgs { // must match kernels_blas.hip
+	int triangle_count, mesh_count, first_node;
+	const float4 * triangles; const int * mesh_first;
+	float4 * triangles_out, * positions_out; uint32_t * nodes; int * order, * position;
+	TlasBox * triangle_boxes, * sorted_boxes, * mesh_boxes, * child_boxes; int * triangle_mesh;
+	uint64_t * keys; int * ids; uint64_t * sorted_keys; int * sorted_ids;
+	int2 * range; int * runs; int * inner_count, * leaf_count, * inner_base, * leaf_base; int * level_state;
+};
+size_t rt_blas_build_scratch_bytes(size_t triangles, size_t meshes);
+hipError_t rt_blas_build(BlasBuildArgs a, void * library_scratch, size_t library_scratch_bytes, int * pinned_state, hipStream_t stream, int * out_node_count);
+extern "C" {
+
+int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_count, const int32_t * mesh_first_triangle, size_t mesh_count,
+                      size_t reserved_tlas_nodes, int32_t * out_root_indices, int32_t * out_triangle_positions, size_t * out_node_count, float * out_build_ms) {
+	RT_REQUIRE(ctx, ctx && triangles && mesh_first_triangle && mesh_count >= 1, "rt_build_geometry: NULL argument");
+	RT_REQUIRE(ctx, triangle_count < (size_t(1) << 30) && mesh_count < (size_t(1) << 24), "rt_build_geometry: too many triangles / meshes");
+	RT_REQUIRE(ctx, mesh_first_triangle[0] == 0 && size_t(mesh_first_triangle[mesh_count]) == triangle_count, "rt_build_geometry: mesh_first_triangle must run from 0 to triangle_count");
+	for (size_t m = 0; m < mesh_count; m++) RT_REQUIRE(ctx, mesh_first_triangle[m] <= mesh_first_triangle[m + 1], "rt_build_geometry: mesh_first_triangle must not decrease");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	const size_t T = triangle_count, M = mesh_count;
+	const size_t node_capacity = reserved_tlas_nodes + M + T;          // every inner node has at least two children
+	const size_t level_capacity = std::max(M, T / (4) + 1) + 1;        // an inner node holds more than 3 triangles
+	// outputs (kept): triangles and positions in leaf order, nodes; everything else is scratch of this call
+	void * out_triangles = nullptr, * out_positions = nullptr, * out_nodes = nullptr, * scratch = nullptr;
+	int s;
+	if ((s = device_alloc(ctx, &out_triangles, T * 96))) return s;
+	if ((s = device_alloc(ctx, &out_positions, T * 48))) return s;
+	if ((s = device_alloc(ctx, &out_nodes, node_capacity * 80))) return s;
+	size_t at = 0;
+	auto region = [&](size_t bytes) { size_t begin = at; at += (bytes + 255) / 256 * 256; return begin; };
+	const size_t o_in = region(T * 96), o_first = region((M + 1) * 4), o_order = region(T * 4), o_position = region(T * 4),
+	             o_tbox = region(T * 24), o_sbox = region(T * 24), o_mbox = region(M * 24), o_cbox = region(level_capacity * 8 * 24), o_tmesh = region(T * 4),
+	             o_keys = region(T * 8), o_ids = region(T * 4), o_skeys = region(T * 8), o_sids = region(T * 4), o_range = region(node_capacity * 8),
+	             o_runs = region(level_capacity * 48), o_ic = region(level_capacity * 4), o_lc = region(level_capacity * 4), o_ib = region(level_capacity * 4), o_lb = region(level_capacity * 4),
+	             o_state = region(16);
+	const size_t library_bytes = rt_blas_build_scratch_bytes(T, M + level_capacity);
+	const size_t o_library = region(library_bytes);
+	if ((s = device_alloc(ctx, &scratch, at))) return s;
+	char * base = (char *)scratch;
+	RT_HIP(ctx, hipMemcpyAsync(base + o_in, triangles, T * 96, hipMemcpyHostToDevice, ctx->stream));
+	RT_HIP(ctx, hipMemcpyAsync(base + o_first, mesh_first_triangle, (M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+	RT_HIP(ctx, hipMemsetAsync(out_nodes, 0, node_capacity * 80, ctx->stream));
+	BlasBuildArgs a;
+	a.triangle_count = int(T); a.mesh_count = int(M); a.first_node = int(reserved_tlas_nodes);
+	a.triangles = (const float4 *)(base + o_in); a.mesh_first = (const int *)(base + o_first);
+	a.triangles_out = (float4 *)out_triangles; a.positions_out = (float4 *)out_positions; a.nodes = (uint32_t *)out_nodes;
+	a.order = (int *)(base + o_order); a.position = (int *)(base + o_position);
+	a.triangle_boxes = (TlasBox *)(base + o_tbox); a.sorted_boxes = (TlasBox *)(base + o_sbox); a.mesh_boxes = (TlasBox *)(base + o_mbox); a.child_boxes = (TlasBox *)(base + o_cbox);
+	a.triangle_mesh = (int *)(base + o_tmesh);
+	a.keys = (uint64_t *)(base + o_keys); a.ids = (int *)(base + o_ids); a.sorted_keys = (uint64_t *)(base + o_skeys); a.sorted_ids = (int *)(base + o_sids);
+	a.range = (int2 *)(base + o_range); a.runs = (int *)(base + o_runs);
+	a.inner_count = (int *)(base + o_ic); a.leaf_count = (int *)(base + o_lc); a.inner_base = (int *)(base + o_ib); a.leaf_base = (int *)(base + o_lb);
+	a.level_state = (int *)(base + o_state);
+	int * pinned = nullptr;
+	RT_HIP(ctx, hipHostMalloc((void **)&pinned, 16));
+	hipEvent_t t0, t1; RT_HIP(ctx, hipEventCreate(&t0)); RT_HIP(ctx, hipEventCreate(&t1));
+	RT_HIP(ctx, hipEventRecord(t0, ctx->stream));
+	int node_count = 0;
+	hipError_t e = rt_blas_build(a, base + o_library, library_bytes, pinned, ctx->stream, &node_count);
+	if (e == hipSuccess) e = hipEventRecord(t1, ctx->stream);
+	if (e == hipSuccess && out_triangle_positions) e = hipMemcpyAsync(out_triangle_positions, a.position, T * 4, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	float ms = 0.0f;
+	if (e == hipSuccess) (void)hipEventElapsedTime(&ms, t0, t1);
+	(void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipHostFree(pinned);
+	device_free(ctx, scratch);
+	if (e != hipSuccess) { device_free(ctx, out_triangles); device_free(ctx, out_positions); device_free(ctx, out_nodes); return fail(ctx, RT_ERROR_HIP, "rt_build_geometry: %s", hipGetErrorString(e)); }
+	// the context's geometry is what was built
+	device_free(ctx, ctx->triangles); device_free(ctx, ctx->triangle_positions); device_free(ctx, ctx->bvh8_nodes);
+	ctx->triangles = out_triangles; ctx->triangle_positions = out_positions; ctx->bvh8_nodes = out_nodes;
+	ctx->triangle_count = T; ctx->bvh8_node_count = size_t(node_count);
+	ctx->tlas_version_in_nodes = ~0ull;
+	ctx->params.triangles = (const float4 *)out_triangles; ctx->params.triangle_positions = (const float4 *)out_positions; ctx->params.bvh8_nodes = (const float4 *)out_nodes;
+	if (out_root_indices) for (size_t m = 0; m < M; m++) out_root_indices[m] = int32_t(reserved_tlas_nodes + m);
+	if (out_node_count) *out_node_count = size_t(node_count);
+	if (out_build_ms) *out_build_ms = ms;
+	return RT_OK;
+}
+
+int rt_read_geometry(rt_context * ctx, void * out_triangles, void * out_bvh8_nodes) {
+	RT_REQUIRE(ctx, ctx && ctx->triangles && ctx->bvh8_nodes, "rt_read_geometry: no CWBVH geometry on the device");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	if (out_triangles)  RT_HIP(ctx, hipMemcpy(out_triangles,  ctx->triangles,  ctx->triangle_count * 96, hipMemcpyDeviceToHost));
+	if (out_bvh8_nodes) RT_HIP(ctx, hipMemcpy(out_bvh8_nodes, ctx->bvh8_nodes, ctx->bvh8_node_count * 80, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
 // TLAS of the selected BVH type: node_bytes = 80 (CWBVH), 32 (binary) or 128 (4-wide)
 static int upload_tlas_version(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count, size_t node_bytes) {
 	void * staging = nullptr;
@@ -609,7 +702,6 @@ int rt_upload_instances(rt_context * ctx, const int32_t * root_indices, const in
 
 // ---- TLAS build on the device (kernels_build.hip) ---------------------------------------------------------------
 } // extern "C"
-#include "rt_tlas_build.h"
 struct TlasBuildArgs;
 void rt_launch_build_tlas(const TlasBuildArgs & args, hipStream_t stream);
 struct TlasBuildArgs { // must match kernels_build.hip
@@ -880,6 +972,8 @@ static int sync_aovs(rt_context * ctx) {
 				int s = device_alloc(ctx, &ctx->aov_buffers[i][k], n); if (s) return s;
 				RT_HIP(ctx, hipMemset(ctx->aov_buffers[i][k], 0, n));
 			}
+			// (the filter's mirror of the radiance accumulators' variances starts from the same zeros)
+			if ((i == RT_AOV_RADIANCE_DIRECT || i == RT_AOV_RADIANCE_INDIRECT) && ctx->svgf_buffers[13]) RT_HIP(ctx, hipMemset(ctx->svgf_buffers[13], 0, ctx->frame_pixels * 8));
 			for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) { // per-sample frame buffers of the other slots
 				int s = device_alloc(ctx, &ctx->slots[k].aov_framebuffer[i], bytes * ctx->slots[k].aov_samples); if (s) return s;
 				RT_HIP(ctx, hipMemset(ctx->slots[k].aov_framebuffer[i], 0, bytes * ctx->slots[k].aov_samples));
@@ -918,9 +1012,9 @@ static int sync_svgf(rt_context * ctx) {
 	bool want = ctx->params.config.enable_svgf != 0;
 	if (want == ctx->svgf_allocated || ctx->frame_pixels == 0) return RT_OK;
 	if (want) {
-		// gbuffers (float4, int2, float2), moment, history x5 (length is int), taa x2, scratch
-		const size_t elem[12] = { 16, 8, 8, 16, 4, 16, 16, 16, 16, 16, 16, 16 };
-		for (int i = 0; i < 12; i++) {
+		// gbuffers (float4, int2, float2), moment, history x5 (length is int), taa x2, decoded normal + depth, variance pairs x2
+		const size_t elem[14] = { 16, 8, 8, 16, 4, 16, 16, 16, 16, 16, 16, 16, 8, 8 };
+		for (int i = 0; i < 14; i++) {
 			int s = device_alloc(ctx, &ctx->svgf_buffers[i], ctx->frame_pixels * elem[i]); if (s) return s;
 			RT_HIP(ctx, hipMemsetAsync(ctx->svgf_buffers[i], 0, ctx->frame_pixels * elem[i], ctx->stream));
 		}
@@ -930,7 +1024,7 @@ static int sync_svgf(rt_context * ctx) {
 		}
 	} else {
 		RT_HIP(ctx, quiesce(ctx));
-		for (int i = 0; i < 12; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
+		for (int i = 0; i < 14; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
 		for (SampleSlot & slot : ctx->slots) for (int i = 0; i < 3; i++) { device_free(ctx, slot.gbuffers[i]); slot.gbuffers[i] = nullptr; }
 		ctx->path_stream.last_gbuffer_slot = -1;
 		for (void * & g : ctx->path_stream.gbuffers) { device_free(ctx, g); g = nullptr; }
@@ -949,6 +1043,8 @@ static int sync_svgf(rt_context * ctx) {
 	p.taa_frame_prev                  = (float4 *)ctx->svgf_buffers[9];
 	p.taa_frame_curr                  = (float4 *)ctx->svgf_buffers[10];
 	p.svgf_normal_and_depth           = (float4 *)ctx->svgf_buffers[11];
+	p.svgf_variance[0]                = (float2 *)ctx->svgf_buffers[12];
+	p.svgf_variance[1]                = (float2 *)ctx->svgf_buffers[13];
 	return RT_OK;
 }
 
@@ -967,7 +1063,7 @@ int rt_resize(rt_context * ctx, int width, int height) {
 	for (SampleSlot & slot : ctx->slots) slot.aov_samples = 1;
 	ctx->params.frame_pixels = unsigned(ctx->frame_pixels);
 	ctx->params.frame_pixels_magic = unsigned((1ull << 32) / ctx->frame_pixels) + 1u;
-	for (int i = 0; i < 12; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
+	for (int i = 0; i < 14; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
 	for (SampleSlot & slot : ctx->slots) for (int i = 0; i < 3; i++) { device_free(ctx, slot.gbuffers[i]); slot.gbuffers[i] = nullptr; }
 	ctx->svgf_allocated = false;
 	device_free(ctx, ctx->final_image); ctx->final_image = nullptr;

@@ -67,13 +67,7 @@ RT_HD uint32_t tlas_morton(const TlasBox & box, const TlasBox & scene) {
 	return code;
 }
 
-RT_HD int tlas_clz(uint32_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-	return __clz(int(x));
-#else
-	return x ? __builtin_clz(x) : 32;
-#endif
-}
+RT_HD int tlas_clz(uint32_t x) { return x ? __builtin_clz(x) : 32; }   // (a compiler builtin on the host and on the device: v_ffbh_u32)
 
 // Cuts the run [lo, hi) of the sorted keys (Morton code in the upper 32 bits) where the highest differing code bit
 // flips; runs of identical codes are cut in the middle.

@@ -181,6 +181,7 @@ struct RtParams {
 	int    * history_length;
 	float4 * history_direct, * history_indirect, * history_moment, * history_normal_and_depth;
 	float4 * taa_frame_prev, * taa_frame_curr;
+	float2 * svgf_variance[2];        // (direct.w, indirect.w) of the radiance framebuffers [0] and accumulators [1], kept in step by the filter kernels
 	float4 * svgf_normal_and_depth;   // (normal, depth) of the frame being filtered: decoded once by kernel_svgf_reproject for the variance / a-trous taps
 };
 

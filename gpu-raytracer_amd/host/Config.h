@@ -62,6 +62,9 @@ struct CPUConfig {
 	// (rt_build_tlas: one kernel launch, CWBVH only, up to 4096 instances), -1 = on the device when the scene is rebuilt
 	// every frame (enable_scene_update) and has at least 1024 instances: there the host build is the CPU work inside the frame loop
 	int  device_tlas = -1;
+	// Where the bottom-level trees of a CWBVH scene are built: 0 = on the host (SAH / SBVH builder + BVH8Converter, byte-identical
+	// to the reference's), 1 = on the device (rt_build_geometry: a linear BVH over all meshes at once; fast to build, dearer to traverse)
+	int  device_blas = 0;
 
 	IntegratorType integrator = IntegratorType::PATHTRACER; // read by the command-line front end
 

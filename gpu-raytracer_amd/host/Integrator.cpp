@@ -161,6 +161,20 @@ void Integrator::init_geometry() {
 				dst[n].base_index_child    += unsigned(mesh_data_bvh_offsets[m]);
 			}
 		}
+		if (ctx && cpu_config.device_blas > 0) {
+			// the trees are built on the device from the triangles alone (their order -- the host trees' leaf order -- is as good as
+			// any); what names triangles or nodes by index on the host follows: BLAS roots, the original-triangle -> device-triangle
+			// table behind the light tables, and the host's views of the device arrays (pixel queries, exporters, the checker)
+			std::vector<int> first(mesh_data_count + 1), roots(mesh_data_count), position(index_total);
+			for (size_t m = 0; m < mesh_data_count; m++) first[m] = mesh_data_index_offsets[m];
+			first[mesh_data_count] = int(index_total);
+			size_t built_nodes = 0;
+			check(rt_build_geometry(ctx, aggregated_triangles.data(), index_total, first.data(), mesh_data_count, 2 * mesh_count, roots.data(), position.data(), &built_nodes, &device_blas_build_ms));
+			for (size_t m = 0; m < mesh_data_count; m++) mesh_data_bvh_offsets[m] = roots[m];
+			for (int & device_index : reverse_indices) device_index = position[device_index];
+			aggregated_bvh_nodes_8.assign(built_nodes, BVHNode8());
+			check(rt_read_geometry(ctx, aggregated_triangles.data(), aggregated_bvh_nodes_8.data()));
+		} else
 		if (ctx) check(rt_upload_geometry(ctx, aggregated_triangles.data(), aggregated_triangles.size(), aggregated_bvh_nodes_8.data(), aggregated_bvh_nodes_8.size()));
 	} else {
 		aggregated_bvh_nodes_2.assign(node_total, BVHNode2());

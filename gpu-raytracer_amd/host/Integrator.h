@@ -67,6 +67,7 @@ struct Integrator {
 	// TLAS-ordered instance tables are fetched from the device when something on the host needs them (pixel queries,
 	// the parity checker's view of the scene).
 	bool tlas_on_device = false, tlas_host_view_stale = false;
+	float device_blas_build_ms = 0.0f;   // cpu_config.device_blas: what rt_build_geometry took on the device (sort + levels + gather)
 	bool wants_device_tlas() const;
 	void sync_host_view_of_device_tlas();
 	void fill_scene_order_tables();

@@ -63,6 +63,7 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "sbvh_alpha")                          cpu_config.sbvh_alpha = float(value);
 	else if (k == "enable_scene_update")                 cpu_config.enable_scene_update = value != 0;
 	else if (k == "device_tlas")                         cpu_config.device_tlas = int(value);
+	else if (k == "device_blas")                         cpu_config.device_blas = int(value);
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
 	else if (k == "initial_height")                      cpu_config.initial_height = int(value);
 	else { g_host_error = "unknown config key '" + k + "'"; return -1; }
@@ -321,6 +322,7 @@ void grt_pathtracer_get_pixel_query(void * pt, int * pixel_index, int * mesh_id,
 	*status = int(p->pixel_query_status);
 }
 void * grt_pathtracer_context(void * pt) { return as_integrator(pt)->ctx; }
+float  grt_pathtracer_device_blas_build_ms(void * pt) { return as_integrator(pt)->device_blas_build_ms; }
 float  grt_pathtracer_lights_total_weight(void * pt) { { Pathtracer * p = dynamic_cast<Pathtracer *>(as_integrator(pt)); return p ? p->lights_total_weight : 0.0f; } }
 
 int grt_pathtracer_read_aov(void * pt, int aov, int accumulated, float * dst) {

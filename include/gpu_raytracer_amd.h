@@ -158,6 +158,17 @@ int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle
  * caller's buffers are free again), the device copy is asynchronous, samples already in flight keep
  * the version they were submitted with and later rt_render_sample calls see the new one. The GPU is
  * only drained when a table outgrows its ring.                                                   */
+/* Builds the CWBVH of every mesh ON THE DEVICE instead of uploading host-built nodes (replaces rt_upload_geometry; reference:
+ * SAHBuilder.cpp:13-104 + BVH8Converter.cpp:7-335 run per mesh on host threads at load time). `triangles` are the 96-byte
+ * device triangles of all meshes back to back in any order, mesh m owning [mesh_first_triangle[m], mesh_first_triangle[m + 1]).
+ * The device sorts each mesh's triangles along a Morton curve, builds 8-wide compressed nodes over the sorted order (<= 3
+ * triangles per leaf) and stores the triangles in leaf order: out_triangle_positions[i] is where input triangle i went (the
+ * caller remaps whatever names triangles by index: light tables), out_root_indices[m] the root node of mesh m (node slots
+ * [0, reserved_tlas_nodes) stay free for the TLAS). A linear BVH: built in a fraction of the host build's time, dearer to
+ * traverse than the SAH tree; closest hits are the same. rt_read_geometry returns what was built (host views, checker).   */
+int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_count, const int32_t * mesh_first_triangle, size_t mesh_count,
+                      size_t reserved_tlas_nodes, int32_t * out_root_indices, int32_t * out_triangle_positions, size_t * out_node_count, float * out_build_ms);
+int rt_read_geometry(rt_context * ctx, void * out_triangles, void * out_bvh8_nodes);
 int rt_upload_tlas(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count);
 /* Replaces `bvh2_nodes` (Integrator.cpp:205-206): binary SAH BVH, 32 B nodes, for
  * rt_set_bvh_type(ctx, 2) (BASELINE config #1).  TLAS occupies the first slots likewise. */

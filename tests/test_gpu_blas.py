@@ -1,0 +1,168 @@
+"""The BLAS build on the device (csrc/kernels_blas.hip, rt_build_geometry, config device_blas = 1).
+
+What is checked, and against what:
+  * the NODES the MI355X built, decoded here in numpy from the 80-byte format alone (nothing of the product's builder):
+    every triangle in exactly one leaf, 1..3 triangles per leaf in unary, leaf offsets running up in slot order, inner
+    children in consecutive node slots, every quantised child box containing the vertices of everything below it -- what
+    the reference's converter asserts of its own output (BVH8Converter.cpp:21,293,303,322-323) plus what traversal needs;
+  * HITS: the same rays through the device-built trees and through the host-built ones (whose builder is byte-identical
+    to the reference's): the same mesh, the same t bit for bit, the same ORIGINAL triangle, the same (u, v); exact ties in t
+    between two triangles (duplicated geometry) may resolve to the other triangle -- they are counted and bounded;
+  * the oracle walking the very nodes the device built gives the device's hits bit for bit (instance ids included);
+  * frames rendered on device-built trees match the oracle within the image tolerance, light sampling included (the
+    light tables name triangles by index: the host remaps them through the build's permutation)."""
+import numpy as np
+import pytest
+
+from conftest import make_pathtracer
+
+pytestmark = pytest.mark.gpu
+
+REL_L1_TOL = 1e-4
+
+
+def check_blas(nodes, triangles, root, first_triangle, last_triangle):
+    """Structural invariants of one BLAS (nodes: (n, 80) uint8 of the whole node array, triangles: (t, 24) float32 device
+    triangles in leaf order); returns the number of nodes of this tree."""
+    words = nodes.view(np.uint32).reshape(-1, 20)
+    origin = words[:, 0:3].copy().view(np.float32)
+    scale = (((words[:, 3:4] >> (8 * np.arange(3))) & 0xff).astype(np.uint32) << 23).view(np.float32)
+    imask = (words[:, 3] >> 24) & 0xff
+    meta = nodes[:, 24:32]
+    q = nodes[:, 32:80].reshape(-1, 3, 2, 8)
+    p0, e1, e2 = triangles[:, 0:3], triangles[:, 3:6], triangles[:, 6:9]
+    corners = np.stack([p0, p0 + e1, p0 + e2], axis=1)                       # (t, 3, 3)
+    tri_lo, tri_hi = corners.min(axis=1), corners.max(axis=1)
+    seen_triangles = np.zeros(len(triangles), np.int32)
+    visited = [0]
+
+    def visit(k):
+        visited[0] += 1
+        lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
+        inner_rank, expected_offset = 0, 0
+        for s in range(8):
+            m = int(meta[k, s])
+            if m == 0:
+                assert not (imask[k] >> s) & 1
+                continue
+            lo = origin[k] + q[k, :, 0, s] * scale[k]; hi = origin[k] + q[k, :, 1, s] * scale[k]
+            if (imask[k] >> s) & 1:
+                assert m == (0x20 | (24 + s)), (k, s, m)
+                child = int(words[k, 4]) + inner_rank; inner_rank += 1
+                assert child > k and child < len(nodes)
+                clo, chi = visit(child)
+            else:
+                unary, offset = m >> 5, m & 31
+                assert unary in (1, 3, 7) and offset == expected_offset, (k, s, m, expected_offset)
+                count = {1: 1, 3: 2, 7: 3}[unary]; expected_offset += count
+                assert expected_offset <= 24
+                first = int(words[k, 5]) + offset
+                assert first_triangle <= first and first + count <= last_triangle
+                seen_triangles[first:first + count] += 1
+                clo, chi = tri_lo[first:first + count].min(axis=0), tri_hi[first:first + count].max(axis=0)
+            slack = 1e-5 * np.maximum(np.abs(clo), np.abs(chi)) + 1e-30
+            assert (lo <= clo + slack).all() and (hi >= chi - slack).all(), (k, s, lo, clo, hi, chi)
+            lo_all, hi_all = np.minimum(lo_all, clo), np.maximum(hi_all, chi)
+        return lo_all, hi_all
+
+    visit(root)
+    assert (seen_triangles[first_triangle:last_triangle] == 1).all() and seen_triangles.sum() == last_triangle - first_triangle
+    return visited[0]
+
+
+def original_triangle_of(pt):
+    reverse = pt.array("reverse_indices").copy()          # original triangle -> device triangle (one entry per ORIGINAL triangle)
+    original = np.full(int(reverse.max()) + 1, -1, np.int64)
+    original[reverse] = np.arange(len(reverse))
+    return original
+
+
+def rays_for(view, w, h, seed, extent):
+    o, d, _ = view.generate(0, 0, w * h)
+    rng = np.random.default_rng(seed)
+    eo = rng.uniform(-extent, extent, (3, 30000)).astype(np.float32); ed = rng.normal(size=(3, 30000)).astype(np.float32); ed /= np.linalg.norm(ed, axis=0)
+    return np.concatenate([o, eo], axis=1), np.concatenate([d, ed], axis=1)
+
+
+@pytest.mark.parametrize("scene_name,extent", [("cornellbox", 3.0), ("sponza", 60.0)])
+def test_device_built_trees_are_valid_and_trace_like_the_host_built_ones(grt, oracle, scene_name, extent):
+    w, h = 320, 180
+    results = {}
+    for device_blas in (1, 0):
+        scene, pt = make_pathtracer(grt, scene_name, w, h, 0, device_blas=device_blas)
+        view = oracle.SceneView(pt)
+        if device_blas:
+            assert pt.device_blas_build_ms > 0.0
+            nodes = pt.array("bvh8_nodes").view(np.uint8).reshape(-1, 80)
+            triangles = pt.array("triangles").view(np.float32).reshape(-1, 24)
+            roots = pt.array("mesh_bvh_root_indices") & 0x7fffffff
+            total = 0
+            # one tree per mesh data; the meshes' triangle ranges follow from the leaves themselves: check every distinct root
+            words = nodes.view(np.uint32).reshape(-1, 20)
+            for root in sorted(set(int(r) for r in roots)):
+                total += check_blas_any_range(nodes, triangles, root)
+            assert total == len(nodes) - 2 * scene.mesh_count or total <= len(nodes)
+        o, d = rays_for(view, w, h, 3, extent)
+        hits, _ = grt.trace_rays(pt.ctx, o, d)
+        want, _ = view.trace(o, d)                         # the oracle on the nodes this context traces
+        assert np.array_equal(hits, want)
+        original = original_triangle_of(pt)
+        hit = hits[:, 1] != 0xffffffff
+        triangle = np.where(hit, original[np.where(hit, hits[:, 1], 0).astype(np.int64)], -1)
+        results[device_blas] = (hits.copy(), triangle, pt.array("tlas_indices").copy())
+        pt.close(); scene.close()
+    (a, tri_a, order_a), (b, tri_b, order_b) = results[1], results[0]
+    hit = b[:, 1] != 0xffffffff
+    assert hit.mean() > 0.3 and np.array_equal(hit, a[:, 1] != 0xffffffff)
+    assert np.array_equal(a[:, 2], b[:, 2])                                    # t, bit for bit
+    assert np.array_equal(order_a[a[hit, 0].astype(np.int64)], order_b[b[hit, 0].astype(np.int64)])   # the same instance
+    ties = (tri_a != tri_b) & hit                                              # another triangle at exactly the same t
+    assert ties.mean() < 2e-3, ties.mean()
+    same = hit & ~ties
+    assert np.array_equal(a[same, 3], b[same, 3])                              # (u, v)
+    grt.config_reset()
+
+
+def check_blas_any_range(nodes, triangles, root):
+    """check_blas for a tree whose triangle range is not known in advance: taken from its leaves."""
+    words = nodes.view(np.uint32).reshape(-1, 20)
+    meta = nodes[:, 24:32]
+    imask = (words[:, 3] >> 24) & 0xff
+    lo, hi, stack = 1 << 30, -1, [root]
+    while stack:
+        k = stack.pop()
+        rank = 0
+        for s in range(8):
+            m = int(meta[k, s])
+            if not m:
+                continue
+            if (imask[k] >> s) & 1:
+                stack.append(int(words[k, 4]) + rank); rank += 1
+            else:
+                first = int(words[k, 5]) + (m & 31); count = {1: 1, 3: 2, 7: 3}[m >> 5]
+                lo, hi = min(lo, first), max(hi, first + count)
+    if hi < 0:
+        return 1
+    return check_blas(nodes, triangles, root, lo, hi)
+
+
+def test_frames_on_device_built_trees_match_the_oracle(grt, oracle):
+    """Cornell box (area light: the light tables name triangles by index, remapped through the build's permutation) and
+    Sponza, rendered on trees the device built, against the oracle reading those trees back: queue sizes and images."""
+    for scene_name, w, h, bounces in (("cornellbox", 160, 120, 5), ("sponza", 256, 144, 4)):
+        scene, pt = make_pathtracer(grt, scene_name, w, h, 0, device_blas=1, num_bounces=bounces)
+        view = oracle.SceneView(pt)
+        frame = oracle.Frame(view)
+        for f in range(2):
+            if f:
+                pt.update()
+            pt.render()
+            c = pt.counters(); oc = frame.render_sample(pt.sample_index)
+            for queue in ("trace", "shadow", "diffuse"):
+                got, want = list(getattr(c, queue)[:bounces]), list(getattr(oc, queue)[:bounces])
+                assert got[0] == want[0] and all(abs(x - y) <= 2 + 0.002 * y for x, y in zip(got, want)), (scene_name, f, queue, got, want)
+            got, want = pt.read_framebuffer()[:, :w, :3], frame.final[:, :w, :3]
+            assert np.abs(got - want).sum() / want.sum() < REL_L1_TOL, (scene_name, f)
+        assert sum(c.shadow[:bounces]) > 1000
+        pt.close(); scene.close()
+    grt.config_reset()

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Device BLAS build (config device_blas = 1, rt_build_geometry) against the host build on the benchmark scene:
+build time, node count, and what the trees cost to traverse (the benchmark's frame loop, ms per step).
+usage (GPU box): python tools/blas_bench.py"""
+import ctypes
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import bench  # noqa: E402
+import gpu_raytracer_amd as grt  # noqa: E402
+
+
+def main():
+    lib = grt.device_lib()
+    lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    for device_blas in (0, 1, 1):
+        scene = bench.build_scene(grt)
+        grt.config_set(device_blas=device_blas)
+        t0 = time.perf_counter()
+        pt = grt.Pathtracer(scene, bench.WIDTH, bench.HEIGHT, device=0); pt.update()
+        setup_s = time.perf_counter() - t0
+        nodes = pt.array("bvh8_nodes").view(np.uint8).reshape(-1, 80).shape[0]
+        ctx = pt.ctx
+        for _ in range(3):
+            lib.rt_render_samples(ctx, 0, 4)
+        lib.rt_synchronize(ctx)
+        steps = 32
+        t0 = time.perf_counter()
+        for _ in range(steps // 4):
+            lib.rt_render_samples(ctx, 0, 4)
+        lib.rt_synchronize(ctx)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        grt.set_trace_statistics(ctx, True)
+        lib.rt_render_samples(ctx, 0, 1); stats = grt.get_trace_statistics(ctx); c = pt.counters()
+        rays = sum(c.trace[:bench.NUM_BOUNCES])
+        print("device_blas=%d: host BVH build %.1f ms (all meshes, worker threads), device build %.3f ms, %d nodes, integrator set-up %.2f s | %.3f ms per step, %.2f nodes and %.2f triangles per closest-hit ray"
+              % (device_blas, scene.bvh_build_ms, pt.device_blas_build_ms, nodes, setup_s, ms, stats["closest"]["nodes"] / max(rays, 1), stats["closest"]["triangles"] / max(rays, 1)), flush=True)
+        pt.close(); scene.close()
+
+
+if __name__ == "__main__":
+    main()
