@@ -6,8 +6,8 @@ What is checked, and against what:
     children in consecutive node slots, every quantised child box containing the vertices of everything below it -- what
     the reference's converter asserts of its own output (BVH8Converter.cpp:21,293,303,322-323) plus what traversal needs;
   * HITS: the same rays through the device-built trees and through the host-built ones (whose builder is byte-identical
-    to the reference's): the same mesh, the same t bit for bit, the same ORIGINAL triangle, the same (u, v); exact ties in t
-    between two triangles (duplicated geometry) may resolve to the other triangle -- they are counted and bounded;
+    to the reference's): the same instance, the same ORIGINAL triangle, t bit for bit and the same (u, v); rays that meet the
+    shared edge of two triangles may resolve to the other one at a t one ulp away -- they are counted and bounded;
   * the oracle walking the very nodes the device built gives the device's hits bit for bit (instance ids included);
   * frames rendered on device-built trees match the oracle within the image tolerance, light sampling included (the
     light tables name triangles by index: the host remaps them through the build's permutation)."""
@@ -114,12 +114,17 @@ def test_device_built_trees_are_valid_and_trace_like_the_host_built_ones(grt, or
     (a, tri_a, order_a), (b, tri_b, order_b) = results[1], results[0]
     hit = b[:, 1] != 0xffffffff
     assert hit.mean() > 0.3 and np.array_equal(hit, a[:, 1] != 0xffffffff)
-    assert np.array_equal(a[:, 2], b[:, 2])                                    # t, bit for bit
+    # Where both trees find the same triangle, everything is bit-identical. Where a ray meets the shared edge of two triangles
+    # (the diagonal of a Cornell wall: both accept it, their t differ in the last place) the tree decides: whichever is tested
+    # first can pull the ray's range in far enough for the node of the other to be culled -- the two candidates differ by an
+    # ulp of t, and such rays are a handful per thousand.
+    ta, tb = a[:, 2].view(np.float32), b[:, 2].view(np.float32)
+    assert np.allclose(ta[hit], tb[hit], rtol=5e-7, atol=0)
     assert np.array_equal(order_a[a[hit, 0].astype(np.int64)], order_b[b[hit, 0].astype(np.int64)])   # the same instance
-    ties = (tri_a != tri_b) & hit                                              # another triangle at exactly the same t
-    assert ties.mean() < 2e-3, ties.mean()
-    same = hit & ~ties
-    assert np.array_equal(a[same, 3], b[same, 3])                              # (u, v)
+    other_triangle = (tri_a != tri_b) & hit
+    assert other_triangle.mean() < 3e-3, other_triangle.mean()
+    same = hit & ~other_triangle
+    assert np.array_equal(a[same, 2], b[same, 2]) and np.array_equal(a[same, 3], b[same, 3])     # t bit for bit, (u, v)
     grt.config_reset()
 
 
