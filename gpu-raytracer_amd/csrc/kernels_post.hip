@@ -131,12 +131,13 @@ RT_DEV float mitchell_netravali(float x) {
 	return 0.0f;
 }
 
+// history_normal_and_depth holds the previous frame's (normal, depth) DECODED (kernel_svgf_finalize copies the frame's decoded
+// image, see kernel_svgf_reproject): up to 4 + 9 of these tests per pixel no longer decode an octahedral normal each.
 RT_DEV bool is_tap_consistent(const RtParams & p, int x, int y, f3 normal, float depth) {
 	if (x < 0 || x >= p.screen_width)  return false;
 	if (y < 0 || y >= p.screen_height) return false;
 	float4 prev = p.history_normal_and_depth[x + y * p.screen_pitch];
-	f3 prev_normal = oct_decode_normal(mk2(prev.x, prev.y));
-	return dot(normal, prev_normal) > 0.95f && fabsf(depth - prev.z) < 2.0f;
+	return dot(normal, mk3(prev.x, prev.y, prev.z)) > 0.95f && fabsf(depth - prev.w) < 2.0f;
 }
 
 // The edge-stopping weights of the variance and a-trous filters (SVGF.h:268-282):
@@ -166,7 +167,10 @@ RT_DEV f2 edge_stopping_weights(const RtParams & p, int delta_x, int delta_y, f2
 	return mk2(w_l_direct, w_l_indirect);
 }
 
-__global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p) {
+// `direct_out` / `indirect_out` / `variance_out` (null without the spatial variance estimate): where kernel_svgf_variance writes.
+// That kernel only has work for pixels whose history is shorter than 4 frames; for all others -- and the sky -- its output is
+// a copy of this kernel's, which this kernel therefore writes itself (the copy used to cost a second pass over 64 B per pixel).
+__global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p, float4 * direct_out, float4 * indirect_out, float2 * variance_out) {
 	int x, y;
 	if (!post_tile_pixel(p, x, y)) return;
 	if (x >= p.screen_width || y >= p.screen_height) return;
@@ -191,7 +195,11 @@ __global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p) {
 	p.svgf_normal_and_depth[pixel_index] = make_float4(normal.x, normal.y, normal.z, depth);
 	// ... and the variance pair (direct.w, indirect.w) of every pixel once more in a float2 image of its own: the a-trous passes
 	// blur it over 3 x 3 neighbours, and a .w picked out of two float4 images costs the cache as much as the float4s
-	if (depth == 0.0f) { p.svgf_variance[0][pixel_index] = make_float2(direct.w, indirect.w); return; } // sky
+	if (depth == 0.0f) { // sky
+		p.svgf_variance[0][pixel_index] = make_float2(direct.w, indirect.w);
+		if (direct_out) { st4(direct_out, pixel_index, direct); st4(indirect_out, pixel_index, indirect); variance_out[pixel_index] = make_float2(direct.w, indirect.w); }
+		return;
+	}
 
 	float s_prev = (0.5f + 0.5f * screen_position_prev.x) * float(p.screen_width);
 	float t_prev = (0.5f + 0.5f * screen_position_prev.y) * float(p.screen_height);
@@ -242,12 +250,14 @@ __global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p) {
 		}
 	}
 
+	int history_now = 0;   // the pixel's history length after this frame
 	if (consistent_weights_sum > 0.0f) {
 		prev_direct   = prev_direct   / consistent_weights_sum;
 		prev_indirect = prev_indirect / consistent_weights_sum;
 		prev_moment   = prev_moment   / consistent_weights_sum;
 
 		int history = ++p.history_length[pixel_index];
+		history_now = history;
 		float inv_history = 1.0f / float(history);
 		float alpha_colour = fmaxf(p.config.alpha_colour, inv_history);
 		float alpha_moment = fmaxf(p.config.alpha_moment, inv_history);
@@ -269,6 +279,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p) {
 	st4(fb_indirect, pixel_index, indirect);
 	st4(p.frame_buffer_moment, pixel_index, moment);
 	p.svgf_variance[0][pixel_index] = make_float2(direct.w, indirect.w);
+	if (direct_out && history_now >= 4) { st4(direct_out, pixel_index, direct); st4(indirect_out, pixel_index, indirect); variance_out[pixel_index] = make_float2(direct.w, indirect.w); }
 }
 
 __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, float2 * variance_out) {
@@ -278,6 +289,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 	int pixel_index = x + y * p.screen_pitch;
 
 	int history = p.history_length[pixel_index];
+	if (history >= 4 && x < p.screen_width) return;   // copied by kernel_svgf_reproject (which does not visit the padding columns: they keep the copy below)
 	if (history >= 4) { float4 d = d_in[pixel_index], i = i_in[pixel_index]; d_out[pixel_index] = d; i_out[pixel_index] = i; variance_out[pixel_index] = make_float2(d.w, i.w); return; }
 
 	const float4 * __restrict__ normal_and_depth = p.svgf_normal_and_depth;   // (normal, depth), decoded by kernel_svgf_reproject
@@ -292,7 +304,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 	f2 grad = mk2(normal_and_depth[xr + y * p.screen_pitch].w - center_depth,
 	              normal_and_depth[x + yd * p.screen_pitch].w - center_depth);
 
-	if (center_depth == 0.0f) { st4(d_out, pixel_index, cd); st4(i_out, pixel_index, ci); variance_out[pixel_index] = make_float2(cd.w, ci.w); return; }
+	if (center_depth == 0.0f) { if (x < p.screen_width) return; st4(d_out, pixel_index, cd); st4(i_out, pixel_index, ci); variance_out[pixel_index] = make_float2(cd.w, ci.w); return; }   // sky: copied by kernel_svgf_reproject
 
 	float sw_d = 1.0f, sw_i = 1.0f;
 	f4 sc_d = cd, sc_i = ci;
@@ -418,7 +430,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_finalize(RtParams p, const fl
 	float4 normal_and_depth = p.gbuffer_normal_and_depth[pixel_index];
 	if (p.config.num_atrous_iterations <= RT_FEEDBACK_ITERATION) { st4(p.history_direct, pixel_index, direct); st4(p.history_indirect, pixel_index, indirect); }
 	p.history_moment[pixel_index] = moment;
-	p.history_normal_and_depth[pixel_index] = normal_and_depth;
+	p.history_normal_and_depth[pixel_index] = p.svgf_normal_and_depth[pixel_index];   // decoded (normal, depth) of this frame
 
 	p.gbuffer_normal_and_depth[pixel_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	p.gbuffer_mesh_id_and_triangle_id[pixel_index] = make_int2(0, 0);
@@ -505,12 +517,12 @@ void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream
 	dim3 grid((tiles + 7) / 8 * 8);   // post_tile_pixel: XCD k sweeps the k-th eighth of the tiles
 	#define RT_TIMED(k, launch) { if (mark) mark(user, k, stream); launch; if (mark) mark(user, k, stream); }
 
-	RT_TIMED(0, hipLaunchKernelGGL(kernel_svgf_reproject, grid, block, 0, stream, p));
-
 	float4 * direct_in    = p.aovs[RT_AOV_RADIANCE_DIRECT].framebuffer;
 	float4 * indirect_in  = p.aovs[RT_AOV_RADIANCE_INDIRECT].framebuffer;
 	float4 * direct_out   = p.aovs[RT_AOV_RADIANCE_DIRECT].accumulator;
 	float4 * indirect_out = p.aovs[RT_AOV_RADIANCE_INDIRECT].accumulator;
+	const bool estimate = p.config.enable_spatial_variance != 0;
+	RT_TIMED(0, hipLaunchKernelGGL(kernel_svgf_reproject, grid, block, 0, stream, p, estimate ? direct_out : nullptr, estimate ? indirect_out : nullptr, estimate ? p.svgf_variance[1] : nullptr));
 
 	// svgf_variance[0] mirrors the .w of the two framebuffers, [1] that of the two accumulators -- pixel for pixel, the ones a pass
 	// leaves unwritten (sky) included: every kernel that writes a (direct, indirect) pair writes the pair's variances as well
