@@ -58,6 +58,10 @@ __global__ void __launch_bounds__(256) kernel_blas_triangle_boxes(BlasBuildArgs 
 		for (int d = 0; d < 3; d++) {
 			float v1 = p0[d] + e1[d], v2 = p0[d] + e2[d];   // the vertices the traversal's Moeller-Trumbore test sees
 			box.min[d] = fminf(p0[d], fminf(v1, v2)); box.max[d] = fmaxf(p0[d], fmaxf(v1, v2));
+			// no flat boxes: the node test is `tmin < tmax`, a box of zero thickness is never entered -- an axis-aligned wall would
+			// be hit only where the quantisation grid happens to pad it. The reference's rule (AABB::fix_if_needed, AABB.h:27-38)
+			float eps = 0.001f;
+			while (box.max[d] - box.min[d] < eps) { box.min[d] -= eps; box.max[d] += eps; eps *= 2.0f; }
 		}
 		a.triangle_boxes[i] = box; a.triangle_mesh[i] = mesh;
 		tlas_box_grow(mine, box);
