@@ -206,11 +206,13 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
 #   accumulate  48 B per pixel and AOV (sample read, accumulator read + write)
 #   SVGF / TAA  every tap the kernels request, enumerated from the tap loops (reference SVGF.h:130-609, TAA.h:10-172);
 #               `unique` next to it is the compulsory traffic (every image read / written once per kernel)
-SVGF_TAP_BYTES = {   # kernel: (bytes requested per pixel, bytes per pixel if every image moved once)
-    "svgf_reproject": (32 + 16 + 8 + 4 * 16 + 4 * 48 + 8 + 48, 32 + 16 + 8 + 16 + 48 + 8 + 48),
-    "svgf_variance":  (32 + 4 + 64, 32 + 4 + 64),             # pixels with a history of >= 4 frames are copied; younger ones gather 48 taps x 64 B (counted below)
-    "svgf_atrous":    (9 * 2 * 16 + 32 + 16 + 2 * 16 + 8 * (32 + 16) + 32, 32 + 16 + 32),
-    "svgf_finalize":  (32 + 16 + 16 + 16 + 16 + 16 + 16 + 16 + 16 + 8, 176),
+SVGF_TAP_BYTES = {   # kernel: (bytes requested per pixel, bytes per pixel if every image moved once); kernels as of round 3
+    # reads radiance pair 32, g-buffer 16 + 8, 4 history (normal, depth) taps, 4 x 3 history taps, history length r/w; writes the pair, the
+    # moments, the decoded (normal, depth), the variance pair, and for pixels with >= 4 frames of history the variance pass's copies
+    "svgf_reproject": (32 + 16 + 8 + 4 * 16 + 4 * 48 + 8 + 32 + 16 + 16 + 8 + 40, 32 + 16 + 8 + 16 + 48 + 8 + 32 + 16 + 16 + 8 + 40),
+    "svgf_variance":  (4, 4),             # only pixels with a history shorter than 4 frames have work (48 taps x 80 B each); the others read their history length
+    "svgf_atrous":    (9 * 8 + 32 + 16 + 2 * 4 + 8 * (32 + 16) + 32 + 8 + 5, 32 + 16 + 8 + 32 + 8 + 5),   # 3x3 variance pairs, centre, 8 taps of (direct, indirect, normal + depth); + the history copy of pass 2
+    "svgf_finalize":  (32 + 16 + 16 + 16 + 16 + 16 + 16 + 16 + 16 + 8, 184),
     "taa":            (16 + 8 + 16 * 16 + 8 * 16 + 16, 16 + 8 + 16 + 16),
     "taa_finalize":   (16 + 16 + 16 + 8, 56),
 }
