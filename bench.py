@@ -63,9 +63,13 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3-6.6
 VALU_PEAK_LANE_INSTR_PER_S = 256 * 4 * 16 * 2.4e9
 
 
+MERGE_STATIC = 1   # --merge-static: 0 stages the scene exactly as the reference does (one BLAS per mesh under the TLAS)
+
+
 def build_scene(grt):
     """BASELINE config #2: Sponza, every odd diffuse material -> roughplastic alpha 0.3."""
     grt.config_reset()
+    grt.config_set(merge_static=MERGE_STATIC)
     scene = grt.Scene(grt.scene_path("sponza"))
     for i in range(1, scene.material_count, 2):
         if scene.material_type(i) == grt.MATERIAL_DIFFUSE:
@@ -141,7 +145,8 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
     passes over this very command (tools/pmc_pass.py). Everything is per traversal launch of the timed region, like `achieved`."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_pass
-    passes = pmc_pass.run_passes(args.steps, args.warmup, groups=pmc_pass.DEFAULT_GROUPS + ["TCC_HIT_sum TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"])
+    passes = pmc_pass.run_passes(args.steps, args.warmup, groups=pmc_pass.DEFAULT_GROUPS + ["TCC_HIT_sum TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"],
+                                  extra_args=("--merge-static", str(args.merge_static)))
     kernels = passes["kernels"]
     out = {"pmc_errors": passes["errors"]} if passes["errors"] else {}
     trace = kernels.get("kernel_trace_stream_bvh8")
@@ -318,9 +323,12 @@ def main():
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage rooflines (a repeat of the timed plan with events around every launch)")
     ap.add_argument("--no-povs", action="store_true", help="skip the sweep over the reference's 9 fixed Sponza points of view (N = 1 only)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: render only rank 0's tiles of an N-GPU split on one GPU (no collective), to exercise the N > 1 code path")
+    ap.add_argument("--merge-static", type=int, default=1, help="1 (default): the 382 instances of Sponza that stand still with the identity transform are flattened into one bottom-level tree (config merge_static); 0: one BLAS per mesh under the TLAS, the reference's layout")
     ap.add_argument("--batch", type=int, default=SPP, help="samples per pixel per submission (rt_render_samples), 1..%d" % SPP)
     ap.add_argument("--samples-in-flight", type=int, default=0, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
     args = ap.parse_args()
+    global MERGE_STATIC
+    MERGE_STATIC = args.merge_static
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
@@ -595,6 +603,8 @@ def main():
                 "workload": "Sponza (Crytek, 262 687 triangles, 384 instances) 1920x1080, samples 0..3 (4 spp), BVH8/CWBVH, diffuse + roughplastic(odd materials, alpha 0.3), NEE+MIS+RR, 10 bounces, constant white sky, mipmapping on, 19 diffuse textures at the reference's dimensions (1024x1024 + mips, BC1 block-compressed as the reference does by default, decoded in the shade kernels; texels replicated 4x4 from the quarter-size maps that travel with the repo), the 5 maps missing upstream are the reference's 1x1 fallback texel",
                 "step": "one sample per pixel for the whole frame; the 4 samples of a frame are one submission (rt_render_samples); consecutive submissions feed one merged wavefront, every launch carries the rays of all submissions in flight",
                 "scheduler": scheduler,
+                "acceleration_structure": ("%d of %d instances (identity transform, static) flattened into one CWBVH of %d triangle copies with one TLAS leaf, hits reported as the scene's own instances and triangles (rt_upload_triangle_aliases); --merge-static 0 runs the reference's layout"
+                                           % (pt.static_geometry_members, scene.mesh_count, int((pt.array("alias_mesh_ids") >= 0).sum()))) if pt.static_geometry_members else "one CWBVH per mesh under a CWBVH TLAS (the reference's layout)",
                 "rays_per_step": round(rays_plan / args.steps), "shadow_rays_per_step": round(shadow_plan / args.steps),
                 "mrays_s_including_shadow": round((rays_plan + shadow_plan) / elapsed / 1e6, 1),
                 "ms_per_4spp_frame": round(elapsed / args.steps * SPP * 1e3, 3),

@@ -73,8 +73,8 @@ def device_lib():
         # first) keeps HIP's default of 4 queues and the context says so when it matters.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
         lib = ctypes.CDLL(DEVICE_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-        if hasattr(lib, "rt_abi_version") and lib.rt_abi_version() != 3:
-            raise DeviceLibraryMissing("%s has ABI version %d, this front end was written for 3 -- rebuild (python __graft_entry__.py)" % (DEVICE_LIB_PATH, lib.rt_abi_version()))
+        if hasattr(lib, "rt_abi_version") and lib.rt_abi_version() != 4:
+            raise DeviceLibraryMissing("%s has ABI version %d, this front end was written for 4 -- rebuild (python __graft_entry__.py)" % (DEVICE_LIB_PATH, lib.rt_abi_version()))
         lib.rt_last_error.restype = c_char_p
         lib.rt_last_error.argtypes = [c_void_p]
         lib.rt_version.restype = c_char_p
@@ -153,6 +153,10 @@ def host_lib():
         lib.grt_pathtracer_context.argtypes = [c_void_p]
         lib.grt_pathtracer_device_blas_build_ms.restype = c_float
         lib.grt_pathtracer_device_blas_build_ms.argtypes = [c_void_p]
+        lib.grt_pathtracer_static_geometry_members.restype = c_int
+        lib.grt_pathtracer_static_geometry_members.argtypes = [c_void_p]
+        lib.grt_pathtracer_static_geometry_build_seconds.restype = ctypes.c_double
+        lib.grt_pathtracer_static_geometry_build_seconds.argtypes = [c_void_p]
         lib.grt_pathtracer_lights_total_weight.restype = c_float
         lib.grt_pathtracer_lights_total_weight.argtypes = [c_void_p]
         lib.grt_pathtracer_read_aov.argtypes = [c_void_p, c_int, c_int, c_void_p]
@@ -421,6 +425,7 @@ _ARRAY_DTYPES = {
     "light_mesh_transform_indices": np.int32, "sky": np.float32, "camera": np.uint8, "svgf_matrices": np.float32,
     "scene_order_roots": np.int32, "scene_order_materials": np.int32, "scene_order_transforms": np.float32,
     "scene_order_transforms_inv": np.float32, "scene_order_transforms_prev": np.float32, "scene_order_boxes": np.float32,
+    "alias_mesh_ids": np.int32, "alias_triangle_ids": np.int32,
 }
 
 
@@ -462,6 +467,15 @@ class Pathtracer:
     def device_blas_build_ms(self):
         """config device_blas = 1: what the BLAS build took on the device (0 when the host built the trees)."""
         return float(host_lib().grt_pathtracer_device_blas_build_ms(self.handle))
+
+    @property
+    def static_geometry_members(self):
+        """config merge_static = 1: instances flattened into the one static bottom-level tree (0: none, or dissolved)."""
+        return int(host_lib().grt_pathtracer_static_geometry_members(self.handle))
+
+    @property
+    def static_geometry_build_seconds(self):
+        return float(host_lib().grt_pathtracer_static_geometry_build_seconds(self.handle))
 
     @property
     def lights_total_weight(self):

@@ -459,6 +459,10 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 		bool inactive = stack.size == 0 && current_group.y == 0 && triangle_group.y == 0;
 
 		if (result_pending) {
+			if (!RT_IS_SHADOW && p.has_triangle_aliases && hit.triangle_id != RT_INVALID) { // a copy in the flattened static BLAS reports its original (rt_upload_triangle_aliases)
+				float4 names = triangles[size_t(hit.triangle_id) * 3 + 2];
+				if (__float_as_int(names.z) >= 0) { hit.mesh_id = __float_as_int(names.z); hit.triangle_id = __float_as_int(names.w); }
+			}
 			if (!NARROW || group_child == 0) source_finish<MODE>(src, RT_IS_SHADOW, ray_index, hit, result_pending == 2);
 			result_pending = 0;
 		}

@@ -415,7 +415,7 @@ enum { SPAN_TRACE = RT_TIMING_TRACE, SPAN_SHADOW = RT_TIMING_SHADOW, SPAN_SORT =
 
 extern "C" {
 
-const char * rt_version(void) { return "gpu-raytracer_amd 0.3 (gfx950, HIP; ABI 3)"; }
+const char * rt_version(void) { return "gpu-raytracer_amd 0.3 (gfx950, HIP; ABI 4)"; }
 int rt_abi_version(void) { return RT_ABI_VERSION; }
 
 const char * rt_last_error(const rt_context * ctx) { return ctx ? ctx->error.c_str() : g_global_error.c_str(); }
@@ -498,6 +498,7 @@ static int upload_triangle_positions(rt_context * ctx, const void * triangles, s
 	for (size_t t = 0; t < triangle_count; t++) memcpy(&positions[t * 12], src + t * 24, 36);
 	int s = upload(ctx, &ctx->triangle_positions, positions.data(), triangle_count * 48); if (s) return s;
 	ctx->params.triangle_positions = (const float4 *)ctx->triangle_positions;
+	ctx->params.has_triangle_aliases = 0;
 	return RT_OK;
 }
 
@@ -511,6 +512,47 @@ int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle
 	ctx->tlas_version_in_nodes = ~0ull;
 	ctx->params.triangles  = (const float4 *)ctx->triangles;
 	ctx->params.bvh8_nodes = (const float4 *)ctx->bvh8_nodes;
+	return RT_OK;
+}
+
+// Static geometry flattened into one BLAS: its triangles are COPIES of triangles that other BLASes own, and a hit on a copy is
+// reported as the instance and the triangle it was copied from (kernels_trace.hip translates once per ray, when the ray is done).
+// The two names are the last 8 bytes of the 48-byte position record (36 B of positions + 12 B of padding), so the translation
+// costs one load from a line the triangle test has touched.
+} // extern "C"
+__global__ void kernel_name_triangles(float4 * positions, const int2 * names, int count) {
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= count) return;
+	float4 last = positions[size_t(i) * 3 + 2];
+	last.z = __int_as_float(names[i].x); last.w = __int_as_float(names[i].y);
+	positions[size_t(i) * 3 + 2] = last;
+}
+extern "C" {
+int rt_upload_triangle_aliases(rt_context * ctx, const int32_t * mesh_ids, const int32_t * triangle_ids) {
+	RT_REQUIRE(ctx, ctx && ctx->triangle_positions, "rt_upload_triangle_aliases: no geometry uploaded");
+	(void)hipSetDevice(ctx->device);
+	if (!mesh_ids || !triangle_ids) { RT_HIP(ctx, quiesce(ctx)); ctx->params.has_triangle_aliases = 0; return RT_OK; }
+	size_t count = ctx->triangle_count;
+	std::vector<int32_t> names(2 * count);
+	bool any = false;
+	for (size_t i = 0; i < count; i++) {
+		bool copy = mesh_ids[i] >= 0;
+		RT_REQUIRE(ctx, !copy || (triangle_ids[i] >= 0 && size_t(triangle_ids[i]) < count && mesh_ids[triangle_ids[i]] < 0), "rt_upload_triangle_aliases: a copy must name a triangle of the array that is not itself a copy");
+		names[2 * i] = copy ? mesh_ids[i] : -1; names[2 * i + 1] = copy ? triangle_ids[i] : -1;
+		any = any || copy;
+	}
+	RT_HIP(ctx, quiesce(ctx));
+	void * device_names = nullptr;
+	int s = device_alloc(ctx, &device_names, names.size() * 4); if (s) return s;
+	hipError_t e = hipMemcpy(device_names, names.data(), names.size() * 4, hipMemcpyHostToDevice);
+	if (e == hipSuccess && count) {
+		kernel_name_triangles<<<unsigned((count + 255) / 256), 256, 0, ctx->stream>>>((float4 *)ctx->triangle_positions, (const int2 *)device_names, int(count));
+		e = hipGetLastError();
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	}
+	device_free(ctx, device_names);
+	if (e != hipSuccess) return fail(ctx, RT_ERROR_HIP, "rt_upload_triangle_aliases: %s", hipGetErrorString(e));
+	ctx->params.has_triangle_aliases = any ? 1 : 0;
 	return RT_OK;
 }
 
@@ -590,6 +632,7 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	ctx->triangle_count = T; ctx->bvh8_node_count = size_t(node_count);
 	ctx->tlas_version_in_nodes = ~0ull;
 	ctx->params.triangles = (const float4 *)out_triangles; ctx->params.triangle_positions = (const float4 *)out_positions; ctx->params.bvh8_nodes = (const float4 *)out_nodes;
+	ctx->params.has_triangle_aliases = 0;
 	if (out_root_indices) for (size_t m = 0; m < M; m++) out_root_indices[m] = int32_t(reserved_tlas_nodes + m);
 	if (out_node_count) *out_node_count = size_t(node_count);
 	if (out_build_ms) *out_build_ms = ms;

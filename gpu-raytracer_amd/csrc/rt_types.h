@@ -112,7 +112,9 @@ struct RtParams {
 	int tlas_node_count;
 	int bvh_width;              // 8: CWBVH kernels (default), 4: 4-wide BVH kernels, 2: binary-BVH kernels
 	const int    * mesh_bvh_root_indices;
-	int mesh_count, mesh_count_pad;   // instances (the fused traversal launch keeps the root table of a small scene in LDS)
+	int mesh_count;                   // instances (the fused traversal launch keeps the root table of a small scene in LDS)
+	int has_triangle_aliases;         // some triangles are copies that report the (instance, triangle) named in the padding of their
+	                                  // position record instead of themselves (rt_upload_triangle_aliases)
 	const int    * mesh_material_ids;
 	const float4 * mesh_transforms, * mesh_transforms_inv, * mesh_transforms_prev;
 	// TLAS built on the device (rt_build_tlas): scene index of an instance -> its position in TLAS order, for tables that

@@ -123,6 +123,12 @@ void SAHBuilder::build(const std::vector<Mesh> & meshes) {
 	build_from_bounds(*this, bounds, centers);
 }
 
+void SAHBuilder::build(const std::vector<AABB> & boxes) {
+	std::vector<Vector3> centers(boxes.size());
+	for (size_t i = 0; i < boxes.size(); i++) centers[i] = boxes[i].get_center();
+	build_from_bounds(*this, boxes, centers);
+}
+
 BVH2 BVH::create_sah_from_triangles(const std::vector<Triangle> & triangles) {
 	BVH2 bvh;
 	SAHBuilder(bvh, triangles.size()).build(triangles);

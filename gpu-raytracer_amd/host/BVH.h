@@ -143,6 +143,7 @@ struct SAHBuilder {
 
 	void build(const std::vector<Triangle> & triangles);
 	void build(const std::vector<Mesh>     & meshes);
+	void build(const std::vector<AABB>     & boxes);   // any boxes (the TLAS over flattened static geometry + the moving instances)
 };
 
 struct BVH8Converter {

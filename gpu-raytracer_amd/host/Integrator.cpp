@@ -1,6 +1,7 @@
 #include "Integrator.h"
 #include "Exporters.h"
 
+#include <chrono>
 #include <stdexcept>
 
 Integrator::Integrator(Scene & scene, int device_ordinal) : scene(scene) {
@@ -161,21 +162,83 @@ void Integrator::init_geometry() {
 				dst[n].base_index_child    += unsigned(mesh_data_bvh_offsets[m]);
 			}
 		}
-		if (ctx && cpu_config.device_blas > 0) {
+		// Flattened static geometry: copies of the identity instances' triangles behind everything else, one more tree over them
+		StaticGeometry & flat = static_geometry;
+		flat = StaticGeometry(); alias_mesh_ids.clear(); alias_triangle_ids.clear();
+		bool build_on_device = ctx && cpu_config.device_blas > 0;
+		std::vector<int> source_member, source_triangle;   // per triangle of the members, in member order: its member, its index among all original triangles
+		std::vector<int> copy_source;                      // per copy, in device order: which of those it copies
+		if (cpu_config.merge_static > 0 && !wants_device_tlas()) {
+			for (size_t i = 0; i < mesh_count; i++) (scene.meshes[i].has_identity_transform() ? flat.members : flat.movers).push_back(int(i));
+			if (flat.members.size() < 2) { flat.members.clear(); flat.movers.clear(); }
+		}
+		if (!flat.members.empty()) {
+			std::vector<Triangle> world;
+			for (size_t j = 0; j < flat.members.size(); j++) {
+				const Mesh & mesh = scene.meshes[flat.members[j]];
+				int handle = mesh.mesh_data_handle.handle;
+				for (size_t t = 0; t < mesh_datas[handle].triangles.size(); t++) {
+					source_member.push_back(int(j)); source_triangle.push_back(mesh_data_triangle_offsets[handle] + int(t));
+					if (!build_on_device) world.push_back(mesh_datas[handle].triangles[t]);
+				}
+			}
+			size_t copies = source_member.size();
+			if (build_on_device) {
+				copy_source.resize(copies);
+				for (size_t c = 0; c < copies; c++) copy_source[c] = int(c);
+			} else {
+				auto started = std::chrono::steady_clock::now();
+				BVH2 binary = BVH::create_sah_from_triangles(world);
+				BVH8 wide;
+				BVH8Converter(wide, binary).convert();
+				flat.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
+				copy_source = wide.indices;
+				flat.root = int(node_total);
+				aggregated_bvh_nodes_8.resize(node_total + wide.nodes.size());
+				for (size_t n = 0; n < wide.nodes.size(); n++) {
+					BVHNode8 & dst = aggregated_bvh_nodes_8[node_total + n];
+					dst = wide.nodes[n];
+					dst.base_index_triangle += unsigned(index_total);
+					dst.base_index_child    += unsigned(node_total);
+				}
+			}
+			aggregated_triangles.resize(index_total + copies);
+			alias_mesh_ids.assign(index_total + copies, -1); alias_triangle_ids.assign(index_total + copies, -1);
+			for (size_t c = 0; c < copies; c++) {
+				int original = reverse_indices[source_triangle[copy_source[c]]];
+				aggregated_triangles[index_total + c] = aggregated_triangles[original];
+				alias_mesh_ids     [index_total + c] = flat.leaves() + source_member[copy_source[c]];   // its member's row behind the TLAS leaves' rows
+				alias_triangle_ids [index_total + c] = original;
+			}
+			flat.built = flat.active = true;
+		}
+		if (build_on_device) {
 			// the trees are built on the device from the triangles alone (their order -- the host trees' leaf order -- is as good as
 			// any); what names triangles or nodes by index on the host follows: BLAS roots, the original-triangle -> device-triangle
 			// table behind the light tables, and the host's views of the device arrays (pixel queries, exporters, the checker)
-			std::vector<int> first(mesh_data_count + 1), roots(mesh_data_count), position(index_total);
+			size_t tree_count = mesh_data_count + (flat.built ? 1 : 0), triangle_count = aggregated_triangles.size();
+			std::vector<int> first(tree_count + 1), roots(tree_count), position(triangle_count);
 			for (size_t m = 0; m < mesh_data_count; m++) first[m] = mesh_data_index_offsets[m];
 			first[mesh_data_count] = int(index_total);
+			first[tree_count]      = int(triangle_count);
 			size_t built_nodes = 0;
-			check(rt_build_geometry(ctx, aggregated_triangles.data(), index_total, first.data(), mesh_data_count, 2 * mesh_count, roots.data(), position.data(), &built_nodes, &device_blas_build_ms));
+			check(rt_build_geometry(ctx, aggregated_triangles.data(), triangle_count, first.data(), tree_count, 2 * mesh_count, roots.data(), position.data(), &built_nodes, &device_blas_build_ms));
 			for (size_t m = 0; m < mesh_data_count; m++) mesh_data_bvh_offsets[m] = roots[m];
 			for (int & device_index : reverse_indices) device_index = position[device_index];
+			if (flat.built) { // the build moved every triangle, copies and originals alike
+				flat.root = roots[mesh_data_count];
+				std::vector<int> moved_mesh(triangle_count, -1), moved_triangle(triangle_count, -1);
+				for (size_t i = 0; i < triangle_count; i++) if (alias_mesh_ids[i] >= 0) { moved_mesh[size_t(position[i])] = alias_mesh_ids[i]; moved_triangle[size_t(position[i])] = position[size_t(alias_triangle_ids[i])]; }
+				alias_mesh_ids.swap(moved_mesh); alias_triangle_ids.swap(moved_triangle);
+			}
 			aggregated_bvh_nodes_8.assign(built_nodes, BVHNode8());
 			check(rt_read_geometry(ctx, aggregated_triangles.data(), aggregated_bvh_nodes_8.data()));
 		} else
 		if (ctx) check(rt_upload_geometry(ctx, aggregated_triangles.data(), aggregated_triangles.size(), aggregated_bvh_nodes_8.data(), aggregated_bvh_nodes_8.size()));
+		if (flat.built) {
+			if (ctx) check(rt_upload_triangle_aliases(ctx, alias_mesh_ids.data(), alias_triangle_ids.data()));
+			tlas_builder = std::make_unique<SAHBuilder>(tlas_raw, size_t(flat.leaves()));
+		}
 	} else {
 		aggregated_bvh_nodes_2.assign(node_total, BVHNode2());
 		memset(aggregated_bvh_nodes_2.data(), 0, node_total * sizeof(BVHNode2));
@@ -263,30 +326,58 @@ void Integrator::build_tlas() {
 		return;
 	}
 	tlas_on_device = false;
-	tlas_builder->build(scene.meshes);
+	StaticGeometry & flat = static_geometry;
+	if (flat.active) { // the flattened instances have to stand still
+		bool still = cpu_config.bvh_type == BVHType::BVH8;
+		for (int member : flat.members) still = still && scene.meshes[member].has_identity_transform();
+		if (!still) { // back to one BLAS per instance, for good: the per-mesh trees never left the device
+			flat.active = false;
+			tlas_builder = std::make_unique<SAHBuilder>(tlas_raw, mesh_count);
+		}
+	}
+	if (flat.active) {
+		std::vector<AABB> leaf_boxes(size_t(flat.leaves()));
+		flat.aabb = AABB::create_empty();   // (Mesh::update fills in the world boxes: they are not known when the geometry is set up)
+		for (int member : flat.members) flat.aabb.expand(scene.meshes[member].aabb);
+		leaf_boxes[0] = flat.aabb;
+		for (size_t k = 0; k < flat.movers.size(); k++) leaf_boxes[1 + k] = scene.meshes[flat.movers[k]].aabb;
+		tlas_builder->build(leaf_boxes);
+	} else {
+		tlas_builder->build(scene.meshes);
+	}
 
 	bool use_bvh8 = cpu_config.bvh_type == BVHType::BVH8;
-	const std::vector<int> * leaf_order;
 	if (cpu_config.bvh_type == BVHType::BVH4) {
 		BVH4Converter(tlas_4, tlas_raw).convert();
 		memcpy((void *)aggregated_bvh_nodes_4.data(), tlas_4.nodes.data(), tlas_4.nodes.size() * sizeof(BVHNode4));
 		if (ctx) check(rt_upload_tlas_bvh4(ctx, tlas_4.nodes.data(), tlas_4.nodes.size()));
 		tlas.indices = tlas_4.indices;
-		leaf_order = &tlas_4.indices;
 	} else if (use_bvh8) {
 		tlas_converter->convert();
 		memcpy(aggregated_bvh_nodes_8.data(), tlas.nodes.data(), tlas.nodes.size() * sizeof(BVHNode8));
 		if (ctx) check(rt_upload_tlas(ctx, tlas.nodes.data(), tlas.nodes.size()));
-		leaf_order = &tlas.indices;
 	} else {
 		memcpy(aggregated_bvh_nodes_2.data(), tlas_raw.nodes.data(), tlas_raw.nodes.size() * sizeof(BVHNode2));
 		if (ctx) check(rt_upload_tlas_bvh2(ctx, tlas_raw.nodes.data(), tlas_raw.nodes.size()));
 		tlas.indices = tlas_raw.indices;
-		leaf_order = &tlas_raw.indices;
+	}
+	if (flat.active) { // TLAS leaf -> scene mesh (leaf 0 of the build was the flattened tree), then the members' rows
+		for (int & leaf : tlas.indices) leaf = leaf == 0 ? -1 : flat.movers[size_t(leaf) - 1];
+		tlas.indices.insert(tlas.indices.end(), flat.members.begin(), flat.members.end());
 	}
 
-	for (size_t i = 0; i < mesh_count; i++) {
-		const Mesh & mesh = scene.meshes[(*leaf_order)[i]];
+	size_t rows = tlas.indices.size();
+	mesh_bvh_root_indices.resize(rows); mesh_material_ids.resize(rows);
+	mesh_transforms.resize(rows); mesh_transforms_inv.resize(rows); mesh_transforms_prev.resize(rows);
+	for (size_t i = 0; i < rows; i++) {
+		if (tlas.indices[i] < 0) { // the flattened static geometry: world space, no material of its own (hits name the members' rows)
+			mesh_bvh_root_indices[i] = flat.root | int(0x80000000u);
+			mesh_material_ids[i] = 0;
+			Matrix4 identity;
+			memcpy(mesh_transforms[i].cells, identity.cells, sizeof(Matrix3x4)); memcpy(mesh_transforms_inv[i].cells, identity.cells, sizeof(Matrix3x4)); memcpy(mesh_transforms_prev[i].cells, identity.cells, sizeof(Matrix3x4));
+			continue;
+		}
+		const Mesh & mesh = scene.meshes[size_t(tlas.indices[i])];
 		mesh_bvh_root_indices[i] = mesh_data_bvh_offsets[mesh.mesh_data_handle.handle] | (int(mesh.has_identity_transform()) << 31);
 		mesh_material_ids[i] = mesh.material_handle.handle;
 		memcpy(mesh_transforms     [i].cells, mesh.transform     .cells, sizeof(Matrix3x4));
@@ -294,7 +385,7 @@ void Integrator::build_tlas() {
 		memcpy(mesh_transforms_prev[i].cells, mesh.transform_prev.cells, sizeof(Matrix3x4));
 	}
 	if (ctx) check(rt_upload_instances(ctx, mesh_bvh_root_indices.data(), mesh_material_ids.data(),
-		mesh_transforms[0].cells, mesh_transforms_inv[0].cells, mesh_transforms_prev[0].cells, mesh_count));
+		mesh_transforms[0].cells, mesh_transforms_inv[0].cells, mesh_transforms_prev[0].cells, rows));
 }
 
 rt_gpu_config Integrator::make_device_config() const {

@@ -84,6 +84,24 @@ struct Integrator {
 	std::vector<int>            mesh_data_triangle_offsets;
 	std::vector<int>            mesh_data_index_offsets;
 
+	// ---- flattened static geometry (cpu_config.merge_static; no counterpart in the reference) ----
+	// The instances that stand in the scene with the identity transform are copied, triangle by triangle, into ONE extra
+	// bottom-level tree. The TLAS then has one leaf for that tree plus one per remaining instance ("movers"), and the
+	// instance tables have a row per TLAS leaf (in TLAS order, as ever) FOLLOWED by a row per flattened instance in fixed
+	// order: a hit on a copy is reported by the device as (row of its instance, its original triangle), so materials,
+	// transforms, light tables, pixel queries and the SVGF ids keep naming the scene's own instances.
+	struct StaticGeometry {
+		bool built  = false;          // the merged tree and the triangle copies are part of the uploaded geometry
+		bool active = false;          // ... and the TLAS / instance tables use them (cleared for good once a member moves)
+		std::vector<int> members;     // scene mesh indices, in the order of their table rows
+		std::vector<int> movers;      // every other instance
+		int    root = 0;              // root node of the merged tree
+		AABB   aabb;
+		double build_seconds = 0.0;   // host SAH + CWBVH conversion (0 when the device built it)
+		int leaves() const { return 1 + int(movers.size()); }
+	} static_geometry;
+	std::vector<int> alias_mesh_ids, alias_triangle_ids;   // per device triangle (-1: not a copy): what rt_upload_triangle_aliases was given
+
 	std::vector<int>       mesh_bvh_root_indices;   // TLAS order; MSB = identity transform
 	std::vector<int>       mesh_material_ids;
 	std::vector<Matrix3x4> mesh_transforms, mesh_transforms_inv, mesh_transforms_prev;
@@ -93,7 +111,7 @@ struct Integrator {
 	std::vector<DeviceMedium>   media;
 
 	BVH2 tlas_raw;
-	BVH8 tlas;                                   // tlas.indices[i] = scene mesh index of TLAS leaf i
+	BVH8 tlas;                                   // tlas.indices[i] = scene mesh index of instance-table row i (TLAS leaf i; -1: the flattened static geometry)
 	BVH4 tlas_4;                                 // bvh_type = BVH4
 	std::unique_ptr<SAHBuilder>    tlas_builder;
 	std::unique_ptr<BVH8Converter> tlas_converter;

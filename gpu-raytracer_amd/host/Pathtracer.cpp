@@ -91,7 +91,9 @@ void Pathtracer::calc_light_mesh_weights() {
 	// Order of the light meshes in the CDF: TLAS order, as in the reference -- unless the TLAS is built on the device, whose
 	// order the host does not know; then scene order, with scene indices as transform indices (the device maps them)
 	double total = 0.0;
-	for (size_t i = 0; i < scene.meshes.size(); i++) {
+	size_t rows = tlas_on_device ? scene.meshes.size() : tlas.indices.size();   // the instance tables' rows
+	for (size_t i = 0; i < rows; i++) {
+		if (!tlas_on_device && tlas.indices[i] < 0) continue;   // the row of the flattened static geometry: its members have rows of their own
 		const Mesh & mesh = scene.meshes[tlas_on_device ? int(i) : tlas.indices[i]];
 		if (mesh.light.weight > 0.0f) {
 			total += double(mesh.light.weight * mesh.scale * mesh.scale);

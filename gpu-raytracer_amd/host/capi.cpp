@@ -64,6 +64,7 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "enable_scene_update")                 cpu_config.enable_scene_update = value != 0;
 	else if (k == "device_tlas")                         cpu_config.device_tlas = int(value);
 	else if (k == "device_blas")                         cpu_config.device_blas = int(value);
+	else if (k == "merge_static")                        cpu_config.merge_static = int(value);
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
 	else if (k == "initial_height")                      cpu_config.initial_height = int(value);
 	else { g_host_error = "unknown config key '" + k + "'"; return -1; }
@@ -323,6 +324,9 @@ void grt_pathtracer_get_pixel_query(void * pt, int * pixel_index, int * mesh_id,
 }
 void * grt_pathtracer_context(void * pt) { return as_integrator(pt)->ctx; }
 float  grt_pathtracer_device_blas_build_ms(void * pt) { return as_integrator(pt)->device_blas_build_ms; }
+// Flattened static geometry: instances in it (0: none, or dissolved because one of them moved), and what its tree took to build on the host
+int    grt_pathtracer_static_geometry_members(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active ? int(p->static_geometry.members.size()) : 0; }
+double grt_pathtracer_static_geometry_build_seconds(void * pt) { return as_integrator(pt)->static_geometry.build_seconds; }
 float  grt_pathtracer_lights_total_weight(void * pt) { { Pathtracer * p = dynamic_cast<Pathtracer *>(as_integrator(pt)); return p ? p->lights_total_weight : 0.0f; } }
 
 int grt_pathtracer_read_aov(void * pt, int aov, int accumulated, float * dst) {
@@ -418,6 +422,8 @@ const void * grt_pathtracer_array(void * pt, const char * name, size_t * bytes) 
 	if (n == "bvh2_nodes")            RET(p->aggregated_bvh_nodes_2)
 	if (n == "bvh4_nodes")            RET(p->aggregated_bvh_nodes_4)
 	if (n == "reverse_indices")       RET(p->reverse_indices)
+	if (n == "alias_mesh_ids")        RET(p->alias_mesh_ids)
+	if (n == "alias_triangle_ids")    RET(p->alias_triangle_ids)
 	if (n == "mesh_bvh_root_indices") RET(p->mesh_bvh_root_indices)
 	if (n == "mesh_material_ids")     RET(p->mesh_material_ids)
 	if (n == "mesh_transforms")       RET(p->mesh_transforms)

@@ -140,8 +140,9 @@ const char * rt_version(void);
  *   1  round 1
  *   2  rt_texture_desc grew `format`, `lod_width`, `lod_height` (32 -> 40 bytes; rt_upload_textures rejects unknown formats)
  *   3  RT_TIMING_* kinds of rt_get_launch_timings, rt_comm_* / rt_all_gather_* entry points (additions only)
+ *   4  rt_upload_triangle_aliases (addition only)
  * Check `rt_abi_version() == RT_ABI_VERSION` once after loading the library.                                          */
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 int rt_abi_version(void);
 
 /* ---- scene upload ------------------------------------------------------------------- */
@@ -152,6 +153,16 @@ int rt_abi_version(void);
  * (BVH/BVH.h:61-80); slots [0, 2*mesh_count) are reserved for the TLAS.                 */
 int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle_count,
                        const void * bvh8_nodes, size_t node_count);
+/* Static geometry flattened into ONE bottom-level tree (no counterpart in the reference, which traverses one BLAS per mesh
+ * under the TLAS whether the meshes move or not -- Integrator.cpp:101-283,399-430): the caller adds COPIES of the triangles
+ * of its static instances to the triangle array, builds (or lets rt_build_geometry build) one more CWBVH over the copies and
+ * gives that tree one TLAS leaf. mesh_ids / triangle_ids have one entry per triangle of the uploaded array: mesh_ids[i] < 0
+ * for an ordinary triangle; for a copy, a closest hit on it is reported as instance mesh_ids[i] (a row of the
+ * rt_upload_instances tables, which may lie behind the rows the TLAS references) and triangle triangle_ids[i] (an ordinary
+ * triangle of the array), so that everything behind traversal -- materials, transforms, light tables, the SVGF ids -- sees
+ * the instances the scene names. Call after rt_upload_geometry / rt_build_geometry, which forget the aliases; NULL arrays
+ * clear them. CWBVH traversal only.                                                                                  */
+int rt_upload_triangle_aliases(rt_context * ctx, const int32_t * mesh_ids, const int32_t * triangle_ids);
 /* Replaces the per-frame TLAS memcpy into the front of `bvh8_nodes` (Integrator.cpp:404-409). The
  * TLAS, the instance tables (rt_upload_instances) and the light tables (rt_upload_lights) are
  * versioned on the device: the call copies the host data into pinned staging and returns (the

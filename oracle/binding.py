@@ -58,6 +58,7 @@ class OracleScene(Structure):
         ("camera", Camera), ("config", GPUConfig),
         ("view_projection", c_float * 16), ("view_projection_prev", c_float * 16),
         ("screen_width", c_int32), ("screen_height", c_int32), ("screen_pitch", c_int32),
+        ("alias_mesh_ids", c_void_p), ("alias_triangle_ids", c_void_p),
     ]
 
 
@@ -215,6 +216,8 @@ class ReferenceFrame:
     see oracle/ref/ref_cuda_harness.cpp) rendering the scene of a SceneView: same protocol as Frame."""
 
     def __init__(self, view):
+        if view.scene.alias_mesh_ids:
+            raise ValueError("the reference's kernels know nothing of flattened static geometry: build this scene with merge_static = 0")
         r = ref_lib()
         if r is None or not hasattr(r, "ref_cuda_frame_create"):
             raise RuntimeError("oracle/_ref was built without the CUDA-on-CPU harness")
@@ -304,6 +307,8 @@ class ReferenceAOFrame:
     """The reference's ambient-occlusion kernels (Src/CUDA/AO.cu, verbatim, on the host CPU) rendering a SceneView."""
 
     def __init__(self, view):
+        if view.scene.alias_mesh_ids:
+            raise ValueError("the reference's kernels know nothing of flattened static geometry: build this scene with merge_static = 0")
         if ref_ao_lib() is None:
             raise RuntimeError("oracle/_ref/libref_ao.so has not been built")
         self.view = view
@@ -512,6 +517,7 @@ class SceneView:
         s.mesh_bvh_root_indices = arr("mesh_bvh_root_indices"); s.mesh_material_ids = arr("mesh_material_ids")
         s.mesh_transforms = arr("mesh_transforms"); s.mesh_transforms_inv = arr("mesh_transforms_inv"); s.mesh_transforms_prev = arr("mesh_transforms_prev")
         s.mesh_count = self.keep["mesh_material_ids"].size
+        s.alias_mesh_ids = arr("alias_mesh_ids"); s.alias_triangle_ids = arr("alias_triangle_ids")   # flattened static geometry, if any
         s.material_types = arr("material_types"); s.materials = arr("materials"); s.material_count = self.keep["material_types"].size
         s.media = arr("media"); s.medium_count = self.keep["media"].size // 8
 

@@ -96,6 +96,11 @@ typedef struct oracle_scene {
 	float           view_projection[16], view_projection_prev[16]; /* SVGF */
 
 	int32_t screen_width, screen_height, screen_pitch;
+
+	/* Flattened static geometry (rt_upload_triangle_aliases): one entry per triangle, or NULL. alias_mesh_ids[i] >= 0: triangle
+	 * i is a copy, a closest hit on it is reported as instance alias_mesh_ids[i], triangle alias_triangle_ids[i].             */
+	const int32_t * alias_mesh_ids;
+	const int32_t * alias_triangle_ids;
 } oracle_scene;
 
 /* Per-ray work counters: define the ALGORITHMIC bytes of a trace:

@@ -459,6 +459,10 @@ void oracle_trace_one(const oracle_scene & s, float3 origin, float3 direction, u
 	RayHit hit; hit.t = INFINITY; hit.u = 0.0f; hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
 	Counters c;
 	if (s.bvh_type == 2) bvh2_traverse<false>(s, ray, 0.0f, hit, c); else if (s.bvh_type == 4) bvh4_traverse<false>(s, ray, 0.0f, hit, c); else bvh8_traverse<false>(s, ray, 0.0f, hit, c);
+	if (s.alias_mesh_ids && hit.triangle_id != RT_INVALID && s.alias_mesh_ids[hit.triangle_id] >= 0) { // a copy in the flattened static BLAS names its original
+		int copy = hit.triangle_id;
+		hit.mesh_id = s.alias_mesh_ids[copy]; hit.triangle_id = s.alias_triangle_ids[copy];
+	}
 	store_hit(hit4, hit);
 	if (stats) { stats->nodes += c.nodes; stats->triangles += c.triangles; stats->instances_transformed += c.inst_xform; stats->instances_identity += c.inst_ident; stats->rays++; }
 }

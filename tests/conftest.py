@@ -11,6 +11,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with `pytest -m gpu`)")
+    config.addinivalue_line("markers", "reference_layout: the scene is staged exactly as the reference stages it -- one BLAS per mesh under the TLAS "
+                                       "(config merge_static = 0) -- because the test feeds the reference's own kernels, a golden vector they produced, or asserts that layout")
 
 
 @pytest.fixture(scope="session")
@@ -21,6 +23,22 @@ def grt():
     if not (os.path.exists(g.DEVICE_LIB_PATH) and os.path.exists(g.HOST_LIB_PATH) and os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so"))):
         entry.build()
     return g
+
+
+@pytest.fixture(autouse=True)
+def _reference_layout(request, grt, monkeypatch):
+    """Tests marked `reference_layout`: every config_reset() of the test leaves merge_static = 0 (the default, 1, flattens the
+    static instances into one extra tree, which the reference's kernels and golden vectors know nothing of)."""
+    if request.node.get_closest_marker("reference_layout"):
+        plain_reset = grt.config_reset
+
+        def reset():
+            plain_reset(); grt.config_set(merge_static=0)
+        monkeypatch.setattr(grt, "config_reset", reset)
+        reset()
+    yield
+    if request.node.get_closest_marker("reference_layout"):
+        monkeypatch.undo(); grt.config_reset()
 
 
 @pytest.fixture(scope="session")

@@ -29,6 +29,7 @@ def secondary_rays(view, o, d, hits, seed):
     return org[:, ok], dirs[:, ok]
 
 
+@pytest.mark.reference_layout
 def test_gpu_frames_equal_the_references_own_kernels(grt, oracle):
     """Closes the loop without the restated oracle in between: the HIP kernels on the MI355X against the reference's
     Pathtracer.cu executed on the CPU (oracle/ref/ref_cuda_harness.cpp, prebuilt into oracle/_ref) on the same

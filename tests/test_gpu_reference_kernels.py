@@ -64,6 +64,7 @@ def render_and_compare(grt, oracle, pt, w, frames, rel_tol, outlier_tol, luts=No
     return totals
 
 
+@pytest.mark.reference_layout
 @pytest.mark.parametrize("plastic", [False, True], ids=["diffuse", "odd-materials-plastic"])
 def test_sponza_frames_equal_the_references_kernels(grt, oracle, plastic):
     """384 instances through the TLAS, 19 mip-mapped BC1 textures (ray-cone LOD, anisotropic lookups at bounce 0), NEE +
@@ -82,6 +83,7 @@ def test_sponza_frames_equal_the_references_kernels(grt, oracle, plastic):
     pt.close(); scene.close(); grt.config_reset()
 
 
+@pytest.mark.reference_layout
 def test_glass_medium_and_conductor_frames_equal_the_references_kernels(grt, oracle, tmp_path):
     """Rough dielectric holding a scattering medium, a smooth dielectric, a rough conductor (BSDF.h:192-525, the medium
     branch of kernel_sort, Kulla-Conty energy compensation). The reference's kernels read the tables the DEVICE integrated
@@ -101,6 +103,7 @@ def test_glass_medium_and_conductor_frames_equal_the_references_kernels(grt, ora
     pt.close(); scene.close(); grt.config_reset()
 
 
+@pytest.mark.reference_layout
 def test_scene_with_everything_equals_the_references_kernels(grt, oracle, tmp_path):
     """A textured rough-plastic floor with uv repeat, two emitters of different power (one a rotated, scaled file mesh:
     light_mesh_transform_indices), a rough dielectric with a back-scattering medium inside, a named conductor, a dim sky."""
@@ -117,6 +120,7 @@ def test_scene_with_everything_equals_the_references_kernels(grt, oracle, tmp_pa
     pt.close(); scene.close(); grt.config_reset()
 
 
+@pytest.mark.reference_layout
 def test_thin_lens_camera_hdr_sky_and_instances_on_the_device(grt, oracle, tmp_path):
     """kernel_generate with a thin-lens camera (aperture samples, focal plane), sample_sky on an HDR environment map at
     every miss, instanced file meshes with rotation + uniform scale: the device's primary rays against the oracle's

@@ -7,6 +7,7 @@ import pytest
 from conftest import make_pathtracer
 
 
+@pytest.mark.reference_layout
 def test_cornell_scene_inventory(grt):
     scene, pt = make_pathtracer(grt, "cornellbox", 512, 512, -1)
     # reference Data/cornellbox/scene.xml: 5 walls + light (rectangles, 2 tris) + 2 cubes (12 tris)
@@ -25,6 +26,7 @@ def test_cornell_scene_inventory(grt):
     pt.close(); scene.close()
 
 
+@pytest.mark.reference_layout
 def test_device_layout_rules(grt):
     """reference Integrator.cpp:101-283,399-430: TLAS slots first, MSB = identity, triangles as edges."""
     scene, pt = make_pathtracer(grt, "cornellbox", 64, 64, -1)
@@ -40,6 +42,7 @@ def test_device_layout_rules(grt):
     pt.close(); scene.close()
 
 
+@pytest.mark.reference_layout
 def test_sponza_inventory(grt):
     scene, pt = make_pathtracer(grt, "sponza", 64, 64, -1)
     assert scene.mesh_count == 384 and scene.mesh_data_count == 383
@@ -76,6 +79,7 @@ def test_unsupported_scene_format_is_an_error(grt, tmp_path):
         grt.Scene(str(bad))
 
 
+@pytest.mark.reference_layout
 def test_mitsuba_materials_media_and_instances(grt, tmp_path):
     (tmp_path / "tri.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
     xml = tmp_path / "scene.xml"

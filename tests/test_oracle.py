@@ -154,6 +154,7 @@ def test_pmj_table_is_a_stratified_02_sequence(grt):
     pt.close(); scene.close()
 
 
+@pytest.mark.reference_layout
 def test_oracle_matches_committed_golden_render(grt, oracle):
     g = np.load(GOLDEN)
     scene, pt = make_pathtracer(grt, "cornellbox", 48, 48, -1, num_bounces=4)
@@ -390,6 +391,7 @@ def _reference_frame(oracle, view):
     return oracle.ReferenceFrame(view)
 
 
+@pytest.mark.reference_layout
 def test_oracle_equals_the_references_own_kernels_run_on_the_cpu(grt, oracle):
     """THE pin of the restated device path: the reference's Pathtracer.cu (every kernel and header, compiled
     verbatim for the host through oracle/ref/cuda_shim and executed one CUDA thread at a time by
@@ -443,6 +445,7 @@ def _compare_with_reference_kernels(oracle, pt, w, samples, rel_tol, outlier_tol
     return totals
 
 
+@pytest.mark.reference_layout
 def test_reference_kernels_on_sponza_textures_instances_and_plastic(grt, oracle):
     """Same pin on Sponza: 384 instances through the TLAS, 19 mip-mapped textures (ray-cone LOD, anisotropic
     bounce-0 lookups -- both sides filter with the software texture unit, the reference's NVIDIA unit being the one
@@ -464,6 +467,7 @@ def test_reference_kernels_on_sponza_textures_instances_and_plastic(grt, oracle)
     pt.close(); scene.close(); grt.config_reset()
 
 
+@pytest.mark.reference_layout
 def test_reference_kernels_on_dielectric_conductor_and_medium(grt, oracle, tmp_path):
     """Rough dielectric with a scattering medium inside, a smooth dielectric and a rough conductor (BSDF.h:192-525,
     the medium branch of kernel_sort, Kulla-Conty energy compensation): queue sizes per material and bounce and the
@@ -487,6 +491,7 @@ def test_reference_binary_and_4_wide_kernels(grt, oracle, bvh_type):
     pt.close(); scene.close(); grt.config_reset()
 
 
+@pytest.mark.reference_layout
 @pytest.mark.parametrize("taa", [1, 0])
 def test_reference_svgf_and_taa_kernels(grt, oracle, taa):
     """SVGF (reproject, spatial variance, six a-trous iterations, finalize) and TAA of the reference (SVGF.h, TAA.h)
@@ -513,6 +518,7 @@ def test_reference_svgf_and_taa_kernels(grt, oracle, taa):
     theirs.close(); pt.close(); scene.close(); grt.config_reset()
 
 
+@pytest.mark.reference_layout
 def test_reference_kulla_conty_table_kernels(grt, oracle):
     """kernel_integrate_dielectric / _conductor (100 000 samples per cell) and the two averaging kernels of the
     reference (KullaConty.h:83-240) against oracle_luts.cpp: a spread of cells of each table, and the averages of
@@ -536,6 +542,7 @@ def test_reference_kulla_conty_table_kernels(grt, oracle):
     theirs.close(); pt.close(); scene.close()
 
 
+@pytest.mark.reference_layout
 @pytest.mark.parametrize("scene_name,w,h,radius", [("cornellbox", 64, 48, 0.5), ("sponza", 96, 54, 1.5)])
 def test_reference_ambient_occlusion_kernels(grt, oracle, scene_name, w, h, radius):
     """The reference's AO integrator (Src/CUDA/AO.cu, verbatim, run on the CPU through oracle/_ref/libref_ao.so)
@@ -573,6 +580,7 @@ def test_reference_kernels_thin_lens_hdr_sky_and_instances(grt, oracle, tmp_path
     pt.close(); scene.close(); grt.config_reset()
 
 
+@pytest.mark.reference_layout
 def test_reference_svgf_reprojection_with_a_moving_camera(grt, oracle):
     """SVGF temporal reprojection under camera motion (kernel_svgf_reproject: previous screen positions from the
     g-buffer, bilinear history taps, consistency tests, disocclusions): history lengths identical, frames within the
@@ -597,6 +605,7 @@ def test_reference_svgf_reprojection_with_a_moving_camera(grt, oracle):
     theirs.close(); pt.close(); scene.close(); grt.config_reset()
 
 
+@pytest.mark.reference_layout
 def test_oracle_matches_golden_frames_rendered_by_the_reference_kernels(grt, oracle):
     """The committed fixture tests/golden/reference_kernels_golden.npz holds frames and queue sizes produced by the
     reference's own Pathtracer.cu on the CPU (tests/golden/make_golden.py --only-reference-kernels): the oracle has to
@@ -623,6 +632,7 @@ def test_oracle_matches_golden_frames_rendered_by_the_reference_kernels(grt, ora
 
 @pytest.mark.parametrize("toggles", [{}, {"enable_multiple_importance_sampling": 0}, {"enable_next_event_estimation": 0}, {"enable_mipmapping": 0}],
                          ids=["default", "no-mis", "no-nee", "no-mipmaps"])
+@pytest.mark.reference_layout
 def test_reference_kernels_on_a_scene_with_everything(grt, oracle, tmp_path, toggles):
     """One scene through the reference's kernels and the oracle with every feature at once: a textured rough-plastic
     floor (uv repeat, mip maps), two emitters of different power of which one is a rotated, scaled file mesh

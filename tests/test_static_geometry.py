@@ -1,0 +1,162 @@
+"""Flattened static geometry (config merge_static, the default): the instances that stand in the scene with the identity
+transform are copied into ONE extra bottom-level tree with a single TLAS leaf; hits on the copies are reported as the
+scene's own instances and triangles (include/gpu_raytracer_amd.h: rt_upload_triangle_aliases). The reference has no such
+thing -- it walks one BLAS per mesh under the TLAS (Integrator.cpp:101-283, 399-430) -- so the bar is: every ray finds
+exactly what it finds in the reference's layout (merge_static = 0), which the other tests pin to the reference's own
+kernels. CPU only: the staged arrays and the oracle's walk over them; tests/test_gpu_parity.py runs the HIP kernels over
+the same arrays."""
+import numpy as np
+import pytest
+
+from conftest import unpack_hits
+from test_tlas import instanced_scene_file
+
+
+def staged(grt, scene_file, w, h, merge, **config):
+    grt.config_reset(); grt.config_set(merge_static=merge, **config)
+    scene = grt.Scene(scene_file); grt.config_set(merge_static=merge, **config)
+    pt = grt.Pathtracer(scene, w, h, device=-1); pt.update()
+    return scene, pt
+
+
+def rays_for(view, w, h, extent, count, seed):
+    rng = np.random.default_rng(seed)
+    o, d, _ = view.generate(0, 0, w * h)
+    extra_o = rng.uniform(-extent, extent, (3, count)).astype(np.float32)
+    extra_d = rng.normal(size=(3, count)).astype(np.float32); extra_d /= np.linalg.norm(extra_d, axis=0)
+    return np.concatenate([o, extra_o], axis=1), np.concatenate([d, extra_d], axis=1)
+
+
+def scene_file_of(grt, name, tmp_path):
+    if name == "instances":   # a floor and two emitters that stand still, 40 rotated / scaled instances that do not qualify
+        return instanced_scene_file(str(tmp_path / "s"), count=40)
+    return grt.scene_path(name)
+
+
+@pytest.mark.parametrize("name,w,h,extent,identity_instances", [("cornellbox", 64, 48, 3.0, 8), ("sponza", 96, 54, 14.0, 382), ("instances", 96, 64, 14.0, None)])
+def test_flattened_static_geometry_traces_like_one_blas_per_mesh(grt, oracle, tmp_path, name, w, h, extent, identity_instances):
+    scene_file = scene_file_of(grt, name, tmp_path)
+    scene_ref, pt_ref = staged(grt, scene_file, w, h, 0)
+    reference = oracle.SceneView(pt_ref)
+    o, d = rays_for(reference, w, h, extent, 6000, 5)
+    hits_ref, stats_ref = reference.trace(o, d)
+    shadow_ref = reference.trace_shadow(o, d, np.full(o.shape[1], 9.0, np.float32))[0]
+    rows_ref = pt_ref.array("tlas_indices").copy(); roots_ref = pt_ref.array("mesh_bvh_root_indices").copy()
+    triangles_ref = pt_ref.array("triangles").reshape(-1, 24).copy(); nodes_ref = pt_ref.array("bvh8_nodes").reshape(-1, 80).copy()
+    assert pt_ref.static_geometry_members == 0 and pt_ref.array("alias_mesh_ids").size == 0
+    materials_ref = np.zeros(scene_ref.mesh_count, np.int32); materials_ref[rows_ref] = pt_ref.array("mesh_material_ids")
+    mesh_count = scene_ref.mesh_count
+    pt_ref.close(); scene_ref.close()
+
+    scene, pt = staged(grt, scene_file, w, h, 1)
+    members = pt.static_geometry_members
+    identity = int((roots_ref < 0).sum())
+    assert members == identity and (identity_instances is None or members == identity_instances) and members >= 2
+    flat = oracle.SceneView(pt)
+
+    # ---- the layout ----
+    rows = pt.array("tlas_indices"); roots = pt.array("mesh_bvh_root_indices")
+    leaves = mesh_count - members + 1
+    assert rows.size == mesh_count + 1 == roots.size
+    assert (rows[:leaves] == -1).sum() == 1 and (rows[leaves:] >= 0).all()                           # one TLAS leaf for the flattened tree, then a row per member
+    assert sorted(rows[rows >= 0].tolist()) == list(range(mesh_count))                               # every scene instance has exactly one row
+    triangles = pt.array("triangles").reshape(-1, 24); nodes = pt.array("bvh8_nodes").reshape(-1, 80)
+    names_row, names_triangle = pt.array("alias_mesh_ids"), pt.array("alias_triangle_ids")            # one entry per device triangle, -1: not a copy
+    assert names_row.size == triangles.shape[0] == names_triangle.size
+    first = triangles_ref.shape[0]
+    assert (names_row[:first] == -1).all() and (names_triangle[:first] == -1).all() and (names_row[first:] >= 0).all()   # host-built trees: the copies are the tail
+    assert np.array_equal(triangles[:first].view(np.uint32), triangles_ref.view(np.uint32))          # everything the reference's layout holds is still there, untouched,
+    assert np.array_equal(nodes[2 * mesh_count:nodes_ref.shape[0]], nodes_ref[2 * mesh_count:])      # ... the per-mesh trees included
+    alias_rows, alias_triangles = names_row[first:], names_triangle[first:]
+    assert (alias_rows >= leaves).all() and (alias_rows < rows.size).all() and (alias_triangles >= 0).all() and (alias_triangles < first).all()
+    assert np.array_equal(triangles[first:].view(np.uint32), triangles[alias_triangles].view(np.uint32))   # a copy IS its original, bit for bit
+    assert np.unique(alias_triangles).size == alias_triangles.size                                   # and every original is copied once
+    flat_root = int(roots[np.flatnonzero(rows == -1)[0]] & 0x7fffffff)
+    assert flat_root == nodes_ref.shape[0] and roots[np.flatnonzero(rows == -1)[0]] < 0              # the extra tree sits behind the others; world space
+    # each copy names a row whose BLAS holds the original: walk that BLAS' triangle range
+    def blas_triangles(root, all_nodes):
+        found, todo = [], [root]
+        while todo:
+            k = todo.pop()
+            words = all_nodes[k].view(np.uint32); meta = all_nodes[k][24:32]; imask = int(words[3] >> 24)
+            inner = 0
+            for s in range(8):
+                m = int(meta[s])
+                if m == 0: continue
+                if (imask >> s) & 1: todo.append(int(words[4]) + inner); inner += 1
+                else: found += [int(words[5]) + (m & 31) + j for j in range(bin(m >> 5).count("1"))]
+        return found
+    for row in np.unique(alias_rows)[:40]:
+        own = set(blas_triangles(int(roots[row] & 0x7fffffff), nodes))
+        assert set(alias_triangles[alias_rows == row].tolist()) == own
+
+    # ---- the rays ----
+    hits, stats = flat.trace(o, d)
+    mesh_ref, tri_ref, t_ref, u_ref, v_ref = unpack_hits(hits_ref); mesh, tri, t, u, v = unpack_hits(hits)
+    hit = tri_ref != -1
+    assert hit.mean() > 0.3 and np.array_equal(hit, tri != -1)
+    assert np.array_equal(t.view(np.uint32), t_ref.view(np.uint32))                                   # the same distance, to the bit, for every ray
+    # ... to the same triangle of the same scene instance -- except where two triangles lie at exactly the closest distance
+    # (a box standing on the floor): a tie goes to whichever the walk meets first, in either layout
+    tie = hit & (tri != tri_ref)
+    assert tie.sum() <= 1e-3 * hit.sum()
+    same = hit & ~tie
+    assert np.array_equal(u[same], u_ref[same]) and np.array_equal(v[same], v_ref[same])
+    assert np.array_equal(rows[mesh[same]], rows_ref[mesh_ref[same]])
+    assert (tri[hit] < first).all() and (rows[mesh[hit]] >= 0).all()                                 # never a copy, never the flattened tree's own row
+    by_scene_mesh = np.zeros(mesh_count, np.int32); by_scene_mesh[rows[rows >= 0]] = pt.array("mesh_material_ids")[rows >= 0]
+    assert np.array_equal(by_scene_mesh, materials_ref)                                              # rows carry their instance's material
+    shadow = flat.trace_shadow(o, d, np.full(o.shape[1], 9.0, np.float32))[0]
+    assert np.array_equal(shadow, shadow_ref) and 0.05 < shadow.mean() < 0.999
+    if name == "sponza":   # what it is for: fewer nodes and no instance entries on the way to the same hits
+        assert stats.nodes < stats_ref.nodes and stats.instances_identity < 0.2 * stats_ref.instances_identity
+    pt.close(); scene.close(); grt.config_reset()
+
+
+def test_frames_do_not_depend_on_the_flattening(grt, oracle):
+    """One emitter, so the light tables hold the same single entry in both layouts: every sample draws the same random
+    numbers, meets the same triangles and materials -- the rendered frames are the same floats."""
+    frames = []
+    for merge in (0, 1):
+        scene, pt = staged(grt, grt.scene_path("cornellbox"), 40, 30, merge, num_bounces=4)
+        view = oracle.SceneView(pt); frame = oracle.Frame(view)
+        for s in range(2): frame.render_sample(s)
+        frames.append(frame.accumulator(0).copy())
+        pt.close(); scene.close()
+    assert frames[0].max() > 0.5 and np.array_equal(frames[0], frames[1])
+    grt.config_reset()
+
+
+def test_a_member_that_moves_dissolves_the_flattening(grt, oracle):
+    scene, pt = staged(grt, grt.scene_path("cornellbox"), 48, 36, 1)
+    assert pt.static_geometry_members == 8 and pt.array("tlas_indices").size == 9
+    scene.set_mesh_transform(6, (0.25, 0.0, -0.1), (0.0, 0.0, 0.0, 1.0), 1.0)
+    pt.invalidate("scene"); pt.update()
+    assert pt.static_geometry_members == 0                                        # for good: the per-mesh trees take over
+    rows = pt.array("tlas_indices").copy()
+    assert sorted(rows.tolist()) == list(range(8)) and pt.array("mesh_bvh_root_indices").size == 8
+    view = oracle.SceneView(pt)
+    o, d = rays_for(view, 48, 36, 3.0, 3000, 9)
+    hits, _ = view.trace(o, d)
+    scene.set_mesh_transform(6, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0), 1.0)       # standing still again does not bring it back
+    pt.invalidate("scene"); pt.update()
+    assert pt.static_geometry_members == 0
+    pt.close(); scene.close()
+
+    scene, pt = staged(grt, grt.scene_path("cornellbox"), 48, 36, 0)
+    scene.set_mesh_transform(6, (0.25, 0.0, -0.1), (0.0, 0.0, 0.0, 1.0), 1.0)
+    pt.invalidate("scene"); pt.update()
+    hits_ref, _ = oracle.SceneView(pt).trace(o, d)
+    rows_ref = pt.array("tlas_indices").copy()
+    hit = hits_ref[:, 1] != 0xffffffff
+    assert np.array_equal(hits[:, 1:], hits_ref[:, 1:]) and np.array_equal(rows[hits[hit, 0].astype(np.int64)], rows_ref[hits_ref[hit, 0].astype(np.int64)])
+    pt.close(); scene.close(); grt.config_reset()
+
+
+def test_the_flattening_is_left_alone_where_it_does_not_apply(grt, tmp_path):
+    for config in ({"bvh_type": 2}, {"bvh_type": 4}, {"device_tlas": 1}):          # CWBVH with a host-built TLAS only (device_tlas needs a device: no-op on the host)
+        scene, pt = staged(grt, grt.scene_path("cornellbox"), 16, 16, 1, **config)
+        if "bvh_type" in config:
+            assert pt.static_geometry_members == 0 and pt.array("alias_mesh_ids").size == 0 and pt.array("tlas_indices").size == 8
+        pt.close(); scene.close()
+    grt.config_reset()

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Experiment input for wave_sim: ALL triangles of the scene's identity instances in ONE bottom-level tree (host SAH builder +
+CWBVH converter over the concatenated triangles), no top-level tree. Header field tlas_count = 0 tells wave_sim to start in the BLAS."""
+import ctypes, os, struct, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import gpu_raytracer_amd as grt
+
+name = sys.argv[1] if len(sys.argv) > 1 else "sponza"
+out = sys.argv[2] if len(sys.argv) > 2 else "/tmp/wave_sim_%s_merged.bin" % name
+w, h = 1920, 1080
+grt.config_reset()
+scene = grt.Scene(grt.scene_path(name)); scene.wait_until_loaded()
+pt = grt.Pathtracer(scene, w, h, device=-1); pt.update()
+tris = np.concatenate([scene.mesh_data_array(m, "triangles", np.float32).reshape(-1, 24) for m in range(scene.mesh_data_count)])
+lib = grt.host_lib()
+import time; t0 = time.time()
+handle = lib.grt_build_blas(np.ascontiguousarray(tris).ctypes.data, tris.shape[0])
+print("SAH + CWBVH over %d triangles: %.2f s" % (tris.shape[0], time.time() - t0))
+def arr(n, dtype):
+    size = ctypes.c_size_t(0); p = lib.grt_built_array(handle, n.encode(), ctypes.byref(size))
+    return np.frombuffer((ctypes.c_char * size.value).from_address(p), dtype=dtype).copy()
+nodes = arr("bvh8_nodes", np.uint8).reshape(-1, 80); idx = arr("bvh8_indices", np.int32)
+t = tris[idx]
+pos = np.concatenate([t[:, 0:3], t[:, 3:6] - t[:, 0:3], t[:, 6:9] - t[:, 0:3]], axis=1).astype(np.float32)   # p0, e1, e2 (host Triangle: positions first)
+cam = np.frombuffer(bytes(pt.array("camera")), dtype=np.float32)[:15].copy()
+with open(out, "wb") as f:
+    f.write(struct.pack("6i", nodes.shape[0], pos.shape[0], 1, 0, w, h))
+    f.write(nodes.tobytes()); f.write(pos.tobytes()); f.write(np.array([0x80000000 - (1 << 32)], np.int32).tobytes() if False else np.array([-2147483648], np.int32).tobytes()); f.write(np.zeros(12, np.float32).tobytes()); f.write(cam.tobytes())
+print("wrote %s: %d nodes, %d triangles" % (out, nodes.shape[0], pos.shape[0]))

@@ -119,7 +119,7 @@ static void run_wave(const Scene & s, const std::vector<Ray> & rays, bool shadow
 		if (want) {
 			for (auto & l : L) if (!l.has_ray && !drained) { long i = fetch(); if (i < 0) break; got++;
 				l.has_ray = true; l.ray_index = int(i); l.shadow = shadow_rays; l.world = rays[i]; l.ray = l.world; l.max_distance = shadow_rays ? l.world.tmax : INFINITY;
-				l.inv = mk3(1.0f / l.ray.d.x, 1.0f / l.ray.d.y, 1.0f / l.ray.d.z); l.oct = octant_inv4(l.ray.d); l.cg_x = 0; l.cg_y = 0x80000000u; l.tg_x = l.tg_y = 0; l.hit = Hit(); l.tlas_stack = -1; l.stack.clear(); }
+				l.inv = mk3(1.0f / l.ray.d.x, 1.0f / l.ray.d.y, 1.0f / l.ray.d.z); l.oct = octant_inv4(l.ray.d); l.cg_x = 0; l.cg_y = 0x80000000u; l.tg_x = l.tg_y = 0; l.hit = Hit(); l.tlas_stack = s.tlas_count == 0 ? -2 : -1; /* no top level: the ray starts inside the one bottom-level tree */ l.stack.clear(); }
 			st.refills++; st.refill_lanes += got; st.instr += c.refill; st.useful += c.refill * got / 64.0;
 		}
 		int alive = 0; for (auto & l : L) if (l.has_ray) alive++;
