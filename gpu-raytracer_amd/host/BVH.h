@@ -200,6 +200,12 @@ struct SBVHBuilder {
 	void build(const std::vector<Triangle> & triangles);
 };
 
+// The binary tree behind the flattened static geometry (StaticBVHBuilder.cpp): binned SAH object + spatial splits, built by all
+// host threads; one triangle reference per leaf, a triangle cut by spatial splits is listed once per leaf that holds a part.
+namespace StaticBVHBuilder {
+	void build(BVH2 & bvh, const std::vector<Triangle> & triangles, int thread_count = 0);
+}
+
 namespace BVHOptimizer {
 	void optimize(BVH2 & bvh); // BVHOptimizer.cpp: insertion-based optimisation (Bittner et al. 2013), cpu_config.enable_bvh_optimization
 }

@@ -66,10 +66,11 @@ struct CPUConfig {
 	// to the reference's), 1 = on the device (rt_build_geometry: a linear BVH over all meshes at once; fast to build, dearer to traverse)
 	int  device_blas = 0;
 	// Static geometry: 1 = the instances that stand in the scene with the identity transform (two or more of them) are flattened
-	// into ONE bottom-level tree that takes a single TLAS leaf -- a ray then walks one well-built tree instead of entering a
-	// dozen overlapping per-mesh trees; hits still name the scene's instances and triangles (rt_upload_triangle_aliases).
-	// CWBVH with the TLAS built on the host only; an instance that starts to move dissolves the flattening. 0 = one BLAS per
-	// mesh under the TLAS, exactly the reference's structure (Integrator.cpp:101-283).
+	// into ONE bottom-level tree that takes a single TLAS leaf -- a ray then walks one well-built tree (StaticBVHBuilder: SAH
+	// object and spatial splits) instead of entering a dozen overlapping per-mesh trees; hits still name the scene's instances
+	// and triangles (rt_upload_triangle_aliases). CWBVH with the TLAS built on the host only; an instance that starts to move
+	// dissolves the flattening. 2 = the same with the per-mesh SAH builder (no spatial splits). 0 = one BLAS per mesh under
+	// the TLAS, exactly the reference's structure (Integrator.cpp:101-283).
 	int  merge_static = 1;
 
 	IntegratorType integrator = IntegratorType::PATHTRACER; // read by the command-line front end

@@ -182,13 +182,14 @@ void Integrator::init_geometry() {
 					if (!build_on_device) world.push_back(mesh_datas[handle].triangles[t]);
 				}
 			}
-			size_t copies = source_member.size();
 			if (build_on_device) {
-				copy_source.resize(copies);
-				for (size_t c = 0; c < copies; c++) copy_source[c] = int(c);
+				copy_source.resize(source_member.size());
+				for (size_t c = 0; c < copy_source.size(); c++) copy_source[c] = int(c);
 			} else {
 				auto started = std::chrono::steady_clock::now();
-				BVH2 binary = BVH::create_sah_from_triangles(world);
+				BVH2 binary;
+				if (cpu_config.merge_static == 2) binary = BVH::create_sah_from_triangles(world);   // the per-mesh builder, for comparison
+				else                              StaticBVHBuilder::build(binary, world);           // spatial splits, all host threads
 				BVH8 wide;
 				BVH8Converter(wide, binary).convert();
 				flat.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
@@ -202,6 +203,7 @@ void Integrator::init_geometry() {
 					dst.base_index_child    += unsigned(node_total);
 				}
 			}
+			size_t copies = copy_source.size();   // more than the members have triangles where spatial splits cut some of them
 			aggregated_triangles.resize(index_total + copies);
 			alias_mesh_ids.assign(index_total + copies, -1); alias_triangle_ids.assign(index_total + copies, -1);
 			for (size_t c = 0; c < copies; c++) {

@@ -604,6 +604,21 @@ void * grt_build_blas(const float * tris24, int n) {
 		return md;
 	GRT_CATCH(nullptr)
 }
+// Experiments with the builder behind a CWBVH: spatial splits (SBVH: a triangle may sit in several leaves, `bvh8_indices` then
+// repeats it) and / or the insertion optimiser, then the same 8-wide collapse.
+void * grt_build_blas_variant(const float * tris24, int n, int spatial_splits, int optimize) {
+	GRT_TRY
+		MeshData * md = new MeshData();
+		md->triangles.resize(n);
+		memcpy((void *)md->triangles.data(), tris24, size_t(n) * sizeof(Triangle));
+		if (spatial_splits == 2) StaticBVHBuilder::build(md->bvh2, md->triangles);
+		else if (spatial_splits) SBVHBuilder(md->bvh2, md->triangles.size()).build(md->triangles);
+		else                SAHBuilder (md->bvh2, md->triangles.size()).build(md->triangles);
+		if (optimize) BVHOptimizer::optimize(md->bvh2);
+		BVH8Converter(md->bvh8, md->bvh2).convert();
+		return md;
+	GRT_CATCH(nullptr)
+}
 // The binary tree of cpu_config.bvh_type (SAH or SBVH), optionally leaf-collapsed as for a
 // file-loaded mesh, and its 4-wide form: query with "device_bvh2_nodes" / "device_bvh2_indices" /
 // "device_bvh4_nodes".

@@ -9,6 +9,7 @@ import gpu_raytracer_amd as grt
 
 name = sys.argv[1] if len(sys.argv) > 1 else "sponza"
 out = sys.argv[2] if len(sys.argv) > 2 else "/tmp/wave_sim_%s_merged.bin" % name
+sbvh = int(sys.argv[3]) if len(sys.argv) > 3 else 0; optimize = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 w, h = 1920, 1080
 grt.config_reset()
 scene = grt.Scene(grt.scene_path(name)); scene.wait_until_loaded()
@@ -16,7 +17,8 @@ pt = grt.Pathtracer(scene, w, h, device=-1); pt.update()
 tris = np.concatenate([scene.mesh_data_array(m, "triangles", np.float32).reshape(-1, 24) for m in range(scene.mesh_data_count)])
 lib = grt.host_lib()
 import time; t0 = time.time()
-handle = lib.grt_build_blas(np.ascontiguousarray(tris).ctypes.data, tris.shape[0])
+lib.grt_build_blas_variant.restype = ctypes.c_void_p; lib.grt_build_blas_variant.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+handle = lib.grt_build_blas_variant(np.ascontiguousarray(tris).ctypes.data, tris.shape[0], sbvh, optimize)
 print("SAH + CWBVH over %d triangles: %.2f s" % (tris.shape[0], time.time() - t0))
 def arr(n, dtype):
     size = ctypes.c_size_t(0); p = lib.grt_built_array(handle, n.encode(), ctypes.byref(size))
