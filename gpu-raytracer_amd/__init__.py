@@ -155,6 +155,8 @@ def host_lib():
         lib.grt_pathtracer_device_blas_build_ms.argtypes = [c_void_p]
         lib.grt_pathtracer_static_geometry_members.restype = c_int
         lib.grt_pathtracer_static_geometry_members.argtypes = [c_void_p]
+        lib.grt_pathtracer_static_geometry_whole_scene.restype = c_int
+        lib.grt_pathtracer_static_geometry_whole_scene.argtypes = [c_void_p]
         lib.grt_pathtracer_static_geometry_build_seconds.restype = ctypes.c_double
         lib.grt_pathtracer_static_geometry_build_seconds.argtypes = [c_void_p]
         lib.grt_pathtracer_lights_total_weight.restype = c_float
@@ -472,6 +474,11 @@ class Pathtracer:
     def static_geometry_members(self):
         """config merge_static = 1: instances flattened into the one static bottom-level tree (0: none, or dissolved)."""
         return int(host_lib().grt_pathtracer_static_geometry_members(self.handle))
+
+    @property
+    def static_geometry_whole_scene(self):
+        """Every instance is in the flattened tree: there is no TLAS, rays start inside the tree (rt_set_static_geometry)."""
+        return bool(host_lib().grt_pathtracer_static_geometry_whole_scene(self.handle))
 
     @property
     def static_geometry_build_seconds(self):

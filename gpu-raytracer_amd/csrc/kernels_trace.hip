@@ -474,9 +474,14 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			inv_dir  = reciprocal(ray.direction);
 			oct_inv4 = ray_get_octant_inv4(ray.direction);
 
-			current_group = make_uint2(0, 0x80000000u);
 			hit.t = RT_INFINITY; hit.u = 0.0f; hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
-			tlas_stack_size = RT_INVALID;
+			// A ray starts at node 0. That is the TLAS root -- or, when the whole scene is one flattened tree (rt_set_static_geometry),
+			// that tree's root, and the ray is INSIDE an instance from the start (row 0, identity: the values mesh_id and
+			// mesh_has_identity_transform hold until an instance is entered, which then never happens): no step on a TLAS root and no
+			// instance entry, which were one of a ray's ~13 node steps and part of a round. (One uniform value instead of a
+			// constant; anything more here -- a push, a root index from the parameters -- cost 16 B of scratch in the loop.)
+			current_group   = make_uint2(0, 0x80000000u);
+			tlas_stack_size = p.entry_tlas_stack_size;
 		}
 
 		int iterations_lost = 0;

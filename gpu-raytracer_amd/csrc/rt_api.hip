@@ -432,6 +432,7 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 	rt_context * ctx = new rt_context();
 	ctx->device = device_ordinal;
 	memset(&ctx->params, 0, sizeof(ctx->params));
+	ctx->params.entry_tlas_stack_size = RT_INVALID;
 	memset(&ctx->last_counters, 0, sizeof(ctx->last_counters));
 	RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
 	RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
@@ -498,7 +499,7 @@ static int upload_triangle_positions(rt_context * ctx, const void * triangles, s
 	for (size_t t = 0; t < triangle_count; t++) memcpy(&positions[t * 12], src + t * 24, 36);
 	int s = upload(ctx, &ctx->triangle_positions, positions.data(), triangle_count * 48); if (s) return s;
 	ctx->params.triangle_positions = (const float4 *)ctx->triangle_positions;
-	ctx->params.has_triangle_aliases = 0;
+	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID;
 	return RT_OK;
 }
 
@@ -553,6 +554,20 @@ int rt_upload_triangle_aliases(rt_context * ctx, const int32_t * mesh_ids, const
 	device_free(ctx, device_names);
 	if (e != hipSuccess) return fail(ctx, RT_ERROR_HIP, "rt_upload_triangle_aliases: %s", hipGetErrorString(e));
 	ctx->params.has_triangle_aliases = any ? 1 : 0;
+	return RT_OK;
+}
+
+// Where rays start: 0 = at the TLAS root in node slot 0; 1 = the whole scene is ONE world-space bottom-level tree whose root node
+// the caller has put into node slot 0 (through rt_upload_tlas), rays are inside it from the start, as instance row 0. A change
+// drains the context first: samples in flight were submitted against the old entry.
+int rt_set_static_geometry(rt_context * ctx, int32_t whole_scene) {
+	RT_REQUIRE(ctx, ctx != nullptr, "rt_set_static_geometry: NULL context");
+	int entry = whole_scene ? 0 : RT_INVALID;
+	if (ctx->params.entry_tlas_stack_size == entry) return RT_OK;
+	RT_REQUIRE(ctx, !whole_scene || ctx->bvh8_nodes, "rt_set_static_geometry: CWBVH geometry only");
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	ctx->params.entry_tlas_stack_size = entry;
 	return RT_OK;
 }
 
@@ -632,7 +647,7 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	ctx->triangle_count = T; ctx->bvh8_node_count = size_t(node_count);
 	ctx->tlas_version_in_nodes = ~0ull;
 	ctx->params.triangles = (const float4 *)out_triangles; ctx->params.triangle_positions = (const float4 *)out_positions; ctx->params.bvh8_nodes = (const float4 *)out_nodes;
-	ctx->params.has_triangle_aliases = 0;
+	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID;
 	if (out_root_indices) for (size_t m = 0; m < M; m++) out_root_indices[m] = int32_t(reserved_tlas_nodes + m);
 	if (out_node_count) *out_node_count = size_t(node_count);
 	if (out_build_ms) *out_build_ms = ms;

@@ -113,6 +113,8 @@ struct RtParams {
 	int bvh_width;              // 8: CWBVH kernels (default), 4: 4-wide BVH kernels, 2: binary-BVH kernels
 	const int    * mesh_bvh_root_indices;
 	int mesh_count;                   // instances (the fused traversal launch keeps the root table of a small scene in LDS)
+	int entry_tlas_stack_size;        // RT_INVALID: rays start at the TLAS root; 0: node 0 is the root of the one world-space tree that holds the
+	                                  // whole scene and rays start inside it, as instance row 0 (rt_set_static_geometry)
 	int has_triangle_aliases;         // some triangles are copies that report the (instance, triangle) named in the padding of their
 	                                  // position record instead of themselves (rt_upload_triangle_aliases)
 	const int    * mesh_material_ids;

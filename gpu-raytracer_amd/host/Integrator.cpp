@@ -169,17 +169,33 @@ void Integrator::init_geometry() {
 		std::vector<int> source_member, source_triangle;   // per triangle of the members, in member order: its member, its index among all original triangles
 		std::vector<int> copy_source;                      // per copy, in device order: which of those it copies
 		if (cpu_config.merge_static > 0 && !wants_device_tlas()) {
-			for (size_t i = 0; i < mesh_count; i++) (scene.meshes[i].has_identity_transform() ? flat.members : flat.movers).push_back(int(i));
+			// every instance that has not been seen moving; merge_static 3: only those with the identity transform, whose copies
+			// are the original triangles bit for bit (a transformed instance's copies are its triangles taken to world space)
+			instance_has_moved.resize(mesh_count, 0);
+			for (size_t i = 0; i < mesh_count; i++) {
+				bool joins = !instance_has_moved[i] && (cpu_config.merge_static != 3 || scene.meshes[i].has_identity_transform());
+				(joins ? flat.members : flat.movers).push_back(int(i));
+			}
 			if (flat.members.size() < 2) { flat.members.clear(); flat.movers.clear(); }
 		}
+		std::vector<Triangle> world;   // the members' triangles in world space, in member order
 		if (!flat.members.empty()) {
-			std::vector<Triangle> world;
+			flat.member_poses.resize(flat.members.size());
 			for (size_t j = 0; j < flat.members.size(); j++) {
 				const Mesh & mesh = scene.meshes[flat.members[j]];
 				int handle = mesh.mesh_data_handle.handle;
+				flat.member_poses[j] = { mesh.position, mesh.rotation, mesh.scale };
+				bool identity = mesh.has_identity_transform();
+				Matrix4 to_world = Matrix4::create_translation(mesh.position) * Matrix4::create_rotation(mesh.rotation) * Matrix4::create_scale(mesh.scale);   // as Mesh::update
 				for (size_t t = 0; t < mesh_datas[handle].triangles.size(); t++) {
 					source_member.push_back(int(j)); source_triangle.push_back(mesh_data_triangle_offsets[handle] + int(t));
-					if (!build_on_device) world.push_back(mesh_datas[handle].triangles[t]);
+					Triangle triangle = mesh_datas[handle].triangles[t];
+					if (!identity) {
+						triangle.position_0 = Matrix4::transform_position(to_world, triangle.position_0);
+						triangle.position_1 = Matrix4::transform_position(to_world, triangle.position_1);
+						triangle.position_2 = Matrix4::transform_position(to_world, triangle.position_2);
+					}
+					world.push_back(triangle);
 				}
 			}
 			if (build_on_device) {
@@ -208,7 +224,12 @@ void Integrator::init_geometry() {
 			alias_mesh_ids.assign(index_total + copies, -1); alias_triangle_ids.assign(index_total + copies, -1);
 			for (size_t c = 0; c < copies; c++) {
 				int original = reverse_indices[source_triangle[copy_source[c]]];
-				aggregated_triangles[index_total + c] = aggregated_triangles[original];
+				const Triangle & placed = world[size_t(copy_source[c])];
+				DeviceTriangle & copy = aggregated_triangles[index_total + c];
+				copy = aggregated_triangles[original];               // only the positions of a copy are ever read (traversal); the rest rides along
+				copy.position_0      = placed.position_0;            // (identity instances: the original's bits)
+				copy.position_edge_1 = placed.position_1 - placed.position_0;
+				copy.position_edge_2 = placed.position_2 - placed.position_0;
 				alias_mesh_ids     [index_total + c] = flat.leaves() + source_member[copy_source[c]];   // its member's row behind the TLAS leaves' rows
 				alias_triangle_ids [index_total + c] = original;
 			}
@@ -329,21 +350,26 @@ void Integrator::build_tlas() {
 	}
 	tlas_on_device = false;
 	StaticGeometry & flat = static_geometry;
-	if (flat.active) { // the flattened instances have to stand still
-		bool still = cpu_config.bvh_type == BVHType::BVH8;
-		for (int member : flat.members) still = still && scene.meshes[member].has_identity_transform();
-		if (!still) { // back to one BLAS per instance, for good: the per-mesh trees never left the device
-			flat.active = false;
-			tlas_builder = std::make_unique<SAHBuilder>(tlas_raw, mesh_count);
+	if (flat.active) { // the flattened instances have to stand where they stood when they were flattened
+		bool moved = cpu_config.bvh_type != BVHType::BVH8;
+		for (size_t j = 0; j < flat.members.size(); j++) {
+			const Mesh & mesh = scene.meshes[size_t(flat.members[j])];
+			const StaticGeometry::Pose & pose = flat.member_poses[j];
+			if (memcmp(&mesh.position, &pose.position, sizeof(Vector3)) || memcmp(&mesh.rotation, &pose.rotation, sizeof(Quaternion)) || mesh.scale != pose.scale) {
+				instance_has_moved[size_t(flat.members[j])] = 1;   // for good: it gets a TLAS leaf of its own from now on
+				moved = true;
+			}
 		}
+		if (moved) init_geometry();   // flatten what still stands still (a one-off stall of a build + upload, per instance that starts to move)
 	}
-	if (flat.active) {
+	bool whole_scene = flat.active && flat.movers.empty();   // everything is in the flattened tree: rays start inside it, there is no TLAS
+	if (flat.active) { // one TLAS leaf for the flattened tree (leaf 0 of the build), one per instance that has moved
 		std::vector<AABB> leaf_boxes(size_t(flat.leaves()));
 		flat.aabb = AABB::create_empty();   // (Mesh::update fills in the world boxes: they are not known when the geometry is set up)
 		for (int member : flat.members) flat.aabb.expand(scene.meshes[member].aabb);
 		leaf_boxes[0] = flat.aabb;
 		for (size_t k = 0; k < flat.movers.size(); k++) leaf_boxes[1 + k] = scene.meshes[flat.movers[k]].aabb;
-		tlas_builder->build(leaf_boxes);
+		if (!whole_scene) tlas_builder->build(leaf_boxes);
 	} else {
 		tlas_builder->build(scene.meshes);
 	}
@@ -355,7 +381,8 @@ void Integrator::build_tlas() {
 		if (ctx) check(rt_upload_tlas_bvh4(ctx, tlas_4.nodes.data(), tlas_4.nodes.size()));
 		tlas.indices = tlas_4.indices;
 	} else if (use_bvh8) {
-		tlas_converter->convert();
+		if (whole_scene) { tlas.indices.assign(1, 0); tlas.nodes.assign(1, aggregated_bvh_nodes_8[size_t(flat.root)]); }   // node 0 = the tree's root (its indices are absolute): rt_set_static_geometry
+		else tlas_converter->convert();
 		memcpy(aggregated_bvh_nodes_8.data(), tlas.nodes.data(), tlas.nodes.size() * sizeof(BVHNode8));
 		if (ctx) check(rt_upload_tlas(ctx, tlas.nodes.data(), tlas.nodes.size()));
 	} else {
@@ -363,7 +390,7 @@ void Integrator::build_tlas() {
 		if (ctx) check(rt_upload_tlas_bvh2(ctx, tlas_raw.nodes.data(), tlas_raw.nodes.size()));
 		tlas.indices = tlas_raw.indices;
 	}
-	if (flat.active) { // TLAS leaf -> scene mesh (leaf 0 of the build was the flattened tree), then the members' rows
+	if (flat.active) { // rows: the TLAS leaves (leaf 0 of the build was the flattened tree: no scene mesh of its own), then the members
 		for (int & leaf : tlas.indices) leaf = leaf == 0 ? -1 : flat.movers[size_t(leaf) - 1];
 		tlas.indices.insert(tlas.indices.end(), flat.members.begin(), flat.members.end());
 	}
@@ -388,6 +415,7 @@ void Integrator::build_tlas() {
 	}
 	if (ctx) check(rt_upload_instances(ctx, mesh_bvh_root_indices.data(), mesh_material_ids.data(),
 		mesh_transforms[0].cells, mesh_transforms_inv[0].cells, mesh_transforms_prev[0].cells, rows));
+	if (ctx && cpu_config.bvh_type == BVHType::BVH8) check(rt_set_static_geometry(ctx, whole_scene ? 1 : 0));
 }
 
 rt_gpu_config Integrator::make_device_config() const {

@@ -85,21 +85,25 @@ struct Integrator {
 	std::vector<int>            mesh_data_index_offsets;
 
 	// ---- flattened static geometry (cpu_config.merge_static; no counterpart in the reference) ----
-	// The instances that stand in the scene with the identity transform are copied, triangle by triangle, into ONE extra
-	// bottom-level tree. The TLAS then has one leaf for that tree plus one per remaining instance ("movers"), and the
-	// instance tables have a row per TLAS leaf (in TLAS order, as ever) FOLLOWED by a row per flattened instance in fixed
-	// order: a hit on a copy is reported by the device as (row of its instance, its original triangle), so materials,
-	// transforms, light tables, pixel queries and the SVGF ids keep naming the scene's own instances.
+	// Every instance that has not been seen moving is copied, triangle by triangle (in world space), into ONE extra
+	// bottom-level tree. The TLAS has one leaf for that tree and one per remaining instance ("movers"); when there are no
+	// movers there is no TLAS at all and rays start inside the tree (rt_set_static_geometry). The instance tables have a row
+	// per TLAS leaf (in TLAS order, as ever) followed by a row per flattened instance in fixed order: a hit on a copy is
+	// reported by the device as (row of its instance, its original triangle), so materials, transforms, light tables,
+	// pixel queries and the SVGF ids keep naming the scene's own instances.
 	struct StaticGeometry {
 		bool built  = false;          // the merged tree and the triangle copies are part of the uploaded geometry
-		bool active = false;          // ... and the TLAS / instance tables use them (cleared for good once a member moves)
+		bool active = false;          // ... and the TLAS / instance tables use them
+		struct Pose { Vector3 position; Quaternion rotation; float scale; };
 		std::vector<int> members;     // scene mesh indices, in the order of their table rows
+		std::vector<Pose> member_poses;   // where they stood when their triangles were copied
 		std::vector<int> movers;      // every other instance
 		int    root = 0;              // root node of the merged tree
 		AABB   aabb;
 		double build_seconds = 0.0;   // host SAH + CWBVH conversion (0 when the device built it)
-		int leaves() const { return 1 + int(movers.size()); }
+		int leaves() const { return 1 + int(movers.size()); }   // rows in front of the members' rows
 	} static_geometry;
+	std::vector<char> instance_has_moved;   // per scene mesh: seen with a changed transform since the scene was loaded -> never flattened again
 	std::vector<int> alias_mesh_ids, alias_triangle_ids;   // per device triangle (-1: not a copy): what rt_upload_triangle_aliases was given
 
 	std::vector<int>       mesh_bvh_root_indices;   // TLAS order; MSB = identity transform

@@ -326,6 +326,8 @@ void * grt_pathtracer_context(void * pt) { return as_integrator(pt)->ctx; }
 float  grt_pathtracer_device_blas_build_ms(void * pt) { return as_integrator(pt)->device_blas_build_ms; }
 // Flattened static geometry: instances in it (0: none, or dissolved because one of them moved), and what its tree took to build on the host
 int    grt_pathtracer_static_geometry_members(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active ? int(p->static_geometry.members.size()) : 0; }
+// 1: everything is in the flattened tree, rays start inside it (rt_set_static_geometry); 0: there is a TLAS
+int    grt_pathtracer_static_geometry_whole_scene(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active && p->static_geometry.movers.empty() ? 1 : 0; }
 double grt_pathtracer_static_geometry_build_seconds(void * pt) { return as_integrator(pt)->static_geometry.build_seconds; }
 float  grt_pathtracer_lights_total_weight(void * pt) { { Pathtracer * p = dynamic_cast<Pathtracer *>(as_integrator(pt)); return p ? p->lights_total_weight : 0.0f; } }
 

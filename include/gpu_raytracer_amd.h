@@ -140,7 +140,7 @@ const char * rt_version(void);
  *   1  round 1
  *   2  rt_texture_desc grew `format`, `lod_width`, `lod_height` (32 -> 40 bytes; rt_upload_textures rejects unknown formats)
  *   3  RT_TIMING_* kinds of rt_get_launch_timings, rt_comm_* / rt_all_gather_* entry points (additions only)
- *   4  rt_upload_triangle_aliases (addition only)
+ *   4  rt_upload_triangle_aliases, rt_set_static_geometry (additions only)
  * Check `rt_abi_version() == RT_ABI_VERSION` once after loading the library.                                          */
 #define RT_ABI_VERSION 4
 int rt_abi_version(void);
@@ -163,6 +163,13 @@ int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle
  * the instances the scene names. Call after rt_upload_geometry / rt_build_geometry, which forget the aliases; NULL arrays
  * clear them. CWBVH traversal only.                                                                                  */
 int rt_upload_triangle_aliases(rt_context * ctx, const int32_t * mesh_ids, const int32_t * triangle_ids);
+/* ... and when NOTHING is left outside that tree (no instance moves), the TLAS has nothing to decide: with whole_scene = 1 the
+ * caller uploads the ROOT NODE OF THE FLATTENED TREE as the one "TLAS" node (rt_upload_tlas, node slot 0; its child and
+ * triangle indices are absolute, so the copy works from there) and row 0 of rt_upload_instances describes the tree (identity
+ * transform); every ray then starts INSIDE the tree -- one node step and one instance entry less per ray. whole_scene = 0
+ * (the state after every geometry upload): node 0 is a TLAS root, as in the reference (BVH8.h:161-165), and a flattened tree
+ * is one of its leaves. Drains the context when the value changes. CWBVH traversal only.                              */
+int rt_set_static_geometry(rt_context * ctx, int32_t whole_scene);
 /* Replaces the per-frame TLAS memcpy into the front of `bvh8_nodes` (Integrator.cpp:404-409). The
  * TLAS, the instance tables (rt_upload_instances) and the light tables (rt_upload_lights) are
  * versioned on the device: the call copies the host data into pinned staging and returns (the

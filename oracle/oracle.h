@@ -101,6 +101,9 @@ typedef struct oracle_scene {
 	 * i is a copy, a closest hit on it is reported as instance alias_mesh_ids[i], triangle alias_triangle_ids[i].             */
 	const int32_t * alias_mesh_ids;
 	const int32_t * alias_triangle_ids;
+	/* rt_set_static_geometry: node 0 is not a TLAS root but the root of ONE world-space tree that holds the whole scene;
+	 * rays start inside it, as instance row 0. */
+	int32_t static_whole_scene;
 } oracle_scene;
 
 /* Per-ray work counters: define the ALGORITHMIC bytes of a trace:

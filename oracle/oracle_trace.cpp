@@ -192,6 +192,8 @@ inline bool bvh8_traverse(const oracle_scene & s, Ray ray, float max_distance, R
 
 	auto push = [&](Group g) { if (stack_size >= ORACLE_STACK_SIZE) { fprintf(stderr, "oracle: traversal stack overflow\n"); abort(); } stack[stack_size++] = g; };
 
+	if (s.static_whole_scene) tlas_stack_size = 0; // rt_set_static_geometry: node 0 is the root of the one world-space tree, the ray is inside it (row 0) from the start
+
 	while (true) {
 		Group triangle_group;
 

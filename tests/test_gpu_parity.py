@@ -93,6 +93,7 @@ def test_trace_edge_cases(grt, oracle):
     pt.close(); scene.close()
 
 
+@pytest.mark.reference_layout
 def test_instanced_scene_trace_is_bit_exact(grt, oracle, tmp_path):
     """TLAS/BLAS with non-identity transforms (rotation, non-unit scale): object-space rays."""
     (tmp_path / "blob.obj").write_text(blob_obj(12))

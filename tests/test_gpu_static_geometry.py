@@ -16,7 +16,7 @@ def test_flattened_sponza_on_the_device_finds_what_the_reference_layout_finds(gr
     results = {}
     for merge in (1, 0):
         scene, pt = make_pathtracer(grt, "sponza", w, h, 0, merge_static=merge)
-        assert pt.static_geometry_members == (382 if merge else 0)
+        assert pt.static_geometry_members == (384 if merge else 0)
         view = oracle.SceneView(pt)
         if merge:
             o, d = rays_for(view, w, h, 14.0, 400000, 21)
@@ -33,37 +33,56 @@ def test_flattened_sponza_on_the_device_finds_what_the_reference_layout_finds(gr
         assert np.array_equal(bounce[pick], view.trace(so[:, pick], sd[:, pick])[0])
         assert np.array_equal(hits[:200000], view.trace(o[:, :200000], d[:, :200000])[0])
         assert np.array_equal(occluded[pick].astype(bool), view.trace_shadow(so[:, pick], sd[:, pick], md[pick])[0].astype(bool))
-        results[merge] = (hits.copy(), bounce.copy(), occluded.copy(), pt.array("tlas_indices").copy(), int((pt.array("alias_mesh_ids") < 0).sum()) if merge else pt.array("triangles").size // 24)
+        results[merge] = (hits.copy(), bounce.copy(), occluded.copy(), pt.array("tlas_indices").copy(), int((pt.array("alias_mesh_ids") < 0).sum()) if merge else pt.array("triangles").size // 24, pt.array("mesh_bvh_root_indices").copy())
         pt.close(); scene.close()
+    roots_reference_layout = results[0][5]
     for which in (0, 1):
         a, b = results[1][which], results[0][which]
         mesh_a, tri_a, t_a, u_a, v_a = unpack_hits(a); mesh_b, tri_b, t_b, u_b, v_b = unpack_hits(b)
         hit = tri_b != -1
-        assert hit.mean() > 0.5 and np.array_equal(hit, tri_a != -1)
-        assert np.array_equal(t_a.view(np.uint32), t_b.view(np.uint32))                    # the same distance, to the bit, for every one of ~2.5 M rays
+        # 382 of the 384 instances stand with the identity transform: their copies are their triangles bit for bit, the hit
+        # is the same to the bit. The other two are copied in world space (the reference's layout takes the ray to object
+        # space instead): the same hit up to rounding.
+        exact = hit & (roots_reference_layout[mesh_b] < 0)
+        both = hit & (tri_a != -1)
+        far_apart = np.zeros(hit.shape, bool); far_apart[both] = np.abs(t_a[both] - t_b[both]) > 1e-5 * np.abs(t_b[both])
+        grazing = (hit != (tri_a != -1)) | (far_apart & ~exact)
+        assert hit.mean() > 0.5 and grazing.sum() <= 1e-4 * hit.sum(), int(grazing.sum())
+        assert exact.sum() > 0.95 * hit.sum() and np.array_equal(t_a.view(np.uint32)[exact], t_b.view(np.uint32)[exact])   # the same distance, to the bit, for ~2.4 M rays
+        hit = hit & ~grazing
         tie = hit & (tri_a != tri_b)                                                       # two triangles at exactly the closest distance: the walk's order decides
         assert tie.sum() <= 1e-3 * hit.sum(), int(tie.sum())
         same = hit & ~tie
-        assert np.array_equal(u_a[same], u_b[same]) and np.array_equal(v_a[same], v_b[same])
+        assert np.array_equal(u_a[same & exact], u_b[same & exact]) and np.array_equal(v_a[same & exact], v_b[same & exact])
         assert np.array_equal(results[1][3][mesh_a[same]], results[0][3][mesh_b[same]])    # the same scene instance
         assert (tri_a[hit] < results[1][4]).all()                                          # never a copy
-    assert np.array_equal(results[1][2], results[0][2])                                    # any-hit: the same rays are occluded
+    assert (results[1][2] != results[0][2]).sum() <= 1e-5 * results[0][2].size             # any-hit: the same rays are occluded (but for a ray grazing one of the two transformed instances)
     grt.config_reset()
 
 
 def test_flattened_scene_with_moving_instances_renders_like_the_oracle(grt, oracle, tmp_path):
-    """Static floor and emitters flattened, 40 transformed instances beside them in the TLAS: frames and queue sizes against
-    the oracle, then one of the static instances starts to move -- the flattening dissolves and the frames still agree."""
+    """43 instances, 40 of them rotated and scaled: all flattened (the TLAS is empty, rays never look at it) -- frames and
+    queue sizes against the oracle; then six of them start to move: the tree is rebuilt without them, they get TLAS leaves,
+    and the frames still agree; then they move again (no rebuild this time)."""
     from test_tlas import instanced_scene_file
     from test_gpu_parity import compare_frames
     grt.config_reset(); grt.config_set(num_bounces=4)
     scene = grt.Scene(instanced_scene_file(str(tmp_path / "s"), count=40)); grt.config_set(num_bounces=4)
     pt = grt.Pathtracer(scene, 192, 128, device=0); pt.update()
-    assert pt.static_geometry_members == 3 and pt.array("tlas_indices").size == scene.mesh_count + 1
+    assert pt.static_geometry_members == 43 and pt.array("tlas_indices").size == 44 and pt.static_geometry_whole_scene
     compare_frames(grt, oracle, pt, 2, 192, 128)
-    scene.set_mesh_transform(0, (0.0, -0.5, 0.0), (0.0, 0.0, 0.0, 1.0), 1.0)
+    for mesh in (0, 5, 6, 7, 20, 41):
+        position, rotation, scale = scene.mesh_transform(mesh)
+        scene.set_mesh_transform(mesh, (position[0] + 0.5, position[1] - 0.25, position[2]), rotation, scale)
     pt.invalidate("scene"); pt.update()
-    assert pt.static_geometry_members == 0 and pt.array("tlas_indices").size == scene.mesh_count
+    assert pt.static_geometry_members == 37 and pt.array("tlas_indices").size == 44 and not pt.static_geometry_whole_scene
+    assert sorted(pt.array("tlas_indices")[:7].tolist()) == [-1, 0, 5, 6, 7, 20, 41]
+    compare_frames(grt, oracle, pt, 2, 192, 128)
+    for mesh in (5, 41):
+        position, rotation, scale = scene.mesh_transform(mesh)
+        scene.set_mesh_transform(mesh, (position[0], position[1] + 1.0, position[2]), rotation, scale * 1.1)
+    pt.invalidate("scene"); pt.update()
+    assert pt.static_geometry_members == 37
     compare_frames(grt, oracle, pt, 2, 192, 128)
     pt.close(); scene.close(); grt.config_reset()
 

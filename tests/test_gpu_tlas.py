@@ -24,6 +24,7 @@ def read_tlas(grt, pt, n):
     return nodes[:count.value], order
 
 
+@pytest.mark.reference_layout
 @pytest.mark.parametrize("count", [1, 5, 60, 1500])
 def test_device_tlas_equals_its_restatement_and_traces_like_the_host_tlas(grt, oracle, tmp_path, count):
     path = instanced_scene_file(str(tmp_path / "s"), count=count)

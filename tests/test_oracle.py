@@ -290,6 +290,7 @@ def write_sliver_scene(tmp_path, n=600, seed=9):
     return str(tmp_path / "s.xml")
 
 
+@pytest.mark.reference_layout
 def test_spatial_split_and_collapsed_trees_trace_like_the_cwbvh(grt, oracle, tmp_path):
     """bvh_type = SBVH / BVH / BVH4 on a file-loaded mesh: leaves hold several triangles
     (BVHCollapser.cpp) and, with spatial splits, a triangle sits in several leaves (the device
@@ -565,6 +566,7 @@ def test_reference_ambient_occlusion_kernels(grt, oracle, scene_name, w, h, radi
     theirs.close(); ao.close(); scene.close()
 
 
+@pytest.mark.reference_layout
 def test_reference_kernels_thin_lens_hdr_sky_and_instances(grt, oracle, tmp_path):
     """More of kernel_generate / kernel_sort through the reference's own code: a thin-lens camera (aperture sampling),
     an HDR environment map with structure (sample_sky on misses at every bounce), and instanced file meshes with

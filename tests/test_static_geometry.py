@@ -33,7 +33,8 @@ def scene_file_of(grt, name, tmp_path):
     return grt.scene_path(name)
 
 
-@pytest.mark.parametrize("name,w,h,extent,identity_instances,merge", [("cornellbox", 64, 48, 3.0, 8, 1), ("sponza", 96, 54, 14.0, 382, 1), ("sponza", 96, 54, 14.0, 382, 2), ("instances", 96, 64, 14.0, None, 1)])
+@pytest.mark.parametrize("name,w,h,extent,identity_instances,merge", [("cornellbox", 64, 48, 3.0, 8, 1), ("sponza", 96, 54, 14.0, 382, 1), ("sponza", 96, 54, 14.0, 382, 2), ("sponza", 96, 54, 14.0, 382, 3),
+                                                                       ("instances", 96, 64, 14.0, 3, 1), ("instances", 96, 64, 14.0, 3, 3)])
 def test_flattened_static_geometry_traces_like_one_blas_per_mesh(grt, oracle, tmp_path, name, w, h, extent, identity_instances, merge):
     scene_file = scene_file_of(grt, name, tmp_path)
     scene_ref, pt_ref = staged(grt, scene_file, w, h, 0)
@@ -46,12 +47,14 @@ def test_flattened_static_geometry_traces_like_one_blas_per_mesh(grt, oracle, tm
     assert pt_ref.static_geometry_members == 0 and pt_ref.array("alias_mesh_ids").size == 0
     materials_ref = np.zeros(scene_ref.mesh_count, np.int32); materials_ref[rows_ref] = pt_ref.array("mesh_material_ids")
     mesh_count = scene_ref.mesh_count
+    assert not pt_ref.static_geometry_whole_scene
     pt_ref.close(); scene_ref.close()
 
     scene, pt = staged(grt, scene_file, w, h, merge)
     members = pt.static_geometry_members
     identity = int((roots_ref < 0).sum())
-    assert members == identity and (identity_instances is None or members == identity_instances) and members >= 2
+    # merge_static 1 / 2: every instance (none has moved); 3: those with the identity transform
+    assert identity == identity_instances and members == (identity if merge == 3 else mesh_count) and members >= 2
     flat = oracle.SceneView(pt)
 
     # ---- the layout ----
@@ -69,10 +72,23 @@ def test_flattened_static_geometry_traces_like_one_blas_per_mesh(grt, oracle, tm
     assert np.array_equal(nodes[2 * mesh_count:nodes_ref.shape[0]], nodes_ref[2 * mesh_count:])      # ... the per-mesh trees included
     alias_rows, alias_triangles = names_row[first:], names_triangle[first:]
     assert (alias_rows >= leaves).all() and (alias_rows < rows.size).all() and (alias_triangles >= 0).all() and (alias_triangles < first).all()
-    assert np.array_equal(triangles[first:].view(np.uint32), triangles[alias_triangles].view(np.uint32))   # a copy IS its original, bit for bit
+    copies, originals = triangles[first:], triangles[alias_triangles]
+    stands_as_loaded = roots[alias_rows] < 0                                                          # copies of identity instances ...
+    assert np.array_equal(copies[stands_as_loaded].view(np.uint32), originals[stands_as_loaded].view(np.uint32))   # ... ARE their originals, bit for bit
+    assert np.array_equal(copies[:, 9:].view(np.uint32), originals[:, 9:].view(np.uint32))           # the others: the original taken to world space
+    placed = pt.array("mesh_transforms").reshape(-1, 3, 4)[alias_rows[~stands_as_loaded]]
+    for part, translate in ((slice(0, 3), 1.0), (slice(3, 6), 0.0), (slice(6, 9), 0.0)):             # position_0, edge_1, edge_2
+        want = np.einsum("nij,nj->ni", placed[:, :, :3], originals[~stands_as_loaded][:, part]) + translate * placed[:, :, 3]
+        assert np.allclose(copies[~stands_as_loaded][:, part], want, rtol=1e-5, atol=1e-5)
+    assert stands_as_loaded.all() == (members == identity)
     copied = np.bincount(alias_triangles, minlength=first)
-    assert copied.max() == 1 if merge == 2 else (copied.max() > 1) == (name == "sponza")            # once each without spatial splits; a triangle they cut, once per part (Sponza's long triangles)
+    pairs = np.unique(np.stack([alias_rows, alias_triangles]), axis=1).shape[1]                      # (instance, triangle): once each without spatial splits;
+    assert copied.min() >= 0 and (pairs == alias_rows.size if merge == 2 else (pairs < alias_rows.size or name != "sponza"))   # a triangle they cut, once per part (Sponza's long triangles)
     flat_root = int(roots[np.flatnonzero(rows == -1)[0]] & 0x7fffffff)
+    # nothing outside the tree: no TLAS, node 0 is a copy of the tree's root and rays start inside it (rt_set_static_geometry)
+    assert pt.static_geometry_whole_scene == (members == mesh_count)
+    if members == mesh_count:
+        assert leaves == 1 and rows[0] == -1 and np.array_equal(nodes[0], nodes[flat_root])
     assert flat_root == nodes_ref.shape[0] and roots[np.flatnonzero(rows == -1)[0]] < 0              # the extra tree sits behind the others; world space
     # each copy names a row whose BLAS holds the original: walk that BLAS' triangle range
     def blas_triangles(root, all_nodes):
@@ -95,20 +111,31 @@ def test_flattened_static_geometry_traces_like_one_blas_per_mesh(grt, oracle, tm
     hits, stats = flat.trace(o, d)
     mesh_ref, tri_ref, t_ref, u_ref, v_ref = unpack_hits(hits_ref); mesh, tri, t, u, v = unpack_hits(hits)
     hit = tri_ref != -1
-    assert hit.mean() > 0.3 and np.array_equal(hit, tri != -1)
-    assert np.array_equal(t.view(np.uint32), t_ref.view(np.uint32))                                   # the same distance, to the bit, for every ray
+    # An identity instance's copies are its triangles bit for bit, and the ray that meets them is the same world-space ray in
+    # both layouts: the same distance, to the bit. A transformed instance's copies are its triangles taken to world space,
+    # where the reference's layout takes the ray to object space instead: the same hit up to rounding (a few ulp of t; u, v
+    # within one step of their 16-bit quantisation), and a ray that grazes an edge may fall on the other side of it.
+    exact = hit & (roots_ref[mesh_ref] < 0)
+    both = hit & (tri != -1)
+    far_apart = np.zeros(hit.shape, bool); far_apart[both] = np.abs(t[both] - t_ref[both]) > 1e-5 * np.abs(t_ref[both])
+    grazing = (hit != (tri != -1)) | (far_apart & ~exact)
+    assert hit.mean() > 0.3 and grazing.sum() <= (0 if members == identity else 2e-3 * hit.sum()), int(grazing.sum())
+    assert np.array_equal(t.view(np.uint32)[exact & ~grazing], t_ref.view(np.uint32)[exact & ~grazing])
+    hit = hit & ~grazing
     # ... to the same triangle of the same scene instance -- except where two triangles lie at exactly the closest distance
     # (a box standing on the floor): a tie goes to whichever the walk meets first, in either layout
     tie = hit & (tri != tri_ref)
     assert tie.sum() <= 1e-3 * hit.sum()
     same = hit & ~tie
-    assert np.array_equal(u[same], u_ref[same]) and np.array_equal(v[same], v_ref[same])
+    assert np.array_equal(u[same & exact], u_ref[same & exact]) and np.array_equal(v[same & exact], v_ref[same & exact])
+    worst = max(int(np.abs(u[same].astype(np.int64) - u_ref[same]).max()), int(np.abs(v[same].astype(np.int64) - v_ref[same]).max()))
+    assert worst <= 8, worst                                                                          # of 65535 (a triangle 0.1 wide, 12 units from the origin: 1e-6 of 12 is 1e-4 of the triangle)
     assert np.array_equal(rows[mesh[same]], rows_ref[mesh_ref[same]])
     assert (tri[hit] < first).all() and (rows[mesh[hit]] >= 0).all()                                 # never a copy, never the flattened tree's own row
     by_scene_mesh = np.zeros(mesh_count, np.int32); by_scene_mesh[rows[rows >= 0]] = pt.array("mesh_material_ids")[rows >= 0]
     assert np.array_equal(by_scene_mesh, materials_ref)                                              # rows carry their instance's material
     shadow = flat.trace_shadow(o, d, np.full(o.shape[1], 9.0, np.float32))[0]
-    assert np.array_equal(shadow, shadow_ref) and 0.05 < shadow.mean() < 0.999
+    assert (shadow != shadow_ref).sum() <= (0 if members == identity else 1e-3 * shadow.size) and 0.05 < shadow.mean() < 0.999
     if name == "sponza":   # what it is for: fewer nodes and no instance entries on the way to the same hits
         assert stats.nodes < stats_ref.nodes and stats.instances_identity < 0.2 * stats_ref.instances_identity
     pt.close(); scene.close(); grt.config_reset()
@@ -128,20 +155,27 @@ def test_frames_do_not_depend_on_the_flattening(grt, oracle):
     grt.config_reset()
 
 
-def test_a_member_that_moves_dissolves_the_flattening(grt, oracle):
+def test_a_member_that_moves_leaves_the_flattened_tree(grt, oracle):
+    """The tree is rebuilt without it (a one-off stall); it keeps a TLAS leaf of its own even when it comes to rest."""
     scene, pt = staged(grt, grt.scene_path("cornellbox"), 48, 36, 1)
-    assert pt.static_geometry_members == 8 and pt.array("tlas_indices").size == 9
+    assert pt.static_geometry_members == 8 and pt.array("tlas_indices").size == 9 and pt.static_geometry_whole_scene
+    triangles_before = pt.array("triangles").size // 24
     scene.set_mesh_transform(6, (0.25, 0.0, -0.1), (0.0, 0.0, 0.0, 1.0), 1.0)
     pt.invalidate("scene"); pt.update()
-    assert pt.static_geometry_members == 0                                        # for good: the per-mesh trees take over
     rows = pt.array("tlas_indices").copy()
-    assert sorted(rows.tolist()) == list(range(8)) and pt.array("mesh_bvh_root_indices").size == 8
+    assert pt.static_geometry_members == 7 and not pt.static_geometry_whole_scene and sorted(rows.tolist()[:2]) == [-1, 6] and sorted(rows[2:].tolist()) == [0, 1, 2, 3, 4, 5, 7]
+    assert pt.array("triangles").size // 24 < triangles_before                 # its copies are gone
     view = oracle.SceneView(pt)
     o, d = rays_for(view, 48, 36, 3.0, 3000, 9)
     hits, _ = view.trace(o, d)
-    scene.set_mesh_transform(6, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0), 1.0)       # standing still again does not bring it back
+    scene.set_mesh_transform(6, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0), 1.0)   # standing still again does not bring it back
     pt.invalidate("scene"); pt.update()
-    assert pt.static_geometry_members == 0
+    assert pt.static_geometry_members == 7
+    scene.set_mesh_transform(6, (0.25, 0.0, -0.1), (0.0, 0.0, 0.0, 1.0), 1.0)
+    for other in (0, 1, 2, 3, 4, 5):                                          # everything but one instance moves: nothing left to flatten
+        scene.set_mesh_transform(other, (0.0, 0.01, 0.0), (0.0, 0.0, 0.0, 1.0), 1.0)
+    pt.invalidate("scene"); pt.update()
+    assert pt.static_geometry_members == 0 and not pt.static_geometry_whole_scene and sorted(pt.array("tlas_indices").tolist()) == list(range(8))
     pt.close(); scene.close()
 
     scene, pt = staged(grt, grt.scene_path("cornellbox"), 48, 36, 0)
@@ -150,7 +184,10 @@ def test_a_member_that_moves_dissolves_the_flattening(grt, oracle):
     hits_ref, _ = oracle.SceneView(pt).trace(o, d)
     rows_ref = pt.array("tlas_indices").copy()
     hit = hits_ref[:, 1] != 0xffffffff
-    assert np.array_equal(hits[:, 1:], hits_ref[:, 1:]) and np.array_equal(rows[hits[hit, 0].astype(np.int64)], rows_ref[hits_ref[hit, 0].astype(np.int64)])
+    assert np.array_equal(hits[:, 2], hits_ref[:, 2])                                                  # the same distance to the bit (the mover is walked in object space in both layouts)
+    same = hit & (hits[:, 1] == hits_ref[:, 1])                                                        # (ties: the box that moved still stands ON the floor)
+    assert same.sum() >= 0.999 * hit.sum() and np.array_equal(hits[same, 3], hits_ref[same, 3])
+    assert np.array_equal(rows[hits[same, 0].astype(np.int64)], rows_ref[hits_ref[same, 0].astype(np.int64)])
     pt.close(); scene.close(); grt.config_reset()
 
 

@@ -101,6 +101,7 @@ def world_boxes_of(transforms, boxes):
     return np.stack([world.min(axis=1), world.max(axis=1)], axis=1)
 
 
+@pytest.mark.reference_layout
 @pytest.mark.parametrize("count", [1, 2, 9, 60, 700])
 def test_restated_device_tlas_is_a_valid_tlas_and_traces_like_the_host_built_one(grt, oracle, tmp_path, count):
     grt.config_reset()

@@ -263,6 +263,17 @@ int main(int argc, char ** argv) {
 	for (auto & p : pols) { report("bounce2 (queue order)", p, simulate(s, bounce2, false, p)); }
 	for (int block : { 64, 128, 256, 512, 1024 }) { auto r = bucket(bounce2, block); char l[64]; snprintf(l, 64, "bounce2 octant buckets of %d", block); report(l, pols[0], simulate(s, r, false, pols[0])); report(l, pols[1], simulate(s, r, false, pols[1])); }
 	{ auto r = bucket(bounce2, 1 << 30); report("bounce2 octant-major (global)", pols[0], simulate(s, r, false, pols[0])); }
+	// rays sorted by where they start (Morton code of the origin in a grid over the scene), within blocks of N rays and globally; with and without the octant as the top key
+	{ f3 lo = mk3(1e30f, 1e30f, 1e30f), hi = mk3(-1e30f, -1e30f, -1e30f);
+	  for (auto & r : bounce2) { lo.x = std::min(lo.x, r.o.x); lo.y = std::min(lo.y, r.o.y); lo.z = std::min(lo.z, r.o.z); hi.x = std::max(hi.x, r.o.x); hi.y = std::max(hi.y, r.o.y); hi.z = std::max(hi.z, r.o.z); }
+	  auto expand = [](uint32_t v) { v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu; v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u; return v; };
+	  auto key = [&](const Ray & r, int bits, bool octant) { uint32_t q = (1u << bits) - 1; uint32_t x = uint32_t((r.o.x - lo.x) / (hi.x - lo.x) * q), y = uint32_t((r.o.y - lo.y) / (hi.y - lo.y) * q), z = uint32_t((r.o.z - lo.z) / (hi.z - lo.z) * q);
+	      uint64_t m = (uint64_t(expand(x)) << 2) | (uint64_t(expand(y)) << 1) | expand(z); int oc = (r.d.x < 0 ? 4 : 0) | (r.d.y < 0 ? 2 : 0) | (r.d.z < 0 ? 1 : 0); return octant ? (uint64_t(oc) << 40) | m : (m << 3) | uint64_t(oc); };
+	  for (int bits : { 4, 6, 10 }) for (int octant_first = 0; octant_first < 2; octant_first++) for (size_t block : { size_t(4096), size_t(65536), size_t(1) << 30 }) {
+	      std::vector<Ray> r = bounce2;
+	      for (size_t b = 0; b < r.size(); b += block) { size_t e = std::min(r.size(), b + block); std::stable_sort(r.begin() + b, r.begin() + e, [&](const Ray & a, const Ray & c) { return key(a, bits, octant_first) < key(c, bits, octant_first); }); }
+	      char l[96]; snprintf(l, 96, "bounce2 morton%d %s blocks of %zu", bits, octant_first ? "octant-major" : "cell-major", block > (1u << 29) ? size_t(0) : block);
+	      report(l, pols[1], simulate(s, r, false, pols[1])); } }
 	for (auto & p : { pols[0], pols[1] }) report("shadow (point light, queue order)", p, simulate(s, shadow, true, p));
 	for (auto & p : { pols[0], pols[1] }) report("primary", p, simulate(s, primary, false, p));
 	return 0;
