@@ -363,7 +363,9 @@ template<int MODE, typename Source> RT_DEV void source_finish(const Source & src
 // UNIFIED: the TLAS nodes have been copied into the slots [0, tlas_node_count) that the BLAS node array reserves for them
 // (the merged wavefront does that whenever the TLAS changes, rt_api.hip: stream_sync_tlas), so a node is fetched from ONE
 // base address: no compare / select of two 64-bit bases and no scalar load of the TLAS size in every round.
-template<int MODE, bool COUNT, bool NARROW, bool UNIFIED = false, typename Source>
+// FLAT: the whole scene is one world-space tree rooted in node 0 (rt_set_static_geometry): there is no TLAS to walk, no instance
+// to enter or leave, no object-space ray -- the code for those and the three registers that track them are compiled out.
+template<int MODE, bool COUNT, bool NARROW, bool UNIFIED = false, bool FLAT = false, typename Source>
 RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr, int ray_count_2 = 0, int * cursor_2 = nullptr) {
 	constexpr bool SHADOW = MODE == RT_TRACE_SHADOW;   // the kind of every ray, unless MODE == RT_TRACE_MIXED: then lane_shadow
 	bool lane_shadow = SHADOW;
@@ -481,7 +483,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			// instance entry, which were one of a ray's ~13 node steps and part of a round. (One uniform value instead of a
 			// constant; anything more here -- a push, a root index from the parameters -- cost 16 B of scratch in the loop.)
 			current_group   = make_uint2(0, 0x80000000u);
-			tlas_stack_size = p.entry_tlas_stack_size;
+			tlas_stack_size = FLAT ? 0 : p.entry_tlas_stack_size;
 		}
 
 		int iterations_lost = 0;
@@ -492,7 +494,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			// this same round. A ray enters ~8 instances on Sponza and most of those leaf groups come off the stack: with the
 			// entry behind the node phase (round 2) such a lane spent a whole round on the entry alone -- 3.8 of a bounce ray's
 			// ~30 rounds. tools/wave_sim: 234 -> 202 wave-instructions per incoherent ray, lane utilisation 0.52 -> 0.59.
-			if (triangle_group.y != 0 && tlas_stack_size == RT_INVALID) {
+			if (!FLAT && triangle_group.y != 0 && tlas_stack_size == RT_INVALID) {
 				int mesh_offset = int(msb(triangle_group.y));
 				triangle_group.y &= ~(1u << mesh_offset);
 				mesh_id = int(triangle_group.x) + mesh_offset;
@@ -559,7 +561,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			// each ray's dependent chain, not by issue slots (profiles/r01_trace_loop_structure.txt).
 			bool occluded = false;
 			{
-				bool has_triangles = triangle_group.y != 0 && tlas_stack_size != RT_INVALID;
+				bool has_triangles = triangle_group.y != 0 && (FLAT || tlas_stack_size != RT_INVALID);
 #if RT_TRI_HOLD > 0
 				// experiment: the triangle phase of a round runs only when at least RT_TRI_HOLD lanes have triangles waiting, or no
 				// running lane of the wave can do anything else (its lanes are at ~20 % of the wave in an ordinary round)
@@ -598,7 +600,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 								hit.t = __uint_as_float(best);
 								hit.u = __shfl(u, from); hit.v = __shfl(v, from);
 								hit.triangle_id = __shfl(my_triangle, from);
-								hit.mesh_id = mesh_id;
+								hit.mesh_id = FLAT ? 0 : mesh_id;
 							}
 						}
 					} else {
@@ -622,7 +624,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					for (int k = 0; k < RT_TRI_BATCH; k++) {
 						if (tri_id[k] != RT_INVALID && !occluded) {
 							if (COUNT) count_triangles++;
-							if (triangle_test_kind(RT_IS_SHADOW, tri_a[k], tri_b[k], make_float4(tri_c[k], 0.0f, 0.0f, 0.0f), mesh_id, tri_id[k], ray, max_distance, hit)) occluded = true;
+							if (triangle_test_kind(RT_IS_SHADOW, tri_a[k], tri_b[k], make_float4(tri_c[k], 0.0f, 0.0f, 0.0f), FLAT ? 0 : mesh_id, tri_id[k], ray, max_distance, hit)) occluded = true;
 						}
 					}
 				}
@@ -658,7 +660,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					current_group.y = 0;
 					running = false;
 				} else {
-				if (stack.size == tlas_stack_size) {
+				if (!FLAT && stack.size == tlas_stack_size) {
 					tlas_stack_size = RT_INVALID;
 					if (!mesh_has_identity_transform) {
 						float unused;
@@ -1173,13 +1175,13 @@ struct MixedStreamSource {
 	RT_DEV void load(bool is_shadow, int i, Ray3 & ray, float & max_distance) const { if (is_shadow) shadow.load(i, ray, max_distance); else closest.load(i, ray, max_distance); }
 	RT_DEV void finish(bool is_shadow, int i, const HitRecord & hit, bool occluded) const { if (is_shadow) shadow.finish(i, hit, occluded); else closest.finish(i, hit, occluded); }
 };
-template<bool COUNT>
+template<bool COUNT, bool FLAT = false>
 RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	const int q = p.stream_iteration & 1;
 	MixedStreamSource src { { p.trace[q].origin, p.trace[q].direction, p.trace[q].hits },
 	                        { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT] } };
 	const int closest_count = p.stream->trace_count[q], shadow_count = p.stream->shadow_count[q ^ 1];
-	if (p.mesh_count <= RT_ROOTS_IN_LDS) {   // (uniform over the launch; before any wave leaves the kernel)
+	if (!FLAT && p.mesh_count <= RT_ROOTS_IN_LDS) {   // (uniform over the launch; before any wave leaves the kernel)
 		for (int i = threadIdx.x; i < p.mesh_count; i += RT_TRACE_BLOCK) shared_roots[i] = p.mesh_bvh_root_indices[i];
 		__syncthreads();
 	}
@@ -1192,15 +1194,16 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	//     where it was a compile-time constant) and a 25 M-ray launch has little to gain from it (0.87 -> 0.83 when mixed).
 	//   profiles/r02_mixed_engine.txt
 	if (!COUNT && closest_count + shadow_count <= RT_NARROW_MAX_RAYS)
-		bvh8_trace_engine<RT_TRACE_MIXED, false, true, true>(p, src, closest_count, &p.stream->cursor[q][0], nullptr, shadow_count, &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_MIXED, false, true, true, FLAT>(p, src, closest_count, &p.stream->cursor[q][0], nullptr, shadow_count, &p.stream->cursor[q][1]);
 	else if (COUNT || closest_count + shadow_count <= RT_MIXED_MAX_RAYS)
-		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true, FLAT>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
 	else {
-		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
-		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true, FLAT>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
+		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true, FLAT>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
 	}
 }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8(RtParams p) { trace_stream<false>(p, nullptr); }
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_flat(RtParams p) { trace_stream<false, true>(p, nullptr); }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_counting(RtParams p, unsigned long long * stats) { trace_stream<true>(p, stats); }
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {
@@ -1276,6 +1279,11 @@ void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, hipS
 	if (stats) {
 		static int grid_counting = trace_grid_size((const void *)kernel_trace_stream_bvh8_counting);
 		hipLaunchKernelGGL(kernel_trace_stream_bvh8_counting, dim3(grid_counting), dim3(RT_TRACE_BLOCK), 0, stream, p, stats);
+		return;
+	}
+	if (p.entry_tlas_stack_size == 0) {   // the whole scene is one world-space tree: the engine without the TLAS / instance code
+		static int grid_flat = trace_grid_size((const void *)kernel_trace_stream_bvh8_flat);
+		hipLaunchKernelGGL(kernel_trace_stream_bvh8_flat, dim3(grid_flat), dim3(RT_TRACE_BLOCK), 0, stream, p);
 		return;
 	}
 	static int grid = trace_grid_size((const void *)kernel_trace_stream_bvh8);

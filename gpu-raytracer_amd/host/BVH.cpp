@@ -170,7 +170,7 @@ int BVH8Converter::fill_cost_table(int node_index) {
 
 	if (node.is_leaf()) {
 		if (node.count != 1) throw std::runtime_error("BVH8 conversion needs exactly one primitive per BVH2 leaf");
-		float cost_leaf = node.aabb.surface_area() * float(node.count);
+		float cost_leaf = node.aabb.surface_area() * float(node.count) * primitive_cost;
 		for (int i = 0; i < 7; i++) { row[i].kind = LEAF; row[i].cost = cost_leaf; }
 		return int(node.count);
 	}
@@ -180,7 +180,7 @@ int BVH8Converter::fill_cost_table(int node_index) {
 	const Decision * row_r = &table[size_t(node.left + 1) * 7];
 
 	{
-		float cost_leaf = num_primitives <= 3 ? float(num_primitives) * node.aabb.surface_area() : INFINITY;
+		float cost_leaf = num_primitives <= 3 ? float(num_primitives) * node.aabb.surface_area() * primitive_cost : INFINITY;
 
 		float cost_distribute = INFINITY;
 		char  take_l = char(INVALID), take_r = char(INVALID);

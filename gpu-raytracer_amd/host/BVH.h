@@ -150,6 +150,7 @@ struct BVH8Converter {
 	BVH8       & bvh8;
 	const BVH2 & bvh2;
 
+	float primitive_cost = 1.0f;   // SAH cost of a triangle test relative to a node step: 1 in the reference's converter (BVH8Converter.cpp:24-115)
 	BVH8Converter(BVH8 & bvh8, const BVH2 & bvh2) : bvh8(bvh8), bvh2(bvh2) { }
 	void convert();
 

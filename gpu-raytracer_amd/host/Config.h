@@ -72,6 +72,9 @@ struct CPUConfig {
 	// dissolves the flattening. 2 = the same with the per-mesh SAH builder (no spatial splits). 0 = one BLAS per mesh under
 	// the TLAS, exactly the reference's structure (Integrator.cpp:101-283).
 	int  merge_static = 1;
+	// ... and what a triangle test costs relative to a node step when that tree's binary form is collapsed into 8-wide nodes
+	// (BVH8Converter: 1 in the reference; here a triangle test runs with a quarter of a wave's lanes, a node step with most)
+	float static_primitive_cost = 1.0f;
 
 	IntegratorType integrator = IntegratorType::PATHTRACER; // read by the command-line front end
 

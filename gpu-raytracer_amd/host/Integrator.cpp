@@ -207,7 +207,9 @@ void Integrator::init_geometry() {
 				if (cpu_config.merge_static == 2) binary = BVH::create_sah_from_triangles(world);   // the per-mesh builder, for comparison
 				else                              StaticBVHBuilder::build(binary, world);           // spatial splits, all host threads
 				BVH8 wide;
-				BVH8Converter(wide, binary).convert();
+				BVH8Converter converter(wide, binary);
+				converter.primitive_cost = cpu_config.static_primitive_cost;
+				converter.convert();
 				flat.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
 				copy_source = wide.indices;
 				flat.root = int(node_total);

@@ -12,6 +12,10 @@
 #include "BVH.h"
 #include "Config.h"
 
+#ifndef STATIC_BVH_BINS
+#define STATIC_BVH_BINS 32
+#endif
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -20,7 +24,7 @@
 
 namespace {
 
-constexpr int BINS = 32;
+constexpr int BINS = STATIC_BVH_BINS;
 
 struct Ref { AABB box; int triangle; };
 

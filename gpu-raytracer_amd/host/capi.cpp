@@ -65,6 +65,7 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "device_tlas")                         cpu_config.device_tlas = int(value);
 	else if (k == "device_blas")                         cpu_config.device_blas = int(value);
 	else if (k == "merge_static")                        cpu_config.merge_static = int(value);
+	else if (k == "static_primitive_cost")               cpu_config.static_primitive_cost = float(value);
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
 	else if (k == "initial_height")                      cpu_config.initial_height = int(value);
 	else { g_host_error = "unknown config key '" + k + "'"; return -1; }
@@ -617,7 +618,7 @@ void * grt_build_blas_variant(const float * tris24, int n, int spatial_splits, i
 		else if (spatial_splits) SBVHBuilder(md->bvh2, md->triangles.size()).build(md->triangles);
 		else                SAHBuilder (md->bvh2, md->triangles.size()).build(md->triangles);
 		if (optimize) BVHOptimizer::optimize(md->bvh2);
-		BVH8Converter(md->bvh8, md->bvh2).convert();
+		{ BVH8Converter converter(md->bvh8, md->bvh2); if (const char * c = getenv("GRT_PRIMITIVE_COST")) converter.primitive_cost = float(atof(c)); converter.convert(); }
 		return md;
 	GRT_CATCH(nullptr)
 }
