@@ -63,6 +63,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3-6.6
 VALU_PEAK_LANE_INSTR_PER_S = 256 * 4 * 16 * 2.4e9
 
 
+TRACE_KERNEL = ["kernel_trace_stream_bvh8"]   # the dominant kernel's name in the rocprofv3 records: ..._flat when the whole scene is one flattened tree (rt_set_static_geometry)
 MERGE_STATIC = 1   # --merge-static: 0 stages the scene exactly as the reference does (one BLAS per mesh under the TLAS)
 
 
@@ -149,7 +150,7 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
                                   extra_args=("--merge-static", str(args.merge_static)))
     kernels = passes["kernels"]
     out = {"pmc_errors": passes["errors"]} if passes["errors"] else {}
-    trace = kernels.get("kernel_trace_stream_bvh8")
+    trace = kernels.get(TRACE_KERNEL[0])
     if not trace:
         return dict(out, traffic=None)
     # what the child rendered with the non-counting traversal kernel: warm-up, the two profiled frames, the timed plan
@@ -366,6 +367,8 @@ def main():
     scene = build_scene(grt)
     pt = grt.Pathtracer(scene, WIDTH, HEIGHT, device=local_rank)
     pt.update()
+    if pt.static_geometry_whole_scene:
+        TRACE_KERNEL[0] = "kernel_trace_stream_bvh8_flat"   # the engine variant without TLAS / instance code
     closed = False
     lib = grt.device_lib()
     ctx = pt.ctx
@@ -551,7 +554,7 @@ def main():
             big = launch_rays >= 0.5 * launch_rays.max()        # the steady-state launches (fill and drain iterations excluded)
             per_launch_gbps = launch_bytes / np.maximum(launch_ms, 1e-6) / 1e6
             roofline.update({
-                "kernel": "kernel_trace_stream_bvh8", "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "kernel": TRACE_KERNEL[0], "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "launches": int(len(launch_ms)), "algorithmic_bytes_per_launch": round(float(launch_bytes.mean())), "avg_launch_ms": round(float(launch_ms.mean()), 4),
                 "launch_ms": spread(launch_ms), "launch_gbps": spread(per_launch_gbps),
                 "steady_state": {"launches": int(big.sum()), "achieved": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9), 1),
@@ -652,7 +655,7 @@ def main():
             result["roofline"].update(pmc)
             r = result["roofline"]
             for stage in r.get("stages", []):   # the counters of the other stages' kernels, where the passes saw them
-                k = pmc_kernels.get({"traversal": "kernel_trace_stream_bvh8", "sort": "kernel_sort_stream", "generate": "kernel_generate_stream", "accumulate": "kernel_accumulate_group"}.get(stage["stage"], "kernel_" + stage["stage"] + "_stream"))
+                k = pmc_kernels.get({"traversal": TRACE_KERNEL[0], "sort": "kernel_sort_stream", "generate": "kernel_generate_stream", "accumulate": "kernel_accumulate_group"}.get(stage["stage"], "kernel_" + stage["stage"] + "_stream"))
                 if k and k.get("SQ_INSTS_VALU", [0, 0])[1] > 0 and k.get("_duration_ns"):
                     stage["lane_utilisation"] = round(k["SQ_THREAD_CYCLES_VALU"][1] / (64.0 * k["SQ_INSTS_VALU"][1]), 3)
                     stage["valu_busy"] = round(4.0 * k.get("SQ_ACTIVE_INST_VALU", [0, 0.0])[1] / (1024.0 * k["_duration_ns"][1] * 2.4), 3)
