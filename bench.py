@@ -562,7 +562,7 @@ def main():
                                  "launch_gbps": spread(per_launch_gbps[big]), "rays_per_launch": int(launch_rays[big].mean())},
                 "closest_hit_share_of_bytes": round(float(launch_closest_bytes.sum() / launch_bytes.sum()), 3),
                 "time_share_of_step": round(float(launch_ms.sum() / (elapsed * 1e3)), 3),
-                "note": "achieved = sum of the algorithmic bytes (SURVEY 8d; counted by the counting variant on the same launches) of ALL traversal launches of the timed region / sum of their HIP-event durations; one launch at a time is resident (single stream), so a duration is the kernel's own. steady_state = launches with at least half the rays of the largest. Working set (2.6 MB nodes + 12.6 MB triangle positions) is L2 / Infinity-Cache resident: algorithmic bytes >> DRAM traffic",
+                "note": "achieved = sum of the algorithmic bytes (SURVEY 8d; counted by the counting variant on the same launches) of ALL traversal launches of the timed region / sum of their HIP-event durations; one launch at a time is resident (single stream), so a duration is the kernel's own. steady_state = launches with at least half the rays of the largest. Working set (%.1f MB nodes + %.1f MB triangle positions%s) is L2 / Infinity-Cache resident: algorithmic bytes >> DRAM traffic" % (pt.array("bvh8_nodes").size / 1e6, pt.array("triangles").size // 24 * 48 / 1e6, ", the per-mesh trees and the flattened tree over copies of their triangles; rays only touch the latter" if pt.static_geometry_members else ""),
             })
         else:
             total_ms = float(launch_ms.sum()) if len(launch_ms) else float("nan")

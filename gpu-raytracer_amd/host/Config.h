@@ -65,12 +65,15 @@ struct CPUConfig {
 	// Where the bottom-level trees of a CWBVH scene are built: 0 = on the host (SAH / SBVH builder + BVH8Converter, byte-identical
 	// to the reference's), 1 = on the device (rt_build_geometry: a linear BVH over all meshes at once; fast to build, dearer to traverse)
 	int  device_blas = 0;
-	// Static geometry: 1 = the instances that stand in the scene with the identity transform (two or more of them) are flattened
-	// into ONE bottom-level tree that takes a single TLAS leaf -- a ray then walks one well-built tree (StaticBVHBuilder: SAH
-	// object and spatial splits) instead of entering a dozen overlapping per-mesh trees; hits still name the scene's instances
-	// and triangles (rt_upload_triangle_aliases). CWBVH with the TLAS built on the host only; an instance that starts to move
-	// dissolves the flattening. 2 = the same with the per-mesh SAH builder (no spatial splits). 0 = one BLAS per mesh under
-	// the TLAS, exactly the reference's structure (Integrator.cpp:101-283).
+	// Static geometry: 1 = every instance that has not been seen moving and whose mesh is not instanced more than twice (two or
+	// more such instances) is flattened into ONE bottom-level tree -- a ray then walks one well-built tree (StaticBVHBuilder:
+	// SAH object and spatial splits) instead of entering a dozen overlapping per-mesh trees; hits still name the scene's
+	// instances and triangles (rt_upload_triangle_aliases), and with nothing left outside the tree rays start inside it
+	// (rt_set_static_geometry). CWBVH with the TLAS built on the host only; an instance that starts to move is taken out
+	// again (one rebuild). 2 = the same with the per-mesh SAH builder (no spatial splits). 3 = only instances with the
+	// identity transform (their copies are their triangles bit for bit; a transformed instance's copies are its triangles
+	// taken to world space, which the reference's layout never does: it takes the ray to object space). 0 = one BLAS per
+	// mesh under the TLAS, exactly the reference's structure (Integrator.cpp:101-283).
 	int  merge_static = 1;
 	// ... and what a triangle test costs relative to a node step when that tree's binary form is collapsed into 8-wide nodes
 	// (BVH8Converter: 1 in the reference; here a triangle test runs with a quarter of a wave's lanes, a node step with most)

@@ -171,9 +171,13 @@ void Integrator::init_geometry() {
 		if (cpu_config.merge_static > 0 && !wants_device_tlas()) {
 			// every instance that has not been seen moving; merge_static 3: only those with the identity transform, whose copies
 			// are the original triangles bit for bit (a transformed instance's copies are its triangles taken to world space)
+			// ... and whose mesh is not instanced more than twice: copying an instanced mesh once per instance is the opposite of what
+			// instancing is for (441 instances of one 102 400-triangle mesh would become a 45 M-triangle tree and 6.5 GB of copies)
 			instance_has_moved.resize(mesh_count, 0);
+			std::vector<int> uses(mesh_data_count, 0);
+			for (const Mesh & mesh : scene.meshes) uses[size_t(mesh.mesh_data_handle.handle)]++;
 			for (size_t i = 0; i < mesh_count; i++) {
-				bool joins = !instance_has_moved[i] && (cpu_config.merge_static != 3 || scene.meshes[i].has_identity_transform());
+				bool joins = !instance_has_moved[i] && uses[size_t(scene.meshes[i].mesh_data_handle.handle)] <= 2 && (cpu_config.merge_static != 3 || scene.meshes[i].has_identity_transform());
 				(joins ? flat.members : flat.movers).push_back(int(i));
 			}
 			if (flat.members.size() < 2) { flat.members.clear(); flat.movers.clear(); }

@@ -61,29 +61,44 @@ def test_flattened_sponza_on_the_device_finds_what_the_reference_layout_finds(gr
 
 
 def test_flattened_scene_with_moving_instances_renders_like_the_oracle(grt, oracle, tmp_path):
-    """43 instances, 40 of them rotated and scaled: all flattened (the TLAS is empty, rays never look at it) -- frames and
-    queue sizes against the oracle; then six of them start to move: the tree is rebuilt without them, they get TLAS leaves,
-    and the frames still agree; then they move again (no rebuild this time)."""
+    """A floor and two emitters flattened (one TLAS leaf), 40 rotated / scaled instances of one mesh beside them in the TLAS
+    (an instanced mesh is not copied per instance): frames and queue sizes against the oracle. Then the floor starts to
+    move: the tree is rebuilt without it and the frames still agree; then an emitter: nothing is left to flatten."""
     from test_tlas import instanced_scene_file
     from test_gpu_parity import compare_frames
     grt.config_reset(); grt.config_set(num_bounces=4)
     scene = grt.Scene(instanced_scene_file(str(tmp_path / "s"), count=40)); grt.config_set(num_bounces=4)
     pt = grt.Pathtracer(scene, 192, 128, device=0); pt.update()
-    assert pt.static_geometry_members == 43 and pt.array("tlas_indices").size == 44 and pt.static_geometry_whole_scene
+    assert pt.static_geometry_members == 3 and pt.array("tlas_indices").size == 44 and not pt.static_geometry_whole_scene
+    assert sorted(pt.array("tlas_indices")[41:].tolist()) == [0, 1, 2] and (pt.array("tlas_indices")[:41] == -1).sum() == 1
     compare_frames(grt, oracle, pt, 2, 192, 128)
-    for mesh in (0, 5, 6, 7, 20, 41):
-        position, rotation, scale = scene.mesh_transform(mesh)
-        scene.set_mesh_transform(mesh, (position[0] + 0.5, position[1] - 0.25, position[2]), rotation, scale)
-    pt.invalidate("scene"); pt.update()
-    assert pt.static_geometry_members == 37 and pt.array("tlas_indices").size == 44 and not pt.static_geometry_whole_scene
-    assert sorted(pt.array("tlas_indices")[:7].tolist()) == [-1, 0, 5, 6, 7, 20, 41]
-    compare_frames(grt, oracle, pt, 2, 192, 128)
-    for mesh in (5, 41):
+    scene.set_mesh_transform(0, (0.5, -0.25, 0.0), (0.0, 0.0, 0.0, 1.0), 1.0)
+    for mesh in (5, 20):                                                      # (instances that had leaves of their own anyway)
         position, rotation, scale = scene.mesh_transform(mesh)
         scene.set_mesh_transform(mesh, (position[0], position[1] + 1.0, position[2]), rotation, scale * 1.1)
     pt.invalidate("scene"); pt.update()
-    assert pt.static_geometry_members == 37
+    assert pt.static_geometry_members == 2 and pt.array("tlas_indices").size == 44 and sorted(pt.array("tlas_indices")[42:].tolist()) == [1, 2]
     compare_frames(grt, oracle, pt, 2, 192, 128)
+    scene.set_mesh_transform(1, (0.0, -0.5, 0.0), (0.0, 0.0, 0.0, 1.0), 1.0)
+    pt.invalidate("scene"); pt.update()
+    assert pt.static_geometry_members == 0 and sorted(pt.array("tlas_indices").tolist()) == list(range(43))
+    compare_frames(grt, oracle, pt, 2, 192, 128)
+    pt.close(); scene.close(); grt.config_reset()
+
+
+def test_world_space_copies_of_transformed_instances_render_like_the_oracle(grt, oracle, tmp_path):
+    """The scene with everything: five instances, two of them a scaled and a rotated instance of one file mesh -- all
+    flattened, the transformed ones as world-space copies, no TLAS. Light sampling, MIS, textures and media behind it see the
+    scene's own instances (the emitter that is a copy is found by index in the light tables)."""
+    from scenes import write_scene_with_everything
+    from test_loaders import _png_bytes
+    from test_gpu_parity import compare_frames
+    grt.config_reset()
+    scene = grt.Scene(write_scene_with_everything(tmp_path, _png_bytes)); scene.set_sky_scale(0.3)
+    grt.config_set(num_bounces=6)
+    pt = grt.Pathtracer(scene, 160, 120, device=0); pt.update()
+    assert pt.static_geometry_members == 5 and pt.static_geometry_whole_scene
+    compare_frames(grt, oracle, pt, 3, 160, 120)
     pt.close(); scene.close(); grt.config_reset()
 
 

@@ -28,14 +28,20 @@ def rays_for(view, w, h, extent, count, seed):
 
 
 def scene_file_of(grt, name, tmp_path):
-    if name == "instances":   # a floor and two emitters that stand still, 40 rotated / scaled instances that do not qualify
+    if name == "instances":   # a floor and two emitters, 40 rotated / scaled instances of one mesh
         return instanced_scene_file(str(tmp_path / "s"), count=40)
+    if name == "everything":  # textured floor (a scaled file mesh), the same mesh again as a rotated emitter, a rectangle emitter, two spheres
+        from scenes import write_scene_with_everything
+        from test_loaders import _png_bytes
+        return write_scene_with_everything(tmp_path, _png_bytes)
     return grt.scene_path(name)
 
 
-@pytest.mark.parametrize("name,w,h,extent,identity_instances,merge", [("cornellbox", 64, 48, 3.0, 8, 1), ("sponza", 96, 54, 14.0, 382, 1), ("sponza", 96, 54, 14.0, 382, 2), ("sponza", 96, 54, 14.0, 382, 3),
-                                                                       ("instances", 96, 64, 14.0, 3, 1), ("instances", 96, 64, 14.0, 3, 3)])
-def test_flattened_static_geometry_traces_like_one_blas_per_mesh(grt, oracle, tmp_path, name, w, h, extent, identity_instances, merge):
+@pytest.mark.parametrize("name,w,h,extent,identity_instances,flattened,merge", [
+    ("cornellbox", 64, 48, 3.0, 8, 8, 1), ("sponza", 96, 54, 14.0, 382, 384, 1), ("sponza", 96, 54, 14.0, 382, 384, 2), ("sponza", 96, 54, 14.0, 382, 382, 3),
+    ("instances", 96, 64, 14.0, 3, 3, 1),       # 40 instances of ONE mesh keep their TLAS leaves: an instanced mesh is not copied per instance
+    ("everything", 80, 60, 6.0, 3, 5, 1)])      # two transformed instances of a mesh among the five: world-space copies
+def test_flattened_static_geometry_traces_like_one_blas_per_mesh(grt, oracle, tmp_path, name, w, h, extent, identity_instances, flattened, merge):
     scene_file = scene_file_of(grt, name, tmp_path)
     scene_ref, pt_ref = staged(grt, scene_file, w, h, 0)
     reference = oracle.SceneView(pt_ref)
@@ -53,8 +59,8 @@ def test_flattened_static_geometry_traces_like_one_blas_per_mesh(grt, oracle, tm
     scene, pt = staged(grt, scene_file, w, h, merge)
     members = pt.static_geometry_members
     identity = int((roots_ref < 0).sum())
-    # merge_static 1 / 2: every instance (none has moved); 3: those with the identity transform
-    assert identity == identity_instances and members == (identity if merge == 3 else mesh_count) and members >= 2
+    # merge_static 1 / 2: every instance (none has moved) whose mesh is not instanced more than twice; 3: of those, the ones with the identity transform
+    assert identity == identity_instances and members == flattened and members >= 2
     flat = oracle.SceneView(pt)
 
     # ---- the layout ----
