@@ -248,8 +248,8 @@ def test_random_samples_are_bit_exact(grt, oracle):
     pt.close(); scene.close()
 
 
-def compare_frames(grt, oracle, pt, frames, w, h):
-    view = oracle.SceneView(pt)
+def compare_frames(grt, oracle, pt, frames, w, h, luts=None):
+    view = oracle.SceneView(pt, luts=luts)
     frame = oracle.Frame(view)
     nb = pt.device_config().num_bounces
     for f in range(frames):
