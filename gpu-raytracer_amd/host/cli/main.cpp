@@ -5,7 +5,8 @@
 //
 // Options without a counterpart in the reference: --device <ordinal>, --devices <a,b,...> (one frame split over several
 // GPUs: row tiles dealt round-robin, one RCCL all-gather per render(), host/FrameSplit.h), --bvh-cache <bool>
-// (the reference always uses its .bvh caches; here they are opt-in), --batch <n> samples per
+// (the reference always uses its .bvh caches; here they are opt-in), --merge-static <0..3> (the flattened static geometry of
+// DESIGN.md 4.6; 0 = the reference's one-tree-per-mesh layout), --batch <n> samples per
 // submission (default 4; 1 = one render() per sample exactly like the reference loop).
 #include <chrono>
 #include <cstdio>
@@ -117,6 +118,10 @@ std::vector<Option> make_options(CommandLine & cl) {
 		}
 	} });
 	o.push_back({ nullptr, "bvh-cache", "Enables or disables reading and writing <mesh>.bvh cache files", 1, [](const char * v) { cpu_config.enable_bvh_cache = parse_bool(v); } });
+	o.push_back({ nullptr, "merge-static", "Static instances flattened into one tree: 1 (default), 2 (no spatial splits), 3 (identity instances only), 0 (one BLAS per mesh under the TLAS, as the reference)", 1, [](const char * v) {
+		cpu_config.merge_static = parse_int(v, "--merge-static");
+		if (cpu_config.merge_static < 0 || cpu_config.merge_static > 3) die("--merge-static must be 0, 1, 2 or 3");
+	} });
 	o.push_back({ nullptr, "batch",     "Samples per submission to the device (1..16)", 1, [&cl](const char * v) {
 		cl.batch = parse_int(v, "--batch");
 		if (cl.batch < 1 || cl.batch > 16) die("--batch must be between 1 and 16");
