@@ -181,6 +181,8 @@ def host_lib():
         lib.grt_frame_split_rank.argtypes = [c_void_p, c_int]
         lib.grt_build_blas.restype = c_void_p
         lib.grt_build_blas.argtypes = [c_void_p, c_int]
+        lib.grt_build_static_bvh.restype = c_void_p
+        lib.grt_build_static_bvh.argtypes = [c_void_p, c_int, c_int]
         lib.grt_build_device_bvh.restype = c_void_p
         lib.grt_build_device_bvh.argtypes = [c_void_p, c_int, c_int]
         lib.grt_built_array.restype = c_void_p

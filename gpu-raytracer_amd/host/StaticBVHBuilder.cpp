@@ -133,17 +133,23 @@ struct Builder {
 	}
 
 	// Splits `refs` into two non-empty sets; returns the axis
-	int partition(std::vector<Ref> & refs, const AABB & node_box, std::vector<Ref> & left, std::vector<Ref> & right, AABB & left_box, AABB & right_box) const {
+	// `budget`: how many references spatial splits may still ADD below this node (in: the node's share, out: what is left for its
+	// children). Without one, triangles that overlap everywhere (a stack of large coplanar triangles) are cut again and again:
+	// 500 of them became 71 000 references. The share is dealt down the tree in proportion to the children's reference counts,
+	// so the tree does not depend on the order in which threads build its parts.
+	int partition(std::vector<Ref> & refs, const AABB & node_box, std::vector<Ref> & left, std::vector<Ref> & right, AABB & left_box, AABB & right_box, long & budget) const {
 		AABB centroid_box = AABB::create_empty();
 		for (const Ref & r : refs) centroid_box.expand(r.box.get_center());
 		Split object = find_object_split(refs, centroid_box);
 
 		Split spatial;
-		if (object.axis >= 0) {
-			AABB shared = AABB::overlap(object.left, object.right);
-			if ((shared.is_valid() ? shared.surface_area() : 0.0f) * inv_root_area > alpha) spatial = find_spatial_split(refs, node_box);
-		} else {
-			spatial = find_spatial_split(refs, node_box); // all centres in one point: only cutting the triangles can separate them
+		if (budget > 0) {
+			if (object.axis >= 0) {
+				AABB shared = AABB::overlap(object.left, object.right);
+				if ((shared.is_valid() ? shared.surface_area() : 0.0f) * inv_root_area > alpha) spatial = find_spatial_split(refs, node_box);
+			} else {
+				spatial = find_spatial_split(refs, node_box); // all centres in one point: only cutting the triangles can separate them
+			}
 		}
 
 		left.clear(); right.clear();
@@ -174,7 +180,9 @@ struct Builder {
 				left.push_back({ part_left, r.triangle });
 				right.push_back({ part_right, r.triangle });
 			}
-			if (!left.empty() && !right.empty() && left.size() < refs.size() && right.size() < refs.size()) { // both sides smaller: progress
+			long added = long(left.size()) + long(right.size()) - long(refs.size());
+			if (!left.empty() && !right.empty() && left.size() < refs.size() && right.size() < refs.size() && added <= budget) { // both sides smaller: progress; and paid for
+				budget -= added;
 				for (const Ref & r : left)  left_box .expand(r.box);
 				for (const Ref & r : right) right_box.expand(r.box);
 				return axis;
@@ -199,17 +207,24 @@ struct Builder {
 		return 0;
 	}
 
-	void build(Tree & tree, int node, std::vector<Ref> & refs) const {
+	static void share(long budget, size_t n_left, size_t n_right, long & left, long & right) {
+		left = long(double(budget) * double(n_left) / double(n_left + n_right));
+		right = budget - left;
+	}
+
+	void build(Tree & tree, int node, std::vector<Ref> & refs, long budget) const {
 		if (refs.size() == 1) { tree.nodes[size_t(node)].triangle = refs[0].triangle; return; }
 		std::vector<Ref> left, right;
 		AABB left_box, right_box;
-		int axis = partition(refs, tree.nodes[size_t(node)].box, left, right, left_box, right_box);
+		int axis = partition(refs, tree.nodes[size_t(node)].box, left, right, left_box, right_box, budget);
+		long budget_left, budget_right;
+		share(budget, left.size(), right.size(), budget_left, budget_right);
 		std::vector<Ref>().swap(refs);
 		int l = int(tree.nodes.size()); tree.nodes.emplace_back(); tree.nodes.emplace_back();
 		tree.nodes[size_t(l)].box = left_box; tree.nodes[size_t(l) + 1].box = right_box;
 		tree.nodes[size_t(node)].left = l; tree.nodes[size_t(node)].right = l + 1; tree.nodes[size_t(node)].axis = axis;
-		build(tree, l, left);
-		build(tree, l + 1, right);
+		build(tree, l, left, budget_left);
+		build(tree, l + 1, right, budget_right);
 	}
 };
 
@@ -231,19 +246,21 @@ void StaticBVHBuilder::build(BVH2 & bvh, const std::vector<Triangle> & triangles
 	if (thread_count <= 0) thread_count = int(std::max(1u, std::thread::hardware_concurrency()));
 	size_t piece = std::max<size_t>(1024, n / (size_t(thread_count) * 8));
 	Tree top; top.nodes.emplace_back(); top.nodes[0].box = root_box;
-	struct Pending { int node; std::vector<Ref> refs; };
+	struct Pending { int node; std::vector<Ref> refs; long budget; };
 	std::vector<Pending> open, pieces;
-	open.push_back({ 0, std::move(refs) });
+	open.push_back({ 0, std::move(refs), long(n) });   // spatial splits may double the references at most (Sponza: +16 %)
 	while (!open.empty()) {
 		std::vector<Pending> next;
 		for (Pending & p : open) {
 			if (p.refs.size() <= piece) { pieces.push_back(std::move(p)); continue; }
 			std::vector<Ref> left, right; AABB left_box, right_box;
-			int axis = builder.partition(p.refs, top.nodes[size_t(p.node)].box, left, right, left_box, right_box);
+			int axis = builder.partition(p.refs, top.nodes[size_t(p.node)].box, left, right, left_box, right_box, p.budget);
+			long budget_left, budget_right;
+			Builder::share(p.budget, left.size(), right.size(), budget_left, budget_right);
 			int l = int(top.nodes.size()); top.nodes.emplace_back(); top.nodes.emplace_back();
 			top.nodes[size_t(l)].box = left_box; top.nodes[size_t(l) + 1].box = right_box;
 			top.nodes[size_t(p.node)].left = l; top.nodes[size_t(p.node)].right = l + 1; top.nodes[size_t(p.node)].axis = axis;
-			next.push_back({ l, std::move(left) }); next.push_back({ l + 1, std::move(right) });
+			next.push_back({ l, std::move(left), budget_left }); next.push_back({ l + 1, std::move(right), budget_right });
 		}
 		open.swap(next);
 	}
@@ -259,7 +276,7 @@ void StaticBVHBuilder::build(BVH2 & bvh, const std::vector<Triangle> & triangles
 			Tree & tree = subtrees[i];
 			tree.nodes.reserve(2 * pieces[i].refs.size());
 			tree.nodes.emplace_back(); tree.nodes[0].box = top.nodes[size_t(pieces[i].node)].box;
-			builder.build(tree, 0, pieces[i].refs);
+			builder.build(tree, 0, pieces[i].refs, pieces[i].budget);
 		}
 	};
 	std::vector<std::thread> threads;

@@ -607,6 +607,18 @@ void * grt_build_blas(const float * tris24, int n) {
 		return md;
 	GRT_CATCH(nullptr)
 }
+// The builder of the flattened static geometry on its own (tests): binary tree in bvh2_*, its 8-wide collapse in bvh8_*.
+// threads <= 0: all hardware threads.
+void * grt_build_static_bvh(const float * tris24, int n, int threads) {
+	GRT_TRY
+		MeshData * md = new MeshData();
+		md->triangles.resize(n);
+		memcpy((void *)md->triangles.data(), tris24, size_t(n) * sizeof(Triangle));
+		StaticBVHBuilder::build(md->bvh2, md->triangles, threads);
+		if (n > 0) BVH8Converter(md->bvh8, md->bvh2).convert();
+		return md;
+	GRT_CATCH(nullptr)
+}
 // Experiments with the builder behind a CWBVH: spatial splits (SBVH: a triangle may sit in several leaves, `bvh8_indices` then
 // repeats it) and / or the insertion optimiser, then the same 8-wide collapse.
 void * grt_build_blas_variant(const float * tris24, int n, int spatial_splits, int optimize) {

@@ -204,3 +204,86 @@ def test_the_flattening_is_left_alone_where_it_does_not_apply(grt, tmp_path):
             assert pt.static_geometry_members == 0 and pt.array("alias_mesh_ids").size == 0 and pt.array("tlas_indices").size == 8
         pt.close(); scene.close()
     grt.config_reset()
+
+
+# ---- the builder of the flattened tree on its own (host/StaticBVHBuilder.cpp) ------------------------------------------------
+
+def build_static(grt, triangles, threads=0):
+    """(n, 3, 3) vertices -> BVH2 nodes (box min, box max, left_or_first, count | axis << 30), leaf -> triangle indices"""
+    import ctypes
+    lib = grt.host_lib()
+    t24 = np.zeros((len(triangles), 24), np.float32); t24[:, :9] = np.asarray(triangles, np.float32).reshape(-1, 9)
+    handle = lib.grt_build_static_bvh(t24.ctypes.data, len(triangles), threads)
+    assert handle, lib.grt_last_error()
+
+    def array(name, dtype):
+        size = ctypes.c_size_t(0); p = lib.grt_built_array(handle, name.encode(), ctypes.byref(size))
+        return np.frombuffer((ctypes.c_char * size.value).from_address(p), dtype=dtype).copy() if size.value else np.zeros(0, dtype)
+    nodes = array("bvh2_nodes", np.uint8).reshape(-1, 32); indices = array("bvh2_indices", np.int32); wide = array("bvh8_nodes", np.uint8)
+    lib.grt_built_free(handle)
+    return nodes, indices, wide
+
+
+def check_static_tree(nodes, indices, triangles, rng):
+    """What traversal relies on: one reference per leaf, children inside their parent, and -- the point of a spatial split --
+    every point of a triangle lies in the box of at least one of the leaves that reference it."""
+    boxes = nodes[:, :24].view(np.float32).reshape(-1, 2, 3); link = nodes[:, 24:28].view(np.int32).ravel(); word = nodes[:, 28:32].view(np.uint32).ravel()
+    count = word & 0x3fffffff
+    leaves_of = {}
+    todo, seen, leaf_order = [0], 0, []
+    while todo:
+        k = todo.pop(); seen += 1
+        if count[k]:
+            assert count[k] == 1                                                   # BVH8Converter wants one primitive per binary leaf
+            leaf_order.append(int(link[k])); leaves_of.setdefault(int(indices[link[k]]), []).append(k)
+            continue
+        for child in (link[k], link[k] + 1):
+            assert (boxes[child, 0] >= boxes[k, 0] - 1e-4).all() and (boxes[child, 1] <= boxes[k, 1] + 1e-4).all(), (k, child)
+            todo.append(int(child))
+    assert sorted(leaf_order) == list(range(len(indices))) and seen == len(nodes) - 1     # every node reached once (node 1 is the alignment dummy)
+    assert sorted(leaves_of) == list(range(len(triangles)))                              # every triangle referenced
+    for t in rng.choice(len(triangles), min(len(triangles), 400), replace=False):
+        w = rng.dirichlet((1, 1, 1), 60).astype(np.float32)
+        points = w @ np.asarray(triangles[t], np.float32)
+        covered = np.zeros(len(points), bool)
+        for k in leaves_of[int(t)]:
+            eps = 1e-4 * (1.0 + np.abs(boxes[k]).max())
+            covered |= ((points >= boxes[k, 0] - eps) & (points <= boxes[k, 1] + eps)).all(axis=1)
+        assert covered.all(), (int(t), len(leaves_of[int(t)]))
+    return max(len(v) for v in leaves_of.values())
+
+
+def test_static_bvh_builder_on_soups_slivers_and_degenerate_input(grt):
+    rng = np.random.default_rng(3)
+    soup = rng.uniform(-1, 1, (3000, 1, 3)) + rng.normal(size=(3000, 3, 3)) * 0.05
+    # long thin triangles crossing a cloud of small ones: what spatial splits are for
+    slivers = np.concatenate([soup[:1500], rng.uniform(-1, 1, (60, 1, 3)) * [1, 0.02, 1] + rng.normal(size=(60, 3, 3)) * [2.0, 0.01, 0.01]])
+    cases = {
+        "soup": soup, "slivers": slivers,
+        "one": soup[:1], "two": soup[:2], "three": soup[:3],
+        "copies": np.repeat(soup[:1], 64, axis=0),                                   # identical references: no plane separates them
+        "points": np.repeat(rng.uniform(-1, 1, (50, 1, 3)), 3, axis=1),              # zero-area triangles
+        "flat": np.concatenate([rng.uniform(-1, 1, (500, 3, 2)), np.zeros((500, 3, 1))], axis=2),   # all in the plane z = 0
+        "scales": np.concatenate([rng.uniform(-1, 1, (800, 1, 3)) + rng.normal(size=(800, 3, 3)) * 1e-3, rng.normal(size=(4, 3, 3)) * 30.0]),
+    }
+    for name, triangles in cases.items():
+        nodes, indices, wide = build_static(grt, triangles)
+        assert wide.size % 80 == 0 and wide.size > 0
+        most = check_static_tree(nodes, indices, triangles, rng)
+        assert len(indices) >= len(triangles) and len(indices) <= 3 * len(triangles) + 8, (name, len(indices))   # splits duplicate references, within reason
+        if name == "slivers":
+            assert most > 1                                                       # the long ones were cut
+        if name in ("one", "two", "three", "copies", "points"):
+            assert len(indices) == len(triangles)                                 # nothing to gain from cutting these
+    nodes, indices, wide = build_static(grt, np.zeros((0, 3, 3)))
+    assert len(indices) == 0 and wide.size == 0
+
+
+def test_static_bvh_builder_does_not_depend_on_the_thread_count(grt):
+    """The pieces handed to the threads are subtrees of ONE tree that every thread count splits the same way."""
+    rng = np.random.default_rng(4)
+    triangles = rng.uniform(-1, 1, (20000, 1, 3)) + rng.normal(size=(20000, 3, 3)) * 0.03
+    reference = build_static(grt, triangles, threads=1)
+    for threads in (2, 3, 8):
+        again = build_static(grt, triangles, threads=threads)
+        assert all(np.array_equal(a, b) for a, b in zip(reference, again)), threads
