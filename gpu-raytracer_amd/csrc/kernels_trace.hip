@@ -1203,7 +1203,9 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	}
 }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8(RtParams p) { trace_stream<false>(p, nullptr); }
-__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_flat(RtParams p) { trace_stream<false, true>(p, nullptr); }
+// (7 waves per SIMD: without the TLAS / instance state the engine fits 72 registers with no scratch; 1.045-1.052 ms of traversal per step
+// against 1.056-1.059 with 6 -- profiles/r03_flattened_static_geometry.txt)
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, 7) kernel_trace_stream_bvh8_flat(RtParams p) { trace_stream<false, true>(p, nullptr); }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_counting(RtParams p, unsigned long long * stats) { trace_stream<true>(p, stats); }
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {
