@@ -114,3 +114,29 @@ def test_pixel_query_names_the_scene_instance_behind_a_flattened_hit(grt):
         pt.close(); scene.close()
     assert answers[0] == answers[1]
     grt.config_reset()
+
+
+def test_alias_and_entry_errors_are_reported(grt):
+    import ctypes
+    lib = grt.device_lib()
+    lib.rt_upload_triangle_aliases.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.rt_set_static_geometry.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    ctx = ctypes.c_void_p()
+    assert lib.rt_create(0, ctypes.byref(ctx)) == 0
+    assert lib.rt_set_static_geometry(ctx, 0) == 0                                   # nothing to change
+    assert lib.rt_set_static_geometry(ctx, 1) != 0 and b"CWBVH" in lib.rt_last_error(ctx)          # no geometry yet
+    names = np.full(4, -1, np.int32)
+    assert lib.rt_upload_triangle_aliases(ctx, names.ctypes.data, names.ctypes.data) != 0 and b"no geometry" in lib.rt_last_error(ctx)
+    lib.rt_destroy(ctx)
+    scene, pt = make_pathtracer(grt, "cornellbox", 32, 32, 0, merge_static=0)
+    count = pt.array("triangles").size // 24
+    rows, triangles = np.full(count, -1, np.int32), np.full(count, -1, np.int32)
+    rows[5], triangles[5] = 0, 7; rows[7], triangles[7] = 0, 2                        # copy 5 names triangle 7, itself a copy
+    assert lib.rt_upload_triangle_aliases(pt.ctx, rows.ctypes.data, triangles.ctypes.data) != 0 and b"not itself a copy" in lib.rt_last_error(pt.ctx)
+    rows[7] = -1; triangles[5] = count                                               # out of range
+    assert lib.rt_upload_triangle_aliases(pt.ctx, rows.ctypes.data, triangles.ctypes.data) != 0
+    triangles[5] = 7
+    assert lib.rt_upload_triangle_aliases(pt.ctx, rows.ctypes.data, triangles.ctypes.data) == 0    # a legal alias: hits on triangle 5 report (row 0, triangle 7)
+    assert lib.rt_upload_triangle_aliases(pt.ctx, None, None) == 0                   # and cleared again
+    pt.render()
+    pt.close(); scene.close(); grt.config_reset()
