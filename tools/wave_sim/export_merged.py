@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""Experiment input for wave_sim: ALL triangles of the scene's identity instances in ONE bottom-level tree (host SAH builder +
-CWBVH converter over the concatenated triangles), no top-level tree. Header field tlas_count = 0 tells wave_sim to start in the BLAS."""
+"""Experiment input for wave_sim: ALL triangles of the scene in ONE bottom-level tree, no top-level tree (header field
+tlas_count = 0 tells wave_sim to start inside the tree) -- how the flattened static geometry of DESIGN.md 4.6 was priced
+before it was built.   export_merged.py <scene> <out.bin> [builder] [optimise]
+builder: 0 = the per-mesh SAH sweep (BVH.cpp), 1 = the reference's SBVH (SBVH.cpp), 2 = StaticBVHBuilder (binned object +
+spatial splits, all threads); optimise: 1 = Bittner's insertion optimiser on the binary tree; then the 8-wide collapse
+(environment GRT_PRIMITIVE_COST: the collapse's cost of a triangle test relative to a node step)."""
 import ctypes, os, struct, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -8,6 +8,7 @@
 //
 //   g++ -O2 -std=c++17 -fopenmp -o /tmp/wave_sim tools/wave_sim/wave_sim.cpp
 //   python tools/wave_sim/export_scene.py sponza && /tmp/wave_sim /tmp/wave_sim_sponza.bin
+//   python tools/wave_sim/export_merged.py sponza /tmp/flat.bin 2 && /tmp/wave_sim /tmp/flat.bin      (one tree over everything: DESIGN.md 4.6)
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
