@@ -366,7 +366,10 @@ void Integrator::build_tlas() {
 				moved = true;
 			}
 		}
-		if (moved) init_geometry();   // flatten what still stands still (a one-off stall of a build + upload, per instance that starts to move)
+		if (moved) { // flatten what still stands still (a one-off stall of a build + upload, per instance that starts to move)
+			init_geometry();
+			if (cpu_config.device_blas > 0) geometry_was_rebuilt();   // (host-built trees: the originals keep their places, the copies are the tail)
+		}
 	}
 	bool whole_scene = flat.active && flat.movers.empty();   // everything is in the flattened tree: rays start inside it, there is no TLAS
 	if (flat.active) { // one TLAS leaf for the flattened tree (leaf 0 of the build), one per instance that has moved

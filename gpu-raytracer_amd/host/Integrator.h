@@ -146,6 +146,10 @@ struct Integrator {
 	bool aov_is_enabled(AOVType t) const { return gpu_config.aov_mask & (1u << int(t)); }
 
 	void build_tlas();
+	// build_tlas has run init_geometry again (a flattened instance moved). With trees built on the device the triangles of the
+	// other meshes may have changed places too (leaf positions are dealt over all trees together): whatever names device
+	// triangles by index has to follow -- the path tracer's light tables.
+	virtual void geometry_was_rebuilt() { }
 
 	virtual void update(float delta);
 	virtual void render() = 0;

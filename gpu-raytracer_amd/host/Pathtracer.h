@@ -37,6 +37,7 @@ struct Pathtracer final : Integrator {
 	void render_samples(int count);
 
 	void calc_light_power();
+	void geometry_was_rebuilt() override { if (scene.has_lights) calc_light_power(); }   // light_triangle_indices name device triangles
 	void calc_light_mesh_weights();
 
 };
