@@ -250,17 +250,39 @@ void StaticBVHBuilder::build(BVH2 & bvh, const std::vector<Triangle> & triangles
 	std::vector<Pending> open, pieces;
 	open.push_back({ 0, std::move(refs), long(n) });   // spatial splits may double the references at most (Sponza: +16 %)
 	while (!open.empty()) {
+		// one level: its nodes are independent of each other -- split them on as many threads as there are nodes (the first levels
+		// have one, two, four nodes: those few passes over all references are what stays sequential), then number the children
+		// in the order of their parents so that the tree does not depend on which thread was first
+		struct Cut { bool is_piece = true; std::vector<Ref> left, right; AABB left_box, right_box; int axis = 0; long budget_left = 0, budget_right = 0; };
+		std::vector<Cut> cuts(open.size());
+		std::atomic<size_t> next_node { 0 };
+		auto split_level = [&]() {
+			for (size_t i = next_node++; i < open.size(); i = next_node++) {
+				Pending & p = open[i];
+				if (p.refs.size() <= piece) continue;
+				Cut & c = cuts[i];
+				c.is_piece = false;
+				long budget = p.budget;
+				c.axis = builder.partition(p.refs, top.nodes[size_t(p.node)].box, c.left, c.right, c.left_box, c.right_box, budget);
+				Builder::share(budget, c.left.size(), c.right.size(), c.budget_left, c.budget_right);
+				std::vector<Ref>().swap(p.refs);
+			}
+		};
+		{
+			std::vector<std::thread> helpers;
+			for (int t = 1; t < thread_count && size_t(t) < open.size(); t++) helpers.emplace_back(split_level);
+			split_level();
+			for (std::thread & t : helpers) t.join();
+		}
 		std::vector<Pending> next;
-		for (Pending & p : open) {
-			if (p.refs.size() <= piece) { pieces.push_back(std::move(p)); continue; }
-			std::vector<Ref> left, right; AABB left_box, right_box;
-			int axis = builder.partition(p.refs, top.nodes[size_t(p.node)].box, left, right, left_box, right_box, p.budget);
-			long budget_left, budget_right;
-			Builder::share(p.budget, left.size(), right.size(), budget_left, budget_right);
+		for (size_t i = 0; i < open.size(); i++) {
+			Pending & p = open[i];
+			Cut & c = cuts[i];
+			if (c.is_piece) { pieces.push_back(std::move(p)); continue; }
 			int l = int(top.nodes.size()); top.nodes.emplace_back(); top.nodes.emplace_back();
-			top.nodes[size_t(l)].box = left_box; top.nodes[size_t(l) + 1].box = right_box;
-			top.nodes[size_t(p.node)].left = l; top.nodes[size_t(p.node)].right = l + 1; top.nodes[size_t(p.node)].axis = axis;
-			next.push_back({ l, std::move(left), budget_left }); next.push_back({ l + 1, std::move(right), budget_right });
+			top.nodes[size_t(l)].box = c.left_box; top.nodes[size_t(l) + 1].box = c.right_box;
+			top.nodes[size_t(p.node)].left = l; top.nodes[size_t(p.node)].right = l + 1; top.nodes[size_t(p.node)].axis = c.axis;
+			next.push_back({ l, std::move(c.left), c.budget_left }); next.push_back({ l + 1, std::move(c.right), c.budget_right });
 		}
 		open.swap(next);
 	}
