@@ -6,8 +6,8 @@
 // tree, quickly. So: the same two kinds of split as Stich et al.'s SBVH -- object splits and spatial splits with reference
 // unsplitting, chosen by SAH cost, spatial ones only tried where the object split's children overlap -- but found by BINNING
 // (32 bins per axis) instead of full sweeps over three sorted lists, over references that carry their own clipped box, and
-// built by all host threads: the top of the tree is split breadth-first on the calling thread until the pieces are small, the
-// pieces are independent subtrees built in parallel. One triangle reference per leaf, as BVH8Converter wants them; a triangle
+// built by all host threads: the top of the tree is split level by level (the nodes of a level in parallel) until the pieces are
+// small, the pieces are independent subtrees built in parallel. One triangle reference per leaf, as BVH8Converter wants them; a triangle
 // cut by spatial splits appears in several leaves (the device copies it once per reference).
 #include "BVH.h"
 #include "Config.h"
