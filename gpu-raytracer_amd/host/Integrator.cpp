@@ -180,7 +180,9 @@ void Integrator::init_geometry() {
 				bool joins = !instance_has_moved[i] && uses[size_t(scene.meshes[i].mesh_data_handle.handle)] <= 2 && (cpu_config.merge_static != 3 || scene.meshes[i].has_identity_transform());
 				(joins ? flat.members : flat.movers).push_back(int(i));
 			}
-			if (flat.members.size() < 2) { flat.members.clear(); flat.movers.clear(); }
+			size_t triangles_to_copy = 0;
+			for (int member : flat.members) triangles_to_copy += mesh_datas[size_t(scene.meshes[size_t(member)].mesh_data_handle.handle)].triangles.size();
+			if (flat.members.size() < 2 || triangles_to_copy == 0) { flat.members.clear(); flat.movers.clear(); }   // nothing to gain / nothing to build a tree over
 		}
 		std::vector<Triangle> world;   // the members' triangles in world space, in member order
 		if (!flat.members.empty()) {
