@@ -314,3 +314,13 @@ def test_svgf_frames_with_a_moving_camera_do_not_depend_on_the_flattening(grt, o
         assert np.array_equal(runs[0][0][f], runs[1][0][f]), f
     assert runs[0][1][3].mean() > 2.0 and (runs[0][1][3] == 0).any()          # most pixels reproject over the four frames, some are disoccluded
     grt.config_reset()
+
+
+def test_static_bvh_builder_survives_non_finite_vertices(grt):
+    """A broken mesh must not hang the build (the splits fall back to halving lists whose boxes cannot be compared)."""
+    rng = np.random.default_rng(1)
+    triangles = rng.uniform(-1, 1, (2000, 1, 3)) + rng.normal(size=(2000, 3, 3)) * 0.05
+    for poison in (np.nan, np.inf, 3e38):
+        broken = triangles.copy(); broken[5, 1, 2] = poison; broken[100, 0, 0] = poison
+        nodes, indices, wide = build_static(grt, broken)
+        assert len(indices) >= 2000 and sorted(set(indices.tolist())) == list(range(2000)) and wide.size > 0
