@@ -147,7 +147,7 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_pass
     passes = pmc_pass.run_passes(args.steps, args.warmup, groups=pmc_pass.DEFAULT_GROUPS + ["TCC_HIT_sum TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"],
-                                  extra_args=("--merge-static", str(args.merge_static)))
+                                  extra_args=("--merge-static", str(args.merge_static), "--node-format", args.node_format))
     kernels = passes["kernels"]
     out = {"pmc_errors": passes["errors"]} if passes["errors"] else {}
     trace = kernels.get(TRACE_KERNEL[0])
@@ -325,6 +325,7 @@ def main():
     ap.add_argument("--no-povs", action="store_true", help="skip the sweep over the reference's 9 fixed Sponza points of view (N = 1 only)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: render only rank 0's tiles of an N-GPU split on one GPU (no collective), to exercise the N > 1 code path")
     ap.add_argument("--merge-static", type=int, default=1, help="1 (default): the 382 instances of Sponza that stand still with the identity transform are flattened into one bottom-level tree (config merge_static); 0: one BLAS per mesh under the TLAS, the reference's layout")
+    ap.add_argument("--node-format", choices=["decoded", "reference"], default="decoded", help="decoded (default): the traversal launches read the library's 96-byte decoded copy of the CWBVH nodes; reference: the uploaded 80-byte nodes (rt_set_node_format)")
     ap.add_argument("--batch", type=int, default=SPP, help="samples per pixel per submission (rt_render_samples), 1..%d" % SPP)
     ap.add_argument("--samples-in-flight", type=int, default=0, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
     args = ap.parse_args()
@@ -369,9 +370,12 @@ def main():
     pt.update()
     if pt.static_geometry_whole_scene:
         TRACE_KERNEL[0] = "kernel_trace_stream_bvh8_flat"   # the engine variant without TLAS / instance code
+    if args.node_format == "decoded":
+        TRACE_KERNEL[0] += "_decoded"
     closed = False
     lib = grt.device_lib()
     ctx = pt.ctx
+    grt.set_node_format(ctx, args.node_format)
     scheduler = os.environ.get("BENCH_SCHEDULER", "merged")     # "slots": the per-submission launch chains, for comparison
     grt.set_scheduler(ctx, scheduler)
     split_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
@@ -608,6 +612,7 @@ def main():
                 "scheduler": scheduler,
                 "acceleration_structure": (("%d of %d instances (all that stand still) flattened into one CWBVH of %d triangle copies" + (", no TLAS: rays start inside the tree (rt_set_static_geometry)" if pt.static_geometry_whole_scene else ", one TLAS leaf beside the other instances") + ", hits reported as the scene's own instances and triangles (rt_upload_triangle_aliases); tree built on the host in %.2f s (SAH object + spatial splits, all threads; at scene load, not in the timed region); --merge-static 0 runs the reference's layout")
                                            % (pt.static_geometry_members, scene.mesh_count, int((pt.array("alias_mesh_ids") >= 0).sum()), pt.static_geometry_build_seconds)) if pt.static_geometry_members else "one CWBVH per mesh under a CWBVH TLAS (the reference's layout)",
+                "node_format": ("decoded: the traversal launches read the library's 96-byte decoded copy of the 80-byte CWBVH nodes (same floats, exponent / meta bytes pre-expanded; rt_set_node_format)" if args.node_format == "decoded" else "reference: the uploaded 80-byte CWBVH nodes"),
                 "rays_per_step": round(rays_plan / args.steps), "shadow_rays_per_step": round(shadow_plan / args.steps),
                 "mrays_s_including_shadow": round((rays_plan + shadow_plan) / elapsed / 1e6, 1),
                 "ms_per_4spp_frame": round(elapsed / args.steps * SPP * 1e3, 3),

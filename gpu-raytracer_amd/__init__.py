@@ -177,6 +177,8 @@ def host_lib():
         lib.grt_frame_split_update.argtypes = [c_void_p, c_float]
         lib.grt_frame_split_render.argtypes = [c_void_p]
         lib.grt_frame_split_render_samples.argtypes = [c_void_p, c_int]
+        lib.grt_frame_split_submitting_threads.restype = c_int
+        lib.grt_frame_split_submitting_threads.argtypes = [c_void_p]
         lib.grt_frame_split_rank.restype = c_void_p
         lib.grt_frame_split_rank.argtypes = [c_void_p, c_int]
         lib.grt_build_blas.restype = c_void_p
@@ -618,6 +620,11 @@ class FrameSplit:
         view.close = lambda: None      # owned by the split
         return view
 
+    @property
+    def submitting_threads(self):
+        """Host threads that enqueue the ranks' launches: one per rank (0 for a single rank: the caller's thread)."""
+        return int(host_lib().grt_frame_split_submitting_threads(self.handle))
+
     def update(self, delta=0.0):
         _host_check(host_lib().grt_frame_split_update(self.handle, float(delta)))
 
@@ -747,6 +754,19 @@ def set_scheduler(ctx, scheduler):
     lib = device_lib()
     lib.rt_set_scheduler.argtypes = [c_void_p, c_int]
     _dev_check(ctx, lib.rt_set_scheduler(ctx, int(scheduler)))
+
+
+NODES_REFERENCE, NODES_DECODED = 0, 1
+
+
+def set_node_format(ctx, node_format):
+    """'decoded' (default): the merged wavefront walks the library's 96-byte decoded copy of the CWBVH nodes;
+    'reference': the uploaded 80-byte nodes (rt_set_node_format). Hits are identical."""
+    if isinstance(node_format, str):
+        node_format = {"reference": NODES_REFERENCE, "decoded": NODES_DECODED}[node_format]
+    lib = device_lib()
+    lib.rt_set_node_format.argtypes = [c_void_p, c_int]
+    _dev_check(ctx, lib.rt_set_node_format(ctx, int(node_format)))
 
 
 def set_frame_pipelining(ctx, enable):

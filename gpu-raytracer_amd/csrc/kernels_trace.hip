@@ -140,6 +140,68 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 	return hit_mask;
 }
 
+// ---- decoded nodes (96 B) -------------------------------------------------------------------------
+// The merged wavefront walks a copy of the node array that kernel_decode_nodes (below) has re-laid for this loop. The 80-byte
+// CWBVH node is a storage format: to use it a lane spends 6 instructions expanding three exponent bytes, 14 (two of them
+// quarter-rate integer multiplies) turning the two meta words into shift amounts, before the first of the 48 fused
+// multiply-adds. A decoded node carries what those instructions produce -- NOT different numbers: every float the slab tests
+// see is bit for bit the one bvh8_node_intersect computes from the 80 bytes, so hits stay identical to the oracle's, which
+// keeps walking the reference's bytes --
+//   float4 0: p.x, p.y, p.z, (e_x << 23) | imask     the x scale 2^e_x as float bits, imask in its (zero) low mantissa byte
+//   float4 1: 2^e_y, 2^e_z, child base index, triangle base index
+//   float4 2: meta[0..3], meta[4..7], inner[0..3], inner[4..7]     inner: 0x07 in the byte of every inner child
+//   float4 3..5: quantised planes as in the reference (lo[0..3], lo[4..7], hi[0..3], hi[4..7]) for x, y, z
+// and the two planes of a child and axis go through ONE v_pk_fma_f32 (CDNA3+: two fp32 fused multiply-adds per lane and
+// issue slot; each half is the IEEE fma of its operands, as v_fma_f32 is).
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define RT_NODE_WIDE_FLOAT4 6
+RT_DEV unsigned bvh8_node_intersect_decoded(const Ray3 & ray, f3 inv_dir, unsigned oct_inv4, float max_distance,
+                                            float4 n0, float4 n1, float4 n2, float4 n3, float4 n4, float4 n5) {
+	f3 p = mk3(n0.x, n0.y, n0.z);
+	f3 adjusted_dir_inv = mk3(
+		__uint_as_float(__float_as_uint(n0.w) & 0x7f800000u) * inv_dir.x,
+		n1.x * inv_dir.y,
+		n1.y * inv_dir.z);
+	f3 adjusted_origin = (p - ray.origin) * inv_dir;
+	const v2f ax = { adjusted_dir_inv.x, adjusted_dir_inv.x }, ox = { adjusted_origin.x, adjusted_origin.x };
+	const v2f ay = { adjusted_dir_inv.y, adjusted_dir_inv.y }, oy = { adjusted_origin.y, adjusted_origin.y };
+	const v2f az = { adjusted_dir_inv.z, adjusted_dir_inv.z }, oz = { adjusted_origin.z, adjusted_origin.z };
+
+	bool neg_x = ray.direction.x < 0.0f, neg_y = ray.direction.y < 0.0f, neg_z = ray.direction.z < 0.0f;
+
+	unsigned hit_mask = 0;
+	#pragma unroll
+	for (int i = 0; i < 2; i++) {
+		unsigned meta4  = __float_as_uint(i == 0 ? n2.x : n2.y);
+		unsigned inner4 = __float_as_uint(i == 0 ? n2.z : n2.w);
+		unsigned bit_index4 = meta4 ^ (oct_inv4 & inner4);   // a shift uses the low 5 bits of its amount: the count bits above them need no mask
+
+		unsigned q_lo_x = __float_as_uint(i == 0 ? n3.x : n3.y), q_hi_x = __float_as_uint(i == 0 ? n3.z : n3.w);
+		unsigned q_lo_y = __float_as_uint(i == 0 ? n4.x : n4.y), q_hi_y = __float_as_uint(i == 0 ? n4.z : n4.w);
+		unsigned q_lo_z = __float_as_uint(i == 0 ? n5.x : n5.y), q_hi_z = __float_as_uint(i == 0 ? n5.z : n5.w);
+
+		unsigned x_min = neg_x ? q_hi_x : q_lo_x, x_max = neg_x ? q_lo_x : q_hi_x;
+		unsigned y_min = neg_y ? q_hi_y : q_lo_y, y_max = neg_y ? q_lo_y : q_hi_y;
+		unsigned z_min = neg_z ? q_hi_z : q_lo_z, z_max = neg_z ? q_lo_z : q_hi_z;
+
+		#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			v2f qx = { float(extract_byte(x_min, j)), float(extract_byte(x_max, j)) };
+			v2f qy = { float(extract_byte(y_min, j)), float(extract_byte(y_max, j)) };
+			v2f qz = { float(extract_byte(z_min, j)), float(extract_byte(z_max, j)) };
+			v2f tx = __builtin_elementwise_fma(qx, ax, ox);
+			v2f ty = __builtin_elementwise_fma(qy, ay, oy);
+			v2f tz = __builtin_elementwise_fma(qz, az, oz);
+
+			float tmin = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
+			float tmax = fminf(fminf(tx.y, ty.y), fminf(tz.y, max_distance));
+
+			if (tmin < tmax) hit_mask |= (extract_byte(meta4, j) >> 5) << (extract_byte(bit_index4, j) & 31u);
+		}
+	}
+	return hit_mask;
+}
+
 // ---- narrow mode: 8 lanes per ray ---------------------------------------------------------------
 // A launch of a few thousand rays cannot fill 64-lane waves with one ray per lane, and its duration is
 // the dependent chain of its longest ray: ~150 steps of ~400 VALU instructions (4 cycles each on a
@@ -365,7 +427,8 @@ template<int MODE, typename Source> RT_DEV void source_finish(const Source & src
 // base address: no compare / select of two 64-bit bases and no scalar load of the TLAS size in every round.
 // FLAT: the whole scene is one world-space tree rooted in node 0 (rt_set_static_geometry): there is no TLAS to walk, no instance
 // to enter or leave, no object-space ray -- the code for those and the three registers that track them are compiled out.
-template<int MODE, bool COUNT, bool NARROW, bool UNIFIED = false, bool FLAT = false, typename Source>
+// WIDE: nodes are read from the decoded copy of the unified node array (bvh8_node_intersect_decoded; wide engine of the merged wavefront only).
+template<int MODE, bool COUNT, bool NARROW, bool UNIFIED = false, bool FLAT = false, bool WIDE = false, typename Source>
 RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr, int ray_count_2 = 0, int * cursor_2 = nullptr) {
 	constexpr bool SHADOW = MODE == RT_TRACE_SHADOW;   // the kind of every ray, unless MODE == RT_TRACE_MIXED: then lane_shadow
 	bool lane_shadow = SHADOW;
@@ -532,18 +595,32 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					unsigned relative_index = __popc(hits_imask & ~(0xffffffffu << slot_index));
 					unsigned child_node_index = child_index_base + relative_index;
 
+					unsigned hitmask, imask;
+					if constexpr (WIDE) {
+						static_assert(UNIFIED && !NARROW, "decoded nodes: the wide engine of the merged wavefront");
+						// 32-bit byte offset from a uniform base (global_load ... v_offset, s[base]): the 64-bit multiply-add of the general form is
+						// a quarter-rate instruction. rt_api.hip selects this engine only while nodes and triangles fit (RT_DECODED_MAX_*).
+						const float4 * node = (const float4 *)((const char *)p.bvh8_nodes_wide + __umul24(child_node_index, RT_NODE_WIDE_FLOAT4 * 16u));
+						float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4], n5 = node[5];
+						if (COUNT) count_nodes++;
+						hitmask = bvh8_node_intersect_decoded(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, n5);
+						imask = __float_as_uint(n0.w) & 0xffu;
+						current_group .x = __float_as_uint(n1.z);
+						triangle_group.x = __float_as_uint(n1.w);
+					} else {
 					const float4 * node = (!UNIFIED && child_node_index < unsigned(p.tlas_node_count) ? p.tlas_nodes : nodes) + size_t(child_node_index) * 5;
 					float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
 					if (COUNT) count_nodes++;
 #ifdef RT_PHASE_STATS
 					if (COUNT && !SHADOW) { phase_node_lanes++; if (RT_PHASE_LEADER()) phase_node_execs++; }
 #endif
-					unsigned hitmask = NARROW ? group8_or(bvh8_node_intersect_child(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, group_child))
-					                          : bvh8_node_intersect(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
-					unsigned imask = extract_byte(__float_as_uint(n0.w), 3);
+					hitmask = NARROW ? group8_or(bvh8_node_intersect_child(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, group_child))
+					                 : bvh8_node_intersect(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
+					imask = extract_byte(__float_as_uint(n0.w), 3);
 
 					current_group .x = __float_as_uint(n1.x);
 					triangle_group.x = __float_as_uint(n1.y);
+					}
 					current_group .y = (hitmask & 0xff000000u) | imask;
 					triangle_group.y = (hitmask & 0x00ffffffu);
 				}
@@ -616,7 +693,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 							int triangle_index = int(msb(triangle_group.y));
 							triangle_group.y &= ~(1u << triangle_index);
 							tri_id[k] = int(triangle_group.x) + triangle_index;
-							const float4 * tri = triangles + size_t(tri_id[k]) * 3;
+							const float4 * tri = WIDE ? (const float4 *)((const char *)triangles + ((unsigned(tri_id[k]) * 3u) << 4)) : triangles + size_t(tri_id[k]) * 3;
 							tri_a[k] = tri[0]; tri_b[k] = tri[1]; tri_c[k] = tri[2].x; // position_0, edge_1, edge_2
 						}
 					}
@@ -1175,7 +1252,7 @@ struct MixedStreamSource {
 	RT_DEV void load(bool is_shadow, int i, Ray3 & ray, float & max_distance) const { if (is_shadow) shadow.load(i, ray, max_distance); else closest.load(i, ray, max_distance); }
 	RT_DEV void finish(bool is_shadow, int i, const HitRecord & hit, bool occluded) const { if (is_shadow) shadow.finish(i, hit, occluded); else closest.finish(i, hit, occluded); }
 };
-template<bool COUNT, bool FLAT = false>
+template<bool COUNT, bool FLAT = false, bool WIDE = false>
 RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	const int q = p.stream_iteration & 1;
 	MixedStreamSource src { { p.trace[q].origin, p.trace[q].direction, p.trace[q].hits },
@@ -1196,16 +1273,22 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	if (!COUNT && closest_count + shadow_count <= RT_NARROW_MAX_RAYS)
 		bvh8_trace_engine<RT_TRACE_MIXED, false, true, true, FLAT>(p, src, closest_count, &p.stream->cursor[q][0], nullptr, shadow_count, &p.stream->cursor[q][1]);
 	else if (COUNT || closest_count + shadow_count <= RT_MIXED_MAX_RAYS)
-		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true, FLAT>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true, FLAT, WIDE>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
 	else {
-		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true, FLAT>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
-		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true, FLAT>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true, FLAT, WIDE>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
+		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true, FLAT, WIDE>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
 	}
 }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8(RtParams p) { trace_stream<false>(p, nullptr); }
 // (7 waves per SIMD: without the TLAS / instance state the engine fits 72 registers with no scratch; 1.045-1.052 ms of traversal per step
 // against 1.056-1.059 with 6 -- profiles/r03_flattened_static_geometry.txt)
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, 7) kernel_trace_stream_bvh8_flat(RtParams p) { trace_stream<false, true>(p, nullptr); }
+// The same two launches on the decoded copy of the node array (rt_set_node_format; the default of the merged wavefront).
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_decoded(RtParams p) { trace_stream<false, false, true>(p, nullptr); }
+#ifndef RT_FLAT_DECODED_WAVES
+#define RT_FLAT_DECODED_WAVES 7
+#endif
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_FLAT_DECODED_WAVES) kernel_trace_stream_bvh8_flat_decoded(RtParams p) { trace_stream<false, true, true>(p, nullptr); }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_counting(RtParams p, unsigned long long * stats) { trace_stream<true>(p, stats); }
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {
@@ -1216,6 +1299,26 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, const float * max_distance, uint8_t * occluded, int ray_count, int * retired) {
 	ShadowExplicitSource src { origin, direction, max_distance, occluded };
 	RT_TRACE_ENGINE<true, false>(p, src, ray_count, retired);
+}
+
+// 80-byte CWBVH nodes [first, first + count) -> their decoded form (see "decoded nodes" above). One thread per node; runs when the
+// geometry changes (all nodes) and when a new TLAS has been copied into its slots (those slots).
+__global__ void kernel_decode_nodes(const uint4 * __restrict__ nodes, uint4 * __restrict__ decoded, int first, int count) {
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= count) return;
+	const uint4 * src = nodes + size_t(first + i) * 5;
+	uint4 n0 = src[0], n1 = src[1];
+	unsigned e_imask = n0.w;
+	auto inner7 = [](unsigned meta4) { return (((meta4 & (meta4 << 1)) & 0x10101010u) >> 4) * 7u; };   // 0b001xxxxx with xxxxx >= 24: an inner child
+	uint4 * dst = decoded + size_t(first + i) * RT_NODE_WIDE_FLOAT4;
+	dst[0] = make_uint4(n0.x, n0.y, n0.z, (extract_byte(e_imask, 0) << 23) | extract_byte(e_imask, 3));
+	dst[1] = make_uint4(extract_byte(e_imask, 1) << 23, extract_byte(e_imask, 2) << 23, n1.x, n1.y);
+	dst[2] = make_uint4(n1.z, n1.w, inner7(n1.z), inner7(n1.w));
+	dst[3] = src[2]; dst[4] = src[3]; dst[5] = src[4];
+}
+void rt_launch_decode_nodes(const void * nodes, void * decoded, int first, int count, hipStream_t stream) {
+	if (count <= 0) return;
+	hipLaunchKernelGGL(kernel_decode_nodes, dim3((count + 255) / 256), dim3(256), 0, stream, (const uint4 *)nodes, (uint4 *)decoded, first, count);
 }
 
 // Persistent grid: enough workgroups to fill every CU to the occupancy the kernel reaches,
@@ -1284,8 +1387,18 @@ void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, hipS
 		return;
 	}
 	if (p.entry_tlas_stack_size == 0) {   // the whole scene is one world-space tree: the engine without the TLAS / instance code
+		if (p.bvh8_nodes_wide) {
+			static int grid_flat_decoded = trace_grid_size((const void *)kernel_trace_stream_bvh8_flat_decoded);
+			hipLaunchKernelGGL(kernel_trace_stream_bvh8_flat_decoded, dim3(grid_flat_decoded), dim3(RT_TRACE_BLOCK), 0, stream, p);
+			return;
+		}
 		static int grid_flat = trace_grid_size((const void *)kernel_trace_stream_bvh8_flat);
 		hipLaunchKernelGGL(kernel_trace_stream_bvh8_flat, dim3(grid_flat), dim3(RT_TRACE_BLOCK), 0, stream, p);
+		return;
+	}
+	if (p.bvh8_nodes_wide) {
+		static int grid_decoded = trace_grid_size((const void *)kernel_trace_stream_bvh8_decoded);
+		hipLaunchKernelGGL(kernel_trace_stream_bvh8_decoded, dim3(grid_decoded), dim3(RT_TRACE_BLOCK), 0, stream, p);
 		return;
 	}
 	static int grid = trace_grid_size((const void *)kernel_trace_stream_bvh8);

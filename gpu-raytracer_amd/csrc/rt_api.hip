@@ -178,6 +178,10 @@ struct rt_context {
 	size_t tlas_node_bytes = 80;        // what the current TLAS version was uploaded as (80 CWBVH, 32 binary, 128 4-wide)
 	int lowest_blas_root = 0x7fffffff;  // over the instances uploaded last: the node slots below it are free for the TLAS copy of the merged wavefront
 	unsigned long long tlas_version = 0, tlas_version_in_nodes = ~0ull;   // the merged wavefront traces a copy of the TLAS inside the BLAS node array (stream_sync_tlas)
+	// ... and walks a DECODED copy of that array (96 B per node, kernels_trace.hip "decoded nodes"; rt_set_node_format)
+	int node_format = RT_NODES_DECODED;
+	void * bvh8_nodes_wide = nullptr; size_t wide_node_capacity = 0;
+	bool wide_nodes_stale = true;       // the BLAS part has to be decoded again (new geometry)
 	size_t bvh4_node_count = 0;
 	size_t bvh8_node_count = 0, bvh2_node_count = 0, triangle_count = 0;
 	size_t mesh_count = 0;
@@ -510,7 +514,7 @@ int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle
 	s = upload(ctx, &ctx->bvh8_nodes, bvh8_nodes, node_count * 80); if (s) return s;
 	s = upload_triangle_positions(ctx, triangles, triangle_count); if (s) return s;
 	ctx->triangle_count = triangle_count; ctx->bvh8_node_count = node_count;
-	ctx->tlas_version_in_nodes = ~0ull;
+	ctx->tlas_version_in_nodes = ~0ull; ctx->wide_nodes_stale = true;
 	ctx->params.triangles  = (const float4 *)ctx->triangles;
 	ctx->params.bvh8_nodes = (const float4 *)ctx->bvh8_nodes;
 	return RT_OK;
@@ -645,7 +649,7 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	device_free(ctx, ctx->triangles); device_free(ctx, ctx->triangle_positions); device_free(ctx, ctx->bvh8_nodes);
 	ctx->triangles = out_triangles; ctx->triangle_positions = out_positions; ctx->bvh8_nodes = out_nodes;
 	ctx->triangle_count = T; ctx->bvh8_node_count = size_t(node_count);
-	ctx->tlas_version_in_nodes = ~0ull;
+	ctx->tlas_version_in_nodes = ~0ull; ctx->wide_nodes_stale = true;
 	ctx->params.triangles = (const float4 *)out_triangles; ctx->params.triangle_positions = (const float4 *)out_positions; ctx->params.bvh8_nodes = (const float4 *)out_nodes;
 	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID;
 	if (out_root_indices) for (size_t m = 0; m < M; m++) out_root_indices[m] = int32_t(reserved_tlas_nodes + m);
@@ -1347,7 +1351,14 @@ int rt_comm_destroy(rt_context * ctx) {
 		for (rt_context *& p : peer->exchange.peers) if (p == ctx) p = nullptr;
 	}
 	x.peers.clear();
+	if (x.ev_packed || x.packed) {   // (a later group may have another world size: its buffers and events are made again, exchange_buffers)
+		(void)hipSetDevice(ctx->device);
+		(void)hipStreamSynchronize(ctx->stream);
+	}
 	if (x.ev_packed) { (void)hipEventDestroy(x.ev_packed); (void)hipEventDestroy(x.ev_copied); x.ev_packed = x.ev_copied = nullptr; }
+	if (x.packed)   device_free(ctx, x.packed);
+	if (x.gathered) device_free(ctx, x.gathered);
+	x.packed = x.gathered = nullptr; x.packed_pixels = 0;
 	x.rank = 0; x.world = 1;
 	return RT_OK;
 }
@@ -1427,7 +1438,7 @@ static int exchange_group(rt_context ** contexts, int count, int what) {
 
 int rt_all_gather_framebuffer(rt_context * ctx) {
 	RT_REQUIRE(ctx, ctx, "rt_all_gather_framebuffer: NULL context");
-	if (ctx->exchange.world == 1) return RT_OK;
+	if (ctx->exchange.world == 1 && !ctx->exchange.comm) return RT_OK;   // (a 1-rank communicator does run its ncclAllGather: tests/test_gpu_rccl.py)
 	RT_REQUIRE(ctx, ctx->exchange.comm, "rt_all_gather_framebuffer: no communicator (rt_comm_init_rank), or an in-process group (use rt_all_gather_framebuffers)");
 	return exchange_group(&ctx, 1, 0);
 }
@@ -1524,6 +1535,16 @@ int rt_set_scheduler(rt_context * ctx, int scheduler) {
 	(void)hipSetDevice(ctx->device);
 	RT_HIP(ctx, quiesce(ctx));
 	ctx->scheduler = scheduler;
+	return RT_OK;
+}
+
+int rt_set_node_format(rt_context * ctx, int format) {
+	RT_REQUIRE(ctx, ctx && (format == RT_NODES_REFERENCE || format == RT_NODES_DECODED), "rt_set_node_format: unknown format");
+	if (ctx->node_format == format) return RT_OK;
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	ctx->node_format = format;
+	ctx->tlas_version_in_nodes = ~0ull; ctx->wide_nodes_stale = true;   // the next submission brings the copy up to date (or drops it)
 	return RT_OK;
 }
 
@@ -1837,9 +1858,34 @@ static int stream_complete(rt_context * ctx, const StreamSubmission * subs, int 
 // per-submission chains that keep frames of different scene versions in flight) is copied into the slots [0, node count)
 // that the BLAS node array reserves for it -- node indices below the TLAS size never name BLAS nodes. Nothing of the merged
 // wavefront is in flight when the TLAS changes (every upload completes it first), and the other kernels never read those slots.
+// The decoded copy follows: all nodes after new geometry, the TLAS slots after a new TLAS (both on the wavefront's stream, behind
+// the launches that still read the old contents).
+static int stream_sync_decoded_nodes(rt_context * ctx, int tlas_slots) {
+	ctx->params.bvh8_nodes_wide = nullptr;
+	if (ctx->node_format != RT_NODES_DECODED || !ctx->bvh8_nodes || ctx->bvh8_node_count == 0) return RT_OK;
+	if (ctx->bvh8_node_count > RT_DECODED_MAX_NODES || ctx->triangle_count > RT_DECODED_MAX_TRIANGLES) return RT_OK;   // beyond its 32-bit offsets: the 80-byte walk
+	hipStream_t st = ctx->path_stream.stream;
+	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));
+	if (ctx->wide_node_capacity < ctx->bvh8_node_count) {
+		RT_HIP(ctx, hipStreamSynchronize(st));
+		device_free(ctx, ctx->bvh8_nodes_wide); ctx->bvh8_nodes_wide = nullptr; ctx->wide_node_capacity = 0;
+		int s = device_alloc(ctx, &ctx->bvh8_nodes_wide, ctx->bvh8_node_count * 96); if (s) return s;
+		ctx->wide_node_capacity = ctx->bvh8_node_count; ctx->wide_nodes_stale = true;
+	}
+	if (ctx->wide_nodes_stale) rt_launch_decode_nodes(ctx->bvh8_nodes, ctx->bvh8_nodes_wide, 0, int(ctx->bvh8_node_count), st);
+	else rt_launch_decode_nodes(ctx->bvh8_nodes, ctx->bvh8_nodes_wide, 0, tlas_slots, st);
+	RT_HIP(ctx, hipGetLastError());
+	ctx->wide_nodes_stale = false;
+	ctx->params.bvh8_nodes_wide = (const float4 *)ctx->bvh8_nodes_wide;
+	return RT_OK;
+}
+
 static int stream_sync_tlas(rt_context * ctx) {
 	if (ctx->tlas_version_in_nodes == ctx->tlas_version) return RT_OK;
-	if (!ctx->params.tlas_nodes || ctx->params.tlas_node_count <= 0) { ctx->tlas_version_in_nodes = ctx->tlas_version; return RT_OK; }   // one BVH, no TLAS: node 0 is its root
+	if (!ctx->params.tlas_nodes || ctx->params.tlas_node_count <= 0) {   // one BVH, no TLAS: node 0 is its root
+		int s = stream_sync_decoded_nodes(ctx, 0); if (s) return s;
+		ctx->tlas_version_in_nodes = ctx->tlas_version; return RT_OK;
+	}
 	if (!ctx->bvh8_nodes || size_t(ctx->params.tlas_node_count) > ctx->bvh8_node_count) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_samples: the TLAS does not fit the node slots the geometry reserves for it");
 	// the copy below overwrites node slots [0, tlas_node_count): they must be CWBVH nodes and must not hold BLAS nodes (the host
 	// classes reserve 2 x meshes slots in front of the first BLAS; a C-API caller with another layout gets an error, not a
@@ -1849,6 +1895,7 @@ static int stream_sync_tlas(rt_context * ctx) {
 	hipStream_t st = ctx->path_stream.stream;
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));
 	RT_HIP(ctx, hipMemcpyAsync(ctx->bvh8_nodes, ctx->params.tlas_nodes, size_t(ctx->params.tlas_node_count) * 80, hipMemcpyDeviceToDevice, st));
+	int s = stream_sync_decoded_nodes(ctx, ctx->params.tlas_node_count); if (s) return s;
 	ctx->tlas_version_in_nodes = ctx->tlas_version;
 	return RT_OK;
 }

@@ -10,8 +10,17 @@
 // from anywhere in the previous frame).
 // The same protocol as the class it wraps: update(delta); render(); ... save_image(). Ranks that share a device
 // ordinal (tests on one GPU) exchange by peer copies, see rt_comm_init_all.
+// One submitting thread per device: render() / render_samples() hand every rank's launches to that rank's own
+// worker thread -- an iteration of the wavefront is ~6 kernel launches per rank, and one host thread enqueueing them for 8 GPUs
+// in turn would make every GPU wait for the seven others' launch overhead. update() stays on the calling thread (the ranks
+// share the host scene and its camera), the exchange is one grouped call after the workers have enqueued their frames.
 #pragma once
+#include <condition_variable>
+#include <exception>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "Pathtracer.h"
@@ -37,8 +46,18 @@ struct FrameSplit {
 	std::vector<float> read_framebuffer() { return ranks.front()->read_framebuffer(); }
 	void save_image(const std::string & filename) { ranks.front()->save_image(filename); }
 
+	int submitting_threads() const { return int(workers.size()); }   // 0 for a single rank (the caller's thread submits)
+
 private:
+	struct Worker {
+		std::thread thread;
+		std::mutex mutex; std::condition_variable wake, done;
+		std::function<void()> job; bool busy = false, stop = false;
+		std::exception_ptr error;
+	};
+	std::vector<std::unique_ptr<Worker>> workers;   // workers[r] submits for ranks[r]
 	std::vector<rt_context *> contexts;
+	void on_every_rank(const std::function<void(int)> & job);   // job(r) on rank r's thread, all ranks concurrently; rethrows the first failure
 	void exchange();
 	void check(rt_context * ctx, int status) const;
 };

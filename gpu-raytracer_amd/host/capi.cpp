@@ -397,6 +397,7 @@ int grt_frame_split_render_samples(void * split, int count) {
 		return 0;
 	GRT_CATCH(-1)
 }
+int grt_frame_split_submitting_threads(void * split) { return ((FrameSplit *)split)->submitting_threads(); }
 // the integrator of one rank (a grt_pathtracer_* handle owned by the split): its framebuffer is the whole frame after render()
 void * grt_frame_split_rank(void * split, int rank) {
 	FrameSplit * s = (FrameSplit *)split;

@@ -345,6 +345,15 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count);
  *   choice for scenes that upload a new TLAS every frame.                                                           */
 enum { RT_SCHEDULER_MERGED = 0, RT_SCHEDULER_SLOTS = 1 };
 int rt_set_scheduler(rt_context * ctx, int scheduler);
+/* Which bytes the traversal launches of the merged scheduler read a CWBVH node from.
+ * RT_NODES_DECODED (default): a device-side copy of the node array that the library keeps next to the uploaded one, 96 bytes
+ *   per node -- the same node with its exponent bytes expanded to float scales and its meta bytes split into the shift words the
+ *   slab loop needs (kernels_trace.hip, "decoded nodes"). Every float the traversal computes is bit for bit the one it computes
+ *   from the reference's 80 bytes (CUDA/Raytracing/BVH8.h:29-111), so hits are identical; the node step is ~20 % shorter.
+ *   The copy is refreshed by the library when geometry or the TLAS change; callers keep uploading 80-byte nodes.
+ * RT_NODES_REFERENCE: traverse the uploaded 80-byte nodes themselves.                                                    */
+enum { RT_NODES_REFERENCE = 0, RT_NODES_DECODED = 1 };
+int rt_set_node_format(rt_context * ctx, int format);
 /* Merged scheduler: one more iteration of the wavefront without new samples (no-op when nothing is in flight), and the
  * number of submissions whose accumulate step has been enqueued so far -- a frame loop that hands every completed
  * frame to a collective calls rt_advance / rt_render_samples and packs the frame when the count moves

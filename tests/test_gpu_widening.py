@@ -107,6 +107,7 @@ def test_frame_split_in_one_process_without_python_collectives(grt):
             scene, pt = make_pathtracer(grt, "cornellbox", 200, 152, -1, **config)
             pt.close()
             split = grt.FrameSplit(scene, 200, 152, [0] * world)
+            assert split.submitting_threads == (world if world > 1 else 0)   # one submitting thread per rank
             for step in steps:
                 split.update()
                 if step == "render":
