@@ -106,7 +106,11 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 		unsigned meta4 = __float_as_uint(i == 0 ? n1.z : n1.w);
 
 		unsigned is_inner4   = (meta4 & (meta4 << 1)) & 0x10101010u;
+#ifdef RT_REF_CHEAP_META
+		unsigned inner_mask4 = ((is_inner4 >> 4) << 3) - (is_inner4 >> 4);   // 0x07 per inner child: a shift and a subtraction instead of the quarter-rate multiply
+#else
 		unsigned inner_mask4 = sign_extend_s8x4(is_inner4 << 3);
+#endif
 		unsigned bit_index4  = (meta4 ^ (oct_inv4 & inner_mask4)) & 0x1f1f1f1fu;
 		unsigned child_bits4 = (meta4 >> 5) & 0x07070707u;
 
@@ -120,12 +124,20 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 
 		#pragma unroll
 		for (int j = 0; j < 4; j++) {
+#ifdef RT_REF_PK
+			typedef float pk2 __attribute__((ext_vector_type(2)));
+			pk2 tx = __builtin_elementwise_fma(pk2{ float(extract_byte(x_min, j)), float(extract_byte(x_max, j)) }, pk2{ adjusted_dir_inv.x, adjusted_dir_inv.x }, pk2{ adjusted_origin.x, adjusted_origin.x });
+			pk2 ty = __builtin_elementwise_fma(pk2{ float(extract_byte(y_min, j)), float(extract_byte(y_max, j)) }, pk2{ adjusted_dir_inv.y, adjusted_dir_inv.y }, pk2{ adjusted_origin.y, adjusted_origin.y });
+			pk2 tz = __builtin_elementwise_fma(pk2{ float(extract_byte(z_min, j)), float(extract_byte(z_max, j)) }, pk2{ adjusted_dir_inv.z, adjusted_dir_inv.z }, pk2{ adjusted_origin.z, adjusted_origin.z });
+			float tx0 = tx.x, tx1 = tx.y, ty0 = ty.x, ty1 = ty.y, tz0 = tz.x, tz1 = tz.y;
+#else
 			float tx0 = __builtin_fmaf(float(extract_byte(x_min, j)), adjusted_dir_inv.x, adjusted_origin.x);
 			float ty0 = __builtin_fmaf(float(extract_byte(y_min, j)), adjusted_dir_inv.y, adjusted_origin.y);
 			float tz0 = __builtin_fmaf(float(extract_byte(z_min, j)), adjusted_dir_inv.z, adjusted_origin.z);
 			float tx1 = __builtin_fmaf(float(extract_byte(x_max, j)), adjusted_dir_inv.x, adjusted_origin.x);
 			float ty1 = __builtin_fmaf(float(extract_byte(y_max, j)), adjusted_dir_inv.y, adjusted_origin.y);
 			float tz1 = __builtin_fmaf(float(extract_byte(z_max, j)), adjusted_dir_inv.z, adjusted_origin.z);
+#endif
 
 			float tmin = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, 0.0f));
 			float tmax = fminf(fminf(tx1, ty1), fminf(tz1, max_distance));
@@ -154,7 +166,9 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 // and the two planes of a child and axis go through ONE v_pk_fma_f32 (CDNA3+: two fp32 fused multiply-adds per lane and
 // issue slot; each half is the IEEE fma of its operands, as v_fma_f32 is).
 typedef float v2f __attribute__((ext_vector_type(2)));
-#define RT_NODE_WIDE_FLOAT4 6
+#ifndef RT_NODE_WIDE_FLOAT4
+#define RT_NODE_WIDE_FLOAT4 6   // (8: one 128-byte cache line per node, an experiment; rt_api.hip allocates 128 B per node either way)
+#endif
 RT_DEV unsigned bvh8_node_intersect_decoded(const Ray3 & ray, f3 inv_dir, unsigned oct_inv4, float max_distance,
                                             float4 n0, float4 n1, float4 n2, float4 n3, float4 n4, float4 n5) {
 	f3 p = mk3(n0.x, n0.y, n0.z);
@@ -189,9 +203,15 @@ RT_DEV unsigned bvh8_node_intersect_decoded(const Ray3 & ray, f3 inv_dir, unsign
 			v2f qx = { float(extract_byte(x_min, j)), float(extract_byte(x_max, j)) };
 			v2f qy = { float(extract_byte(y_min, j)), float(extract_byte(y_max, j)) };
 			v2f qz = { float(extract_byte(z_min, j)), float(extract_byte(z_max, j)) };
+#ifdef RT_DECODED_NO_PK
+			v2f tx = { __builtin_fmaf(qx.x, ax.x, ox.x), __builtin_fmaf(qx.y, ax.x, ox.x) };
+			v2f ty = { __builtin_fmaf(qy.x, ay.x, oy.x), __builtin_fmaf(qy.y, ay.x, oy.x) };
+			v2f tz = { __builtin_fmaf(qz.x, az.x, oz.x), __builtin_fmaf(qz.y, az.x, oz.x) };
+#else
 			v2f tx = __builtin_elementwise_fma(qx, ax, ox);
 			v2f ty = __builtin_elementwise_fma(qy, ay, oy);
 			v2f tz = __builtin_elementwise_fma(qz, az, oz);
+#endif
 
 			float tmin = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
 			float tmax = fminf(fminf(tx.y, ty.y), fminf(tz.y, max_distance));

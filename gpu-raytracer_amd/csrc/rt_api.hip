@@ -825,6 +825,7 @@ int rt_build_tlas(rt_context * ctx, const int32_t * root_indices, const int32_t 
 	ctx->mesh_count = n; ctx->params.mesh_count = int(n);
 	ctx->params.tlas_nodes = (const float4 *)tlas_device;
 	ctx->params.tlas_node_count = int(2 * n);     // the node slots reserved for the TLAS; BLAS nodes start behind them
+	ctx->params.entry_tlas_stack_size = RT_INVALID;   // node 0 is a TLAS root from now on: rays start above the instances (rt_set_static_geometry(ctx, 1) does not survive a TLAS build)
 	ctx->tlas_version++;
 	ctx->params.mesh_bvh_root_indices = a.out_root_indices;
 	ctx->params.mesh_material_ids     = a.out_material_ids;
@@ -1869,7 +1870,7 @@ static int stream_sync_decoded_nodes(rt_context * ctx, int tlas_slots) {
 	if (ctx->wide_node_capacity < ctx->bvh8_node_count) {
 		RT_HIP(ctx, hipStreamSynchronize(st));
 		device_free(ctx, ctx->bvh8_nodes_wide); ctx->bvh8_nodes_wide = nullptr; ctx->wide_node_capacity = 0;
-		int s = device_alloc(ctx, &ctx->bvh8_nodes_wide, ctx->bvh8_node_count * 96); if (s) return s;
+		int s = device_alloc(ctx, &ctx->bvh8_nodes_wide, ctx->bvh8_node_count * 128); if (s) return s;   // (96 bytes per node in use; room for the 128-byte experiment, RT_NODE_WIDE_FLOAT4 = 8)
 		ctx->wide_node_capacity = ctx->bvh8_node_count; ctx->wide_nodes_stale = true;
 	}
 	if (ctx->wide_nodes_stale) rt_launch_decode_nodes(ctx->bvh8_nodes, ctx->bvh8_nodes_wide, 0, int(ctx->bvh8_node_count), st);

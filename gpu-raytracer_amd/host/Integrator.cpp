@@ -350,6 +350,14 @@ void Integrator::build_tlas() {
 	if (wants_device_tlas()) {
 		// Everything in scene order; the device sorts, builds and re-orders (replaces the SAH build, the CWBVH conversion and
 		// the table shuffle below: Integrator.cpp:399-430 of the reference)
+		if (static_geometry.active) {
+			// the device TLAS was switched on (device_tlas, enable_scene_update) after the scene had been flattened: a device-built TLAS
+			// has a leaf per scene instance and knows nothing of the flattened tree, its aliases or a ray entry inside node 0 --
+			// stage the geometry again the reference's way (init_geometry does not flatten while wants_device_tlas() holds)
+			init_geometry();
+			if (cpu_config.device_blas > 0) geometry_was_rebuilt();
+			check(rt_set_static_geometry(ctx, 0));
+		}
 		fill_scene_order_tables();
 		check(rt_build_tlas(ctx, scene_order_roots.data(), scene_order_materials.data(), scene_order_transforms[0].cells, scene_order_transforms_inv[0].cells,
 		                    scene_order_transforms_prev[0].cells, scene_order_boxes.data(), mesh_count));

@@ -39,11 +39,34 @@ def assert_queues_agree(got, want, label, rel=0.002, slack=2):
         assert (np.abs(got[name] - want[name]) <= slack + rel * want[name]).all(), (label, name, got[name].tolist(), want[name].tolist())
 
 
-def assert_frames_agree(got, want, label, rel_tol=REL_L1_TOL, outlier_tol=OUTLIER_FRACTION_TOL, outlier_step=0.01):
+REL_L2_TOL = 2e-3   # per-pixel L2 (see pixel_l2): the bound BASELINE.md section 4 / north_star ask for, stated in DESIGN.md section 2
+
+
+def pixel_l2(got, want):
+    """Per-pixel L2 distance of two RGB frames, as ONE number: the root of the mean (over pixels) squared Euclidean RGB distance,
+    relative to the root-mean-square pixel of the expected frame. Unlike the relative L1 next to it, it is dominated by the FEW
+    pixels that differ a lot (a path whose roulette / acceptance decision flipped carries a whole different sample)."""
+    d2 = ((got.astype(np.float64) - want) ** 2).sum(axis=2)
+    return float(np.sqrt(d2.mean()) / np.sqrt((want.astype(np.float64) ** 2).sum(axis=2).mean()))
+
+
+def record(label, **numbers):
+    """The numbers behind the assertions, kept for DESIGN.md (gpurun_out/ travels back from the GPU box)."""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_numbers.txt"), "a") as f:
+            f.write("%-44s %s\n" % (label, "  ".join("%s %.3g" % kv for kv in numbers.items())))
+    except OSError:
+        pass
+
+
+def assert_frames_agree(got, want, label, rel_tol=REL_L1_TOL, outlier_tol=OUTLIER_FRACTION_TOL, outlier_step=0.01, l2_tol=REL_L2_TOL):
     assert np.isfinite(got).all(), label
     rel = np.abs(got - want).sum() / want.sum()
     outliers = (np.abs(got - want).max(axis=2) > outlier_step * (want.max(axis=2) + 1e-3)).mean()
-    assert rel < rel_tol and outliers < outlier_tol, (label, rel, outliers)
+    l2 = pixel_l2(got, want)
+    record(label, rel_l1=rel, outlier_fraction=outliers, pixel_l2=l2, worst_pixel=float(np.abs(got - want).max()))
+    assert rel < rel_tol and outliers < outlier_tol and l2 < l2_tol, (label, rel, outliers, l2)
 
 
 def test_benchmarked_sponza_frame_matches_the_oracle(grt, oracle):
@@ -63,7 +86,16 @@ def test_benchmarked_sponza_frame_matches_the_oracle(grt, oracle):
     got_queues = queues_of(pt.counters(), nb)     # the last submission: its 4 samples summed per bounce
     got = pt.read_framebuffer()[:, :W, :3].copy()
 
-    frame = oracle.Frame(oracle.SceneView(pt))
+    # The oracle renders the REFERENCE'S LAYOUT of the same scene -- one CWBVH per mesh under the TLAS, 384 instance entries,
+    # object-space rays for the two transformed instances -- staged by a second integrator without a device (merge_static 0).
+    # The device frame comes from the DEFAULT layout (all 384 instances flattened into one world-space tree with spatial
+    # splits, the engine without TLAS code, decoded nodes): what is benchmarked meets what the reference defines in one
+    # comparison, exact ties between coplanar triangles and world-space copies included.
+    assert pt.static_geometry_whole_scene and pt.static_geometry_members == 384
+    grt.config_set(merge_static=0)
+    staged = grt.Pathtracer(scene, W, H, device=-1); staged.update()
+    assert staged.static_geometry_members == 0
+    frame = oracle.Frame(oracle.SceneView(staged))
     want_queues = {name: np.zeros(nb, np.int64) for name in QUEUES}
     for s in range(bench.SPP):
         oc = queues_of(frame.render_sample(s), nb)
@@ -71,8 +103,9 @@ def test_benchmarked_sponza_frame_matches_the_oracle(grt, oracle):
             want_queues[name] += oc[name]
     assert want_queues["trace"][0] == bench.SPP * W * H and want_queues["plastic"].sum() > 0
     assert_queues_agree(got_queues, want_queues, "bench frame")
-    assert_frames_agree(got, frame.final[:, :W, :3], "bench frame")
-    pt.close(); scene.close()
+    assert_frames_agree(got, frame.final[:, :W, :3], "bench frame (default layout) vs oracle (reference layout)")
+    staged.close(); pt.close(); scene.close()
+    grt.config_reset()
 
 
 def test_sponza_svgf_taa_with_a_moving_camera_at_full_size(grt, oracle):

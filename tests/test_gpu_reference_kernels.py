@@ -144,3 +144,67 @@ def test_thin_lens_camera_hdr_sky_and_instances_on_the_device(grt, oracle, tmp_p
     totals = render_and_compare(grt, oracle, pt, w, 3, 1e-4, 2e-3)
     assert totals["plastic"] > 2000 and totals["shadow"] == 0              # lit by the sky alone
     pt.close(); scene.close(); grt.config_reset()
+
+
+def _one_hop(grt, oracle, scene, w, h, frames, rel_tol, outlier_tol, l2_tol, label, luts=None):
+    """The device renders the DEFAULT layout of `scene` (static instances flattened into one world-space tree: aliases, re-indexed
+    light tables, decoded nodes, the engine without TLAS code when nothing is left outside); the reference's own kernels render
+    the REFERENCE'S layout of the same scene, staged by a second integrator that has no device (merge_static 0). One comparison,
+    no restated oracle and no second device run in between."""
+    from test_gpu_full_size import pixel_l2, record
+    grt.config_set(merge_static=1)
+    pt = grt.Pathtracer(scene, w, h, device=0); pt.update()
+    assert pt.static_geometry_members >= 2
+    if luts == "device":
+        pt.render(); luts = grt.read_luts(pt.ctx); pt.close()
+        pt = grt.Pathtracer(scene, w, h, device=0); pt.update()
+    grt.config_set(merge_static=0)
+    staged = grt.Pathtracer(scene, w, h, device=-1); staged.update()
+    assert staged.static_geometry_members == 0
+    theirs = reference_frame(oracle, oracle.SceneView(staged, luts=luts))
+    nb = pt.device_config().num_bounces
+    totals = {}
+    for f in range(frames):
+        if f:
+            pt.update()
+        pt.render()
+        c = pt.counters()
+        rc = theirs.render_sample(pt.sample_index)
+        for queue in QUEUES:
+            got, want = list(getattr(c, queue)[:nb]), [int(v) for v in rc[queue][:nb]]
+            assert got[0] == want[0] and all(abs(a - b) <= 2 + 0.002 * b for a, b in zip(got, want)), (label, f, queue, got, want)
+            totals[queue] = totals.get(queue, 0) + sum(got)
+        got, want = pt.read_framebuffer()[:, :w, :3], theirs.final[:, :w, :3]
+        assert np.isfinite(got).all() and np.isfinite(want).all()
+        rel = np.abs(got - want).sum() / want.sum()
+        outliers = (np.abs(got - want).max(axis=2) > 0.01 * (want.max(axis=2) + 1e-3)).mean()
+        l2 = pixel_l2(got, want)
+        record("%s frame %d (one hop)" % (label, f), rel_l1=rel, outlier_fraction=outliers, pixel_l2=l2)
+        assert rel < rel_tol and outliers < outlier_tol and l2 < l2_tol, (label, f, rel, outliers, l2)
+    theirs.close(); staged.close(); pt.close()
+    return totals
+
+
+def test_benchmark_scene_in_the_default_layout_meets_the_references_kernels_in_one_hop(grt, oracle):
+    """The benchmarked configuration -- Sponza, odd materials rough plastic, BC1 textures, NEE + MIS + RR -- at 640x360, rendered
+    by the device in the layout bench.py times (all 384 instances flattened, kernel_trace_stream_bvh8_flat_decoded) against
+    Src/CUDA/Pathtracer.cu walking the reference's own TLAS + 383 BLAS."""
+    grt.config_reset()
+    scene = grt.Scene(grt.scene_path("sponza"))
+    for i in range(1, scene.material_count, 2):
+        if scene.material_type(i) == grt.MATERIAL_DIFFUSE:
+            scene.set_material(i, grt.MATERIAL_PLASTIC, None, 0.3)
+    grt.config_set(num_bounces=5)
+    totals = _one_hop(grt, oracle, scene, 640, 360, 2, 3e-4, 2e-3, 3e-3, "sponza plastic 640x360")
+    assert totals["diffuse"] > 120000 and totals["plastic"] > 120000 and totals["shadow"] > 200000
+    scene.close(); grt.config_reset()
+
+
+def test_scene_with_everything_in_the_default_layout_meets_the_references_kernels_in_one_hop(grt, oracle, tmp_path):
+    from test_loaders import _png_bytes
+    from scenes import write_scene_with_everything
+    grt.config_reset()
+    scene = grt.Scene(write_scene_with_everything(tmp_path, _png_bytes)); scene.set_sky_scale(0.3)
+    totals = _one_hop(grt, oracle, scene, 216, 144, 3, 2e-4, 3e-3, 3e-3, "scene with everything", luts="device")
+    assert totals["plastic"] > 20000 and totals["dielectric"] > 5000 and totals["conductor"] > 1500 and totals["shadow"] > 20000
+    scene.close(); grt.config_reset()

@@ -130,3 +130,26 @@ def test_merged_wavefront_on_a_scene_with_more_instances_than_its_lds_root_table
             pt.close(); scene.close()
         assert np.array_equal(images[0], images[1]) and images[0][..., :3].max() > 0, device_tlas
     grt.config_reset()
+
+
+def test_device_tlas_switched_on_after_the_scene_was_flattened(grt, oracle, tmp_path):
+    """A scene is staged with its static instances flattened (the default; here the whole scene: rays start inside node 0). Then
+    device_tlas is switched on at run time: the TLAS the device builds has a leaf per scene instance and node 0 becomes its
+    root -- the integrator has to stage the reference's layout again and rt_build_tlas has to move the ray entry back above the
+    instances, or every ray would read TLAS leaves as triangles. Frames before and after against the oracle."""
+    from test_gpu_parity import compare_frames
+    path = instanced_scene_file(str(tmp_path / "s"), count=2)     # floor + two emitters + 2 blobs of one mesh: all five stand still, all are flattened
+    grt.config_reset(); grt.config_set(num_bounces=4)
+    scene = grt.Scene(path); grt.config_set(num_bounces=4)
+    pt = grt.Pathtracer(scene, 160, 100, device=0); pt.update()
+    assert pt.static_geometry_whole_scene and pt.static_geometry_members == scene.mesh_count
+    compare_frames(grt, oracle, pt, 2, 160, 100)
+    grt.config_set(device_tlas=1)
+    pt.invalidate("scene"); pt.update()
+    assert pt.static_geometry_members == 0 and not pt.static_geometry_whole_scene
+    compare_frames(grt, oracle, pt, 2, 160, 100)
+    position, rotation, scale = scene.mesh_transform(4)
+    scene.set_mesh_transform(4, (position[0] + 1.0, position[1], position[2]), rotation, scale)
+    pt.invalidate("scene"); pt.update()
+    compare_frames(grt, oracle, pt, 2, 160, 100)
+    pt.close(); scene.close(); grt.config_reset()
