@@ -71,7 +71,9 @@ def build_scene(grt):
     """BASELINE config #2: Sponza, every odd diffuse material -> roughplastic alpha 0.3."""
     grt.config_reset()
     grt.config_set(merge_static=MERGE_STATIC)
-    scene = grt.Scene(grt.scene_path("sponza"))
+    # the reference's own 19 diffuse maps when build() could install them (assets/_cache, see install_reference_sponza_textures),
+    # else the quarter-size maps that travel inside the repository, every texel replicated 4x4
+    scene = grt.Scene(grt.scene_path("sponza_reference_maps" if grt.reference_sponza_textures_installed() else "sponza"))
     for i in range(1, scene.material_count, 2):
         if scene.material_type(i) == grt.MATERIAL_DIFFUSE:
             scene.set_material(i, grt.MATERIAL_PLASTIC, None, 0.3)
@@ -313,6 +315,46 @@ def config3_section(grt, scene, device, stream_gbps, frames=64):
         grt.config_set(enable_svgf=0, enable_taa=0)
 
 
+def reference_layout_section(grt, device, steps, warmup, node_format):
+    """The same frame loop on the REFERENCE'S acceleration-structure layout (config merge_static 0: one CWBVH per mesh under a
+    CWBVH TLAS, 384 instance entries), in the same process on the same GPU, so that the line the driver records carries both
+    layouts: the headline is measured on the flattened tree, a layout the reference does not have."""
+    import ctypes
+    global MERGE_STATIC
+    keep = MERGE_STATIC
+    MERGE_STATIC = 0
+    try:
+        scene = build_scene(grt)
+        pt = grt.Pathtracer(scene, WIDTH, HEIGHT, device=device)
+        try:
+            pt.update()
+            lib, ctx = grt.device_lib(), pt.ctx
+            grt.set_node_format(ctx, node_format)
+            lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+            lib.rt_synchronize.argtypes = [ctypes.c_void_p]
+            def submit(samples):
+                for _ in range(0, samples, SPP):
+                    if lib.rt_render_samples(ctx, 0, SPP) != 0:
+                        raise RuntimeError(lib.rt_last_error(ctx).decode())
+            submit(max(warmup, SPP)); lib.rt_synchronize(ctx)
+            lib.rt_render_samples(ctx, 0, 1); c = pt.counters(); rays = int(sum(c.trace[:NUM_BOUNCES]))   # closest-hit rays of one sample
+            grt.set_profiling(ctx, 2)
+            t0 = time.perf_counter()
+            submit(steps)
+            lib.rt_synchronize(ctx)
+            elapsed = time.perf_counter() - t0
+            trace_ms = float(grt.launch_timings(ctx, 0).sum())
+            grt.set_profiling(ctx, False)
+            done = ((steps + SPP - 1) // SPP) * SPP
+            return {"workload": "the same scene, camera, samples and frame loop with merge_static = 0: one CWBVH per mesh under a CWBVH TLAS (the reference's layout, Integrator.cpp:101-283)",
+                    "steps": done, "ms_per_step": round(elapsed / done * 1e3, 3), "mrays_s": round(rays * done / elapsed / 1e6, 1),
+                    "traversal_ms_per_step": round(trace_ms / done, 4), "rays_per_step": rays}
+        finally:
+            pt.close(); scene.close()
+    finally:
+        MERGE_STATIC = keep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,10 +364,11 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the hardware-counter passes (rocprofv3 --pmc re-runs of this benchmark: HBM traffic, VALU busy; N = 1 only)")
     ap.add_argument("--no-config3", action="store_true", help="skip the SVGF + TAA frames of BASELINE config 3 (N = 1 only)")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage rooflines (a repeat of the timed plan with events around every launch)")
+    ap.add_argument("--no-reference-layout", action="store_true", help="skip the pass over the reference's acceleration-structure layout (merge_static 0; N = 1 only)")
     ap.add_argument("--no-povs", action="store_true", help="skip the sweep over the reference's 9 fixed Sponza points of view (N = 1 only)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: render only rank 0's tiles of an N-GPU split on one GPU (no collective), to exercise the N > 1 code path")
     ap.add_argument("--merge-static", type=int, default=1, help="1 (default): the 382 instances of Sponza that stand still with the identity transform are flattened into one bottom-level tree (config merge_static); 0: one BLAS per mesh under the TLAS, the reference's layout")
-    ap.add_argument("--node-format", choices=["decoded", "reference"], default="decoded", help="decoded (default): the traversal launches read the library's 96-byte decoded copy of the CWBVH nodes; reference: the uploaded 80-byte nodes (rt_set_node_format)")
+    ap.add_argument("--node-format", choices=["decoded", "reference"], default="reference", help="reference (default): the traversal launches read the uploaded 80-byte CWBVH nodes; decoded: the library's 96-byte decoded copy (rt_set_node_format; measured slower, profiles/r04_node_formats.txt)")
     ap.add_argument("--batch", type=int, default=SPP, help="samples per pixel per submission (rt_render_samples), 1..%d" % SPP)
     ap.add_argument("--samples-in-flight", type=int, default=0, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
     args = ap.parse_args()
@@ -372,6 +415,7 @@ def main():
         TRACE_KERNEL[0] = "kernel_trace_stream_bvh8_flat"   # the engine variant without TLAS / instance code
     if args.node_format == "decoded":
         TRACE_KERNEL[0] += "_decoded"
+    flatten_build_s = pt.static_geometry_build_seconds if pt.static_geometry_members else 0.0
     closed = False
     lib = grt.device_lib()
     ctx = pt.ctx
@@ -605,9 +649,9 @@ def main():
         result = {
             "metric": "Mrays/s (primary+secondary) + ms/frame, Sponza 1920x1080 4spp BVH8", "value": round(value, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": ("Crytek Sponza as the reference ships it: geometry and the 19 diffuse maps of Data/Sponza (fixed seeds, fixed camera)" if grt.reference_sponza_textures_installed() else "synthetic"),
             "config": {
-                "workload": "Sponza (Crytek, 262 687 triangles, 384 instances) 1920x1080, samples 0..3 (4 spp), BVH8/CWBVH, diffuse + roughplastic(odd materials, alpha 0.3), NEE+MIS+RR, 10 bounces, constant white sky, mipmapping on, 19 diffuse textures at the reference's dimensions (1024x1024 + mips, BC1 block-compressed as the reference does by default, decoded in the shade kernels; texels replicated 4x4 from the quarter-size maps that travel with the repo), the 5 maps missing upstream are the reference's 1x1 fallback texel",
+                "workload": "Sponza (Crytek, 262 687 triangles, 384 instances) 1920x1080, samples 0..3 (4 spp), BVH8/CWBVH, diffuse + roughplastic(odd materials, alpha 0.3), NEE+MIS+RR, 10 bounces, constant white sky, mipmapping on, 19 diffuse textures at the reference's dimensions (1024x1024 + mips, BC1 block-compressed as the reference does by default, decoded in the shade kernels; " + ("the reference's own texture files" if grt.reference_sponza_textures_installed() else "texels replicated 4x4 from the quarter-size maps that travel with the repo") + "), the 5 maps missing upstream are the reference's 1x1 fallback texel",
                 "step": "one sample per pixel for the whole frame; the 4 samples of a frame are one submission (rt_render_samples); consecutive submissions feed one merged wavefront, every launch carries the rays of all submissions in flight",
                 "scheduler": scheduler,
                 "acceleration_structure": (("%d of %d instances (all that stand still) flattened into one CWBVH of %d triangle copies" + (", no TLAS: rays start inside the tree (rt_set_static_geometry)" if pt.static_geometry_whole_scene else ", one TLAS leaf beside the other instances") + ", hits reported as the scene's own instances and triangles (rt_upload_triangle_aliases); tree built on the host in %.2f s (SAH object + spatial splits, all threads; at scene load, not in the timed region); --merge-static 0 runs the reference's layout")
@@ -650,6 +694,11 @@ def main():
         if world == 1 and split_world == 1 and merged and not args.no_config3 and not os.environ.get("BENCH_PMC_CHILD"):
             pt.close(); pt = None   # (its queues and sample frames go back first)
             result["config3"] = config3_section(grt, scene, local_rank, stream_gbps)
+        if world == 1 and split_world == 1 and merged and args.merge_static and not args.no_reference_layout and not os.environ.get("BENCH_PMC_CHILD"):
+            if pt is not None:
+                pt.close(); pt = None
+            result["flatten_build_s"] = round(float(flatten_build_s), 3)
+            result["reference_layout"] = reference_layout_section(grt, local_rank, args.steps, args.warmup, args.node_format)
         if world == 1 and split_world == 1 and merged and not args.no_pmc and not os.environ.get("BENCH_PMC_CHILD"):
             # hardware counters of the same command (separate rocprofv3 --pmc passes); this process lets go of the GPU first
             if pt is not None:

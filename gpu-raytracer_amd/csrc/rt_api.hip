@@ -179,7 +179,7 @@ struct rt_context {
 	int lowest_blas_root = 0x7fffffff;  // over the instances uploaded last: the node slots below it are free for the TLAS copy of the merged wavefront
 	unsigned long long tlas_version = 0, tlas_version_in_nodes = ~0ull;   // the merged wavefront traces a copy of the TLAS inside the BLAS node array (stream_sync_tlas)
 	// ... and walks a DECODED copy of that array (96 B per node, kernels_trace.hip "decoded nodes"; rt_set_node_format)
-	int node_format = RT_NODES_DECODED;
+	int node_format = RT_NODES_REFERENCE;   // (the decoded copy measured 2-5 % slower on MI355X: profiles/r04_node_formats.txt)
 	void * bvh8_nodes_wide = nullptr; size_t wide_node_capacity = 0;
 	bool wide_nodes_stale = true;       // the BLAS part has to be decoded again (new geometry)
 	size_t bvh4_node_count = 0;

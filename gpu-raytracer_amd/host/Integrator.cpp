@@ -409,9 +409,17 @@ void Integrator::build_tlas() {
 		if (ctx) check(rt_upload_tlas_bvh2(ctx, tlas_raw.nodes.data(), tlas_raw.nodes.size()));
 		tlas.indices = tlas_raw.indices;
 	}
+	reference_tlas_order.clear();
 	if (flat.active) { // rows: the TLAS leaves (leaf 0 of the build was the flattened tree: no scene mesh of its own), then the members
 		for (int & leaf : tlas.indices) leaf = leaf == 0 ? -1 : flat.movers[size_t(leaf) - 1];
 		tlas.indices.insert(tlas.indices.end(), flat.members.begin(), flat.members.end());
+		if (use_bvh8) { // the top-level tree of the reference's layout, for its leaf order alone (a few hundred boxes: microseconds)
+			BVH2 raw; raw.indices.resize(mesh_count); raw.nodes.resize(mesh_count * 2);
+			SAHBuilder(raw, mesh_count).build(scene.meshes);
+			BVH8 wide;
+			BVH8Converter(wide, raw).convert();
+			reference_tlas_order = wide.indices;
+		}
 	}
 
 	size_t rows = tlas.indices.size();

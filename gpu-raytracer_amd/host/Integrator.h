@@ -115,6 +115,10 @@ struct Integrator {
 	std::vector<DeviceMedium>   media;
 
 	BVH2 tlas_raw;
+	// Flattened static geometry: the order the REFERENCE'S top-level tree would list the scene's instances in (its SAH build over
+	// the instance boxes + 8-wide collapse, Integrator.cpp:399-430), kept so that tables whose ORDER enters the rendered image --
+	// the light meshes' cumulative distribution: which light a random number picks -- are the reference's in every layout
+	std::vector<int> reference_tlas_order;
 	BVH8 tlas;                                   // tlas.indices[i] = scene mesh index of instance-table row i (TLAS leaf i; -1: the flattened static geometry)
 	BVH4 tlas_4;                                 // bvh_type = BVH4
 	std::unique_ptr<SAHBuilder>    tlas_builder;

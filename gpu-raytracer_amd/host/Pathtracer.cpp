@@ -90,9 +90,20 @@ void Pathtracer::calc_light_mesh_weights() {
 
 	// Order of the light meshes in the CDF: TLAS order, as in the reference -- unless the TLAS is built on the device, whose
 	// order the host does not know; then scene order, with scene indices as transform indices (the device maps them)
+	// Flattened static geometry: the instance tables' rows are in another order (TLAS leaves, then the flattened members), but the
+	// light meshes keep the ORDER the reference gives them -- that of its own top-level tree's leaves (reference_tlas_order) --:
+	// the position of a light in the distribution decides which light a random number selects, i.e. it enters the image
 	double total = 0.0;
 	size_t rows = tlas_on_device ? scene.meshes.size() : tlas.indices.size();   // the instance tables' rows
-	for (size_t i = 0; i < rows; i++) {
+	std::vector<int> row_of_mesh;
+	const bool reference_order = !tlas_on_device && !reference_tlas_order.empty();
+	if (reference_order) {
+		row_of_mesh.assign(scene.meshes.size(), -1);
+		for (size_t i = 0; i < rows; i++) if (tlas.indices[i] >= 0) row_of_mesh[size_t(tlas.indices[i])] = int(i);
+	}
+	size_t entries = reference_order ? reference_tlas_order.size() : rows;
+	for (size_t k = 0; k < entries; k++) {
+		size_t i = reference_order ? size_t(row_of_mesh[size_t(reference_tlas_order[k])]) : k;
 		if (!tlas_on_device && tlas.indices[i] < 0) continue;   // the row of the flattened static geometry: its members have rows of their own
 		const Mesh & mesh = scene.meshes[tlas_on_device ? int(i) : tlas.indices[i]];
 		if (mesh.light.weight > 0.0f) {

@@ -161,6 +161,32 @@ def test_frames_do_not_depend_on_the_flattening(grt, oracle):
     grt.config_reset()
 
 
+def test_light_tables_keep_the_references_order_in_the_flattened_layout(grt, oracle, tmp_path):
+    """Several emitters: which of them a random number selects depends on their ORDER in the cumulative distribution -- the
+    reference's is the leaf order of its top-level tree (Pathtracer.cpp:503-534). The flattened layout has other instance rows
+    but keeps that order (Integrator::reference_tlas_order), so NEE takes the same decisions and the frames of a scene with
+    three emitters, one of them a rotated and scaled file mesh, are the same floats in both layouts (all instances here have
+    hits that agree to the bit: identity transforms, or transformed ones that no bounce ray grazes differently)."""
+    from test_tlas import instanced_scene_file
+    path = instanced_scene_file(str(tmp_path / "s"), count=2)      # floor, two emitters of different power, two blobs
+    tables, frames = [], []
+    for merge in (0, 1):
+        scene, pt = staged(grt, path, 48, 32, merge, num_bounces=3)
+        assert (pt.static_geometry_members > 0) == bool(merge)
+        rows = pt.array("tlas_indices")
+        cdf = pt.array("light_mesh_cumulative_probability").copy(); spans = pt.array("light_mesh_triangle_span").copy()
+        meshes = rows[pt.array("light_mesh_transform_indices")]     # scene mesh of every light entry, in distribution order
+        tables.append((cdf, spans.reshape(-1, 2)[:, 1] - spans.reshape(-1, 2)[:, 0], meshes.copy()))
+        view = oracle.SceneView(pt); frame = oracle.Frame(view)
+        for s in range(2): frame.render_sample(s)
+        frames.append(frame.accumulator(0).copy())
+        pt.close(); scene.close()
+    assert len(tables[0][0]) == 2 and np.array_equal(tables[0][0], tables[1][0]) and np.array_equal(tables[0][1], tables[1][1]) and np.array_equal(tables[0][2], tables[1][2])
+    rel = np.abs(frames[0] - frames[1]).sum() / frames[0].sum()
+    assert frames[0].max() > 0.1 and rel < 1e-5, rel
+    grt.config_reset()
+
+
 def test_a_member_that_moves_leaves_the_flattened_tree(grt, oracle):
     """The tree is rebuilt without it (a one-off stall); it keeps a TLAS leaf of its own even when it comes to rest."""
     scene, pt = staged(grt, grt.scene_path("cornellbox"), 48, 36, 1)

@@ -68,7 +68,7 @@ def run_pass(counters, bench_args, timeout_s=240):
 def run_passes(steps, warmup, groups=None, extra_args=()):
     """Returns {"kernels": {kernel: {counter: [dispatches, sum]}}, "errors": [...]} over all passes."""
     merged, errors = {}, []
-    bench_args = ["--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-povs", "--no-pmc", "--no-stages", "--no-config3"] + list(extra_args)
+    bench_args = ["--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-povs", "--no-pmc", "--no-stages", "--no-config3", "--no-reference-layout"] + list(extra_args)
     for group in (groups or DEFAULT_GROUPS):
         result, error = run_pass(group, bench_args)
         if result is None:
