@@ -64,13 +64,14 @@ VALU_PEAK_LANE_INSTR_PER_S = 256 * 4 * 16 * 2.4e9
 
 
 TRACE_KERNEL = ["kernel_trace_stream_bvh8"]   # the dominant kernel's name in the rocprofv3 records: ..._flat when the whole scene is one flattened tree (rt_set_static_geometry)
+NODE_CACHE = 1     # --node-cache: 0 walks every node of the flattened tree from global memory (config node_cache)
 MERGE_STATIC = 1   # --merge-static: 0 stages the scene exactly as the reference does (one BLAS per mesh under the TLAS)
 
 
 def build_scene(grt):
     """BASELINE config #2: Sponza, every odd diffuse material -> roughplastic alpha 0.3."""
     grt.config_reset()
-    grt.config_set(merge_static=MERGE_STATIC)
+    grt.config_set(merge_static=MERGE_STATIC, node_cache=NODE_CACHE)
     # the reference's own 19 diffuse maps when build() could install them (assets/_cache, see install_reference_sponza_textures),
     # else the quarter-size maps that travel inside the repository, every texel replicated 4x4
     scene = grt.Scene(grt.scene_path("sponza_reference_maps" if grt.reference_sponza_textures_installed() else "sponza"))
@@ -149,7 +150,7 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_pass
     passes = pmc_pass.run_passes(args.steps, args.warmup, groups=pmc_pass.DEFAULT_GROUPS + ["TCC_HIT_sum TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"],
-                                  extra_args=("--merge-static", str(args.merge_static), "--node-format", args.node_format))
+                                  extra_args=("--merge-static", str(args.merge_static), "--node-format", args.node_format, "--node-cache", str(args.node_cache)))
     kernels = passes["kernels"]
     out = {"pmc_errors": passes["errors"]} if passes["errors"] else {}
     trace = kernels.get(TRACE_KERNEL[0])
@@ -368,12 +369,15 @@ def main():
     ap.add_argument("--no-povs", action="store_true", help="skip the sweep over the reference's 9 fixed Sponza points of view (N = 1 only)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: render only rank 0's tiles of an N-GPU split on one GPU (no collective), to exercise the N > 1 code path")
     ap.add_argument("--merge-static", type=int, default=1, help="1 (default): the 382 instances of Sponza that stand still with the identity transform are flattened into one bottom-level tree (config merge_static); 0: one BLAS per mesh under the TLAS, the reference's layout")
+    ap.add_argument("--node-cache", type=int, default=1, help="1 (default): the traversal launch of the flattened scene keeps the top three levels of the tree in LDS (rt_set_node_cache); 0: every node from global memory")
+    ap.add_argument("--exchange", choices=["native", "torch"], default="native", help="N > 1: who runs the per-frame all-gather. native (default): the library's own frame exchange, ncclAllGather on the context's stream through rt_comm_init_rank / rt_all_gather_framebuffer (torch.distributed only carries the 128-byte communicator id and the timing reductions); torch: dist.all_gather_into_tensor on torch's stream around rt_pack_pixels / rt_unpack_pixels. Falls back to torch when the library cannot set up its communicator")
     ap.add_argument("--node-format", choices=["decoded", "reference"], default="reference", help="reference (default): the traversal launches read the uploaded 80-byte CWBVH nodes; decoded: the library's 96-byte decoded copy (rt_set_node_format; measured slower, profiles/r04_node_formats.txt)")
     ap.add_argument("--batch", type=int, default=SPP, help="samples per pixel per submission (rt_render_samples), 1..%d" % SPP)
     ap.add_argument("--samples-in-flight", type=int, default=0, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
     args = ap.parse_args()
-    global MERGE_STATIC
+    global MERGE_STATIC, NODE_CACHE
     MERGE_STATIC = args.merge_static
+    NODE_CACHE = args.node_cache
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
@@ -415,6 +419,8 @@ def main():
         TRACE_KERNEL[0] = "kernel_trace_stream_bvh8_flat"   # the engine variant without TLAS / instance code
     if args.node_format == "decoded":
         TRACE_KERNEL[0] += "_decoded"
+    elif pt.static_geometry_whole_scene and args.node_cache and pt.static_geometry_node_cache[1] > 0:
+        TRACE_KERNEL[0] += "_cached"
     flatten_build_s = pt.static_geometry_build_seconds if pt.static_geometry_members else 0.0
     closed = False
     lib = grt.device_lib()
@@ -453,11 +459,40 @@ def main():
     else:
         check(lib.rt_set_pixel_tiles(ctx, split.tile_pixels, rank, split_world))
 
+    # The library's own frame exchange (include/gpu_raytracer_amd.h: rt_comm_*): rank 0 makes the communicator id, torch.distributed
+    # hands the 128 bytes to the others (its only part in the data path), every rank joins with ncclCommInitRank. From then on a
+    # completed frame is exchanged by ONE call that packs, all-gathers over RCCL on the context's stream and unpacks.
+    exchange = "torch"
+    if world > 1 and args.exchange == "native" and backend == "nccl" and not os.environ.get("BENCH_SHARE_GPU"):
+        lib.rt_comm_unique_id.argtypes = [ctypes.c_void_p]
+        lib.rt_comm_init_rank.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        lib.rt_all_gather_framebuffer.argtypes = [ctypes.c_void_p]
+        uid = ctypes.create_string_buffer(128)
+        made = lib.rt_comm_unique_id(uid) if rank == 0 else 0
+        carrier = torch.tensor(list(uid.raw) + [made], dtype=torch.int32, device=device)
+        dist.broadcast(carrier, 0)
+        values = carrier.cpu().tolist()
+        joined = 1
+        if values[128] == 0:
+            joined = lib.rt_comm_init_rank(ctx, bytes(bytearray(v & 0xff for v in values[:128])), rank, world)
+        verdict = torch.tensor([joined], dtype=torch.int32, device=device)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MAX)     # every rank or none
+        if int(verdict.item()) == 0:
+            exchange = "native"
+        else:
+            if joined == 0:
+                lib.rt_comm_destroy.argtypes = [ctypes.c_void_p]; lib.rt_comm_destroy(ctx)
+            if rank == 0:
+                sys.stderr.write("bench: the library's RCCL communicator could not be set up (%s); exchanging through torch.distributed\n" % lib.rt_last_error(ctx).decode(errors="replace"))
+
     def exchange_frame():
         """The one data-path collective: this rank's accumulated tiles -> every rank's final framebuffer. Stream-ordered in
         both directions, the host does not block: pack after the previous all_gather has read `packed`, all_gather after
         the pack, unpack after the all_gather; later frames are already being traced meanwhile."""
         if split_world == 1 or os.environ.get("BENCH_NO_GATHER"):
+            return
+        if exchange == "native":
+            check(lib.rt_all_gather_framebuffer(ctx))
             return
         torch_stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.rt_context_wait_for_stream(ctx, torch_stream))
@@ -656,12 +691,13 @@ def main():
                 "scheduler": scheduler,
                 "acceleration_structure": (("%d of %d instances (all that stand still) flattened into one CWBVH of %d triangle copies" + (", no TLAS: rays start inside the tree (rt_set_static_geometry)" if pt.static_geometry_whole_scene else ", one TLAS leaf beside the other instances") + ", hits reported as the scene's own instances and triangles (rt_upload_triangle_aliases); tree built on the host in %.2f s (SAH object + spatial splits, all threads; at scene load, not in the timed region); --merge-static 0 runs the reference's layout")
                                            % (pt.static_geometry_members, scene.mesh_count, int((pt.array("alias_mesh_ids") >= 0).sum()), pt.static_geometry_build_seconds)) if pt.static_geometry_members else "one CWBVH per mesh under a CWBVH TLAS (the reference's layout)",
+                "node_cache": ("the top three levels of the flattened tree (%d nodes of 80 bytes, breadth-first from the root) live in LDS for the traversal launch (rt_set_node_cache)" % pt.static_geometry_node_cache[1]) if (pt.static_geometry_whole_scene and args.node_cache) else "off",
                 "node_format": ("decoded: the traversal launches read the library's 96-byte decoded copy of the 80-byte CWBVH nodes (same floats, exponent / meta bytes pre-expanded; rt_set_node_format)" if args.node_format == "decoded" else "reference: the uploaded 80-byte CWBVH nodes"),
                 "rays_per_step": round(rays_plan / args.steps), "shadow_rays_per_step": round(shadow_plan / args.steps),
                 "mrays_s_including_shadow": round((rays_plan + shadow_plan) / elapsed / 1e6, 1),
                 "ms_per_4spp_frame": round(elapsed / args.steps * SPP * 1e3, 3),
                 "emulated_world": args.emulate_world, "ranks": (dist.get_world_size() if world > 1 else 1),
-                "parallelism": "tile-split x%d + one RCCL all-gather of the accumulated float4 frame per %d-spp frame, unpacked into every rank's framebuffer" % (world, SPP) if world > 1 else "single GPU",
+                "parallelism": ("tile-split x%d + one RCCL all-gather of the accumulated float4 frame per %d-spp frame, unpacked into every rank's framebuffer; exchange: %s" % (world, SPP, "the library's own (rt_all_gather_framebuffer: ncclAllGather on the context's stream)" if exchange == "native" else "torch.distributed all_gather_into_tensor around rt_pack_pixels / rt_unpack_pixels")) if world > 1 else "single GPU",
                 "samples_per_submission": args.batch, "submissions_in_flight": ("num_bounces (merged wavefront)" if merged else args.samples_in_flight),
                 # rt_set_frame_pipelining: the submissions of a tile split are small, up to 8 of them share one iteration of the wavefront
                 "submissions_per_iteration": (min(8, -(-WIDTH * HEIGHT * SPP // max(1, split.local_pixels * args.batch))) if (merged and split_world > 1) else 1),

@@ -157,6 +157,10 @@ def host_lib():
         lib.grt_pathtracer_static_geometry_members.argtypes = [c_void_p]
         lib.grt_pathtracer_static_geometry_whole_scene.restype = c_int
         lib.grt_pathtracer_static_geometry_whole_scene.argtypes = [c_void_p]
+        lib.grt_pathtracer_static_geometry_root.restype = c_int
+        lib.grt_pathtracer_static_geometry_root.argtypes = [c_void_p]
+        lib.grt_pathtracer_static_geometry_top_nodes.restype = c_int
+        lib.grt_pathtracer_static_geometry_top_nodes.argtypes = [c_void_p]
         lib.grt_pathtracer_static_geometry_build_seconds.restype = ctypes.c_double
         lib.grt_pathtracer_static_geometry_build_seconds.argtypes = [c_void_p]
         lib.grt_pathtracer_lights_total_weight.restype = c_float
@@ -526,6 +530,12 @@ class Pathtracer:
     def static_geometry_whole_scene(self):
         """Every instance is in the flattened tree: there is no TLAS, rays start inside the tree (rt_set_static_geometry)."""
         return bool(host_lib().grt_pathtracer_static_geometry_whole_scene(self.handle))
+
+    @property
+    def static_geometry_node_cache(self):
+        """(root node of the flattened tree, nodes from it that make up its top three levels): the breadth-first range the traversal
+        launch may keep in LDS (rt_set_node_cache)."""
+        return int(host_lib().grt_pathtracer_static_geometry_root(self.handle)), int(host_lib().grt_pathtracer_static_geometry_top_nodes(self.handle))
 
     @property
     def static_geometry_build_seconds(self):

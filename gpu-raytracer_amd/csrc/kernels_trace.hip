@@ -152,6 +152,86 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 	return hit_mask;
 }
 
+// ---- the node test again, written for the two vector pipes of this chip ---------------------------------------------------------
+// profiles/r04_instruction_costs.txt: on MI355X v_fma / v_mul / v_add / v_sub_f32, v_and / v_or / v_xor / v_bitop3_b32, v_add_u32,
+// v_lshrrev_b32 and v_mov_b32 retire a 64-lane wave in ~2.2 cycles and OVERLAP with the other class (v_cvt_f32_ubyte, v_min / v_max
+// / v_max3, v_cmp, v_cndmask, v_bfe, v_lshlrev, v_perm, v_or3, v_mul_lo ...: 4.1 cycles; a 4-cycle and a 2-cycle instruction
+// interleaved cost 4.5 cycles per PAIR). The node test above spends ~150 instructions of the 4-cycle class per node -- the 48
+// conversions and 32 min / max it cannot avoid, and ~70 that select, extract and assemble -- beside ~75 of the 2-cycle class that
+// ride along for free. Same arithmetic, same floats, same hit mask; what changes is which instructions move the integers:
+//   * plane selection by direction sign: a bitfield select with a per-ray sign mask (v_bitop3_b32) instead of 12 v_cndmask;
+//   * which children are inner nodes: shifts RIGHT, and, subtract (0x07 per inner child = y - (y >> 3) with y = bits 3 and 4 of the
+//     meta byte both set) instead of two left shifts and a multiply;
+//   * a child's contribution (count bits << bit index): ONE v_lshlrev_b32 with both operands byte-selected (SDWA) instead of
+//     v_bfe + v_lshrrev + v_lshlrev;
+//   * the hit test: v_cmpx_lt_f32 narrows the execution mask to the lanes that hit, ONE v_or_b32 adds the contribution, a scalar
+//     move restores the mask -- instead of v_cmp + v_cndmask + half a v_or3.
+#ifndef RT_FAST_NODE
+#define RT_FAST_NODE 0
+#endif
+RT_DEV unsigned bvh8_node_intersect_fast(const Ray3 & ray, f3 inv_dir, unsigned oct_inv4, float max_distance,
+                                         float4 n0, float4 n1, float4 n2, float4 n3, float4 n4) {
+	f3 p = mk3(n0.x, n0.y, n0.z);
+	unsigned e_imask = __float_as_uint(n0.w);
+	f3 adjusted_dir_inv = mk3(
+		__uint_as_float(extract_byte(e_imask, 0) << 23) * inv_dir.x,
+		__uint_as_float(extract_byte(e_imask, 1) << 23) * inv_dir.y,
+		__uint_as_float(extract_byte(e_imask, 2) << 23) * inv_dir.z);
+	f3 adjusted_origin = (p - ray.origin) * inv_dir;
+
+	// all ones where the direction component is negative (oct_inv4 carries the three comparisons: bit 2 / 1 / 0 of every byte is SET
+	// for a component that is not negative). Opaque to the optimiser, which would turn the selects below back into v_cndmask.
+	unsigned neg_x = ((oct_inv4 >> 2) & 1u) - 1u, neg_y = ((oct_inv4 >> 1) & 1u) - 1u, neg_z = (oct_inv4 & 1u) - 1u;
+	asm("" : "+v"(neg_x)); asm("" : "+v"(neg_y)); asm("" : "+v"(neg_z));
+	const unsigned long long all_lanes = __builtin_amdgcn_read_exec();
+
+	unsigned hit_mask = 0;
+	#pragma unroll
+	for (int i = 0; i < 2; i++) {
+		unsigned meta4 = __float_as_uint(i == 0 ? n1.z : n1.w);
+		unsigned both  = (meta4 & (meta4 >> 1)) & 0x08080808u;       // bits 3 and 4 of a meta byte set: offset >= 24, an inner child
+		unsigned inner7 = both - (both >> 3);                          // 0x07 in the byte of every inner child
+		unsigned bit_index4  = meta4 ^ (oct_inv4 & inner7);            // (a shift uses the low 5 bits of its amount: the count bits above them need no mask)
+		unsigned child_bits4 = (meta4 >> 5) & 0x07070707u;
+
+		unsigned q_lo_x = __float_as_uint(i == 0 ? n2.x : n2.y), q_hi_x = __float_as_uint(i == 0 ? n2.z : n2.w);
+		unsigned q_lo_y = __float_as_uint(i == 0 ? n3.x : n3.y), q_hi_y = __float_as_uint(i == 0 ? n3.z : n3.w);
+		unsigned q_lo_z = __float_as_uint(i == 0 ? n4.x : n4.y), q_hi_z = __float_as_uint(i == 0 ? n4.z : n4.w);
+
+		// v_bitop3_b32 with the truth table of (c ? b : a) over the index a * 4 + b * 2 + c: 0xd8 (written out: the compiler's own choice
+		// for (a & ~c) | (b & c) is v_bfi_b32, an instruction of the 4-cycle class)
+		unsigned x_min = __builtin_amdgcn_bitop3_b32(q_lo_x, q_hi_x, neg_x, 0xd8), x_max = __builtin_amdgcn_bitop3_b32(q_hi_x, q_lo_x, neg_x, 0xd8);
+		unsigned y_min = __builtin_amdgcn_bitop3_b32(q_lo_y, q_hi_y, neg_y, 0xd8), y_max = __builtin_amdgcn_bitop3_b32(q_hi_y, q_lo_y, neg_y, 0xd8);
+		unsigned z_min = __builtin_amdgcn_bitop3_b32(q_lo_z, q_hi_z, neg_z, 0xd8), z_max = __builtin_amdgcn_bitop3_b32(q_hi_z, q_lo_z, neg_z, 0xd8);
+
+		#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			float tx0 = __builtin_fmaf(float(extract_byte(x_min, j)), adjusted_dir_inv.x, adjusted_origin.x);
+			float ty0 = __builtin_fmaf(float(extract_byte(y_min, j)), adjusted_dir_inv.y, adjusted_origin.y);
+			float tz0 = __builtin_fmaf(float(extract_byte(z_min, j)), adjusted_dir_inv.z, adjusted_origin.z);
+			float tx1 = __builtin_fmaf(float(extract_byte(x_max, j)), adjusted_dir_inv.x, adjusted_origin.x);
+			float ty1 = __builtin_fmaf(float(extract_byte(y_max, j)), adjusted_dir_inv.y, adjusted_origin.y);
+			float tz1 = __builtin_fmaf(float(extract_byte(z_max, j)), adjusted_dir_inv.z, adjusted_origin.z);
+
+			float tmin = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, 0.0f));
+			float tmax = fminf(fminf(tx1, ty1), fminf(tz1, max_distance));
+
+			unsigned contribution;
+			if (j == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(contribution) : "v"(bit_index4), "v"(child_bits4));
+			if (j == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(contribution) : "v"(bit_index4), "v"(child_bits4));
+			if (j == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(contribution) : "v"(bit_index4), "v"(child_bits4));
+			if (j == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(contribution) : "v"(bit_index4), "v"(child_bits4));
+#if RT_FAST_NODE >= 2
+			// (tmin < tmax) ? hit_mask |= contribution : nothing -- as a narrowed execution mask; v_cmpx_lt_f32 is false for unordered operands, as the comparison above
+			asm volatile("v_cmpx_lt_f32 %1, %2\n\tv_or_b32 %0, %0, %3\n\ts_mov_b64 exec, %4" : "+v"(hit_mask) : "v"(tmin), "v"(tmax), "v"(contribution), "s"(all_lanes) : "vcc");
+#else
+			if (tmin < tmax) hit_mask |= contribution;
+#endif
+		}
+	}
+	return hit_mask;
+}
+
 // ---- decoded nodes (96 B) -------------------------------------------------------------------------
 // The merged wavefront walks a copy of the node array that kernel_decode_nodes (below) has re-laid for this loop. The 80-byte
 // CWBVH node is a storage format: to use it a lane spends 6 instructions expanding three exponent bytes, 14 (two of them
@@ -423,6 +503,13 @@ __shared__ int   shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4]; // per wave: ne
 // wait behind it in the middle of a round; from LDS it costs a fraction of that latency.
 #define RT_ROOTS_IN_LDS 1024
 __shared__ int   shared_roots[RT_ROOTS_IN_LDS];
+// The flattened scene's launch with a node cache (rt_set_node_cache): the top levels of the tree, 80 bytes each, copied from the node
+// array when the workgroup starts. Node fetches that fall into the range are five ds_read_b128 instead of five divergent
+// global_load_dwordx4: the texture-address unit, which this kernel keeps 72-86 % busy, never sees them.
+__shared__ float4 shared_top_nodes[RT_NODE_CACHE_MAX * 5];
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f LdsFloat4;   // (typed: ds_read_b128, not a FLAT load)
+RT_DEV float4 lds_float4(const LdsFloat4 * p) { v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 
 // The common traversal engine. RaySource supplies rays and consumes results so that the same
 // code serves the wavefront queues and the stand-alone entry points.
@@ -448,7 +535,8 @@ template<int MODE, typename Source> RT_DEV void source_finish(const Source & src
 // FLAT: the whole scene is one world-space tree rooted in node 0 (rt_set_static_geometry): there is no TLAS to walk, no instance
 // to enter or leave, no object-space ray -- the code for those and the three registers that track them are compiled out.
 // WIDE: nodes are read from the decoded copy of the unified node array (bvh8_node_intersect_decoded; wide engine of the merged wavefront only).
-template<int MODE, bool COUNT, bool NARROW, bool UNIFIED = false, bool FLAT = false, bool WIDE = false, typename Source>
+// CACHE: FLAT with the top of the tree in shared_top_nodes (the caller has filled it).
+template<int MODE, bool COUNT, bool NARROW, bool UNIFIED = false, bool FLAT = false, bool WIDE = false, bool CACHE = false, typename Source>
 RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr, int ray_count_2 = 0, int * cursor_2 = nullptr) {
 	constexpr bool SHADOW = MODE == RT_TRACE_SHADOW;   // the kind of every ray, unless MODE == RT_TRACE_MIXED: then lane_shadow
 	bool lane_shadow = SHADOW;
@@ -628,13 +716,27 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 						current_group .x = __float_as_uint(n1.z);
 						triangle_group.x = __float_as_uint(n1.w);
 					} else {
+					float4 n0, n1, n2, n3, n4;
+					bool from_lds = false;
+					if constexpr (CACHE) {
+						static_assert(FLAT && !NARROW, "node cache: the wide engines of the flattened scene");
+						const unsigned in_range = child_node_index - unsigned(p.node_cache_first);   // (node 0 is a copy of the first cached node, the root)
+						from_lds = child_node_index == 0u || in_range < unsigned(p.node_cache_count);
+						if (from_lds) {
+							const LdsFloat4 * cached = (const LdsFloat4 *)shared_top_nodes + (child_node_index == 0u ? 0u : in_range) * 5u;
+							n0 = lds_float4(cached); n1 = lds_float4(cached + 1); n2 = lds_float4(cached + 2); n3 = lds_float4(cached + 3); n4 = lds_float4(cached + 4);
+						}
+					}
+					if (!from_lds) {
 					const float4 * node = (!UNIFIED && child_node_index < unsigned(p.tlas_node_count) ? p.tlas_nodes : nodes) + size_t(child_node_index) * 5;
-					float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
+					n0 = node[0]; n1 = node[1]; n2 = node[2]; n3 = node[3]; n4 = node[4];
+					}
 					if (COUNT) count_nodes++;
 #ifdef RT_PHASE_STATS
 					if (COUNT && !SHADOW) { phase_node_lanes++; if (RT_PHASE_LEADER()) phase_node_execs++; }
 #endif
 					hitmask = NARROW ? group8_or(bvh8_node_intersect_child(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, group_child))
+					        : (RT_FAST_NODE && UNIFIED) ? bvh8_node_intersect_fast(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4)
 					                 : bvh8_node_intersect(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
 					imask = extract_byte(__float_as_uint(n0.w), 3);
 
@@ -1272,7 +1374,7 @@ struct MixedStreamSource {
 	RT_DEV void load(bool is_shadow, int i, Ray3 & ray, float & max_distance) const { if (is_shadow) shadow.load(i, ray, max_distance); else closest.load(i, ray, max_distance); }
 	RT_DEV void finish(bool is_shadow, int i, const HitRecord & hit, bool occluded) const { if (is_shadow) shadow.finish(i, hit, occluded); else closest.finish(i, hit, occluded); }
 };
-template<bool COUNT, bool FLAT = false, bool WIDE = false>
+template<bool COUNT, bool FLAT = false, bool WIDE = false, bool CACHE = false>
 RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	const int q = p.stream_iteration & 1;
 	MixedStreamSource src { { p.trace[q].origin, p.trace[q].direction, p.trace[q].hits },
@@ -1280,6 +1382,10 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	const int closest_count = p.stream->trace_count[q], shadow_count = p.stream->shadow_count[q ^ 1];
 	if (!FLAT && p.mesh_count <= RT_ROOTS_IN_LDS) {   // (uniform over the launch; before any wave leaves the kernel)
 		for (int i = threadIdx.x; i < p.mesh_count; i += RT_TRACE_BLOCK) shared_roots[i] = p.mesh_bvh_root_indices[i];
+		__syncthreads();
+	}
+	if (CACHE) {
+		for (int i = threadIdx.x; i < p.node_cache_count * 5; i += RT_TRACE_BLOCK) shared_top_nodes[i] = p.bvh8_nodes[size_t(p.node_cache_first) * 5 + i];
 		__syncthreads();
 	}
 	// Which engine (the counts are only known on the device; the choice is uniform over the launch):
@@ -1293,16 +1399,24 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	if (!COUNT && closest_count + shadow_count <= RT_NARROW_MAX_RAYS)
 		bvh8_trace_engine<RT_TRACE_MIXED, false, true, true, FLAT>(p, src, closest_count, &p.stream->cursor[q][0], nullptr, shadow_count, &p.stream->cursor[q][1]);
 	else if (COUNT || closest_count + shadow_count <= RT_MIXED_MAX_RAYS)
-		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true, FLAT, WIDE>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true, FLAT, WIDE, CACHE>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
 	else {
-		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true, FLAT, WIDE>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
-		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true, FLAT, WIDE>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true, FLAT, WIDE, CACHE>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
+		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true, FLAT, WIDE, CACHE>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
 	}
 }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8(RtParams p) { trace_stream<false>(p, nullptr); }
 // (7 waves per SIMD: without the TLAS / instance state the engine fits 72 registers with no scratch; 1.045-1.052 ms of traversal per step
 // against 1.056-1.059 with 6 -- profiles/r03_flattened_static_geometry.txt)
-__global__ void __launch_bounds__(RT_TRACE_BLOCK, 7) kernel_trace_stream_bvh8_flat(RtParams p) { trace_stream<false, true>(p, nullptr); }
+#ifndef RT_FLAT_WAVES
+#define RT_FLAT_WAVES 7
+#endif
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_FLAT_WAVES) kernel_trace_stream_bvh8_flat(RtParams p) { trace_stream<false, true>(p, nullptr); }
+// The flattened scene with the top of its tree in LDS (rt_set_node_cache). 25.6 KB of LDS per workgroup: 6 workgroups per CU.
+#ifndef RT_FLAT_CACHED_WAVES
+#define RT_FLAT_CACHED_WAVES 6
+#endif
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_FLAT_CACHED_WAVES) kernel_trace_stream_bvh8_flat_cached(RtParams p) { trace_stream<false, true, false, true>(p, nullptr); }
 // The same two launches on the decoded copy of the node array (rt_set_node_format; the default of the merged wavefront).
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_decoded(RtParams p) { trace_stream<false, false, true>(p, nullptr); }
 #ifndef RT_FLAT_DECODED_WAVES
@@ -1407,6 +1521,11 @@ void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, hipS
 		return;
 	}
 	if (p.entry_tlas_stack_size == 0) {   // the whole scene is one world-space tree: the engine without the TLAS / instance code
+		if (p.node_cache_count > 0 && !p.bvh8_nodes_wide) {
+			static int grid_flat_cached = trace_grid_size((const void *)kernel_trace_stream_bvh8_flat_cached);
+			hipLaunchKernelGGL(kernel_trace_stream_bvh8_flat_cached, dim3(grid_flat_cached), dim3(RT_TRACE_BLOCK), 0, stream, p);
+			return;
+		}
 		if (p.bvh8_nodes_wide) {
 			static int grid_flat_decoded = trace_grid_size((const void *)kernel_trace_stream_bvh8_flat_decoded);
 			hipLaunchKernelGGL(kernel_trace_stream_bvh8_flat_decoded, dim3(grid_flat_decoded), dim3(RT_TRACE_BLOCK), 0, stream, p);

@@ -503,7 +503,7 @@ static int upload_triangle_positions(rt_context * ctx, const void * triangles, s
 	for (size_t t = 0; t < triangle_count; t++) memcpy(&positions[t * 12], src + t * 24, 36);
 	int s = upload(ctx, &ctx->triangle_positions, positions.data(), triangle_count * 48); if (s) return s;
 	ctx->params.triangle_positions = (const float4 *)ctx->triangle_positions;
-	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID;
+	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID; ctx->params.node_cache_count = 0;
 	return RT_OK;
 }
 
@@ -572,6 +572,17 @@ int rt_set_static_geometry(rt_context * ctx, int32_t whole_scene) {
 	(void)hipSetDevice(ctx->device);
 	RT_HIP(ctx, quiesce(ctx));
 	ctx->params.entry_tlas_stack_size = entry;
+	ctx->params.node_cache_count = 0;
+	return RT_OK;
+}
+
+int rt_set_node_cache(rt_context * ctx, int32_t first_node, int32_t count) {
+	RT_REQUIRE(ctx, ctx != nullptr, "rt_set_node_cache: NULL context");
+	if (count <= 0) { ctx->params.node_cache_count = 0; return RT_OK; }
+	RT_REQUIRE(ctx, ctx->params.entry_tlas_stack_size == 0, "rt_set_node_cache: rays have to start inside the one tree (rt_set_static_geometry(ctx, 1)) first");
+	RT_REQUIRE(ctx, count <= RT_NODE_CACHE_MAX && first_node >= 1 && size_t(first_node) + size_t(count) <= ctx->bvh8_node_count, "rt_set_node_cache: at most 64 nodes inside the uploaded node array, behind node slot 0");
+	// (launches already enqueued carry their own copy of the parameters; the range is read from the node array at launch time)
+	ctx->params.node_cache_first = first_node; ctx->params.node_cache_count = count;
 	return RT_OK;
 }
 
@@ -602,10 +613,21 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	const size_t level_capacity = std::max(M, T / (4) + 1) + 1;        // an inner node holds more than 3 triangles
 	// outputs (kept): triangles and positions in leaf order, nodes; everything else is scratch of this call
 	void * out_triangles = nullptr, * out_positions = nullptr, * out_nodes = nullptr, * scratch = nullptr;
+	int * pinned = nullptr; hipEvent_t t0 = nullptr, t1 = nullptr;
+	// ONE way out on failure: whatever of the outputs, the scratch area, the pinned word and the timing events exists is released
+	// (a scratch allocation that does not fit is a recoverable error: it must not strand the hundreds of MB allocated before it)
+	auto give_up = [&](int status) {
+		device_free(ctx, scratch); device_free(ctx, out_triangles); device_free(ctx, out_positions); device_free(ctx, out_nodes);
+		if (pinned) (void)hipHostFree(pinned);
+		if (t0) (void)hipEventDestroy(t0);
+		if (t1) (void)hipEventDestroy(t1);
+		return status;
+	};
+	#define RT_BUILD_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return give_up(fail(ctx, RT_ERROR_HIP, "rt_build_geometry: %s failed: %s", #call, hipGetErrorString(e_))); } while (0)
 	int s;
-	if ((s = device_alloc(ctx, &out_triangles, T * 96))) return s;
-	if ((s = device_alloc(ctx, &out_positions, T * 48))) return s;
-	if ((s = device_alloc(ctx, &out_nodes, node_capacity * 80))) return s;
+	if ((s = device_alloc(ctx, &out_triangles, T * 96))) return give_up(s);
+	if ((s = device_alloc(ctx, &out_positions, T * 48))) return give_up(s);
+	if ((s = device_alloc(ctx, &out_nodes, node_capacity * 80))) return give_up(s);
 	size_t at = 0;
 	auto region = [&](size_t bytes) { size_t begin = at; at += (bytes + 255) / 256 * 256; return begin; };
 	const size_t o_in = region(T * 96), o_first = region((M + 1) * 4), o_order = region(T * 4), o_position = region(T * 4),
@@ -615,11 +637,11 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	             o_state = region(16);
 	const size_t library_bytes = rt_blas_build_scratch_bytes(T, M + level_capacity);
 	const size_t o_library = region(library_bytes);
-	if ((s = device_alloc(ctx, &scratch, at))) return s;
+	if ((s = device_alloc(ctx, &scratch, at))) return give_up(s);
 	char * base = (char *)scratch;
-	RT_HIP(ctx, hipMemcpyAsync(base + o_in, triangles, T * 96, hipMemcpyHostToDevice, ctx->stream));
-	RT_HIP(ctx, hipMemcpyAsync(base + o_first, mesh_first_triangle, (M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-	RT_HIP(ctx, hipMemsetAsync(out_nodes, 0, node_capacity * 80, ctx->stream));
+	RT_BUILD_HIP(hipMemcpyAsync(base + o_in, triangles, T * 96, hipMemcpyHostToDevice, ctx->stream));
+	RT_BUILD_HIP(hipMemcpyAsync(base + o_first, mesh_first_triangle, (M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+	RT_BUILD_HIP(hipMemsetAsync(out_nodes, 0, node_capacity * 80, ctx->stream));
 	BlasBuildArgs a;
 	a.triangle_count = int(T); a.mesh_count = int(M); a.first_node = int(reserved_tlas_nodes);
 	a.triangles = (const float4 *)(base + o_in); a.mesh_first = (const int *)(base + o_first);
@@ -631,10 +653,9 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	a.range = (int2 *)(base + o_range); a.runs = (int *)(base + o_runs);
 	a.inner_count = (int *)(base + o_ic); a.leaf_count = (int *)(base + o_lc); a.inner_base = (int *)(base + o_ib); a.leaf_base = (int *)(base + o_lb);
 	a.level_state = (int *)(base + o_state);
-	int * pinned = nullptr;
-	RT_HIP(ctx, hipHostMalloc((void **)&pinned, 16));
-	hipEvent_t t0, t1; RT_HIP(ctx, hipEventCreate(&t0)); RT_HIP(ctx, hipEventCreate(&t1));
-	RT_HIP(ctx, hipEventRecord(t0, ctx->stream));
+	RT_BUILD_HIP(hipHostMalloc((void **)&pinned, 16));
+	RT_BUILD_HIP(hipEventCreate(&t0)); RT_BUILD_HIP(hipEventCreate(&t1));
+	RT_BUILD_HIP(hipEventRecord(t0, ctx->stream));
 	int node_count = 0;
 	hipError_t e = rt_blas_build(a, base + o_library, library_bytes, pinned, ctx->stream, &node_count);
 	if (e == hipSuccess) e = hipEventRecord(t1, ctx->stream);
@@ -642,16 +663,17 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 	float ms = 0.0f;
 	if (e == hipSuccess) (void)hipEventElapsedTime(&ms, t0, t1);
+	if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); return give_up(fail(ctx, RT_ERROR_HIP, "rt_build_geometry: %s", hipGetErrorString(e))); }
 	(void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipHostFree(pinned);
 	device_free(ctx, scratch);
-	if (e != hipSuccess) { device_free(ctx, out_triangles); device_free(ctx, out_positions); device_free(ctx, out_nodes); return fail(ctx, RT_ERROR_HIP, "rt_build_geometry: %s", hipGetErrorString(e)); }
+	#undef RT_BUILD_HIP
 	// the context's geometry is what was built
 	device_free(ctx, ctx->triangles); device_free(ctx, ctx->triangle_positions); device_free(ctx, ctx->bvh8_nodes);
 	ctx->triangles = out_triangles; ctx->triangle_positions = out_positions; ctx->bvh8_nodes = out_nodes;
 	ctx->triangle_count = T; ctx->bvh8_node_count = size_t(node_count);
 	ctx->tlas_version_in_nodes = ~0ull; ctx->wide_nodes_stale = true;
 	ctx->params.triangles = (const float4 *)out_triangles; ctx->params.triangle_positions = (const float4 *)out_positions; ctx->params.bvh8_nodes = (const float4 *)out_nodes;
-	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID;
+	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID; ctx->params.node_cache_count = 0;
 	if (out_root_indices) for (size_t m = 0; m < M; m++) out_root_indices[m] = int32_t(reserved_tlas_nodes + m);
 	if (out_node_count) *out_node_count = size_t(node_count);
 	if (out_build_ms) *out_build_ms = ms;
@@ -825,6 +847,7 @@ int rt_build_tlas(rt_context * ctx, const int32_t * root_indices, const int32_t 
 	ctx->mesh_count = n; ctx->params.mesh_count = int(n);
 	ctx->params.tlas_nodes = (const float4 *)tlas_device;
 	ctx->params.tlas_node_count = int(2 * n);     // the node slots reserved for the TLAS; BLAS nodes start behind them
+	ctx->params.node_cache_count = 0;
 	ctx->params.entry_tlas_stack_size = RT_INVALID;   // node 0 is a TLAS root from now on: rays start above the instances (rt_set_static_geometry(ctx, 1) does not survive a TLAS build)
 	ctx->tlas_version++;
 	ctx->params.mesh_bvh_root_indices = a.out_root_indices;
@@ -1085,6 +1108,13 @@ static int sync_svgf(rt_context * ctx) {
 			int s = device_alloc(ctx, &ctx->slots[k].gbuffers[i], ctx->frame_pixels * elem[i]); if (s) return s;
 			RT_HIP(ctx, hipMemsetAsync(ctx->slots[k].gbuffers[i], 0, ctx->frame_pixels * elem[i], ctx->stream));
 		}
+		// The filter keeps (direct.w, indirect.w) of the radiance accumulators mirrored in svgf_variance[1] and writes both only where it
+		// filters (not at sky pixels). The mirror starts at zero, so the accumulators' .w have to: radiance accumulated WITHOUT the filter
+		// before it was switched on would leave stale .w at the sky pixels the variance blur taps across a silhouette. With SVGF on the
+		// two accumulators are the filter's ping-pong images (SVGF.h:416-554) and the sample count restarts, so nothing is lost.
+		RT_HIP(ctx, quiesce(ctx));
+		for (int aov : { RT_AOV_RADIANCE_DIRECT, RT_AOV_RADIANCE_INDIRECT })
+			if (ctx->aov_buffers[aov][1]) RT_HIP(ctx, hipMemsetAsync(ctx->aov_buffers[aov][1], 0, ctx->frame_pixels * 16, ctx->stream));
 	} else {
 		RT_HIP(ctx, quiesce(ctx));
 		for (int i = 0; i < 14; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }

@@ -116,6 +116,7 @@ struct RtParams {
 	int mesh_count;                   // instances (the fused traversal launch keeps the root table of a small scene in LDS)
 	int entry_tlas_stack_size;        // RT_INVALID: rays start at the TLAS root; 0: node 0 is the root of the one world-space tree that holds the
 	                                  // whole scene and rays start inside it, as instance row 0 (rt_set_static_geometry)
+	int node_cache_first, node_cache_count;   // nodes [first, first + count): the top levels of that tree, which its traversal launch copies to LDS (rt_set_node_cache); 0: none
 	int has_triangle_aliases;         // some triangles are copies that report the (instance, triangle) named in the padding of their
 	                                  // position record instead of themselves (rt_upload_triangle_aliases)
 	const int    * mesh_material_ids;

@@ -148,6 +148,30 @@ BVH2 BVH::create_from_triangles(const std::vector<Triangle> & triangles) {
 // BVH2 -> BVH8 (CWBVH)
 // ---------------------------------------------------------------------------------------------
 
+int bvh8_order_breadth_first(BVH8 & bvh, int max_depth) {
+	if (bvh.nodes.empty()) return 0;
+	std::vector<int> order, depth;            // order[new index] = old index
+	order.reserve(bvh.nodes.size()); depth.reserve(bvh.nodes.size());
+	order.push_back(0); depth.push_back(0);
+	std::vector<unsigned> new_child_base(bvh.nodes.size(), 0);
+	for (size_t at = 0; at < order.size(); at++) {
+		const BVHNode8 & node = bvh.nodes[size_t(order[at])];
+		new_child_base[size_t(order[at])] = unsigned(order.size());
+		int children = __builtin_popcount(unsigned(node.imask));
+		for (int c = 0; c < children; c++) { order.push_back(int(node.base_index_child) + c); depth.push_back(depth[at] + 1); }
+	}
+	if (order.size() != bvh.nodes.size()) throw std::runtime_error("bvh8_order_breadth_first: the node array holds nodes the root does not reach");
+	std::vector<BVHNode8> moved(bvh.nodes.size());
+	int top = 0;
+	for (size_t at = 0; at < order.size(); at++) {
+		moved[at] = bvh.nodes[size_t(order[at])];
+		if (moved[at].imask) moved[at].base_index_child = new_child_base[size_t(order[at])];
+		if (depth[at] <= max_depth) top = int(at) + 1;
+	}
+	bvh.nodes.swap(moved);
+	return top;
+}
+
 void BVH8Converter::convert() {
 	bvh8.indices.clear();
 	bvh8.indices.reserve(bvh2.indices.size());

@@ -78,6 +78,10 @@ struct CPUConfig {
 	// ... and what a triangle test costs relative to a node step when that tree's binary form is collapsed into 8-wide nodes
 	// (BVH8Converter: 1 in the reference; here a triangle test runs with a quarter of a wave's lanes, a node step with most)
 	float static_primitive_cost = 1.0f;
+	// ... and whether the traversal launches keep that tree's top three levels (at most 64 nodes, 5 KB) in LDS (rt_set_node_cache):
+	// the traversal is bound by the texture-address unit's rate of divergent 16-byte loads, and 40 % of a ray's node steps touch
+	// those few nodes
+	int node_cache = 1;
 
 	IntegratorType integrator = IntegratorType::PATHTRACER; // read by the command-line front end
 

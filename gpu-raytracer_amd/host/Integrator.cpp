@@ -216,6 +216,7 @@ void Integrator::init_geometry() {
 				BVH8Converter converter(wide, binary);
 				converter.primitive_cost = cpu_config.static_primitive_cost;
 				converter.convert();
+				flat.top_nodes = std::min(bvh8_order_breadth_first(wide, 2), RT_NODE_CACHE_MAX);   // levels 0..2: at most 1 + 8 + 64 nodes
 				flat.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
 				copy_source = wide.indices;
 				flat.root = int(node_total);
@@ -442,7 +443,11 @@ void Integrator::build_tlas() {
 	}
 	if (ctx) check(rt_upload_instances(ctx, mesh_bvh_root_indices.data(), mesh_material_ids.data(),
 		mesh_transforms[0].cells, mesh_transforms_inv[0].cells, mesh_transforms_prev[0].cells, rows));
-	if (ctx && cpu_config.bvh_type == BVHType::BVH8) check(rt_set_static_geometry(ctx, whole_scene ? 1 : 0));
+	if (ctx && cpu_config.bvh_type == BVHType::BVH8) {
+		check(rt_set_static_geometry(ctx, whole_scene ? 1 : 0));
+		// rays start inside the one tree: its top levels (breadth-first: the first nodes from its root) may live in LDS
+		check(rt_set_node_cache(ctx, flat.root, whole_scene && cpu_config.node_cache ? flat.top_nodes : 0));
+	}
 }
 
 rt_gpu_config Integrator::make_device_config() const {

@@ -66,6 +66,7 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "device_blas")                         cpu_config.device_blas = int(value);
 	else if (k == "merge_static")                        cpu_config.merge_static = int(value);
 	else if (k == "static_primitive_cost")               cpu_config.static_primitive_cost = float(value);
+	else if (k == "node_cache")                          cpu_config.node_cache = int(value);
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
 	else if (k == "initial_height")                      cpu_config.initial_height = int(value);
 	else { g_host_error = "unknown config key '" + k + "'"; return -1; }
@@ -329,6 +330,9 @@ float  grt_pathtracer_device_blas_build_ms(void * pt) { return as_integrator(pt)
 int    grt_pathtracer_static_geometry_members(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active ? int(p->static_geometry.members.size()) : 0; }
 // 1: everything is in the flattened tree, rays start inside it (rt_set_static_geometry); 0: there is a TLAS
 int    grt_pathtracer_static_geometry_whole_scene(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active && p->static_geometry.movers.empty() ? 1 : 0; }
+// the flattened tree's root node and how many nodes from it (breadth-first order) are its top levels: the range given to rt_set_node_cache
+int    grt_pathtracer_static_geometry_root(void * pt) { return as_integrator(pt)->static_geometry.root; }
+int    grt_pathtracer_static_geometry_top_nodes(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active ? p->static_geometry.top_nodes : 0; }
 double grt_pathtracer_static_geometry_build_seconds(void * pt) { return as_integrator(pt)->static_geometry.build_seconds; }
 float  grt_pathtracer_lights_total_weight(void * pt) { { Pathtracer * p = dynamic_cast<Pathtracer *>(as_integrator(pt)); return p ? p->lights_total_weight : 0.0f; } }
 

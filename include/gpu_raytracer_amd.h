@@ -353,6 +353,15 @@ int rt_set_scheduler(rt_context * ctx, int scheduler);
  *   The copy is refreshed by the library when geometry or the TLAS change; callers keep uploading 80-byte nodes.
  * RT_NODES_REFERENCE: traverse the uploaded 80-byte nodes themselves.                                                    */
 enum { RT_NODES_REFERENCE = 0, RT_NODES_DECODED = 1 };
+/* Nodes the traversal launches of the merged scheduler may keep in LDS: [first_node, first_node + count) have to be the top of the
+ * one tree rays start in (rt_set_static_geometry(ctx, 1); node slot 0 holds a copy of first_node, the root), in breadth-first
+ * order, count <= RT_NODE_CACHE_MAX; 0 switches it off, and so does every call that replaces geometry or the ray entry. The
+ * reference walks every node from global memory (CUDA/Raytracing/BVH8.h:113-274) with NVIDIA's texture path behind it; on
+ * MI355X the traversal is bound by the rate at which the texture-address unit takes divergent 16-byte loads (72-86 % busy,
+ * profiles/r04_pmc_traversal_breakdown.json), and the top three levels of the tree are 40 % of a ray's node steps. The LDS copy
+ * holds the same bytes: hits do not change.                                                                              */
+#define RT_NODE_CACHE_MAX 64
+int rt_set_node_cache(rt_context * ctx, int32_t first_node, int32_t count);
 int rt_set_node_format(rt_context * ctx, int format);
 /* Merged scheduler: one more iteration of the wavefront without new samples (no-op when nothing is in flight), and the
  * number of submissions whose accumulate step has been enqueued so far -- a frame loop that hands every completed

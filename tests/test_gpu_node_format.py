@@ -52,3 +52,19 @@ def test_decoded_nodes_follow_a_moving_instance_and_a_format_switch(grt, oracle,
         pt.invalidate("scene"); pt.update()
         compare_frames(grt, oracle, pt, 2, 192, 128)
     pt.close(); scene.close(); grt.config_reset()
+
+
+def test_the_node_cache_does_not_change_a_frame(grt):
+    """rt_set_node_cache: the flattened scene's traversal launch reads the top three levels of its tree from an LDS copy (the same
+    80 bytes per node). Frames, AOVs and queue sizes are those of the launch that reads every node from global memory; a scene
+    whose tree has fewer nodes than the cache holds (Cornell box: 2 nodes) included."""
+    for scene_name, w, h in (("sponza", 640, 360), ("cornellbox", 320, 240)):
+        results = []
+        for node_cache in (1, 0):
+            plan = [(0, 4), (4, 4)]
+            results.append(_render_plan(grt, scene_name, w, h, "merged", plan, dict(num_bounces=6, node_cache=node_cache), None, (grt.AOV_ALBEDO,)))
+        assert np.array_equal(results[0][0], results[1][0]) and results[0][0][..., :3].max() > 0.0, scene_name
+        assert np.array_equal(results[0][1][0], results[1][1][0]) and results[0][2] == results[1][2], scene_name
+    scene, pt = make_pathtracer(grt, "sponza", 64, 36, 0)
+    assert pt.static_geometry_whole_scene and 9 < pt.static_geometry_node_cache[1] <= 64
+    pt.close(); scene.close(); grt.config_reset()

@@ -161,6 +161,31 @@ def test_frames_do_not_depend_on_the_flattening(grt, oracle):
     grt.config_reset()
 
 
+def test_the_flattened_tree_is_in_breadth_first_order_for_the_node_cache(grt):
+    """rt_set_node_cache keeps the first nodes of the flattened tree in LDS: they have to be its top levels. The builder's
+    8-wide collapse emits nodes depth-first; bvh8_order_breadth_first renumbers them level by level (children stay consecutive
+    in slot order, so traversal does not notice -- every other test of this file walks the renumbered tree)."""
+    scene, pt = staged(grt, grt.scene_path("sponza"), 64, 36, 1)
+    root, top = pt.static_geometry_node_cache
+    nodes = pt.array("bvh8_nodes").view(np.uint32).reshape(-1, 20)
+    count = nodes.shape[0] - root
+    depth = np.full(count, -1, np.int64); depth[0] = 0
+    reached = 1
+    for n in range(count):                      # breadth-first: a node's children come after every node of its own level
+        assert depth[n] >= 0
+        word = nodes[root + n]
+        children = bin(int(word[3]) >> 24).count("1")
+        if children:
+            first = int(word[4]) - root
+            assert first == reached             # ... exactly where the nodes reached so far end
+            depth[first:first + children] = depth[n] + 1
+            reached += children
+    assert reached == count and (np.diff(depth) >= 0).all()
+    assert top == min(64, int((depth <= 2).sum())) and 9 < top <= 64
+    assert np.array_equal(nodes[0], nodes[root])     # node slot 0: the copy of the root rays start in
+    pt.close(); scene.close(); grt.config_reset()
+
+
 def test_light_tables_keep_the_references_order_in_the_flattened_layout(grt, oracle, tmp_path):
     """Several emitters: which of them a random number selects depends on their ORDER in the cumulative distribution -- the
     reference's is the leaf order of its top-level tree (Pathtracer.cpp:503-534). The flattened layout has other instance rows

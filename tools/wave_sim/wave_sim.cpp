@@ -35,6 +35,7 @@ static inline float as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f;
 static inline unsigned as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 
 struct Scene {
+	std::vector<int> depth;   // per node (single-tree scenes): levels below the root
 	int node_count, tri_count, mesh_count, tlas_count, width, height;
 	std::vector<uint8_t> nodes; std::vector<float> tris; std::vector<int> roots; std::vector<float> xinv; float cam[15];
 };
@@ -106,6 +107,7 @@ struct Stats {
 	double rounds = 0, instr = 0, useful = 0; // wave-instructions issued, lane-instructions useful / 64
 	double node_exec = 0, node_lanes = 0, tri_exec[8] = {}, tri_lanes[8] = {}, inst_exec = 0, inst_lanes = 0, end_pop_lanes = 0, refills = 0, refill_lanes = 0;
 	double nodes = 0, tris = 0, rays = 0, insts = 0, leafpops = 0;
+	double depth_visits[24] = {};   // node steps by depth of the node below the root of a single flattened tree (what an LDS-resident top of the tree would serve)
 	void add(const Stats & o) { const double * a = &o.rounds; double * b = &rounds; for (size_t i = 0; i < sizeof(Stats) / sizeof(double); i++) b[i] += a[i]; }
 };
 
@@ -156,6 +158,7 @@ static void run_wave(const Scene & s, const std::vector<Ray> & rays, bool shadow
 						if (l.cg_y & 0xff000000u) { l.stack.push_back({ l.cg_x, l.cg_y }); npush++; }
 						unsigned slot = (off - 24) ^ (l.oct & 0xffu), rel = __builtin_popcount(hits_imask & ~(0xffffffffu << slot));
 						const uint8_t * node = &s.nodes[size_t(base + rel) * 80];
+						if (!s.depth.empty()) st.depth_visits[std::min(23, s.depth[size_t(base + rel)])]++;
 						unsigned hm = node_intersect(l.ray, l.inv, l.oct, l.shadow ? l.max_distance : l.hit.t, node);
 						uint32_t w[8]; memcpy(w, node, 32);
 						l.cg_x = w[4]; l.tg_x = w[5]; l.cg_y = (hm & 0xff000000u) | (w[3] >> 24); l.tg_y = hm & 0x00ffffffu; st.nodes++;
@@ -221,6 +224,7 @@ static void report(const char * label, const Policy & pol, const Stats & st) {
 	printf("%-34s %-22s rays %8.0f | rounds/ray %5.2f nodes %5.2f tris %5.2f inst %4.2f leafpop %4.2f | wave-instr/ray %6.1f util %.3f | node exec/round %.2f lanes %.1f | tri", label, pol.name, st.rays,
 		st.rounds * 64 / st.rays / 1.0 / 64 * 64 / 64 * 64 / 64, st.nodes / st.rays, st.tris / st.rays, st.insts / st.rays, st.leafpops / st.rays, st.instr / st.rays, st.useful / st.instr, st.node_exec / st.rounds, st.node_lanes / std::max(1.0, st.node_exec));
 	for (int k = 0; k < pol.tri_batch && k < 4; k++) printf(" [%d] %.2f x %.1f", k, st.tri_exec[k] / st.rounds, st.tri_lanes[k] / std::max(1.0, st.tri_exec[k]));
+	if (st.depth_visits[0] > 0) { printf(" | node steps per ray by depth:"); for (int d = 0; d < 12; d++) printf(" %.2f", st.depth_visits[d] / st.rays); }
 	printf(" | refill every %.1f rounds x %.1f lanes\n", st.rounds / std::max(1.0, st.refills), st.refill_lanes / std::max(1.0, st.refills));
 }
 
@@ -231,6 +235,17 @@ int main(int argc, char ** argv) {
 	s.nodes.resize(size_t(s.node_count) * 80); s.tris.resize(size_t(s.tri_count) * 9); s.roots.resize(s.mesh_count); s.xinv.resize(size_t(s.mesh_count) * 12);
 	if (fread(s.nodes.data(), 1, s.nodes.size(), f) != s.nodes.size() || fread(s.tris.data(), 4, s.tris.size(), f) != s.tris.size() || fread(s.roots.data(), 4, s.roots.size(), f) != s.roots.size() || fread(s.xinv.data(), 4, s.xinv.size(), f) != s.xinv.size() || fread(s.cam, 4, 15, f) != 15) return 1;
 	fclose(f);
+	if (s.tlas_count == 0) { // one tree: depth of every node (children of a node are consecutive from its child base, one per bit of its inner mask)
+		s.depth.assign(size_t(s.node_count), 0);
+		std::vector<int> queue = { 0 };
+		for (size_t q = 0; q < queue.size(); q++) {
+			uint32_t w[5]; memcpy(w, &s.nodes[size_t(queue[q]) * 80], 20);
+			int children = __builtin_popcount(w[3] >> 24);
+			for (int c = 0; c < children; c++) { s.depth[size_t(w[4]) + c] = s.depth[size_t(queue[q])] + 1; queue.push_back(int(w[4]) + c); }
+		}
+		std::vector<int> per_level(24, 0); for (int d : s.depth) per_level[std::min(23, d)]++;
+		printf("nodes per level:"); for (int d = 0; d < 12; d++) printf(" %d", per_level[d]); printf("\n");
+	}
 	int stride = argc > 2 ? atoi(argv[2]) : 2;   // every stride-th pixel row/column block keeps wave coherence: we subsample whole 64-pixel runs
 	// primary rays (pinhole, pixel centres), in scan order, subsampled by whole rows
 	std::vector<Ray> primary;
