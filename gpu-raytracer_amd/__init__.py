@@ -161,6 +161,14 @@ def host_lib():
         lib.grt_pathtracer_static_geometry_root.argtypes = [c_void_p]
         lib.grt_pathtracer_static_geometry_top_nodes.restype = c_int
         lib.grt_pathtracer_static_geometry_top_nodes.argtypes = [c_void_p]
+        lib.grt_pathtracer_set_flatten_asynchronously.restype = None
+        lib.grt_pathtracer_set_flatten_asynchronously.argtypes = [c_void_p, c_int]
+        lib.grt_pathtracer_reflattens_completed.restype = c_int
+        lib.grt_pathtracer_reflattens_completed.argtypes = [c_void_p]
+        lib.grt_pathtracer_reflatten_in_progress.restype = c_int
+        lib.grt_pathtracer_reflatten_in_progress.argtypes = [c_void_p]
+        lib.grt_pathtracer_static_geometry_bytes.restype = ctypes.c_double
+        lib.grt_pathtracer_static_geometry_bytes.argtypes = [c_void_p]
         lib.grt_pathtracer_static_geometry_build_seconds.restype = ctypes.c_double
         lib.grt_pathtracer_static_geometry_build_seconds.argtypes = [c_void_p]
         lib.grt_pathtracer_lights_total_weight.restype = c_float
@@ -536,6 +544,25 @@ class Pathtracer:
         """(root node of the flattened tree, nodes from it that make up its top three levels): the breadth-first range the traversal
         launch may keep in LDS (rt_set_node_cache)."""
         return int(host_lib().grt_pathtracer_static_geometry_root(self.handle)), int(host_lib().grt_pathtracer_static_geometry_top_nodes(self.handle))
+
+    def set_flatten_asynchronously(self, enable):
+        """True (default): when a flattened instance starts to move the new tree is built on a worker thread while frames are rendered
+        in the reference's layout; False: rebuilt inside update() (a stall of the build time)."""
+        host_lib().grt_pathtracer_set_flatten_asynchronously(self.handle, 1 if enable else 0)
+
+    @property
+    def reflattens_completed(self):
+        return int(host_lib().grt_pathtracer_reflattens_completed(self.handle))
+
+    @property
+    def reflatten_in_progress(self):
+        """0: none; 1: a worker thread is building the tree; 2: it is done, the next update() installs it."""
+        return int(host_lib().grt_pathtracer_reflatten_in_progress(self.handle))
+
+    @property
+    def static_geometry_bytes(self):
+        """Device bytes the flattened tree adds: its triangle copies (shading + traversal records + names) and its nodes."""
+        return int(host_lib().grt_pathtracer_static_geometry_bytes(self.handle))
 
     @property
     def static_geometry_build_seconds(self):

@@ -75,6 +75,13 @@ struct CPUConfig {
 	// taken to world space, which the reference's layout never does: it takes the ray to object space). 0 = one BLAS per
 	// mesh under the TLAS, exactly the reference's structure (Integrator.cpp:101-283).
 	int  merge_static = 1;
+	// The flattening policy, as memory (a copy costs ~176 bytes per triangle: 96 B shading triangle, 48 B traversal positions, the
+	// names of the original, its share of the tree's nodes): a mesh that is instanced N times joins only if the N - 1 copies BEYOND
+	// the first stay under static_mesh_copy_limit_mb -- copying an instanced mesh per instance is the opposite of what instancing
+	// is for (441 instances of a 102 400-triangle mesh: 7.9 GB and a 45 M-triangle tree to build) --, and meshes join in scene order
+	// until all copies together reach static_copy_budget_mb. What does not join keeps its TLAS leaf.
+	int  static_mesh_copy_limit_mb = 64;
+	int  static_copy_budget_mb = 2048;
 	// ... and what a triangle test costs relative to a node step when that tree's binary form is collapsed into 8-wide nodes
 	// (BVH8Converter: 1 in the reference; here a triangle test runs with a quarter of a wave's lanes, a node step with most)
 	float static_primitive_cost = 1.0f;

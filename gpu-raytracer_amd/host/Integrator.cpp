@@ -2,6 +2,7 @@
 #include "Exporters.h"
 
 #include <chrono>
+#include <cstring>
 #include <stdexcept>
 
 Integrator::Integrator(Scene & scene, int device_ordinal) : scene(scene) {
@@ -15,6 +16,8 @@ Integrator::Integrator(Scene & scene, int device_ordinal) : scene(scene) {
 }
 
 Integrator::~Integrator() {
+	if (pending_flatten && pending_flatten->worker.joinable()) pending_flatten->worker.join();
+	for (auto & retired : retired_flattens) if (retired->worker.joinable()) retired->worker.join();
 	if (ctx) rt_destroy(ctx);
 }
 
@@ -65,6 +68,111 @@ void Integrator::init_materials() {
 		}
 		check(rt_upload_textures(ctx, descs.data(), descs.size()));
 	}
+}
+
+// ---- flattened static geometry: who joins, their triangles in world space, the tree ------------------------------------------------
+
+// Every instance that has not been seen moving -- merge_static 3: only those with the identity transform, whose copies are the
+// original triangles bit for bit (a transformed instance's copies are its triangles taken to world space) -- as far as the copies
+// fit the budget (Config.h static_mesh_copy_limit_mb / static_copy_budget_mb). Scene order.
+std::vector<int> Integrator::flatten_candidates() const {
+	const std::vector<MeshData> & mesh_datas = scene.asset_manager.mesh_datas;
+	size_t mesh_count = scene.meshes.size();
+	std::vector<int> members;
+	const double bytes_per_copy = 176.0;
+	auto moved = [&](size_t i) { return i < instance_has_moved.size() && instance_has_moved[i]; };
+	std::vector<int> uses(mesh_datas.size(), 0);
+	for (size_t i = 0; i < mesh_count; i++) if (!moved(i)) uses[size_t(scene.meshes[i].mesh_data_handle.handle)]++;
+	double budget = double(cpu_config.static_copy_budget_mb) * 1048576.0;
+	for (size_t i = 0; i < mesh_count; i++) {
+		size_t handle = size_t(scene.meshes[i].mesh_data_handle.handle);
+		double one_copy = double(mesh_datas[handle].triangles.size()) * bytes_per_copy;
+		bool joins = !moved(i) && (cpu_config.merge_static != 3 || scene.meshes[i].has_identity_transform())
+		          && double(uses[handle] - 1) * one_copy <= double(cpu_config.static_mesh_copy_limit_mb) * 1048576.0   // the copies beyond the first: what instancing saves
+		          && one_copy <= budget;
+		if (joins) { budget -= one_copy; members.push_back(int(i)); }
+	}
+	return members;
+}
+
+std::vector<Triangle> Integrator::world_triangles_of(const std::vector<int> & members, std::vector<int> * source_member, std::vector<int> * source_triangle) const {
+	const std::vector<MeshData> & mesh_datas = scene.asset_manager.mesh_datas;
+	std::vector<Triangle> world;
+	for (size_t j = 0; j < members.size(); j++) {
+		const Mesh & mesh = scene.meshes[size_t(members[j])];
+		int handle = mesh.mesh_data_handle.handle;
+		bool identity = mesh.has_identity_transform();
+		Matrix4 to_world = Matrix4::create_translation(mesh.position) * Matrix4::create_rotation(mesh.rotation) * Matrix4::create_scale(mesh.scale);   // as Mesh::update
+		for (size_t t = 0; t < mesh_datas[size_t(handle)].triangles.size(); t++) {
+			if (source_member) { source_member->push_back(int(j)); source_triangle->push_back(mesh_data_triangle_offsets[size_t(handle)] + int(t)); }
+			Triangle triangle = mesh_datas[size_t(handle)].triangles[t];
+			if (!identity) {
+				triangle.position_0 = Matrix4::transform_position(to_world, triangle.position_0);
+				triangle.position_1 = Matrix4::transform_position(to_world, triangle.position_1);
+				triangle.position_2 = Matrix4::transform_position(to_world, triangle.position_2);
+			}
+			world.push_back(triangle);
+		}
+	}
+	return world;
+}
+
+// SAH object + spatial splits on all host threads, the reference's 8-wide collapse, breadth-first node order. A pure function of
+// its input and the configuration (it runs on a worker thread when a flattened instance has started to move).
+static void build_flattened_tree(const std::vector<Triangle> & world, BVH8 & wide, int & top_nodes) {
+	BVH2 binary;
+	if (cpu_config.merge_static == 2) binary = BVH::create_sah_from_triangles(world);   // the per-mesh builder, for comparison
+	else                              StaticBVHBuilder::build(binary, world);           // spatial splits, all host threads
+	BVH8Converter converter(wide, binary);
+	converter.primitive_cost = cpu_config.static_primitive_cost;
+	converter.convert();
+	top_nodes = std::min(bvh8_order_breadth_first(wide, 2), RT_NODE_CACHE_MAX);   // levels 0..2: at most 1 + 8 + 64 nodes
+}
+
+// Lets go of the current background build without waiting for it: a build that is still running moves to retired_flattens and is
+// joined once it has finished (or when the integrator goes).
+void Integrator::drop_flatten_worker() {
+	for (size_t i = 0; i < retired_flattens.size();) {
+		if (retired_flattens[i]->ready.load()) { retired_flattens[i]->worker.join(); retired_flattens.erase(retired_flattens.begin() + long(i)); } else i++;
+	}
+	if (!pending_flatten) return;
+	if (pending_flatten->ready.load()) { if (pending_flatten->worker.joinable()) pending_flatten->worker.join(); pending_flatten.reset(); }
+	else retired_flattens.push_back(std::move(pending_flatten));
+}
+
+// Do the members the background build was started for still stand where they stood? (The interim layout does not flatten, so nobody
+// else watches them.) One that moved is a mover for good, like a flattened instance that starts to move.
+bool Integrator::pending_flatten_is_current() {
+	bool current = true;
+	for (size_t j = 0; j < pending_flatten->members.size(); j++) {
+		const Mesh & mesh = scene.meshes[size_t(pending_flatten->members[j])];
+		const StaticGeometry::Pose & pose = pending_flatten->poses[j];
+		if (memcmp(&mesh.position, &pose.position, sizeof(Vector3)) || memcmp(&mesh.rotation, &pose.rotation, sizeof(Quaternion)) || mesh.scale != pose.scale) {
+			instance_has_moved[size_t(pending_flatten->members[j])] = 1;
+			current = false;
+		}
+	}
+	return current;
+}
+
+// The tree of the instances that still stand still, built beside the frame loop.
+void Integrator::start_flatten_worker() {
+	drop_flatten_worker();   // (a build for a member set that is out of date by now: it has to finish before its input can go)
+	std::vector<int> members = flatten_candidates();
+	size_t triangles = 0;
+	for (int member : members) triangles += scene.asset_manager.mesh_datas[size_t(scene.meshes[size_t(member)].mesh_data_handle.handle)].triangles.size();
+	if (members.size() < 2 || triangles == 0) return;   // nothing left to flatten
+	pending_flatten = std::make_unique<PendingFlatten>();
+	pending_flatten->members = members;
+	for (int member : members) { const Mesh & mesh = scene.meshes[size_t(member)]; pending_flatten->poses.push_back({ mesh.position, mesh.rotation, mesh.scale }); }
+	pending_flatten->world = world_triangles_of(members, nullptr, nullptr);
+	PendingFlatten * job = pending_flatten.get();
+	job->worker = std::thread([job] {
+		auto started = std::chrono::steady_clock::now();
+		try { build_flattened_tree(job->world, job->wide, job->top_nodes); } catch (...) { job->failed = true; }
+		job->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
+		job->ready.store(true);
+	});
 }
 
 // Concatenates all BLASes into one node array / one triangle array
@@ -168,18 +276,12 @@ void Integrator::init_geometry() {
 		bool build_on_device = ctx && cpu_config.device_blas > 0;
 		std::vector<int> source_member, source_triangle;   // per triangle of the members, in member order: its member, its index among all original triangles
 		std::vector<int> copy_source;                      // per copy, in device order: which of those it copies
+		instance_has_moved.resize(mesh_count, 0);
 		if (cpu_config.merge_static > 0 && !wants_device_tlas()) {
-			// every instance that has not been seen moving; merge_static 3: only those with the identity transform, whose copies
-			// are the original triangles bit for bit (a transformed instance's copies are its triangles taken to world space)
-			// ... and whose mesh is not instanced more than twice: copying an instanced mesh once per instance is the opposite of what
-			// instancing is for (441 instances of one 102 400-triangle mesh would become a 45 M-triangle tree and 6.5 GB of copies)
-			instance_has_moved.resize(mesh_count, 0);
-			std::vector<int> uses(mesh_data_count, 0);
-			for (const Mesh & mesh : scene.meshes) uses[size_t(mesh.mesh_data_handle.handle)]++;
-			for (size_t i = 0; i < mesh_count; i++) {
-				bool joins = !instance_has_moved[i] && uses[size_t(scene.meshes[i].mesh_data_handle.handle)] <= 2 && (cpu_config.merge_static != 3 || scene.meshes[i].has_identity_transform());
-				(joins ? flat.members : flat.movers).push_back(int(i));
-			}
+			flat.members = flatten_candidates();
+			std::vector<char> is_member(mesh_count, 0);
+			for (int member : flat.members) is_member[size_t(member)] = 1;
+			for (size_t i = 0; i < mesh_count; i++) if (!is_member[i]) flat.movers.push_back(int(i));
 			size_t triangles_to_copy = 0;
 			for (int member : flat.members) triangles_to_copy += mesh_datas[size_t(scene.meshes[size_t(member)].mesh_data_handle.handle)].triangles.size();
 			if (flat.members.size() < 2 || triangles_to_copy == 0) { flat.members.clear(); flat.movers.clear(); }   // nothing to gain / nothing to build a tree over
@@ -189,35 +291,25 @@ void Integrator::init_geometry() {
 			flat.member_poses.resize(flat.members.size());
 			for (size_t j = 0; j < flat.members.size(); j++) {
 				const Mesh & mesh = scene.meshes[flat.members[j]];
-				int handle = mesh.mesh_data_handle.handle;
 				flat.member_poses[j] = { mesh.position, mesh.rotation, mesh.scale };
-				bool identity = mesh.has_identity_transform();
-				Matrix4 to_world = Matrix4::create_translation(mesh.position) * Matrix4::create_rotation(mesh.rotation) * Matrix4::create_scale(mesh.scale);   // as Mesh::update
-				for (size_t t = 0; t < mesh_datas[handle].triangles.size(); t++) {
-					source_member.push_back(int(j)); source_triangle.push_back(mesh_data_triangle_offsets[handle] + int(t));
-					Triangle triangle = mesh_datas[handle].triangles[t];
-					if (!identity) {
-						triangle.position_0 = Matrix4::transform_position(to_world, triangle.position_0);
-						triangle.position_1 = Matrix4::transform_position(to_world, triangle.position_1);
-						triangle.position_2 = Matrix4::transform_position(to_world, triangle.position_2);
-					}
-					world.push_back(triangle);
-				}
 			}
+			world = world_triangles_of(flat.members, &source_member, &source_triangle);
 			if (build_on_device) {
 				copy_source.resize(source_member.size());
 				for (size_t c = 0; c < copy_source.size(); c++) copy_source[c] = int(c);
 			} else {
-				auto started = std::chrono::steady_clock::now();
-				BVH2 binary;
-				if (cpu_config.merge_static == 2) binary = BVH::create_sah_from_triangles(world);   // the per-mesh builder, for comparison
-				else                              StaticBVHBuilder::build(binary, world);           // spatial splits, all host threads
 				BVH8 wide;
-				BVH8Converter converter(wide, binary);
-				converter.primitive_cost = cpu_config.static_primitive_cost;
-				converter.convert();
-				flat.top_nodes = std::min(bvh8_order_breadth_first(wide, 2), RT_NODE_CACHE_MAX);   // levels 0..2: at most 1 + 8 + 64 nodes
-				flat.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
+				PendingFlatten * prebuilt = pending_flatten && pending_flatten->ready.load() && !pending_flatten->failed && pending_flatten->members == flat.members
+				                         && pending_flatten->world.size() == world.size() && memcmp(pending_flatten->world.data(), world.data(), world.size() * sizeof(Triangle)) == 0 ? pending_flatten.get() : nullptr;
+				if (prebuilt) {   // the worker thread built exactly this tree while the frame loop went on (build_tlas, "a member moved")
+					wide.nodes.swap(prebuilt->wide.nodes); wide.indices.swap(prebuilt->wide.indices);
+					flat.top_nodes = prebuilt->top_nodes; flat.build_seconds = prebuilt->build_seconds;
+					reflattens_completed++;
+				} else {
+					auto started = std::chrono::steady_clock::now();
+					build_flattened_tree(world, wide, flat.top_nodes);
+					flat.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
+				}
 				copy_source = wide.indices;
 				flat.root = int(node_total);
 				aggregated_bvh_nodes_8.resize(node_total + wide.nodes.size());
@@ -243,6 +335,7 @@ void Integrator::init_geometry() {
 				alias_triangle_ids [index_total + c] = original;
 			}
 			flat.built = flat.active = true;
+			flat.copy_bytes = copies * (sizeof(DeviceTriangle) + 48 + 8) + (aggregated_bvh_nodes_8.size() - node_total) * sizeof(BVHNode8);
 		}
 		if (build_on_device) {
 			// the trees are built on the device from the triangles alone (their order -- the host trees' leaf order -- is as good as
@@ -377,9 +470,27 @@ void Integrator::build_tlas() {
 				moved = true;
 			}
 		}
-		if (moved) { // flatten what still stands still (a one-off stall of a build + upload, per instance that starts to move)
+		if (moved) { // flatten what still stands still
+			if (flatten_asynchronously && cpu_config.bvh_type == BVHType::BVH8 && cpu_config.device_blas <= 0) {
+				// ... beside the frame loop: this frame and the next ones are rendered in the reference's layout (every instance a TLAS
+				// leaf; the per-mesh trees and their triangles have been on the device all along), a worker builds the new tree
+				start_flatten_worker();
+				flat.active = false; flat.members.clear(); flat.movers.clear();
+				alias_mesh_ids.clear(); alias_triangle_ids.clear();          // (the copies stay where they are, unreachable: no TLAS leaf leads to their tree)
+				if (ctx) check(rt_upload_triangle_aliases(ctx, nullptr, nullptr));
+				tlas_raw.indices.resize(mesh_count); tlas_raw.nodes.resize(mesh_count * 2);
+				tlas_builder = std::make_unique<SAHBuilder>(tlas_raw, mesh_count);
+			} else {   // ... now: a one-off stall of a build + upload
+				init_geometry();
+				if (cpu_config.device_blas > 0) geometry_was_rebuilt();   // (host-built trees: the originals keep their places, the copies are the tail)
+			}
+		}
+	} else if (pending_flatten) {
+		if (!pending_flatten_is_current()) start_flatten_worker();   // one of its members moved meanwhile: a new build for those that are left (the old one is not waited for)
+		else if (pending_flatten->ready.load()) {
+			// the worker is done: stage the flattened layout again (init_geometry recognises its own member set and input and takes the tree)
 			init_geometry();
-			if (cpu_config.device_blas > 0) geometry_was_rebuilt();   // (host-built trees: the originals keep their places, the copies are the tail)
+			drop_flatten_worker();
 		}
 	}
 	bool whole_scene = flat.active && flat.movers.empty();   // everything is in the flattened tree: rays start inside it, there is no TLAS
@@ -502,6 +613,7 @@ void Integrator::update(float delta) {
 		pixel_query_status = PixelQueryStatus::INACTIVE;
 	}
 
+	if (pending_flatten && pending_flatten->ready.load()) invalidated_scene = true;   // the tree built beside the frame loop is there: build_tlas installs it
 	if (invalidated_scene) {
 		invalidated_scene = false;
 		build_tlas();

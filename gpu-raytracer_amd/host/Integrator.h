@@ -7,7 +7,9 @@
 //   sample_index, aov_enable/aov_disable/aov_is_enabled, set_pixel_query.
 // GL interop, ImGui and NVRTC hot-reload have no counterpart (headless).
 #pragma once
+#include <atomic>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "Scene.h"
@@ -99,11 +101,35 @@ struct Integrator {
 		std::vector<Pose> member_poses;   // where they stood when their triangles were copied
 		std::vector<int> movers;      // every other instance
 		int    root = 0;              // root node of the merged tree
+		size_t copy_bytes = 0;        // what the copies and the tree's nodes add to the device's geometry
 		int    top_nodes = 0;         // its nodes are in breadth-first order; so many of them (from the root) make up its top levels (rt_set_node_cache)
 		AABB   aabb;
 		double build_seconds = 0.0;   // host SAH + CWBVH conversion (0 when the device built it)
 		int leaves() const { return 1 + int(movers.size()); }   // rows in front of the members' rows
 	} static_geometry;
+	// A flattened instance that starts to move leaves the tree -- WITHOUT stalling the frame loop for the rebuild (0.5 s for Sponza):
+	// the frame in which it is noticed, and every frame until the new tree is there, is rendered in the reference's layout (a TLAS
+	// over all instances; their trees and triangles are still on the device, untouched by the flattening), while a worker thread
+	// builds the tree of the members that are left. update() notices the finished build, init_geometry() takes the tree instead of
+	// building one (what remains on the frame loop's thread is staging and the upload).
+	struct PendingFlatten {
+		std::thread worker;
+		std::atomic<bool> ready { false };
+		std::vector<int> members;               // the member set the tree was built for
+		std::vector<StaticGeometry::Pose> poses; // ... and where they stood
+		std::vector<Triangle> world;            // their triangles in world space, in member order (the build's input)
+		BVH8 wide; int top_nodes = 0; double build_seconds = 0.0;
+		bool failed = false;
+	};
+	std::unique_ptr<PendingFlatten> pending_flatten;
+	std::vector<std::unique_ptr<PendingFlatten>> retired_flattens;   // builds whose input went out of date while they ran: joined when they are done, never waited for
+	bool pending_flatten_is_current();
+	bool flatten_asynchronously = true;     // (false: rebuild inside build_tlas, as round 3 did -- tests compare the two)
+	int  reflattens_completed = 0;
+	void start_flatten_worker();
+	void drop_flatten_worker();
+	std::vector<int> flatten_candidates() const;
+	std::vector<Triangle> world_triangles_of(const std::vector<int> & members, std::vector<int> * source_member, std::vector<int> * source_triangle) const;
 	std::vector<char> instance_has_moved;   // per scene mesh: seen with a changed transform since the scene was loaded -> never flattened again
 	std::vector<int> alias_mesh_ids, alias_triangle_ids;   // per device triangle (-1: not a copy): what rt_upload_triangle_aliases was given
 

@@ -67,6 +67,8 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "merge_static")                        cpu_config.merge_static = int(value);
 	else if (k == "static_primitive_cost")               cpu_config.static_primitive_cost = float(value);
 	else if (k == "node_cache")                          cpu_config.node_cache = int(value);
+	else if (k == "static_mesh_copy_limit_mb")           cpu_config.static_mesh_copy_limit_mb = int(value);
+	else if (k == "static_copy_budget_mb")               cpu_config.static_copy_budget_mb = int(value);
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
 	else if (k == "initial_height")                      cpu_config.initial_height = int(value);
 	else { g_host_error = "unknown config key '" + k + "'"; return -1; }
@@ -333,6 +335,13 @@ int    grt_pathtracer_static_geometry_whole_scene(void * pt) { Integrator * p = 
 // the flattened tree's root node and how many nodes from it (breadth-first order) are its top levels: the range given to rt_set_node_cache
 int    grt_pathtracer_static_geometry_root(void * pt) { return as_integrator(pt)->static_geometry.root; }
 int    grt_pathtracer_static_geometry_top_nodes(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active ? p->static_geometry.top_nodes : 0; }
+// re-flattening when a member starts to move: 1 (default) builds the new tree on a worker thread while the frame loop renders in the
+// reference's layout, 0 rebuilds inside update(); how many such background builds have been installed; whether one is in progress
+void grt_pathtracer_set_flatten_asynchronously(void * pt, int enable) { as_integrator(pt)->flatten_asynchronously = enable != 0; }
+int  grt_pathtracer_reflattens_completed(void * pt) { return as_integrator(pt)->reflattens_completed; }
+int  grt_pathtracer_reflatten_in_progress(void * pt) { Integrator * p = as_integrator(pt); return p->pending_flatten ? (p->pending_flatten->ready.load() ? 2 : 1) : 0; }
+// bytes the flattened tree adds to the device's geometry: its triangle copies (shading + traversal records) and its nodes
+double grt_pathtracer_static_geometry_bytes(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active ? double(p->static_geometry.copy_bytes) : 0.0; }
 double grt_pathtracer_static_geometry_build_seconds(void * pt) { return as_integrator(pt)->static_geometry.build_seconds; }
 float  grt_pathtracer_lights_total_weight(void * pt) { { Pathtracer * p = dynamic_cast<Pathtracer *>(as_integrator(pt)); return p ? p->lights_total_weight : 0.0f; } }
 

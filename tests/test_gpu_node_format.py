@@ -41,8 +41,8 @@ def test_decoded_nodes_follow_a_moving_instance_and_a_format_switch(grt, oracle,
     """40 instances beside a flattened floor: the TLAS changes every frame, its node slots are decoded again each time; the
     format is switched in the middle of the sequence (the wavefront drains, the copy is rebuilt). Frames against the oracle."""
     from test_tlas import instanced_scene_file
-    grt.config_reset(); grt.config_set(num_bounces=4)
-    scene = grt.Scene(instanced_scene_file(str(tmp_path / "s"), count=40)); grt.config_set(num_bounces=4)
+    grt.config_reset(); grt.config_set(num_bounces=4, static_mesh_copy_limit_mb=1)   # (the blob stays instanced: 40 TLAS leaves beside the flattened tree's)
+    scene = grt.Scene(instanced_scene_file(str(tmp_path / "s"), count=40)); grt.config_set(num_bounces=4, static_mesh_copy_limit_mb=1)
     pt = grt.Pathtracer(scene, 192, 128, device=0); pt.update()
     compare_frames(grt, oracle, pt, 2, 192, 128)
     for step, node_format in enumerate(("decoded", "reference", "decoded")):

@@ -56,10 +56,12 @@ def test_flattened_static_geometry_traces_like_one_blas_per_mesh(grt, oracle, tm
     assert not pt_ref.static_geometry_whole_scene
     pt_ref.close(); scene_ref.close()
 
-    scene, pt = staged(grt, scene_file, w, h, merge)
+    # ("instances": the 39 extra copies of the blob would cost 5 MB; with a 1 MB limit per mesh it stays instanced and the layout is the
+    # mixed one -- a TLAS with a leaf for the flattened tree beside 40 instance leaves --, see test_the_flattening_policy_is_a_memory_budget)
+    scene, pt = staged(grt, scene_file, w, h, merge, **(dict(static_mesh_copy_limit_mb=1) if name == "instances" else {}))
     members = pt.static_geometry_members
     identity = int((roots_ref < 0).sum())
-    # merge_static 1 / 2: every instance (none has moved) whose mesh is not instanced more than twice; 3: of those, the ones with the identity transform
+    # merge_static 1 / 2: every instance (none has moved) whose copies fit the budget; 3: of those, the ones with the identity transform
     assert identity == identity_instances and members == flattened and members >= 2
     flat = oracle.SceneView(pt)
 
@@ -213,8 +215,10 @@ def test_light_tables_keep_the_references_order_in_the_flattened_layout(grt, ora
 
 
 def test_a_member_that_moves_leaves_the_flattened_tree(grt, oracle):
-    """The tree is rebuilt without it (a one-off stall); it keeps a TLAS leaf of its own even when it comes to rest."""
+    """The tree is rebuilt without it (here inside update(): set_flatten_asynchronously(False); the background rebuild has the next
+    test); it keeps a TLAS leaf of its own even when it comes to rest."""
     scene, pt = staged(grt, grt.scene_path("cornellbox"), 48, 36, 1)
+    pt.set_flatten_asynchronously(False)
     assert pt.static_geometry_members == 8 and pt.array("tlas_indices").size == 9 and pt.static_geometry_whole_scene
     triangles_before = pt.array("triangles").size // 24
     scene.set_mesh_transform(6, (0.25, 0.0, -0.1), (0.0, 0.0, 0.0, 1.0), 1.0)
@@ -248,11 +252,76 @@ def test_a_member_that_moves_leaves_the_flattened_tree(grt, oracle):
     pt.close(); scene.close(); grt.config_reset()
 
 
+def test_a_member_that_moves_is_taken_out_beside_the_frame_loop(grt, oracle):
+    """The default: update() does NOT wait for the new tree. The frame in which the move is noticed, and every frame until a worker
+    thread has built the tree of the members that are left, is staged in the reference's layout (a TLAS leaf per instance; their
+    trees and triangles never left the device arrays) -- hits against the plain reference staging of the same scene: identical --;
+    the first update() after the worker is done installs the flattened layout, with the tree the worker built."""
+    import time
+    scene, pt = staged(grt, grt.scene_path("cornellbox"), 48, 36, 1)
+    assert pt.static_geometry_members == 8 and pt.reflatten_in_progress == 0
+    scene.set_mesh_transform(6, (0.25, 0.0, -0.1), (0.0, 0.0, 0.0, 1.0), 1.0)
+    pt.invalidate("scene")
+    started = time.perf_counter(); pt.update(); waited = time.perf_counter() - started
+    assert pt.static_geometry_members == 0 and pt.reflatten_in_progress in (1, 2) and sorted(pt.array("tlas_indices").tolist()) == list(range(8))
+    assert pt.array("alias_mesh_ids").size == 0
+    view = oracle.SceneView(pt)
+    o, d = rays_for(view, 48, 36, 3.0, 3000, 9)
+    interim, _ = view.trace(o, d)
+    rows_interim = pt.array("tlas_indices").copy()
+    deadline = time.time() + 30
+    while pt.reflatten_in_progress != 2 and time.time() < deadline: time.sleep(0.01)
+    assert pt.reflatten_in_progress == 2
+    pt.update()                                                               # nothing was invalidated: the finished build alone brings the new layout in
+    assert pt.static_geometry_members == 7 and pt.reflattens_completed == 1 and pt.reflatten_in_progress == 0
+    rows = pt.array("tlas_indices").copy()
+    assert sorted(rows.tolist()[:2]) == [-1, 6] and sorted(rows[2:].tolist()) == [0, 1, 2, 3, 4, 5, 7]
+    flattened, _ = oracle.SceneView(pt).trace(o, d)
+    hit = interim[:, 1] != 0xffffffff
+    assert hit.mean() > 0.3 and np.array_equal(flattened[:, 2], interim[:, 2])           # the same distances to the bit in the interim and in the new layout
+    same = hit & (flattened[:, 1] == interim[:, 1])
+    assert same.sum() >= 0.999 * hit.sum() and np.array_equal(rows[flattened[same, 0].astype(np.int64)], rows_interim[interim[same, 0].astype(np.int64)])
+    # a second mover while nothing is pending, then a third one WHILE the worker runs: its tree is out of date when it arrives and is not taken
+    scene.set_mesh_transform(5, (0.0, 0.05, 0.0), (0.0, 0.0, 0.0, 1.0), 1.0); pt.invalidate("scene"); pt.update()
+    scene.set_mesh_transform(4, (0.0, 0.05, 0.0), (0.0, 0.0, 0.0, 1.0), 1.0); pt.invalidate("scene"); pt.update()
+    deadline = time.time() + 30
+    while pt.reflatten_in_progress == 1 and time.time() < deadline: time.sleep(0.01)
+    pt.update()
+    assert pt.static_geometry_members == 5 and sorted(pt.array("tlas_indices")[4:].tolist()) == [0, 1, 2, 3, 7]
+    final, _ = oracle.SceneView(pt).trace(o, d)
+    assert (final[:, 1] != 0xffffffff).mean() > 0.3
+    pt.close(); scene.close(); grt.config_reset()
+
+
 def test_the_flattening_is_left_alone_where_it_does_not_apply(grt, tmp_path):
     for config in ({"bvh_type": 2}, {"bvh_type": 4}, {"device_tlas": 1}):          # CWBVH with a host-built TLAS only (device_tlas needs a device: no-op on the host)
         scene, pt = staged(grt, grt.scene_path("cornellbox"), 16, 16, 1, **config)
         if "bvh_type" in config:
             assert pt.static_geometry_members == 0 and pt.array("alias_mesh_ids").size == 0 and pt.array("tlas_indices").size == 8
+        pt.close(); scene.close()
+    grt.config_reset()
+
+
+def test_the_flattening_policy_is_a_memory_budget(grt, tmp_path):
+    """Which instances are copied into the flattened tree is decided in bytes (Config.h static_mesh_copy_limit_mb /
+    static_copy_budget_mb; ~176 B per copied triangle), not by a count of instances: an instanced mesh joins while the copies
+    BEYOND its first stay under the per-mesh limit, everything joins until the total budget is reached; what stays outside keeps
+    its TLAS leaf. The extra device bytes are reported (static_geometry_bytes)."""
+    from test_tlas import instanced_scene_file
+    path = instanced_scene_file(str(tmp_path / "s"), count=40)          # floor, two emitters, 40 instances of one 768-triangle blob
+    grt.config_reset()
+    scene = grt.Scene(path); scene.wait_until_loaded()
+    blob_triangles = max(scene.mesh_data_array(m, "triangles", np.float32).size // 24 for m in range(scene.mesh_data_count))
+    scene.close()
+    cases = [({}, 3 + 40),                                                                        # 39 extra copies of the blob: 39 x 768 x 176 B = 5 MB, under the default 64 MB
+             (dict(static_mesh_copy_limit_mb=1), 3),                                              # ... over 1 MB: the blob stays instanced
+             (dict(static_copy_budget_mb=1), 3 + int((1048576 - 3 * 2 * 176) // (blob_triangles * 176)))]   # the total budget: the rectangles and as many blobs as fit
+    for config, members in cases:
+        scene, pt = staged(grt, path, 32, 24, 1, **config)
+        assert pt.static_geometry_members == members, (config, pt.static_geometry_members, members)
+        copies = int((pt.array("alias_mesh_ids") >= 0).sum())
+        assert pt.static_geometry_bytes >= copies * (96 + 48 + 8) and pt.static_geometry_bytes < copies * 176 * 2 + 4096
+        assert (pt.array("tlas_indices") >= 0).sum() == scene.mesh_count                          # every scene instance still has exactly one row
         pt.close(); scene.close()
     grt.config_reset()
 
