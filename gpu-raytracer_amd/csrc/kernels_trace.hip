@@ -1468,6 +1468,9 @@ static int trace_grid_size(const void * kernel) {
 	int blocks_per_cu = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, RT_TRACE_BLOCK, 0) != hipSuccess || blocks_per_cu <= 0) blocks_per_cu = 2;
 	if (blocks_per_cu > 8) blocks_per_cu = 8;
+	// experiment knob (tools/two_context_overlap.py): a persistent grid that does not take every wave slot leaves room for another
+	// context's sort / shade launches beside it
+	if (const char * cap = getenv("GRT_TRACE_BLOCKS_PER_CU")) { int n = atoi(cap); if (n >= 1 && n < blocks_per_cu) blocks_per_cu = n; }
 	if (getenv("GRT_DEBUG")) fprintf(stderr, "[grt] trace kernel grid: %d CUs x %d workgroups of %d threads\n", cached_cus, blocks_per_cu, RT_TRACE_BLOCK);
 	return cached_cus * blocks_per_cu;
 }
