@@ -133,7 +133,7 @@ static void build_flattened_tree(const std::vector<Triangle> & world, BVH8 & wid
 // joined once it has finished (or when the integrator goes).
 void Integrator::drop_flatten_worker() {
 	for (size_t i = 0; i < retired_flattens.size();) {
-		if (retired_flattens[i]->ready.load()) { retired_flattens[i]->worker.join(); retired_flattens.erase(retired_flattens.begin() + long(i)); } else i++;
+		if (retired_flattens[i]->ready.load()) { if (retired_flattens[i]->worker.joinable()) retired_flattens[i]->worker.join(); retired_flattens.erase(retired_flattens.begin() + long(i)); } else i++;
 	}
 	if (!pending_flatten) return;
 	if (pending_flatten->ready.load()) { if (pending_flatten->worker.joinable()) pending_flatten->worker.join(); pending_flatten.reset(); }
@@ -165,11 +165,29 @@ void Integrator::start_flatten_worker() {
 	pending_flatten = std::make_unique<PendingFlatten>();
 	pending_flatten->members = members;
 	for (int member : members) { const Mesh & mesh = scene.meshes[size_t(member)]; pending_flatten->poses.push_back({ mesh.position, mesh.rotation, mesh.scale }); }
-	pending_flatten->world = world_triangles_of(members, nullptr, nullptr);
+	pending_flatten->world = world_triangles_of(members, &pending_flatten->source_member, &pending_flatten->source_triangle);
 	PendingFlatten * job = pending_flatten.get();
-	job->worker = std::thread([job] {
+	// (the worker reads the reference part of the staged arrays -- the originals of the triangles it copies -- which nothing rewrites
+	// while it runs: init_geometry waits for every worker before it restages that part)
+	const std::vector<DeviceTriangle> * originals = &aggregated_triangles; const std::vector<int> * device_index = &reverse_indices;
+	job->worker = std::thread([job, originals, device_index] {
 		auto started = std::chrono::steady_clock::now();
-		try { build_flattened_tree(job->world, job->wide, job->top_nodes); } catch (...) { job->failed = true; }
+		try {
+			build_flattened_tree(job->world, job->wide, job->top_nodes);
+			size_t copies = job->wide.indices.size();
+			job->copy_triangles.resize(copies); job->copy_member.resize(copies); job->copy_original.resize(copies);
+			for (size_t c = 0; c < copies; c++) {
+				size_t source = size_t(job->wide.indices[c]);
+				int original = (*device_index)[size_t(job->source_triangle[source])];
+				const Triangle & placed = job->world[source];
+				DeviceTriangle & copy = job->copy_triangles[c];
+				copy = (*originals)[size_t(original)];
+				copy.position_0      = placed.position_0;
+				copy.position_edge_1 = placed.position_1 - placed.position_0;
+				copy.position_edge_2 = placed.position_2 - placed.position_0;
+				job->copy_member[c] = job->source_member[source]; job->copy_original[c] = original;
+			}
+		} catch (...) { job->failed = true; }
 		job->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
 		job->ready.store(true);
 	});
@@ -181,9 +199,19 @@ void Integrator::start_flatten_worker() {
 //   * node slots [0, 2*mesh_count) are reserved for the per-frame TLAS
 //   * each BLAS' child / triangle base offsets are rebased into the shared arrays
 void Integrator::init_geometry() {
+	// A tree that the worker thread built for the instances that stand still (build_tlas) is being installed: the reference part
+	// of the staged arrays -- every mesh's triangles and nodes, 40 of the 60 ms this function takes for Sponza -- is what it was,
+	// only the copies and the flattened tree's nodes behind it are replaced
+	const bool only_the_flattened_part = pending_flatten && pending_flatten->ready.load() && !pending_flatten->failed && staged_index_total > 0
+	                                  && cpu_config.bvh_type == BVHType::BVH8 && cpu_config.device_blas <= 0 && aggregated_triangles.size() >= staged_index_total
+	                                  && aggregated_bvh_nodes_8.size() >= staged_node_total;
+	if (!only_the_flattened_part) {
+	if (pending_flatten && pending_flatten->worker.joinable() && !pending_flatten->ready.load()) pending_flatten->worker.join();   // (they read what is restaged below)
+	for (auto & retired : retired_flattens) if (retired->worker.joinable()) retired->worker.join();
 	scene.asset_manager.wait_until_loaded();
 	scene.asset_manager.prepare_device_bvhs(cpu_config.bvh_type);
 	for (Mesh & mesh : scene.meshes) mesh.calc_aabb(scene);
+	}
 
 	const std::vector<MeshData> & mesh_datas = scene.asset_manager.mesh_datas;
 	size_t mesh_data_count = mesh_datas.size();
@@ -207,9 +235,12 @@ void Integrator::init_geometry() {
 		index_total    += use_bvh8 ? mesh_datas[m].bvh8.indices.size() : mesh_datas[m].device_bvh2.indices.size();
 	}
 
+	if (only_the_flattened_part) aggregated_triangles.resize(index_total);
+	else {
 	aggregated_triangles.assign(index_total, DeviceTriangle());
 	reverse_indices.assign(triangle_total, 0);
-	for (size_t m = 0; m < mesh_data_count; m++) {
+	}
+	for (size_t m = 0; m < mesh_data_count && !only_the_flattened_part; m++) {
 		const MeshData & md = mesh_datas[m];
 		const std::vector<int> & order = use_bvh8 ? md.bvh8.indices : md.device_bvh2.indices; // a spatial-split tree lists a triangle once per leaf that holds a part of it
 		for (size_t i = 0; i < order.size(); i++) {
@@ -259,9 +290,13 @@ void Integrator::init_geometry() {
 		return;
 	}
 	if (use_bvh8) {
+		staged_index_total = index_total; staged_node_total = node_total;
+		if (only_the_flattened_part) aggregated_bvh_nodes_8.resize(node_total);
+		else {
 		aggregated_bvh_nodes_8.assign(node_total, BVHNode8());
 		memset(aggregated_bvh_nodes_8.data(), 0, node_total * sizeof(BVHNode8));
-		for (size_t m = 0; m < mesh_data_count; m++) {
+		}
+		for (size_t m = 0; m < mesh_data_count && !only_the_flattened_part; m++) {
 			const std::vector<BVHNode8> & nodes = mesh_datas[m].bvh8.nodes;
 			BVHNode8 * dst = aggregated_bvh_nodes_8.data() + mesh_data_bvh_offsets[m];
 			for (size_t n = 0; n < nodes.size(); n++) {
@@ -293,14 +328,17 @@ void Integrator::init_geometry() {
 				const Mesh & mesh = scene.meshes[flat.members[j]];
 				flat.member_poses[j] = { mesh.position, mesh.rotation, mesh.scale };
 			}
-			world = world_triangles_of(flat.members, &source_member, &source_triangle);
+			// (the worker's input and what it derived from it are taken over as they are: build_tlas has checked that its members stand
+			// where they stood when it started, pending_flatten_is_current)
+			PendingFlatten * prebuilt = !build_on_device && pending_flatten && pending_flatten->ready.load() && !pending_flatten->failed && pending_flatten->members == flat.members
+			                         && pending_flatten_is_current() ? pending_flatten.get() : nullptr;
+			if (prebuilt) { world.swap(prebuilt->world); source_member.swap(prebuilt->source_member); source_triangle.swap(prebuilt->source_triangle); }
+			else world = world_triangles_of(flat.members, &source_member, &source_triangle);
 			if (build_on_device) {
 				copy_source.resize(source_member.size());
 				for (size_t c = 0; c < copy_source.size(); c++) copy_source[c] = int(c);
 			} else {
 				BVH8 wide;
-				PendingFlatten * prebuilt = pending_flatten && pending_flatten->ready.load() && !pending_flatten->failed && pending_flatten->members == flat.members
-				                         && pending_flatten->world.size() == world.size() && memcmp(pending_flatten->world.data(), world.data(), world.size() * sizeof(Triangle)) == 0 ? pending_flatten.get() : nullptr;
 				if (prebuilt) {   // the worker thread built exactly this tree while the frame loop went on (build_tlas, "a member moved")
 					wide.nodes.swap(prebuilt->wide.nodes); wide.indices.swap(prebuilt->wide.indices);
 					flat.top_nodes = prebuilt->top_nodes; flat.build_seconds = prebuilt->build_seconds;
@@ -323,6 +361,11 @@ void Integrator::init_geometry() {
 			size_t copies = copy_source.size();   // more than the members have triangles where spatial splits cut some of them
 			aggregated_triangles.resize(index_total + copies);
 			alias_mesh_ids.assign(index_total + copies, -1); alias_triangle_ids.assign(index_total + copies, -1);
+			if (prebuilt && prebuilt->copy_triangles.size() == copies) {   // ... the copies too (the worker filled them in: 15 ms for Sponza)
+				memcpy((void *)&aggregated_triangles[index_total], prebuilt->copy_triangles.data(), copies * sizeof(DeviceTriangle));
+				memcpy(&alias_triangle_ids[index_total], prebuilt->copy_original.data(), copies * sizeof(int));
+				for (size_t c = 0; c < copies; c++) alias_mesh_ids[index_total + c] = flat.leaves() + prebuilt->copy_member[c];
+			} else
 			for (size_t c = 0; c < copies; c++) {
 				int original = reverse_indices[source_triangle[copy_source[c]]];
 				const Triangle & placed = world[size_t(copy_source[c])];

@@ -118,12 +118,15 @@ struct Integrator {
 		std::vector<int> members;               // the member set the tree was built for
 		std::vector<StaticGeometry::Pose> poses; // ... and where they stood
 		std::vector<Triangle> world;            // their triangles in world space, in member order (the build's input)
+		std::vector<int> source_member, source_triangle;   // per world triangle: its member, its index among all original triangles
+		std::vector<DeviceTriangle> copy_triangles; std::vector<int> copy_member, copy_original;   // the tree's leaf triangles as they go behind the staged originals
 		BVH8 wide; int top_nodes = 0; double build_seconds = 0.0;
 		bool failed = false;
 	};
 	std::unique_ptr<PendingFlatten> pending_flatten;
 	std::vector<std::unique_ptr<PendingFlatten>> retired_flattens;   // builds whose input went out of date while they ran: joined when they are done, never waited for
 	bool pending_flatten_is_current();
+	size_t staged_index_total = 0, staged_node_total = 0;   // triangles / nodes of the reference part of the staged arrays (in front of the copies / the flattened tree)
 	bool flatten_asynchronously = true;     // (false: rebuild inside build_tlas, as round 3 did -- tests compare the two)
 	int  reflattens_completed = 0;
 	void start_flatten_worker();
