@@ -182,7 +182,7 @@ def test_a_moving_member_does_not_stall_the_frame_loop_for_the_rebuild(grt, orac
             assert pt.reflattens_completed >= 1
         longest[background] = max(times)
         record("moving member, %s rebuild" % ("background" if background else "in-line"), steady_frame_ms=steady * 1e3, longest_frame_ms=max(times) * 1e3, frames=len(times), build_s=pt.static_geometry_build_seconds)
-        pt.invalidate("camera"); pt.update()                                   # (accumulation starts again at sample 0, where compare_frames' oracle starts)
+        pt.invalidate("scene"); pt.update()                                    # (accumulation starts again at sample 0, where compare_frames' oracle starts)
         assert pt.sample_index == 0 and pt.static_geometry_members == 383
         compare_frames(grt, oracle, pt, 2, 640, 360)
         pt.close(); scene.close()
