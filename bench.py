@@ -65,13 +65,14 @@ VALU_PEAK_LANE_INSTR_PER_S = 256 * 4 * 16 * 2.4e9
 
 TRACE_KERNEL = ["kernel_trace_stream_bvh8"]   # the dominant kernel's name in the rocprofv3 records: ..._flat when the whole scene is one flattened tree (rt_set_static_geometry)
 NODE_CACHE = 0     # --node-cache: 0 walks every node of the flattened tree from global memory (config node_cache)
+EXPAND_TEXTURES = 1   # --expand-textures: 0 keeps BC1 blocks compressed on the device, decoded per texel fetch (config expand_block_compressed_textures)
 MERGE_STATIC = 1   # --merge-static: 0 stages the scene exactly as the reference does (one BLAS per mesh under the TLAS)
 
 
 def build_scene(grt):
     """BASELINE config #2: Sponza, every odd diffuse material -> roughplastic alpha 0.3."""
     grt.config_reset()
-    grt.config_set(merge_static=MERGE_STATIC, node_cache=NODE_CACHE)
+    grt.config_set(merge_static=MERGE_STATIC, node_cache=NODE_CACHE, expand_block_compressed_textures=EXPAND_TEXTURES)
     # the reference's own 19 diffuse maps when build() could install them (assets/_cache, see install_reference_sponza_textures),
     # else the quarter-size maps that travel inside the repository, every texel replicated 4x4
     scene = grt.Scene(grt.scene_path("sponza_reference_maps" if grt.reference_sponza_textures_installed() else "sponza"))
@@ -369,13 +370,15 @@ def main():
     ap.add_argument("--no-povs", action="store_true", help="skip the sweep over the reference's 9 fixed Sponza points of view (N = 1 only)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: render only rank 0's tiles of an N-GPU split on one GPU (no collective), to exercise the N > 1 code path")
     ap.add_argument("--merge-static", type=int, default=1, help="1 (default): the 382 instances of Sponza that stand still with the identity transform are flattened into one bottom-level tree (config merge_static); 0: one BLAS per mesh under the TLAS, the reference's layout")
+    ap.add_argument("--expand-textures", type=int, default=1, help="1 (default): BC1 textures are decoded once, at upload, into 64-byte blocks of texels (rt_set_texture_expansion); 0: the 8-byte blocks stay compressed and every texel fetch decodes one")
     ap.add_argument("--node-cache", type=int, default=0, help="1: the traversal launch of the flattened scene keeps the top three levels of the tree in LDS (rt_set_node_cache; measured 1.3 %% slower); 0 (default): every node from global memory")
     ap.add_argument("--exchange", choices=["native", "torch"], default="native", help="N > 1: who runs the per-frame all-gather. native (default): the library's own frame exchange, ncclAllGather on the context's stream through rt_comm_init_rank / rt_all_gather_framebuffer (torch.distributed only carries the 128-byte communicator id and the timing reductions); torch: dist.all_gather_into_tensor on torch's stream around rt_pack_pixels / rt_unpack_pixels. Falls back to torch when the library cannot set up its communicator")
     ap.add_argument("--node-format", choices=["decoded", "reference"], default="reference", help="reference (default): the traversal launches read the uploaded 80-byte CWBVH nodes; decoded: the library's 96-byte decoded copy (rt_set_node_format; measured slower, profiles/r04_node_formats.txt)")
     ap.add_argument("--batch", type=int, default=SPP, help="samples per pixel per submission (rt_render_samples), 1..%d" % SPP)
     ap.add_argument("--samples-in-flight", type=int, default=0, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
     args = ap.parse_args()
-    global MERGE_STATIC, NODE_CACHE
+    global MERGE_STATIC, NODE_CACHE, EXPAND_TEXTURES
+    EXPAND_TEXTURES = args.expand_textures
     MERGE_STATIC = args.merge_static
     NODE_CACHE = args.node_cache
 

@@ -73,8 +73,8 @@ def device_lib():
         # first) keeps HIP's default of 4 queues and the context says so when it matters.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
         lib = ctypes.CDLL(DEVICE_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-        if hasattr(lib, "rt_abi_version") and lib.rt_abi_version() != 4:
-            raise DeviceLibraryMissing("%s has ABI version %d, this front end was written for 4 -- rebuild (python __graft_entry__.py)" % (DEVICE_LIB_PATH, lib.rt_abi_version()))
+        if hasattr(lib, "rt_abi_version") and lib.rt_abi_version() != 5:
+            raise DeviceLibraryMissing("%s has ABI version %d, this front end was written for 5 -- rebuild (python __graft_entry__.py)" % (DEVICE_LIB_PATH, lib.rt_abi_version()))
         lib.rt_last_error.restype = c_char_p
         lib.rt_last_error.argtypes = [c_void_p]
         lib.rt_version.restype = c_char_p

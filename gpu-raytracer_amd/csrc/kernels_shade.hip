@@ -142,6 +142,19 @@ __global__ void kernel_stream_advance(RtStreamControl * control, int iteration, 
 	if (progress) { progress[1] = total; __threadfence_system(); progress[0] = iteration; }
 }
 
+// rt_upload_textures, RT_TEXTURE_BC1_EXPANDED: one thread per texel, the same bc1_texel the per-fetch path runs.
+__global__ void kernel_expand_bc1(const uint2 * __restrict__ blocks, uchar4 * __restrict__ texels, size_t texel_count) {
+	for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < texel_count; i += size_t(gridDim.x) * blockDim.x)
+		texels[i] = bc1_texel(blocks[i >> 4], int(i & 3), int((i >> 2) & 3));
+}
+void rt_launch_expand_bc1(const uint2 * blocks, uchar4 * texels, size_t block_count, hipStream_t stream) {
+	if (block_count == 0) return;
+	size_t texel_count = block_count * 16;
+	size_t groups = (texel_count + 255) / 256;
+	unsigned grid = unsigned(groups < 65536 ? groups : 65536);
+	hipLaunchKernelGGL(kernel_expand_bc1, dim3(grid), dim3(256), 0, stream, blocks, texels, texel_count);
+}
+
 __global__ void kernel_random(RtParams p, int dimension, const unsigned * pixel_indices, int count, unsigned bounce, unsigned sample_index, float2 * out) {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= count) return;
@@ -318,7 +331,12 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 		packed_hit = in.hits[index];
 		HitInfo hit = unpack_hit(packed_hit);
 
-		if (bounce > 0 && p.config.enable_mipmapping) { ray_cone_angle = in.cone_angle[index]; ray_cone_width = in.cone_width[index]; }
+		// Merged wavefront: the bounce of an entry comes out of the slot table, i.e. behind two dependent loads; the entry's other fields
+		// are fetched beside them, not after them (every queue array has a slot for every entry; what bounce 0 never wrote is not used).
+		if (MERGED ? p.config.enable_mipmapping : (bounce > 0 && p.config.enable_mipmapping)) {
+			float angle = in.cone_angle[index], width = in.cone_width[index];
+			if (bounce > 0) { ray_cone_angle = angle; ray_cone_width = width; }
+		}
 
 		int x = pixel_index % p.screen_pitch;
 		int y = pixel_index / p.screen_pitch;
@@ -326,7 +344,8 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 		bool allow_nee     = pixel_index_and_flags & RT_FLAG_ALLOW_NEE;
 		bool inside_medium = pixel_index_and_flags & RT_FLAG_INSIDE_MEDIUM;
 
-		throughput = bounce == 0 ? mk3(1.0f) : load3(in.throughput, index);
+		if (MERGED) { f3 carried = load3(in.throughput, index); throughput = bounce == 0 ? mk3(1.0f) : carried; }
+		else throughput = bounce == 0 ? mk3(1.0f) : load3(in.throughput, index);
 
 		if (inside_medium) {
 			medium_id = in.medium[index];
@@ -460,27 +479,31 @@ __global__ void __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES) kernel_sort_stre
 
 struct TextureLOD { f2 gradient_1, gradient_2; float lod; };
 
+template<bool COMPRESSED>
 RT_DEV f3 sample_albedo(const RtParams & p, int bounce, f3 diffuse, int texture_id, f2 tex_coord, const TextureLOD & lod) { // RayCone.h:19-29
 	if (texture_id == RT_INVALID) return diffuse;
 	const RtTexture tex = p.textures[texture_id];
 	if (p.config.enable_mipmapping) {
-		if (bounce == 0) return diffuse * mk3(texture_get_grad(tex, tex_coord.x, tex_coord.y, lod.gradient_1, lod.gradient_2));
-		return diffuse * mk3(texture_get_lod(tex, tex_coord.x, tex_coord.y, lod.lod + tex.lod_bias));
+		if (bounce == 0) return diffuse * mk3(texture_get_grad<COMPRESSED>(tex, tex_coord.x, tex_coord.y, lod.gradient_1, lod.gradient_2));
+		return diffuse * mk3(texture_get_lod<COMPRESSED>(tex, tex_coord.x, tex_coord.y, lod.lod + tex.lod_bias));
 	}
-	return diffuse * mk3(texture_get(tex, tex_coord.x, tex_coord.y));
+	return diffuse * mk3(texture_get<COMPRESSED>(tex, tex_coord.x, tex_coord.y));
 }
 
 struct BSDFCommon {
 	int pixel_index, bounce, sample_index;
+	RandomPath rng;   // random_path(pixel_index, sample_index): what every random_sample of this hit shares
 	f3 tangent, bitangent, normal, omega_i;
 };
 
-struct BSDFDiffuse : BSDFCommon {
+// COMPRESSED: whether a texture may hold BC1 blocks to be decoded per fetch (see texture_bilinear)
+template<bool COMPRESSED>
+struct BSDFDiffuseT : BSDFCommon {
 	static constexpr bool HAS_ALBEDO = true;
 	f3 diffuse; int texture_id; f3 albedo;
 	RT_DEV void init(const RtParams & p, bool, int material_id) { float4 m = p.materials[2 * material_id]; diffuse = mk3(m.x, m.y, m.z); texture_id = __float_as_int(m.w); }
 	RT_DEV void calc_albedo(const RtParams & p, f3 & throughput, f2 tex_coord, const TextureLOD & lod) {
-		albedo = sample_albedo(p, bounce, diffuse, texture_id, tex_coord, lod);
+		albedo = sample_albedo<COMPRESSED>(p, bounce, diffuse, texture_id, tex_coord, lod);
 		if (bounce == 0) aov_set(p, RT_AOV_ALBEDO, pixel_index, mk4(albedo));
 		if (!(p.config.enable_svgf && bounce == 0)) throughput *= albedo;
 	}
@@ -491,7 +514,7 @@ struct BSDFDiffuse : BSDFCommon {
 		return pdf_is_valid(pdf);
 	}
 	RT_DEV bool sample(const RtParams & p, f3 &, int &, f3 & direction_out, float & pdf) const {
-		f2 r = random_sample(p, DIM_BSDF_0, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+		f2 r = random_sample(p, rng, DIM_BSDF_0, unsigned(bounce));
 		f3 omega_o = sample_cosine_weighted_direction(r.x, r.y);
 		direction_out = local_to_world(omega_o, tangent, bitangent, normal);
 		pdf = omega_o.z * RT_ONE_OVER_PI;
@@ -501,17 +524,33 @@ struct BSDFDiffuse : BSDFCommon {
 	RT_DEV bool allow_nee() const { return true; }
 };
 
-struct BSDFPlastic : BSDFCommon {
+typedef BSDFDiffuseT<true> BSDFDiffuse;
+
+template<bool COMPRESSED>
+struct BSDFPlasticT : BSDFCommon {
 	static constexpr bool HAS_ALBEDO = true;
 	static constexpr float IOR = 1.5f;
 	static constexpr float ETA = 1.0f / IOR;
 	f3 diffuse; int texture_id; float linear_roughness; f3 albedo;
+	float F_i, lambda_i, G1_i;
 	RT_DEV void init(const RtParams & p, bool, int material_id) {
 		float4 m = p.materials[2 * material_id]; diffuse = mk3(m.x, m.y, m.z); texture_id = __float_as_int(m.w);
 		linear_roughness = p.materials[2 * material_id + 1].x;
+		// what the light sample's evaluation (eval) and the bounce (sample) both need of the incoming direction, computed once per hit
+		float ax = roughness_to_alpha(linear_roughness);
+		F_i = fresnel_dielectric(omega_i.z, ETA);
+		lambda_i = ggx_lambda(omega_i, ax, ax);
+		G1_i = 1.0f / (1.0f + lambda_i);   // ggx_G1(omega_i, ax, ay)
+	}
+	// ggx_G2(omega_o, omega_i, omega_m, ax, ay) with the cached lambda of omega_i (the sum in the function's order)
+	RT_DEV float G2_with(f3 omega_o, f3 omega_m, float ax, float ay) const {
+		bool i_back = dot(omega_i, omega_m) * omega_i.z <= 0.0f;
+		bool o_back = dot(omega_o, omega_m) * omega_o.z <= 0.0f;
+		if (i_back || o_back) return 0.0f;
+		return 1.0f / (1.0f + ggx_lambda(omega_o, ax, ay) + lambda_i);
 	}
 	RT_DEV void calc_albedo(const RtParams & p, f3 &, f2 tex_coord, const TextureLOD & lod) {
-		albedo = sample_albedo(p, bounce, diffuse, texture_id, tex_coord, lod);
+		albedo = sample_albedo<COMPRESSED>(p, bounce, diffuse, texture_id, tex_coord, lod);
 		if (bounce == 0) aov_set(p, RT_AOV_ALBEDO, pixel_index, mk4(albedo));
 	}
 	RT_DEV f3 diffuse_lobe(float F_i, float F_o, float cos_o) const {
@@ -526,10 +565,9 @@ struct BSDFPlastic : BSDFCommon {
 		float ax = roughness_to_alpha(linear_roughness), ay = ax;
 		float F  = fresnel_dielectric(dot(omega_i, omega_m), ETA);
 		float D  = ggx_D(omega_m, ax, ay);
-		float G1 = ggx_G1(omega_i, ax, ay);
-		float G2 = ggx_G2(omega_o, omega_i, omega_m, ax, ay);
+		float G1 = G1_i;
+		float G2 = G2_with(omega_o, omega_m, ax, ay);
 		f3 brdf_specular = mk3(F * G2 * D / (4.0f * omega_i.z));
-		float F_i = fresnel_dielectric(omega_i.z, ETA);
 		float F_o = fresnel_dielectric(omega_o.z, ETA);
 		f3 brdf_diffuse = diffuse_lobe(F_i, F_o, omega_o.z);
 		float pdf_specular = G1 * D / (4.0f * omega_i.z);
@@ -539,9 +577,8 @@ struct BSDFPlastic : BSDFCommon {
 		return pdf_is_valid(pdf);
 	}
 	RT_DEV bool sample(const RtParams & p, f3 & throughput, int &, f3 & direction_out, float & pdf) const {
-		float rand_fresnel = random_sample(p, DIM_BSDF_0, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index)).x;
-		f2    rand_brdf    = random_sample(p, DIM_BSDF_1, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
-		float F_i = fresnel_dielectric(omega_i.z, ETA);
+		float rand_fresnel = random_sample(p, rng, DIM_BSDF_0, unsigned(bounce)).x;
+		f2    rand_brdf    = random_sample(p, rng, DIM_BSDF_1, unsigned(bounce));
 		float ax = roughness_to_alpha(linear_roughness), ay = ax;
 		f3 omega_m, omega_o;
 		if (rand_fresnel < F_i) {
@@ -554,8 +591,8 @@ struct BSDFPlastic : BSDFCommon {
 		if (omega_m.z < 0.0f) return false;
 		float F  = fresnel_dielectric(dot(omega_i, omega_m), ETA);
 		float D  = ggx_D(omega_m, ax, ay);
-		float G1 = ggx_G1(omega_i, ax, ay);
-		float G2 = ggx_G2(omega_o, omega_i, omega_m, ax, ay);
+		float G1 = G1_i;
+		float G2 = G2_with(omega_o, omega_m, ax, ay);
 		f3 brdf_specular = mk3(F * G2 * D / (4.0f * omega_i.z));
 		float F_o = fresnel_dielectric(omega_o.z, ETA);
 		f3 brdf_diffuse = diffuse_lobe(F_i, F_o, omega_o.z);
@@ -569,6 +606,8 @@ struct BSDFPlastic : BSDFCommon {
 	RT_DEV bool has_texture() const { return texture_id != RT_INVALID; }
 	RT_DEV bool allow_nee() const { return true; }
 };
+
+typedef BSDFPlasticT<true> BSDFPlastic;
 
 struct BSDFDielectric : BSDFCommon {
 	static constexpr bool HAS_ALBEDO = false;
@@ -630,8 +669,8 @@ struct BSDFDielectric : BSDFCommon {
 		return pdf_is_valid(pdf);
 	}
 	RT_DEV bool sample(const RtParams & p, f3 & throughput, int & medium_id, f3 & direction_out, float & pdf) const {
-		f2 r0 = random_sample(p, DIM_BSDF_0, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
-		f2 r1 = random_sample(p, DIM_BSDF_1, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+		f2 r0 = random_sample(p, rng, DIM_BSDF_0, unsigned(bounce));
+		f2 r1 = random_sample(p, rng, DIM_BSDF_1, unsigned(bounce));
 		float ax = roughness_to_alpha(linear_roughness), ay = ax;
 		bool entering_material; float E_i, ratio, E_avg_enter, E_avg_leave;
 		common(p, entering_material, E_i, ratio, E_avg_enter, E_avg_leave);
@@ -703,8 +742,8 @@ struct BSDFConductor : BSDFCommon {
 		return pdf_is_valid(pdf);
 	}
 	RT_DEV bool sample(const RtParams & p, f3 & throughput, int &, f3 & direction_out, float & pdf) const {
-		f2 r0 = random_sample(p, DIM_BSDF_0, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
-		f2 r1 = random_sample(p, DIM_BSDF_1, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+		f2 r0 = random_sample(p, rng, DIM_BSDF_0, unsigned(bounce));
+		f2 r1 = random_sample(p, rng, DIM_BSDF_1, unsigned(bounce));
 		float ax = roughness_to_alpha(linear_roughness), ay = ax;
 		float E_i = conductor_directional_albedo(p, linear_roughness, omega_i.z);
 		f3 omega_m, omega_o;
@@ -729,12 +768,29 @@ struct BSDFConductor : BSDFCommon {
 
 // ---- next event estimation (Pathtracer.cu:465-555) ----------------------------------------------------------
 
-RT_DEV int sample_light(const RtParams & p, float u1, float u2, int & transform_id) { // Sampling.h:180-190
-	int light_mesh_id = binary_search(p.light_mesh_cumulative_probability, 0, p.light_mesh_count - 1, u1);
+// The two cumulative tables of light sampling, copied into LDS by the workgroup when they fit (Sponza: 2 meshes, 480 triangles):
+// the two binary searches are chains of ~2 + ~9 dependent loads per hit, each a round trip to L2 from a kernel that runs 3-4 waves
+// per SIMD; from LDS a step costs a twentieth of that. Same floats, same comparisons.
+#define RT_LIGHT_MESHES_IN_LDS    64
+#define RT_LIGHT_TRIANGLES_IN_LDS 2048
+struct LightTablesLDS { float mesh_cdf[RT_LIGHT_MESHES_IN_LDS]; float triangle_cdf[RT_LIGHT_TRIANGLES_IN_LDS]; };
+RT_DEV bool light_tables_fit_lds(const RtParams & p) { return p.light_mesh_count <= RT_LIGHT_MESHES_IN_LDS && p.light_triangle_count <= RT_LIGHT_TRIANGLES_IN_LDS; }
+RT_DEV void light_tables_to_lds(const RtParams & p, LightTablesLDS & lds) {   // whole workgroup; the caller's next barrier publishes the copy
+	if (!light_tables_fit_lds(p)) return;
+	for (int i = threadIdx.x; i < p.light_mesh_count;     i += blockDim.x) lds.mesh_cdf[i]     = p.light_mesh_cumulative_probability[i];
+	for (int i = threadIdx.x; i < p.light_triangle_count; i += blockDim.x) lds.triangle_cdf[i] = p.light_triangle_cumulative_probability[i];
+}
+typedef const __attribute__((address_space(3))) float * LdsFloatTable;   // (typed: ds_read_b32, not a FLAT load)
+
+RT_DEV int sample_light(const RtParams & p, const LightTablesLDS * lds, float u1, float u2, int & transform_id) { // Sampling.h:180-190
+	const bool from_lds = lds != nullptr && light_tables_fit_lds(p);   // uniform
+	int light_mesh_id = from_lds ? binary_search((LdsFloatTable)lds->mesh_cdf, 0, p.light_mesh_count - 1, u1)
+	                             : binary_search(p.light_mesh_cumulative_probability, 0, p.light_mesh_count - 1, u1);
 	transform_id = p.light_mesh_transform_indices[light_mesh_id];
 	if (p.mesh_position) transform_id = p.mesh_position[transform_id]; // device-built TLAS: the host only knows scene indices
 	int2 span = p.light_mesh_triangle_span[light_mesh_id];
-	int light_triangle_id = binary_search(p.light_triangle_cumulative_probability, span.x, span.y, u2);
+	int light_triangle_id = from_lds ? binary_search((LdsFloatTable)lds->triangle_cdf, span.x, span.y, u2)
+	                                 : binary_search(p.light_triangle_cumulative_probability, span.x, span.y, u2);
 	return p.light_triangle_indices[light_triangle_id];
 }
 
@@ -742,12 +798,12 @@ struct ShadowRay { f3 origin, direction; float max_distance; f3 illumination; };
 
 // Returns true and fills `shadow` when the light sample has to be traced (the caller appends it).
 template<typename BSDF>
-RT_DEV bool next_event_estimation(const RtParams & p, int pixel_index, int bounce, int sample_index, const BSDF & bsdf, f3 hit_point, f3 normal, f3 geometric_normal, f3 throughput, ShadowRay & shadow) {
-	f2 rand_light    = random_sample(p, DIM_NEE_LIGHT,    unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
-	f2 rand_triangle = random_sample(p, DIM_NEE_TRIANGLE, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index));
+RT_DEV bool next_event_estimation(const RtParams & p, const LightTablesLDS * light_lds, int pixel_index, int bounce, int sample_index, const BSDF & bsdf, f3 hit_point, f3 normal, f3 geometric_normal, f3 throughput, ShadowRay & shadow) {
+	f2 rand_light    = random_sample(p, bsdf.rng, DIM_NEE_LIGHT,    unsigned(bounce));
+	f2 rand_triangle = random_sample(p, bsdf.rng, DIM_NEE_TRIANGLE, unsigned(bounce));
 
 	int light_mesh_id;
-	int light_triangle_id = sample_light(p, rand_light.x, rand_light.y, light_mesh_id);
+	int light_triangle_id = sample_light(p, light_lds, rand_light.x, rand_light.y, light_mesh_id);
 	f2 light_uv = sample_triangle(rand_triangle.x, rand_triangle.y);
 
 	f3 p0, e1, e2;
@@ -830,7 +886,9 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 	int * const shadow_counter = MERGED ? &p.stream->shadow_count[iq]    : &p.sizes->shadow[launch_bounce];
 	int * const trace_counter  = MERGED ? &p.stream->trace_count[iq ^ 1] : &p.sizes->trace[launch_bounce + 1];
 	const bool nee_enabled = p.config.enable_next_event_estimation && p.lights_total_weight > 0.0f; // uniform
-	if (MERGED) stream_stats_clear(stats_lds);
+	__shared__ LightTablesLDS light_lds;
+	if (nee_enabled && blockIdx.x * blockDim.x < unsigned(buffer_size)) light_tables_to_lds(p, light_lds);
+	if (MERGED) stream_stats_clear(stats_lds); else __syncthreads();   // (either way a barrier: the tables are in place)
 
 	// every thread of the workgroup makes the same number of rounds (block_aggregated_append has barriers)
 	for (int first = blockIdx.x * blockDim.x; first < buffer_size; first += gridDim.x * blockDim.x) {
@@ -857,7 +915,8 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 		bool inside_medium = pixel_index_and_flags & RT_FLAG_INSIDE_MEDIUM;
 		medium_id = inside_medium ? q.medium[index] : RT_INVALID;
 
-		throughput = bounce == 0 ? mk3(1.0f) : load3(q.throughput, index);
+		if (MERGED) { f3 carried = load3(q.throughput, index); throughput = bounce == 0 ? mk3(1.0f) : carried; }   // (beside the slot-table lookup, see sort_rays)
+		else throughput = bounce == 0 ? mk3(1.0f) : load3(q.throughput, index);
 
 		TriangleFull tri = triangle_get_full(p, hit.triangle_id);
 		hit_point = barycentric(hit.u, hit.v, tri.position_0, tri.position_edge_1, tri.position_edge_2);
@@ -874,8 +933,10 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 
 		float curvature = 0.0f;
 		if (p.config.enable_mipmapping) {
+			float carried_angle = 0.0f, carried_width = 0.0f;
+			if (MERGED || bounce > 0) { carried_angle = q.cone_angle[index]; carried_width = q.cone_width[index]; }
 			if (bounce == 0) { cone_angle = p.camera.pixel_spread_angle; cone_width = cone_angle * hit.t; }
-			else             { cone_angle = q.cone_angle[index]; cone_width = q.cone_width[index] + cone_angle * hit.t; }
+			else             { cone_angle = carried_angle; cone_width = carried_width + cone_angle * hit.t; }
 			curvature = triangle_get_curvature(tri.position_edge_1, tri.position_edge_2, tri.normal_edge_1, tri.normal_edge_2) * mesh_scale_inv;
 		}
 
@@ -896,7 +957,7 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 
 		int material_id = p.mesh_material_ids[hit.mesh_id];
 
-		bsdf.pixel_index = pixel_index; bsdf.bounce = bounce; bsdf.sample_index = sample_index;
+		bsdf.pixel_index = pixel_index; bsdf.bounce = bounce; bsdf.sample_index = sample_index; bsdf.rng = random_path(p, unsigned(pixel_index), unsigned(sample_index));
 		bsdf.tangent = tangent; bsdf.bitangent = bitangent; bsdf.normal = normal; bsdf.omega_i = omega_i;
 		bsdf.init(p, entering_material, material_id);
 
@@ -933,7 +994,7 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 		}
 
 		if (nee_enabled && bsdf.allow_nee()) {
-			has_shadow_ray = next_event_estimation(p, pixel_index, bounce, sample_index, bsdf, hit_point, normal, geometric_normal, throughput, shadow);
+			has_shadow_ray = next_event_estimation(p, &light_lds, pixel_index, bounce, sample_index, bsdf, hit_point, normal, geometric_normal, throughput, shadow);
 		}
 		return true;
 		};
@@ -981,6 +1042,11 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_materia
 __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_plastic(RtParams p, int bounce, int sample_index)    { shade_material<BSDFPlastic,    1, false>(p, bounce, sample_index); }
 __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_dielectric(RtParams p, int bounce, int sample_index) { shade_material<BSDFDielectric, 2, false>(p, bounce, sample_index); }
 __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_conductor(RtParams p, int bounce, int sample_index)  { shade_material<BSDFConductor,  3, false>(p, bounce, sample_index); }
+// ..._texels: no texture on the device holds compressed blocks (RtParams::textures_compressed == 0)
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_diffuse_texels(RtParams p, int bounce, int sample_index) { shade_material<BSDFDiffuseT<false>, 0, false>(p, bounce, sample_index); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_plastic_texels(RtParams p, int bounce, int sample_index) { shade_material<BSDFPlasticT<false>, 1, false>(p, bounce, sample_index); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_diffuse_stream_texels(RtParams p) { shade_material<BSDFDiffuseT<false>, 0, true>(p, 0, 0); }
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_plastic_stream_texels(RtParams p) { shade_material<BSDFPlasticT<false>, 1, true>(p, 0, 0); }
 __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_diffuse_stream(RtParams p)    { shade_material<BSDFDiffuse,    0, true>(p, 0, 0); }
 __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_plastic_stream(RtParams p)    { shade_material<BSDFPlastic,    1, true>(p, 0, 0); }
 __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_dielectric_stream(RtParams p) { shade_material<BSDFDielectric, 2, true>(p, 0, 0); }
@@ -1061,8 +1127,8 @@ void rt_launch_sort(const RtParams & p, int bounce, int sample_index, hipStream_
 void rt_launch_material(const RtParams & p, int material_slot, int bounce, int sample_index, hipStream_t stream) {
 	dim3 grid(2048), block(RT_SHADE_BLOCK);
 	switch (material_slot) {
-		case 0: hipLaunchKernelGGL(kernel_material_diffuse,    grid, block, 0, stream, p, bounce, sample_index); break;
-		case 1: hipLaunchKernelGGL(kernel_material_plastic,    grid, block, 0, stream, p, bounce, sample_index); break;
+		case 0: if (p.textures_compressed) hipLaunchKernelGGL(kernel_material_diffuse, grid, block, 0, stream, p, bounce, sample_index); else hipLaunchKernelGGL(kernel_material_diffuse_texels, grid, block, 0, stream, p, bounce, sample_index); break;
+		case 1: if (p.textures_compressed) hipLaunchKernelGGL(kernel_material_plastic, grid, block, 0, stream, p, bounce, sample_index); else hipLaunchKernelGGL(kernel_material_plastic_texels, grid, block, 0, stream, p, bounce, sample_index); break;
 		case 2: hipLaunchKernelGGL(kernel_material_dielectric, grid, block, 0, stream, p, bounce, sample_index); break;
 		case 3: hipLaunchKernelGGL(kernel_material_conductor,  grid, block, 0, stream, p, bounce, sample_index); break;
 	}
@@ -1086,8 +1152,8 @@ void rt_launch_sort_stream(const RtParams & p, hipStream_t stream) {
 void rt_launch_material_stream(const RtParams & p, int material_slot, hipStream_t stream) {
 	dim3 grid(RT_STREAM_SHADE_GRID), block(RT_SHADE_BLOCK);
 	switch (material_slot) {
-		case 0: hipLaunchKernelGGL(kernel_material_diffuse_stream,    grid, block, 0, stream, p); break;
-		case 1: hipLaunchKernelGGL(kernel_material_plastic_stream,    grid, block, 0, stream, p); break;
+		case 0: if (p.textures_compressed) hipLaunchKernelGGL(kernel_material_diffuse_stream, grid, block, 0, stream, p); else hipLaunchKernelGGL(kernel_material_diffuse_stream_texels, grid, block, 0, stream, p); break;
+		case 1: if (p.textures_compressed) hipLaunchKernelGGL(kernel_material_plastic_stream, grid, block, 0, stream, p); else hipLaunchKernelGGL(kernel_material_plastic_stream_texels, grid, block, 0, stream, p); break;
 		case 2: hipLaunchKernelGGL(kernel_material_dielectric_stream, grid, block, 0, stream, p); break;
 		case 3: hipLaunchKernelGGL(kernel_material_conductor_stream,  grid, block, 0, stream, p); break;
 	}

@@ -179,6 +179,8 @@ struct rt_context {
 	int lowest_blas_root = 0x7fffffff;  // over the instances uploaded last: the node slots below it are free for the TLAS copy of the merged wavefront
 	unsigned long long tlas_version = 0, tlas_version_in_nodes = ~0ull;   // the merged wavefront traces a copy of the TLAS inside the BLAS node array (stream_sync_tlas)
 	// ... and walks a DECODED copy of that array (96 B per node, kernels_trace.hip "decoded nodes"; rt_set_node_format)
+	bool expand_bc1 = true;   // rt_set_texture_expansion: BC1 textures are decoded once, at upload (rt_types.h: RT_TEXTURE_BC1_EXPANDED)
+	size_t texture_bytes = 0; // what rt_upload_textures holds on the device
 	int node_format = RT_NODES_REFERENCE;   // (the decoded copy measured 2-5 % slower on MI355X: profiles/r04_node_formats.txt)
 	void * bvh8_nodes_wide = nullptr; size_t wide_node_capacity = 0;
 	bool wide_nodes_stale = true;       // the BLAS part has to be decoded again (new geometry)
@@ -910,7 +912,7 @@ int rt_upload_textures(rt_context * ctx, const rt_texture_desc * descs, size_t c
 	RT_REQUIRE(ctx, ctx && (descs || count == 0), "rt_upload_textures: NULL argument");
 	(void)hipSetDevice(ctx->device);
 	for (void * p : ctx->texture_data) device_free(ctx, p);
-	ctx->texture_data.clear();
+	ctx->texture_data.clear(); ctx->texture_bytes = 0;
 	std::vector<RtTexture> table(count);
 	for (size_t i = 0; i < count; i++) {
 		const rt_texture_desc & d = descs[i];
@@ -923,16 +925,29 @@ int rt_upload_textures(rt_context * ctx, const rt_texture_desc * descs, size_t c
 		}
 		void * dev = nullptr;
 		int s = upload(ctx, &dev, d.texels, bytes); if (s) return s;
+		int device_format = d.format;
+		if (d.format == RT_TEXTURE_BC1 && ctx->expand_bc1) {   // decode every block once, here, instead of once per texel fetch
+			void * expanded = nullptr;
+			s = device_alloc(ctx, &expanded, bytes * 8); if (s) { device_free(ctx, dev); return s; }
+			rt_launch_expand_bc1((const uint2 *)dev, (uchar4 *)expanded, bytes / 8, ctx->stream);
+			hipError_t e = hipGetLastError(); if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+			device_free(ctx, dev);
+			if (e != hipSuccess) { device_free(ctx, expanded); return fail(ctx, RT_ERROR_HIP, "rt_upload_textures: expanding BC1 blocks failed: %s", hipGetErrorString(e)); }
+			dev = expanded; bytes *= 8; device_format = RT_TEXTURE_BC1_EXPANDED;
+		}
 		ctx->texture_data.push_back(dev);
+		ctx->texture_bytes += bytes;
 		table[i].texels = (const uchar4 *)dev;
 		table[i].width = d.width; table[i].height = d.height; table[i].mip_levels = d.mip_levels;
-		table[i].format = d.format; table[i].pad = 0;
+		table[i].format = device_format; table[i].pad = 0;
 		int lod_width  = d.lod_width  > 0 ? d.lod_width  : d.width;
 		int lod_height = d.lod_height > 0 ? d.lod_height : d.height;
 		table[i].lod_bias = 0.5f * log2f(float(lod_width * lod_height)); // Integrator.cpp:95
 	}
 	int s = upload(ctx, &ctx->texture_table, table.data(), count * sizeof(RtTexture)); if (s) return s;
 	ctx->params.textures = (const RtTexture *)ctx->texture_table;
+	ctx->params.textures_compressed = 0;
+	for (const RtTexture & t : table) if (t.format == RT_TEXTURE_BC1) ctx->params.textures_compressed = 1;
 	return RT_OK;
 }
 
@@ -958,6 +973,7 @@ int rt_upload_lights(rt_context * ctx,
 	ctx->params.light_mesh_triangle_span              = (const int2 *)(base + offset[3]);
 	ctx->params.light_mesh_transform_indices          = (const int *)(base + offset[4]);
 	ctx->params.light_mesh_count    = int(light_mesh_count);
+	ctx->params.light_triangle_count = int(light_triangle_count);
 	ctx->params.lights_total_weight = lights_total_weight;
 	return RT_OK;
 }
@@ -1568,6 +1584,13 @@ int rt_set_scheduler(rt_context * ctx, int scheduler) {
 	ctx->scheduler = scheduler;
 	return RT_OK;
 }
+
+int rt_set_texture_expansion(rt_context * ctx, int enable) {
+	RT_REQUIRE(ctx, ctx, "rt_set_texture_expansion: NULL context");
+	ctx->expand_bc1 = enable != 0;   // takes effect at the next rt_upload_textures
+	return RT_OK;
+}
+size_t rt_texture_bytes(rt_context * ctx) { return ctx ? ctx->texture_bytes : 0; }
 
 int rt_set_node_format(rt_context * ctx, int format) {
 	RT_REQUIRE(ctx, ctx && (format == RT_NODES_REFERENCE || format == RT_NODES_DECODED), "rt_set_node_format: unknown format");

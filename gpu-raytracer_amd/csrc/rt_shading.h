@@ -54,13 +54,24 @@ RT_DEV unsigned permute(unsigned index, unsigned length, unsigned seed) {
 	return (index + seed) & mask;
 }
 
-// random<Dim>() of the reference (CUDA/Sampling.h:44-84)
-RT_DEV f2 random_sample(const RtParams & p, int dimension, unsigned pixel_index, unsigned bounce, unsigned sample_index) {
+// random<Dim>() of the reference (CUDA/Sampling.h:44-84), in two steps: what depends on the path alone -- the pixel behind the
+// virtual index, its cell of the blue-noise tile (two divisions by the pitch), the sample number -- is computed once per hit
+// (random_path), a shade kernel then draws its four pairs of numbers from it. Same integers, same floats as the one-step form.
+struct RandomPath { unsigned pixel, sample_index, blue_noise_cell; };
+RT_DEV RandomPath random_path(const RtParams & p, unsigned pixel_index, unsigned sample_index) {
 	// callers pass the virtual pixel index of the path and the first sample of the batch (rt_types.h)
+	RandomPath r;
 	unsigned sample_in_batch;
-	pixel_index = rt_split_virtual_pixel(p, pixel_index, sample_in_batch);
-	sample_index += sample_in_batch;
-	unsigned hash = pcg_hash((pixel_index * unsigned(DIM_NUM_DIMENSIONS) + unsigned(dimension)) * RT_MAX_BOUNCES + bounce);
+	r.pixel = rt_split_virtual_pixel(p, pixel_index, sample_in_batch);
+	r.sample_index = sample_index + sample_in_batch;
+	unsigned x = (r.pixel % unsigned(p.screen_pitch)) % RT_BLUE_NOISE_TEXTURE_DIM;
+	unsigned y = (r.pixel / unsigned(p.screen_pitch)) % RT_BLUE_NOISE_TEXTURE_DIM;
+	r.blue_noise_cell = x + y * RT_BLUE_NOISE_TEXTURE_DIM;
+	return r;
+}
+RT_DEV f2 random_sample(const RtParams & p, const RandomPath & path, int dimension, unsigned bounce) {
+	unsigned sample_index = path.sample_index;
+	unsigned hash = pcg_hash((path.pixel * unsigned(DIM_NUM_DIMENSIONS) + unsigned(dimension)) * RT_MAX_BOUNCES + bounce);
 
 	if (sample_index >= RT_PMJ_NUM_SAMPLES_PER_SEQUENCE) {
 		const float one_over_max_unsigned = __uint_as_float(0x2f7fffffu);
@@ -73,19 +84,22 @@ RT_DEV f2 random_sample(const RtParams & p, int dimension, unsigned pixel_index,
 	if (dim >= RT_PMJ_NUM_SEQUENCES) sample_index = permute(sample_index, RT_PMJ_NUM_SAMPLES_PER_SEQUENCE, hash);
 
 	float2 s = p.pmj_samples[(dim % RT_PMJ_NUM_SEQUENCES) * RT_PMJ_NUM_SAMPLES_PER_SEQUENCE + sample_index];
-
-	unsigned x = (pixel_index % unsigned(p.screen_pitch)) % RT_BLUE_NOISE_TEXTURE_DIM;
-	unsigned y = (pixel_index / unsigned(p.screen_pitch)) % RT_BLUE_NOISE_TEXTURE_DIM;
-	uchar2 bn = p.blue_noise[(dim % RT_BLUE_NOISE_NUM_TEXTURES) * (RT_BLUE_NOISE_TEXTURE_DIM * RT_BLUE_NOISE_TEXTURE_DIM) + x + y * RT_BLUE_NOISE_TEXTURE_DIM];
+	uchar2 bn = p.blue_noise[(dim % RT_BLUE_NOISE_NUM_TEXTURES) * (RT_BLUE_NOISE_TEXTURE_DIM * RT_BLUE_NOISE_TEXTURE_DIM) + path.blue_noise_cell];
 
 	f2 sample = mk2(s.x + float(bn.x) * (1.0f / 255.0f), s.y + float(bn.y) * (1.0f / 255.0f));
 	if (sample.x >= 1.0f) sample.x -= 1.0f;
 	if (sample.y >= 1.0f) sample.y -= 1.0f;
 	return sample;
 }
+RT_DEV f2 random_sample(const RtParams & p, int dimension, unsigned pixel_index, unsigned bounce, unsigned sample_index) {
+	return random_sample(p, random_path(p, pixel_index, sample_index), dimension, bounce);
+}
 
 // ---- warps (CUDA/Sampling.h:86-178) ---------------------------------------------------------------
-RT_DEV f2 sincos_pair(float x) { return mk2(sinf(x), cosf(x)); }
+// sinf and cosf of this library each reduce the argument and evaluate BOTH polynomials before they pick one by quadrant (ocml
+// sincosred): sincosf does that once and returns the same two floats (the reference calls the hardware approximation __sincosf here,
+// Util.h:191-195; the oracle calls libm)
+RT_DEV f2 sincos_pair(float x) { float s, c; sincosf(x, &s, &c); return mk2(s, c); }
 
 RT_DEV float sample_tent(float u) {
 	if (u < 0.5f) return safe_sqrt(2.0f * u) - 1.0f;
@@ -153,7 +167,8 @@ RT_DEV f3 sample_visible_normals_ggx(f3 omega, float alpha_x, float alpha_y, flo
 	return normalize(mk3(alpha_x * n_h.x, alpha_y * n_h.y, n_h.z));
 }
 
-RT_DEV int binary_search(const float * __restrict__ cdf, int index_first, int index_last, float value) {
+template<typename Table>
+RT_DEV int binary_search(const Table cdf, int index_first, int index_last, float value) {
 	int left = index_first, right = index_last;
 	while (true) {
 		int middle = (left + right) / 2;
@@ -208,20 +223,20 @@ RT_DEV uchar4 bc1_texel(uint2 block, int x_in_block, int y_in_block) {
 	return make_uchar4(0, 0, 0, 0);
 }
 
-// A mip level as the filter sees it: where it starts (in texels for RGBA8, in blocks for BC1) and its size.
+// A mip level as the filter sees it: where it starts (in texels for RGBA8, in blocks for BC1 and expanded BC1) and its size.
 struct RtTextureLevel { size_t offset; int w, h; };
 RT_DEV RtTextureLevel texture_level(const RtTexture & tex, int level) {
 	RtTextureLevel r; r.offset = 0;
 	for (int l = 0; l < level; l++) {
 		int lw = max(tex.width >> l, 1), lh = max(tex.height >> l, 1);
-		r.offset += tex.format == RT_TEXTURE_BC1 ? size_t((lw + 3) >> 2) * ((lh + 3) >> 2) : size_t(lw) * lh;
+		r.offset += tex.format != RT_TEXTURE_RGBA8 ? size_t((lw + 3) >> 2) * ((lh + 3) >> 2) : size_t(lw) * lh;
 	}
 	r.w = max(tex.width >> level, 1); r.h = max(tex.height >> level, 1);
 	return r;
 }
 RT_DEV RtTextureLevel texture_level_after(const RtTexture & tex, const RtTextureLevel & at, int level) {   // level + 1, from `level`
 	RtTextureLevel r;
-	r.offset = at.offset + (tex.format == RT_TEXTURE_BC1 ? size_t((at.w + 3) >> 2) * ((at.h + 3) >> 2) : size_t(at.w) * at.h);
+	r.offset = at.offset + (tex.format != RT_TEXTURE_RGBA8 ? size_t((at.w + 3) >> 2) * ((at.h + 3) >> 2) : size_t(at.w) * at.h);
 	r.w = max(tex.width >> (level + 1), 1); r.h = max(tex.height >> (level + 1), 1);
 	return r;
 }
@@ -231,6 +246,9 @@ RT_DEV f4 texel_to_float(uchar4 c) { return mk4(float(c.x) * (1.0f / 255.0f), fl
 // The two columns and the two rows are wrapped ONCE each -- with a mask where the size is a power of two (every BC1 level
 // is), a remainder otherwise: the integer remainders of a tap-by-tap formulation (eight per footprint, ~20 instructions each
 // without a divide unit) were most of what a texture lookup cost. Same texels, same arithmetic on them.
+// COMPRESSED = false: the caller knows that no texture on the device holds BC1 blocks (RtParams::textures_compressed == 0, the
+// default: rt_set_texture_expansion) -- the per-fetch decode is compiled out, and with it 1 300 instructions and the registers it pins.
+template<bool COMPRESSED = true>
 RT_DEV f4 texture_bilinear(const RtTexture & tex, const RtTextureLevel & lv, float s, float t) {
 	const int w = lv.w, h = lv.h;
 	float x = s * float(w) - 0.5f, y = t * float(h) - 0.5f;
@@ -240,7 +258,15 @@ RT_DEV f4 texture_bilinear(const RtTexture & tex, const RtTextureLevel & lv, flo
 	if ((w & (w - 1)) == 0) { x0 &= w - 1; x1 &= w - 1; } else { x0 = wrap_index(x0, w); x1 = x0 + 1 == w ? 0 : x0 + 1; }
 	if ((h & (h - 1)) == 0) { y0 &= h - 1; y1 &= h - 1; } else { y0 = wrap_index(y0, h); y1 = y0 + 1 == h ? 0 : y0 + 1; }
 	uchar4 c00, c10, c01, c11;
-	if (tex.format == RT_TEXTURE_BC1) {
+	if (!COMPRESSED && tex.format == RT_TEXTURE_BC1_EXPANDED) {   // (a context holds compressed blocks OR expanded ones, never both: rt_upload_textures)   // the blocks of the BC1 chain, decoded at upload: texel (x, y) is entry (y & 3) * 4 + (x & 3) of block (y >> 2, x >> 2)
+		const uchar4 * texels = tex.texels + (lv.offset << 4);
+		const unsigned blocks_per_row = unsigned(w + 3) >> 2;
+		const unsigned row0 = (unsigned(y0) >> 2) * blocks_per_row, row1 = (unsigned(y1) >> 2) * blocks_per_row;   // (32 bits: a level has far fewer than 2^28 blocks)
+		const unsigned in0 = (unsigned(y0) & 3u) << 2, in1 = (unsigned(y1) & 3u) << 2;
+		const unsigned col0 = ((unsigned(x0) >> 2) << 4) | (unsigned(x0) & 3u), col1 = ((unsigned(x1) >> 2) << 4) | (unsigned(x1) & 3u);
+		c00 = texels[(row0 << 4) + in0 + col0]; c10 = texels[(row0 << 4) + in0 + col1];
+		c01 = texels[(row1 << 4) + in1 + col0]; c11 = texels[(row1 << 4) + in1 + col1];
+	} else if (COMPRESSED && tex.format == RT_TEXTURE_BC1) {
 		const uint2 * blocks = (const uint2 *)tex.texels + lv.offset;
 		const int blocks_per_row = (w + 3) >> 2;
 		const size_t row0 = size_t(y0 >> 2) * blocks_per_row, row1 = size_t(y1 >> 2) * blocks_per_row;
@@ -254,7 +280,8 @@ RT_DEV f4 texture_bilinear(const RtTexture & tex, const RtTextureLevel & lv, flo
 	}
 	return lerp4(lerp4(texel_to_float(c00), texel_to_float(c10), fx), lerp4(texel_to_float(c01), texel_to_float(c11), fx), fy);
 }
-RT_DEV f4 texture_get(const RtTexture & tex, float s, float t) { return texture_bilinear(tex, texture_level(tex, 0), s, t); }
+template<bool COMPRESSED = true>
+RT_DEV f4 texture_get(const RtTexture & tex, float s, float t) { return texture_bilinear<COMPRESSED>(tex, texture_level(tex, 0), s, t); }
 
 // Trilinear between floor(lod) and the next level; the levels are looked up once per filtered fetch, not once per probe.
 struct RtTrilinear { RtTextureLevel l0, l1; float fl; bool single; };
@@ -270,12 +297,15 @@ RT_DEV RtTrilinear texture_trilinear_levels(const RtTexture & tex, float lod) {
 	r.l1 = r.single ? r.l0 : texture_level_after(tex, r.l0, l0);
 	return r;
 }
+template<bool COMPRESSED = true>
 RT_DEV f4 texture_trilinear(const RtTexture & tex, const RtTrilinear & tri, float s, float t) {
-	f4 a = texture_bilinear(tex, tri.l0, s, t);
+	f4 a = texture_bilinear<COMPRESSED>(tex, tri.l0, s, t);
 	if (tri.single) return a;
-	return lerp4(a, texture_bilinear(tex, tri.l1, s, t), tri.fl);
+	return lerp4(a, texture_bilinear<COMPRESSED>(tex, tri.l1, s, t), tri.fl);
 }
-RT_DEV f4 texture_get_lod(const RtTexture & tex, float s, float t, float lod) { return texture_trilinear(tex, texture_trilinear_levels(tex, lod), s, t); }
+template<bool COMPRESSED = true>
+RT_DEV f4 texture_get_lod(const RtTexture & tex, float s, float t, float lod) { return texture_trilinear<COMPRESSED>(tex, texture_trilinear_levels(tex, lod), s, t); }
+template<bool COMPRESSED = true>
 RT_DEV f4 texture_get_grad(const RtTexture & tex, float s, float t, f2 dx, f2 dy) {
 	float w = float(tex.width), h = float(tex.height);
 	float px = sqrtf(square(dx.x * w) + square(dx.y * h));
@@ -290,7 +320,7 @@ RT_DEV f4 texture_get_grad(const RtTexture & tex, float s, float t, f2 dx, f2 dy
 	f4 sum = mk4(0.0f);
 	for (int i = 0; i < n; i++) {
 		float o = (float(i) + 0.5f) / n_f - 0.5f;
-		sum += texture_trilinear(tex, tri, s + major.x * o, t + major.y * o);
+		sum += texture_trilinear<COMPRESSED>(tex, tri, s + major.x * o, t + major.y * o);
 	}
 	return sum * (1.0f / n_f);
 }

@@ -87,12 +87,19 @@ struct RtStreamControl {               // queue sizes and ray-claim cursors; [it
 };
 
 struct RtTexture {
-	const uchar4 * texels;   // linear RGBA8, mip levels back to back; or BC1 blocks (uint2 each), see `format`
+	const uchar4 * texels;   // linear RGBA8, mip levels back to back; or BC1 blocks (uint2 each); or expanded blocks (16 texels each), see `format`
 	int   width, height, mip_levels;
 	float lod_bias;          // 0.5 * log2(width * height)   (Integrator.cpp:95)
-	int   format;            // RT_TEXTURE_RGBA8 / RT_TEXTURE_BC1
+	int   format;            // RT_TEXTURE_RGBA8 / RT_TEXTURE_BC1 / RT_TEXTURE_BC1_EXPANDED
 	int   pad;
 };
+// Device-only format (rt_set_texture_expansion, on by default): a BC1 texture whose blocks rt_upload_textures has decoded ONCE,
+// with the shade kernels' own bc1_texel, into 16 RGBA8 texels each -- 64 bytes per block, row-major inside the block, blocks and
+// levels in the order of the compressed chain. The reference leaves the decode to NVIDIA's texture unit; this chip has none, and
+// decoding a block per texel fetch was ~55 vector instructions x 8 texels x up to 16 probes per lookup: a third of a shade
+// kernel's instructions. 8 x the bytes of BC1 (Sponza: 13 -> 105 MB of 288 GB), the same texel values to the bit, and a bilinear
+// footprint still lies in one or two 64-byte blocks (a linear RGBA8 image would spread it over two rows).
+#define RT_TEXTURE_BC1_EXPANDED 2
 
 struct RtAOV { float4 * framebuffer, * accumulator; };
 
@@ -129,13 +136,14 @@ struct RtParams {
 	const float4  * materials;  // 2 float4 per material
 	const float4  * media;      // 2 float4 per medium
 	const RtTexture * textures;
+	int textures_compressed;          // 1: at least one texture holds BC1 blocks that a fetch has to decode (rt_set_texture_expansion(ctx, 0)); picks the material kernels' instantiation
 	// lights
 	const int   * light_triangle_indices;
 	const float * light_triangle_cumulative_probability;
 	const float * light_mesh_cumulative_probability;
 	const int2  * light_mesh_triangle_span;
 	const int   * light_mesh_transform_indices;
-	int   light_mesh_count;
+	int   light_mesh_count, light_triangle_count;
 	float lights_total_weight;
 	// rng
 	const float2 * pmj_samples;
@@ -228,6 +236,7 @@ __device__ __forceinline__ RtPathInfo rt_stream_path_info(const RtParams & p, un
 
 // Launch helpers implemented in the kernel translation units
 void rt_launch_generate(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, hipStream_t stream);
+void rt_launch_expand_bc1(const uint2 * blocks, uchar4 * texels, size_t block_count, hipStream_t stream);
 void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream);
 // merged wavefront (the iteration is p.stream_iteration); stats: null, or 10 x u64 as for the counting variants below
 void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, int slot_base, int queue_offset, hipStream_t stream);

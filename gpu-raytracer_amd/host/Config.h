@@ -97,6 +97,10 @@ struct CPUConfig {
 	// BC1-quantise power-of-two textures like the reference does by default (BlockCompression.cpp). Off by
 	// default here until the textured GPU parity tests have been re-run with it.
 	bool enable_block_compression = true;  // the reference's default (Config.h:55): every power-of-two texture is stored as BC1
+	// Block-compressed textures are decoded ONCE, when they are uploaded (rt_set_texture_expansion): the device keeps 64 bytes per
+	// 4x4 block instead of 8 and the shade kernels fetch texels instead of decoding a block per fetch -- the same texel values.
+	// false: the 8-byte blocks stay compressed on the device (an eighth of the memory, a third more shade time).
+	bool expand_block_compressed_textures = true;
 	BVHType bvh_type = BVHType::BVH8;
 
 	// "<mesh file>.bvh" caches (BVHCache.h). The reference always reads and writes them; a library

@@ -66,6 +66,7 @@ void Integrator::init_materials() {
 				descs[i].format = RT_TEXTURE_BC1;
 			}
 		}
+		check(rt_set_texture_expansion(ctx, cpu_config.expand_block_compressed_textures ? 1 : 0));
 		check(rt_upload_textures(ctx, descs.data(), descs.size()));
 	}
 }

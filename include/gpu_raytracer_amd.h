@@ -141,8 +141,9 @@ const char * rt_version(void);
  *   2  rt_texture_desc grew `format`, `lod_width`, `lod_height` (32 -> 40 bytes; rt_upload_textures rejects unknown formats)
  *   3  RT_TIMING_* kinds of rt_get_launch_timings, rt_comm_* / rt_all_gather_* entry points (additions only)
  *   4  rt_upload_triangle_aliases, rt_set_static_geometry (additions only)
+ *   5  rt_set_texture_expansion, rt_texture_bytes (additions only; BC1 textures are decoded at upload unless asked otherwise)
  * Check `rt_abi_version() == RT_ABI_VERSION` once after loading the library.                                          */
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 int rt_abi_version(void);
 
 /* ---- scene upload ------------------------------------------------------------------- */
@@ -228,6 +229,15 @@ int rt_upload_materials(rt_context * ctx, const uint8_t * types, const void * ma
 int rt_upload_media(rt_context * ctx, const void * media, size_t count);
 /* Replaces `textures` (Integrator.cpp:33-98). */
 int rt_upload_textures(rt_context * ctx, const rt_texture_desc * descs, size_t count);
+/* Where RT_TEXTURE_BC1 textures are decoded. enable = 1 (the default): once, by rt_upload_textures -- the device keeps 16 RGBA8
+ * texels (64 bytes) per block, blocks and mip levels in the order of the compressed chain, and a filtered fetch reads texels.
+ * enable = 0: the device keeps the 8-byte blocks and the shade kernels decode a block per texel fetch. The reference hands
+ * the blocks to NVIDIA's texture unit (Assets/TextureLoader.cpp:208-262, CUDA/Material.h:60-75), which decodes for free; CDNA
+ * compute has no such unit and the per-fetch decode was a third of a shade kernel's instructions, while 8 x the bytes of the
+ * compressed chain is nothing next to 288 GB. Both settings produce the same texel values (one decode routine), hence the same
+ * images. Takes effect at the next rt_upload_textures. rt_texture_bytes: device bytes the uploaded textures occupy.          */
+int rt_set_texture_expansion(rt_context * ctx, int enable);
+size_t rt_texture_bytes(rt_context * ctx);
 /* Replaces light_* globals and lights_total_weight (Pathtracer.cpp:455-534).             */
 int rt_upload_lights(rt_context * ctx,
                      const int32_t * light_triangle_indices, const float * light_triangle_cumulative_probability, size_t light_triangle_count,

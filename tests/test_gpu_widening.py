@@ -4,6 +4,7 @@ row can never hide the hot-path parity tests."""
 import os
 import sys
 
+import ctypes
 import numpy as np
 import pytest
 
@@ -93,6 +94,29 @@ def test_block_compressed_textures_render_like_the_oracle(grt, oracle):
         frames[compress] = pt.read_framebuffer()[:, :320, :3].copy()
         pt.close(); scene.close()
     assert not np.array_equal(frames[0], frames[1])
+
+
+def test_textures_decoded_at_upload_render_what_the_per_fetch_decode_renders(grt):
+    """rt_set_texture_expansion (config expand_block_compressed_textures, on by default): rt_upload_textures decodes every BC1 block
+    once into 16 texels and the material kernels' `_texels` instantiation fetches those; off, the device keeps the 8-byte blocks and
+    decodes one per texel fetch (the reference leaves that to the texture unit: TextureLoader.cpp:208-262). One decode routine,
+    so the albedo AOV (anisotropic probes at bounce 0) and a 4-bounce frame (trilinear lookups after it) are the same to the bit,
+    under both schedulers; the expanded chain is 8 x the bytes."""
+    results = {}
+    for expand in (1, 0):
+        for scheduler in ("merged", "slots"):
+            scene, pt = make_pathtracer(grt, "sponza", 320, 180, 0, num_bounces=4, enable_block_compression=1, expand_block_compressed_textures=expand)
+            grt.set_scheduler(pt.ctx, scheduler)
+            pt.aov_enable(grt.AOV_ALBEDO); pt.update()
+            pt.render(); pt.render()
+            lib = grt.device_lib(); lib.rt_texture_bytes.restype = ctypes.c_size_t; lib.rt_texture_bytes.argtypes = [ctypes.c_void_p]
+            results[expand, scheduler] = (pt.read_aov(grt.AOV_ALBEDO).copy(), pt.read_framebuffer().copy(), lib.rt_texture_bytes(pt.ctx))
+            pt.close(); scene.close()
+    for scheduler in ("merged", "slots"):
+        on, off = results[1, scheduler], results[0, scheduler]
+        assert np.array_equal(on[0].view(np.uint32), off[0].view(np.uint32)) and np.array_equal(on[1].view(np.uint32), off[1].view(np.uint32))
+        assert off[2] > 1 << 20 and 7.9 * off[2] < on[2] <= 8 * off[2]   # (the 1x1 stand-ins of untextured slots are not compressed)
+    assert np.abs(results[1, "merged"][0]).sum() > 0
 
 
 def test_frame_split_in_one_process_without_python_collectives(grt):
