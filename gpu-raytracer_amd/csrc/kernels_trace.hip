@@ -54,12 +54,15 @@
 #define RT_TRI_HOLD 0        // see the triangle phase; 0 = every round (tools/wave_sim: 8 / 16 save ~1.5 % of the issue slots, measured: see profiles/r03_traversal_variants.txt)
 #endif
 #ifndef RT_SHADOW_FAR_FIRST
-// Shadow rays walk a node's children far end first. Sponza, the benchmark's 8.8 M shadow rays of four samples (two thirds of them
-// occluded): an occluded ray finds its occluder after 11.8 node steps instead of 13.2, all shadow rays 12.9 instead of 13.8 --
-// the near end of a shadow ray is the surface it starts on, whose neighbourhood fills the nearest boxes without ever occluding.
-// (A per-pixel "last occluder tested first" was priced on the same rays: the cached triangle occludes 3 % of the next rays of
-// its pixel -- Sponza's occluders are small and the light sample moves --, i.e. it costs more tests than it saves; profiles/r04_shadow_rays.txt.)
-#define RT_SHADOW_FAR_FIRST 1
+// 1: shadow rays take a node's children far end first (an any-hit answer does not depend on the order). Priced on the benchmark's
+// own 8.8 M shadow rays of four samples (Sponza, two thirds of them occluded; profiles/r04_shadow_rays.txt): an occluded ray finds
+// its occluder after 11.8 node steps instead of 13.2, all shadow rays 12.9 instead of 13.8 (-6.8 %) -- the near end of a shadow ray
+// is the surface it starts on, whose neighbourhood fills the nearest boxes without ever occluding. Measured on MI355X, same box:
+// traversal 1.036 ms per step against 1.038 -- nothing: the shadow phase's waves lose as much to divergence as the rays save in
+// steps. Off, so that the shadow walk stays the reference's (and the oracle's node / triangle counters stay equal to the device's).
+// (A per-pixel "last occluder tested first" was priced on the same rays: the cached triangle occludes 3 % of the next rays of its
+// pixel -- Sponza's occluders are small and the light sample moves -- i.e. it costs more triangle tests than it saves.)
+#define RT_SHADOW_FAR_FIRST 0
 #endif
 #ifndef RT_N_D
 #define RT_N_D 4            // dynamic fetch: tolerated idle lanes per iteration (N_d = 4 of 32 in the reference)
