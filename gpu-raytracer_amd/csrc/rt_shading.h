@@ -241,6 +241,9 @@ RT_DEV RtTextureLevel texture_level_after(const RtTexture & tex, const RtTexture
 	return r;
 }
 RT_DEV f4 texel_to_float(uchar4 c) { return mk4(float(c.x) * (1.0f / 255.0f), float(c.y) * (1.0f / 255.0f), float(c.z) * (1.0f / 255.0f), float(c.w) * (1.0f / 255.0f)); }
+typedef const __attribute__((address_space(1))) unsigned * GlobalWords;
+RT_DEV unsigned texel_word(uchar4 c) { return unsigned(c.x) | (unsigned(c.y) << 8) | (unsigned(c.z) << 16) | (unsigned(c.w) << 24); }
+RT_DEV f4 texel_to_float(unsigned c) { return mk4(float(c & 0xffu) * (1.0f / 255.0f), float((c >> 8) & 0xffu) * (1.0f / 255.0f), float((c >> 16) & 0xffu) * (1.0f / 255.0f), float(c >> 24) * (1.0f / 255.0f)); }
 
 // One bilinear footprint: the four texels around (s, t) of one level, wrap addressing, weights in full fp32.
 // The two columns and the two rows are wrapped ONCE each -- with a mask where the size is a power of two (every BC1 level
@@ -257,9 +260,13 @@ RT_DEV f4 texture_bilinear(const RtTexture & tex, const RtTextureLevel & lv, flo
 	int x0 = int(x0f), y0 = int(y0f), x1 = x0 + 1, y1 = y0 + 1;
 	if ((w & (w - 1)) == 0) { x0 &= w - 1; x1 &= w - 1; } else { x0 = wrap_index(x0, w); x1 = x0 + 1 == w ? 0 : x0 + 1; }
 	if ((h & (h - 1)) == 0) { y0 &= h - 1; y1 &= h - 1; } else { y0 = wrap_index(y0, h); y1 = y0 + 1 == h ? 0 : y0 + 1; }
-	uchar4 c00, c10, c01, c11;
-	if (!COMPRESSED && tex.format == RT_TEXTURE_BC1_EXPANDED) {   // (a context holds compressed blocks OR expanded ones, never both: rt_upload_textures)   // the blocks of the BC1 chain, decoded at upload: texel (x, y) is entry (y & 3) * 4 + (x & 3) of block (y >> 2, x >> 2)
-		const uchar4 * texels = tex.texels + (lv.offset << 4);
+	// Texels travel as one 32-bit word each (r | g << 8 | b << 16 | a << 24) and are read through pointers that carry the global
+	// address space: the texel pointer comes out of a table in memory, and a pointer of unknown provenance is dereferenced with FLAT
+	// loads (the LDS aperture check in the address path, LDS and memory counters tied together).
+	unsigned c00, c10, c01, c11;
+	if (!COMPRESSED && tex.format == RT_TEXTURE_BC1_EXPANDED) {   // (a context holds compressed blocks OR expanded ones, never both: rt_upload_textures)
+		// the blocks of the BC1 chain, decoded at upload: texel (x, y) is entry (y & 3) * 4 + (x & 3) of block (y >> 2, x >> 2)
+		const GlobalWords texels = (GlobalWords)tex.texels + (lv.offset << 4);
 		const unsigned blocks_per_row = unsigned(w + 3) >> 2;
 		const unsigned row0 = (unsigned(y0) >> 2) * blocks_per_row, row1 = (unsigned(y1) >> 2) * blocks_per_row;   // (32 bits: a level has far fewer than 2^28 blocks)
 		const unsigned in0 = (unsigned(y0) & 3u) << 2, in1 = (unsigned(y1) & 3u) << 2;
@@ -267,14 +274,15 @@ RT_DEV f4 texture_bilinear(const RtTexture & tex, const RtTextureLevel & lv, flo
 		c00 = texels[(row0 << 4) + in0 + col0]; c10 = texels[(row0 << 4) + in0 + col1];
 		c01 = texels[(row1 << 4) + in1 + col0]; c11 = texels[(row1 << 4) + in1 + col1];
 	} else if (COMPRESSED && tex.format == RT_TEXTURE_BC1) {
-		const uint2 * blocks = (const uint2 *)tex.texels + lv.offset;
+		const GlobalWords blocks = (GlobalWords)tex.texels + (lv.offset << 1);   // 8-byte blocks: two words each
 		const int blocks_per_row = (w + 3) >> 2;
 		const size_t row0 = size_t(y0 >> 2) * blocks_per_row, row1 = size_t(y1 >> 2) * blocks_per_row;
-		uint2 b00 = blocks[row0 + (x0 >> 2)], b10 = blocks[row0 + (x1 >> 2)], b01 = blocks[row1 + (x0 >> 2)], b11 = blocks[row1 + (x1 >> 2)];
-		c00 = bc1_texel(b00, x0 & 3, y0 & 3); c10 = bc1_texel(b10, x1 & 3, y0 & 3);
-		c01 = bc1_texel(b01, x0 & 3, y1 & 3); c11 = bc1_texel(b11, x1 & 3, y1 & 3);
+		const size_t i00 = (row0 + (x0 >> 2)) << 1, i10 = (row0 + (x1 >> 2)) << 1, i01 = (row1 + (x0 >> 2)) << 1, i11 = (row1 + (x1 >> 2)) << 1;
+		uint2 b00 = make_uint2(blocks[i00], blocks[i00 + 1]), b10 = make_uint2(blocks[i10], blocks[i10 + 1]), b01 = make_uint2(blocks[i01], blocks[i01 + 1]), b11 = make_uint2(blocks[i11], blocks[i11 + 1]);
+		c00 = texel_word(bc1_texel(b00, x0 & 3, y0 & 3)); c10 = texel_word(bc1_texel(b10, x1 & 3, y0 & 3));
+		c01 = texel_word(bc1_texel(b01, x0 & 3, y1 & 3)); c11 = texel_word(bc1_texel(b11, x1 & 3, y1 & 3));
 	} else {
-		const uchar4 * texels = tex.texels + lv.offset;
+		const GlobalWords texels = (GlobalWords)tex.texels + lv.offset;
 		const size_t row0 = size_t(y0) * w, row1 = size_t(y1) * w;
 		c00 = texels[row0 + x0]; c10 = texels[row0 + x1]; c01 = texels[row1 + x0]; c11 = texels[row1 + x1];
 	}
