@@ -11,7 +11,9 @@
 //   * albedo / sky / LUT fetches go through the software texture unit in rt_shading.h.
 #include "rt_shading.h"
 
+#ifndef RT_SHADE_BLOCK
 #define RT_SHADE_BLOCK 256
+#endif
 #ifndef RT_SHADE_WAVES
 // The material kernels wait on scattered triangle / texture / light-table reads; left alone the compiler uses 129-140 VGPRs
 // (3 waves per SIMD). Asking for 4 waves caps them at 128 registers: one more wave to hide the latency behind.
@@ -26,7 +28,7 @@
 #define RT_RAY_BUCKET(d) 0u
 #endif
 #ifndef RT_SORT_BLOCK
-#define RT_SORT_BLOCK 512   // kernel_sort: 8 waves share one atomic per material queue
+#define RT_SORT_BLOCK 1024  // kernel_sort: 16 waves share one atomic per material queue (256: 0.230 ms per step, 512: 0.143, 1024: 0.138; profiles/r04_shade_stage.txt)
 #endif
 #ifndef RT_SORT_WAVES
 #define RT_SORT_WAVES 2    // minimum waves per SIMD asked of the sort kernels' register allocation (2 = one 512-thread workgroup per CU: no cap)
@@ -160,72 +162,6 @@ __global__ void kernel_random(RtParams p, int dimension, const unsigned * pixel_
 	if (i >= count) return;
 	f2 r = random_sample(p, dimension, pixel_indices[i], bounce, sample_index);
 	out[i] = make_float2(r.x, r.y);
-}
-
-// ---- small scene tables in LDS ------------------------------------------------------------------------------
-// What a sort or material kernel looks up per ray BEFORE it can fetch what it is going to work on -- the slot of the merged
-// wavefront's sample table (-> bounce, sample), the hit instance's material, that material's type and parameters, its texture's
-// descriptor -- is a chain of four or five dependent loads, each a round trip to L2, in kernels that run 3-4 waves per SIMD with
-// their vector ALUs 19 % (sort), 39 % (diffuse) and 61 % (plastic) busy (profiles/r04_kernel_counters.txt). The tables are tiny
-// (Sponza: 385 instances, 26 materials, 24 textures): every workgroup of these persistent grids copies them into LDS once and looks
-// them up there. A table that does not fit keeps its lookups in global memory (uniform branch). Same values either way.
-#define RT_LDS_MESHES    2048
-#define RT_LDS_MATERIALS 64
-#define RT_LDS_TEXTURES  64
-typedef int   v4i __attribute__((ext_vector_type(4)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-struct SceneTablesLDS {
-	v4i slots[RT_STREAM_SAMPLE_SLOTS];           // RtStreamSlot (merged wavefront only)
-	int mesh_material_ids[RT_LDS_MESHES];
-	v4f materials[2 * RT_LDS_MATERIALS];
-	int material_types[RT_LDS_MATERIALS];
-	v4i textures[2 * RT_LDS_TEXTURES];           // RtTexture, 32 bytes
-};
-static_assert(sizeof(RtStreamSlot) == 16 && sizeof(RtTexture) == 32, "SceneTablesLDS copies these as int4");
-typedef const __attribute__((address_space(3))) SceneTablesLDS * SceneTables;   // (typed: ds_read, not FLAT loads)
-
-template<bool MERGED>
-RT_DEV void scene_tables_to_lds(const RtParams & p, SceneTablesLDS & t) {   // whole workgroup; the caller's next barrier publishes the copy
-	const int tid = int(threadIdx.x), step = int(blockDim.x);
-	if (MERGED) for (int i = tid; i < RT_STREAM_SAMPLE_SLOTS; i += step) { int4 e = ((const int4 *)p.stream_table->slots)[i]; t.slots[i] = v4i{ e.x, e.y, e.z, e.w }; }
-	if (p.mesh_count <= RT_LDS_MESHES) for (int i = tid; i < p.mesh_count; i += step) t.mesh_material_ids[i] = p.mesh_material_ids[i];
-	if (p.material_table_count <= RT_LDS_MATERIALS) {
-		for (int i = tid; i < 2 * p.material_table_count; i += step) { float4 m = p.materials[i]; t.materials[i] = v4f{ m.x, m.y, m.z, m.w }; }
-		for (int i = tid; i < p.material_table_count; i += step) t.material_types[i] = p.material_types[i];
-	}
-	if (p.texture_table_count <= RT_LDS_TEXTURES) for (int i = tid; i < 2 * p.texture_table_count; i += step) { int4 e = ((const int4 *)p.textures)[i]; t.textures[i] = v4i{ e.x, e.y, e.z, e.w }; }
-}
-RT_DEV RtStreamSlot scene_stream_slot(const RtParams & p, SceneTables t, unsigned slot) {
-	if (t) { v4i e = t->slots[slot]; return { e.x, e.y, e.z, e.w }; }
-	return p.stream_table->slots[slot];
-}
-RT_DEV int scene_mesh_material(const RtParams & p, SceneTables t, int mesh_id) { return (t && p.mesh_count <= RT_LDS_MESHES) ? t->mesh_material_ids[mesh_id] : p.mesh_material_ids[mesh_id]; }
-RT_DEV int scene_material_type(const RtParams & p, SceneTables t, int material_id) { return (t && p.material_table_count <= RT_LDS_MATERIALS) ? t->material_types[material_id] : int(p.material_types[material_id]); }
-RT_DEV float4 scene_material(const RtParams & p, SceneTables t, int index) {   // index = 2 * material_id (+ 1)
-	if (t && p.material_table_count <= RT_LDS_MATERIALS) { v4f m = t->materials[index]; return make_float4(m.x, m.y, m.z, m.w); }
-	return p.materials[index];
-}
-RT_DEV RtTexture scene_texture(const RtParams & p, SceneTables t, int texture_id) {
-	if (t && p.texture_table_count <= RT_LDS_TEXTURES) {
-		v4i a = t->textures[2 * texture_id], b = t->textures[2 * texture_id + 1];
-		RtTexture r;
-		r.texels = (const uchar4 *)((unsigned long long)(unsigned)a.x | ((unsigned long long)(unsigned)a.y << 32));
-		r.width = a.z; r.height = a.w; r.mip_levels = b.x; r.lod_bias = __int_as_float(b.y); r.format = b.z; r.pad = b.w;
-		return r;
-	}
-	return p.textures[texture_id];
-}
-// rt_stream_path_info (rt_types.h) with the slot read through the tables
-RT_DEV RtPathInfo scene_path_info(const RtParams & p, SceneTables t, unsigned virtual_pixel) {
-	unsigned slot;
-	rt_split_virtual_pixel(p, virtual_pixel, slot);
-	RtStreamSlot e = scene_stream_slot(p, t, slot);
-	RtPathInfo info;
-	info.bounce = p.stream_iteration - e.birth_iteration;
-	info.submission = e.submission;
-	info.sample_index_for_rng = unsigned(e.sample_index) - slot;
-	info.first_of_submission = e.index_in_submission == 0;
-	return info;
 }
 
 // ---- kernel_sort -----------------------------------------------------------------------------------
@@ -372,10 +308,7 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 		MERGED ? &p.stream->material_count[0] : &p.sizes->diffuse[launch_bounce],    MERGED ? &p.stream->material_count[1] : &p.sizes->plastic[launch_bounce],
 		MERGED ? &p.stream->material_count[2] : &p.sizes->dielectric[launch_bounce], MERGED ? &p.stream->material_count[3] : &p.sizes->conductor[launch_bounce] };
 	int * const next_trace_counter = MERGED ? &p.stream->trace_count[q ^ 1] : &p.sizes->trace[launch_bounce + 1];
-	__shared__ SceneTablesLDS tables_lds;
-	const SceneTables tables = (SceneTables)&tables_lds;
-	if (blockIdx.x * blockDim.x < unsigned(ray_count)) scene_tables_to_lds<MERGED>(p, tables_lds);
-	if (MERGED) stream_stats_clear(stats_lds); else __syncthreads();   // (either way a barrier: the tables are in place)
+	if (MERGED) stream_stats_clear(stats_lds);
 
 	// every thread of the workgroup makes the same number of rounds (block_aggregated_append has barriers)
 	for (int first = blockIdx.x * blockDim.x; first < ray_count; first += gridDim.x * blockDim.x) {
@@ -393,7 +326,7 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 		pixel_index = int(pixel_index_and_flags & ~RT_FLAGS_ALL);
 		bool first_of_submission = true;
 		if (MERGED) {
-			RtPathInfo info = scene_path_info(p, tables, unsigned(pixel_index));
+			RtPathInfo info = rt_stream_path_info(p, unsigned(pixel_index));
 			bounce = info.bounce; sample_index = int(info.sample_index_for_rng); submission = info.submission; first_of_submission = info.first_of_submission;
 		}
 		ray_direction = load3(in.direction, index);
@@ -476,8 +409,8 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 			p.pixel_query_out[1] = hit.triangle_id;
 		}
 
-		int material_id = scene_mesh_material(p, tables, hit.mesh_id);
-		int material_type = scene_material_type(p, tables, material_id);
+		int material_id = p.mesh_material_ids[hit.mesh_id];
+		int material_type = p.material_types[material_id];
 
 		if (material_type == RT_MATERIAL_LIGHT) {
 			f3 p0, e1, e2;
@@ -495,7 +428,7 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 				svgf_set_gbuffers(p, x, y, hit, light_point, light_geometric_normal, light_point_prev);
 			}
 
-			f3 emission = mk3(scene_material(p, tables, 2 * material_id));
+			f3 emission = mk3(p.materials[2 * material_id]);
 
 			bool count_light = p.config.enable_next_event_estimation ? !allow_nee : true;
 			if (count_light) {
@@ -549,9 +482,9 @@ __global__ void __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES) kernel_sort_stre
 struct TextureLOD { f2 gradient_1, gradient_2; float lod; };
 
 template<bool COMPRESSED>
-RT_DEV f3 sample_albedo(const RtParams & p, SceneTables tables, int bounce, f3 diffuse, int texture_id, f2 tex_coord, const TextureLOD & lod) { // RayCone.h:19-29
+RT_DEV f3 sample_albedo(const RtParams & p, int bounce, f3 diffuse, int texture_id, f2 tex_coord, const TextureLOD & lod) { // RayCone.h:19-29
 	if (texture_id == RT_INVALID) return diffuse;
-	const RtTexture tex = scene_texture(p, tables, texture_id);
+	const RtTexture tex = p.textures[texture_id];
 	if (p.config.enable_mipmapping) {
 		if (bounce == 0) return diffuse * mk3(texture_get_grad<COMPRESSED>(tex, tex_coord.x, tex_coord.y, lod.gradient_1, lod.gradient_2));
 		return diffuse * mk3(texture_get_lod<COMPRESSED>(tex, tex_coord.x, tex_coord.y, lod.lod + tex.lod_bias));
@@ -570,10 +503,9 @@ template<bool COMPRESSED>
 struct BSDFDiffuseT : BSDFCommon {
 	static constexpr bool HAS_ALBEDO = true;
 	f3 diffuse; int texture_id; f3 albedo;
-	SceneTables tables;
-	RT_DEV void init(const RtParams & p, SceneTables t, bool, int material_id) { tables = t; float4 m = scene_material(p, t, 2 * material_id); diffuse = mk3(m.x, m.y, m.z); texture_id = __float_as_int(m.w); }
+	RT_DEV void init(const RtParams & p, bool, int material_id) { float4 m = p.materials[2 * material_id]; diffuse = mk3(m.x, m.y, m.z); texture_id = __float_as_int(m.w); }
 	RT_DEV void calc_albedo(const RtParams & p, f3 & throughput, f2 tex_coord, const TextureLOD & lod) {
-		albedo = sample_albedo<COMPRESSED>(p, tables, bounce, diffuse, texture_id, tex_coord, lod);
+		albedo = sample_albedo<COMPRESSED>(p, bounce, diffuse, texture_id, tex_coord, lod);
 		if (bounce == 0) aov_set(p, RT_AOV_ALBEDO, pixel_index, mk4(albedo));
 		if (!(p.config.enable_svgf && bounce == 0)) throughput *= albedo;
 	}
@@ -603,11 +535,9 @@ struct BSDFPlasticT : BSDFCommon {
 	static constexpr float ETA = 1.0f / IOR;
 	f3 diffuse; int texture_id; float linear_roughness; f3 albedo;
 	float F_i, lambda_i, G1_i;
-	SceneTables tables;
-	RT_DEV void init(const RtParams & p, SceneTables t, bool, int material_id) {
-		tables = t;
-		float4 m = scene_material(p, t, 2 * material_id); diffuse = mk3(m.x, m.y, m.z); texture_id = __float_as_int(m.w);
-		linear_roughness = scene_material(p, t, 2 * material_id + 1).x;
+	RT_DEV void init(const RtParams & p, bool, int material_id) {
+		float4 m = p.materials[2 * material_id]; diffuse = mk3(m.x, m.y, m.z); texture_id = __float_as_int(m.w);
+		linear_roughness = p.materials[2 * material_id + 1].x;
 		// what the light sample's evaluation (eval) and the bounce (sample) both need of the incoming direction, computed once per hit
 		float ax = roughness_to_alpha(linear_roughness);
 		F_i = fresnel_dielectric(omega_i.z, ETA);
@@ -622,7 +552,7 @@ struct BSDFPlasticT : BSDFCommon {
 		return 1.0f / (1.0f + ggx_lambda(omega_o, ax, ay) + lambda_i);
 	}
 	RT_DEV void calc_albedo(const RtParams & p, f3 &, f2 tex_coord, const TextureLOD & lod) {
-		albedo = sample_albedo<COMPRESSED>(p, tables, bounce, diffuse, texture_id, tex_coord, lod);
+		albedo = sample_albedo<COMPRESSED>(p, bounce, diffuse, texture_id, tex_coord, lod);
 		if (bounce == 0) aov_set(p, RT_AOV_ALBEDO, pixel_index, mk4(albedo));
 	}
 	RT_DEV f3 diffuse_lobe(float F_i, float F_o, float cos_o) const {
@@ -684,8 +614,8 @@ typedef BSDFPlasticT<true> BSDFPlastic;
 struct BSDFDielectric : BSDFCommon {
 	static constexpr bool HAS_ALBEDO = false;
 	int medium_id_material; float ior, linear_roughness, eta;
-	RT_DEV void init(const RtParams & p, SceneTables t, bool entering_material, int material_id) {
-		float4 m = scene_material(p, t, 2 * material_id);
+	RT_DEV void init(const RtParams & p, bool entering_material, int material_id) {
+		float4 m = p.materials[2 * material_id];
 		medium_id_material = __float_as_int(m.x); ior = m.y; linear_roughness = m.z;
 		eta = entering_material ? 1.0f / ior : ior;
 	}
@@ -781,8 +711,8 @@ struct BSDFDielectric : BSDFCommon {
 struct BSDFConductor : BSDFCommon {
 	static constexpr bool HAS_ALBEDO = false;
 	f3 eta3, k3; float linear_roughness;
-	RT_DEV void init(const RtParams & p, SceneTables t, bool, int material_id) {
-		float4 a = scene_material(p, t, 2 * material_id), b = scene_material(p, t, 2 * material_id + 1);
+	RT_DEV void init(const RtParams & p, bool, int material_id) {
+		float4 a = p.materials[2 * material_id], b = p.materials[2 * material_id + 1];
 		eta3 = mk3(a.x, a.y, a.z); linear_roughness = a.w; k3 = mk3(b.x, b.y, b.z);
 	}
 	RT_DEV void calc_albedo(const RtParams &, f3 &, f2, const TextureLOD &) { }
@@ -843,6 +773,9 @@ struct BSDFConductor : BSDFCommon {
 // The two cumulative tables of light sampling, copied into LDS by the workgroup when they fit (Sponza: 2 meshes, 480 triangles):
 // the two binary searches are chains of ~2 + ~9 dependent loads per hit, each a round trip to L2 from a kernel that runs 3-4 waves
 // per SIMD; from LDS a step costs a twentieth of that. Same floats, same comparisons.
+#ifndef RT_LIGHT_TABLES_LDS
+#define RT_LIGHT_TABLES_LDS 1
+#endif
 #define RT_LIGHT_MESHES_IN_LDS    64
 #define RT_LIGHT_TRIANGLES_IN_LDS 2048
 struct LightTablesLDS { float mesh_cdf[RT_LIGHT_MESHES_IN_LDS]; float triangle_cdf[RT_LIGHT_TRIANGLES_IN_LDS]; };
@@ -870,7 +803,7 @@ struct ShadowRay { f3 origin, direction; float max_distance; f3 illumination; };
 
 // Returns true and fills `shadow` when the light sample has to be traced (the caller appends it).
 template<typename BSDF>
-RT_DEV bool next_event_estimation(const RtParams & p, SceneTables tables, const LightTablesLDS * light_lds, int pixel_index, int bounce, int sample_index, const BSDF & bsdf, f3 hit_point, f3 normal, f3 geometric_normal, f3 throughput, ShadowRay & shadow) {
+RT_DEV bool next_event_estimation(const RtParams & p, const LightTablesLDS * light_lds, int pixel_index, int bounce, int sample_index, const BSDF & bsdf, f3 hit_point, f3 normal, f3 geometric_normal, f3 throughput, ShadowRay & shadow) {
 	f2 rand_light    = random_sample(p, bsdf.rng, DIM_NEE_LIGHT,    unsigned(bounce));
 	f2 rand_triangle = random_sample(p, bsdf.rng, DIM_NEE_TRIANGLE, unsigned(bounce));
 
@@ -897,8 +830,8 @@ RT_DEV bool next_event_estimation(const RtParams & p, SceneTables tables, const 
 	float cos_theta_light = abs_dot(to_light, light_geometric_normal);
 	float cos_theta_hit = dot(to_light, normal);
 
-	int light_material_id = scene_mesh_material(p, tables, light_mesh_id);
-	f3 emission = mk3(scene_material(p, tables, 2 * light_material_id));
+	int light_material_id = p.mesh_material_ids[light_mesh_id];
+	f3 emission = mk3(p.materials[2 * light_material_id]);
 
 	f3 bsdf_value; float bsdf_pdf;
 	if (!bsdf.eval(p, to_light, cos_theta_hit, bsdf_value, bsdf_pdf)) return false;
@@ -958,10 +891,13 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 	int * const shadow_counter = MERGED ? &p.stream->shadow_count[iq]    : &p.sizes->shadow[launch_bounce];
 	int * const trace_counter  = MERGED ? &p.stream->trace_count[iq ^ 1] : &p.sizes->trace[launch_bounce + 1];
 	const bool nee_enabled = p.config.enable_next_event_estimation && p.lights_total_weight > 0.0f; // uniform
+#if RT_LIGHT_TABLES_LDS
 	__shared__ LightTablesLDS light_lds;
-	__shared__ SceneTablesLDS tables_lds;
-	const SceneTables tables = (SceneTables)&tables_lds;
-	if (blockIdx.x * blockDim.x < unsigned(buffer_size)) { if (nee_enabled) light_tables_to_lds(p, light_lds); scene_tables_to_lds<MERGED>(p, tables_lds); }
+	if (nee_enabled && blockIdx.x * blockDim.x < unsigned(buffer_size)) light_tables_to_lds(p, light_lds);
+	const LightTablesLDS * const light_tables = &light_lds;
+#else
+	const LightTablesLDS * const light_tables = nullptr;
+#endif
 	if (MERGED) stream_stats_clear(stats_lds); else __syncthreads();   // (either way a barrier: the tables are in place)
 
 	// every thread of the workgroup makes the same number of rounds (block_aggregated_append has barriers)
@@ -980,7 +916,7 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 		unsigned pixel_index_and_flags = q.pixel_index_and_flags[index];
 		pixel_index = int(pixel_index_and_flags & ~RT_FLAGS_ALL);
 		if (MERGED) {
-			RtPathInfo info = scene_path_info(p, tables, unsigned(pixel_index));
+			RtPathInfo info = rt_stream_path_info(p, unsigned(pixel_index));
 			bounce = info.bounce; sample_index = int(info.sample_index_for_rng); submission = info.submission;
 		}
 		f3 ray_direction = load3(q.direction, index);
@@ -1029,11 +965,11 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 		f3 omega_i = world_to_local(-ray_direction, tangent, bitangent, normal);
 		if (omega_i.z <= 0.0f) return false;
 
-		int material_id = scene_mesh_material(p, tables, hit.mesh_id);
+		int material_id = p.mesh_material_ids[hit.mesh_id];
 
 		bsdf.pixel_index = pixel_index; bsdf.bounce = bounce; bsdf.sample_index = sample_index; bsdf.rng = random_path(p, unsigned(pixel_index), unsigned(sample_index));
 		bsdf.tangent = tangent; bsdf.bitangent = bitangent; bsdf.normal = normal; bsdf.omega_i = omega_i;
-		bsdf.init(p, tables, entering_material, material_id);
+		bsdf.init(p, entering_material, material_id);
 
 		if (BSDF::HAS_ALBEDO) {
 			TextureLOD lod = { mk2(0.0f, 0.0f), mk2(0.0f, 0.0f), 0.0f };
@@ -1068,7 +1004,7 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 		}
 
 		if (nee_enabled && bsdf.allow_nee()) {
-			has_shadow_ray = next_event_estimation(p, tables, &light_lds, pixel_index, bounce, sample_index, bsdf, hit_point, normal, geometric_normal, throughput, shadow);
+			has_shadow_ray = next_event_estimation(p, light_tables, pixel_index, bounce, sample_index, bsdf, hit_point, normal, geometric_normal, throughput, shadow);
 		}
 		return true;
 		};

@@ -882,7 +882,6 @@ int rt_upload_materials(rt_context * ctx, const uint8_t * types, const void * ma
 	s = upload(ctx, &ctx->materials, materials, count * 32); if (s) return s;
 	ctx->params.material_types = (const uint8_t *)ctx->material_types;
 	ctx->params.materials      = (const float4 *)ctx->materials;
-	ctx->params.material_table_count = int(count);
 
 	// Scene::check_materials (Scene.cpp:50-70): which material kernels have to run at all
 	for (bool & h : ctx->has_material) h = false;
@@ -947,7 +946,6 @@ int rt_upload_textures(rt_context * ctx, const rt_texture_desc * descs, size_t c
 	}
 	int s = upload(ctx, &ctx->texture_table, table.data(), count * sizeof(RtTexture)); if (s) return s;
 	ctx->params.textures = (const RtTexture *)ctx->texture_table;
-	ctx->params.texture_table_count = int(count);
 	ctx->params.textures_compressed = 0;
 	for (const RtTexture & t : table) if (t.format == RT_TEXTURE_BC1) ctx->params.textures_compressed = 1;
 	return RT_OK;

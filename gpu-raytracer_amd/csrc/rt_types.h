@@ -136,7 +136,6 @@ struct RtParams {
 	const float4  * materials;  // 2 float4 per material
 	const float4  * media;      // 2 float4 per medium
 	const RtTexture * textures;
-	int material_table_count, texture_table_count;   // entries of material_types / materials / textures (small tables are copied into LDS by the sort and material kernels)
 	int textures_compressed;          // 1: at least one texture holds BC1 blocks that a fetch has to decode (rt_set_texture_expansion(ctx, 0)); picks the material kernels' instantiation
 	// lights
 	const int   * light_triangle_indices;
