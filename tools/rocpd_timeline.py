@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""The last <ms> milliseconds of a rocprofv3 kernel trace (rocpd database) as a timeline: start (us from the first listed kernel),
+duration, gap to the previous kernel's end, name. Usage: tools/rocpd_timeline.py <results.db> [ms = 8]"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1]); ms = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
+    if not rows:
+        print("no kernels"); return
+    t_last = max(r[2] for r in rows)
+    rows = [r for r in rows if r[1] >= t_last - ms * 1e6]
+    t0 = rows[0][1]; prev_end = t0
+    for name, start, end in rows:
+        print("%10.1f us  %9.1f us  gap %7.1f  %s" % ((start - t0) / 1e3, (end - start) / 1e3, (start - prev_end) / 1e3, name.split("(")[0][-60:]))
+        prev_end = max(prev_end, end)
+
+
+if __name__ == "__main__":
+    main()
