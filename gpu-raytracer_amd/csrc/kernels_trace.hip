@@ -896,6 +896,197 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 	#undef RT_IS_SHADOW
 }
 
+// ---- the flattened scene's engine with the NEXT node's loads in flight behind the triangle tests ------------------------------------
+// A round of the engine above is a serial chain with TWO memory latencies in it: the node (pop -> five loads -> slab tests) and then
+// the triangles the slab tests found (loads -> Moeller-Trumbore); a resident wave spends 37 % of its time parked on s_waitcnt
+// (profiles/r04_traversal_experiments.txt). Which node a lane tests next does not depend on the triangle tests in front of it -- only
+// the distance its slab tests will be clipped to does --, so here a lane picks its next node (closest pending child, or the top of the
+// stack) and issues the five loads BEFORE the triangle tests of the round, as soon as it knows that this round's batch empties its
+// leaf; the slab tests on that node run at the top of the next round, on registers that have been on their way for a triangle
+// phase. The visiting order, the clip distances and therefore every hit are those of the engine above (and of the oracle); what is
+// paid is 20 registers that stay live through the triangle phase.
+// FLAT only (no TLAS, no instances), one ray per lane, no counters.
+#ifndef RT_FLAT_PIPELINE
+#define RT_FLAT_PIPELINE 0
+#endif
+#ifndef RT_PIPE_TRI_BATCH
+#define RT_PIPE_TRI_BATCH RT_TRI_BATCH
+#endif
+template<int MODE, typename Source>
+RT_DEV void bvh8_trace_engine_flat_pipelined(const RtParams & p, Source & src, int ray_count, int * cursor_1, int ray_count_2 = 0, int * cursor_2 = nullptr) {
+	constexpr bool SHADOW = MODE == RT_TRACE_SHADOW;
+	bool lane_shadow = SHADOW;
+	#define RT_IS_SHADOW (MODE == RT_TRACE_MIXED ? lane_shadow : SHADOW)
+	const float4 * __restrict__ nodes     = p.bvh8_nodes;
+	const float4 * __restrict__ triangles = p.triangle_positions;
+
+	unsigned lane = threadIdx.x & (RT_WAVE_SIZE - 1);
+	unsigned wave = threadIdx.x / RT_WAVE_SIZE;
+
+	TraversalStack stack;
+	stack.lds   = (LdsUint2 *)&shared_stack[wave * (RT_LDS_STACK * RT_WAVE_SIZE) + lane];
+	stack.spill_stride = int(gridDim.x * blockDim.x);
+	stack.spill = (GlobalUint2 *)(p.stack_spill + (blockIdx.x * blockDim.x + threadIdx.x));
+	stack.size  = 0;
+
+	const int waves_in_grid = int(gridDim.x) * (RT_TRACE_BLOCK / RT_WAVE_SIZE);
+	const int rays_total = ray_count + (MODE == RT_TRACE_MIXED ? ray_count_2 : 0);
+	const int ray_block = max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (rays_total / (2 * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
+	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * unsigned(ray_block) >= unsigned(rays_total)) return;
+	typedef volatile __attribute__((address_space(3))) int LdsFetchWord;
+	LdsFetchWord * fetch_state = (LdsFetchWord *)&shared_fetch[wave][0];
+	if (lane == 0) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[2] = 0; fetch_state[3] = 0; }
+	auto fetch_ray = [&]() -> int {   // as in bvh8_trace_engine
+		while (true) {
+			if (fetch_state[2]) return -1;
+			const bool second_queue = MODE == RT_TRACE_MIXED && fetch_state[3] != 0;
+			const int queue_count = second_queue ? ray_count_2 : ray_count;
+			int * const queue_cursor = second_queue ? cursor_2 : cursor_1;
+			unsigned long long want = __ballot(1);
+			int n_want = __popcll(want);
+			unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(want >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(want), 0u));
+			bool elected = rank == 0;
+			int next = fetch_state[0], end = fetch_state[1];
+			if (next >= end) {
+				int base = 0;
+				if (elected) base = atomicAdd(queue_cursor, ray_block);
+				base = __builtin_amdgcn_readfirstlane(base);
+				next = min(base, queue_count);
+				end  = min(base + ray_block, queue_count);
+			}
+			int give = min(n_want, end - next);
+			if (elected) {
+				fetch_state[0] = next + give;
+				fetch_state[1] = end;
+				if (next >= end) {
+					if (MODE == RT_TRACE_MIXED && !second_queue) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[3] = 1; }
+					else fetch_state[2] = 1;
+				}
+			}
+			if (int(rank) < give) { if (MODE == RT_TRACE_MIXED) lane_shadow = second_queue; return next + int(rank); }
+		}
+	};
+
+	uint2 current_group  = make_uint2(0, 0);   // meaningful between a node's slab tests and the choice of the next node only
+	uint2 triangle_group = make_uint2(0, 0);
+	float4 pn0 = make_float4(0, 0, 0, 0), pn1 = pn0, pn2 = pn0, pn3 = pn0, pn4 = pn0;   // the node this lane tests next
+	bool have_next = false;
+
+	int  ray_index = 0;
+	Ray3 ray;
+	f3   inv_dir;
+	unsigned oct_inv4 = 0;
+	float max_distance = 0.0f;
+	HitRecord hit;
+
+	int result_pending = 0;
+	while (true) {
+		bool inactive = !have_next && triangle_group.y == 0;
+
+		if (result_pending) {
+			if (!RT_IS_SHADOW && p.has_triangle_aliases && hit.triangle_id != RT_INVALID) {
+				float4 names = triangles[size_t(hit.triangle_id) * 3 + 2];
+				if (__float_as_int(names.z) >= 0) { hit.mesh_id = __float_as_int(names.z); hit.triangle_id = __float_as_int(names.w); }
+			}
+			source_finish<MODE>(src, RT_IS_SHADOW, ray_index, hit, result_pending == 2);
+			result_pending = 0;
+		}
+		if (inactive) {
+			ray_index = fetch_ray();
+			if (ray_index < 0) return;
+
+			source_load<MODE>(src, RT_IS_SHADOW, ray_index, ray, max_distance);
+			inv_dir  = reciprocal(ray.direction);
+			oct_inv4 = ray_get_octant_inv4(ray.direction);
+			hit.t = RT_INFINITY; hit.u = 0.0f; hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
+			pn0 = nodes[0]; pn1 = nodes[1]; pn2 = nodes[2]; pn3 = nodes[3]; pn4 = nodes[4];   // the root
+			have_next = true;
+		}
+
+		int iterations_lost = 0;
+		bool running = true;
+		do {
+			if (running) {
+				// ---- slab tests on the node that was fetched during the previous round
+				if (have_next) {
+					unsigned hitmask = bvh8_node_intersect(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, pn0, pn1, pn2, pn3, pn4);
+					unsigned imask = extract_byte(__float_as_uint(pn0.w), 3);
+					current_group  = make_uint2(__float_as_uint(pn1.x), (hitmask & 0xff000000u) | imask);
+					triangle_group = make_uint2(__float_as_uint(pn1.y), hitmask & 0x00ffffffu);
+					have_next = false;
+				}
+
+				// ---- does this round's batch empty the lane's leaf? Then its next node is chosen now: the stack is popped BEFORE the
+				// triangle loads are issued (a spilled entry is a global load: loads come back in order, and a wait for it behind the
+				// triangle loads would be a wait for them) ...
+				const bool leaf_done = __popc(triangle_group.y) <= RT_PIPE_TRI_BATCH;
+				if (leaf_done && (current_group.y & 0xff000000u) == 0 && stack.size != 0) current_group = stack.pop();   // (a flattened scene's stack holds node groups only)
+				asm volatile("" : "+v"(current_group.x), "+v"(current_group.y));   // the popped entry is waited for HERE, not behind the loads below
+				const bool need_node = leaf_done && (current_group.y & 0xff000000u) != 0;
+
+				// ---- ... the triangle loads ...
+				int    tri_id[RT_PIPE_TRI_BATCH];
+				float4 tri_a[RT_PIPE_TRI_BATCH], tri_b[RT_PIPE_TRI_BATCH];
+				float  tri_c[RT_PIPE_TRI_BATCH];
+				#pragma unroll
+				for (int k = 0; k < RT_PIPE_TRI_BATCH; k++) {
+					tri_id[k] = RT_INVALID;
+					if (triangle_group.y != 0) {
+						int triangle_index = int(msb(triangle_group.y));
+						triangle_group.y &= ~(1u << triangle_index);
+						tri_id[k] = int(triangle_group.x) + triangle_index;
+						const float4 * tri = triangles + size_t(tri_id[k]) * 3;
+						tri_a[k] = tri[0]; tri_b[k] = tri[1]; tri_c[k] = tri[2].x;
+					}
+				}
+
+				// ---- ... and LAST the five loads of the next node, which stay in flight behind the triangle tests. Issued by every running
+				// lane, outside any branch (a lane with nothing to fetch reads the root into registers it does not look at): loads under
+				// a branch would make the compiler's wait for the triangles a wait for everything outstanding.
+				unsigned next_node_index = 0;
+				if (need_node) {
+					unsigned hits_imask = current_group.y;
+					unsigned child_index_offset = msb(hits_imask);
+					current_group.y &= ~(1u << child_index_offset);
+					if (current_group.y & 0xff000000u) stack.push(current_group);
+					unsigned slot_index     = (child_index_offset - 24) ^ (oct_inv4 & 0xffu);
+					unsigned relative_index = __popc(hits_imask & ~(0xffffffffu << slot_index));
+					next_node_index = current_group.x + relative_index;
+					current_group.y = 0;
+				}
+				{
+					const float4 * node = nodes + size_t(next_node_index) * 5;
+					pn0 = node[0]; pn1 = node[1]; pn2 = node[2]; pn3 = node[3]; pn4 = node[4];
+				}
+				have_next = need_node;
+
+				// ---- the triangle tests, in the sequential order (a shadow ray's second test runs whatever the first found: the answer is
+				// the same, and every load of the round has a use on every path)
+				bool occluded = false;
+				#pragma unroll
+				for (int k = 0; k < RT_PIPE_TRI_BATCH; k++) {
+					if (tri_id[k] != RT_INVALID) {
+						if (triangle_test_kind(RT_IS_SHADOW, tri_a[k], tri_b[k], make_float4(tri_c[k], 0.0f, 0.0f, 0.0f), 0, tri_id[k], ray, max_distance, hit)) occluded = true;
+					}
+				}
+
+				if (RT_IS_SHADOW && occluded) {
+					result_pending = 2;
+					stack.size = 0;
+					triangle_group.y = 0;
+					have_next = false;
+					running = false;
+				} else if (!have_next && triangle_group.y == 0) {
+					result_pending = 1;
+					running = false;
+				}
+			}
+			iterations_lost += RT_WAVE_SIZE - __popcll(__ballot(running)) - RT_N_D;
+		} while (iterations_lost < RT_N_W);
+	}
+	#undef RT_IS_SHADOW
+}
+
 
 #define RT_TRACE_LAUNCH_WAVES RT_TRACE_WAVES_PER_SIMD
 #ifndef RT_MIXED_MAX_RAYS
@@ -1411,6 +1602,14 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	//   profiles/r02_mixed_engine.txt
 	if (!COUNT && closest_count + shadow_count <= RT_NARROW_MAX_RAYS)
 		bvh8_trace_engine<RT_TRACE_MIXED, false, true, true, FLAT>(p, src, closest_count, &p.stream->cursor[q][0], nullptr, shadow_count, &p.stream->cursor[q][1]);
+	else if constexpr (RT_FLAT_PIPELINE && FLAT && !COUNT && !WIDE && !CACHE) {
+		if (closest_count + shadow_count <= RT_MIXED_MAX_RAYS)
+			bvh8_trace_engine_flat_pipelined<RT_TRACE_MIXED>(p, src, closest_count, &p.stream->cursor[q][0], shadow_count, &p.stream->cursor[q][1]);
+		else {
+			bvh8_trace_engine_flat_pipelined<RT_TRACE_CLOSEST>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
+			bvh8_trace_engine_flat_pipelined<RT_TRACE_SHADOW >(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
+		}
+	}
 	else if (COUNT || closest_count + shadow_count <= RT_MIXED_MAX_RAYS)
 		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true, FLAT, WIDE, CACHE>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
 	else {
