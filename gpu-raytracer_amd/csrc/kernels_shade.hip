@@ -19,6 +19,14 @@
 // (3 waves per SIMD). Asking for 4 waves caps them at 128 registers: one more wave to hide the latency behind.
 #define RT_SHADE_WAVES 4
 #endif
+#ifndef RT_SORT_EARLY
+// 1: the sort kernel fetches what hangs on the hit (instance -> material id -> material type) and the roulette's random number (slot table ->
+// sample tables) as soon as the queue entry is there, side by side, not in the order the classification consults them.
+#define RT_SORT_EARLY 0
+#endif
+#ifndef RT_SHADE_ONE_APPEND
+#define RT_SHADE_ONE_APPEND 1   // 1: the shadow-ray and the continuation-ray append of a shade round share barriers and atomic latency (block_bucketed_append2)
+#endif
 #ifndef RT_OCTANT_BUCKETS
 #define RT_OCTANT_BUCKETS 1   // a shade workgroup appends its rays ordered by direction octant (rt_math.h: block_bucketed_append)
 #endif
@@ -31,7 +39,12 @@
 #define RT_SORT_BLOCK 1024  // kernel_sort: 16 waves share one atomic per material queue (256: 0.230 ms per step, 512: 0.143, 1024: 0.138; profiles/r04_shade_stage.txt)
 #endif
 #ifndef RT_SORT_WAVES
-#define RT_SORT_WAVES 2    // minimum waves per SIMD asked of the sort kernels' register allocation (2 = one 512-thread workgroup per CU: no cap)
+// Waves per SIMD asked of the sort kernels' register allocation. The kernel is a chain of dependent gathers (queue entry -> slot table -> sample
+// tables of the roulette; hit -> instance material -> material type) at a fifth of the vector ALUs: what it needs is rays in flight. 8 = 64
+// registers (the general form takes 100: one 1024-thread workgroup per CU, 4 waves per SIMD), two workgroups per CU; the 128 bytes of scratch
+// that costs sit in the branches Sponza never takes (media, emitters seen by a BSDF ray). Measured, one box: sort 0.135 -> 0.103 ms per step
+// (profiles/r04_shade_stage.txt, 5.); 512-thread workgroups at 6 waves (80 registers): 0.165.
+#define RT_SORT_WAVES 8
 #endif
 
 struct HitInfo { float t, u, v; int mesh_id, triangle_id; };
@@ -167,13 +180,16 @@ __global__ void kernel_random(RtParams p, int dimension, const unsigned * pixel_
 // ---- kernel_sort -----------------------------------------------------------------------------------
 
 // Returns true if the path terminates (Pathtracer.cu:199-218)
-RT_DEV bool russian_roulette(const RtParams & p, int pixel_index, int bounce, int sample_index, f3 & throughput) {
+// whether russian_roulette() will draw its random number for a path at this bounce
+RT_DEV bool russian_roulette_draws(const RtParams & p, int bounce) { return bounce != p.config.num_bounces - 1 && p.config.enable_russian_roulette && bounce > 0; }
+// `drawn`: null, or the number random_sample(DIM_RUSSIAN_ROULETTE, ...).x the caller has fetched already (where russian_roulette_draws())
+RT_DEV bool russian_roulette(const RtParams & p, int pixel_index, int bounce, int sample_index, f3 & throughput, const float * drawn = nullptr) {
 	if (bounce == p.config.num_bounces - 1) return true;
 	if (p.config.enable_russian_roulette && bounce > 0) {
 		f3 t = throughput;
 		if (p.config.enable_svgf) t *= mk3(aov_get(p, RT_AOV_ALBEDO, pixel_index));
 		float survival_probability = saturate(fmaxf(fmaxf(t.x, t.y), t.z));
-		float r = random_sample(p, DIM_RUSSIAN_ROULETTE, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index)).x;
+		float r = drawn ? *drawn : random_sample(p, DIM_RUSSIAN_ROULETTE, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index)).x;
 		if (r > survival_probability) return true;
 		throughput /= survival_probability;
 	}
@@ -332,6 +348,13 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 		ray_direction = load3(in.direction, index);
 		packed_hit = in.hits[index];
 		HitInfo hit = unpack_hit(packed_hit);
+#if RT_SORT_EARLY
+		const int material_id_early   = p.mesh_material_ids[hit.mesh_id];   // (a miss carries instance 0: the loads are valid, their values unused)
+		const int material_type_early = p.material_types[material_id_early];
+		float roulette_number = 0.0f;
+		const bool roulette_drawn = russian_roulette_draws(p, bounce);
+		if (roulette_drawn) roulette_number = random_sample(p, DIM_RUSSIAN_ROULETTE, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index)).x;
+#endif
 
 		// Merged wavefront: the bounce of an entry comes out of the slot table, i.e. behind two dependent loads; the entry's other fields
 		// are fetched beside them, not after them (every queue array has a slot for every entry; what bounce 0 never wrote is not used).
@@ -409,8 +432,12 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 			p.pixel_query_out[1] = hit.triangle_id;
 		}
 
+#if RT_SORT_EARLY
+		const int material_id = material_id_early, material_type = material_type_early;
+#else
 		int material_id = p.mesh_material_ids[hit.mesh_id];
 		int material_type = p.material_types[material_id];
+#endif
 
 		if (material_type == RT_MATERIAL_LIGHT) {
 			f3 p0, e1, e2;
@@ -451,7 +478,11 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 			return -1;
 		}
 
+#if RT_SORT_EARLY
+		if (russian_roulette(p, pixel_index, bounce, sample_index, throughput, roulette_drawn ? &roulette_number : nullptr)) return -1;
+#else
 		if (russian_roulette(p, pixel_index, bounce, sample_index, throughput)) return -1;
+#endif
 
 		switch (material_type) {
 			case RT_MATERIAL_DIFFUSE:    return 0;
@@ -482,14 +513,19 @@ __global__ void __launch_bounds__(RT_SORT_BLOCK, RT_SORT_WAVES) kernel_sort_stre
 struct TextureLOD { f2 gradient_1, gradient_2; float lod; };
 
 template<bool COMPRESSED>
-RT_DEV f3 sample_albedo(const RtParams & p, int bounce, f3 diffuse, int texture_id, f2 tex_coord, const TextureLOD & lod) { // RayCone.h:19-29
+RT_DEV f3 sample_albedo(const RtParams & p, int bounce, f3 diffuse, int texture_id, const RtTexture & tex, f2 tex_coord, const TextureLOD & lod) { // RayCone.h:19-29
 	if (texture_id == RT_INVALID) return diffuse;
-	const RtTexture tex = p.textures[texture_id];
 	if (p.config.enable_mipmapping) {
 		if (bounce == 0) return diffuse * mk3(texture_get_grad<COMPRESSED>(tex, tex_coord.x, tex_coord.y, lod.gradient_1, lod.gradient_2));
 		return diffuse * mk3(texture_get_lod<COMPRESSED>(tex, tex_coord.x, tex_coord.y, lod.lod + tex.lod_bias));
 	}
 	return diffuse * mk3(texture_get<COMPRESSED>(tex, tex_coord.x, tex_coord.y));
+}
+template<bool COMPRESSED>
+RT_DEV f3 sample_albedo(const RtParams & p, int bounce, f3 diffuse, int texture_id, f2 tex_coord, const TextureLOD & lod) {
+	if (texture_id == RT_INVALID) return diffuse;
+	const RtTexture tex = p.textures[texture_id];
+	return sample_albedo<COMPRESSED>(p, bounce, diffuse, texture_id, tex, tex_coord, lod);
 }
 
 struct BSDFCommon {
@@ -801,11 +837,13 @@ RT_DEV int sample_light(const RtParams & p, const LightTablesLDS * lds, float u1
 
 struct ShadowRay { f3 origin, direction; float max_distance; f3 illumination; };
 
-// Returns true and fills `shadow` when the light sample has to be traced (the caller appends it).
-template<typename BSDF>
-RT_DEV bool next_event_estimation(const RtParams & p, const LightTablesLDS * light_lds, int pixel_index, int bounce, int sample_index, const BSDF & bsdf, f3 hit_point, f3 normal, f3 geometric_normal, f3 throughput, ShadowRay & shadow) {
-	f2 rand_light    = random_sample(p, bsdf.rng, DIM_NEE_LIGHT,    unsigned(bounce));
-	f2 rand_triangle = random_sample(p, bsdf.rng, DIM_NEE_TRIANGLE, unsigned(bounce));
+// The light sample of a hit: a point on an emitter chosen by the two cumulative tables, in world space, with the emitter's normal and emission.
+// It depends on the path's random numbers alone, not on the surface. (Measured, profiles/r04_shade_stage.txt 5.: taking it BEFORE the surface
+// set-up, so that its loads run beside the hit's own chain, changes nothing -- the material kernels are not waiting on that chain.)
+struct LightSample { f3 point, geometric_normal, emission; };
+RT_DEV LightSample nee_pick_light(const RtParams & p, const LightTablesLDS * light_lds, const RandomPath & rng, int bounce) {
+	f2 rand_light    = random_sample(p, rng, DIM_NEE_LIGHT,    unsigned(bounce));
+	f2 rand_triangle = random_sample(p, rng, DIM_NEE_TRIANGLE, unsigned(bounce));
 
 	int light_mesh_id;
 	int light_triangle_id = sample_light(p, light_lds, rand_light.x, rand_light.y, light_mesh_id);
@@ -813,13 +851,23 @@ RT_DEV bool next_event_estimation(const RtParams & p, const LightTablesLDS * lig
 
 	f3 p0, e1, e2;
 	triangle_get_positions(p, light_triangle_id, p0, e1, e2);
-	f3 light_point = barycentric(light_uv.x, light_uv.y, p0, e1, e2);
-	f3 light_geometric_normal = cross(e1, e2);
+	LightSample light;
+	light.point = barycentric(light_uv.x, light_uv.y, p0, e1, e2);
+	light.geometric_normal = cross(e1, e2);
 
 	const float4 * light_world = p.mesh_transforms + size_t(light_mesh_id) * 3;
-	light_point = m_position(light_world, light_point);
-	light_geometric_normal = normalize(m_direction(light_world, light_geometric_normal));
+	light.point = m_position(light_world, light.point);
+	light.geometric_normal = normalize(m_direction(light_world, light.geometric_normal));
 
+	int light_material_id = p.mesh_material_ids[light_mesh_id];
+	light.emission = mk3(p.materials[2 * light_material_id]);
+	return light;
+}
+
+// Connects a hit with its light sample. Returns true and fills `shadow` when the sample has to be traced (the caller appends it).
+template<typename BSDF>
+RT_DEV bool nee_connect(const RtParams & p, const LightSample & light, const BSDF & bsdf, f3 hit_point, f3 normal, f3 geometric_normal, f3 throughput, ShadowRay & shadow) {
+	f3 light_point = light.point, light_geometric_normal = light.geometric_normal;
 	hit_point   = ray_origin_epsilon_offset(hit_point,   light_point - hit_point, geometric_normal);
 	light_point = ray_origin_epsilon_offset(light_point, hit_point - light_point, light_geometric_normal);
 
@@ -830,8 +878,7 @@ RT_DEV bool next_event_estimation(const RtParams & p, const LightTablesLDS * lig
 	float cos_theta_light = abs_dot(to_light, light_geometric_normal);
 	float cos_theta_hit = dot(to_light, normal);
 
-	int light_material_id = p.mesh_material_ids[light_mesh_id];
-	f3 emission = mk3(p.materials[2 * light_material_id]);
+	f3 emission = light.emission;
 
 	f3 bsdf_value; float bsdf_pdf;
 	if (!bsdf.eval(p, to_light, cos_theta_hit, bsdf_value, bsdf_pdf)) return false;
@@ -846,6 +893,10 @@ RT_DEV bool next_event_estimation(const RtParams & p, const LightTablesLDS * lig
 	shadow.direction = to_light;
 	shadow.max_distance = distance_to_light;
 	return true;
+}
+template<typename BSDF>
+RT_DEV bool next_event_estimation(const RtParams & p, const LightTablesLDS * light_lds, int pixel_index, int bounce, int sample_index, const BSDF & bsdf, f3 hit_point, f3 normal, f3 geometric_normal, f3 throughput, ShadowRay & shadow) {
+	return nee_connect(p, nee_pick_light(p, light_lds, bsdf.rng, bounce), bsdf, hit_point, normal, geometric_normal, throughput, shadow);
 }
 
 // ---- shade_material<BSDF> (Pathtracer.cu:557-757) -------------------------------------------------------------
@@ -887,6 +938,9 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 	                               : (SLOT == 0 ? p.sizes->diffuse[launch_bounce] : SLOT == 1 ? p.sizes->plastic[launch_bounce] : SLOT == 2 ? p.sizes->dielectric[launch_bounce] : p.sizes->conductor[launch_bounce]);
 
 	__shared__ BlockBucketLDS<RT_SHADE_BLOCK / RT_WAVE_SIZE> append_lds;
+#if RT_SHADE_ONE_APPEND
+	__shared__ BlockBucket2LDS<RT_SHADE_BLOCK / RT_WAVE_SIZE> append2_lds;
+#endif
 	__shared__ StreamStatsLDS stats_lds;
 	int * const shadow_counter = MERGED ? &p.stream->shadow_count[iq]    : &p.sizes->shadow[launch_bounce];
 	int * const trace_counter  = MERGED ? &p.stream->trace_count[iq ^ 1] : &p.sizes->trace[launch_bounce + 1];
@@ -1011,24 +1065,36 @@ RT_DEV void shade_material(const RtParams & p, int launch_bounce, int launch_sam
 
 		bool alive = set_up_surface();
 
+		auto store_shadow_ray = [&](int shadow_ray_index) {
+			store3(p.shadow.origin,    shadow_ray_index, shadow.origin);
+			store3(p.shadow.direction, shadow_ray_index, shadow.direction);
+			p.shadow.max_distance[shadow_ray_index] = shadow.max_distance;
+			// merged wavefront: the trace launch that consumes the ray cannot know its bounce from a launch argument
+			unsigned pixel_word = unsigned(pixel_index) | (MERGED && bounce == 0 ? RT_SHADOW_FLAG_BOUNCE_0 : 0u);
+			p.shadow.illumination_and_pixel_index[shadow_ray_index] = make_float4(shadow.illumination.x, shadow.illumination.y, shadow.illumination.z, __uint_as_float(pixel_word));
+		};
+		if (nee_enabled && MERGED) stream_stats_add(stats_lds, has_shadow_ray, submission, RT_STAT_SHADOW);
+#if !RT_SHADE_ONE_APPEND
 		if (nee_enabled) {
-			if (MERGED) stream_stats_add(stats_lds, has_shadow_ray, submission, RT_STAT_SHADOW);
 			// (both ray queues: the workgroup's rays ordered by direction octant, see block_bucketed_append)
 			int shadow_ray_index = block_bucketed_append(has_shadow_ray, RT_RAY_BUCKET(shadow.direction), shadow_counter, append_lds);
-			if (has_shadow_ray) {
-				store3(p.shadow.origin,    shadow_ray_index, shadow.origin);
-				store3(p.shadow.direction, shadow_ray_index, shadow.direction);
-				p.shadow.max_distance[shadow_ray_index] = shadow.max_distance;
-				// merged wavefront: the trace launch that consumes the ray cannot know its bounce from a launch argument
-				unsigned pixel_word = unsigned(pixel_index) | (MERGED && bounce == 0 ? RT_SHADOW_FLAG_BOUNCE_0 : 0u);
-				p.shadow.illumination_and_pixel_index[shadow_ray_index] = make_float4(shadow.illumination.x, shadow.illumination.y, shadow.illumination.z, __uint_as_float(pixel_word));
-			}
+			if (has_shadow_ray) store_shadow_ray(shadow_ray_index);
 		}
+#endif
 
 		f3 direction_out = mk3(0.0f); float pdf = 0.0f;
 		bool continues = alive && bsdf.sample(p, throughput, medium_id, direction_out, pdf);
 
-		int index_out = block_bucketed_append(continues, RT_RAY_BUCKET(direction_out), trace_counter, append_lds);
+		int index_out;
+#if RT_SHADE_ONE_APPEND
+		// the round's two appends (shadow ray, continuation ray) in one: two workgroup barriers and one atomic latency instead of four and two
+		if (nee_enabled) {
+			int shadow_ray_index;
+			block_bucketed_append2(has_shadow_ray, RT_RAY_BUCKET(shadow.direction), shadow_counter, continues, RT_RAY_BUCKET(direction_out), trace_counter, append2_lds, shadow_ray_index, index_out);
+			if (has_shadow_ray) store_shadow_ray(shadow_ray_index);
+		} else
+#endif
+		index_out = block_bucketed_append(continues, RT_RAY_BUCKET(direction_out), trace_counter, append_lds);
 		if (!continues) continue;
 
 		f3 origin_out = ray_origin_epsilon_offset(hit_point, direction_out, geometric_normal);

@@ -12,7 +12,8 @@ OBJS=""
 for src in csrc/*.hip; do
   base=$(basename $src .hip)
   if echo " $FILES " | grep -q " $base.hip "; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -I../include $FLAGS -c -o csrc/_variants/$NAME/$base.o $src
+    PERFILE=""; case $base in kernels_shade|kernels_post) PERFILE="-fno-slp-vectorize";; esac   # (the Makefile's HIPFLAGS_<unit>)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -I../include $PERFILE $FLAGS -c -o csrc/_variants/$NAME/$base.o $src
     OBJS="$OBJS csrc/_variants/$NAME/$base.o"
   else
     OBJS="$OBJS csrc/$base.o"
