@@ -19,11 +19,6 @@
 // (3 waves per SIMD). Asking for 4 waves caps them at 128 registers: one more wave to hide the latency behind.
 #define RT_SHADE_WAVES 4
 #endif
-#ifndef RT_SORT_EARLY
-// 1: the sort kernel fetches what hangs on the hit (instance -> material id -> material type) and the roulette's random number (slot table ->
-// sample tables) as soon as the queue entry is there, side by side, not in the order the classification consults them.
-#define RT_SORT_EARLY 0
-#endif
 #ifndef RT_SHADE_ONE_APPEND
 #define RT_SHADE_ONE_APPEND 1   // 1: the shadow-ray and the continuation-ray append of a shade round share barriers and atomic latency (block_bucketed_append2)
 #endif
@@ -180,16 +175,13 @@ __global__ void kernel_random(RtParams p, int dimension, const unsigned * pixel_
 // ---- kernel_sort -----------------------------------------------------------------------------------
 
 // Returns true if the path terminates (Pathtracer.cu:199-218)
-// whether russian_roulette() will draw its random number for a path at this bounce
-RT_DEV bool russian_roulette_draws(const RtParams & p, int bounce) { return bounce != p.config.num_bounces - 1 && p.config.enable_russian_roulette && bounce > 0; }
-// `drawn`: null, or the number random_sample(DIM_RUSSIAN_ROULETTE, ...).x the caller has fetched already (where russian_roulette_draws())
-RT_DEV bool russian_roulette(const RtParams & p, int pixel_index, int bounce, int sample_index, f3 & throughput, const float * drawn = nullptr) {
+RT_DEV bool russian_roulette(const RtParams & p, int pixel_index, int bounce, int sample_index, f3 & throughput) {
 	if (bounce == p.config.num_bounces - 1) return true;
 	if (p.config.enable_russian_roulette && bounce > 0) {
 		f3 t = throughput;
 		if (p.config.enable_svgf) t *= mk3(aov_get(p, RT_AOV_ALBEDO, pixel_index));
 		float survival_probability = saturate(fmaxf(fmaxf(t.x, t.y), t.z));
-		float r = drawn ? *drawn : random_sample(p, DIM_RUSSIAN_ROULETTE, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index)).x;
+		float r = random_sample(p, DIM_RUSSIAN_ROULETTE, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index)).x;
 		if (r > survival_probability) return true;
 		throughput /= survival_probability;
 	}
@@ -348,13 +340,6 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 		ray_direction = load3(in.direction, index);
 		packed_hit = in.hits[index];
 		HitInfo hit = unpack_hit(packed_hit);
-#if RT_SORT_EARLY
-		const int material_id_early   = p.mesh_material_ids[hit.mesh_id];   // (a miss carries instance 0: the loads are valid, their values unused)
-		const int material_type_early = p.material_types[material_id_early];
-		float roulette_number = 0.0f;
-		const bool roulette_drawn = russian_roulette_draws(p, bounce);
-		if (roulette_drawn) roulette_number = random_sample(p, DIM_RUSSIAN_ROULETTE, unsigned(pixel_index), unsigned(bounce), unsigned(sample_index)).x;
-#endif
 
 		// Merged wavefront: the bounce of an entry comes out of the slot table, i.e. behind two dependent loads; the entry's other fields
 		// are fetched beside them, not after them (every queue array has a slot for every entry; what bounce 0 never wrote is not used).
@@ -432,12 +417,8 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 			p.pixel_query_out[1] = hit.triangle_id;
 		}
 
-#if RT_SORT_EARLY
-		const int material_id = material_id_early, material_type = material_type_early;
-#else
 		int material_id = p.mesh_material_ids[hit.mesh_id];
 		int material_type = p.material_types[material_id];
-#endif
 
 		if (material_type == RT_MATERIAL_LIGHT) {
 			f3 p0, e1, e2;
@@ -478,11 +459,7 @@ RT_DEV void sort_rays(const RtParams & p, int launch_bounce, int launch_sample_i
 			return -1;
 		}
 
-#if RT_SORT_EARLY
-		if (russian_roulette(p, pixel_index, bounce, sample_index, throughput, roulette_drawn ? &roulette_number : nullptr)) return -1;
-#else
 		if (russian_roulette(p, pixel_index, bounce, sample_index, throughput)) return -1;
-#endif
 
 		switch (material_type) {
 			case RT_MATERIAL_DIFFUSE:    return 0;
