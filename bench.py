@@ -266,7 +266,8 @@ def stage_rooflines(grt, ctx, counters_per_sample, plan, steps, stream_gbps, tex
 def config3_section(grt, scene, device, stream_gbps, frames=64):
     """BASELINE config 3 (Sponza 1080p, SVGF with 6 a-trous passes + TAA, one sample per filtered frame, the camera moving
     between frames): ms per filtered frame in the merged wavefront, and every filter kernel priced against the stream bandwidth."""
-    grt.config_set(enable_svgf=1, enable_taa=1, num_atrous_iterations=6)
+    svgf_tiles = int(os.environ.get("BENCH_SVGF_TILES", "1"))   # 0: the a-trous passes load every tap from the images (rt_set_svgf_tiles), for comparison
+    grt.config_set(enable_svgf=1, enable_taa=1, num_atrous_iterations=6, svgf_lds_tiles=svgf_tiles)
     pt = grt.Pathtracer(scene, WIDTH, HEIGHT, device=device)
     try:
         pt.update()
@@ -310,7 +311,7 @@ def config3_section(grt, scene, device, stream_gbps, frames=64):
                 "ms_per_filtered_frame": round(ms_frame, 3), "rays_per_frame": rays, "mrays_s": round(rays / ms_frame / 1e3, 1),
                 "filter_ms_per_frame": round(filter_ms, 4), "traversal_ms_per_frame": round(trace_ms, 4),
                 "filter_frac_of_stream_unique_bytes": round(unique_total / (filter_ms * 1e-3) / 1e9 / stream_gbps, 4) if filter_ms > 0 else None,
-                "kernels": kernels,
+                "kernels": kernels, "svgf_lds_tiles": svgf_tiles,
                 "note": "tap bytes = every tap the kernel requests (SVGF.h / TAA.h tap loops), unique bytes = each image once; frac against the measured stream-read bandwidth"}
     finally:
         pt.close()

@@ -73,8 +73,8 @@ def device_lib():
         # first) keeps HIP's default of 4 queues and the context says so when it matters.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
         lib = ctypes.CDLL(DEVICE_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-        if hasattr(lib, "rt_abi_version") and lib.rt_abi_version() != 5:
-            raise DeviceLibraryMissing("%s has ABI version %d, this front end was written for 5 -- rebuild (python __graft_entry__.py)" % (DEVICE_LIB_PATH, lib.rt_abi_version()))
+        if hasattr(lib, "rt_abi_version") and lib.rt_abi_version() != 6:
+            raise DeviceLibraryMissing("%s has ABI version %d, this front end was written for 6 -- rebuild (python __graft_entry__.py)" % (DEVICE_LIB_PATH, lib.rt_abi_version()))
         lib.rt_last_error.restype = c_char_p
         lib.rt_last_error.argtypes = [c_void_p]
         lib.rt_version.restype = c_char_p
@@ -837,6 +837,14 @@ def set_scheduler(ctx, scheduler):
 
 
 NODES_REFERENCE, NODES_DECODED = 0, 1
+
+
+def set_svgf_tiles(ctx, enable):
+    """True (default): the a-trous passes of the SVGF filter stage a workgroup's taps in LDS; False: every tap is a global
+    load (rt_set_svgf_tiles). Images are bit-identical."""
+    lib = device_lib()
+    lib.rt_set_svgf_tiles.argtypes = [c_void_p, c_int]
+    _dev_check(ctx, lib.rt_set_svgf_tiles(ctx, 1 if enable else 0))
 
 
 def set_node_format(ctx, node_format):

@@ -344,42 +344,52 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 // v_exp_f32 each (edge_stopping_weights): ~600 vector instructions per pixel where the literal form ran ~3 000 -- the pass
 // moves 80 B of compulsory traffic per pixel and was bound by the vector ALUs at a third of the stream bandwidth
 // (BENCH config3 kernels; profiles/r03_svgf.txt).
-__global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const float4 * __restrict__ d_in, const float4 * __restrict__ i_in, float4 * __restrict__ d_out, float4 * __restrict__ i_out, const float2 * __restrict__ variance_in, float2 * __restrict__ variance_out, int step_size) {
-	int x, y;
-	if (!post_tile_pixel(p, x, y)) return;
-	if (x >= p.screen_width || y >= p.screen_height) return;
+// The arithmetic of a pixel, shared by the two kernels below: `tap_d / tap_i / tap_nd (i, j)` return (direct, indirect, normal + depth) of the
+// pixel at (x + i * step_size, y + j * step_size), i, j in {-1, 0, 1} -- read from the images by one kernel, from the workgroup's LDS tile by the other.
+// What a pixel of an a-trous pass reads of its IMMEDIATE neighbours, whatever the step size: the 3 x 3 blur of the variance pair and the depths
+// to the right and below (the depth gradient). Loaded first -- in the tiled kernel before the barrier, beside the staging loads.
+struct AtrousNeighbourhood { float vb_d, vb_i, depth_right, depth_below; };
+RT_DEV AtrousNeighbourhood svgf_atrous_neighbourhood(const RtParams & p, int x, int y, const float2 * __restrict__ variance_in) {
 	const int pitch = p.screen_pitch;
-	int pixel_index = x + y * pitch;
 	const float4 * __restrict__ normal_and_depth = p.svgf_normal_and_depth;   // (normal, depth), decoded by kernel_svgf_reproject
-
 	// clamped neighbours for the variance blur
 	const int xl = max(x - 1, 0), xr1 = min(x + 1, p.screen_width - 1), yu = max(y - 1, 0), yd1 = min(y + 1, p.screen_height - 1);
 	const int col[3] = { xl, x, xr1 }, row[3] = { yu * pitch, y * pitch, yd1 * pitch };
-	float vb_d = 0.0f, vb_i = 0.0f;
+	AtrousNeighbourhood n;
+	n.vb_d = 0.0f; n.vb_i = 0.0f;
 	#pragma unroll
 	for (int j = 0; j < 3; j++) {
 		#pragma unroll
 		for (int i = 0; i < 3; i++) {
 			const float kernel_weight = (i == 1 ? 0.5f : 0.25f) * (j == 1 ? 0.5f : 0.25f) * 1.0f;   // 0.25 * 2^-(|i| + |j|), |i| = distance from the centre
 			const float2 variance = variance_in[col[i] + row[j]];   // (d_in[..].w, i_in[..].w), see kernel_svgf_reproject
-			vb_d += variance.x * kernel_weight;
-			vb_i += variance.y * kernel_weight;
+			n.vb_d += variance.x * kernel_weight;
+			n.vb_i += variance.y * kernel_weight;
 		}
 	}
-	float denom_d = 1.0f / sqrtf(p.config.sigma_l * p.config.sigma_l * fmaxf(0.0f, vb_d) + RT_SVGF_EPSILON);
-	float denom_i = 1.0f / sqrtf(p.config.sigma_l * p.config.sigma_l * fmaxf(0.0f, vb_i) + RT_SVGF_EPSILON);
+	int xr = min(x + 1, pitch - 1), yd = min(y + 1, p.screen_height - 1);
+	n.depth_right = normal_and_depth[xr + y * pitch].w;
+	n.depth_below = normal_and_depth[x + yd * pitch].w;
+	return n;
+}
 
-	f4 cd = ld4(d_in, pixel_index), ci = ld4(i_in, pixel_index);
+template<typename TapD, typename TapI, typename TapND>
+RT_DEV void svgf_atrous_pixel(const RtParams & p, int x, int y, int step_size, const AtrousNeighbourhood & near, float4 * __restrict__ d_out, float4 * __restrict__ i_out,
+                              float2 * __restrict__ variance_out, TapD tap_d, TapI tap_i, TapND tap_nd) {
+	const int pitch = p.screen_pitch;
+	int pixel_index = x + y * pitch;
+	float denom_d = 1.0f / sqrtf(p.config.sigma_l * p.config.sigma_l * fmaxf(0.0f, near.vb_d) + RT_SVGF_EPSILON);
+	float denom_i = 1.0f / sqrtf(p.config.sigma_l * p.config.sigma_l * fmaxf(0.0f, near.vb_i) + RT_SVGF_EPSILON);
+
+	f4 cd = mk4(tap_d(0, 0)), ci = mk4(tap_i(0, 0));
 	float cl_d = luminance(cd.x, cd.y, cd.z), cl_i = luminance(ci.x, ci.y, ci.z);
 
-	float4 cnd = normal_and_depth[pixel_index];
+	float4 cnd = tap_nd(0, 0);
 	f3 center_normal = mk3(cnd.x, cnd.y, cnd.z);
 	float center_depth = cnd.w;
 	if (center_depth == 0.0f) return; // sky: outputs intentionally not written (SVGF.h:462)
 
-	int xr = min(x + 1, pitch - 1), yd = min(y + 1, p.screen_height - 1);
-	f2 grad = mk2(normal_and_depth[xr + y * pitch].w - center_depth,
-	              normal_and_depth[x + yd * pitch].w - center_depth);
+	f2 grad = mk2(near.depth_right - center_depth, near.depth_below - center_depth);
 
 	const bool in_x[3] = { x - step_size >= 0, true, x + step_size < p.screen_width };
 	const bool in_y[3] = { y - step_size >= 0, true, y + step_size < p.screen_height };
@@ -391,9 +401,8 @@ __global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const floa
 		for (int i = -1; i <= 1; i++) {
 			if (i == 0 && j == 0) continue;
 			if (in_x[i + 1] && in_y[j + 1]) {
-				int tap_index = pixel_index + i * step_size + j * step_size * pitch;
-				f4 td = ld4(d_in, tap_index), ti = ld4(i_in, tap_index);
-				float4 nd = normal_and_depth[tap_index];
+				f4 td = mk4(tap_d(i, j)), ti = mk4(tap_i(i, j));
+				float4 nd = tap_nd(i, j);
 				float l_d = luminance(td.x, td.y, td.z), l_i = luminance(ti.x, ti.y, ti.z);
 				f2 w = edge_stopping_weights(p, i * step_size, j * step_size, grad, center_depth, nd.w, center_normal, mk3(nd.x, nd.y, nd.z), cl_d, cl_i, l_d, l_i, denom_d, denom_i);
 				sw_d += w.x; sw_i += w.y;
@@ -409,6 +418,93 @@ __global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const floa
 	st4(i_out, pixel_index, sc_i);
 	variance_out[pixel_index] = make_float2(sc_d.w, sc_i.w);
 	if (step_size == (1 << RT_FEEDBACK_ITERATION)) { st4(p.history_direct, pixel_index, sc_d); st4(p.history_indirect, pixel_index, sc_i); }
+}
+
+__global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const float4 * __restrict__ d_in, const float4 * __restrict__ i_in, float4 * __restrict__ d_out, float4 * __restrict__ i_out, const float2 * __restrict__ variance_in, float2 * __restrict__ variance_out, int step_size) {
+	int x, y;
+	if (!post_tile_pixel(p, x, y)) return;
+	if (x >= p.screen_width || y >= p.screen_height) return;
+	const int pitch = p.screen_pitch, pixel_index = x + y * pitch;
+	const float4 * __restrict__ normal_and_depth = p.svgf_normal_and_depth;
+	svgf_atrous_pixel(p, x, y, step_size, svgf_atrous_neighbourhood(p, x, y, variance_in), d_out, i_out, variance_out,
+		[&](int i, int j) { return d_in[pixel_index + i * step_size + j * step_size * pitch]; },
+		[&](int i, int j) { return i_in[pixel_index + i * step_size + j * step_size * pitch]; },
+		[&](int i, int j) { return normal_and_depth[pixel_index + i * step_size + j * step_size * pitch]; });
+}
+
+// The same pass with the three tapped images of a workgroup staged in LDS (rt_set_svgf_tiles, on by default).
+// The pass above asks for 9 x 48 B of taps per pixel of which 48 B are compulsory; its 64 x 4 tiles share the taps of a row among their
+// lanes but not the three rows a tap pattern spans (for a step of 4 and more they are twelve different rows for four rows of pixels), and what
+// L1 does not hold comes over the L2 -> L1 path again: ~560 B per pixel and pass, 17 TB/s at 0.063 ms per 1080p pass -- the pass is bound
+// by THAT, at half the stream rate of its compulsory bytes (BENCH config3: frac_unique 0.51). Two things make a tile's taps mostly its own:
+//   * a workgroup's TY rows of pixels are STEP rows apart (y = y_base + STEP * k): the row above the first and the row below the last are
+//     all it needs beside its own -- (TY + 2) / TY rows per row of pixels at every step size, where adjacent rows need 3 from step 4 on;
+//   * the columns are 64 adjacent pixels plus STEP on either side, loaded once into LDS ([row][column], float4 per image) and tapped
+//     from there with ds_read_b128: the L1 / L2 path sees (64 + 2 STEP) / 64 x (TY + 2) / TY of the compulsory bytes (1.3 x at step 1,
+//     2.5 x at step 32) instead of 9 x.
+// The 3 x 3 variance blur and the depth gradient look at a pixel's immediate neighbours, which are not in the tile unless STEP is 1: they
+// stay global loads (8 and 16 bytes, rows shared by the lanes of a wave). Same arithmetic per pixel (svgf_atrous_pixel): images are
+// bit-identical to the untiled pass (tests/test_gpu_materials_svgf.py::test_svgf_lds_tiles_do_not_change_a_frame).
+// Tiles are numbered column-fastest within one residue class of rows, XCD k takes the k-th eighth of the sequence (as post_tile_pixel):
+// neighbours in x, which share their STEP halo columns, run back to back on one L2.
+#ifndef RT_ATROUS_ROWS
+#define RT_ATROUS_ROWS 8   // rows of pixels per workgroup (one wave each) of the tiled passes up to step 16
+#endif
+template<int STEP, int TY>
+__global__ void __launch_bounds__(64 * TY) kernel_svgf_atrous_tiled(RtParams p, const float4 * __restrict__ d_in, const float4 * __restrict__ i_in, float4 * __restrict__ d_out, float4 * __restrict__ i_out, const float2 * __restrict__ variance_in, float2 * __restrict__ variance_out) {
+	constexpr int W = 64 + 2 * STEP, ROWS = TY + 2, N = W * ROWS, THREADS = 64 * TY;
+	__shared__ float4 tile_d[N], tile_i[N], tile_nd[N];
+	const unsigned tiles_x = (unsigned(p.screen_width) + 63u) / 64u;
+	const unsigned blocks_y = (unsigned(p.screen_height) + unsigned(TY * STEP) - 1u) / unsigned(TY * STEP);
+	const unsigned tiles = tiles_x * unsigned(STEP) * blocks_y, per_xcd = gridDim.x / 8u;
+	const unsigned tile = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+	if (tile >= tiles) return;   // (the whole workgroup: no barrier is left waiting)
+	const int x0 = int(tile % tiles_x) * 64;
+	const unsigned above = tile / tiles_x;
+	const int y_base = int(above / unsigned(STEP)) * (TY * STEP) + int(above % unsigned(STEP));
+	const int pitch = p.screen_pitch;
+	const float4 * __restrict__ normal_and_depth = p.svgf_normal_and_depth;
+
+	// this thread's pixel, and what it needs of its immediate neighbours (global loads: issued before the staging loop, they land with it)
+	const int tx = int(threadIdx.x) & 63, ty = int(threadIdx.x) >> 6;
+	const int x = x0 + tx, y = y_base + STEP * ty;
+	const bool has_pixel = x < p.screen_width && y < p.screen_height;
+	AtrousNeighbourhood near = { 0.0f, 0.0f, 0.0f, 0.0f };
+	if (has_pixel) near = svgf_atrous_neighbourhood(p, x, y, variance_in);
+
+	// stage: row r of the tile is image row y_base + STEP * (r - 1), column c is image column x0 - STEP + c. Positions outside the image are never
+	// tapped (in_x / in_y of svgf_atrous_pixel); they are filled from the clamped position so that every load is inside the images.
+	for (int pos = int(threadIdx.x); pos < N; pos += THREADS) {
+		const int c = pos % W, r = pos / W;
+		const int gx = min(max(x0 - STEP + c, 0), p.screen_width - 1), gy = min(max(y_base + STEP * (r - 1), 0), p.screen_height - 1);
+		const int source = gx + gy * pitch;
+		tile_d[pos] = d_in[source]; tile_i[pos] = i_in[source]; tile_nd[pos] = normal_and_depth[source];
+	}
+	__syncthreads();
+
+	if (!has_pixel) return;
+	const int centre = (ty + 1) * W + tx + STEP;
+	svgf_atrous_pixel(p, x, y, STEP, near, d_out, i_out, variance_out,
+		[&](int i, int j) { return tile_d [centre + i * STEP + j * W]; },
+		[&](int i, int j) { return tile_i [centre + i * STEP + j * W]; },
+		[&](int i, int j) { return tile_nd[centre + i * STEP + j * W]; });
+}
+template<int STEP, int TY>
+static void launch_atrous_tiled(const RtParams & p, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, const float2 * variance_in, float2 * variance_out, hipStream_t stream) {
+	const unsigned tiles = ((unsigned(p.screen_width) + 63u) / 64u) * unsigned(STEP) * ((unsigned(p.screen_height) + unsigned(TY * STEP) - 1u) / unsigned(TY * STEP));
+	hipLaunchKernelGGL((kernel_svgf_atrous_tiled<STEP, TY>), dim3((tiles + 7) / 8 * 8), dim3(64 * TY), 0, stream, p, d_in, i_in, d_out, i_out, variance_in, variance_out);
+}
+// false: no tiled form for this step size (more than six iterations): the caller launches kernel_svgf_atrous
+static bool launch_atrous_tiled_step(const RtParams & p, int step_size, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, const float2 * variance_in, float2 * variance_out, hipStream_t stream) {
+	switch (step_size) {   // LDS per workgroup: (64 + 2 STEP) x (TY + 2) x 48 B = 31.7 / 32.6 / 34.6 / 38.4 / 46.1 / 36.9 KB with 8 rows (4 at step 32)
+		case 1:  launch_atrous_tiled<1,  RT_ATROUS_ROWS>(p, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
+		case 2:  launch_atrous_tiled<2,  RT_ATROUS_ROWS>(p, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
+		case 4:  launch_atrous_tiled<4,  RT_ATROUS_ROWS>(p, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
+		case 8:  launch_atrous_tiled<8,  RT_ATROUS_ROWS>(p, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
+		case 16: launch_atrous_tiled<16, RT_ATROUS_ROWS>(p, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
+		case 32: launch_atrous_tiled<32, 4>(p, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
+	}
+	return false;
 }
 
 __global__ void __launch_bounds__(256) kernel_svgf_finalize(RtParams p, const float4 * colour_direct, const float4 * colour_indirect) {
@@ -427,7 +523,6 @@ __global__ void __launch_bounds__(256) kernel_svgf_finalize(RtParams p, const fl
 		st4(p.taa_frame_curr, pixel_index, colour);
 	}
 	float4 moment = p.frame_buffer_moment[pixel_index];
-	float4 normal_and_depth = p.gbuffer_normal_and_depth[pixel_index];
 	if (p.config.num_atrous_iterations <= RT_FEEDBACK_ITERATION) { st4(p.history_direct, pixel_index, direct); st4(p.history_indirect, pixel_index, indirect); }
 	p.history_moment[pixel_index] = moment;
 	p.history_normal_and_depth[pixel_index] = p.svgf_normal_and_depth[pixel_index];   // decoded (normal, depth) of this frame
@@ -439,9 +534,11 @@ __global__ void __launch_bounds__(256) kernel_svgf_finalize(RtParams p, const fl
 
 RT_DEV f3 clamp3(f3 v, f3 lo, f3 hi) { return mk3(clampf(v.x, lo.x, hi.x), clampf(v.y, lo.y, hi.y), clampf(v.z, lo.z, hi.z)); }
 
-// Reads taa_frame_curr / taa_frame_prev, writes final_image; kernel_taa_finalize then turns it into the next frame's
-// taa_frame_prev and the displayed image. (The reference writes the `accumulator` surface in place, which is safe there
-// for the same reason: kernel_taa never reads it.)
+// Reads taa_frame_curr (3 x 3 around the pixel) and taa_frame_prev (4 x 4 around where the pixel was), and writes what the reference's
+// kernel_taa and kernel_taa_finalize write between them (TAA.h:10-172): the resolved colour as the NEXT frame's history, the displayed image
+// (the tone mapping undone), the cleared motion vector. The history goes to a third image, taa_frame_next -- other threads are still reading
+// taa_frame_prev --, and the host swaps the two pointers after the launch (rt_api.hip: after every rt_launch_svgf_taa). The reference needs
+// the second kernel because it resolves in place; here that pass (read 16, write 40 bytes per pixel) is gone.
 __global__ void __launch_bounds__(256) kernel_taa(RtParams p, int sample_index) {
 	int x, y;
 	if (!post_tile_pixel(p, x, y)) return;
@@ -449,7 +546,14 @@ __global__ void __launch_bounds__(256) kernel_taa(RtParams p, int sample_index) 
 	int pixel_index = x + y * p.screen_pitch;
 
 	f4 colour = ld4(p.taa_frame_curr, pixel_index);
-	if (sample_index == 0) { st4(p.final_image, pixel_index, colour); return; }
+	auto finish = [&](f4 resolved) {   // kernel_taa_finalize (TAA.h:150-172)
+		st4(p.taa_frame_next, pixel_index, resolved);
+		resolved = resolved * resolved;
+		resolved = resolved / (1.0f - luminance(resolved.x, resolved.y, resolved.z));
+		st4(p.final_image, pixel_index, resolved);
+		p.gbuffer_screen_position_prev[pixel_index] = make_float2(0.0f, 0.0f);
+	};
+	if (sample_index == 0) { finish(colour); return; }
 
 	float2 sp = p.gbuffer_screen_position_prev[pixel_index];
 	float s_prev = (0.5f + 0.5f * sp.x) * float(p.screen_width);
@@ -493,21 +597,7 @@ __global__ void __launch_bounds__(256) kernel_taa(RtParams p, int sample_index) 
 		f3 integrated = ycocg_to_rgb(lerp_ref(colour_prev, colour_curr, 0.1f));
 		colour.x = integrated.x; colour.y = integrated.y; colour.z = integrated.z;
 	}
-	st4(p.final_image, pixel_index, colour);
-}
-
-__global__ void __launch_bounds__(256) kernel_taa_finalize(RtParams p) {
-	int x, y;
-	if (!post_tile_pixel(p, x, y)) return;
-	if (x >= p.screen_width || y >= p.screen_height) return;
-	int pixel_index = x + y * p.screen_pitch;
-
-	f4 colour = ld4(p.final_image, pixel_index);
-	st4(p.taa_frame_prev, pixel_index, colour);
-	colour = colour * colour;
-	colour = colour / (1.0f - luminance(colour.x, colour.y, colour.z));
-	st4(p.final_image, pixel_index, colour);
-	p.gbuffer_screen_position_prev[pixel_index] = make_float2(0.0f, 0.0f);
+	finish(colour);
 }
 
 // Launch order of Pathtracer::render (Pathtracer.cpp:798-838)
@@ -534,7 +624,11 @@ void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream
 		float2 * v = variance_in; variance_in = variance_out; variance_out = v;
 	}
 	for (int i = 0; i < p.config.num_atrous_iterations; i++) {
-		RT_TIMED(2, hipLaunchKernelGGL(kernel_svgf_atrous, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out, variance_in, variance_out, 1 << i));
+		auto atrous_pass = [&](int step_size) {
+			if (p.svgf_tiles && launch_atrous_tiled_step(p, step_size, direct_in, indirect_in, direct_out, indirect_out, variance_in, variance_out, stream)) return;
+			hipLaunchKernelGGL(kernel_svgf_atrous, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out, variance_in, variance_out, step_size);
+		};
+		RT_TIMED(2, atrous_pass(1 << i));
 		float4 * t = direct_in; direct_in = direct_out; direct_out = t;
 		t = indirect_in; indirect_in = indirect_out; indirect_out = t;
 		float2 * v = variance_in; variance_in = variance_out; variance_out = v;
@@ -542,8 +636,7 @@ void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream
 	RT_TIMED(3, hipLaunchKernelGGL(kernel_svgf_finalize, grid, block, 0, stream, p, direct_in, indirect_in));
 
 	if (p.config.enable_taa) {
-		RT_TIMED(4, hipLaunchKernelGGL(kernel_taa, grid, block, 0, stream, p, sample_index));
-		RT_TIMED(5, hipLaunchKernelGGL(kernel_taa_finalize, grid, block, 0, stream, p));
+		RT_TIMED(4, hipLaunchKernelGGL(kernel_taa, grid, block, 0, stream, p, sample_index));   // (the caller swaps taa_frame_prev / taa_frame_next)
 	}
 	#undef RT_TIMED
 }

@@ -202,7 +202,7 @@ struct rt_context {
 	// frame resources
 	void * aov_buffers[RT_AOV_COUNT][2] = { };
 	void * final_image = nullptr;
-	void * svgf_buffers[14] = { }; bool svgf_allocated = false;
+	void * svgf_buffers[15] = { }; bool svgf_allocated = false;
 	size_t frame_pixels = 0; // pitch * height
 
 	// frame exchange of the tile split (rt_comm_*): this context's rank in a group of `world` contexts, each on its own GPU
@@ -439,6 +439,7 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 	ctx->device = device_ordinal;
 	memset(&ctx->params, 0, sizeof(ctx->params));
 	ctx->params.entry_tlas_stack_size = RT_INVALID;
+	ctx->params.svgf_tiles = 1;
 	memset(&ctx->last_counters, 0, sizeof(ctx->last_counters));
 	RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
 	RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
@@ -1115,8 +1116,8 @@ static int sync_svgf(rt_context * ctx) {
 	if (want == ctx->svgf_allocated || ctx->frame_pixels == 0) return RT_OK;
 	if (want) {
 		// gbuffers (float4, int2, float2), moment, history x5 (length is int), taa x2, decoded normal + depth, variance pairs x2
-		const size_t elem[14] = { 16, 8, 8, 16, 4, 16, 16, 16, 16, 16, 16, 16, 8, 8 };
-		for (int i = 0; i < 14; i++) {
+		const size_t elem[15] = { 16, 8, 8, 16, 4, 16, 16, 16, 16, 16, 16, 16, 8, 8, 16 };
+		for (int i = 0; i < 15; i++) {
 			int s = device_alloc(ctx, &ctx->svgf_buffers[i], ctx->frame_pixels * elem[i]); if (s) return s;
 			RT_HIP(ctx, hipMemsetAsync(ctx->svgf_buffers[i], 0, ctx->frame_pixels * elem[i], ctx->stream));
 		}
@@ -1133,7 +1134,7 @@ static int sync_svgf(rt_context * ctx) {
 			if (ctx->aov_buffers[aov][1]) RT_HIP(ctx, hipMemsetAsync(ctx->aov_buffers[aov][1], 0, ctx->frame_pixels * 16, ctx->stream));
 	} else {
 		RT_HIP(ctx, quiesce(ctx));
-		for (int i = 0; i < 14; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
+		for (int i = 0; i < 15; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
 		for (SampleSlot & slot : ctx->slots) for (int i = 0; i < 3; i++) { device_free(ctx, slot.gbuffers[i]); slot.gbuffers[i] = nullptr; }
 		ctx->path_stream.last_gbuffer_slot = -1;
 		for (void * & g : ctx->path_stream.gbuffers) { device_free(ctx, g); g = nullptr; }
@@ -1154,6 +1155,7 @@ static int sync_svgf(rt_context * ctx) {
 	p.svgf_normal_and_depth           = (float4 *)ctx->svgf_buffers[11];
 	p.svgf_variance[0]                = (float2 *)ctx->svgf_buffers[12];
 	p.svgf_variance[1]                = (float2 *)ctx->svgf_buffers[13];
+	p.taa_frame_next                  = (float4 *)ctx->svgf_buffers[14];   // (prev and next trade places after every filtered frame: kernel_taa)
 	return RT_OK;
 }
 
@@ -1195,6 +1197,12 @@ int rt_set_svgf_matrices(rt_context * ctx, const float * view_projection, const 
 	RT_REQUIRE(ctx, ctx && view_projection && view_projection_prev, "rt_set_svgf_matrices: NULL argument");
 	memcpy(ctx->params.view_projection,      view_projection,      64);
 	memcpy(ctx->params.view_projection_prev, view_projection_prev, 64);
+	return RT_OK;
+}
+
+int rt_set_svgf_tiles(rt_context * ctx, int enable) {
+	RT_REQUIRE(ctx, ctx, "rt_set_svgf_tiles: NULL context");
+	ctx->params.svgf_tiles = enable != 0;   // (read at launch time: the filter launches of frames already enqueued keep what they were enqueued with)
 	return RT_OK;
 }
 
@@ -1288,6 +1296,7 @@ int rt_filter_frame(rt_context * ctx, int sample_index) {
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));      // after the scatter of the gathered tiles (main stream)
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
 	rt_launch_svgf_taa(p, sample_index, st);
+	if (ctx->params.config.enable_taa) std::swap(ctx->params.taa_frame_prev, ctx->params.taa_frame_next);
 	for (int i = 0; i < RT_AOV_COUNT; i++) if (p.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(p.aovs[i].framebuffer, 0, ctx->frame_pixels * 16, st)); // aovs_clear_to_zero
 	RT_HIP(ctx, hipEventRecord(slot.ev_done, st));
 	RT_HIP(ctx, hipGetLastError());
@@ -1860,9 +1869,11 @@ static int stream_complete(rt_context * ctx, const StreamSubmission * subs, int 
 		for (int k = 0; k < count; k++) {
 			const StreamSubmission & sub = subs[k];
 			RtParams pf = p;
+			pf.taa_frame_prev = ctx->params.taa_frame_prev; pf.taa_frame_next = ctx->params.taa_frame_next;   // (they trade places after every filtered frame)
 			for (int i = 0; i < RT_AOV_COUNT; i++) if (pf.aovs[i].framebuffer) pf.aovs[i].framebuffer += size_t(sub.slot_base) * ctx->frame_pixels;
 			pf.gbuffer_normal_and_depth += size_t(sub.slot_base) * ctx->frame_pixels; pf.gbuffer_mesh_id_and_triangle_id += size_t(sub.slot_base) * ctx->frame_pixels; pf.gbuffer_screen_position_prev += size_t(sub.slot_base) * ctx->frame_pixels;
 			rt_launch_svgf_taa(pf, sub.first_sample, st, ctx->launch_timing_all && ctx->time_this_sample ? svgf_span_mark : nullptr, ctx);
+			if (ctx->params.config.enable_taa) std::swap(ctx->params.taa_frame_prev, ctx->params.taa_frame_next);
 			for (int i = 0; i < RT_AOV_COUNT; i++) if (pf.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(pf.aovs[i].framebuffer, 0, ctx->frame_pixels * 16 * size_t(sub.sample_count), st)); // aovs_clear_to_zero
 		}
 	} else
@@ -2263,7 +2274,7 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	stage_mark(ctx, STAGE_POST, st);
 	const bool deferred = p.config.enable_svgf && ctx->defer_filter; // rt_filter_frame does the rest once the ranks have exchanged their tiles
 	if (deferred) { }
-	else if (p.config.enable_svgf) rt_launch_svgf_taa(p, sample_index, st);
+	else if (p.config.enable_svgf) { p.taa_frame_prev = ctx->params.taa_frame_prev; p.taa_frame_next = ctx->params.taa_frame_next; rt_launch_svgf_taa(p, sample_index, st); if (ctx->params.config.enable_taa) std::swap(ctx->params.taa_frame_prev, ctx->params.taa_frame_next); }
 	else rt_launch_accumulate(p, float(sample_index), range_offset, range_count, st);
 	stage_mark(ctx, STAGE_END, st);
 

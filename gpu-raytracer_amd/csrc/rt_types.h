@@ -136,6 +136,7 @@ struct RtParams {
 	const float4  * materials;  // 2 float4 per material
 	const float4  * media;      // 2 float4 per medium
 	const RtTexture * textures;
+	int svgf_tiles;                   // 1 (default): the a-trous passes stage a workgroup's taps in LDS (rt_set_svgf_tiles; kernels_post.hip: kernel_svgf_atrous_tiled)
 	int textures_compressed;          // 1: at least one texture holds BC1 blocks that a fetch has to decode (rt_set_texture_expansion(ctx, 0)); picks the material kernels' instantiation
 	// lights
 	const int   * light_triangle_indices;
@@ -194,7 +195,7 @@ struct RtParams {
 	float4 * frame_buffer_moment;
 	int    * history_length;
 	float4 * history_direct, * history_indirect, * history_moment, * history_normal_and_depth;
-	float4 * taa_frame_prev, * taa_frame_curr;
+	float4 * taa_frame_prev, * taa_frame_curr, * taa_frame_next;   // next: where kernel_taa writes the history of the following frame (swapped with prev after every filtered frame)
 	float2 * svgf_variance[2];        // (direct.w, indirect.w) of the radiance framebuffers [0] and accumulators [1], kept in step by the filter kernels
 	float4 * svgf_normal_and_depth;   // (normal, depth) of the frame being filtered: decoded once by kernel_svgf_reproject for the variance / a-trous taps
 };

@@ -101,6 +101,9 @@ struct CPUConfig {
 	// 4x4 block instead of 8 and the shade kernels fetch texels instead of decoding a block per fetch -- the same texel values.
 	// false: the 8-byte blocks stay compressed on the device (an eighth of the memory, a third more shade time).
 	bool expand_block_compressed_textures = true;
+	// The SVGF filter's a-trous passes stage a workgroup's taps in LDS (rt_set_svgf_tiles); false: every tap is a global load, as in the
+	// reference's kernel_svgf_atrous. Bit-identical images either way.
+	bool svgf_lds_tiles = true;
 	BVHType bvh_type = BVHType::BVH8;
 
 	// "<mesh file>.bvh" caches (BVHCache.h). The reference always reads and writes them; a library

@@ -690,6 +690,7 @@ void Integrator::update(float delta) {
 		sample_index = 0;
 		rt_gpu_config c = make_device_config();
 		if (ctx) check(rt_set_config(ctx, &c));
+		if (ctx) check(rt_set_svgf_tiles(ctx, cpu_config.svgf_lds_tiles ? 1 : 0));
 	} else if (scene.camera.moved && !gpu_config.enable_svgf) {
 		sample_index = 0;
 	} else {

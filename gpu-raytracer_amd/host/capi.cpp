@@ -54,6 +54,7 @@ int grt_config_set(const char * key, double value) {
 	}
 	else if (k == "enable_block_compression")            cpu_config.enable_block_compression = value != 0;
 	else if (k == "expand_block_compressed_textures")    cpu_config.expand_block_compressed_textures = value != 0;
+	else if (k == "svgf_lds_tiles")                      cpu_config.svgf_lds_tiles = value != 0;
 	else if (k == "enable_bvh_optimization")             cpu_config.enable_bvh_optimization = value != 0;
 	else if (k == "bvh_optimizer_max_time")              cpu_config.bvh_optimizer_max_time = int(value);
 	else if (k == "bvh_optimizer_max_num_batches")       cpu_config.bvh_optimizer_max_num_batches = int(value);

@@ -142,8 +142,9 @@ const char * rt_version(void);
  *   3  RT_TIMING_* kinds of rt_get_launch_timings, rt_comm_* / rt_all_gather_* entry points (additions only)
  *   4  rt_upload_triangle_aliases, rt_set_static_geometry (additions only)
  *   5  rt_set_texture_expansion, rt_texture_bytes (additions only; BC1 textures are decoded at upload unless asked otherwise)
+ *   6  rt_set_svgf_tiles (addition only)
  * Check `rt_abi_version() == RT_ABI_VERSION` once after loading the library.                                          */
-#define RT_ABI_VERSION 5
+#define RT_ABI_VERSION 6
 int rt_abi_version(void);
 
 /* ---- scene upload ------------------------------------------------------------------- */
@@ -258,6 +259,12 @@ int rt_set_camera(rt_context * ctx, const rt_camera * camera);
 /* Replaces `svgf_data` (Pathtracer.cpp:707-717): two row-major 4x4 matrices.              */
 int rt_set_svgf_matrices(rt_context * ctx, const float * view_projection, const float * view_projection_prev);
 int rt_set_config(rt_context * ctx, const rt_gpu_config * config);
+/* How the a-trous passes of the SVGF filter (CUDA/SVGF/SVGF.h:416-554: kernel_svgf_atrous, one thread per pixel, nine taps of three images
+ * through the texture cache) fetch their taps. enable = 1 (the default): a workgroup stages the (direct, indirect, normal + depth) values
+ * its pixels tap -- rows `step` apart, 64 adjacent columns plus `step` on either side -- in LDS once and taps from there; enable = 0: every
+ * tap is a global load, as in the reference. The arithmetic of a pixel is one function for both: images are bit-identical. Passes with a
+ * step above 32 (more than six iterations) always use the untiled form.                                                        */
+int rt_set_svgf_tiles(rt_context * ctx, int enable);
 /* Multi-GPU tile split: this context only renders pixels [offset, offset+count) of the
  * scan-order frame (the reference's kernel_generate(sample, pixel_offset, pixel_count),
  * Pathtracer.cu:122-131). Default = whole frame.                                          */

@@ -133,6 +133,25 @@ def test_svgf_frames_pipeline_without_changing_the_image(grt):
         assert np.array_equal(image, first), label
 
 
+@pytest.mark.parametrize("size", [(200, 150), (333, 77)])
+def test_svgf_lds_tiles_do_not_change_a_frame(grt, size):
+    """rt_set_svgf_tiles: the a-trous passes with a workgroup's taps staged in LDS (rows `step` apart, the default) against the
+    passes that load every tap from the images -- six frames with history, spatial variance, six iterations (steps 1 .. 32,
+    i.e. every instantiation of the tiled kernel) and TAA, bit-identical, also at a size that is no multiple of anything
+    (partial tiles in x, rows beyond the image in the last block of every residue class)."""
+    images = {}
+    for tiles in (False, True):
+        scene, pt = make_pathtracer(grt, "cornellbox", size[0], size[1], 0, num_bounces=4, enable_svgf=1, enable_taa=1, svgf_lds_tiles=int(tiles))
+        for f in range(6):
+            if f:
+                pt.update()
+            pt.render()
+        images[tiles] = pt.read_framebuffer().copy()
+        pt.close(); scene.close()
+    assert np.isfinite(images[True]).all() and images[True][..., :3].max() > 0.0
+    assert np.array_equal(images[True], images[False])
+
+
 @pytest.mark.parametrize("bsdf,lo,hi", [
     ('<bsdf type="roughconductor"><rgb name="eta" value="0.2, 0.2, 0.2"/><rgb name="k" value="8, 8, 8"/><float name="alpha" value="0.4"/></bsdf>', 0.93, 1.01),
     ('<bsdf type="roughdielectric"><float name="intIOR" value="1.5"/><float name="alpha" value="0.3"/></bsdf>', 0.95, 1.03)])
