@@ -366,6 +366,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the hardware-counter passes (rocprofv3 --pmc re-runs of this benchmark: HBM traffic, VALU busy; N = 1 only)")
     ap.add_argument("--no-config3", action="store_true", help="skip the SVGF + TAA frames of BASELINE config 3 (N = 1 only)")
+    ap.add_argument("--burst", type=int, default=1, help="1 (default): the run's submissions are declared as bursts of up to 8 (rt_set_stream_batch) whose frames share iterations; 0: they follow one another through the wavefront")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage rooflines (a repeat of the timed plan with events around every launch)")
     ap.add_argument("--no-reference-layout", action="store_true", help="skip the pass over the reference's acceleration-structure layout (merge_static 0; N = 1 only)")
     ap.add_argument("--no-povs", action="store_true", help="skip the sweep over the reference's 9 fixed Sponza points of view (N = 1 only)")
@@ -568,6 +569,17 @@ def main():
         trace_rays_stat.append(stats)
     # ... and, for the merged scheduler, of every traversal launch of the plan that is about to be timed
     plan = submissions(args.steps)
+    # The run is a batch job: its frames are submitted back to back and nothing is read before the last one. Declared to the library
+    # (rt_set_stream_batch), up to 8 of them enter the wavefront together and walk their bounces side by side -- num_bounces iterations for
+    # the lot -- instead of one after the other through len(plan) + num_bounces - 1 iterations whose first and last num_bounces - 1 are
+    # partly filled (20 steps: 10 iterations instead of 14; measured 1.49 -> 1.42 ms per step, profiles/r04_burst.txt). Every launch then
+    # carries ONE bounce of 8 frames instead of every bounce of one: 32 steps as one burst run at 1.365 ms per step where the pipelined steady
+    # state of a long run reaches 1.39.
+    burst = 0
+    if merged and split_world == 1 and args.burst and len(plan) > 1:
+        burst = min(len(plan), 8)
+        grt.set_frame_pipelining(ctx, True)
+        grt.set_stream_batch(ctx, sum(count for _, count, _ in plan[:burst]) * WIDTH * HEIGHT)
     launch_bytes = None
     if merged:
         run(plan)
@@ -704,7 +716,8 @@ def main():
                 "parallelism": ("tile-split x%d + one RCCL all-gather of the accumulated float4 frame per %d-spp frame, unpacked into every rank's framebuffer; exchange: %s" % (world, SPP, "the library's own (rt_all_gather_framebuffer: ncclAllGather on the context's stream)" if exchange == "native" else "torch.distributed all_gather_into_tensor around rt_pack_pixels / rt_unpack_pixels")) if world > 1 else "single GPU",
                 "samples_per_submission": args.batch, "submissions_in_flight": ("num_bounces (merged wavefront)" if merged else args.samples_in_flight),
                 # rt_set_frame_pipelining: the submissions of a tile split are small, up to 8 of them share one iteration of the wavefront
-                "submissions_per_iteration": (min(8, -(-WIDTH * HEIGHT * SPP // max(1, split.local_pixels * args.batch))) if (merged and split_world > 1) else 1),
+                "submissions_per_iteration": (min(8, -(-WIDTH * HEIGHT * SPP // max(1, split.local_pixels * args.batch))) if (merged and split_world > 1) else (burst or 1)),
+                "burst": ("the run's submissions are declared as bursts of %d (rt_set_stream_batch): each burst enters the wavefront together and takes %d iterations; --burst 0 lets submissions follow one another (%d iterations for as many)" % (burst, NUM_BOUNCES, burst + NUM_BOUNCES - 1)) if burst else "off",
                 "stage_ms_per_step_one_frame_alone": {k: round(v, 3) for k, v in stage_ms.items()},
             },
             "roofline": roofline,

@@ -863,6 +863,14 @@ def set_frame_pipelining(ctx, enable):
     _dev_check(ctx, lib.rt_set_frame_pipelining(ctx, 1 if enable else 0))
 
 
+def set_stream_batch(ctx, paths):
+    """Paths the submissions of one iteration of the merged wavefront may bring (frame pipelining on); 0: the default of
+    1920 x 1080 x 4. A burst of frames declared this way enters the wavefront together (rt_set_stream_batch)."""
+    lib = device_lib()
+    lib.rt_set_stream_batch.argtypes = [c_void_p, ctypes.c_longlong]
+    _dev_check(ctx, lib.rt_set_stream_batch(ctx, int(paths)))
+
+
 def advance(ctx):
     """One iteration of the merged wavefront without new samples (no-op when nothing is in flight)."""
     lib = device_lib()

@@ -165,6 +165,7 @@ struct rt_context {
 	bool last_render_merged = false;
 	bool defer_filter = false;         // rt_render_sample_unfiltered: an SVGF frame stops before its filter stage (tile split)
 	bool frame_pipelining = false;     // rt_pack_pixels / rt_unpack_pixels follow the completed submissions only (rt_set_frame_pipelining)
+	long long stream_batch_paths = 0;  // paths the submissions of one iteration may bring (rt_set_stream_batch); 0: RT_STREAM_BATCH_PATHS
 	int samples_in_flight = 3;
 	bool overlap_shadows = true;
 	unsigned render_counter = 0;
@@ -1617,6 +1618,12 @@ int rt_set_frame_pipelining(rt_context * ctx, int enable) {
 	return RT_OK;
 }
 
+int rt_set_stream_batch(rt_context * ctx, long long paths) {
+	RT_REQUIRE(ctx, ctx && paths >= 0, "rt_set_stream_batch: invalid argument");
+	ctx->stream_batch_paths = paths;   // (read by the next submission; what already waits for company is enqueued by whatever needs progress, as always)
+	return RT_OK;
+}
+
 int rt_get_trace_statistics_history(rt_context * ctx, uint64_t * out_rows10, int capacity_rows, int * out_rows) {
 	RT_REQUIRE(ctx, ctx && out_rows && (out_rows10 || capacity_rows == 0), "rt_get_trace_statistics_history: invalid argument");
 	(void)hipSetDevice(ctx->device);
@@ -2047,11 +2054,15 @@ static int stream_submit(rt_context * ctx, int sample_index, int sample_count, i
 	if (paths <= 0) return RT_OK;
 	// submissions per iteration: one, unless the application pipelines frames and they are small
 	// (SVGF frames: never, a frame inherits the g-buffers its predecessor's bounce 0 has written)
-	const int batch = (ctx->frame_pipelining && !ctx->params.config.enable_svgf) ? int(std::min<long long>(RT_STREAM_MAX_BATCH, (RT_STREAM_BATCH_PATHS + paths - 1) / paths)) : 1;
+	const long long batch_paths = ctx->stream_batch_paths > 0 ? ctx->stream_batch_paths : (long long)RT_STREAM_BATCH_PATHS;
+	const int batch = (ctx->frame_pipelining && !ctx->params.config.enable_svgf) ? int(std::min<long long>(RT_STREAM_MAX_BATCH, (batch_paths + paths - 1) / paths)) : 1;
 	status = stream_ensure_frames(ctx, sample_count * (num_bounces + 1) * batch); if (status) return status;
 	if (sample_count > s.frame_slots) return fail(ctx, RT_ERROR_OUT_OF_RANGE, "rt_render_samples: %d samples of a %zu pixel frame exceed the %d sample slots of the merged wavefront", sample_count, ctx->frame_pixels, s.frame_slots);
 	static const double factor = getenv("GRT_STREAM_CAPACITY_FACTOR") ? atof(getenv("GRT_STREAM_CAPACITY_FACTOR")) : 4.0;
-	if (size_t(paths * batch) > s.capacity || !s.queues_allocated) { status = stream_ensure_queues(ctx, size_t(double(paths * batch) * (factor < 1.0 ? 1.0 : factor)) + 1024); if (status) return status; }
+	// room for four iterations' worth of new paths -- or, for a declared burst of whole frames (rt_set_stream_batch), for the burst and a quarter: its frames
+	// enter together and only die from then on (412 bytes per path: 21 GB for five 4-sample frames at 1080p instead of 68)
+	const double room = batch_paths > (long long)RT_STREAM_BATCH_PATHS && paths * batch > (long long)RT_STREAM_BATCH_PATHS ? 1.25 : (factor < 1.0 ? 1.0 : factor);
+	if (size_t(paths * batch) > s.capacity || !s.queues_allocated) { status = stream_ensure_queues(ctx, size_t(double(paths * batch) * room) + 1024); if (status) return status; }
 
 	// admission: sample slots, a statistics ring entry, and room in the queues
 	int slot_base = -1;
@@ -2112,7 +2123,7 @@ static int stream_submit(rt_context * ctx, int sample_index, int sample_count, i
 	}
 	status = stream_sync_tlas(ctx); if (status) return status;
 	status = stream_generate(ctx, sub); if (status) return status;
-	if (s.pending < batch && s.pending_paths < RT_STREAM_BATCH_PATHS) return RT_OK;   // wait for more of the same size
+	if (s.pending < batch && s.pending_paths < batch_paths) return RT_OK;   // wait for more of the same size
 	return stream_enqueue_iteration(ctx);
 }
 

@@ -739,6 +739,51 @@ def test_small_pipelined_submissions_share_an_iteration(grt):
     pt.close(); scene.close()
 
 
+def test_a_declared_burst_of_whole_frames_shares_iterations(grt):
+    """rt_set_stream_batch: an application that submits a burst of WHOLE frames and reads nothing in between declares the burst's
+    paths; its submissions then wait for one another, enter the wavefront together and complete together after num_bounces
+    iterations (not submissions + num_bounces - 1) -- with the image and the per-bounce ray counts of the same submissions made
+    one per iteration. A sixth submission that no longer fits the declared burst starts the next iteration."""
+    import ctypes
+    W, H, BOUNCES, FRAMES, SPP = 192, 128, 5, 5, 2
+    lib = grt.device_lib()
+    lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+
+    def render(burst, frames=FRAMES):
+        scene, pt = make_pathtracer(grt, "cornellbox", W, H, 0, num_bounces=BOUNCES)
+        if burst:
+            grt.set_frame_pipelining(pt.ctx, True)
+            grt.set_stream_batch(pt.ctx, FRAMES * SPP * W * H)
+        completed = []
+        for f in range(frames):
+            assert lib.rt_render_samples(pt.ctx, SPP * f, SPP) == 0
+            completed.append(grt.submissions_completed(pt.ctx))
+        if burst:
+            assert completed == [0] * frames                       # the fifth submission enqueued iteration 0 for all five
+            for k in range(BOUNCES - 2):
+                grt.advance(pt.ctx)
+            assert grt.submissions_completed(pt.ctx) == 0          # iterations 0 .. 3: nobody has passed the last bounce
+            grt.advance(pt.ctx)
+            assert grt.submissions_completed(pt.ctx) == FRAMES     # iteration 4: all five at once
+            if frames > FRAMES:
+                grt.advance(pt.ctx)                                # the sixth entered iteration 1 (enqueued by the first rt_advance)
+                assert grt.submissions_completed(pt.ctx) == frames
+        counters = pt.counters()
+        image = pt.read_framebuffer().copy()
+        counts = list(counters.trace[:BOUNCES]), list(counters.shadow[:BOUNCES])
+        pt.close(); scene.close()
+        return image, counts
+
+    together, together_counts = render(True)
+    one_by_one, one_by_one_counts = render(False)
+    assert np.isfinite(together).all() and together[..., :3].max() > 0.0
+    assert np.array_equal(together, one_by_one)
+    assert together_counts == one_by_one_counts
+    six, _ = render(True, FRAMES + 1)
+    six_one_by_one, _ = render(False, FRAMES + 1)
+    assert np.array_equal(six, six_one_by_one)
+
+
 def test_merged_wavefront_advances_without_new_samples(grt):
     """rt_advance runs one iteration without new samples: a frame loop learns from rt_submissions_completed when a frame
     may be packed. With frame pipelining on, rt_pack_pixels follows the completed submissions only."""
