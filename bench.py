@@ -196,7 +196,7 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
             out["binding"] = {"bound": "valu", "unit": "lane-instr/s", "peak": VALU_PEAK_LANE_INSTR_PER_S, "achieved": float("%.4g" % useful),
                               "frac": round(useful / VALU_PEAK_LANE_INSTR_PER_S, 4),
                               "issue_slots_used": counters.get("valu_busy"), "lane_utilisation": counters["valu_lane_utilisation"],
-                              "note": "achieved = SQ_THREAD_CYCLES_VALU (active lanes summed over all vector instructions) of the traversal launches / their time in the counter pass; frac = issue_slots_used x lane_utilisation up to clock effects (the chip runs below 2.4 GHz under this load). The vector ALUs are the unit this kernel saturates; what is left is the idle half of each instruction's lanes"}
+                              "note": "achieved = SQ_THREAD_CYCLES_VALU (active lanes summed over all vector instructions) of the traversal launches / their time in the counter pass; frac = issue_slots_used x lane_utilisation up to clock effects. issue_slots_used counts EVERY vector instruction as four cycles (the counter does): ~1.0 means one instruction per 4 cycles and SIMD, not a saturated pipe -- this chip retires fma / mul / add / logic in ~2.2 cycles and conversions / min / max / compares / selects in ~4.1 (profiles/r04_instruction_costs.txt), the round's mix would need ~3.15. Round 4 (DESIGN.md 4.1, profiles/r04_traversal_experiments.txt): the launch does not wait for memory latency (a software-pipelined engine at 5 waves = the shipped one at 7) and is held by two units at once, the vector ALUs and the CU's L1 / address path (TCP busy 88 %, TA 72 %); the idle 42 % of the lanes are the triangle phase of a round running with a fifth of the wave"}
     if "TCC_HIT_sum" in trace and "TCC_MISS_sum" in trace and (trace["TCC_HIT_sum"][1] + trace["TCC_MISS_sum"][1]) > 0:
         out.setdefault("binding", {})["l2_hit_rate"] = round(trace["TCC_HIT_sum"][1] / (trace["TCC_HIT_sum"][1] + trace["TCC_MISS_sum"][1]), 4)
     if "TCP_TOTAL_CACHE_ACCESSES_sum" in trace and trace["TCP_TOTAL_CACHE_ACCESSES_sum"][1] > 0 and "TCP_TCC_READ_REQ_sum" in trace:
@@ -695,7 +695,7 @@ def main():
                                   "achieved": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
                                   "frac": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9 / stream_gbps, 4)})
             roofline["stages"] = stages
-            roofline["stages_note"] = "a repeat of the timed plan with HIP events around every launch (rt_set_profiling 3); frac = algorithmic bytes (SURVEY 8d formulas, bench.py stage_rooflines) / stage time / measured stream-read bandwidth; the shade kernels are gather chains, the traversal is VALU-bound (see binding): for those the fraction is a yardstick, not the limit"
+            roofline["stages_note"] = "a repeat of the timed plan with HIP events around every launch (rt_set_profiling 3); frac = algorithmic bytes (SURVEY 8d formulas, bench.py stage_rooflines) / stage time / measured stream-read bandwidth; the sort kernel is a gather chain, the material kernels and the traversal are bound by instruction issue (traversal: together with the L1 / address path, see binding): for those the fraction is a yardstick, not the limit"
             grt.set_profiling(ctx, False)
         result = {
             "metric": "Mrays/s (primary+secondary) + ms/frame, Sponza 1920x1080 4spp BVH8", "value": round(value, 1), "unit": "Mrays/s",
@@ -762,7 +762,8 @@ def main():
             result["roofline"].update(pmc)
             r = result["roofline"]
             for stage in r.get("stages", []):   # the counters of the other stages' kernels, where the passes saw them
-                k = pmc_kernels.get({"traversal": TRACE_KERNEL[0], "sort": "kernel_sort_stream", "generate": "kernel_generate_stream", "accumulate": "kernel_accumulate_group"}.get(stage["stage"], "kernel_" + stage["stage"] + "_stream"))
+                name = {"traversal": TRACE_KERNEL[0], "sort": "kernel_sort_stream", "generate": "kernel_generate_stream", "accumulate": "kernel_accumulate_group"}.get(stage["stage"], "kernel_" + stage["stage"] + "_stream")
+                k = pmc_kernels.get(name) or pmc_kernels.get(name + "_texels")   # (material kernels: the instantiation without the per-fetch BC1 decode, rt_set_texture_expansion)
                 if k and k.get("SQ_INSTS_VALU", [0, 0])[1] > 0 and k.get("_duration_ns"):
                     stage["lane_utilisation"] = round(k["SQ_THREAD_CYCLES_VALU"][1] / (64.0 * k["SQ_INSTS_VALU"][1]), 3)
                     stage["valu_busy"] = round(4.0 * k.get("SQ_ACTIVE_INST_VALU", [0, 0.0])[1] / (1024.0 * k["_duration_ns"][1] * 2.4), 3)
@@ -771,7 +772,7 @@ def main():
                 # how much of what the traversal reads is served by the caches (L1 + L2 + Infinity Cache together): the
                 # algorithmic bytes are a lower bound of its requests, the memory-side traffic is what got past the caches
                 r["cache_hit_fraction_lower_bound"] = round(1.0 - r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
-                r["bound_in_practice"] = ("VALU issue and the dependent chain of each ray: vector ALUs busy %.2f at a lane utilisation of %.2f; the memory side moves %.0f %% of the algorithmic bytes, which is why frac can exceed 1 (see roofline.binding; DESIGN.md 4.1)"
+                r["bound_in_practice"] = ("vector-ALU issue together with the CU's L1 / address path (neither alone: DESIGN.md 4.1, round 4): %.2f vector instructions per 4 cycles and SIMD at a lane utilisation of %.2f; the memory side moves %.0f %% of the algorithmic bytes, which is why frac can exceed 1 (see roofline.binding)"
                                           % (r.get("counters", {}).get("valu_busy", float("nan")), r.get("counters", {}).get("valu_lane_utilisation", float("nan")), 100.0 * r["traffic"] / r["algorithmic_bytes_per_launch"]))
         print(json.dumps(result))
 
