@@ -229,6 +229,15 @@ int main(int argc, char ** argv) {
 		Pathtracer * pathtracer = dynamic_cast<Pathtracer *>(integrator.get());
 		auto t1 = std::chrono::steady_clock::now();
 		int target = cpu_config.output_sample_index;
+		// A headless render of `-N n` samples is a batch job: nothing is read before the last sample. Declared to the device library
+		// (rt_set_stream_batch), up to eight of its submissions enter the merged wavefront together and walk their bounces side by side
+		// instead of one after the other (the same image). Not for SVGF frames (each inherits its predecessor's g-buffers).
+		if (pathtracer && integrator->ctx && cl.batch > 1 && target + 1 > cl.batch && !gpu_config.enable_svgf) {
+			const long long submissions = (long long)(target + cl.batch) / cl.batch;
+			const long long burst = submissions < 8 ? submissions : 8;
+			if (rt_set_frame_pipelining(integrator->ctx, 1) != RT_OK || rt_set_stream_batch(integrator->ctx, burst * cl.batch * (long long)cpu_config.initial_width * cpu_config.initial_height) != RT_OK)
+				die(std::string("ERROR: ") + rt_last_error(integrator->ctx));
+		}
 		while (true) {
 			integrator->update(0.0f);
 			int remaining = target - integrator->sample_index + 1;
