@@ -9,8 +9,10 @@
 //   2  64-bit keys: mesh << 32 | 30-bit Morton code of the triangle's box centre inside its mesh's box; ONE radix sort of all
 //      triangles of all meshes (rocPRIM; a sort is a solved problem and not on the frame path)
 //   3  breadth-first over ALL meshes at once, one level per round of four launches: a node covers a run of the sorted order;
-//        runs     one thread per node cuts its run at the highest differing Morton bits, the widest piece again and again,
-//                 until there are 8 pieces or none holds more than 3 triangles (pieces of <= 3 triangles are leaves)
+//        runs     one thread per node cuts its run at the highest differing Morton bits -- the piece with the LARGEST SURFACE AREA again and
+//                 again (the usual rule of a wide collapse: the box a ray is most likely to enter is the one worth refining; round 4, it was
+//                 the widest piece) -- until there are 8 pieces or none holds more than 3 triangles (pieces of <= 3 triangles are leaves).
+//                 A piece's box comes from a table of the boxes of all power-of-two runs of the sorted order (two look-ups per piece).
 //        scan     exclusive prefix sums over the level: inner children -> node indices, leaf triangles -> triangle positions
 //        boxes    one WAVE per child: the union of its run's triangle boxes (runs are long near the roots)
 //        nodes    eight lanes per node: octant slots by the greedy assignment of the reference's converter
@@ -38,6 +40,8 @@ struct BlasBuildArgs {
 	int * order, * position;                         // leaf position -> input triangle, and back
 	// scratch
 	TlasBox * triangle_boxes, * sorted_boxes, * mesh_boxes, * child_boxes;
+	TlasBox * box_table;                             // [table_levels][triangle_count]: entry (j, i) = box of sorted triangles [i, i + 2^(j+1)), clamped at the end (level 0 of the idea is sorted_boxes)
+	int table_levels, split_widest;                  // split_widest: the round-3 rule (the piece with the most triangles first), for comparison
 	int * triangle_mesh;
 	uint64_t * keys; int * ids;                      // unsorted
 	uint64_t * sorted_keys; int * sorted_ids;
@@ -94,6 +98,26 @@ __global__ void __launch_bounds__(256) kernel_blas_sorted_boxes(BlasBuildArgs a)
 	if (i < a.triangle_count) a.sorted_boxes[i] = a.triangle_boxes[a.sorted_ids[i]];
 }
 
+// boxes of the runs [i, i + 2^level) of the sorted order, level = 1 .. table_levels, each from the two halves one level below
+__global__ void __launch_bounds__(256) kernel_blas_box_table(BlasBuildArgs a, int level) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.triangle_count) return;
+	const TlasBox * below = level == 1 ? a.sorted_boxes : a.box_table + size_t(level - 2) * a.triangle_count;
+	TlasBox box = below[i];
+	const int other = i + (1 << (level - 1));
+	if (other < a.triangle_count) tlas_box_grow(box, below[other]);
+	a.box_table[size_t(level - 1) * a.triangle_count + i] = box;
+}
+// surface area of the box of the sorted triangles [lo, hi), hi > lo: the union of the two (overlapping) power-of-two runs that cover it
+RT_DEV float blas_run_area(const BlasBuildArgs & a, int lo, int hi) {
+	const int k = 31 - __clz(hi - lo);
+	const TlasBox * runs = k == 0 ? a.sorted_boxes : a.box_table + size_t(k - 1) * a.triangle_count;
+	TlasBox box = runs[lo];
+	tlas_box_grow(box, runs[hi - (1 << k)]);
+	const float dx = box.max[0] - box.min[0], dy = box.max[1] - box.min[1], dz = box.max[2] - box.min[2];
+	return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
 // [lo, hi) cut where the highest differing Morton bit flips; equal codes: in the middle
 RT_DEV int blas_split(const uint64_t * __restrict__ keys, int lo, int hi) {
 	const uint32_t first = uint32_t(keys[lo]), last = uint32_t(keys[hi - 1]);
@@ -116,14 +140,26 @@ __global__ void __launch_bounds__(256) kernel_blas_runs(BlasBuildArgs a, int lev
 	#pragma unroll
 	for (int c = 1; c < 9; c++) begin[c] = range.y;
 	int count = range.y > range.x ? 1 : 0;
+	// what a piece weighs when the next one to cut is chosen: its surface area (or, split_widest, its number of triangles)
+	float weight[8];
+	#pragma unroll
+	for (int c = 0; c < 8; c++) weight[c] = 0.0f;
+	if (range.y - range.x > RT_BLAS_LEAF) weight[0] = a.split_widest ? float(range.y - range.x) : blas_run_area(a, range.x, range.y);
 	for (int round = 0; round < 7 && count > 0; round++) {
-		int widest = -1, width = RT_BLAS_LEAF, widest_lo = 0, widest_hi = 0;
+		int widest = -1, widest_lo = 0, widest_hi = 0; float heaviest = -1.0f;
 		#pragma unroll
-		for (int c = 0; c < 8; c++) if (c < count && begin[c + 1] - begin[c] > width) { width = begin[c + 1] - begin[c]; widest = c; widest_lo = begin[c]; widest_hi = begin[c + 1]; }
+		for (int c = 0; c < 8; c++) if (c < count && begin[c + 1] - begin[c] > RT_BLAS_LEAF && weight[c] > heaviest) { heaviest = weight[c]; widest = c; widest_lo = begin[c]; widest_hi = begin[c + 1]; }
 		if (widest < 0) break;
 		const int cut = blas_split(a.sorted_keys, widest_lo, widest_hi);
+		float left = float(cut - widest_lo), right = float(widest_hi - cut);
+		if (!a.split_widest) {   // (a piece of <= 3 triangles is never cut again: its weight is not looked at)
+			left  = cut - widest_lo > RT_BLAS_LEAF ? blas_run_area(a, widest_lo, cut) : 0.0f;
+			right = widest_hi - cut > RT_BLAS_LEAF ? blas_run_area(a, cut, widest_hi) : 0.0f;
+		}
 		#pragma unroll
 		for (int c = 8; c >= 1; c--) { if (c > widest + 1) begin[c] = begin[c - 1]; else if (c == widest + 1) begin[c] = cut; }
+		#pragma unroll
+		for (int c = 7; c >= 0; c--) { if (c > widest + 1) weight[c] = weight[c - 1]; else if (c == widest + 1) weight[c] = right; else if (c == widest) weight[c] = left; }
 		count++;
 	}
 	int inner = 0, leaf_triangles = 0;
@@ -297,6 +333,7 @@ hipError_t rt_blas_build(BlasBuildArgs a, void * library_scratch, size_t library
 		size_t bytes = library_scratch_bytes;
 		if ((e = rocprim::radix_sort_pairs(library_scratch, bytes, a.keys, a.sorted_keys, a.ids, a.sorted_ids, size_t(T), 0, 32 + mesh_bits, stream)) != hipSuccess) return e;
 		hipLaunchKernelGGL(kernel_blas_sorted_boxes, dim3((T + 255) / 256), dim3(256), 0, stream, a);
+		if (!a.split_widest) for (int level = 1; level <= a.table_levels; level++) hipLaunchKernelGGL(kernel_blas_box_table, dim3((T + 255) / 256), dim3(256), 0, stream, a, level);
 	}
 	int level_first = a.first_node, level_nodes = M, nodes_used = a.first_node + M, triangles_placed = 0;
 	while (level_nodes > 0) {

@@ -596,7 +596,7 @@ struct BlasBuildArgs { // must match kernels_blas.hip
 	int triangle_count, mesh_count, first_node;
 	const float4 * triangles; const int * mesh_first;
 	float4 * triangles_out, * positions_out; uint32_t * nodes; int * order, * position;
-	TlasBox * triangle_boxes, * sorted_boxes, * mesh_boxes, * child_boxes; int * triangle_mesh;
+	TlasBox * triangle_boxes, * sorted_boxes, * mesh_boxes, * child_boxes; TlasBox * box_table; int table_levels, split_widest; int * triangle_mesh;
 	uint64_t * keys; int * ids; uint64_t * sorted_keys; int * sorted_ids;
 	int2 * range; int * runs; int * inner_count, * leaf_count, * inner_base, * leaf_base; int * level_state;
 };
@@ -639,6 +639,10 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	             o_keys = region(T * 8), o_ids = region(T * 4), o_skeys = region(T * 8), o_sids = region(T * 4), o_range = region(node_capacity * 8),
 	             o_runs = region(level_capacity * 48), o_ic = region(level_capacity * 4), o_lc = region(level_capacity * 4), o_ib = region(level_capacity * 4), o_lb = region(level_capacity * 4),
 	             o_state = region(16);
+	// boxes of all power-of-two runs of the sorted order (kernel_blas_box_table: the area of any run is two look-ups): levels 1 .. floor(log2 T)
+	int table_levels = 0; while ((size_t(2) << table_levels) <= T) table_levels++;
+	static const bool split_widest = getenv("GRT_BLAS_SPLIT_WIDEST") != nullptr;   // round 3's rule (most triangles first), for tools/blas_bench.py
+	const size_t o_table = region(split_widest ? 0 : size_t(table_levels) * T * 24);
 	const size_t library_bytes = rt_blas_build_scratch_bytes(T, M + level_capacity);
 	const size_t o_library = region(library_bytes);
 	if ((s = device_alloc(ctx, &scratch, at))) return give_up(s);
@@ -653,6 +657,7 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	a.order = (int *)(base + o_order); a.position = (int *)(base + o_position);
 	a.triangle_boxes = (TlasBox *)(base + o_tbox); a.sorted_boxes = (TlasBox *)(base + o_sbox); a.mesh_boxes = (TlasBox *)(base + o_mbox); a.child_boxes = (TlasBox *)(base + o_cbox);
 	a.triangle_mesh = (int *)(base + o_tmesh);
+	a.box_table = (TlasBox *)(base + o_table); a.table_levels = table_levels; a.split_widest = split_widest ? 1 : 0;
 	a.keys = (uint64_t *)(base + o_keys); a.ids = (int *)(base + o_ids); a.sorted_keys = (uint64_t *)(base + o_skeys); a.sorted_ids = (int *)(base + o_sids);
 	a.range = (int2 *)(base + o_range); a.runs = (int *)(base + o_runs);
 	a.inner_count = (int *)(base + o_ic); a.leaf_count = (int *)(base + o_lc); a.inner_base = (int *)(base + o_ib); a.leaf_base = (int *)(base + o_lb);

@@ -19,7 +19,7 @@ def main():
     lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     for device_blas in (0, 1, 1):
         scene = bench.build_scene(grt)
-        grt.config_set(device_blas=device_blas)
+        grt.config_set(device_blas=device_blas, merge_static=int(os.environ.get("MERGE_STATIC", "1")))   # (MERGE_STATIC=0: one tree per mesh under the TLAS, the reference's layout)
         t0 = time.perf_counter()
         pt = grt.Pathtracer(scene, bench.WIDTH, bench.HEIGHT, device=0); pt.update()
         setup_s = time.perf_counter() - t0
