@@ -32,7 +32,8 @@ static std::vector<Tri> tris; static std::vector<Box> tbox; static float cam[15]
 
 static uint32_t expand(uint32_t v) { v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu; v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u; return v; }
 
-enum Policy { LBVH, SAH_EXACT, SAH_CANDIDATES, SAH_ALIGNED };
+enum Policy { LBVH, SAH_EXACT, SAH_CANDIDATES, SAH_ALIGNED, RECORDED };
+static std::vector<int> cut_depth;   // RECORDED: depth at which the boundary in front of position p was cut by the binary build (INT_MAX: never)
 struct Build { const std::vector<uint64_t> & keys; const std::vector<Box> & sbox; Policy policy; bool area_first; int candidates; std::vector<Box> prefix, suffix; };
 
 static Box range_box(const std::vector<Box> & sbox, int a, int b) { Box r; for (int i = a; i < b; i++) r.grow(sbox[i]); return r; }
@@ -80,6 +81,31 @@ static int aligned_split(const Build & b, int lo, int hi, int levels) {
 	return best < 0 ? (lo + hi) / 2 : lo + best;
 }
 
+static int recorded_split(int lo, int hi) { int best = (lo + hi) / 2, depth = 0x7fffffff; for (int p = lo + 1; p < hi; p++) if (cut_depth[p] < depth) { depth = cut_depth[p]; best = p; } return best; }
+
+// top-down binned SAH (16 bins per axis over the centroid box, object splits only) down to <= 3 triangles: re-orders ids[lo, hi) and records the cuts
+static void binned_sah(std::vector<int> & ids, const std::vector<Box> & boxes, int lo, int hi, int depth, int bins) {
+	if (hi - lo <= 3) return;
+	Box cb; for (int i = lo; i < hi; i++) { const Box & b = boxes[ids[i]]; Box c; for (int d = 0; d < 3; d++) c.lo[d] = c.hi[d] = 0.5f * (b.lo[d] + b.hi[d]); cb.grow(c); }
+	int best_axis = -1, best_plane = 0; float best_cost = 1e38f;
+	for (int axis = 0; axis < 3; axis++) {
+		float extent = cb.hi[axis] - cb.lo[axis]; if (!(extent > 0)) continue;
+		std::vector<Box> bb(bins); std::vector<int> bc(bins, 0);
+		for (int i = lo; i < hi; i++) { const Box & b = boxes[ids[i]]; float c = 0.5f * (b.lo[axis] + b.hi[axis]); int k = std::min(bins - 1, int((c - cb.lo[axis]) / extent * bins)); bb[k].grow(b); bc[k]++; }
+		std::vector<float> la(bins), ra(bins); std::vector<int> ln(bins), rn(bins);
+		{ Box acc; int n = 0; for (int k = 0; k < bins; k++) { acc.grow(bb[k]); n += bc[k]; la[k] = n ? acc.area() : 0; ln[k] = n; } }
+		{ Box acc; int n = 0; for (int k = bins - 1; k >= 0; k--) { acc.grow(bb[k]); n += bc[k]; ra[k] = n ? acc.area() : 0; rn[k] = n; } }
+		for (int k = 0; k + 1 < bins; k++) if (ln[k] > 0 && rn[k + 1] > 0) { float cost = la[k] * ln[k] + ra[k + 1] * rn[k + 1]; if (cost < best_cost) { best_cost = cost; best_axis = axis; best_plane = k; } }
+	}
+	int cut;
+	if (best_axis < 0) cut = (lo + hi) / 2;
+	else { float extent = cb.hi[best_axis] - cb.lo[best_axis];
+		auto left = [&](int id) { const Box & b = boxes[id]; float c = 0.5f * (b.lo[best_axis] + b.hi[best_axis]); return std::min(bins - 1, int((c - cb.lo[best_axis]) / extent * bins)) <= best_plane; };
+		cut = int(std::stable_partition(ids.begin() + lo, ids.begin() + hi, left) - ids.begin()); }
+	cut_depth[cut] = depth;
+	binned_sah(ids, boxes, lo, cut, depth + 1, bins); binned_sah(ids, boxes, cut, hi, depth + 1, bins);
+}
+
 static int build_node(Tree & t, const Build & b, int lo, int hi) {
 	int index = int(t.nodes.size()); t.nodes.emplace_back();
 	int begin[9]; begin[0] = lo; for (int c = 1; c < 9; c++) begin[c] = hi; int count = 1;
@@ -90,7 +116,7 @@ static int build_node(Tree & t, const Build & b, int lo, int hi) {
 			float k = !b.area_first ? float(n) : b.candidates == -1 ? area : b.candidates == -2 ? area * sqrtf(float(n)) : b.candidates == -3 ? area * log2f(float(n)) : area * n;
 			if (k > key) { key = k; pick = c; } }
 		if (pick < 0) break;
-		int cut = b.policy == LBVH ? lbvh_split(b.keys, begin[pick], begin[pick + 1]) : b.policy == SAH_ALIGNED ? aligned_split(b, begin[pick], begin[pick + 1], b.candidates) : sah_split(b, begin[pick], begin[pick + 1], 3);
+		int cut = b.policy == RECORDED ? recorded_split(begin[pick], begin[pick + 1]) : b.policy == LBVH ? lbvh_split(b.keys, begin[pick], begin[pick + 1]) : b.policy == SAH_ALIGNED ? aligned_split(b, begin[pick], begin[pick + 1], b.candidates) : sah_split(b, begin[pick], begin[pick + 1], 3);
 		for (int c = 8; c >= 1; c--) { if (c > pick + 1) begin[c] = begin[c - 1]; else if (c == pick + 1) begin[c] = cut; }
 		count++;
 	}
@@ -188,6 +214,20 @@ int main(int argc, char ** argv) {
 		#pragma omp parallel for reduction(+:bn, bt)
 		for (size_t i = 0; i < bounce.size(); i++) { float best = 1e30f; int hit = -1; long a = 0, c = 0; trace(t, bounce[i], best, hit, a, c); bn += a; bt += c; }
 		printf("%-74s nodes %7zu  cost %7.1f | primary %5.2f nodes %5.2f tris | bounce %5.2f nodes %5.2f tris\n", v.name, t.nodes.size(), sah, double(pn) / primary.size(), double(pt) / primary.size(), double(bn) / bounce.size(), double(bt) / bounce.size());
+	}
+	for (int bins : { 8, 16, 32 }) for (int area_first = 0; area_first < 2; area_first++) {
+		std::vector<int> ids(tri_count); for (int i = 0; i < tri_count; i++) ids[i] = i;
+		cut_depth.assign(size_t(tri_count) + 1, 0x7fffffff);
+		binned_sah(ids, tbox, 0, tri_count, 0, bins);
+		std::vector<Box> ob(tri_count); for (int i = 0; i < tri_count; i++) ob[i] = tbox[ids[i]];
+		Tree t; t.order = ids; Build b { skeys, ob, RECORDED, area_first != 0, -1, {}, {} };
+		build_node(t, b, 0, tri_count);
+		long pn = 0, pt = 0, bn = 0, bt = 0;
+		#pragma omp parallel for reduction(+:pn, pt)
+		for (size_t i = 0; i < primary.size(); i++) { float best = 1e30f; int hit = -1; long a = 0, c = 0; trace(t, primary[i], best, hit, a, c); pn += a; pt += c; }
+		#pragma omp parallel for reduction(+:bn, bt)
+		for (size_t i = 0; i < bounce.size(); i++) { float best = 1e30f; int hit = -1; long a = 0, c = 0; trace(t, bounce[i], best, hit, a, c); bn += a; bt += c; }
+		printf("binned SAH, %2d bins, binary tree collapsed 8-wide, %-34s nodes %7zu               | primary %5.2f nodes %5.2f tris | bounce %5.2f nodes %5.2f tris\n", bins, area_first ? "largest area first" : "widest piece first", t.nodes.size(), double(pn) / primary.size(), double(pt) / primary.size(), double(bn) / bounce.size(), double(bt) / bounce.size());
 	}
 	return 0;
 }
