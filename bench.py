@@ -744,7 +744,7 @@ def main():
             result["povs"] = {"source": "Util/PerfTest.h:30-40 (povs_sponza), 16 steps each", "per_pov": povs,
                               "ms_per_step_avg": round(float(ms_all.mean()), 3), "ms_per_step_stddev": round(float(ms_all.std()), 3),
                               "mrays_s_avg": round(float(mr_all.mean()), 1), "mrays_s_stddev": round(float(mr_all.std()), 1)}
-        if world == 1 and split_world == 1 and merged and not args.no_config3 and not os.environ.get("BENCH_PMC_CHILD"):
+        if world == 1 and split_world == 1 and merged and not args.no_config3 and (not os.environ.get("BENCH_PMC_CHILD") or os.environ.get("BENCH_PMC_CONFIG3")):   # (tools/svgf_counters.py profiles this section)
             pt.close(); pt = None   # (its queues and sample frames go back first)
             result["config3"] = config3_section(grt, scene, local_rank, stream_gbps)
         if world == 1 and split_world == 1 and merged and args.merge_static and not args.no_reference_layout and not os.environ.get("BENCH_PMC_CHILD"):
