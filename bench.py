@@ -576,10 +576,10 @@ def main():
     # carries ONE bounce of 8 frames instead of every bounce of one: 32 steps as one burst run at 1.365 ms per step where the pipelined steady
     # state of a long run reaches 1.39.
     burst = 0
-    if merged and split_world == 1 and args.burst and len(plan) > 1:
+    if merged and args.burst and len(plan) > 1:   # (every rank of a tile split declares its share the same way: its small submissions shared iterations already, up to 8.3 M paths)
         burst = min(len(plan), 8)
         grt.set_frame_pipelining(ctx, True)
-        grt.set_stream_batch(ctx, sum(count for _, count, _ in plan[:burst]) * WIDTH * HEIGHT)
+        grt.set_stream_batch(ctx, sum(count for _, count, _ in plan[:burst]) * (WIDTH * HEIGHT if split_world == 1 else split.local_pixels))
     launch_bytes = None
     if merged:
         run(plan)
@@ -716,7 +716,7 @@ def main():
                 "parallelism": ("tile-split x%d + one RCCL all-gather of the accumulated float4 frame per %d-spp frame, unpacked into every rank's framebuffer; exchange: %s" % (world, SPP, "the library's own (rt_all_gather_framebuffer: ncclAllGather on the context's stream)" if exchange == "native" else "torch.distributed all_gather_into_tensor around rt_pack_pixels / rt_unpack_pixels")) if world > 1 else "single GPU",
                 "samples_per_submission": args.batch, "submissions_in_flight": ("num_bounces (merged wavefront)" if merged else args.samples_in_flight),
                 # rt_set_frame_pipelining: the submissions of a tile split are small, up to 8 of them share one iteration of the wavefront
-                "submissions_per_iteration": (min(8, -(-WIDTH * HEIGHT * SPP // max(1, split.local_pixels * args.batch))) if (merged and split_world > 1) else (burst or 1)),
+                "submissions_per_iteration": (burst or (min(8, -(-WIDTH * HEIGHT * SPP // max(1, split.local_pixels * args.batch))) if (merged and split_world > 1) else 1)),
                 "burst": ("the run's submissions are declared as bursts of %d (rt_set_stream_batch): each burst enters the wavefront together and takes %d iterations; --burst 0 lets submissions follow one another (%d iterations for as many)" % (burst, NUM_BOUNCES, burst + NUM_BOUNCES - 1)) if burst else "off",
                 "stage_ms_per_step_one_frame_alone": {k: round(v, 3) for k, v in stage_ms.items()},
             },

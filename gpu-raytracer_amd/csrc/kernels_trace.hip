@@ -177,8 +177,11 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 //     v_bfe + v_lshrrev + v_lshlrev;
 //   * the hit test: v_cmpx_lt_f32 narrows the execution mask to the lanes that hit, ONE v_or_b32 adds the contribution, a scalar
 //     move restores the mask -- instead of v_cmp + v_cndmask + half a v_or3.
+// Measured (profiles/r04_traversal_experiments.txt, items 3 and 7): under the pipelined schedule, at 6 waves per SIMD, -0.8 % -- left off; with every launch
+// carrying ONE bounce of a burst (rt_set_stream_batch) -1.4 % of the traversal time against the shipped 7-wave kernel, on one box, twice: on (2), with the
+// flattened scene's launch at 6 waves (80 registers, no scratch; at 7 the rewritten test spills 20 bytes). 1: the same without the v_cmpx form. 0: the plain test.
 #ifndef RT_FAST_NODE
-#define RT_FAST_NODE 0
+#define RT_FAST_NODE 2
 #endif
 RT_DEV unsigned bvh8_node_intersect_fast(const Ray3 & ray, f3 inv_dir, unsigned oct_inv4, float max_distance,
                                          float4 n0, float4 n1, float4 n2, float4 n3, float4 n4) {
@@ -749,7 +752,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					if (COUNT && !SHADOW) { phase_node_lanes++; if (RT_PHASE_LEADER()) phase_node_execs++; }
 #endif
 					hitmask = NARROW ? group8_or(bvh8_node_intersect_child(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, group_child))
-					        : (RT_FAST_NODE && UNIFIED) ? bvh8_node_intersect_fast(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4)
+					        : (RT_FAST_NODE && UNIFIED && FLAT) ? bvh8_node_intersect_fast(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4)
 					                 : bvh8_node_intersect(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
 					imask = extract_byte(__float_as_uint(n0.w), 3);
 
@@ -1618,10 +1621,10 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	}
 }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8(RtParams p) { trace_stream<false>(p, nullptr); }
-// (7 waves per SIMD: without the TLAS / instance state the engine fits 72 registers with no scratch; 1.045-1.052 ms of traversal per step
-// against 1.056-1.059 with 6 -- profiles/r03_flattened_static_geometry.txt)
+// (With the plain node test: 7 waves per SIMD -- without the TLAS / instance state the engine fits 72 registers with no scratch; 1.045-1.052 ms of traversal per
+// step against 1.056-1.059 with 6, profiles/r03_flattened_static_geometry.txt. With RT_FAST_NODE 2: 6 waves, 80 registers, see there.)
 #ifndef RT_FLAT_WAVES
-#define RT_FLAT_WAVES 7
+#define RT_FLAT_WAVES (RT_FAST_NODE ? 6 : 7)
 #endif
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_FLAT_WAVES) kernel_trace_stream_bvh8_flat(RtParams p) { trace_stream<false, true>(p, nullptr); }
 // The flattened scene with the top of its tree in LDS (rt_set_node_cache). 25.6 KB of LDS per workgroup: 6 workgroups per CU.
