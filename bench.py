@@ -216,15 +216,16 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
 #   accumulate  48 B per pixel and AOV (sample read, accumulator read + write)
 #   SVGF / TAA  every tap the kernels request, enumerated from the tap loops (reference SVGF.h:130-609, TAA.h:10-172);
 #               `unique` next to it is the compulsory traffic (every image read / written once per kernel)
-SVGF_TAP_BYTES = {   # kernel: (bytes requested per pixel, bytes per pixel if every image moved once); kernels as of round 3
+SVGF_TAP_BYTES = {   # kernel: (bytes requested per pixel, bytes per pixel if every image moved once); kernels as of round 4 (the a-trous taps are what the ALGORITHM asks for: the tiled kernel serves most of them from LDS)
     # reads radiance pair 32, g-buffer 16 + 8, 4 history (normal, depth) taps, 4 x 3 history taps, history length r/w; writes the pair, the
     # moments, the decoded (normal, depth), the variance pair, and for pixels with >= 4 frames of history the variance pass's copies
     "svgf_reproject": (32 + 16 + 8 + 4 * 16 + 4 * 48 + 8 + 32 + 16 + 16 + 8 + 40, 32 + 16 + 8 + 16 + 48 + 8 + 32 + 16 + 16 + 8 + 40),
     "svgf_variance":  (4, 4),             # only pixels with a history shorter than 4 frames have work (48 taps x 80 B each); the others read their history length
     "svgf_atrous":    (9 * 8 + 32 + 16 + 2 * 4 + 8 * (32 + 16) + 32 + 8 + 5, 32 + 16 + 8 + 32 + 8 + 5),   # 3x3 variance pairs, centre, 8 taps of (direct, indirect, normal + depth); + the history copy of pass 2
     "svgf_finalize":  (32 + 16 + 16 + 16 + 16 + 16 + 16 + 16 + 16 + 8, 184),
-    "taa":            (16 + 8 + 16 * 16 + 8 * 16 + 16, 16 + 8 + 16 + 16),
-    "taa_finalize":   (16 + 16 + 16 + 8, 56),
+    # round 4: kernel_taa_finalize is folded into kernel_taa (reads the frame, its motion vector, 16 history + 8 neighbour taps; writes the next history, the
+    # displayed image and the cleared motion vector)
+    "taa":            (16 + 8 + 16 * 16 + 8 * 16 + 16 + 16 + 8, 16 + 8 + 16 + 16 + 16 + 8),
 }
 
 
@@ -702,8 +703,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": ("Crytek Sponza as the reference ships it: geometry and the 19 diffuse maps of Data/Sponza (fixed seeds, fixed camera)" if grt.reference_sponza_textures_installed() else "synthetic"),
             "config": {
-                "workload": "Sponza (Crytek, 262 687 triangles, 384 instances) 1920x1080, samples 0..3 (4 spp), BVH8/CWBVH, diffuse + roughplastic(odd materials, alpha 0.3), NEE+MIS+RR, 10 bounces, constant white sky, mipmapping on, 19 diffuse textures at the reference's dimensions (1024x1024 + mips, BC1 block-compressed as the reference does by default, decoded in the shade kernels; " + ("the reference's own texture files" if grt.reference_sponza_textures_installed() else "texels replicated 4x4 from the quarter-size maps that travel with the repo") + "), the 5 maps missing upstream are the reference's 1x1 fallback texel",
-                "step": "one sample per pixel for the whole frame; the 4 samples of a frame are one submission (rt_render_samples); consecutive submissions feed one merged wavefront, every launch carries the rays of all submissions in flight",
+                "workload": "Sponza (Crytek, 262 687 triangles, 384 instances) 1920x1080, samples 0..3 (4 spp), BVH8/CWBVH, diffuse + roughplastic(odd materials, alpha 0.3), NEE+MIS+RR, 10 bounces, constant white sky, mipmapping on, 19 diffuse textures at the reference's dimensions (1024x1024 + mips, BC1 block-compressed as the reference does by default, decoded once at upload (rt_set_texture_expansion); " + ("the reference's own texture files" if grt.reference_sponza_textures_installed() else "texels replicated 4x4 from the quarter-size maps that travel with the repo") + "), the 5 maps missing upstream are the reference's 1x1 fallback texel",
+                "step": "one sample per pixel for the whole frame; the 4 samples of a frame are one submission (rt_render_samples); the submissions feed one merged wavefront (see burst: declared as a burst they enter it together and every launch carries one bounce of all of them; one by one, every launch carries the rays of all submissions in flight)",
                 "scheduler": scheduler,
                 "acceleration_structure": (("%d of %d instances (all that stand still) flattened into one CWBVH of %d triangle copies" + (", no TLAS: rays start inside the tree (rt_set_static_geometry)" if pt.static_geometry_whole_scene else ", one TLAS leaf beside the other instances") + ", hits reported as the scene's own instances and triangles (rt_upload_triangle_aliases); tree built on the host in %.2f s (SAH object + spatial splits, all threads; at scene load, not in the timed region); --merge-static 0 runs the reference's layout")
                                            % (pt.static_geometry_members, scene.mesh_count, int((pt.array("alias_mesh_ids") >= 0).sum()), pt.static_geometry_build_seconds)) if pt.static_geometry_members else "one CWBVH per mesh under a CWBVH TLAS (the reference's layout)",
