@@ -5,7 +5,7 @@
 // BVH8Converter (Src/BVH/Converters/BVH8Converter.cpp:7-335). The OUTPUT is the same data structure -- 80-byte CWBVH
 // nodes (BVH8.h:19-25) over triangles stored in leaf order, up to 3 triangles per leaf, octant-ordered child slots,
 // quantised child boxes -- which is all the traversal kernels know about; the TREE is not the reference's: a linear BVH.
-//   1  box of every triangle, box of every mesh (one workgroup per mesh)
+//   1  box of every triangle (one thread each), box of every mesh (integer atomics on order-preserving keys, one set per wave)
 //   2  64-bit keys: mesh << 32 | 30-bit Morton code of the triangle's box centre inside its mesh's box; ONE radix sort of all
 //      triangles of all meshes (rocPRIM; a sort is a solved problem and not on the frame path)
 //   3  breadth-first over ALL meshes at once, one level per round of four launches: a node covers a run of the sorted order;
@@ -51,14 +51,31 @@ struct BlasBuildArgs {
 	int * level_state;                               // { nodes used, triangles placed, nodes of the next level }
 };
 
+// Step 1 in three launches, all of them as wide as the input: a mesh's box used to be reduced by ONE workgroup per mesh, which is the whole chip
+// idle behind one CU when the "mesh" is a flattened scene of half a million triangles (2 of that build's 2.8 ms). Floats are accumulated as integers
+// whose order is the floats' (the usual sign flip): atomicMin / atomicMax then do the reduction.
+RT_DEV int blas_ordered(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+RT_DEV float blas_unordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ void __launch_bounds__(256) kernel_blas_mesh_boxes_begin(BlasBuildArgs a) {
+	const int mesh = blockIdx.x * blockDim.x + threadIdx.x;
+	if (mesh >= a.mesh_count) return;
+	int * box = (int *)&a.mesh_boxes[mesh];
+	for (int d = 0; d < 3; d++) { box[d] = blas_ordered(3.0e38f); box[3 + d] = blas_ordered(-3.0e38f); }   // (tlas_box_empty)
+}
+
 __global__ void __launch_bounds__(256) kernel_blas_triangle_boxes(BlasBuildArgs a) {
-	const int mesh = blockIdx.x, first = a.mesh_first[mesh], last = a.mesh_first[mesh + 1];
-	TlasBox mine; tlas_box_empty(mine);
-	for (int i = first + int(threadIdx.x); i < last; i += int(blockDim.x)) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool valid = i < a.triangle_count;
+	int mesh = 0;
+	TlasBox box; tlas_box_empty(box);
+	if (valid) {
+		int lo = 0, hi = a.mesh_count;   // the mesh whose range [mesh_first[m], mesh_first[m + 1]) holds triangle i (empty meshes have empty ranges and are skipped)
+		while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (a.mesh_first[mid] <= i) lo = mid; else hi = mid; }
+		mesh = lo;
 		const float4 * t = a.triangles + size_t(i) * 6;
 		float4 t0 = t[0], t1 = t[1], t2 = t[2];
 		const float p0[3] = { t0.x, t0.y, t0.z }, e1[3] = { t0.w, t1.x, t1.y }, e2[3] = { t1.z, t1.w, t2.x };
-		TlasBox box;
 		for (int d = 0; d < 3; d++) {
 			float v1 = p0[d] + e1[d], v2 = p0[d] + e2[d];   // the vertices the traversal's Moeller-Trumbore test sees
 			box.min[d] = fminf(p0[d], fminf(v1, v2)); box.max[d] = fmaxf(p0[d], fmaxf(v1, v2));
@@ -68,21 +85,33 @@ __global__ void __launch_bounds__(256) kernel_blas_triangle_boxes(BlasBuildArgs 
 			while (box.max[d] - box.min[d] < eps) { box.min[d] -= eps; box.max[d] += eps; eps *= 2.0f; }
 		}
 		a.triangle_boxes[i] = box; a.triangle_mesh[i] = mesh;
-		tlas_box_grow(mine, box);
 	}
-	__shared__ float reduce[4][6];
-	for (int d = 0; d < 3; d++) {
-		float lo = mine.min[d], hi = mine.max[d];
-		for (int offset = 32; offset > 0; offset >>= 1) { lo = fminf(lo, __shfl_xor(lo, offset)); hi = fmaxf(hi, __shfl_xor(hi, offset)); }
-		if ((threadIdx.x & 63) == 0) { reduce[threadIdx.x >> 6][d] = lo; reduce[threadIdx.x >> 6][3 + d] = hi; }
+	// the mesh's box: one set of atomics per wave where the whole wave is inside one mesh (all but the waves that straddle a boundary). Every lane of the
+	// wave stays in the reduction -- the ones beyond the input hold the empty box -- so that no shuffle reads a lane that has left
+	const unsigned long long active = __ballot(valid);
+	if (active == 0ull) return;   // (the whole wave)
+	const int leader = __ffsll((long long)active) - 1;
+	const int first_mesh = __shfl(mesh, leader);
+	const bool uniform = __ballot(valid && mesh == first_mesh) == active;
+	int * target = (int *)&a.mesh_boxes[valid ? mesh : first_mesh];
+	if (uniform) {
+		#pragma unroll
+		for (int d = 0; d < 3; d++) {
+			float lo = box.min[d], hi = box.max[d];
+			for (int offset = 32; offset > 0; offset >>= 1) { lo = fminf(lo, __shfl_xor(lo, offset)); hi = fmaxf(hi, __shfl_xor(hi, offset)); }
+			if (int(threadIdx.x & 63) == leader) { atomicMin(&target[d], blas_ordered(lo)); atomicMax(&target[3 + d], blas_ordered(hi)); }
+		}
+	} else if (valid) {
+		for (int d = 0; d < 3; d++) { atomicMin(&target[d], blas_ordered(box.min[d])); atomicMax(&target[3 + d], blas_ordered(box.max[d])); }
 	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		TlasBox box; tlas_box_empty(box);
-		for (int w = 0; w < 4; w++) for (int d = 0; d < 3; d++) { box.min[d] = fminf(box.min[d], reduce[w][d]); box.max[d] = fmaxf(box.max[d], reduce[w][3 + d]); }
-		a.mesh_boxes[mesh] = box;
-		a.range[a.first_node + mesh] = make_int2(first, last);   // the root of the mesh covers all of it
-	}
+}
+
+__global__ void __launch_bounds__(256) kernel_blas_mesh_boxes_end(BlasBuildArgs a) {
+	const int mesh = blockIdx.x * blockDim.x + threadIdx.x;
+	if (mesh >= a.mesh_count) return;
+	int * box = (int *)&a.mesh_boxes[mesh];
+	for (int d = 0; d < 6; d++) box[d] = __float_as_int(blas_unordered(box[d]));
+	a.range[a.first_node + mesh] = make_int2(a.mesh_first[mesh], a.mesh_first[mesh + 1]);   // the root of the mesh covers all of it
 }
 
 __global__ void __launch_bounds__(256) kernel_blas_keys(BlasBuildArgs a) {
@@ -326,7 +355,9 @@ hipError_t rt_blas_build(BlasBuildArgs a, void * library_scratch, size_t library
 	const int T = a.triangle_count, M = a.mesh_count;
 	hipError_t e;
 	if ((e = hipMemsetAsync(a.level_state, 0, 3 * sizeof(int), stream)) != hipSuccess) return e;
-	hipLaunchKernelGGL(kernel_blas_triangle_boxes, dim3(M), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(kernel_blas_mesh_boxes_begin, dim3((M + 255) / 256), dim3(256), 0, stream, a);
+	if (T > 0) hipLaunchKernelGGL(kernel_blas_triangle_boxes, dim3((T + 255) / 256), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(kernel_blas_mesh_boxes_end, dim3((M + 255) / 256), dim3(256), 0, stream, a);
 	if (T > 0) {
 		hipLaunchKernelGGL(kernel_blas_keys, dim3((T + 255) / 256), dim3(256), 0, stream, a);
 		int mesh_bits = 1; while ((1ll << mesh_bits) < M) mesh_bits++;
