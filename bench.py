@@ -57,10 +57,31 @@ SPONZA_POVS = [
     ((-92.179306, 74.721153, 12.197323), (0.009840, 0.621556, 0.007809, -0.783262)),
     ((-129.707321, 17.916590, 43.054050), (0.011467, 0.408287, 0.005129, -0.912762)),
 ]
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3-6.6 TB/s is achievable
-# Vector-ALU peak for ordinary (non-packed) instructions: 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz. (The 157.3 TFLOP/s
-# FP32 figure of the data sheet is this x 2 for the fused multiply-add x 2 for v_pk_fma_f32; traversal is neither.)
-VALU_PEAK_LANE_INSTR_PER_S = 256 * 4 * 16 * 2.4e9
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, "Chip-level parameters"); ~6.3-6.6 TB/s is achievable
+# ---- the peaks the traversal launch is priced against (roofline.binding); every one from /opt/skills/guides/MI355X_MICROARCH.md ----------
+CLOCK_HZ = 2.4e9          # max clock
+CUS, SIMDS_PER_CU = 256, 4
+# Vector ALUs: four SIMD-32 per CU, a 64-lane wave-instruction issues over 2 cycles ("Wave scheduling"; "Per-instruction cycle constants": v_fma_f32
+# 2 cyc) = 32 lane-instructions per SIMD and cycle. 256 x 4 x 32 x 2.4e9 = 7.86e13 lane-instructions per second -- the data sheet's 157.3 TFLOP/s FP32
+# counts each fused multiply-add as two. (Rounds 3-4 priced against half of this, 16 lanes per cycle: wrong, the review of round 4 said so.)
+VALU_PEAK_LANE_INSTR_PER_S = CUS * SIMDS_PER_CU * 32 * CLOCK_HZ
+# What the kernel's own instruction mix could reach at best (profiles/r04_instruction_costs.txt, tools/microbench/valu_rates.hip, measured on this chip):
+# fma / mul / add / sub / logic / v_bitop3 / v_mov / right shifts retire a wave in ~2.3 cycles ("fast"), conversions / min / max / compares / selects / left
+# shifts / bit-field instructions in ~4.1 ("slow"), and one of each interleaved take 4.5 cycles per PAIR (they overlap).
+VALU_CYCLES_FAST, VALU_CYCLES_SLOW, VALU_CYCLES_PAIR = 2.3, 4.1, 4.52
+# Static mix of one round of the shipped closest-hit engine (kernel_trace_stream_bvh8_flat, profiles/trace_round_mix.json, tools/isa_loop_mix.py): vector instructions, of which slow
+TRACE_ROUND_VALU, TRACE_ROUND_VALU_SLOW = 381, 159
+try:   # tools/isa_loop_mix.py --json profiles/trace_round_mix.json, re-run whenever the traversal kernel changes
+    _mix = json.load(open(os.path.join(ROOT, "profiles", "trace_round_mix.json")))
+    TRACE_ROUND_VALU, TRACE_ROUND_VALU_SLOW = int(_mix["valu"]), int(_mix["valu_slow"])
+except Exception:
+    pass
+# L1 (vector cache, one per CU): 64 B per clock and CU ("Memory hierarchy": `global_load_dwordx4` moves 64 lanes x 16 B in 16 address cycles) = one 64-byte
+# tag look-up per clock: 256 x 2.4e9 look-ups per second, 39.3 TB/s.   L2: 34.5 TB/s aggregate ("L2 (per XCD)").
+L1_PEAK_LOOKUPS_PER_S = CUS * CLOCK_HZ
+L1_PEAK_GBPS = CUS * 64 * CLOCK_HZ / 1e9
+L2_PEAK_GBPS = 34500.0
+L1_TO_L2_REQUEST_BYTES = 64   # TCP_TCC_READ_REQ counts 64-byte requests (a 128-byte line miss is two)
 
 
 TRACE_KERNEL = ["kernel_trace_stream_bvh8"]   # the dominant kernel's name in the rocprofv3 records: ..._flat when the whole scene is one flattened tree (rt_set_static_geometry)
@@ -150,7 +171,7 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
     passes over this very command (tools/pmc_pass.py). Everything is per traversal launch of the timed region, like `achieved`."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_pass
-    passes = pmc_pass.run_passes(args.steps, args.warmup, groups=pmc_pass.DEFAULT_GROUPS + ["TCC_HIT_sum TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"],
+    passes = pmc_pass.run_passes(args.steps, args.warmup, groups=pmc_pass.DEFAULT_GROUPS + ["TCC_HIT_sum TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_GATE_EN1_sum TA_TA_BUSY_sum"],
                                   extra_args=("--merge-static", str(args.merge_static), "--node-format", args.node_format, "--node-cache", str(args.node_cache)))
     kernels = passes["kernels"]
     out = {"pmc_errors": passes["errors"]} if passes["errors"] else {}
@@ -184,19 +205,61 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
         if c.get("SQ_WAVE_CYCLES"):
             counters["wave_cycles_waiting"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)
             counters["wave_cycles_issuing_valu"] = round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"], 3)
-        if c.get("_duration_ns"):   # VALU issue per SIMD: SQ_ACTIVE_INST_VALU (quad-cycles, MI355X_MICROARCH.md) x 4 / (1024 SIMDs x kernel cycles at 2.4 GHz)
-            counters["valu_busy"] = round(4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024.0 * c["_duration_ns"] * 2.4), 3)
-            counters["valu_busy_definition"] = "4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles of the traversal launches in the counter pass, 2.4 GHz)"
-            counters["waves_resident_per_simd"] = round(4.0 * c.get("SQ_WAVE_CYCLES", 0.0) / (1024.0 * c["_duration_ns"] * 2.4), 2)
+        seconds = c.get("_duration_ns", 0.0) * 1e-9      # the traversal launches of the counter pass (their own kernel-trace durations)
+        if seconds > 0:
+            simd_cycles = CUS * SIMDS_PER_CU * seconds * CLOCK_HZ
+            counters["valu_instructions_per_cycle_and_simd"] = round(c["SQ_INSTS_VALU"] / simd_cycles, 4)    # peak 0.5: one 64-lane instruction per 2 cycles (SIMD-32)
+            counters["cycles_per_valu_instruction_and_simd"] = round(simd_cycles / c["SQ_INSTS_VALU"], 3)
+            counters["waves_resident_per_simd"] = round(4.0 * c.get("SQ_WAVE_CYCLES", 0.0) / simd_cycles, 2)   # SQ_WAVE_CYCLES counts quad-cycles
         counters["valu_thread_instructions_per_ray"] = round(c["SQ_THREAD_CYCLES_VALU"] * scale * launches_timed / args.steps / max(rays_per_step, 1.0), 1)
         out["counters"] = counters
-        if c.get("_duration_ns"):
-            # the roofline that BINDS this kernel: useful (active-lane) vector instructions per second against the chip's issue peak
-            useful = c["SQ_THREAD_CYCLES_VALU"] / (c["_duration_ns"] * 1e-9)
-            out["binding"] = {"bound": "valu", "unit": "lane-instr/s", "peak": VALU_PEAK_LANE_INSTR_PER_S, "achieved": float("%.4g" % useful),
-                              "frac": round(useful / VALU_PEAK_LANE_INSTR_PER_S, 4),
-                              "issue_slots_used": counters.get("valu_busy"), "lane_utilisation": counters["valu_lane_utilisation"],
-                              "note": "achieved = SQ_THREAD_CYCLES_VALU (active lanes summed over all vector instructions) of the traversal launches / their time in the counter pass; frac = issue_slots_used x lane_utilisation up to clock effects. issue_slots_used counts EVERY vector instruction as four cycles (the counter does): ~1.0 means one instruction per 4 cycles and SIMD, not a saturated pipe -- this chip retires fma / mul / add / logic in ~2.2 cycles and conversions / min / max / compares / selects in ~4.1 (profiles/r04_instruction_costs.txt), the round's mix would need ~3.15. Round 4 (DESIGN.md 4.1, profiles/r04_traversal_experiments.txt): the launch does not wait for memory latency (a software-pipelined engine at 5 waves = the shipped one at 7) and is held by two units at once, the vector ALUs and the CU's L1 / address path (TCP busy 88 %, TA 72 %); the idle 42 % of the lanes are the triangle phase of a round running with a fifth of the wave"}
+        if seconds > 0:
+            # ---- roofline.binding: every unit the launch leans on, each against ITS peak from the guide, every fraction <= 1 -----------------
+            lane_util = counters["valu_lane_utilisation"]
+            useful = c["SQ_THREAD_CYCLES_VALU"] / seconds                     # active lanes summed over all vector instructions, per second
+            issue = c["SQ_INSTS_VALU"] / simd_cycles                          # wave-instructions per cycle and SIMD
+            fast, slow = TRACE_ROUND_VALU - TRACE_ROUND_VALU_SLOW, TRACE_ROUND_VALU_SLOW
+            best_overlapped = (min(fast, slow) * VALU_CYCLES_PAIR + (fast - slow) * VALU_CYCLES_FAST if fast >= slow else min(fast, slow) * VALU_CYCLES_PAIR + (slow - fast) * VALU_CYCLES_SLOW) / TRACE_ROUND_VALU
+            best_serial = (fast * VALU_CYCLES_FAST + slow * VALU_CYCLES_SLOW) / TRACE_ROUND_VALU
+            measured_cpi = simd_cycles / c["SQ_INSTS_VALU"]
+            binding = {"bound": "valu", "unit": "lane-instr/s", "peak": VALU_PEAK_LANE_INSTR_PER_S, "achieved": float("%.4g" % useful),
+                       "frac": round(useful / VALU_PEAK_LANE_INSTR_PER_S, 4),
+                       "peak_derivation": "MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 per CU x 32 lanes per cycle (a 64-lane wave-instruction issues over 2 cycles: v_fma_f32 2 cyc) x 2.4 GHz = 7.86e13 lane-instructions/s (= the data sheet's 157.3 TFLOP/s FP32 with a fused multiply-add counted as two)",
+                       "lane_utilisation": lane_util, "issue_frac": round(issue / 0.5, 4),
+                       "issue_frac_definition": "vector wave-instructions per cycle and SIMD (SQ_INSTS_VALU / (1024 SIMDs x launch cycles at 2.4 GHz)) over the peak of one per 2 cycles; frac = issue_frac x lane_utilisation",
+                       "mix_aware": {"round": {"valu": TRACE_ROUND_VALU, "slow_class": TRACE_ROUND_VALU_SLOW, "source": "static mix of one round of the closest-hit engine, profiles/trace_round_mix.json, tools/isa_loop_mix.py"},
+                                     "class_cycles": {"fast": VALU_CYCLES_FAST, "slow": VALU_CYCLES_SLOW, "pair_interleaved": VALU_CYCLES_PAIR, "source": "profiles/r04_instruction_costs.txt (tools/microbench/valu_rates.hip on MI355X)"},
+                                     "best_cycles_per_instruction": {"classes_overlapping": round(best_overlapped, 3), "classes_serial": round(best_serial, 3)}, "measured_cycles_per_instruction": round(measured_cpi, 3),
+                                     "frac_classes_overlapping": round(best_overlapped / measured_cpi * lane_util, 4), "frac_classes_serial": round(best_serial / measured_cpi * lane_util, 4),
+                                     "note": "what the round's OWN instruction mix could reach: half of its vector instructions are conversions / min / max / compares / selects (4.1 cycles per wave), the other half multiply-adds and logic (2.3), one of each interleaved takes 4.5 per pair. frac_* = (best cycles per instruction / measured) x lane utilisation"}}
+            if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+                lookups = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / seconds
+                l1 = {"bound": "l1 (vector cache: tag look-ups)", "unit": "64-byte look-ups/s", "peak": L1_PEAK_LOOKUPS_PER_S, "achieved": float("%.4g" % lookups), "frac": round(lookups / L1_PEAK_LOOKUPS_PER_S, 4),
+                      "peak_derivation": "MI355X_MICROARCH.md: a global_load_dwordx4 of a wave (64 lanes x 16 B) takes 16 address cycles = 64 B per clock and CU, one look-up per clock: 256 CUs x 2.4 GHz (39.3 TB/s)",
+                      "lookups_per_vector_memory_instruction": round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / max(c.get("SQ_INSTS_VMEM_RD", 0.0) + c.get("SQ_INSTS_VMEM_WR", 0.0), 1.0), 2) if c.get("SQ_INSTS_VMEM_RD") else None}
+                if c.get("TCP_GATE_EN1_sum"):
+                    l1["busy"] = round(c["TCP_GATE_EN1_sum"] / (CUS * seconds * CLOCK_HZ), 4); l1["busy_definition"] = "TCP_GATE_EN1 (cycles the L1 is clocked for work, summed over the 256 CUs) / (256 x launch cycles at 2.4 GHz)"
+                if c.get("TA_TA_BUSY_sum"):
+                    l1["address_unit_busy"] = round(c["TA_TA_BUSY_sum"] / (CUS * seconds * CLOCK_HZ), 4)
+                binding["l1"] = l1
+                if c.get("TCP_TCC_READ_REQ_sum"):
+                    l2_gbps = c["TCP_TCC_READ_REQ_sum"] * L1_TO_L2_REQUEST_BYTES / seconds / 1e9
+                    binding["l2"] = {"bound": "l2 (read bandwidth)", "unit": "GB/s", "peak": L2_PEAK_GBPS, "achieved": round(l2_gbps, 1), "frac": round(l2_gbps / L2_PEAK_GBPS, 4),
+                                     "peak_derivation": "MI355X_MICROARCH.md 'L2 (per XCD)': ~34.5 TB/s aggregate; achieved = TCP_TCC_READ_REQ x 64 B / launch time"}
+            if out.get("traffic") and len(launch_ms):
+                hbm_gbps = out["traffic"] / (float(np.mean(launch_ms)) * 1e-3) / 1e9
+                binding["hbm"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": round(hbm_gbps, 1), "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4),
+                                  "note": "memory-side bytes of the launch (roofline.traffic: FETCH_SIZE + WRITE_SIZE, calibrated) / its HIP-event duration: what HBM + Infinity Cache actually move"}
+            fracs = {"valu (lane-instructions)": binding["frac"], "valu issue (wave-instructions)": binding["issue_frac"], "valu, mix-aware": binding["mix_aware"]["frac_classes_serial"]}
+            for key in ("l1", "l2", "hbm"):
+                if key in binding:
+                    fracs[key] = binding[key].get("busy", binding[key]["frac"]) if key == "l1" else binding[key]["frac"]
+            binding["utilisation_by_unit"] = fracs
+            binding["closest_to_its_roof"] = max(fracs, key=fracs.get)
+            binding["note"] = ("The launch is branchy pointer chasing: no unit is saturated, the two closest to their roofs are the CU's L1 (tag look-ups of divergent 16-byte loads: 5 per node step and lane, 3 per triangle) and vector issue. "
+                               "valu frac = useful lane-instructions against the guide's peak; it is low because (a) the triangle phase of a round runs with a fifth of the wave's lanes (lane_utilisation), (b) half the instructions are of the 4-cycle class (mix_aware), "
+                               "(c) waves wait for the L1 (counters.wave_cycles_waiting). DESIGN.md 4.1 has the experiments behind this reading")
+            out["binding"] = binding
     if "TCC_HIT_sum" in trace and "TCC_MISS_sum" in trace and (trace["TCC_HIT_sum"][1] + trace["TCC_MISS_sum"][1]) > 0:
         out.setdefault("binding", {})["l2_hit_rate"] = round(trace["TCC_HIT_sum"][1] / (trace["TCC_HIT_sum"][1] + trace["TCC_MISS_sum"][1]), 4)
     if "TCP_TOTAL_CACHE_ACCESSES_sum" in trace and trace["TCP_TOTAL_CACHE_ACCESSES_sum"][1] > 0 and "TCP_TCC_READ_REQ_sum" in trace:
@@ -260,7 +323,7 @@ def stage_rooflines(grt, ctx, counters_per_sample, plan, steps, stream_gbps, tex
             continue
         gbps = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         stages.append({"stage": name, "launches": launches, "ms_per_step": round(ms / steps, 4), "algorithmic_bytes_per_step": round(nbytes / steps),
-                       "achieved": round(gbps, 1), "unit": "GB/s", "frac": round(gbps / stream_gbps, 4)})
+                       "achieved": round(gbps, 1), "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "ratio_to_measured_stream": round(gbps / stream_gbps, 4)})
     return stages
 
 
@@ -655,10 +718,13 @@ def main():
             per_launch_gbps = launch_bytes / np.maximum(launch_ms, 1e-6) / 1e6
             roofline.update({
                 "kernel": TRACE_KERNEL[0], "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "frac_is": "SURVEY 8d's figure: ALGORITHMIC bytes / launch time / HBM peak. The bytes are served by the caches (binding.l1_hit_rate, l2_hit_rate), so this is a yardstick that can exceed 1, NOT a utilisation; the utilisations (all <= 1) are hbm_frac (counter bytes over the same peak), l1_frac_of_algorithmic_bytes and roofline.binding",
+                "l1_frac_of_algorithmic_bytes": round(achieved / L1_PEAK_GBPS, 4),
                 "launches": int(len(launch_ms)), "algorithmic_bytes_per_launch": round(float(launch_bytes.mean())), "avg_launch_ms": round(float(launch_ms.mean()), 4),
                 "launch_ms": spread(launch_ms), "launch_gbps": spread(per_launch_gbps),
                 "steady_state": {"launches": int(big.sum()), "achieved": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9), 1),
-                                 "frac": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9 / HBM_PEAK_GBPS), 4),
+                                 "ratio_to_hbm_peak_cache_served": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9 / HBM_PEAK_GBPS), 4),
+                                 "l1_frac_of_algorithmic_bytes": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9 / L1_PEAK_GBPS), 4),
                                  "launch_gbps": spread(per_launch_gbps[big]), "rays_per_launch": int(launch_rays[big].mean())},
                 "closest_hit_share_of_bytes": round(float(launch_closest_bytes.sum() / launch_bytes.sum()), 3),
                 "time_share_of_step": round(float(launch_ms.sum() / (elapsed * 1e3)), 3),
@@ -686,7 +752,7 @@ def main():
         })
         stream_gbps = roofline["measured_stream_read_gbps"]
         if roofline.get("achieved"):   # the denominator SURVEY 8d names: what a streaming read reaches on THIS GPU
-            roofline["frac_of_measured_stream"] = round(roofline["achieved"] / stream_gbps, 4)
+            roofline["ratio_to_measured_stream_cache_served"] = round(roofline["achieved"] / stream_gbps, 4)
         if stages_raw:
             trace_ms = float(grt.launch_timings(ctx, "trace").sum())
             stages = stage_rooflines(grt, ctx, counters_per_sample, plan, args.steps, stream_gbps)
@@ -694,9 +760,10 @@ def main():
                 stages.insert(1, {"stage": "traversal", "launches": int(len(launch_bytes)), "ms_per_step": round(trace_ms / args.steps, 4),
                                   "algorithmic_bytes_per_step": round(float(launch_bytes.sum()) / args.steps),
                                   "achieved": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
-                                  "frac": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9 / stream_gbps, 4)})
+                                  "ratio_to_hbm_peak_cache_served": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                  "l1_frac_of_algorithmic_bytes": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9 / L1_PEAK_GBPS, 4)})
             roofline["stages"] = stages
-            roofline["stages_note"] = "a repeat of the timed plan with HIP events around every launch (rt_set_profiling 3); frac = algorithmic bytes (SURVEY 8d formulas, bench.py stage_rooflines) / stage time / measured stream-read bandwidth; the sort kernel is a gather chain, the material kernels and the traversal are bound by instruction issue (traversal: together with the L1 / address path, see binding): for those the fraction is a yardstick, not the limit"
+            roofline["stages_note"] = "a repeat of the timed plan with HIP events around every launch (rt_set_profiling 3); frac = algorithmic bytes (SURVEY 8d formulas, bench.py stage_rooflines) / stage time / the 8 TB/s HBM peak, ratio_to_measured_stream = the same over what a 1 GiB streaming read reaches on this GPU (a read-only probe: a read + write stage such as accumulate can pass it); the traversal's bytes are cache-served, its entry carries a labelled ratio and the L1 fraction instead of frac; the sort kernel is a gather chain, the material kernels are bound by instruction issue: their fraction is a yardstick, not the limit"
             grt.set_profiling(ctx, False)
         result = {
             "metric": "Mrays/s (primary+secondary) + ms/frame, Sponza 1920x1080 4spp BVH8", "value": round(value, 1), "unit": "Mrays/s",
@@ -767,14 +834,16 @@ def main():
                 k = pmc_kernels.get(name) or pmc_kernels.get(name + "_texels")   # (material kernels: the instantiation without the per-fetch BC1 decode, rt_set_texture_expansion)
                 if k and k.get("SQ_INSTS_VALU", [0, 0])[1] > 0 and k.get("_duration_ns"):
                     stage["lane_utilisation"] = round(k["SQ_THREAD_CYCLES_VALU"][1] / (64.0 * k["SQ_INSTS_VALU"][1]), 3)
-                    stage["valu_busy"] = round(4.0 * k.get("SQ_ACTIVE_INST_VALU", [0, 0.0])[1] / (1024.0 * k["_duration_ns"][1] * 2.4), 3)
+                    stage["valu_issue_frac"] = round(k["SQ_INSTS_VALU"][1] / (1024.0 * k["_duration_ns"][1] * 2.4) / 0.5, 3)   # wave-instructions per cycle and SIMD over the peak of one per 2 cycles
                     stage["waves_per_simd"] = round(4.0 * k.get("SQ_WAVE_CYCLES", [0, 0.0])[1] / (1024.0 * k["_duration_ns"][1] * 2.4), 2)
             if r.get("traffic") and r.get("algorithmic_bytes_per_launch"):
                 # how much of what the traversal reads is served by the caches (L1 + L2 + Infinity Cache together): the
                 # algorithmic bytes are a lower bound of its requests, the memory-side traffic is what got past the caches
                 r["cache_hit_fraction_lower_bound"] = round(1.0 - r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
-                r["bound_in_practice"] = ("vector-ALU issue together with the CU's L1 / address path (neither alone: DESIGN.md 4.1, round 4): %.2f vector instructions per 4 cycles and SIMD at a lane utilisation of %.2f; the memory side moves %.0f %% of the algorithmic bytes, which is why frac can exceed 1 (see roofline.binding)"
-                                          % (r.get("counters", {}).get("valu_busy", float("nan")), r.get("counters", {}).get("valu_lane_utilisation", float("nan")), 100.0 * r["traffic"] / r["algorithmic_bytes_per_launch"]))
+                r["hbm_frac"] = round(r["traffic"] / (float(np.mean(launch_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if len(launch_ms) else None
+                bind = r.get("binding", {})
+                r["bound_in_practice"] = ("no unit saturated; closest to its roof: %s. Utilisations (each against its peak from MI355X_MICROARCH.md, roofline.binding): %s. The memory side moves %.0f %% of the algorithmic bytes (hbm_frac %.2f), which is why the SURVEY 8d figure `frac` can exceed 1"
+                                          % (bind.get("closest_to_its_roof"), json.dumps(bind.get("utilisation_by_unit")), 100.0 * r["traffic"] / r["algorithmic_bytes_per_launch"], r["hbm_frac"] or float("nan")))
         print(json.dumps(result))
 
     if not closed:

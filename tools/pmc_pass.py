@@ -19,7 +19,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT_GROUPS = ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE"]
+# (8 SQ slots + 1 GRBM per pass: MI355X_MICROARCH.md "rocprofv3 PMC slots")
+DEFAULT_GROUPS = ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"]
 
 
 def summarise(db_path):
