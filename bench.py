@@ -85,7 +85,6 @@ L1_TO_L2_REQUEST_BYTES = 64   # TCP_TCC_READ_REQ counts 64-byte requests (a 128-
 
 
 TRACE_KERNEL = ["kernel_trace_stream_bvh8"]   # the dominant kernel's name in the rocprofv3 records: ..._flat when the whole scene is one flattened tree (rt_set_static_geometry)
-NODE_CACHE = 0     # --node-cache: 0 walks every node of the flattened tree from global memory (config node_cache)
 EXPAND_TEXTURES = 1   # --expand-textures: 0 keeps BC1 blocks compressed on the device, decoded per texel fetch (config expand_block_compressed_textures)
 MERGE_STATIC = 1   # --merge-static: 0 stages the scene exactly as the reference does (one BLAS per mesh under the TLAS)
 
@@ -93,7 +92,7 @@ MERGE_STATIC = 1   # --merge-static: 0 stages the scene exactly as the reference
 def build_scene(grt):
     """BASELINE config #2: Sponza, every odd diffuse material -> roughplastic alpha 0.3."""
     grt.config_reset()
-    grt.config_set(merge_static=MERGE_STATIC, node_cache=NODE_CACHE, expand_block_compressed_textures=EXPAND_TEXTURES)
+    grt.config_set(merge_static=MERGE_STATIC, expand_block_compressed_textures=EXPAND_TEXTURES)
     # the reference's own 19 diffuse maps when build() could install them (assets/_cache, see install_reference_sponza_textures),
     # else the quarter-size maps that travel inside the repository, every texel replicated 4x4
     scene = grt.Scene(grt.scene_path("sponza_reference_maps" if grt.reference_sponza_textures_installed() else "sponza"))
@@ -172,7 +171,7 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_pass
     passes = pmc_pass.run_passes(args.steps, args.warmup, groups=pmc_pass.DEFAULT_GROUPS + ["TCC_HIT_sum TCC_MISS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_GATE_EN1_sum TA_TA_BUSY_sum"],
-                                  extra_args=("--merge-static", str(args.merge_static), "--node-format", args.node_format, "--node-cache", str(args.node_cache)))
+                                  extra_args=("--merge-static", str(args.merge_static)))
     kernels = passes["kernels"]
     out = {"pmc_errors": passes["errors"]} if passes["errors"] else {}
     trace = kernels.get(TRACE_KERNEL[0])
@@ -382,7 +381,7 @@ def config3_section(grt, scene, device, stream_gbps, frames=64):
         grt.config_set(enable_svgf=0, enable_taa=0)
 
 
-def reference_layout_section(grt, device, steps, warmup, node_format):
+def reference_layout_section(grt, device, steps, warmup):
     """The same frame loop on the REFERENCE'S acceleration-structure layout (config merge_static 0: one CWBVH per mesh under a
     CWBVH TLAS, 384 instance entries), in the same process on the same GPU, so that the line the driver records carries both
     layouts: the headline is measured on the flattened tree, a layout the reference does not have."""
@@ -396,7 +395,6 @@ def reference_layout_section(grt, device, steps, warmup, node_format):
         try:
             pt.update()
             lib, ctx = grt.device_lib(), pt.ctx
-            grt.set_node_format(ctx, node_format)
             lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
             lib.rt_synchronize.argtypes = [ctypes.c_void_p]
             def submit(samples):
@@ -437,16 +435,13 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: render only rank 0's tiles of an N-GPU split on one GPU (no collective), to exercise the N > 1 code path")
     ap.add_argument("--merge-static", type=int, default=1, help="1 (default): the 382 instances of Sponza that stand still with the identity transform are flattened into one bottom-level tree (config merge_static); 0: one BLAS per mesh under the TLAS, the reference's layout")
     ap.add_argument("--expand-textures", type=int, default=1, help="1 (default): BC1 textures are decoded once, at upload, into 64-byte blocks of texels (rt_set_texture_expansion); 0: the 8-byte blocks stay compressed and every texel fetch decodes one")
-    ap.add_argument("--node-cache", type=int, default=0, help="1: the traversal launch of the flattened scene keeps the top three levels of the tree in LDS (rt_set_node_cache; measured 1.3 %% slower); 0 (default): every node from global memory")
     ap.add_argument("--exchange", choices=["native", "torch"], default="native", help="N > 1: who runs the per-frame all-gather. native (default): the library's own frame exchange, ncclAllGather on the context's stream through rt_comm_init_rank / rt_all_gather_framebuffer (torch.distributed only carries the 128-byte communicator id and the timing reductions); torch: dist.all_gather_into_tensor on torch's stream around rt_pack_pixels / rt_unpack_pixels. Falls back to torch when the library cannot set up its communicator")
-    ap.add_argument("--node-format", choices=["decoded", "reference"], default="reference", help="reference (default): the traversal launches read the uploaded 80-byte CWBVH nodes; decoded: the library's 96-byte decoded copy (rt_set_node_format; measured slower, profiles/r04_node_formats.txt)")
     ap.add_argument("--batch", type=int, default=SPP, help="samples per pixel per submission (rt_render_samples), 1..%d" % SPP)
     ap.add_argument("--samples-in-flight", type=int, default=0, help="samples per pixel rendered concurrently (rt_set_samples_in_flight)")
     args = ap.parse_args()
-    global MERGE_STATIC, NODE_CACHE, EXPAND_TEXTURES
+    global MERGE_STATIC, EXPAND_TEXTURES
     EXPAND_TEXTURES = args.expand_textures
     MERGE_STATIC = args.merge_static
-    NODE_CACHE = args.node_cache
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
@@ -486,15 +481,10 @@ def main():
     pt.update()
     if pt.static_geometry_whole_scene:
         TRACE_KERNEL[0] = "kernel_trace_stream_bvh8_flat"   # the engine variant without TLAS / instance code
-    if args.node_format == "decoded":
-        TRACE_KERNEL[0] += "_decoded"
-    elif pt.static_geometry_whole_scene and args.node_cache and pt.static_geometry_node_cache[1] > 0:
-        TRACE_KERNEL[0] += "_cached"
     flatten_build_s = pt.static_geometry_build_seconds if pt.static_geometry_members else 0.0
     closed = False
     lib = grt.device_lib()
     ctx = pt.ctx
-    grt.set_node_format(ctx, args.node_format)
     scheduler = os.environ.get("BENCH_SCHEDULER", "merged")     # "slots": the per-submission launch chains, for comparison
     grt.set_scheduler(ctx, scheduler)
     split_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
@@ -775,8 +765,6 @@ def main():
                 "scheduler": scheduler,
                 "acceleration_structure": (("%d of %d instances (all that stand still) flattened into one CWBVH of %d triangle copies" + (", no TLAS: rays start inside the tree (rt_set_static_geometry)" if pt.static_geometry_whole_scene else ", one TLAS leaf beside the other instances") + ", hits reported as the scene's own instances and triangles (rt_upload_triangle_aliases); tree built on the host in %.2f s (SAH object + spatial splits, all threads; at scene load, not in the timed region); --merge-static 0 runs the reference's layout")
                                            % (pt.static_geometry_members, scene.mesh_count, int((pt.array("alias_mesh_ids") >= 0).sum()), pt.static_geometry_build_seconds)) if pt.static_geometry_members else "one CWBVH per mesh under a CWBVH TLAS (the reference's layout)",
-                "node_cache": ("the top three levels of the flattened tree (%d nodes of 80 bytes, breadth-first from the root) live in LDS for the traversal launch (rt_set_node_cache)" % pt.static_geometry_node_cache[1]) if (pt.static_geometry_whole_scene and args.node_cache) else "off",
-                "node_format": ("decoded: the traversal launches read the library's 96-byte decoded copy of the 80-byte CWBVH nodes (same floats, exponent / meta bytes pre-expanded; rt_set_node_format)" if args.node_format == "decoded" else "reference: the uploaded 80-byte CWBVH nodes"),
                 "rays_per_step": round(rays_plan / args.steps), "shadow_rays_per_step": round(shadow_plan / args.steps),
                 "mrays_s_including_shadow": round((rays_plan + shadow_plan) / elapsed / 1e6, 1),
                 "ms_per_4spp_frame": round(elapsed / args.steps * SPP * 1e3, 3),
@@ -819,7 +807,7 @@ def main():
             if pt is not None:
                 pt.close(); pt = None
             result["flatten_build_s"] = round(float(flatten_build_s), 3)
-            result["reference_layout"] = reference_layout_section(grt, local_rank, args.steps, args.warmup, args.node_format)
+            result["reference_layout"] = reference_layout_section(grt, local_rank, args.steps, args.warmup)
         if world == 1 and split_world == 1 and merged and not args.no_pmc and not os.environ.get("BENCH_PMC_CHILD"):
             # hardware counters of the same command (separate rocprofv3 --pmc passes); this process lets go of the GPU first
             if pt is not None:

@@ -73,8 +73,8 @@ def device_lib():
         # first) keeps HIP's default of 4 queues and the context says so when it matters.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
         lib = ctypes.CDLL(DEVICE_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-        if hasattr(lib, "rt_abi_version") and lib.rt_abi_version() != 6:
-            raise DeviceLibraryMissing("%s has ABI version %d, this front end was written for 6 -- rebuild (python __graft_entry__.py)" % (DEVICE_LIB_PATH, lib.rt_abi_version()))
+        if hasattr(lib, "rt_abi_version") and lib.rt_abi_version() != 7:
+            raise DeviceLibraryMissing("%s has ABI version %d, this front end was written for 7 -- rebuild (python __graft_entry__.py)" % (DEVICE_LIB_PATH, lib.rt_abi_version()))
         lib.rt_last_error.restype = c_char_p
         lib.rt_last_error.argtypes = [c_void_p]
         lib.rt_version.restype = c_char_p
@@ -540,9 +540,9 @@ class Pathtracer:
         return bool(host_lib().grt_pathtracer_static_geometry_whole_scene(self.handle))
 
     @property
-    def static_geometry_node_cache(self):
-        """(root node of the flattened tree, nodes from it that make up its top three levels): the breadth-first range the traversal
-        launch may keep in LDS (rt_set_node_cache)."""
+    def static_geometry_top_levels(self):
+        """(root node of the flattened tree, nodes from it that make up its top three levels): the tree is numbered breadth-first, what
+        every ray walks comes first."""
         return int(host_lib().grt_pathtracer_static_geometry_root(self.handle)), int(host_lib().grt_pathtracer_static_geometry_top_nodes(self.handle))
 
     def set_flatten_asynchronously(self, enable):
@@ -836,7 +836,6 @@ def set_scheduler(ctx, scheduler):
     _dev_check(ctx, lib.rt_set_scheduler(ctx, int(scheduler)))
 
 
-NODES_REFERENCE, NODES_DECODED = 0, 1
 
 
 def set_svgf_tiles(ctx, enable):
@@ -845,16 +844,6 @@ def set_svgf_tiles(ctx, enable):
     lib = device_lib()
     lib.rt_set_svgf_tiles.argtypes = [c_void_p, c_int]
     _dev_check(ctx, lib.rt_set_svgf_tiles(ctx, 1 if enable else 0))
-
-
-def set_node_format(ctx, node_format):
-    """'decoded' (default): the merged wavefront walks the library's 96-byte decoded copy of the CWBVH nodes;
-    'reference': the uploaded 80-byte nodes (rt_set_node_format). Hits are identical."""
-    if isinstance(node_format, str):
-        node_format = {"reference": NODES_REFERENCE, "decoded": NODES_DECODED}[node_format]
-    lib = device_lib()
-    lib.rt_set_node_format.argtypes = [c_void_p, c_int]
-    _dev_check(ctx, lib.rt_set_node_format(ctx, int(node_format)))
 
 
 def set_frame_pipelining(ctx, enable):

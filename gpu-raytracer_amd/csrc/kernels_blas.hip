@@ -25,6 +25,7 @@
 // than the SAH tree (measured: profiles/r03_device_blas.txt): the host classes use it on request (device_blas = 1).
 #include "rt_math.h"
 #include "rt_tlas_build.h"
+#include <algorithm>
 
 #include <cstring>   // (rocPRIM's texture iterator calls memset from host code without including it)
 #include <rocprim/rocprim.hpp>
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(256) kernel_blas_runs(BlasBuildArgs a, int lev
 	for (int round = 0; round < 7 && count > 0; round++) {
 		int widest = -1, widest_lo = 0, widest_hi = 0; float heaviest = -1.0f;
 		#pragma unroll
-		for (int c = 0; c < 8; c++) if (c < count && begin[c + 1] - begin[c] > RT_BLAS_LEAF && weight[c] > heaviest) { heaviest = weight[c]; widest = c; widest_lo = begin[c]; widest_hi = begin[c + 1]; }
+		for (int c = 0; c < 8; c++) if (c < count && begin[c + 1] - begin[c] > RT_BLAS_LEAF && !(weight[c] <= heaviest)) {   /* (written so that a piece whose area is NaN -- non-finite vertices -- is still cut: `>` would skip it for ever) */ heaviest = weight[c]; widest = c; widest_lo = begin[c]; widest_hi = begin[c + 1]; }
 		if (widest < 0) break;
 		const int cut = blas_split(a.sorted_keys, widest_lo, widest_hi);
 		float left = float(cut - widest_lo), right = float(widest_hi - cut);
@@ -351,7 +352,7 @@ size_t rt_blas_build_scratch_bytes(size_t triangles, size_t meshes) {
 	return sort_bytes + scan_bytes + 512;
 }
 
-hipError_t rt_blas_build(BlasBuildArgs a, void * library_scratch, size_t library_scratch_bytes, int * pinned_state, hipStream_t stream, int * out_node_count) {
+hipError_t rt_blas_build(BlasBuildArgs a, void * library_scratch, size_t library_scratch_bytes, int * pinned_state, hipStream_t stream, int * out_node_count, size_t node_capacity) {
 	const int T = a.triangle_count, M = a.mesh_count;
 	hipError_t e;
 	if ((e = hipMemsetAsync(a.level_state, 0, 3 * sizeof(int), stream)) != hipSuccess) return e;
@@ -367,7 +368,12 @@ hipError_t rt_blas_build(BlasBuildArgs a, void * library_scratch, size_t library
 		if (!a.split_widest) for (int level = 1; level <= a.table_levels; level++) hipLaunchKernelGGL(kernel_blas_box_table, dim3((T + 255) / 256), dim3(256), 0, stream, a, level);
 	}
 	int level_first = a.first_node, level_nodes = M, nodes_used = a.first_node + M, triangles_placed = 0;
+	int levels = 0;
 	while (level_nodes > 0) {
+		// A level writes its own nodes and the ranges of up to 8 children per node behind them; a build that would leave the arrays, or
+		// that goes on for more levels than 30 Morton bits + the halving of equal keys can give, is given up (bad input) instead of followed.
+		// (an inner child holds more than RT_BLAS_LEAF triangles and the children of a level are disjoint: at most T / 4 of them)
+		if (size_t(nodes_used) + std::min(size_t(level_nodes) * 8, size_t(T) / (RT_BLAS_LEAF + 1) + 1) > node_capacity || ++levels > 192) return hipErrorInvalidValue;
 		hipLaunchKernelGGL(kernel_blas_runs, dim3((level_nodes + 255) / 256), dim3(256), 0, stream, a, level_first, level_nodes);
 		size_t bytes = library_scratch_bytes;
 		if ((e = rocprim::exclusive_scan(library_scratch, bytes, a.inner_count, a.inner_base, 0, size_t(level_nodes), rocprim::plus<int>(), stream)) != hipSuccess) return e;

@@ -50,20 +50,10 @@
 #ifndef RT_FETCH_BLOCK_MAX
 #define RT_FETCH_BLOCK_MAX 128   // rays claimed per cursor atomic; measured 64..1024, see profiles/r01_trace_fetch_block.txt
 #endif
-#ifndef RT_TRI_HOLD
-#define RT_TRI_HOLD 0        // see the triangle phase; 0 = every round (tools/wave_sim: 8 / 16 save ~1.5 % of the issue slots, measured: see profiles/r03_traversal_variants.txt)
-#endif
-#ifndef RT_SHADOW_FAR_FIRST
-// 1: shadow rays take a node's children far end first (an any-hit answer does not depend on the order). Priced on the benchmark's
-// own 8.8 M shadow rays of four samples (Sponza, two thirds of them occluded; profiles/r04_shadow_rays.txt): an occluded ray finds
-// its occluder after 11.8 node steps instead of 13.2, all shadow rays 12.9 instead of 13.8 (-6.8 %) -- the near end of a shadow ray
-// is the surface it starts on, whose neighbourhood fills the nearest boxes without ever occluding. Measured on MI355X, same box:
-// traversal 1.036 ms per step against 1.038 -- nothing: the shadow phase's waves lose as much to divergence as the rays save in
-// steps. Off, so that the shadow walk stays the reference's (and the oracle's node / triangle counters stay equal to the device's).
-// (A per-pixel "last occluder tested first" was priced on the same rays: the cached triangle occludes 3 % of the next rays of its
-// pixel -- Sponza's occluders are small and the light sample moves -- i.e. it costs more triangle tests than it saves.)
-#define RT_SHADOW_FAR_FIRST 0
-#endif
+// Measured and not kept (profiles/r03_variants_at_20_steps.txt, profiles/r04_shadow_rays.txt, profiles/r04_traversal_experiments.txt; the code is gone, the
+// numbers are there): holding the triangle phase back until 8 / 16 lanes want it (+-0), shadow rays taking a node's children far end first (-6.8 % node
+// steps, 0 % time), 96-byte decoded nodes (+5 %), the top of the tree in LDS (+1.3 %), the next node's loads issued behind the triangle tests (+-0 at
+// one wave per SIMD less), v_pk_fma_f32 slab tests (+3 %), per-XCD ray cursors (-8 % rays/s).
 #ifndef RT_N_D
 #define RT_N_D 4            // dynamic fetch: tolerated idle lanes per iteration (N_d = 4 of 32 in the reference)
 #define RT_N_W 16           // dynamic fetch: lost lane-iterations before refilling  (N_w = 16 of 32); swept 0/1 .. 24/64, profiles/r01_trace_fetch_block.txt
@@ -117,11 +107,7 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 		unsigned meta4 = __float_as_uint(i == 0 ? n1.z : n1.w);
 
 		unsigned is_inner4   = (meta4 & (meta4 << 1)) & 0x10101010u;
-#ifdef RT_REF_CHEAP_META
-		unsigned inner_mask4 = ((is_inner4 >> 4) << 3) - (is_inner4 >> 4);   // 0x07 per inner child: a shift and a subtraction instead of the quarter-rate multiply
-#else
 		unsigned inner_mask4 = sign_extend_s8x4(is_inner4 << 3);
-#endif
 		unsigned bit_index4  = (meta4 ^ (oct_inv4 & inner_mask4)) & 0x1f1f1f1fu;
 		unsigned child_bits4 = (meta4 >> 5) & 0x07070707u;
 
@@ -135,20 +121,12 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 
 		#pragma unroll
 		for (int j = 0; j < 4; j++) {
-#ifdef RT_REF_PK
-			typedef float pk2 __attribute__((ext_vector_type(2)));
-			pk2 tx = __builtin_elementwise_fma(pk2{ float(extract_byte(x_min, j)), float(extract_byte(x_max, j)) }, pk2{ adjusted_dir_inv.x, adjusted_dir_inv.x }, pk2{ adjusted_origin.x, adjusted_origin.x });
-			pk2 ty = __builtin_elementwise_fma(pk2{ float(extract_byte(y_min, j)), float(extract_byte(y_max, j)) }, pk2{ adjusted_dir_inv.y, adjusted_dir_inv.y }, pk2{ adjusted_origin.y, adjusted_origin.y });
-			pk2 tz = __builtin_elementwise_fma(pk2{ float(extract_byte(z_min, j)), float(extract_byte(z_max, j)) }, pk2{ adjusted_dir_inv.z, adjusted_dir_inv.z }, pk2{ adjusted_origin.z, adjusted_origin.z });
-			float tx0 = tx.x, tx1 = tx.y, ty0 = ty.x, ty1 = ty.y, tz0 = tz.x, tz1 = tz.y;
-#else
 			float tx0 = __builtin_fmaf(float(extract_byte(x_min, j)), adjusted_dir_inv.x, adjusted_origin.x);
 			float ty0 = __builtin_fmaf(float(extract_byte(y_min, j)), adjusted_dir_inv.y, adjusted_origin.y);
 			float tz0 = __builtin_fmaf(float(extract_byte(z_min, j)), adjusted_dir_inv.z, adjusted_origin.z);
 			float tx1 = __builtin_fmaf(float(extract_byte(x_max, j)), adjusted_dir_inv.x, adjusted_origin.x);
 			float ty1 = __builtin_fmaf(float(extract_byte(y_max, j)), adjusted_dir_inv.y, adjusted_origin.y);
 			float tz1 = __builtin_fmaf(float(extract_byte(z_max, j)), adjusted_dir_inv.z, adjusted_origin.z);
-#endif
 
 			float tmin = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, 0.0f));
 			float tmax = fminf(fminf(tx1, ty1), fminf(tz1, max_distance));
@@ -177,14 +155,17 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 //     v_bfe + v_lshrrev + v_lshlrev;
 //   * the hit test: v_cmpx_lt_f32 narrows the execution mask to the lanes that hit, ONE v_or_b32 adds the contribution, a scalar
 //     move restores the mask -- instead of v_cmp + v_cndmask + half a v_or3.
-// Measured (profiles/r04_traversal_experiments.txt, items 3 and 7): under the pipelined schedule, at 6 waves per SIMD, -0.8 % -- left off; with every launch
-// carrying ONE bounce of a burst (rt_set_stream_batch) -1.4 % of the traversal time against the shipped 7-wave kernel, on one box, twice: on (2), with the
-// flattened scene's launch at 6 waves (80 registers, no scratch; at 7 the rewritten test spills 20 bytes). 1: the same without the v_cmpx form. 0: the plain test.
+// Measured (profiles/r04_traversal_experiments.txt, items 3 and 7): with every launch carrying ONE bounce of a burst (rt_set_stream_batch) -1.4 % of the
+// traversal time against the plain test at 7 waves, on one box, twice; the flattened scene's launch runs it at 6 waves (80 registers, no scratch).
+// 1: on (gfx950 only: v_bitop3_b32, SDWA and v_cmpx are this chip's; any other target compiles the plain test). 0: the plain test everywhere.
 #ifndef RT_FAST_NODE
-#define RT_FAST_NODE 2
+#define RT_FAST_NODE 1
 #endif
 RT_DEV unsigned bvh8_node_intersect_fast(const Ray3 & ray, f3 inv_dir, unsigned oct_inv4, float max_distance,
                                          float4 n0, float4 n1, float4 n2, float4 n3, float4 n4) {
+#if !defined(__gfx950__)
+	return bvh8_node_intersect(ray, inv_dir, oct_inv4, max_distance, n0, n1, n2, n3, n4);   // (host pass and any other target)
+#else
 	f3 p = mk3(n0.x, n0.y, n0.z);
 	unsigned e_imask = __float_as_uint(n0.w);
 	f3 adjusted_dir_inv = mk3(
@@ -197,9 +178,12 @@ RT_DEV unsigned bvh8_node_intersect_fast(const Ray3 & ray, f3 inv_dir, unsigned 
 	// for a component that is not negative). Opaque to the optimiser, which would turn the selects below back into v_cndmask.
 	unsigned neg_x = ((oct_inv4 >> 2) & 1u) - 1u, neg_y = ((oct_inv4 >> 1) & 1u) - 1u, neg_z = (oct_inv4 & 1u) - 1u;
 	asm("" : "+v"(neg_x)); asm("" : "+v"(neg_y)); asm("" : "+v"(neg_z));
-	const unsigned long long all_lanes = __builtin_amdgcn_read_exec();
 
 	unsigned hit_mask = 0;
+	// The lanes that run this test, read by an instruction of its own directly in front of the eight places that narrow and restore the mask
+	// (volatile asm statements keep their order; the code between here and the last restore is straight-line: the loops are unrolled).
+	unsigned long long all_lanes;
+	asm volatile("s_mov_b64 %0, exec" : "=s"(all_lanes));
 	#pragma unroll
 	for (int i = 0; i < 2; i++) {
 		unsigned meta4 = __float_as_uint(i == 0 ? n1.z : n1.w);
@@ -235,85 +219,12 @@ RT_DEV unsigned bvh8_node_intersect_fast(const Ray3 & ray, f3 inv_dir, unsigned 
 			if (j == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(contribution) : "v"(bit_index4), "v"(child_bits4));
 			if (j == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(contribution) : "v"(bit_index4), "v"(child_bits4));
 			if (j == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(contribution) : "v"(bit_index4), "v"(child_bits4));
-#if RT_FAST_NODE >= 2
 			// (tmin < tmax) ? hit_mask |= contribution : nothing -- as a narrowed execution mask; v_cmpx_lt_f32 is false for unordered operands, as the comparison above
 			asm volatile("v_cmpx_lt_f32 %1, %2\n\tv_or_b32 %0, %0, %3\n\ts_mov_b64 exec, %4" : "+v"(hit_mask) : "v"(tmin), "v"(tmax), "v"(contribution), "s"(all_lanes) : "vcc");
-#else
-			if (tmin < tmax) hit_mask |= contribution;
-#endif
 		}
 	}
 	return hit_mask;
-}
-
-// ---- decoded nodes (96 B) -------------------------------------------------------------------------
-// The merged wavefront walks a copy of the node array that kernel_decode_nodes (below) has re-laid for this loop. The 80-byte
-// CWBVH node is a storage format: to use it a lane spends 6 instructions expanding three exponent bytes, 14 (two of them
-// quarter-rate integer multiplies) turning the two meta words into shift amounts, before the first of the 48 fused
-// multiply-adds. A decoded node carries what those instructions produce -- NOT different numbers: every float the slab tests
-// see is bit for bit the one bvh8_node_intersect computes from the 80 bytes, so hits stay identical to the oracle's, which
-// keeps walking the reference's bytes --
-//   float4 0: p.x, p.y, p.z, (e_x << 23) | imask     the x scale 2^e_x as float bits, imask in its (zero) low mantissa byte
-//   float4 1: 2^e_y, 2^e_z, child base index, triangle base index
-//   float4 2: meta[0..3], meta[4..7], inner[0..3], inner[4..7]     inner: 0x07 in the byte of every inner child
-//   float4 3..5: quantised planes as in the reference (lo[0..3], lo[4..7], hi[0..3], hi[4..7]) for x, y, z
-// and the two planes of a child and axis go through ONE v_pk_fma_f32 (CDNA3+: two fp32 fused multiply-adds per lane and
-// issue slot; each half is the IEEE fma of its operands, as v_fma_f32 is).
-typedef float v2f __attribute__((ext_vector_type(2)));
-#ifndef RT_NODE_WIDE_FLOAT4
-#define RT_NODE_WIDE_FLOAT4 6   // (8: one 128-byte cache line per node, an experiment; rt_api.hip allocates 128 B per node either way)
 #endif
-RT_DEV unsigned bvh8_node_intersect_decoded(const Ray3 & ray, f3 inv_dir, unsigned oct_inv4, float max_distance,
-                                            float4 n0, float4 n1, float4 n2, float4 n3, float4 n4, float4 n5) {
-	f3 p = mk3(n0.x, n0.y, n0.z);
-	f3 adjusted_dir_inv = mk3(
-		__uint_as_float(__float_as_uint(n0.w) & 0x7f800000u) * inv_dir.x,
-		n1.x * inv_dir.y,
-		n1.y * inv_dir.z);
-	f3 adjusted_origin = (p - ray.origin) * inv_dir;
-	const v2f ax = { adjusted_dir_inv.x, adjusted_dir_inv.x }, ox = { adjusted_origin.x, adjusted_origin.x };
-	const v2f ay = { adjusted_dir_inv.y, adjusted_dir_inv.y }, oy = { adjusted_origin.y, adjusted_origin.y };
-	const v2f az = { adjusted_dir_inv.z, adjusted_dir_inv.z }, oz = { adjusted_origin.z, adjusted_origin.z };
-
-	bool neg_x = ray.direction.x < 0.0f, neg_y = ray.direction.y < 0.0f, neg_z = ray.direction.z < 0.0f;
-
-	unsigned hit_mask = 0;
-	#pragma unroll
-	for (int i = 0; i < 2; i++) {
-		unsigned meta4  = __float_as_uint(i == 0 ? n2.x : n2.y);
-		unsigned inner4 = __float_as_uint(i == 0 ? n2.z : n2.w);
-		unsigned bit_index4 = meta4 ^ (oct_inv4 & inner4);   // a shift uses the low 5 bits of its amount: the count bits above them need no mask
-
-		unsigned q_lo_x = __float_as_uint(i == 0 ? n3.x : n3.y), q_hi_x = __float_as_uint(i == 0 ? n3.z : n3.w);
-		unsigned q_lo_y = __float_as_uint(i == 0 ? n4.x : n4.y), q_hi_y = __float_as_uint(i == 0 ? n4.z : n4.w);
-		unsigned q_lo_z = __float_as_uint(i == 0 ? n5.x : n5.y), q_hi_z = __float_as_uint(i == 0 ? n5.z : n5.w);
-
-		unsigned x_min = neg_x ? q_hi_x : q_lo_x, x_max = neg_x ? q_lo_x : q_hi_x;
-		unsigned y_min = neg_y ? q_hi_y : q_lo_y, y_max = neg_y ? q_lo_y : q_hi_y;
-		unsigned z_min = neg_z ? q_hi_z : q_lo_z, z_max = neg_z ? q_lo_z : q_hi_z;
-
-		#pragma unroll
-		for (int j = 0; j < 4; j++) {
-			v2f qx = { float(extract_byte(x_min, j)), float(extract_byte(x_max, j)) };
-			v2f qy = { float(extract_byte(y_min, j)), float(extract_byte(y_max, j)) };
-			v2f qz = { float(extract_byte(z_min, j)), float(extract_byte(z_max, j)) };
-#ifdef RT_DECODED_NO_PK
-			v2f tx = { __builtin_fmaf(qx.x, ax.x, ox.x), __builtin_fmaf(qx.y, ax.x, ox.x) };
-			v2f ty = { __builtin_fmaf(qy.x, ay.x, oy.x), __builtin_fmaf(qy.y, ay.x, oy.x) };
-			v2f tz = { __builtin_fmaf(qz.x, az.x, oz.x), __builtin_fmaf(qz.y, az.x, oz.x) };
-#else
-			v2f tx = __builtin_elementwise_fma(qx, ax, ox);
-			v2f ty = __builtin_elementwise_fma(qy, ay, oy);
-			v2f tz = __builtin_elementwise_fma(qz, az, oz);
-#endif
-
-			float tmin = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
-			float tmax = fminf(fminf(tx.y, ty.y), fminf(tz.y, max_distance));
-
-			if (tmin < tmax) hit_mask |= (extract_byte(meta4, j) >> 5) << (extract_byte(bit_index4, j) & 31u);
-		}
-	}
-	return hit_mask;
 }
 
 // ---- narrow mode: 8 lanes per ray ---------------------------------------------------------------
@@ -517,14 +428,6 @@ __shared__ int   shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4]; // per wave: ne
 // wait behind it in the middle of a round; from LDS it costs a fraction of that latency.
 #define RT_ROOTS_IN_LDS 1024
 __shared__ int   shared_roots[RT_ROOTS_IN_LDS];
-// The flattened scene's launch with a node cache (rt_set_node_cache): the top levels of the tree, 80 bytes each, copied from the node
-// array when the workgroup starts. Node fetches that fall into the range are five ds_read_b128 instead of five divergent
-// global_load_dwordx4: the texture-address unit, which this kernel keeps 72-86 % busy, never sees them.
-__shared__ float4 shared_top_nodes[RT_NODE_CACHE_MAX * 5];
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) v4f LdsFloat4;   // (typed: ds_read_b128, not a FLAT load)
-RT_DEV float4 lds_float4(const LdsFloat4 * p) { v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
-
 // The common traversal engine. RaySource supplies rays and consumes results so that the same
 // code serves the wavefront queues and the stand-alone entry points.
 // COUNT adds per-ray work counters (nodes fetched, triangles tested, instance entries) that are
@@ -548,9 +451,7 @@ template<int MODE, typename Source> RT_DEV void source_finish(const Source & src
 // base address: no compare / select of two 64-bit bases and no scalar load of the TLAS size in every round.
 // FLAT: the whole scene is one world-space tree rooted in node 0 (rt_set_static_geometry): there is no TLAS to walk, no instance
 // to enter or leave, no object-space ray -- the code for those and the three registers that track them are compiled out.
-// WIDE: nodes are read from the decoded copy of the unified node array (bvh8_node_intersect_decoded; wide engine of the merged wavefront only).
-// CACHE: FLAT with the top of the tree in shared_top_nodes (the caller has filled it).
-template<int MODE, bool COUNT, bool NARROW, bool UNIFIED = false, bool FLAT = false, bool WIDE = false, bool CACHE = false, typename Source>
+template<int MODE, bool COUNT, bool NARROW, bool UNIFIED = false, bool FLAT = false, typename Source>
 RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr, int ray_count_2 = 0, int * cursor_2 = nullptr) {
 	constexpr bool SHADOW = MODE == RT_TRACE_SHADOW;   // the kind of every ray, unless MODE == RT_TRACE_MIXED: then lane_shadow
 	bool lane_shadow = SHADOW;
@@ -633,10 +534,6 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 	int  mesh_id = 0;
 	bool mesh_has_identity_transform = true;
 	unsigned count_nodes = 0, count_triangles = 0, count_inst_xform = 0, count_inst_ident = 0;
-#ifdef RT_PHASE_STATS   // debug build: SIMD lane occupancy of the two phases, reported in the shadow slots stats[5..9]
-	unsigned phase_iterations = 0, phase_node_execs = 0, phase_node_lanes = 0, phase_tri_rounds = 0, phase_tri_lanes = 0;
-	#define RT_PHASE_LEADER() (__builtin_amdgcn_mbcnt_hi(unsigned(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(__ballot(1)), 0u)) == 0)
-#endif
 
 	// A finished ray hands over its result at the next refill, together with the other lanes that finished since the last
 	// one: inside the loop the hand-over ran in almost every round for 2-3 of 64 lanes, and its stores sat in front of the
@@ -707,9 +604,8 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 				if (current_group.y & 0xff000000u) {
 					// take the closest pending child of current_group (pushing the rest) and fetch its node
 					unsigned hits_imask = current_group.y;
-					// closest hit: the nearest child first (the highest bit: octant order). A shadow ray only asks WHETHER anything lies
-					// between its ends, which no visiting order changes; RT_SHADOW_FAR_FIRST takes its children from the other end.
-					unsigned child_index_offset = (RT_SHADOW_FAR_FIRST && RT_IS_SHADOW) ? unsigned(__builtin_ctz(hits_imask & 0xff000000u)) : msb(hits_imask);
+					// the nearest child first (the highest bit: octant order), for shadow rays as well: the walk stays the reference's
+					unsigned child_index_offset = msb(hits_imask);
 					unsigned child_index_base   = current_group.x;
 
 					current_group.y &= ~(1u << child_index_offset);
@@ -719,53 +615,20 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					unsigned relative_index = __popc(hits_imask & ~(0xffffffffu << slot_index));
 					unsigned child_node_index = child_index_base + relative_index;
 
-					unsigned hitmask, imask;
-					if constexpr (WIDE) {
-						static_assert(UNIFIED && !NARROW, "decoded nodes: the wide engine of the merged wavefront");
-						// 32-bit byte offset from a uniform base (global_load ... v_offset, s[base]): the 64-bit multiply-add of the general form is
-						// a quarter-rate instruction. rt_api.hip selects this engine only while nodes and triangles fit (RT_DECODED_MAX_*).
-						const float4 * node = (const float4 *)((const char *)p.bvh8_nodes_wide + __umul24(child_node_index, RT_NODE_WIDE_FLOAT4 * 16u));
-						float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4], n5 = node[5];
-						if (COUNT) count_nodes++;
-						hitmask = bvh8_node_intersect_decoded(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, n5);
-						imask = __float_as_uint(n0.w) & 0xffu;
-						current_group .x = __float_as_uint(n1.z);
-						triangle_group.x = __float_as_uint(n1.w);
-					} else {
-					float4 n0, n1, n2, n3, n4;
-					bool from_lds = false;
-					if constexpr (CACHE) {
-						static_assert(FLAT && !NARROW, "node cache: the wide engines of the flattened scene");
-						const unsigned in_range = child_node_index - unsigned(p.node_cache_first);   // (node 0 is a copy of the first cached node, the root)
-						from_lds = child_node_index == 0u || in_range < unsigned(p.node_cache_count);
-						if (from_lds) {
-							const LdsFloat4 * cached = (const LdsFloat4 *)shared_top_nodes + (child_node_index == 0u ? 0u : in_range) * 5u;
-							n0 = lds_float4(cached); n1 = lds_float4(cached + 1); n2 = lds_float4(cached + 2); n3 = lds_float4(cached + 3); n4 = lds_float4(cached + 4);
-						}
-					}
-					if (!from_lds) {
 					const float4 * node = (!UNIFIED && child_node_index < unsigned(p.tlas_node_count) ? p.tlas_nodes : nodes) + size_t(child_node_index) * 5;
-					n0 = node[0]; n1 = node[1]; n2 = node[2]; n3 = node[3]; n4 = node[4];
-					}
+					float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
 					if (COUNT) count_nodes++;
-#ifdef RT_PHASE_STATS
-					if (COUNT && !SHADOW) { phase_node_lanes++; if (RT_PHASE_LEADER()) phase_node_execs++; }
-#endif
-					hitmask = NARROW ? group8_or(bvh8_node_intersect_child(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, group_child))
-					        : (RT_FAST_NODE && UNIFIED && FLAT) ? bvh8_node_intersect_fast(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4)
+					unsigned hitmask = NARROW ? group8_or(bvh8_node_intersect_child(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, group_child))
+					                 : (RT_FAST_NODE && UNIFIED && FLAT) ? bvh8_node_intersect_fast(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4)
 					                 : bvh8_node_intersect(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
-					imask = extract_byte(__float_as_uint(n0.w), 3);
+					unsigned imask = extract_byte(__float_as_uint(n0.w), 3);
 
 					current_group .x = __float_as_uint(n1.x);
 					triangle_group.x = __float_as_uint(n1.y);
-					}
 					current_group .y = (hitmask & 0xff000000u) | imask;
 					triangle_group.y = (hitmask & 0x00ffffffu);
 				}
 			}
-#ifdef RT_PHASE_STATS
-			if (COUNT && !SHADOW && RT_PHASE_LEADER()) phase_iterations++;
-#endif
 
 			// ---- triangle phase: ONE batch per round, then back to the node phase. Lanes with more
 			// triangles than a batch keep them in triangle_group and take part in the next rounds while
@@ -777,18 +640,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			bool occluded = false;
 			{
 				bool has_triangles = triangle_group.y != 0 && (FLAT || tlas_stack_size != RT_INVALID);
-#if RT_TRI_HOLD > 0
-				// experiment: the triangle phase of a round runs only when at least RT_TRI_HOLD lanes have triangles waiting, or no
-				// running lane of the wave can do anything else (its lanes are at ~20 % of the wave in an ordinary round)
-				if (!NARROW) {
-					const int waiting = __popcll(__ballot(has_triangles)), others = __popcll(__ballot(!has_triangles));
-					if (waiting < RT_TRI_HOLD && others > 0) has_triangles = false;
-				}
-#endif
 				if (has_triangles) {
-#ifdef RT_PHASE_STATS
-					if (COUNT && !SHADOW) { phase_tri_lanes++; if (RT_PHASE_LEADER()) phase_tri_rounds++; }
-#endif
 					if (NARROW) {
 						// lane c of the group takes the c-th triangle from the top; all 8 lanes compute the rest mask
 						unsigned rest = triangle_group.y; int my_bit = -1;
@@ -831,7 +683,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 							int triangle_index = int(msb(triangle_group.y));
 							triangle_group.y &= ~(1u << triangle_index);
 							tri_id[k] = int(triangle_group.x) + triangle_index;
-							const float4 * tri = WIDE ? (const float4 *)((const char *)triangles + ((unsigned(tri_id[k]) * 3u) << 4)) : triangles + size_t(tri_id[k]) * 3;
+							const float4 * tri = triangles + size_t(tri_id[k]) * 3;
 							tri_a[k] = tri[0]; tri_b[k] = tri[1]; tri_c[k] = tri[2].x; // position_0, edge_1, edge_2
 						}
 					}
@@ -853,13 +705,6 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 				atomicAdd(&bucket[2], (unsigned long long)count_inst_xform); atomicAdd(&bucket[3], (unsigned long long)count_inst_ident);
 				atomicAdd(&bucket[4], 1ull);
 				count_nodes = count_triangles = count_inst_xform = count_inst_ident = 0;
-#ifdef RT_PHASE_STATS
-				if (!SHADOW) {
-					atomicAdd(&stats[5], (unsigned long long)phase_iterations); atomicAdd(&stats[6], (unsigned long long)phase_node_execs); atomicAdd(&stats[7], (unsigned long long)phase_node_lanes);
-					atomicAdd(&stats[8], (unsigned long long)phase_tri_rounds); atomicAdd(&stats[9], (unsigned long long)phase_tri_lanes);
-					phase_iterations = phase_node_execs = phase_node_lanes = phase_tri_rounds = phase_tri_lanes = 0;
-				}
-#endif
 			}
 			if (RT_IS_SHADOW && occluded) {
 				result_pending = 2;
@@ -893,197 +738,6 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			}
 			}
 
-			iterations_lost += RT_WAVE_SIZE - __popcll(__ballot(running)) - RT_N_D;
-		} while (iterations_lost < RT_N_W);
-	}
-	#undef RT_IS_SHADOW
-}
-
-// ---- the flattened scene's engine with the NEXT node's loads in flight behind the triangle tests ------------------------------------
-// A round of the engine above is a serial chain with TWO memory latencies in it: the node (pop -> five loads -> slab tests) and then
-// the triangles the slab tests found (loads -> Moeller-Trumbore); a resident wave spends 37 % of its time parked on s_waitcnt
-// (profiles/r04_traversal_experiments.txt). Which node a lane tests next does not depend on the triangle tests in front of it -- only
-// the distance its slab tests will be clipped to does --, so here a lane picks its next node (closest pending child, or the top of the
-// stack) and issues the five loads BEFORE the triangle tests of the round, as soon as it knows that this round's batch empties its
-// leaf; the slab tests on that node run at the top of the next round, on registers that have been on their way for a triangle
-// phase. The visiting order, the clip distances and therefore every hit are those of the engine above (and of the oracle); what is
-// paid is 20 registers that stay live through the triangle phase.
-// FLAT only (no TLAS, no instances), one ray per lane, no counters.
-#ifndef RT_FLAT_PIPELINE
-#define RT_FLAT_PIPELINE 0
-#endif
-#ifndef RT_PIPE_TRI_BATCH
-#define RT_PIPE_TRI_BATCH RT_TRI_BATCH
-#endif
-template<int MODE, typename Source>
-RT_DEV void bvh8_trace_engine_flat_pipelined(const RtParams & p, Source & src, int ray_count, int * cursor_1, int ray_count_2 = 0, int * cursor_2 = nullptr) {
-	constexpr bool SHADOW = MODE == RT_TRACE_SHADOW;
-	bool lane_shadow = SHADOW;
-	#define RT_IS_SHADOW (MODE == RT_TRACE_MIXED ? lane_shadow : SHADOW)
-	const float4 * __restrict__ nodes     = p.bvh8_nodes;
-	const float4 * __restrict__ triangles = p.triangle_positions;
-
-	unsigned lane = threadIdx.x & (RT_WAVE_SIZE - 1);
-	unsigned wave = threadIdx.x / RT_WAVE_SIZE;
-
-	TraversalStack stack;
-	stack.lds   = (LdsUint2 *)&shared_stack[wave * (RT_LDS_STACK * RT_WAVE_SIZE) + lane];
-	stack.spill_stride = int(gridDim.x * blockDim.x);
-	stack.spill = (GlobalUint2 *)(p.stack_spill + (blockIdx.x * blockDim.x + threadIdx.x));
-	stack.size  = 0;
-
-	const int waves_in_grid = int(gridDim.x) * (RT_TRACE_BLOCK / RT_WAVE_SIZE);
-	const int rays_total = ray_count + (MODE == RT_TRACE_MIXED ? ray_count_2 : 0);
-	const int ray_block = max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (rays_total / (2 * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
-	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * unsigned(ray_block) >= unsigned(rays_total)) return;
-	typedef volatile __attribute__((address_space(3))) int LdsFetchWord;
-	LdsFetchWord * fetch_state = (LdsFetchWord *)&shared_fetch[wave][0];
-	if (lane == 0) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[2] = 0; fetch_state[3] = 0; }
-	auto fetch_ray = [&]() -> int {   // as in bvh8_trace_engine
-		while (true) {
-			if (fetch_state[2]) return -1;
-			const bool second_queue = MODE == RT_TRACE_MIXED && fetch_state[3] != 0;
-			const int queue_count = second_queue ? ray_count_2 : ray_count;
-			int * const queue_cursor = second_queue ? cursor_2 : cursor_1;
-			unsigned long long want = __ballot(1);
-			int n_want = __popcll(want);
-			unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(want >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(want), 0u));
-			bool elected = rank == 0;
-			int next = fetch_state[0], end = fetch_state[1];
-			if (next >= end) {
-				int base = 0;
-				if (elected) base = atomicAdd(queue_cursor, ray_block);
-				base = __builtin_amdgcn_readfirstlane(base);
-				next = min(base, queue_count);
-				end  = min(base + ray_block, queue_count);
-			}
-			int give = min(n_want, end - next);
-			if (elected) {
-				fetch_state[0] = next + give;
-				fetch_state[1] = end;
-				if (next >= end) {
-					if (MODE == RT_TRACE_MIXED && !second_queue) { fetch_state[0] = 0; fetch_state[1] = 0; fetch_state[3] = 1; }
-					else fetch_state[2] = 1;
-				}
-			}
-			if (int(rank) < give) { if (MODE == RT_TRACE_MIXED) lane_shadow = second_queue; return next + int(rank); }
-		}
-	};
-
-	uint2 current_group  = make_uint2(0, 0);   // meaningful between a node's slab tests and the choice of the next node only
-	uint2 triangle_group = make_uint2(0, 0);
-	float4 pn0 = make_float4(0, 0, 0, 0), pn1 = pn0, pn2 = pn0, pn3 = pn0, pn4 = pn0;   // the node this lane tests next
-	bool have_next = false;
-
-	int  ray_index = 0;
-	Ray3 ray;
-	f3   inv_dir;
-	unsigned oct_inv4 = 0;
-	float max_distance = 0.0f;
-	HitRecord hit;
-
-	int result_pending = 0;
-	while (true) {
-		bool inactive = !have_next && triangle_group.y == 0;
-
-		if (result_pending) {
-			if (!RT_IS_SHADOW && p.has_triangle_aliases && hit.triangle_id != RT_INVALID) {
-				float4 names = triangles[size_t(hit.triangle_id) * 3 + 2];
-				if (__float_as_int(names.z) >= 0) { hit.mesh_id = __float_as_int(names.z); hit.triangle_id = __float_as_int(names.w); }
-			}
-			source_finish<MODE>(src, RT_IS_SHADOW, ray_index, hit, result_pending == 2);
-			result_pending = 0;
-		}
-		if (inactive) {
-			ray_index = fetch_ray();
-			if (ray_index < 0) return;
-
-			source_load<MODE>(src, RT_IS_SHADOW, ray_index, ray, max_distance);
-			inv_dir  = reciprocal(ray.direction);
-			oct_inv4 = ray_get_octant_inv4(ray.direction);
-			hit.t = RT_INFINITY; hit.u = 0.0f; hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
-			pn0 = nodes[0]; pn1 = nodes[1]; pn2 = nodes[2]; pn3 = nodes[3]; pn4 = nodes[4];   // the root
-			have_next = true;
-		}
-
-		int iterations_lost = 0;
-		bool running = true;
-		do {
-			if (running) {
-				// ---- slab tests on the node that was fetched during the previous round
-				if (have_next) {
-					unsigned hitmask = bvh8_node_intersect(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, pn0, pn1, pn2, pn3, pn4);
-					unsigned imask = extract_byte(__float_as_uint(pn0.w), 3);
-					current_group  = make_uint2(__float_as_uint(pn1.x), (hitmask & 0xff000000u) | imask);
-					triangle_group = make_uint2(__float_as_uint(pn1.y), hitmask & 0x00ffffffu);
-					have_next = false;
-				}
-
-				// ---- does this round's batch empty the lane's leaf? Then its next node is chosen now: the stack is popped BEFORE the
-				// triangle loads are issued (a spilled entry is a global load: loads come back in order, and a wait for it behind the
-				// triangle loads would be a wait for them) ...
-				const bool leaf_done = __popc(triangle_group.y) <= RT_PIPE_TRI_BATCH;
-				if (leaf_done && (current_group.y & 0xff000000u) == 0 && stack.size != 0) current_group = stack.pop();   // (a flattened scene's stack holds node groups only)
-				asm volatile("" : "+v"(current_group.x), "+v"(current_group.y));   // the popped entry is waited for HERE, not behind the loads below
-				const bool need_node = leaf_done && (current_group.y & 0xff000000u) != 0;
-
-				// ---- ... the triangle loads ...
-				int    tri_id[RT_PIPE_TRI_BATCH];
-				float4 tri_a[RT_PIPE_TRI_BATCH], tri_b[RT_PIPE_TRI_BATCH];
-				float  tri_c[RT_PIPE_TRI_BATCH];
-				#pragma unroll
-				for (int k = 0; k < RT_PIPE_TRI_BATCH; k++) {
-					tri_id[k] = RT_INVALID;
-					if (triangle_group.y != 0) {
-						int triangle_index = int(msb(triangle_group.y));
-						triangle_group.y &= ~(1u << triangle_index);
-						tri_id[k] = int(triangle_group.x) + triangle_index;
-						const float4 * tri = triangles + size_t(tri_id[k]) * 3;
-						tri_a[k] = tri[0]; tri_b[k] = tri[1]; tri_c[k] = tri[2].x;
-					}
-				}
-
-				// ---- ... and LAST the five loads of the next node, which stay in flight behind the triangle tests. Issued by every running
-				// lane, outside any branch (a lane with nothing to fetch reads the root into registers it does not look at): loads under
-				// a branch would make the compiler's wait for the triangles a wait for everything outstanding.
-				unsigned next_node_index = 0;
-				if (need_node) {
-					unsigned hits_imask = current_group.y;
-					unsigned child_index_offset = msb(hits_imask);
-					current_group.y &= ~(1u << child_index_offset);
-					if (current_group.y & 0xff000000u) stack.push(current_group);
-					unsigned slot_index     = (child_index_offset - 24) ^ (oct_inv4 & 0xffu);
-					unsigned relative_index = __popc(hits_imask & ~(0xffffffffu << slot_index));
-					next_node_index = current_group.x + relative_index;
-					current_group.y = 0;
-				}
-				{
-					const float4 * node = nodes + size_t(next_node_index) * 5;
-					pn0 = node[0]; pn1 = node[1]; pn2 = node[2]; pn3 = node[3]; pn4 = node[4];
-				}
-				have_next = need_node;
-
-				// ---- the triangle tests, in the sequential order (a shadow ray's second test runs whatever the first found: the answer is
-				// the same, and every load of the round has a use on every path)
-				bool occluded = false;
-				#pragma unroll
-				for (int k = 0; k < RT_PIPE_TRI_BATCH; k++) {
-					if (tri_id[k] != RT_INVALID) {
-						if (triangle_test_kind(RT_IS_SHADOW, tri_a[k], tri_b[k], make_float4(tri_c[k], 0.0f, 0.0f, 0.0f), 0, tri_id[k], ray, max_distance, hit)) occluded = true;
-					}
-				}
-
-				if (RT_IS_SHADOW && occluded) {
-					result_pending = 2;
-					stack.size = 0;
-					triangle_group.y = 0;
-					have_next = false;
-					running = false;
-				} else if (!have_next && triangle_group.y == 0) {
-					result_pending = 1;
-					running = false;
-				}
-			}
 			iterations_lost += RT_WAVE_SIZE - __popcll(__ballot(running)) - RT_N_D;
 		} while (iterations_lost < RT_N_W);
 	}
@@ -1563,11 +1217,7 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_shadow_bvh8_counting(RtParams p, int bounce, unsigned long long * stats) {
 	ShadowQueueSource src { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT], bounce };
-#ifdef RT_PHASE_STATS
-	RT_TRACE_ENGINE<true, false>(p, src, p.sizes->shadow[bounce], p.xcd_counters + (2 * bounce + 1) * RT_NUM_XCD); // slots 5..9 carry the phase statistics
-#else
 	RT_TRACE_ENGINE<true, true>(p, src, p.sizes->shadow[bounce], p.xcd_counters + (2 * bounce + 1) * RT_NUM_XCD, stats + 5);
-#endif
 }
 
 // The ONE traversal launch of an iteration of the merged wavefront: the closest-hit rays of the iteration (primary rays of
@@ -1581,7 +1231,7 @@ struct MixedStreamSource {
 	RT_DEV void load(bool is_shadow, int i, Ray3 & ray, float & max_distance) const { if (is_shadow) shadow.load(i, ray, max_distance); else closest.load(i, ray, max_distance); }
 	RT_DEV void finish(bool is_shadow, int i, const HitRecord & hit, bool occluded) const { if (is_shadow) shadow.finish(i, hit, occluded); else closest.finish(i, hit, occluded); }
 };
-template<bool COUNT, bool FLAT = false, bool WIDE = false, bool CACHE = false>
+template<bool COUNT, bool FLAT = false>
 RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	const int q = p.stream_iteration & 1;
 	MixedStreamSource src { { p.trace[q].origin, p.trace[q].direction, p.trace[q].hits },
@@ -1589,10 +1239,6 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	const int closest_count = p.stream->trace_count[q], shadow_count = p.stream->shadow_count[q ^ 1];
 	if (!FLAT && p.mesh_count <= RT_ROOTS_IN_LDS) {   // (uniform over the launch; before any wave leaves the kernel)
 		for (int i = threadIdx.x; i < p.mesh_count; i += RT_TRACE_BLOCK) shared_roots[i] = p.mesh_bvh_root_indices[i];
-		__syncthreads();
-	}
-	if (CACHE) {
-		for (int i = threadIdx.x; i < p.node_cache_count * 5; i += RT_TRACE_BLOCK) shared_top_nodes[i] = p.bvh8_nodes[size_t(p.node_cache_first) * 5 + i];
 		__syncthreads();
 	}
 	// Which engine (the counts are only known on the device; the choice is uniform over the launch):
@@ -1605,39 +1251,20 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	//   profiles/r02_mixed_engine.txt
 	if (!COUNT && closest_count + shadow_count <= RT_NARROW_MAX_RAYS)
 		bvh8_trace_engine<RT_TRACE_MIXED, false, true, true, FLAT>(p, src, closest_count, &p.stream->cursor[q][0], nullptr, shadow_count, &p.stream->cursor[q][1]);
-	else if constexpr (RT_FLAT_PIPELINE && FLAT && !COUNT && !WIDE && !CACHE) {
-		if (closest_count + shadow_count <= RT_MIXED_MAX_RAYS)
-			bvh8_trace_engine_flat_pipelined<RT_TRACE_MIXED>(p, src, closest_count, &p.stream->cursor[q][0], shadow_count, &p.stream->cursor[q][1]);
-		else {
-			bvh8_trace_engine_flat_pipelined<RT_TRACE_CLOSEST>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
-			bvh8_trace_engine_flat_pipelined<RT_TRACE_SHADOW >(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
-		}
-	}
 	else if (COUNT || closest_count + shadow_count <= RT_MIXED_MAX_RAYS)
-		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true, FLAT, WIDE, CACHE>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true, FLAT>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
 	else {
-		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true, FLAT, WIDE, CACHE>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
-		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true, FLAT, WIDE, CACHE>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true, FLAT>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
+		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true, FLAT>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
 	}
 }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8(RtParams p) { trace_stream<false>(p, nullptr); }
-// (With the plain node test: 7 waves per SIMD -- without the TLAS / instance state the engine fits 72 registers with no scratch; 1.045-1.052 ms of traversal per
-// step against 1.056-1.059 with 6, profiles/r03_flattened_static_geometry.txt. With RT_FAST_NODE 2: 6 waves, 80 registers, see there.)
+// The flattened scene's launch: without the TLAS / instance state the engine fits 80 registers with no scratch at 6 waves per SIMD with the two-pipe node
+// test (the plain test: 72 registers at 7 waves; profiles/r03_flattened_static_geometry.txt, profiles/r04_traversal_experiments.txt item 7).
 #ifndef RT_FLAT_WAVES
 #define RT_FLAT_WAVES (RT_FAST_NODE ? 6 : 7)
 #endif
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_FLAT_WAVES) kernel_trace_stream_bvh8_flat(RtParams p) { trace_stream<false, true>(p, nullptr); }
-// The flattened scene with the top of its tree in LDS (rt_set_node_cache). 25.6 KB of LDS per workgroup: 6 workgroups per CU.
-#ifndef RT_FLAT_CACHED_WAVES
-#define RT_FLAT_CACHED_WAVES 6
-#endif
-__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_FLAT_CACHED_WAVES) kernel_trace_stream_bvh8_flat_cached(RtParams p) { trace_stream<false, true, false, true>(p, nullptr); }
-// The same two launches on the decoded copy of the node array (rt_set_node_format; the default of the merged wavefront).
-__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_decoded(RtParams p) { trace_stream<false, false, true>(p, nullptr); }
-#ifndef RT_FLAT_DECODED_WAVES
-#define RT_FLAT_DECODED_WAVES 7
-#endif
-__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_FLAT_DECODED_WAVES) kernel_trace_stream_bvh8_flat_decoded(RtParams p) { trace_stream<false, true, true>(p, nullptr); }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_counting(RtParams p, unsigned long long * stats) { trace_stream<true>(p, stats); }
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {
@@ -1650,44 +1277,19 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_
 	RT_TRACE_ENGINE<true, false>(p, src, ray_count, retired);
 }
 
-// 80-byte CWBVH nodes [first, first + count) -> their decoded form (see "decoded nodes" above). One thread per node; runs when the
-// geometry changes (all nodes) and when a new TLAS has been copied into its slots (those slots).
-__global__ void kernel_decode_nodes(const uint4 * __restrict__ nodes, uint4 * __restrict__ decoded, int first, int count) {
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= count) return;
-	const uint4 * src = nodes + size_t(first + i) * 5;
-	uint4 n0 = src[0], n1 = src[1];
-	unsigned e_imask = n0.w;
-	auto inner7 = [](unsigned meta4) { return (((meta4 & (meta4 << 1)) & 0x10101010u) >> 4) * 7u; };   // 0b001xxxxx with xxxxx >= 24: an inner child
-	uint4 * dst = decoded + size_t(first + i) * RT_NODE_WIDE_FLOAT4;
-	dst[0] = make_uint4(n0.x, n0.y, n0.z, (extract_byte(e_imask, 0) << 23) | extract_byte(e_imask, 3));
-	dst[1] = make_uint4(extract_byte(e_imask, 1) << 23, extract_byte(e_imask, 2) << 23, n1.x, n1.y);
-	dst[2] = make_uint4(n1.z, n1.w, inner7(n1.z), inner7(n1.w));
-	dst[3] = src[2]; dst[4] = src[3]; dst[5] = src[4];
-}
-void rt_launch_decode_nodes(const void * nodes, void * decoded, int first, int count, hipStream_t stream) {
-	if (count <= 0) return;
-	hipLaunchKernelGGL(kernel_decode_nodes, dim3((count + 255) / 256), dim3(256), 0, stream, (const uint4 *)nodes, (uint4 *)decoded, first, count);
-}
-
 // Persistent grid: enough workgroups to fill every CU to the occupancy the kernel reaches,
 // a multiple of 8 so that all XCDs get the same share (block b runs on XCD b % 8).
 static int trace_grid_size(const void * kernel) {
-	static int cached_cus = 0;
-	if (!cached_cus) {
-		int device = 0;
+	static const int cus = [] {   // (a function-local static: initialised once, also when several submitting threads arrive together -- FrameSplit)
+		int device = 0, count = 0;
 		(void)hipGetDevice(&device);
-		(void)hipDeviceGetAttribute(&cached_cus, hipDeviceAttributeMultiprocessorCount, device);
-		if (cached_cus <= 0) cached_cus = 256;
-	}
+		(void)hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, device);
+		return count > 0 ? count : 256;
+	}();
 	int blocks_per_cu = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, RT_TRACE_BLOCK, 0) != hipSuccess || blocks_per_cu <= 0) blocks_per_cu = 2;
 	if (blocks_per_cu > 8) blocks_per_cu = 8;
-	// experiment knob (tools/two_context_overlap.py): a persistent grid that does not take every wave slot leaves room for another
-	// context's sort / shade launches beside it
-	if (const char * cap = getenv("GRT_TRACE_BLOCKS_PER_CU")) { int n = atoi(cap); if (n >= 1 && n < blocks_per_cu) blocks_per_cu = n; }
-	if (getenv("GRT_DEBUG")) fprintf(stderr, "[grt] trace kernel grid: %d CUs x %d workgroups of %d threads\n", cached_cus, blocks_per_cu, RT_TRACE_BLOCK);
-	return cached_cus * blocks_per_cu;
+	return cus * blocks_per_cu;
 }
 
 void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream) {
@@ -1739,23 +1341,8 @@ void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, hipS
 		return;
 	}
 	if (p.entry_tlas_stack_size == 0) {   // the whole scene is one world-space tree: the engine without the TLAS / instance code
-		if (p.node_cache_count > 0 && !p.bvh8_nodes_wide) {
-			static int grid_flat_cached = trace_grid_size((const void *)kernel_trace_stream_bvh8_flat_cached);
-			hipLaunchKernelGGL(kernel_trace_stream_bvh8_flat_cached, dim3(grid_flat_cached), dim3(RT_TRACE_BLOCK), 0, stream, p);
-			return;
-		}
-		if (p.bvh8_nodes_wide) {
-			static int grid_flat_decoded = trace_grid_size((const void *)kernel_trace_stream_bvh8_flat_decoded);
-			hipLaunchKernelGGL(kernel_trace_stream_bvh8_flat_decoded, dim3(grid_flat_decoded), dim3(RT_TRACE_BLOCK), 0, stream, p);
-			return;
-		}
 		static int grid_flat = trace_grid_size((const void *)kernel_trace_stream_bvh8_flat);
 		hipLaunchKernelGGL(kernel_trace_stream_bvh8_flat, dim3(grid_flat), dim3(RT_TRACE_BLOCK), 0, stream, p);
-		return;
-	}
-	if (p.bvh8_nodes_wide) {
-		static int grid_decoded = trace_grid_size((const void *)kernel_trace_stream_bvh8_decoded);
-		hipLaunchKernelGGL(kernel_trace_stream_bvh8_decoded, dim3(grid_decoded), dim3(RT_TRACE_BLOCK), 0, stream, p);
 		return;
 	}
 	static int grid = trace_grid_size((const void *)kernel_trace_stream_bvh8);

@@ -179,12 +179,8 @@ struct rt_context {
 	size_t tlas_node_bytes = 80;        // what the current TLAS version was uploaded as (80 CWBVH, 32 binary, 128 4-wide)
 	int lowest_blas_root = 0x7fffffff;  // over the instances uploaded last: the node slots below it are free for the TLAS copy of the merged wavefront
 	unsigned long long tlas_version = 0, tlas_version_in_nodes = ~0ull;   // the merged wavefront traces a copy of the TLAS inside the BLAS node array (stream_sync_tlas)
-	// ... and walks a DECODED copy of that array (96 B per node, kernels_trace.hip "decoded nodes"; rt_set_node_format)
 	bool expand_bc1 = true;   // rt_set_texture_expansion: BC1 textures are decoded once, at upload (rt_types.h: RT_TEXTURE_BC1_EXPANDED)
 	size_t texture_bytes = 0; // what rt_upload_textures holds on the device
-	int node_format = RT_NODES_REFERENCE;   // (the decoded copy measured 2-5 % slower on MI355X: profiles/r04_node_formats.txt)
-	void * bvh8_nodes_wide = nullptr; size_t wide_node_capacity = 0;
-	bool wide_nodes_stale = true;       // the BLAS part has to be decoded again (new geometry)
 	size_t bvh4_node_count = 0;
 	size_t bvh8_node_count = 0, bvh2_node_count = 0, triangle_count = 0;
 	size_t mesh_count = 0;
@@ -507,7 +503,7 @@ static int upload_triangle_positions(rt_context * ctx, const void * triangles, s
 	for (size_t t = 0; t < triangle_count; t++) memcpy(&positions[t * 12], src + t * 24, 36);
 	int s = upload(ctx, &ctx->triangle_positions, positions.data(), triangle_count * 48); if (s) return s;
 	ctx->params.triangle_positions = (const float4 *)ctx->triangle_positions;
-	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID; ctx->params.node_cache_count = 0;
+	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID;
 	return RT_OK;
 }
 
@@ -518,7 +514,7 @@ int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle
 	s = upload(ctx, &ctx->bvh8_nodes, bvh8_nodes, node_count * 80); if (s) return s;
 	s = upload_triangle_positions(ctx, triangles, triangle_count); if (s) return s;
 	ctx->triangle_count = triangle_count; ctx->bvh8_node_count = node_count;
-	ctx->tlas_version_in_nodes = ~0ull; ctx->wide_nodes_stale = true;
+	ctx->tlas_version_in_nodes = ~0ull;
 	ctx->params.triangles  = (const float4 *)ctx->triangles;
 	ctx->params.bvh8_nodes = (const float4 *)ctx->bvh8_nodes;
 	return RT_OK;
@@ -576,17 +572,6 @@ int rt_set_static_geometry(rt_context * ctx, int32_t whole_scene) {
 	(void)hipSetDevice(ctx->device);
 	RT_HIP(ctx, quiesce(ctx));
 	ctx->params.entry_tlas_stack_size = entry;
-	ctx->params.node_cache_count = 0;
-	return RT_OK;
-}
-
-int rt_set_node_cache(rt_context * ctx, int32_t first_node, int32_t count) {
-	RT_REQUIRE(ctx, ctx != nullptr, "rt_set_node_cache: NULL context");
-	if (count <= 0) { ctx->params.node_cache_count = 0; return RT_OK; }
-	RT_REQUIRE(ctx, ctx->params.entry_tlas_stack_size == 0, "rt_set_node_cache: rays have to start inside the one tree (rt_set_static_geometry(ctx, 1)) first");
-	RT_REQUIRE(ctx, count <= RT_NODE_CACHE_MAX && first_node >= 1 && size_t(first_node) + size_t(count) <= ctx->bvh8_node_count, "rt_set_node_cache: at most 64 nodes inside the uploaded node array, behind node slot 0");
-	// (launches already enqueued carry their own copy of the parameters; the range is read from the node array at launch time)
-	ctx->params.node_cache_first = first_node; ctx->params.node_cache_count = count;
 	return RT_OK;
 }
 
@@ -601,7 +586,7 @@ struct BlasBuildArgs { // must match kernels_blas.hip
 	int2 * range; int * runs; int * inner_count, * leaf_count, * inner_base, * leaf_base; int * level_state;
 };
 size_t rt_blas_build_scratch_bytes(size_t triangles, size_t meshes);
-hipError_t rt_blas_build(BlasBuildArgs a, void * library_scratch, size_t library_scratch_bytes, int * pinned_state, hipStream_t stream, int * out_node_count);
+hipError_t rt_blas_build(BlasBuildArgs a, void * library_scratch, size_t library_scratch_bytes, int * pinned_state, hipStream_t stream, int * out_node_count, size_t node_capacity);
 extern "C" {
 
 int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_count, const int32_t * mesh_first_triangle, size_t mesh_count,
@@ -666,7 +651,7 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	RT_BUILD_HIP(hipEventCreate(&t0)); RT_BUILD_HIP(hipEventCreate(&t1));
 	RT_BUILD_HIP(hipEventRecord(t0, ctx->stream));
 	int node_count = 0;
-	hipError_t e = rt_blas_build(a, base + o_library, library_bytes, pinned, ctx->stream, &node_count);
+	hipError_t e = rt_blas_build(a, base + o_library, library_bytes, pinned, ctx->stream, &node_count, node_capacity);
 	if (e == hipSuccess) e = hipEventRecord(t1, ctx->stream);
 	if (e == hipSuccess && out_triangle_positions) e = hipMemcpyAsync(out_triangle_positions, a.position, T * 4, hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -680,9 +665,9 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	device_free(ctx, ctx->triangles); device_free(ctx, ctx->triangle_positions); device_free(ctx, ctx->bvh8_nodes);
 	ctx->triangles = out_triangles; ctx->triangle_positions = out_positions; ctx->bvh8_nodes = out_nodes;
 	ctx->triangle_count = T; ctx->bvh8_node_count = size_t(node_count);
-	ctx->tlas_version_in_nodes = ~0ull; ctx->wide_nodes_stale = true;
+	ctx->tlas_version_in_nodes = ~0ull;
 	ctx->params.triangles = (const float4 *)out_triangles; ctx->params.triangle_positions = (const float4 *)out_positions; ctx->params.bvh8_nodes = (const float4 *)out_nodes;
-	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID; ctx->params.node_cache_count = 0;
+	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID;
 	if (out_root_indices) for (size_t m = 0; m < M; m++) out_root_indices[m] = int32_t(reserved_tlas_nodes + m);
 	if (out_node_count) *out_node_count = size_t(node_count);
 	if (out_build_ms) *out_build_ms = ms;
@@ -856,7 +841,6 @@ int rt_build_tlas(rt_context * ctx, const int32_t * root_indices, const int32_t 
 	ctx->mesh_count = n; ctx->params.mesh_count = int(n);
 	ctx->params.tlas_nodes = (const float4 *)tlas_device;
 	ctx->params.tlas_node_count = int(2 * n);     // the node slots reserved for the TLAS; BLAS nodes start behind them
-	ctx->params.node_cache_count = 0;
 	ctx->params.entry_tlas_stack_size = RT_INVALID;   // node 0 is a TLAS root from now on: rays start above the instances (rt_set_static_geometry(ctx, 1) does not survive a TLAS build)
 	ctx->tlas_version++;
 	ctx->params.mesh_bvh_root_indices = a.out_root_indices;
@@ -1302,7 +1286,7 @@ int rt_filter_frame(rt_context * ctx, int sample_index) {
 	RT_HIP(ctx, hipEventRecord(ctx->ev_main, ctx->stream));      // after the scatter of the gathered tiles (main stream)
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_main, 0));
 	rt_launch_svgf_taa(p, sample_index, st);
-	if (ctx->params.config.enable_taa) std::swap(ctx->params.taa_frame_prev, ctx->params.taa_frame_next);
+	if (p.config.enable_taa) std::swap(ctx->params.taa_frame_prev, ctx->params.taa_frame_next);   // (the snapshot that launched kernel_taa decides, not a config set meanwhile)
 	for (int i = 0; i < RT_AOV_COUNT; i++) if (p.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(p.aovs[i].framebuffer, 0, ctx->frame_pixels * 16, st)); // aovs_clear_to_zero
 	RT_HIP(ctx, hipEventRecord(slot.ev_done, st));
 	RT_HIP(ctx, hipGetLastError());
@@ -1607,16 +1591,6 @@ int rt_set_texture_expansion(rt_context * ctx, int enable) {
 }
 size_t rt_texture_bytes(rt_context * ctx) { return ctx ? ctx->texture_bytes : 0; }
 
-int rt_set_node_format(rt_context * ctx, int format) {
-	RT_REQUIRE(ctx, ctx && (format == RT_NODES_REFERENCE || format == RT_NODES_DECODED), "rt_set_node_format: unknown format");
-	if (ctx->node_format == format) return RT_OK;
-	(void)hipSetDevice(ctx->device);
-	RT_HIP(ctx, quiesce(ctx));
-	ctx->node_format = format;
-	ctx->tlas_version_in_nodes = ~0ull; ctx->wide_nodes_stale = true;   // the next submission brings the copy up to date (or drops it)
-	return RT_OK;
-}
-
 int rt_set_frame_pipelining(rt_context * ctx, int enable) {
 	RT_REQUIRE(ctx, ctx, "rt_set_frame_pipelining: NULL context");
 	ctx->frame_pipelining = enable != 0;
@@ -1885,7 +1859,7 @@ static int stream_complete(rt_context * ctx, const StreamSubmission * subs, int 
 			for (int i = 0; i < RT_AOV_COUNT; i++) if (pf.aovs[i].framebuffer) pf.aovs[i].framebuffer += size_t(sub.slot_base) * ctx->frame_pixels;
 			pf.gbuffer_normal_and_depth += size_t(sub.slot_base) * ctx->frame_pixels; pf.gbuffer_mesh_id_and_triangle_id += size_t(sub.slot_base) * ctx->frame_pixels; pf.gbuffer_screen_position_prev += size_t(sub.slot_base) * ctx->frame_pixels;
 			rt_launch_svgf_taa(pf, sub.first_sample, st, ctx->launch_timing_all && ctx->time_this_sample ? svgf_span_mark : nullptr, ctx);
-			if (ctx->params.config.enable_taa) std::swap(ctx->params.taa_frame_prev, ctx->params.taa_frame_next);
+			if (pf.config.enable_taa) std::swap(ctx->params.taa_frame_prev, ctx->params.taa_frame_next);   // (the submission's own config snapshot launched kernel_taa: the same one decides the swap)
 			for (int i = 0; i < RT_AOV_COUNT; i++) if (pf.aovs[i].framebuffer) RT_HIP(ctx, hipMemsetAsync(pf.aovs[i].framebuffer, 0, ctx->frame_pixels * 16 * size_t(sub.sample_count), st)); // aovs_clear_to_zero
 		}
 	} else
@@ -1935,32 +1909,9 @@ static int stream_complete(rt_context * ctx, const StreamSubmission * subs, int 
 // per-submission chains that keep frames of different scene versions in flight) is copied into the slots [0, node count)
 // that the BLAS node array reserves for it -- node indices below the TLAS size never name BLAS nodes. Nothing of the merged
 // wavefront is in flight when the TLAS changes (every upload completes it first), and the other kernels never read those slots.
-// The decoded copy follows: all nodes after new geometry, the TLAS slots after a new TLAS (both on the wavefront's stream, behind
-// the launches that still read the old contents).
-static int stream_sync_decoded_nodes(rt_context * ctx, int tlas_slots) {
-	ctx->params.bvh8_nodes_wide = nullptr;
-	if (ctx->node_format != RT_NODES_DECODED || !ctx->bvh8_nodes || ctx->bvh8_node_count == 0) return RT_OK;
-	if (ctx->bvh8_node_count > RT_DECODED_MAX_NODES || ctx->triangle_count > RT_DECODED_MAX_TRIANGLES) return RT_OK;   // beyond its 32-bit offsets: the 80-byte walk
-	hipStream_t st = ctx->path_stream.stream;
-	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));
-	if (ctx->wide_node_capacity < ctx->bvh8_node_count) {
-		RT_HIP(ctx, hipStreamSynchronize(st));
-		device_free(ctx, ctx->bvh8_nodes_wide); ctx->bvh8_nodes_wide = nullptr; ctx->wide_node_capacity = 0;
-		int s = device_alloc(ctx, &ctx->bvh8_nodes_wide, ctx->bvh8_node_count * 128); if (s) return s;   // (96 bytes per node in use; room for the 128-byte experiment, RT_NODE_WIDE_FLOAT4 = 8)
-		ctx->wide_node_capacity = ctx->bvh8_node_count; ctx->wide_nodes_stale = true;
-	}
-	if (ctx->wide_nodes_stale) rt_launch_decode_nodes(ctx->bvh8_nodes, ctx->bvh8_nodes_wide, 0, int(ctx->bvh8_node_count), st);
-	else rt_launch_decode_nodes(ctx->bvh8_nodes, ctx->bvh8_nodes_wide, 0, tlas_slots, st);
-	RT_HIP(ctx, hipGetLastError());
-	ctx->wide_nodes_stale = false;
-	ctx->params.bvh8_nodes_wide = (const float4 *)ctx->bvh8_nodes_wide;
-	return RT_OK;
-}
-
 static int stream_sync_tlas(rt_context * ctx) {
 	if (ctx->tlas_version_in_nodes == ctx->tlas_version) return RT_OK;
 	if (!ctx->params.tlas_nodes || ctx->params.tlas_node_count <= 0) {   // one BVH, no TLAS: node 0 is its root
-		int s = stream_sync_decoded_nodes(ctx, 0); if (s) return s;
 		ctx->tlas_version_in_nodes = ctx->tlas_version; return RT_OK;
 	}
 	if (!ctx->bvh8_nodes || size_t(ctx->params.tlas_node_count) > ctx->bvh8_node_count) return fail(ctx, RT_ERROR_NOT_READY, "rt_render_samples: the TLAS does not fit the node slots the geometry reserves for it");
@@ -1972,7 +1923,6 @@ static int stream_sync_tlas(rt_context * ctx) {
 	hipStream_t st = ctx->path_stream.stream;
 	RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_scene, 0));
 	RT_HIP(ctx, hipMemcpyAsync(ctx->bvh8_nodes, ctx->params.tlas_nodes, size_t(ctx->params.tlas_node_count) * 80, hipMemcpyDeviceToDevice, st));
-	int s = stream_sync_decoded_nodes(ctx, ctx->params.tlas_node_count); if (s) return s;
 	ctx->tlas_version_in_nodes = ctx->tlas_version;
 	return RT_OK;
 }
@@ -2290,7 +2240,7 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count) {
 	stage_mark(ctx, STAGE_POST, st);
 	const bool deferred = p.config.enable_svgf && ctx->defer_filter; // rt_filter_frame does the rest once the ranks have exchanged their tiles
 	if (deferred) { }
-	else if (p.config.enable_svgf) { p.taa_frame_prev = ctx->params.taa_frame_prev; p.taa_frame_next = ctx->params.taa_frame_next; rt_launch_svgf_taa(p, sample_index, st); if (ctx->params.config.enable_taa) std::swap(ctx->params.taa_frame_prev, ctx->params.taa_frame_next); }
+	else if (p.config.enable_svgf) { p.taa_frame_prev = ctx->params.taa_frame_prev; p.taa_frame_next = ctx->params.taa_frame_next; rt_launch_svgf_taa(p, sample_index, st); if (p.config.enable_taa) std::swap(ctx->params.taa_frame_prev, ctx->params.taa_frame_next); }
 	else rt_launch_accumulate(p, float(sample_index), range_offset, range_count, st);
 	stage_mark(ctx, STAGE_END, st);
 

@@ -111,7 +111,6 @@ struct RtParams {
 	const float4 * triangles;            // 6 float4: full shading triangle
 	const float4 * triangle_positions;   // 3 float4: position_0, edge_1, edge_2 (traversal copy)
 	const float4 * bvh8_nodes;
-	const float4 * bvh8_nodes_wide;      // decoded copy of bvh8_nodes (6 float4 per node, kernels_trace.hip "decoded nodes"); null: not in use
 	const float4 * bvh2_nodes;  // 2 float4 per node
 	const float4 * bvh4_nodes;  // 8 float4 per node
 	// The TLAS (node indices [0, tlas_node_count) of whichever BVH type is selected) is versioned per
@@ -123,7 +122,6 @@ struct RtParams {
 	int mesh_count;                   // instances (the fused traversal launch keeps the root table of a small scene in LDS)
 	int entry_tlas_stack_size;        // RT_INVALID: rays start at the TLAS root; 0: node 0 is the root of the one world-space tree that holds the
 	                                  // whole scene and rays start inside it, as instance row 0 (rt_set_static_geometry)
-	int node_cache_first, node_cache_count;   // nodes [first, first + count): the top levels of that tree, which its traversal launch copies to LDS (rt_set_node_cache); 0: none
 	int has_triangle_aliases;         // some triangles are copies that report the (instance, triangle) named in the padding of their
 	                                  // position record instead of themselves (rt_upload_triangle_aliases)
 	const int    * mesh_material_ids;
@@ -243,9 +241,6 @@ void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream);
 void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, int slot_base, int queue_offset, hipStream_t stream);
 void rt_launch_stream_advance(RtStreamControl * control, int iteration, int generated, int * progress, hipStream_t stream);
 void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, hipStream_t stream);
-#define RT_DECODED_MAX_NODES     (1u << 24)            // decoded engine: node offset = index (24 bits) * 96 in one full-rate multiply
-#define RT_DECODED_MAX_TRIANGLES (0xffffffffu / 48u)   //                 triangle offset = index * 48 in 32 bits
-void rt_launch_decode_nodes(const void * nodes_80_bytes, void * decoded_96_bytes, int first, int count, hipStream_t stream);
 void rt_launch_sort_stream(const RtParams & p, hipStream_t stream);
 void rt_launch_material_stream(const RtParams & p, int material_slot, hipStream_t stream);
 void rt_launch_trace_shadow(const RtParams & p, int bounce, hipStream_t stream);

@@ -78,7 +78,7 @@ struct BVH8 {
 
 // Renumbers the nodes of a tree rooted in node 0 level by level (children of a node stay consecutive, in slot order: traversal does
 // not notice). Afterwards the nodes of depth <= max_depth are the first `return value` nodes: what the traversal kernel of the
-// flattened scene keeps in LDS (rt_set_node_cache) -- every ray walks them, 40 % of all node steps on Sponza touch the top three levels.
+// flattened scene keeps together at the front of its node array -- every ray walks them, 40 % of all node steps on Sponza touch the top three levels.
 int bvh8_order_breadth_first(BVH8 & bvh, int max_depth);
 
 struct Mesh;

@@ -85,11 +85,6 @@ struct CPUConfig {
 	// ... and what a triangle test costs relative to a node step when that tree's binary form is collapsed into 8-wide nodes
 	// (BVH8Converter: 1 in the reference; here a triangle test runs with a quarter of a wave's lanes, a node step with most)
 	float static_primitive_cost = 1.0f;
-	// ... and whether the traversal launches keep that tree's top three levels (at most 64 nodes, 5 KB) in LDS (rt_set_node_cache):
-	// 40 % of a ray's node steps touch those few nodes and the kernel keeps the texture-address unit 72 % busy -- but measured on
-	// MI355X the launch with the LDS copy is 1.3 % SLOWER (6 workgroups per CU instead of 7, two fetch paths per round;
-	// profiles/r04_traversal_experiments.txt), so it is off unless asked for
-	int node_cache = 0;
 
 	IntegratorType integrator = IntegratorType::PATHTRACER; // read by the command-line front end
 

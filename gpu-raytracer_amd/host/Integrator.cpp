@@ -127,7 +127,7 @@ static void build_flattened_tree(const std::vector<Triangle> & world, BVH8 & wid
 	BVH8Converter converter(wide, binary);
 	converter.primitive_cost = cpu_config.static_primitive_cost;
 	converter.convert();
-	top_nodes = std::min(bvh8_order_breadth_first(wide, 2), RT_NODE_CACHE_MAX);   // levels 0..2: at most 1 + 8 + 64 nodes
+	top_nodes = std::min(bvh8_order_breadth_first(wide, 2), 64);   // levels 0..2 (at most 1 + 8 + 64 nodes) come first: the part of the tree every ray walks is one contiguous run
 }
 
 // Lets go of the current background build without waiting for it: a build that is still running moves to retired_flattens and is
@@ -360,6 +360,11 @@ void Integrator::init_geometry() {
 				}
 			}
 			size_t copies = copy_source.size();   // more than the members have triangles where spatial splits cut some of them
+			// A retired worker (a build whose members moved while it ran, start_flatten_worker) may still be reading the reference part of
+			// this array through a raw pointer. Growing within the capacity leaves that part where it is; a reallocation would pull it
+			// from under the worker, so such a worker is waited for first (only then: the install frame otherwise never waits).
+			if (index_total + copies > aggregated_triangles.capacity())
+				for (auto & retired : retired_flattens) if (retired->worker.joinable()) retired->worker.join();
 			aggregated_triangles.resize(index_total + copies);
 			alias_mesh_ids.assign(index_total + copies, -1); alias_triangle_ids.assign(index_total + copies, -1);
 			if (prebuilt && prebuilt->copy_triangles.size() == copies) {   // ... the copies too (the worker filled them in: 15 ms for Sponza)
@@ -488,6 +493,7 @@ void Integrator::build_tlas() {
 	if (wants_device_tlas()) {
 		// Everything in scene order; the device sorts, builds and re-orders (replaces the SAH build, the CWBVH conversion and
 		// the table shuffle below: Integrator.cpp:399-430 of the reference)
+		if (pending_flatten) drop_flatten_worker();   // a tree built beside the frame loop has no place under a device-built TLAS: let go of it (update() would ask for a rebuild every frame while it is "ready")
 		if (static_geometry.active) {
 			// the device TLAS was switched on (device_tlas, enable_scene_update) after the scene had been flattened: a device-built TLAS
 			// has a leaf per scene instance and knows nothing of the flattened tree, its aliases or a ray entry inside node 0 --
@@ -601,7 +607,6 @@ void Integrator::build_tlas() {
 	if (ctx && cpu_config.bvh_type == BVHType::BVH8) {
 		check(rt_set_static_geometry(ctx, whole_scene ? 1 : 0));
 		// rays start inside the one tree: its top levels (breadth-first: the first nodes from its root) may live in LDS
-		check(rt_set_node_cache(ctx, flat.root, whole_scene && cpu_config.node_cache ? flat.top_nodes : 0));
 	}
 }
 

@@ -102,7 +102,7 @@ struct Integrator {
 		std::vector<int> movers;      // every other instance
 		int    root = 0;              // root node of the merged tree
 		size_t copy_bytes = 0;        // what the copies and the tree's nodes add to the device's geometry
-		int    top_nodes = 0;         // its nodes are in breadth-first order; so many of them (from the root) make up its top levels (rt_set_node_cache)
+		int    top_nodes = 0;         // its nodes are in breadth-first order; so many of them (from the root) make up its top levels
 		AABB   aabb;
 		double build_seconds = 0.0;   // host SAH + CWBVH conversion (0 when the device built it)
 		int leaves() const { return 1 + int(movers.size()); }   // rows in front of the members' rows

@@ -68,7 +68,6 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "device_blas")                         cpu_config.device_blas = int(value);
 	else if (k == "merge_static")                        cpu_config.merge_static = int(value);
 	else if (k == "static_primitive_cost")               cpu_config.static_primitive_cost = float(value);
-	else if (k == "node_cache")                          cpu_config.node_cache = int(value);
 	else if (k == "static_mesh_copy_limit_mb")           cpu_config.static_mesh_copy_limit_mb = int(value);
 	else if (k == "static_copy_budget_mb")               cpu_config.static_copy_budget_mb = int(value);
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
@@ -334,7 +333,7 @@ float  grt_pathtracer_device_blas_build_ms(void * pt) { return as_integrator(pt)
 int    grt_pathtracer_static_geometry_members(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active ? int(p->static_geometry.members.size()) : 0; }
 // 1: everything is in the flattened tree, rays start inside it (rt_set_static_geometry); 0: there is a TLAS
 int    grt_pathtracer_static_geometry_whole_scene(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active && p->static_geometry.movers.empty() ? 1 : 0; }
-// the flattened tree's root node and how many nodes from it (breadth-first order) are its top levels: the range given to rt_set_node_cache
+// the flattened tree's root node and how many nodes from it (breadth-first order) are its top levels
 int    grt_pathtracer_static_geometry_root(void * pt) { return as_integrator(pt)->static_geometry.root; }
 int    grt_pathtracer_static_geometry_top_nodes(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active ? p->static_geometry.top_nodes : 0; }
 // re-flattening when a member starts to move: 1 (default) builds the new tree on a worker thread while the frame loop renders in the

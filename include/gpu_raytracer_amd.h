@@ -142,9 +142,11 @@ const char * rt_version(void);
  *   3  RT_TIMING_* kinds of rt_get_launch_timings, rt_comm_* / rt_all_gather_* entry points (additions only)
  *   4  rt_upload_triangle_aliases, rt_set_static_geometry (additions only)
  *   5  rt_set_texture_expansion, rt_texture_bytes (additions only; BC1 textures are decoded at upload unless asked otherwise)
- *   6  rt_set_svgf_tiles, rt_set_stream_batch (additions only)
+ *   6  rt_set_svgf_tiles, rt_set_stream_batch (additions only; 5 and 6 also carried rt_set_node_format / rt_set_node_cache)
+ *   7  rt_set_node_format (a 96-byte decoded copy of the node array) and rt_set_node_cache (the top of the flattened tree in LDS) REMOVED:
+ *      both measured slower than the 80-byte walk on MI355X (profiles/r04_traversal_experiments.txt items 2 and 4) and were off by default
  * Check `rt_abi_version() == RT_ABI_VERSION` once after loading the library.                                          */
-#define RT_ABI_VERSION 6
+#define RT_ABI_VERSION 7
 int rt_abi_version(void);
 
 /* ---- scene upload ------------------------------------------------------------------- */
@@ -362,24 +364,6 @@ int rt_render_samples(rt_context * ctx, int sample_index, int sample_count);
  *   choice for scenes that upload a new TLAS every frame.                                                           */
 enum { RT_SCHEDULER_MERGED = 0, RT_SCHEDULER_SLOTS = 1 };
 int rt_set_scheduler(rt_context * ctx, int scheduler);
-/* Which bytes the traversal launches of the merged scheduler read a CWBVH node from.
- * RT_NODES_DECODED (default): a device-side copy of the node array that the library keeps next to the uploaded one, 96 bytes
- *   per node -- the same node with its exponent bytes expanded to float scales and its meta bytes split into the shift words the
- *   slab loop needs (kernels_trace.hip, "decoded nodes"). Every float the traversal computes is bit for bit the one it computes
- *   from the reference's 80 bytes (CUDA/Raytracing/BVH8.h:29-111), so hits are identical; the node step is ~20 % shorter.
- *   The copy is refreshed by the library when geometry or the TLAS change; callers keep uploading 80-byte nodes.
- * RT_NODES_REFERENCE: traverse the uploaded 80-byte nodes themselves.                                                    */
-enum { RT_NODES_REFERENCE = 0, RT_NODES_DECODED = 1 };
-/* Nodes the traversal launches of the merged scheduler may keep in LDS: [first_node, first_node + count) have to be the top of the
- * one tree rays start in (rt_set_static_geometry(ctx, 1); node slot 0 holds a copy of first_node, the root), in breadth-first
- * order, count <= RT_NODE_CACHE_MAX; 0 switches it off, and so does every call that replaces geometry or the ray entry. The
- * reference walks every node from global memory (CUDA/Raytracing/BVH8.h:113-274) with NVIDIA's texture path behind it; on
- * MI355X the traversal is bound by the rate at which the texture-address unit takes divergent 16-byte loads (72-86 % busy,
- * profiles/r04_pmc_traversal_breakdown.json), and the top three levels of the tree are 40 % of a ray's node steps. The LDS copy
- * holds the same bytes: hits do not change.                                                                              */
-#define RT_NODE_CACHE_MAX 64
-int rt_set_node_cache(rt_context * ctx, int32_t first_node, int32_t count);
-int rt_set_node_format(rt_context * ctx, int format);
 /* Merged scheduler: one more iteration of the wavefront without new samples (no-op when nothing is in flight), and the
  * number of submissions whose accumulate step has been enqueued so far -- a frame loop that hands every completed
  * frame to a collective calls rt_advance / rt_render_samples and packs the frame when the count moves

@@ -151,7 +151,7 @@ def _one_hop(grt, oracle, scene, w, h, frames, rel_tol, outlier_tol, l2_tol, lab
     light tables, decoded nodes, the engine without TLAS code when nothing is left outside); the reference's own kernels render
     the REFERENCE'S layout of the same scene, staged by a second integrator that has no device (merge_static 0). One comparison,
     no restated oracle and no second device run in between."""
-    from test_gpu_full_size import pixel_l2, record
+    from test_gpu_full_size import pixel_l2, pixel_breakdown, record
     grt.config_set(merge_static=1)
     pt = grt.Pathtracer(scene, w, h, device=0); pt.update()
     assert pt.static_geometry_members >= 2
@@ -180,6 +180,7 @@ def _one_hop(grt, oracle, scene, w, h, frames, rel_tol, outlier_tol, l2_tol, lab
         outliers = (np.abs(got - want).max(axis=2) > 0.01 * (want.max(axis=2) + 1e-3)).mean()
         l2 = pixel_l2(got, want)
         record("%s frame %d (one hop)" % (label, f), rel_l1=rel, outlier_fraction=outliers, pixel_l2=l2)
+        pixel_breakdown(got, want, "%s frame %d (one hop: device, default layout, vs Pathtracer.cu on the CPU, reference layout)" % (label, f))
         assert rel < rel_tol and outliers < outlier_tol and l2 < l2_tol, (label, f, rel, outliers, l2)
     theirs.close(); staged.close(); pt.close()
     return totals

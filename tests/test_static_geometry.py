@@ -163,12 +163,12 @@ def test_frames_do_not_depend_on_the_flattening(grt, oracle):
     grt.config_reset()
 
 
-def test_the_flattened_tree_is_in_breadth_first_order_for_the_node_cache(grt):
-    """rt_set_node_cache keeps the first nodes of the flattened tree in LDS: they have to be its top levels. The builder's
+def test_the_flattened_tree_is_in_breadth_first_order(grt):
+    """The first nodes of the flattened tree are its top levels (what every ray walks is one contiguous run). The builder's
     8-wide collapse emits nodes depth-first; bvh8_order_breadth_first renumbers them level by level (children stay consecutive
     in slot order, so traversal does not notice -- every other test of this file walks the renumbered tree)."""
     scene, pt = staged(grt, grt.scene_path("sponza"), 64, 36, 1)
-    root, top = pt.static_geometry_node_cache
+    root, top = pt.static_geometry_top_levels
     nodes = pt.array("bvh8_nodes").view(np.uint32).reshape(-1, 20)
     count = nodes.shape[0] - root
     depth = np.full(count, -1, np.int64); depth[0] = 0

@@ -90,6 +90,9 @@ struct Policy {
 	int ray_block = 128;
 	int tri_hold = 0;           // postponing: run the triangle phase only with >= this many lanes wanting it (or nobody can step)
 	bool pop_in_node_phase = false; // a lane whose round ends with nothing pending pops and may take its node step in the SAME... (unused)
+	int second_min = 0;         // the k-th (k >= 1) test of a batch runs only when at least this many lanes have a k-th triangle; else those triangles wait for the next round
+	bool coop = false;          // cooperative triangle phase: every pending (ray, triangle) pair of the wave gets a lane of its own (hand-over through LDS), all pending triangles of a lane in one round
+	double coop_owner = 43, coop_helper = 58, coop_readback = 8;   // instruction prices: prefix + slot writes (all running lanes), fetch + test + result write per pass of 64 pairs, read-back per triangle trip
 };
 
 // instruction prices per block (VALU wave-instructions, kernel_trace_stream_bvh8 wide closest engine, round 2 ISA)
@@ -172,10 +175,25 @@ static void run_wave(const Scene & s, const std::vector<Ray> & rays, bool shadow
 			// triangle phase
 			{ int wanting = 0, stepping = 0; for (auto & l : L) if (l.running) { if (l.tg_y != 0 && l.tlas_stack != -1) wanting++; else if (l.tg_y == 0 && (l.cg_y & 0xff000000u)) stepping++; }
 				bool go = wanting > 0 && (wanting >= pol.tri_hold || stepping == 0);
+				if (go && pol.coop) {
+					int pairs = 0, max_n = 0;
+					for (auto & l : L) if (l.running && l.tg_y != 0 && l.tlas_stack != -1) { bool occluded = false; int n = 0;
+						while (l.tg_y != 0) { int ti = int(msb(l.tg_y)); l.tg_y &= ~(1u << ti); n++; pairs++;
+							if (!occluded) { st.tris++; if (triangle_test(s, l.shadow, int(l.tg_x) + ti, l.ray, l.max_distance, l.hit)) occluded = true; } }
+						max_n = std::max(max_n, n);
+						if (occluded) { l.stack.clear(); l.cg_y = 0; l.tg_y = 0; l.running = false; l.hit.tri = -2; } }
+					int running = 0; for (auto & l : L) if (l.running) running++;
+					int passes = (pairs + 63) / 64;
+					st.instr += pol.coop_owner + passes * pol.coop_helper + pol.coop_readback * max_n;
+					st.useful += pol.coop_owner * wanting / 64.0 + pol.coop_helper * pairs / 64.0 + pol.coop_readback * pairs / 64.0;
+					st.tri_exec[0] += passes; st.tri_lanes[0] += pairs;
+				} else
 				if (go) { st.instr += c.tri_head; st.useful += c.tri_head * wanting / 64.0;
 					int per_k[8] = {};
+					int want_k[8] = {};
+					if (pol.second_min > 0) for (auto & l : L) if (l.running && l.tg_y != 0 && l.tlas_stack != -1) { int n = __builtin_popcount(l.tg_y); for (int k = 0; k < pol.tri_batch && k < n; k++) want_k[k]++; }
 					for (auto & l : L) if (l.running && l.tg_y != 0 && l.tlas_stack != -1) { bool occluded = false;
-						for (int k = 0; k < pol.tri_batch && l.tg_y != 0; k++) { int ti = int(msb(l.tg_y)); l.tg_y &= ~(1u << ti);
+						for (int k = 0; k < pol.tri_batch && l.tg_y != 0; k++) { if (k >= 1 && pol.second_min > 0 && want_k[k] < pol.second_min) break; int ti = int(msb(l.tg_y)); l.tg_y &= ~(1u << ti);
 							if (!occluded) { per_k[k]++; st.tris++; if (triangle_test(s, l.shadow, int(l.tg_x) + ti, l.ray, l.max_distance, l.hit)) occluded = true; } }
 						if (occluded) { l.stack.clear(); l.cg_y = 0; l.tg_y = 0; l.running = false; l.hit.tri = -2; } }
 					for (int k = 0; k < pol.tri_batch; k++) if (per_k[k]) { st.tri_exec[k]++; st.tri_lanes[k] += per_k[k]; st.instr += c.tri_test; st.useful += c.tri_test * per_k[k] / 64.0; }
@@ -276,6 +294,17 @@ int main(int argc, char ** argv) {
 	{ Policy p; p.name = "early+hold16"; p.early_instance = true; p.tri_hold = 16; pols.push_back(p); }
 	{ Policy p; p.name = "early nd2 nw8"; p.early_instance = true; p.n_d = 2; p.n_w = 8; pols.push_back(p); }
 	{ Policy p; p.name = "early nd8 nw32"; p.early_instance = true; p.n_d = 8; p.n_w = 32; pols.push_back(p); }
+	if (argc > 3) {   // the triangle-phase experiments of round 5 only
+		std::vector<Policy> q;
+		{ Policy p; q.push_back(p); }
+		for (int m : { 4, 8, 12, 16, 24 }) { Policy p; p.name = "second slot if >= m lanes"; p.second_min = m; q.push_back(p); }
+		for (int m : { 8, 16 }) { Policy p; p.name = "batch 3, slots 2,3 if >= m"; p.tri_batch = 3; p.second_min = m; q.push_back(p); }
+		{ Policy p; p.name = "coop (43/58/8)"; p.coop = true; q.push_back(p); }
+		{ Policy p; p.name = "coop cheap (25/55/6)"; p.coop = true; p.coop_owner = 25; p.coop_helper = 55; p.coop_readback = 6; q.push_back(p); }
+		{ Policy p; p.name = "coop free (0/52/0)"; p.coop = true; p.coop_owner = 0; p.coop_helper = 52.5; p.coop_readback = 0; q.push_back(p); }
+		for (auto & p : q) { report("bounce2", p, simulate(s, bounce2, false, p)); report("shadow ", p, simulate(s, shadow, true, p)); report("primary", p, simulate(s, primary, false, p)); }
+		return 0;
+	}
 	for (auto & p : pols) { report("bounce2 (queue order)", p, simulate(s, bounce2, false, p)); }
 	for (int block : { 64, 128, 256, 512, 1024 }) { auto r = bucket(bounce2, block); char l[64]; snprintf(l, 64, "bounce2 octant buckets of %d", block); report(l, pols[0], simulate(s, r, false, pols[0])); report(l, pols[1], simulate(s, r, false, pols[1])); }
 	{ auto r = bucket(bounce2, 1 << 30); report("bounce2 octant-major (global)", pols[0], simulate(s, r, false, pols[0])); }
