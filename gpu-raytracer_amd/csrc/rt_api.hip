@@ -199,7 +199,7 @@ struct rt_context {
 	// frame resources
 	void * aov_buffers[RT_AOV_COUNT][2] = { };
 	void * final_image = nullptr;
-	void * svgf_buffers[15] = { }; bool svgf_allocated = false;
+	void * svgf_buffers[16] = { }; bool svgf_allocated = false;   // [15]: one word, RtParams::svgf_young_pixels
 	size_t frame_pixels = 0; // pitch * height
 
 	// frame exchange of the tile split (rt_comm_*): this context's rank in a group of `world` contexts, each on its own GPU
@@ -1111,6 +1111,7 @@ static int sync_svgf(rt_context * ctx) {
 			int s = device_alloc(ctx, &ctx->svgf_buffers[i], ctx->frame_pixels * elem[i]); if (s) return s;
 			RT_HIP(ctx, hipMemsetAsync(ctx->svgf_buffers[i], 0, ctx->frame_pixels * elem[i], ctx->stream));
 		}
+		{ int s = device_alloc(ctx, &ctx->svgf_buffers[15], 64); if (s) return s; RT_HIP(ctx, hipMemsetAsync(ctx->svgf_buffers[15], 0, 64, ctx->stream)); }
 		for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) for (int i = 0; i < 3; i++) {
 			int s = device_alloc(ctx, &ctx->slots[k].gbuffers[i], ctx->frame_pixels * elem[i]); if (s) return s;
 			RT_HIP(ctx, hipMemsetAsync(ctx->slots[k].gbuffers[i], 0, ctx->frame_pixels * elem[i], ctx->stream));
@@ -1124,7 +1125,7 @@ static int sync_svgf(rt_context * ctx) {
 			if (ctx->aov_buffers[aov][1]) RT_HIP(ctx, hipMemsetAsync(ctx->aov_buffers[aov][1], 0, ctx->frame_pixels * 16, ctx->stream));
 	} else {
 		RT_HIP(ctx, quiesce(ctx));
-		for (int i = 0; i < 15; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
+		for (int i = 0; i < 16; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
 		for (SampleSlot & slot : ctx->slots) for (int i = 0; i < 3; i++) { device_free(ctx, slot.gbuffers[i]); slot.gbuffers[i] = nullptr; }
 		ctx->path_stream.last_gbuffer_slot = -1;
 		for (void * & g : ctx->path_stream.gbuffers) { device_free(ctx, g); g = nullptr; }
@@ -1146,6 +1147,7 @@ static int sync_svgf(rt_context * ctx) {
 	p.svgf_variance[0]                = (float2 *)ctx->svgf_buffers[12];
 	p.svgf_variance[1]                = (float2 *)ctx->svgf_buffers[13];
 	p.taa_frame_next                  = (float4 *)ctx->svgf_buffers[14];   // (prev and next trade places after every filtered frame: kernel_taa)
+	p.svgf_young_pixels               = (int    *)ctx->svgf_buffers[15];
 	return RT_OK;
 }
 

@@ -194,6 +194,7 @@ struct RtParams {
 	int    * history_length;
 	float4 * history_direct, * history_indirect, * history_moment, * history_normal_and_depth;
 	float4 * taa_frame_prev, * taa_frame_curr, * taa_frame_next;   // next: where kernel_taa writes the history of the following frame (swapped with prev after every filtered frame)
+	int * svgf_young_pixels;          // != 0: this frame's kernel_svgf_reproject left a pixel with fewer than 4 frames of history, kernel_svgf_variance has work; cleared by kernel_svgf_finalize
 	float2 * svgf_variance[2];        // (direct.w, indirect.w) of the radiance framebuffers [0] and accumulators [1], kept in step by the filter kernels
 	float4 * svgf_normal_and_depth;   // (normal, depth) of the frame being filtered: decoded once by kernel_svgf_reproject for the variance / a-trous taps
 };
