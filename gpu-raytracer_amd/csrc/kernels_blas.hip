@@ -50,6 +50,7 @@ struct BlasBuildArgs {
 	int * runs;                                      // per node of the level: begin[9], children, inner children, leaf triangles
 	int * inner_count, * leaf_count, * inner_base, * leaf_base;   // per node of the level
 	int * level_state;                               // { nodes used, triangles placed, nodes of the next level }
+	const float * given_boxes; int given_first, given_count;   // rt_set_build_boxes: triangles [given_first, given_first + given_count) come with boxes of their own (6 floats: min, max), null / 0: none
 };
 
 // Step 1 in three launches, all of them as wide as the input: a mesh's box used to be reduced by ONE workgroup per mesh, which is the whole chip
@@ -77,9 +78,14 @@ __global__ void __launch_bounds__(256) kernel_blas_triangle_boxes(BlasBuildArgs 
 		const float4 * t = a.triangles + size_t(i) * 6;
 		float4 t0 = t[0], t1 = t[1], t2 = t[2];
 		const float p0[3] = { t0.x, t0.y, t0.z }, e1[3] = { t0.w, t1.x, t1.y }, e2[3] = { t1.z, t1.w, t2.x };
+		// a REFERENCE: the triangle is a copy of one that the caller has cut into pieces (early split clipping, host/StaticBVHBuilder.cpp: presplit), and
+		// this copy stands for the piece inside the given box -- the tree is built over the pieces' boxes, the leaf still tests the whole triangle
+		const bool given = a.given_boxes && i >= a.given_first && i - a.given_first < a.given_count;
+		const float * piece = given ? a.given_boxes + size_t(i - a.given_first) * 6 : nullptr;
 		for (int d = 0; d < 3; d++) {
 			float v1 = p0[d] + e1[d], v2 = p0[d] + e2[d];   // the vertices the traversal's Moeller-Trumbore test sees
 			box.min[d] = fminf(p0[d], fminf(v1, v2)); box.max[d] = fmaxf(p0[d], fmaxf(v1, v2));
+			if (given) { box.min[d] = fmaxf(box.min[d], piece[d]); box.max[d] = fminf(box.max[d], piece[3 + d]); if (box.max[d] < box.min[d]) box.max[d] = box.min[d]; }   // (never larger than the triangle's own)
 			// no flat boxes: the node test is `tmin < tmax`, a box of zero thickness is never entered -- an axis-aligned wall would
 			// be hit only where the quantisation grid happens to pad it. The reference's rule (AABB::fix_if_needed, AABB.h:27-38)
 			float eps = 0.001f;

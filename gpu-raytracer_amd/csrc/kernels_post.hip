@@ -280,18 +280,13 @@ __global__ void __launch_bounds__(256) kernel_svgf_reproject(RtParams p, float4 
 	st4(p.frame_buffer_moment, pixel_index, moment);
 	p.svgf_variance[0][pixel_index] = make_float2(direct.w, indirect.w);
 	if (direct_out && history_now >= 4) { st4(direct_out, pixel_index, direct); st4(indirect_out, pixel_index, indirect); variance_out[pixel_index] = make_float2(direct.w, indirect.w); }
-	// a pixel the spatial variance estimate has to visit (kernel_svgf_variance): with a static camera there is none from the fourth frame on,
-	// and that launch leaves at its first instruction (every lane stores the same word: a benign race)
-	if (direct_out && history_now < 4) *p.svgf_young_pixels = 1;
+	// a pixel the spatial variance estimate has to visit: listed for kernel_svgf_variance_listed (one atomic per wave)
+	if (direct_out && history_now < 4) { int slot = wave_aggregated_append(p.svgf_young_pixels); p.svgf_young_pixels[RT_SVGF_YOUNG_HEADER + slot] = pixel_index; }
 }
 
-__global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, float2 * variance_out) {
-	// Nothing to do: every pixel that is not sky has at least 4 frames of history (kernel_svgf_reproject wrote this pass's copies and raised no
-	// flag) and the image has no padding columns to copy. The pass was 0.032 ms of launch + a read of every pixel's history length per 1080p frame.
-	if (p.screen_pitch == p.screen_width && *p.svgf_young_pixels == 0) return;
-	int x, y;
-	if (!post_tile_pixel(p, x, y)) return;
-	if (x >= p.screen_pitch || y >= p.screen_height) return; // pitch, as in the reference (SVGF.h:293)
+// The spatial variance estimate of ONE pixel (SVGF.h:286-414): a 7 x 7 edge-stopping blur for pixels with fewer than 4 frames of history, nothing
+// (or, in the padding columns, a copy) for the others.
+RT_DEV void svgf_variance_pixel(const RtParams & p, int x, int y, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, float2 * variance_out) {
 	int pixel_index = x + y * p.screen_pitch;
 
 	int history = p.history_length[pixel_index];
@@ -342,6 +337,71 @@ __global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const fl
 	st4(d_out, pixel_index, sc_d);
 	st4(i_out, pixel_index, sc_i);
 	variance_out[pixel_index] = make_float2(sc_d.w, sc_i.w);
+}
+
+// Every pixel of the frame (and its padding columns, as the reference: SVGF.h:293) ...
+__global__ void __launch_bounds__(256) kernel_svgf_variance(RtParams p, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, float2 * variance_out) {
+	int x, y;
+	if (!post_tile_pixel(p, x, y)) return;
+	if (x >= p.screen_pitch || y >= p.screen_height) return;
+	svgf_variance_pixel(p, x, y, d_in, i_in, d_out, i_out, variance_out);
+}
+// ... or only the pixels kernel_svgf_reproject has listed (svgf_young_pixels: those it left with fewer than 4 frames of history; everything else
+// it has copied itself), ONE WAVE per listed pixel, one of the 48 taps per lane. From the fourth frame of a view on the young pixels are the
+// disoccluded ones along silhouettes, a per cent of the frame -- and the pass over all pixels took 0.034 ms all the same: not for the launch, but
+// because a young pixel's lane walked its 48 taps one after the other (four dependent-latency loads each) while the rest of the machine had left.
+// A lane per tap makes that one load latency and a wave reduction. The sums are formed in a tree instead of in tap order: the last bits differ from
+// kernel_svgf_variance (and the oracle) as any re-association does, far inside the filter's tolerance; results do not depend on the launch shape.
+// Used when the image has no padding columns (those are only ever copied, by the kernel above).
+RT_DEV float wave_sum(float v) {
+	#pragma unroll
+	for (int offset = 32; offset > 0; offset >>= 1) v += __shfl_xor(v, offset);
+	return v;
+}
+__global__ void __launch_bounds__(256) kernel_svgf_variance_listed(RtParams p, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, float2 * variance_out) {
+	const int count = p.svgf_young_pixels[0];
+	const int lane = int(threadIdx.x) & 63, waves = int(gridDim.x * blockDim.x) >> 6;
+	const int tap_j = lane / 7 - 3, tap_i = lane % 7 - 3;   // lanes 0..48: the 7 x 7 window (lane 24 is the centre), 49..63: idle
+	const float4 * __restrict__ normal_and_depth = p.svgf_normal_and_depth;
+	const float luminance_denom = 1.0f / p.config.sigma_l;
+	for (int k = int(blockIdx.x * blockDim.x + threadIdx.x) >> 6; k < count; k += waves) {
+		const int pixel_index = p.svgf_young_pixels[RT_SVGF_YOUNG_HEADER + k];
+		const int x = pixel_index % p.screen_pitch, y = pixel_index / p.screen_pitch;
+		f4 cd = ld4(d_in, pixel_index), ci = ld4(i_in, pixel_index);
+		float cl_d = luminance(cd.x, cd.y, cd.z), cl_i = luminance(ci.x, ci.y, ci.z);
+		float4 cnd = normal_and_depth[pixel_index];
+		f3 center_normal = mk3(cnd.x, cnd.y, cnd.z);
+		float center_depth = cnd.w;
+		if (center_depth == 0.0f) continue;   // (sky is never listed; uniform over the wave)
+		int xr = min(x + 1, p.screen_pitch - 1), yd = min(y + 1, p.screen_height - 1);
+		f2 grad = mk2(normal_and_depth[xr + y * p.screen_pitch].w - center_depth, normal_and_depth[x + yd * p.screen_pitch].w - center_depth);
+
+		const int tap_x = x + tap_i, tap_y = y + tap_j;
+		const bool tap = lane < 49 && lane != 24 && tap_x >= 0 && tap_x < p.screen_width && tap_y >= 0 && tap_y < p.screen_height;
+		float w_d = 0.0f, w_i = 0.0f;
+		f4 td = mk4(0.0f), ti = mk4(0.0f), moment = mk4(0.0f);
+		if (tap) {
+			const int tap_index = tap_x + tap_y * p.screen_pitch;
+			td = ld4(d_in, tap_index); ti = ld4(i_in, tap_index); moment = ld4(p.frame_buffer_moment, tap_index);
+			float l_d = luminance(td.x, td.y, td.z), l_i = luminance(ti.x, ti.y, ti.z);
+			float4 nd = normal_and_depth[tap_index];
+			f2 w = edge_stopping_weights(p, tap_i, tap_j, grad, center_depth, nd.w, center_normal, mk3(nd.x, nd.y, nd.z), cl_d, cl_i, l_d, l_i, luminance_denom, luminance_denom);
+			w_d = w.x; w_i = w.y;
+		}
+		float sw_d = 1.0f + wave_sum(w_d), sw_i = 1.0f + wave_sum(w_i);
+		f4 sc_d = cd + mk4(wave_sum(w_d * td.x), wave_sum(w_d * td.y), wave_sum(w_d * td.z), wave_sum(w_d * td.w));
+		f4 sc_i = ci + mk4(wave_sum(w_i * ti.x), wave_sum(w_i * ti.y), wave_sum(w_i * ti.z), wave_sum(w_i * ti.w));
+		f4 sum_moment = mk4(wave_sum(moment.x * w_d), wave_sum(moment.y * w_i), wave_sum(moment.z * w_d), wave_sum(moment.w * w_i));
+		if (lane != 0) continue;
+		sw_d = fmaxf(sw_d, 1e-6f); sw_i = fmaxf(sw_i, 1e-6f);
+		sc_d = sc_d / sw_d; sc_i = sc_i / sw_i;
+		sum_moment = mk4(sum_moment.x / sw_d, sum_moment.y / sw_i, sum_moment.z / sw_d, sum_moment.w / sw_i);
+		sc_d.w = fmaxf(0.0f, sum_moment.z - sum_moment.x * sum_moment.x);
+		sc_i.w = fmaxf(0.0f, sum_moment.w - sum_moment.y * sum_moment.y);
+		st4(d_out, pixel_index, sc_d);
+		st4(i_out, pixel_index, sc_i);
+		variance_out[pixel_index] = make_float2(sc_d.w, sc_i.w);
+	}
 }
 
 // One a-trous pass (SVGF.h:416-554). Per pixel: the 3x3 Gaussian blur of the variance (9 taps, .w only), then 8 taps at
@@ -519,7 +579,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_finalize(RtParams p, const fl
 	if (x >= p.screen_width || y >= p.screen_height) return;
 	int pixel_index = x + y * p.screen_pitch;
 
-	if (pixel_index == 0) *p.svgf_young_pixels = 0;   // (this frame's variance pass is behind us: the next frame's reproject raises it again)
+	if (pixel_index == 0) p.svgf_young_pixels[0] = 0;   // (this frame's variance pass is behind us: the next frame's reproject fills the list again)
 	f4 direct = ld4(colour_direct, pixel_index), indirect = ld4(colour_indirect, pixel_index);
 	f4 colour = (direct + indirect) * aov_get(p, RT_AOV_ALBEDO, pixel_index);
 	st4(p.final_image, pixel_index, colour);
@@ -625,7 +685,8 @@ void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream
 	// leaves unwritten (sky) included: every kernel that writes a (direct, indirect) pair writes the pair's variances as well
 	float2 * variance_in = p.svgf_variance[0], * variance_out = p.svgf_variance[1];
 	if (p.config.enable_spatial_variance) {
-		RT_TIMED(1, hipLaunchKernelGGL(kernel_svgf_variance, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out, variance_out));
+		if (p.screen_pitch == p.screen_width) { RT_TIMED(1, hipLaunchKernelGGL(kernel_svgf_variance_listed, dim3(2048), dim3(256), 0, stream, p, direct_in, indirect_in, direct_out, indirect_out, variance_out)); }
+		else { RT_TIMED(1, hipLaunchKernelGGL(kernel_svgf_variance, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out, variance_out)); }
 		float4 * t = direct_in; direct_in = direct_out; direct_out = t;
 		t = indirect_in; indirect_in = indirect_out; indirect_out = t;
 		float2 * v = variance_in; variance_in = variance_out; variance_out = v;

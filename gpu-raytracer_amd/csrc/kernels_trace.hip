@@ -61,22 +61,8 @@
 
 struct Ray3 { f3 origin, direction; };
 
-// Cache policy of the loads that stream (experiments of round 5, off unless the macro is set): a triangle is tested by the lane that found it and
-// hardly ever by another soon after, a ray is read once -- with the non-temporal hint such a load is served by L2 without taking a line of the
-// CU's 32-KB L1, which the nodes (88 % hit rate, the unit closest to its roof: roofline.binding.l1) then keep to themselves.
-#ifndef RT_OFFSETS_32
-#define RT_OFFSETS_32 0   // experiment: see the node fetch of the FLAT engine
-#endif
-#ifndef RT_NT_TRIANGLES
-#define RT_NT_TRIANGLES 0
-#endif
-#ifndef RT_NT_RAYS
-#define RT_NT_RAYS 0
-#endif
-typedef float v4f_nt __attribute__((ext_vector_type(4)));
-RT_DEV float4 load4_stream(const float4 * p) { v4f_nt v = __builtin_nontemporal_load((const v4f_nt *)p); return make_float4(v.x, v.y, v.z, v.w); }
-RT_DEV float  load1_stream(const float * p)  { return __builtin_nontemporal_load(p); }
-RT_DEV f3 load3_stream(RtVec3SoA v, int i) { return { __builtin_nontemporal_load(v.x + i), __builtin_nontemporal_load(v.y + i), __builtin_nontemporal_load(v.z + i) }; }
+// Measured in round 5 and not kept (profiles/r05_traversal_experiments.txt): the non-temporal hint on the triangle loads (they would leave the CU's L1 to the
+// nodes) costs +37 % -- neighbouring lanes and the two triangles of a batch share lines after all --, on the ray loads / hit stores +1.6 %.
 
 RT_DEV unsigned msb(unsigned x) { return 31u - unsigned(__clz(int(x))); }
 RT_DEV unsigned extract_byte(unsigned x, unsigned i) { return (x >> (i * 8)) & 0xffu; }
@@ -632,9 +618,10 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					unsigned relative_index = __popc(hits_imask & ~(0xffffffffu << slot_index));
 					unsigned child_node_index = child_index_base + relative_index;
 
-					// FLAT (rt_set_static_geometry has checked that both arrays stay below 4 GiB): a 32-bit byte offset from the uniform base -- `global_load ...
-					// v_offset, s[base]` -- where the general form builds a 64-bit address per lane (v_mad_u64_u32, a quarter-rate instruction, and a 64-bit move)
-					const float4 * node = (RT_OFFSETS_32 && FLAT) ? (const float4 *)((const char *)nodes + __umul24(child_node_index, 80u))
+					// FLAT (launched only while both arrays stay below 4 GiB, RtParams::geometry_below_4gib): a 32-bit byte offset from the uniform base -- `global_load ...
+					// v_offset, s[base]` -- where the general form builds a 64-bit address per lane (v_mad_u64_u32 + a 64-bit move per fetch); -0.7 % of the traversal
+					// time (round 5, one box, the shipped build measured before and after: 0.9997 / 0.9928 / 1.0001 ms per step)
+					const float4 * node = FLAT ? (const float4 *)((const char *)nodes + __umul24(child_node_index, 80u))
 					                    : (!UNIFIED && child_node_index < unsigned(p.tlas_node_count) ? p.tlas_nodes : nodes) + size_t(child_node_index) * 5;
 					float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
 					if (COUNT) count_nodes++;
@@ -703,9 +690,8 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 							int triangle_index = int(msb(triangle_group.y));
 							triangle_group.y &= ~(1u << triangle_index);
 							tri_id[k] = int(triangle_group.x) + triangle_index;
-							const float4 * tri = (RT_OFFSETS_32 && FLAT) ? (const float4 *)((const char *)triangles + unsigned(tri_id[k]) * 48u) : triangles + size_t(tri_id[k]) * 3;
-							if (RT_NT_TRIANGLES) { tri_a[k] = load4_stream(tri); tri_b[k] = load4_stream(tri + 1); tri_c[k] = load1_stream(&tri[2].x); }
-							else { tri_a[k] = tri[0]; tri_b[k] = tri[1]; tri_c[k] = tri[2].x; } // position_0, edge_1, edge_2
+							const float4 * tri = FLAT ? (const float4 *)((const char *)triangles + unsigned(tri_id[k]) * 48u) : triangles + size_t(tri_id[k]) * 3;
+							tri_a[k] = tri[0]; tri_b[k] = tri[1]; tri_c[k] = tri[2].x; // position_0, edge_1, edge_2
 						}
 					}
 					#pragma unroll
@@ -793,14 +779,8 @@ RT_DEV uint4 pack_hit(const HitRecord & h) { // Buffers.h:25-32
 struct ClosestHitSource {
 	RtVec3SoA origin, direction;
 	uint4 * hits;
-	RT_DEV void load(int i, Ray3 & ray, float & max_distance) const {
-		if (RT_NT_RAYS) { ray.origin = load3_stream(origin, i); ray.direction = load3_stream(direction, i); } else { ray.origin = load3(origin, i); ray.direction = load3(direction, i); }
-		max_distance = RT_INFINITY;
-	}
-	RT_DEV void finish(int i, const HitRecord & hit, bool) const {
-		if (RT_NT_RAYS) { uint4 h = pack_hit(hit); typedef unsigned v4u_nt __attribute__((ext_vector_type(4))); v4u_nt v = { h.x, h.y, h.z, h.w }; __builtin_nontemporal_store(v, (v4u_nt *)(hits + i)); }
-		else hits[i] = pack_hit(hit);
-	}
+	RT_DEV void load(int i, Ray3 & ray, float & max_distance) const { ray.origin = load3(origin, i); ray.direction = load3(direction, i); max_distance = RT_INFINITY; }
+	RT_DEV void finish(int i, const HitRecord & hit, bool) const { hits[i] = pack_hit(hit); }
 };
 
 // Wavefront shadow rays: a MISS adds the pre-computed illumination to the AOVs
@@ -830,10 +810,7 @@ struct ShadowQueueSource {
 struct ShadowStreamSource {
 	RtShadowBuffer buffer;
 	RtAOV radiance, direct, indirect;
-	RT_DEV void load(int i, Ray3 & ray, float & max_distance) const {
-		if (RT_NT_RAYS) { ray.origin = load3_stream(buffer.origin, i); ray.direction = load3_stream(buffer.direction, i); max_distance = load1_stream(buffer.max_distance + i); }
-		else { ray.origin = load3(buffer.origin, i); ray.direction = load3(buffer.direction, i); max_distance = buffer.max_distance[i]; }
-	}
+	RT_DEV void load(int i, Ray3 & ray, float & max_distance) const { ray.origin = load3(buffer.origin, i); ray.direction = load3(buffer.direction, i); max_distance = buffer.max_distance[i]; }
 	RT_DEV void finish(int i, const HitRecord &, bool occluded) const {
 		if (occluded) return;
 		float4 ip = buffer.illumination_and_pixel_index[i];
@@ -1370,7 +1347,7 @@ void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, hipS
 		hipLaunchKernelGGL(kernel_trace_stream_bvh8_counting, dim3(grid_counting), dim3(RT_TRACE_BLOCK), 0, stream, p, stats);
 		return;
 	}
-	if (p.entry_tlas_stack_size == 0) {   // the whole scene is one world-space tree: the engine without the TLAS / instance code
+	if (p.entry_tlas_stack_size == 0 && p.geometry_below_4gib) {   // the whole scene is one world-space tree: the engine without the TLAS / instance code (32-bit offsets; a larger scene walks the general engine from node 0)
 		static int grid_flat = trace_grid_size((const void *)kernel_trace_stream_bvh8_flat);
 		hipLaunchKernelGGL(kernel_trace_stream_bvh8_flat, dim3(grid_flat), dim3(RT_TRACE_BLOCK), 0, stream, p);
 		return;

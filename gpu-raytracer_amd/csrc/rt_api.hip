@@ -181,6 +181,7 @@ struct rt_context {
 	unsigned long long tlas_version = 0, tlas_version_in_nodes = ~0ull;   // the merged wavefront traces a copy of the TLAS inside the BLAS node array (stream_sync_tlas)
 	bool expand_bc1 = true;   // rt_set_texture_expansion: BC1 textures are decoded once, at upload (rt_types.h: RT_TEXTURE_BC1_EXPANDED)
 	size_t texture_bytes = 0; // what rt_upload_textures holds on the device
+	std::vector<float> build_boxes; size_t build_boxes_first = 0;   // rt_set_build_boxes: consumed by the next rt_build_geometry
 	size_t bvh4_node_count = 0;
 	size_t bvh8_node_count = 0, bvh2_node_count = 0, triangle_count = 0;
 	size_t mesh_count = 0;
@@ -199,7 +200,7 @@ struct rt_context {
 	// frame resources
 	void * aov_buffers[RT_AOV_COUNT][2] = { };
 	void * final_image = nullptr;
-	void * svgf_buffers[16] = { }; bool svgf_allocated = false;   // [15]: one word, RtParams::svgf_young_pixels
+	void * svgf_buffers[16] = { }; bool svgf_allocated = false;   // [15]: RtParams::svgf_young_pixels
 	size_t frame_pixels = 0; // pitch * height
 
 	// frame exchange of the tile split (rt_comm_*): this context's rank in a group of `world` contexts, each on its own GPU
@@ -517,6 +518,7 @@ int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle
 	ctx->tlas_version_in_nodes = ~0ull;
 	ctx->params.triangles  = (const float4 *)ctx->triangles;
 	ctx->params.bvh8_nodes = (const float4 *)ctx->bvh8_nodes;
+	ctx->params.geometry_below_4gib = node_count * 80 < (1ull << 32) && triangle_count * 48 < (1ull << 32);
 	return RT_OK;
 }
 
@@ -584,10 +586,18 @@ struct BlasBuildArgs { // must match kernels_blas.hip
 	TlasBox * triangle_boxes, * sorted_boxes, * mesh_boxes, * child_boxes; TlasBox * box_table; int table_levels, split_widest; int * triangle_mesh;
 	uint64_t * keys; int * ids; uint64_t * sorted_keys; int * sorted_ids;
 	int2 * range; int * runs; int * inner_count, * leaf_count, * inner_base, * leaf_base; int * level_state;
+	const float * given_boxes; int given_first, given_count;
 };
 size_t rt_blas_build_scratch_bytes(size_t triangles, size_t meshes);
 hipError_t rt_blas_build(BlasBuildArgs a, void * library_scratch, size_t library_scratch_bytes, int * pinned_state, hipStream_t stream, int * out_node_count, size_t node_capacity);
 extern "C" {
+
+int rt_set_build_boxes(rt_context * ctx, const float * boxes, size_t first_triangle, size_t count) {
+	RT_REQUIRE(ctx, ctx && (boxes || count == 0), "rt_set_build_boxes: NULL argument");
+	ctx->build_boxes.assign(boxes, boxes + 6 * count);
+	ctx->build_boxes_first = first_triangle;
+	return RT_OK;
+}
 
 int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_count, const int32_t * mesh_first_triangle, size_t mesh_count,
                       size_t reserved_tlas_nodes, int32_t * out_root_indices, int32_t * out_triangle_positions, size_t * out_node_count, float * out_build_ms) {
@@ -630,10 +640,15 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	const size_t o_table = region(split_widest ? 0 : size_t(table_levels) * T * 24);
 	const size_t library_bytes = rt_blas_build_scratch_bytes(T, M + level_capacity);
 	const size_t o_library = region(library_bytes);
+	// rt_set_build_boxes: boxes that come with some of the triangles (taken by THIS build; whatever does not fit the input is ignored)
+	std::vector<float> given_boxes; given_boxes.swap(ctx->build_boxes);
+	const size_t given_first = ctx->build_boxes_first, given_count = given_first + given_boxes.size() / 6 <= T ? given_boxes.size() / 6 : 0;
+	const size_t o_given = region(given_count * 24);
 	if ((s = device_alloc(ctx, &scratch, at))) return give_up(s);
 	char * base = (char *)scratch;
 	RT_BUILD_HIP(hipMemcpyAsync(base + o_in, triangles, T * 96, hipMemcpyHostToDevice, ctx->stream));
 	RT_BUILD_HIP(hipMemcpyAsync(base + o_first, mesh_first_triangle, (M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+	if (given_count) RT_BUILD_HIP(hipMemcpyAsync(base + o_given, given_boxes.data(), given_count * 24, hipMemcpyHostToDevice, ctx->stream));
 	RT_BUILD_HIP(hipMemsetAsync(out_nodes, 0, node_capacity * 80, ctx->stream));
 	BlasBuildArgs a;
 	a.triangle_count = int(T); a.mesh_count = int(M); a.first_node = int(reserved_tlas_nodes);
@@ -647,6 +662,7 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	a.range = (int2 *)(base + o_range); a.runs = (int *)(base + o_runs);
 	a.inner_count = (int *)(base + o_ic); a.leaf_count = (int *)(base + o_lc); a.inner_base = (int *)(base + o_ib); a.leaf_base = (int *)(base + o_lb);
 	a.level_state = (int *)(base + o_state);
+	a.given_boxes = given_count ? (const float *)(base + o_given) : nullptr; a.given_first = int(given_first); a.given_count = int(given_count);
 	RT_BUILD_HIP(hipHostMalloc((void **)&pinned, 16));
 	RT_BUILD_HIP(hipEventCreate(&t0)); RT_BUILD_HIP(hipEventCreate(&t1));
 	RT_BUILD_HIP(hipEventRecord(t0, ctx->stream));
@@ -667,6 +683,7 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	ctx->triangle_count = T; ctx->bvh8_node_count = size_t(node_count);
 	ctx->tlas_version_in_nodes = ~0ull;
 	ctx->params.triangles = (const float4 *)out_triangles; ctx->params.triangle_positions = (const float4 *)out_positions; ctx->params.bvh8_nodes = (const float4 *)out_nodes;
+	ctx->params.geometry_below_4gib = size_t(node_count) * 80 < (1ull << 32) && size_t(T) * 48 < (1ull << 32);
 	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID;
 	if (out_root_indices) for (size_t m = 0; m < M; m++) out_root_indices[m] = int32_t(reserved_tlas_nodes + m);
 	if (out_node_count) *out_node_count = size_t(node_count);
@@ -1111,7 +1128,7 @@ static int sync_svgf(rt_context * ctx) {
 			int s = device_alloc(ctx, &ctx->svgf_buffers[i], ctx->frame_pixels * elem[i]); if (s) return s;
 			RT_HIP(ctx, hipMemsetAsync(ctx->svgf_buffers[i], 0, ctx->frame_pixels * elem[i], ctx->stream));
 		}
-		{ int s = device_alloc(ctx, &ctx->svgf_buffers[15], 64); if (s) return s; RT_HIP(ctx, hipMemsetAsync(ctx->svgf_buffers[15], 0, 64, ctx->stream)); }
+		{ int s = device_alloc(ctx, &ctx->svgf_buffers[15], (RT_SVGF_YOUNG_HEADER + ctx->frame_pixels) * 4); if (s) return s; RT_HIP(ctx, hipMemsetAsync(ctx->svgf_buffers[15], 0, RT_SVGF_YOUNG_HEADER * 4, ctx->stream)); }
 		for (int k = 1; k < RT_MAX_SAMPLE_SLOTS; k++) if (ctx->slots[k].created) for (int i = 0; i < 3; i++) {
 			int s = device_alloc(ctx, &ctx->slots[k].gbuffers[i], ctx->frame_pixels * elem[i]); if (s) return s;
 			RT_HIP(ctx, hipMemsetAsync(ctx->slots[k].gbuffers[i], 0, ctx->frame_pixels * elem[i], ctx->stream));

@@ -120,6 +120,7 @@ struct RtParams {
 	int bvh_width;              // 8: CWBVH kernels (default), 4: 4-wide BVH kernels, 2: binary-BVH kernels
 	const int    * mesh_bvh_root_indices;
 	int mesh_count;                   // instances (the fused traversal launch keeps the root table of a small scene in LDS)
+	int geometry_below_4gib;          // bvh8_nodes and triangle_positions are both shorter than 4 GiB: the flattened scene's engine addresses them with 32-bit offsets
 	int entry_tlas_stack_size;        // RT_INVALID: rays start at the TLAS root; 0: node 0 is the root of the one world-space tree that holds the
 	                                  // whole scene and rays start inside it, as instance row 0 (rt_set_static_geometry)
 	int has_triangle_aliases;         // some triangles are copies that report the (instance, triangle) named in the padding of their
@@ -194,7 +195,7 @@ struct RtParams {
 	int    * history_length;
 	float4 * history_direct, * history_indirect, * history_moment, * history_normal_and_depth;
 	float4 * taa_frame_prev, * taa_frame_curr, * taa_frame_next;   // next: where kernel_taa writes the history of the following frame (swapped with prev after every filtered frame)
-	int * svgf_young_pixels;          // != 0: this frame's kernel_svgf_reproject left a pixel with fewer than 4 frames of history, kernel_svgf_variance has work; cleared by kernel_svgf_finalize
+	int * svgf_young_pixels;          // [0]: how many pixels this frame's kernel_svgf_reproject left with fewer than 4 frames of history, [RT_SVGF_YOUNG_HEADER ...]: their indices (kernel_svgf_variance_listed); emptied by kernel_svgf_finalize
 	float2 * svgf_variance[2];        // (direct.w, indirect.w) of the radiance framebuffers [0] and accumulators [1], kept in step by the filter kernels
 	float4 * svgf_normal_and_depth;   // (normal, depth) of the frame being filtered: decoded once by kernel_svgf_reproject for the variance / a-trous taps
 };
@@ -250,6 +251,7 @@ void rt_launch_trace_shadow_ao(const RtParams & p, hipStream_t stream);
 void rt_launch_sort(const RtParams & p, int bounce, int sample_index, hipStream_t stream);
 void rt_launch_material(const RtParams & p, int material_slot, int bounce, int sample_index, hipStream_t stream);
 void rt_launch_accumulate(const RtParams & p, float frames_accumulated, int pixel_offset, int pixel_count, hipStream_t stream);
+#define RT_SVGF_YOUNG_HEADER 16
 #define RT_ACCUMULATE_GROUP 8
 struct RtAccumulateGroup { int count; int first_sample[RT_ACCUMULATE_GROUP], sample_count[RT_ACCUMULATE_GROUP], slot_base[RT_ACCUMULATE_GROUP]; };
 void rt_launch_accumulate_group(const RtParams & p, const RtAccumulateGroup & group, int pixel_offset, int pixel_count, hipStream_t stream);

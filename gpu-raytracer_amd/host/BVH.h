@@ -210,6 +210,8 @@ struct SBVHBuilder {
 // host threads; one triangle reference per leaf, a triangle cut by spatial splits is listed once per leaf that holds a part.
 namespace StaticBVHBuilder {
 	void build(BVH2 & bvh, const std::vector<Triangle> & triangles, int thread_count = 0);
+	// Early split clipping for the device builder: per reference the triangle it is a piece of and the piece's box (6 floats: min, max)
+	void presplit(const std::vector<Triangle> & triangles, float limit, std::vector<int> & source, std::vector<float> & boxes, int max_pieces = 64);
 }
 
 namespace BVHOptimizer {

@@ -65,6 +65,10 @@ struct CPUConfig {
 	// Where the bottom-level trees of a CWBVH scene are built: 0 = on the host (SAH / SBVH builder + BVH8Converter, byte-identical
 	// to the reference's), 1 = on the device (rt_build_geometry: a linear BVH over all meshes at once; fast to build, dearer to traverse)
 	int  device_blas = 0;
+	// ... and, for the flattened tree of such a build, early split clipping in front of it: a triangle longer than this fraction of the flattened
+	// geometry's longest side is cut into pieces, each piece a reference with its own box (StaticBVHBuilder::presplit, rt_set_build_boxes) -- the
+	// Morton-order builder has no spatial splits of its own. 0: off.
+	float device_presplit = 0.08f;   // (Sponza, flattened, ms per step of the benchmark: 0 1.72, 0.3 1.67, 0.15 1.61, 0.1 1.56, 0.075 1.55, 0.05 1.62, 0.025 1.62; host tree 1.43: profiles/r05_device_blas_presplit.txt)
 	// Static geometry: 1 = every instance that has not been seen moving and whose mesh is not instanced more than twice (two or
 	// more such instances) is flattened into ONE bottom-level tree -- a ray then walks one well-built tree (StaticBVHBuilder:
 	// SAH object and spatial splits) instead of entering a dozen overlapping per-mesh trees; hits still name the scene's

@@ -312,6 +312,7 @@ void Integrator::init_geometry() {
 		bool build_on_device = ctx && cpu_config.device_blas > 0;
 		std::vector<int> source_member, source_triangle;   // per triangle of the members, in member order: its member, its index among all original triangles
 		std::vector<int> copy_source;                      // per copy, in device order: which of those it copies
+		std::vector<float> copy_boxes;                     // device build with early split clipping: the box of the piece each copy stands for (6 floats)
 		instance_has_moved.resize(mesh_count, 0);
 		if (cpu_config.merge_static > 0 && !wants_device_tlas()) {
 			flat.members = flatten_candidates();
@@ -336,8 +337,19 @@ void Integrator::init_geometry() {
 			if (prebuilt) { world.swap(prebuilt->world); source_member.swap(prebuilt->source_member); source_triangle.swap(prebuilt->source_triangle); }
 			else world = world_triangles_of(flat.members, &source_member, &source_triangle);
 			if (build_on_device) {
-				copy_source.resize(source_member.size());
-				for (size_t c = 0; c < copy_source.size(); c++) copy_source[c] = int(c);
+				// the device's builder cuts at Morton bits and has no spatial splits: the few triangles that span a good part of the scene are cut here, into
+				// references with boxes of their own (one copy per piece; the copies name their original as every copy does)
+				float longest = 0.0f;
+				if (cpu_config.device_presplit > 0.0f) {
+					AABB all = AABB::create_empty();
+					for (const Triangle & t : world) { all.expand(t.position_0); all.expand(t.position_1); all.expand(t.position_2); }
+					for (int d = 0; d < 3; d++) longest = std::max(longest, all.max[d] - all.min[d]);
+				}
+				if (longest > 0.0f) StaticBVHBuilder::presplit(world, cpu_config.device_presplit * longest, copy_source, copy_boxes);
+				else {
+					copy_source.resize(source_member.size());
+					for (size_t c = 0; c < copy_source.size(); c++) copy_source[c] = int(c);
+				}
 			} else {
 				BVH8 wide;
 				if (prebuilt) {   // the worker thread built exactly this tree while the frame loop went on (build_tlas, "a member moved")
@@ -396,6 +408,7 @@ void Integrator::init_geometry() {
 			first[mesh_data_count] = int(index_total);
 			first[tree_count]      = int(triangle_count);
 			size_t built_nodes = 0;
+			if (flat.built && copy_boxes.size() == 6 * (triangle_count - index_total)) check(rt_set_build_boxes(ctx, copy_boxes.data(), index_total, triangle_count - index_total));
 			check(rt_build_geometry(ctx, aggregated_triangles.data(), triangle_count, first.data(), tree_count, 2 * mesh_count, roots.data(), position.data(), &built_nodes, &device_blas_build_ms));
 			for (size_t m = 0; m < mesh_data_count; m++) mesh_data_bvh_offsets[m] = roots[m];
 			for (int & device_index : reverse_indices) device_index = position[device_index];

@@ -66,6 +66,7 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "enable_scene_update")                 cpu_config.enable_scene_update = value != 0;
 	else if (k == "device_tlas")                         cpu_config.device_tlas = int(value);
 	else if (k == "device_blas")                         cpu_config.device_blas = int(value);
+	else if (k == "device_presplit")                     cpu_config.device_presplit = float(value);
 	else if (k == "merge_static")                        cpu_config.merge_static = int(value);
 	else if (k == "static_primitive_cost")               cpu_config.static_primitive_cost = float(value);
 	else if (k == "static_mesh_copy_limit_mb")           cpu_config.static_mesh_copy_limit_mb = int(value);
@@ -648,6 +649,19 @@ void * grt_build_blas_variant(const float * tris24, int n, int spatial_splits, i
 		{ BVH8Converter converter(md->bvh8, md->bvh2); if (const char * c = getenv("GRT_PRIMITIVE_COST")) converter.primitive_cost = float(atof(c)); converter.convert(); }
 		return md;
 	GRT_CATCH(nullptr)
+}
+// StaticBVHBuilder::presplit (early split clipping in front of the device's BLAS build) on `n` host triangles: writes up to `capacity` references
+// (source triangle, 6 floats of box each) and returns how many there are (may exceed capacity: call again with room).
+int grt_static_presplit(const float * tris24, int n, float limit, int * out_source, float * out_boxes, int capacity) {
+	GRT_TRY
+		std::vector<Triangle> triangles(static_cast<size_t>(n));
+		memcpy((void *)triangles.data(), tris24, size_t(n) * sizeof(Triangle));
+		std::vector<int> source; std::vector<float> boxes;
+		StaticBVHBuilder::presplit(triangles, limit, source, boxes);
+		int count = int(source.size());
+		if (count <= capacity) { memcpy(out_source, source.data(), size_t(count) * sizeof(int)); memcpy(out_boxes, boxes.data(), size_t(count) * 6 * sizeof(float)); }
+		return count;
+	GRT_CATCH(-1)
 }
 // The binary tree of cpu_config.bvh_type (SAH or SBVH), optionally leaf-collapsed as for a
 // file-loaded mesh, and its 4-wide form: query with "device_bvh2_nodes" / "device_bvh2_indices" /

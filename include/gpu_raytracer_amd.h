@@ -144,7 +144,8 @@ const char * rt_version(void);
  *   5  rt_set_texture_expansion, rt_texture_bytes (additions only; BC1 textures are decoded at upload unless asked otherwise)
  *   6  rt_set_svgf_tiles, rt_set_stream_batch (additions only; 5 and 6 also carried rt_set_node_format / rt_set_node_cache)
  *   7  rt_set_node_format (a 96-byte decoded copy of the node array) and rt_set_node_cache (the top of the flattened tree in LDS) REMOVED:
- *      both measured slower than the 80-byte walk on MI355X (profiles/r04_traversal_experiments.txt items 2 and 4) and were off by default
+ *      both measured slower than the 80-byte walk on MI355X (profiles/r04_traversal_experiments.txt items 2 and 4) and were off by default;
+ *      rt_set_build_boxes added
  * Check `rt_abi_version() == RT_ABI_VERSION` once after loading the library.                                          */
 #define RT_ABI_VERSION 7
 int rt_abi_version(void);
@@ -190,6 +191,13 @@ int rt_set_static_geometry(rt_context * ctx, int32_t whole_scene);
  * traverse than the SAH tree; closest hits are the same. rt_read_geometry returns what was built (host views, checker).   */
 int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_count, const int32_t * mesh_first_triangle, size_t mesh_count,
                       size_t reserved_tlas_nodes, int32_t * out_root_indices, int32_t * out_triangle_positions, size_t * out_node_count, float * out_build_ms);
+/* Spatial splits for the build above, decided by the caller (early split clipping): triangles [first_triangle, first_triangle + count) of the NEXT
+ * rt_build_geometry are references -- copies of triangles that were cut into pieces, one copy per piece -- and `boxes` (6 floats each: min xyz,
+ * max xyz) are the pieces' boxes. The tree is built over those boxes (intersected with the triangle's own), a leaf still tests the whole
+ * triangle, so hits do not change; what changes is how many nodes a ray walks past a floor or wall triangle that spans half the scene
+ * (the reference gets this from SBVHBuilder.cpp's spatial splits). Consumed by one build; the flattened static geometry uses it
+ * (host/Integrator.cpp, cpu_config.device_presplit), whose copies carry the names of their originals (rt_upload_triangle_aliases).        */
+int rt_set_build_boxes(rt_context * ctx, const float * boxes, size_t first_triangle, size_t count);
 int rt_read_geometry(rt_context * ctx, void * out_triangles, void * out_bvh8_nodes);
 int rt_upload_tlas(rt_context * ctx, const void * tlas_nodes, size_t tlas_node_count);
 /* Replaces `bvh2_nodes` (Integrator.cpp:205-206): binary SAH BVH, 32 B nodes, for

@@ -22,9 +22,11 @@ pytestmark = pytest.mark.gpu
 REL_L1_TOL = 1e-4
 
 
-def check_blas(nodes, triangles, root, seen_triangles):
+def check_blas(nodes, triangles, root, seen_triangles, is_reference=None):
     """Structural invariants of one BLAS (nodes: (n, 80) uint8 of the whole node array, triangles: (t, 24) float32 device
-    triangles in leaf order); counts every triangle it finds in a leaf in `seen_triangles`, returns the number of nodes."""
+    triangles in leaf order); counts every triangle it finds in a leaf in `seen_triangles`, returns the number of nodes.
+    is_reference[t]: triangle t is a copy in the flattened tree, i.e. possibly one PIECE of an original that early split clipping
+    has cut (cpu_config.device_presplit): its leaf box holds the piece, so it lies inside the triangle's box instead of around it."""
     words = nodes.view(np.uint32).reshape(-1, 20)
     origin = words[:, 0:3].copy().view(np.float32)
     scale = (((words[:, 3:4] >> (8 * np.arange(3))) & 0xff).astype(np.uint32) << 23).view(np.float32)
@@ -60,6 +62,14 @@ def check_blas(nodes, triangles, root, seen_triangles):
                 assert 0 <= first and first + count <= len(triangles)
                 seen_triangles[first:first + count] += 1
                 clo, chi = tri_lo[first:first + count].min(axis=0), tri_hi[first:first + count].max(axis=0)
+                if is_reference is not None and is_reference[first:first + count].any():
+                    # pieces: the box overlaps the triangles' and does not stick out of it by more than the quantisation grid and the padding of flat boxes
+                    grid = scale[k] + 0.01
+                    assert (hi > lo).all() and (lo >= clo - grid).all() and (hi <= chi + grid).all() and (hi >= clo).all() and (lo <= chi).all(), (k, s, lo, clo, hi, chi)
+                    # what the nodes above have to contain is the pieces' own box, which this leaf box is the outward rounding of: less than one grid step of
+                    # THIS node per side, one more where a flat box was given its thickness
+                    # (an upper bound of the pieces' minimum and a lower bound of their maximum: all the assertions below need)
+                    clo, chi = lo + 2 * scale[k], hi - 2 * scale[k]
             assert (hi > lo).all(), (k, s, lo, hi)      # the node test is `tmin < tmax`: a child box of zero thickness is never entered
             slack = 1e-5 * np.maximum(np.abs(clo), np.abs(chi)) + 1e-30
             assert (lo <= clo + slack).all() and (hi >= chi - slack).all(), (k, s, lo, clo, hi, chi)
@@ -114,7 +124,13 @@ def test_device_built_trees_are_valid_and_trace_like_the_host_built_ones(grt, or
             # (b) the recursive check (child boxes, numbering, offsets) on a sample of the trees -- all of them on a small scene
             sample = distinct_roots if len(distinct_roots) <= 16 else distinct_roots[::8]
             seen = np.zeros(len(triangles), np.int32)
-            tree_nodes = sum(check_blas(nodes, triangles, root, seen) for root in sample)
+            aliases = pt.array("alias_mesh_ids")
+            is_reference = (aliases >= 0) if len(aliases) == len(triangles) else np.zeros(len(triangles), bool)
+            if pt.static_geometry_members:   # the flattened tree, built over the pieces of early split clipping: its boxes hold pieces
+                flat_root = pt.static_geometry_top_levels[0]
+                if flat_root not in sample: sample = list(sample) + [flat_root]
+                assert scene_name != "sponza" or int(is_reference.sum()) > 1.02 * (len(triangles) - int(is_reference.sum()))   # Sponza: the cut triangles add > 2 % references
+            tree_nodes = sum(check_blas(nodes, triangles, root, seen, is_reference) for root in sample)
             assert seen.max() == 1 and tree_nodes <= len(nodes) - 2 * scene.mesh_count
         o, d = rays_for(view, w, h, 3, extent)
         hits, _ = grt.trace_rays(pt.ctx, o, d)

@@ -444,3 +444,46 @@ def test_static_bvh_builder_survives_non_finite_vertices(grt):
         broken = triangles.copy(); broken[5, 1, 2] = poison; broken[100, 0, 0] = poison
         nodes, indices, wide = build_static(grt, broken)
         assert len(indices) >= 2000 and sorted(set(indices.tolist())) == list(range(2000)) and wide.size > 0
+
+
+def test_early_split_clipping_covers_every_triangle_with_the_boxes_of_its_pieces(grt):
+    """StaticBVHBuilder::presplit (in front of the device's Morton-order BLAS build, which has no spatial splits): a triangle longer than the limit
+    is cut into pieces, each a reference with the piece's box. What the tree needs of those boxes: every point of a triangle lies in the box of
+    one of ITS pieces (a ray that hits the triangle there walks into a leaf that holds it), no piece's box sticks out of the triangle's own box
+    by more than the ulp it is widened by, pieces are no longer than the limit, and a triangle within the limit stays one reference."""
+    import ctypes
+    lib = grt.host_lib()
+    lib.grt_static_presplit.restype = ctypes.c_int
+    lib.grt_static_presplit.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    rng = np.random.default_rng(7)
+    n = 400
+    tris = np.zeros((n, 24), np.float32)
+    centre = rng.uniform(-10, 10, (n, 1, 3))
+    size = np.where(rng.random((n, 1, 1)) < 0.15, rng.uniform(5, 40, (n, 1, 1)), rng.uniform(0.01, 0.5, (n, 1, 1)))   # a few huge ones among the small
+    corners = (centre + rng.normal(size=(n, 3, 3)) * size).astype(np.float32)
+    corners[::17, :, 1] = corners[::17, :1, 1]                                   # axis-aligned (flat) ones, like a floor
+    tris[:, 0:9] = corners.reshape(n, 9)
+    tris[:, 9:18] = np.tile(np.array([0, 1, 0], np.float32), (n, 3))             # (normals / uvs ride along untouched)
+    limit = 2.0
+    source = np.zeros(64 * n, np.int32); boxes = np.zeros((64 * n, 6), np.float32)
+    count = lib.grt_static_presplit(tris.ctypes.data, n, ctypes.c_float(limit), source.ctypes.data, boxes.ctypes.data, len(source))
+    assert n < count <= len(source)
+    source, boxes = source[:count], boxes[:count]
+    assert (np.diff(source) >= 0).all() and set(source.tolist()) == set(range(n))   # pieces of a triangle are consecutive, every triangle has some
+    lo_t, hi_t = corners.min(axis=1), corners.max(axis=1)
+    pieces = np.bincount(source, minlength=n)
+    extent_t = (hi_t - lo_t).max(axis=1)
+    assert (pieces[extent_t <= limit] == 1).all() and (pieces[extent_t > 2 * limit] >= 2).all() and pieces.max() <= 64
+    pad = 0.01 + 1e-5 * np.abs(np.concatenate([lo_t, hi_t], axis=1)).max(axis=1)    # a flat box is padded by 0.001 (AABB::fix_if_needed), a cut one widened by an ulp
+    assert (boxes[:, :3] >= lo_t[source] - pad[source, None]).all() and (boxes[:, 3:] <= hi_t[source] + pad[source, None]).all()
+    assert (boxes[:, 3:] > boxes[:, :3]).all()                                       # no box of zero thickness (the node test is strict)
+    uncapped = pieces[source] < 60
+    assert ((boxes[:, 3:] - boxes[:, :3]).max(axis=1)[uncapped] <= limit + 0.01).all()
+    # coverage: random points of every triangle
+    for t in np.flatnonzero(pieces > 1)[:60]:
+        u = rng.random((300, 2)); flip = u.sum(axis=1) > 1; u[flip] = 1 - u[flip]
+        pts = corners[t, 0] + u[:, :1] * (corners[t, 1] - corners[t, 0]) + u[:, 1:] * (corners[t, 2] - corners[t, 0])
+        mine = boxes[source == t]
+        tol = 1e-5 * np.abs(corners[t]).max()                                    # the points themselves are rounded
+        inside = ((pts[:, None, :] >= mine[None, :, :3] - tol) & (pts[:, None, :] <= mine[None, :, 3:] + tol)).all(axis=2).any(axis=1)
+        assert inside.all(), (int(t), int((~inside).sum()))

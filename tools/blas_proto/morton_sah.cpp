@@ -114,6 +114,9 @@ static int build_node(Tree & t, const Build & b, int lo, int hi) {
 		for (int c = 0; c < count; c++) { int n = begin[c + 1] - begin[c]; if (n <= 3) continue;
 			float area = range_box(b.sbox, begin[c], begin[c + 1]).area();
 			float k = !b.area_first ? float(n) : b.candidates == -1 ? area : b.candidates == -2 ? area * sqrtf(float(n)) : b.candidates == -3 ? area * log2f(float(n)) : area * n;
+			// -4 / -5 / -6: largest area first, but a SMALL piece (4 .. 6 / 9 / 12 triangles) -- which would otherwise become a whole node of its own for a handful of triangles -- is
+			// cut first as long as the node has slots for its halves (round 5: node steps are what the device tree has too many of)
+			if (b.candidates <= -4) { int small = b.candidates == -4 ? 6 : b.candidates == -5 ? 9 : 12; k = area; if (n <= small) k += 1e30f; }
 			if (k > key) { key = k; pick = c; } }
 		if (pick < 0) break;
 		int cut = b.policy == RECORDED ? recorded_split(begin[pick], begin[pick + 1]) : b.policy == LBVH ? lbvh_split(b.keys, begin[pick], begin[pick + 1]) : b.policy == SAH_ALIGNED ? aligned_split(b, begin[pick], begin[pick + 1], b.candidates) : sah_split(b, begin[pick], begin[pick + 1], 3);
@@ -159,6 +162,36 @@ int main(int argc, char ** argv) {
 	tris.resize(tri_count); tbox.resize(tri_count); Box scene;
 	for (int i = 0; i < tri_count; i++) { const float * r = &raw[size_t(i) * 9]; tris[i] = { { r[0], r[1], r[2] }, { r[3], r[4], r[5] }, { r[6], r[7], r[8] } };
 		V v[3] = { tris[i].p0, tris[i].p0 + tris[i].e1, tris[i].p0 + tris[i].e2 }; Box b; for (auto & p : v) { Box q; q.lo[0] = q.hi[0] = p.x; q.lo[1] = q.hi[1] = p.y; q.lo[2] = q.hi[2] = p.z; b.grow(q); } tbox[i] = b; scene.grow(b); }
+	// Early split clipping (round 5): a triangle whose box is longer than `presplit` x the scene's longest side along some axis is cut in two at the middle of
+	// that axis, the pieces clipped (Sutherland-Hodgman) and boxed tightly, and so on; every piece becomes a REFERENCE with the triangle's data and its own box --
+	// what the flattened tree's copies already are. Blind (no cost function), one thread per triangle on a device: the question is how close it brings the Morton
+	// build to the host's SAH + spatial-split tree.
+	const float presplit = argc > 5 ? float(atof(argv[5])) : 0.0f;
+	if (presplit > 0.0f) {
+		float longest = 0; for (int d = 0; d < 3; d++) longest = std::max(longest, scene.hi[d] - scene.lo[d]);
+		const float limit = presplit * longest;
+		std::vector<Tri> rt; std::vector<Box> rb;
+		struct Piece { std::vector<V> poly; };
+		for (int i = 0; i < tri_count; i++) {
+			std::vector<Piece> work; work.push_back({ { tris[i].p0, tris[i].p0 + tris[i].e1, tris[i].p0 + tris[i].e2 } });
+			int made = 0;
+			while (!work.empty()) {
+				Piece pc = work.back(); work.pop_back();
+				Box b; for (auto & q : pc.poly) { Box c; c.lo[0] = c.hi[0] = q.x; c.lo[1] = c.hi[1] = q.y; c.lo[2] = c.hi[2] = q.z; b.grow(c); }
+				int axis = 0; float ext = 0; for (int d = 0; d < 3; d++) if (b.hi[d] - b.lo[d] > ext) { ext = b.hi[d] - b.lo[d]; axis = d; }
+				if (ext <= limit || made + int(work.size()) >= 63) { rt.push_back(tris[i]); rb.push_back(b); made++; continue; }
+				float mid = 0.5f * (b.lo[axis] + b.hi[axis]);
+				auto comp = [&](const V & v) { return axis == 0 ? v.x : axis == 1 ? v.y : v.z; };
+				Piece lo_p, hi_p; size_t n = pc.poly.size();
+				for (size_t k = 0; k < n; k++) { V a = pc.poly[k], c = pc.poly[(k + 1) % n]; float fa = comp(a) - mid, fc = comp(c) - mid;
+					if (fa <= 0) lo_p.poly.push_back(a); if (fa >= 0) hi_p.poly.push_back(a);
+					if ((fa < 0 && fc > 0) || (fa > 0 && fc < 0)) { float t = fa / (fa - fc); V x = a + (c - a) * t; lo_p.poly.push_back(x); hi_p.poly.push_back(x); } }
+				if (lo_p.poly.size() >= 3) work.push_back(lo_p); if (hi_p.poly.size() >= 3) work.push_back(hi_p);
+			}
+		}
+		printf("early split clipping at %.4f of the scene's longest side: %d triangles -> %zu references (+%.1f %%)\n", presplit, tri_count, rt.size(), 100.0 * (double(rt.size()) / tri_count - 1.0));
+		tris.swap(rt); tbox.swap(rb); tri_count = int(tris.size());
+	}
 	const int bits = argc > 2 ? atoi(argv[2]) : 10;   // Morton bits per axis (the device build: 10)
 	const int size_every = argc > 3 ? atoi(argv[3]) : 0;   // extended Morton codes (Vinkler et al. 2017): a bit of the triangle's SIZE after every so many position bits (0: none)
 	const int size_first = argc > 4 ? atoi(argv[4]) : 0;   // position bits in front of the first size bit
@@ -195,7 +228,7 @@ int main(int argc, char ** argv) {
 
 	struct Variant { const char * name; Policy policy; bool area_first; int candidates; };
 	const Variant variants[] = { { "linear BVH (highest differing bit, widest piece first)", LBVH, false, 0 }, { "linear BVH cuts, largest area x count first", LBVH, true, 0 },
-		{ "linear BVH cuts, largest AREA first", LBVH, true, -1 }, { "linear BVH cuts, largest area x sqrt(count) first", LBVH, true, -2 }, { "linear BVH cuts, largest area x log2(count) first", LBVH, true, -3 },
+		{ "linear BVH cuts, largest AREA first", LBVH, true, -1 }, { "linear BVH cuts, area first, pieces of <= 6 triangles cut first", LBVH, true, -4 }, { "linear BVH cuts, area first, pieces of <= 9 cut first", LBVH, true, -5 }, { "linear BVH cuts, area first, pieces of <= 12 cut first", LBVH, true, -6 }, { "linear BVH cuts, largest area x sqrt(count) first", LBVH, true, -2 }, { "linear BVH cuts, largest area x log2(count) first", LBVH, true, -3 },
 		{ "SAH cut over ALL positions of the Morton order, widest first", SAH_EXACT, false, 0 }, { "SAH cut over all positions, largest area x count first", SAH_EXACT, true, 0 },
 		{ "SAH cut over 63 candidates x 3 refinements, largest area x count first", SAH_CANDIDATES, true, 63 }, { "SAH cut over 15 candidates x 3 refinements, largest area x count first", SAH_CANDIDATES, true, 15 },
 		{ "SAH over the cell boundaries of the next 2 Morton bits, area x count first", SAH_ALIGNED, true, 2 }, { "SAH over the cell boundaries of the next 3 Morton bits, area x count first", SAH_ALIGNED, true, 3 },
