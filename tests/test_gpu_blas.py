@@ -129,7 +129,7 @@ def test_device_built_trees_are_valid_and_trace_like_the_host_built_ones(grt, or
             if pt.static_geometry_members:   # the flattened tree, built over the pieces of early split clipping: its boxes hold pieces
                 flat_root = pt.static_geometry_top_levels[0]
                 if flat_root not in sample: sample = list(sample) + [flat_root]
-                assert scene_name != "sponza" or int(is_reference.sum()) > 1.02 * (len(triangles) - int(is_reference.sum()))   # Sponza: the cut triangles add > 2 % references
+                assert scene_name != "sponza" or int(is_reference.sum()) > 1.005 * (len(triangles) - int(is_reference.sum()))   # Sponza at the default fraction 0.08: the cut triangles add 1.75 % references
             tree_nodes = sum(check_blas(nodes, triangles, root, seen, is_reference) for root in sample)
             assert seen.max() == 1 and tree_nodes <= len(nodes) - 2 * scene.mesh_count
         o, d = rays_for(view, w, h, 3, extent)
@@ -238,8 +238,10 @@ def test_device_build_on_awkward_meshes(grt, oracle, tmp_path):
             nodes = pt.array("bvh8_nodes").view(np.uint8).reshape(-1, 80)
             triangles = pt.array("triangles").view(np.float32).reshape(-1, 24)
             seen = np.zeros(len(triangles), np.int32)
+            aliases = pt.array("alias_mesh_ids")   # copies in the flattened tree: early split clipping may have cut their originals into pieces (the 30-unit triangles of scales.obj)
+            is_reference = (aliases >= 0) if len(aliases) == len(triangles) else np.zeros(len(triangles), bool)
             for root in sorted(set(int(r) & 0x7fffffff for r in pt.array("mesh_bvh_root_indices"))):
-                check_blas(nodes, triangles, root, seen)
+                check_blas(nodes, triangles, root, seen, is_reference)
             assert (seen == 1).all(), (int((seen == 0).sum()), int((seen > 1).sum()))
         o, d, _ = view.generate(0, 0, w * h)
         eo = rng.uniform(-10, 10, (3, 20000)).astype(np.float32) * np.array([[1.0], [0.3], [0.7]], np.float32)
