@@ -89,6 +89,9 @@ struct CPUConfig {
 	// ... and what a triangle test costs relative to a node step when that tree's binary form is collapsed into 8-wide nodes
 	// (BVH8Converter: 1 in the reference; here a triangle test runs with a quarter of a wave's lanes, a node step with most)
 	float static_primitive_cost = 1.0f;
+	// ... and early split clipping (StaticBVHBuilder::presplit, as in front of the device build) in front of that builder's own SAH + spatial splits: fraction of
+	// the geometry's longest side above which a triangle is cut blindly first. 0: off.
+	float static_presplit = 0.0f;
 
 	IntegratorType integrator = IntegratorType::PATHTRACER; // read by the command-line front end
 

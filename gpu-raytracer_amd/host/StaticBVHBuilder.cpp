@@ -240,6 +240,19 @@ void StaticBVHBuilder::build(BVH2 & bvh, const std::vector<Triangle> & triangles
 	std::vector<Ref> refs(n);
 	AABB root_box = AABB::create_empty();
 	for (size_t i = 0; i < n; i++) { refs[i] = { triangles[i].get_aabb(), int(i) }; root_box.expand(refs[i].box); }
+	if (cpu_config.static_presplit > 0.0f) {   // early split clipping in front of the SAH + spatial-split build as well (experiment of round 5, off: see Config.h)
+		float longest = 0.0f;
+		for (int d = 0; d < 3; d++) longest = std::max(longest, root_box.max[d] - root_box.min[d]);
+		std::vector<int> source; std::vector<float> boxes;
+		presplit(triangles, cpu_config.static_presplit * longest, source, boxes);
+		refs.resize(source.size());
+		for (size_t r = 0; r < source.size(); r++) {
+			AABB box; box.min = Vector3(boxes[6 * r], boxes[6 * r + 1], boxes[6 * r + 2]); box.max = Vector3(boxes[6 * r + 3], boxes[6 * r + 4], boxes[6 * r + 5]);
+			refs[r] = { box, source[r] };
+			root_box.expand(box);   // (a piece's box is an ulp wider than the piece)
+		}
+		n = refs.size();
+	}
 	Builder builder { triangles, 1.0f / root_box.surface_area(), cpu_config.sbvh_alpha };
 
 	// top of the tree on this thread, breadth-first, until the pieces are small enough to hand out

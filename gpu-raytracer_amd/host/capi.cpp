@@ -67,6 +67,7 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "device_tlas")                         cpu_config.device_tlas = int(value);
 	else if (k == "device_blas")                         cpu_config.device_blas = int(value);
 	else if (k == "device_presplit")                     cpu_config.device_presplit = float(value);
+	else if (k == "static_presplit")                     cpu_config.static_presplit = float(value);
 	else if (k == "merge_static")                        cpu_config.merge_static = int(value);
 	else if (k == "static_primitive_cost")               cpu_config.static_primitive_cost = float(value);
 	else if (k == "static_mesh_copy_limit_mb")           cpu_config.static_mesh_copy_limit_mb = int(value);

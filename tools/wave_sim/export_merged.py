@@ -16,6 +16,7 @@ out = sys.argv[2] if len(sys.argv) > 2 else "/tmp/wave_sim_%s_merged.bin" % name
 sbvh = int(sys.argv[3]) if len(sys.argv) > 3 else 0; optimize = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 w, h = 1920, 1080
 grt.config_reset()
+if os.environ.get("STATIC_PRESPLIT"): grt.config_set(static_presplit=float(os.environ["STATIC_PRESPLIT"]))
 scene = grt.Scene(grt.scene_path(name)); scene.wait_until_loaded()
 pt = grt.Pathtracer(scene, w, h, device=-1); pt.update()
 tris = np.concatenate([scene.mesh_data_array(m, "triangles", np.float32).reshape(-1, 24) for m in range(scene.mesh_data_count)])
