@@ -553,6 +553,13 @@ def main():
         if exchange == "native":
             check(lib.rt_all_gather_framebuffer(ctx))
             return
+        if world == 1 and not os.environ.get("BENCH_EMULATE_THROUGH_TORCH"):
+            # --emulate-world: what the native exchange does on this rank minus the collective itself -- pack this rank's tiles and unpack the whole frame, both on the
+            # context's stream, no hand-over to another stream (the torch path below costs the emulation 0.4 ms of host round trips per burst that a real rank, which
+            # exchanges through rt_all_gather_framebuffer, does not have: profiles/r04_tile_split_rank_timeline.txt)
+            check(lib.rt_pack_pixels(ctx, gathered.data_ptr(), split.tile_pixels, rank, split_world, split.tiles_per_rank))
+            check(lib.rt_unpack_pixels(ctx, gathered.data_ptr(), split.tile_pixels, split_world, split.tiles_per_rank))
+            return
         torch_stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.rt_context_wait_for_stream(ctx, torch_stream))
         check(lib.rt_pack_pixels(ctx, packed.data_ptr(), split.tile_pixels, rank, split_world, split.tiles_per_rank))
