@@ -670,8 +670,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     check(lib.rt_synchronize(ctx))
-    # HIP events around EVERY traversal launch of the timed region, each on the stream the launch runs on
-    grt.set_profiling(ctx, 0 if os.environ.get("BENCH_NO_LAUNCH_TIMING") else 2)
+    # HIP events around EVERY traversal launch of the timed region, each on the stream the launch runs on -- at N = 1, the configuration the roofline record is
+    # quoted on. A rank of a tile split runs launches an N-th the size: the two event packets per launch are 0.38 ms of its 6 ms burst at N = 8 (measured:
+    # 0.303 -> 0.284 ms per step, profiles/r05_tile_split_bound.txt), so there the timed region runs bare and an untimed repeat behind it carries the events.
+    events_in_timed_region = split_world == 1 and not os.environ.get("BENCH_NO_LAUNCH_TIMING")
+    grt.set_profiling(ctx, 2 if events_in_timed_region else 0)
     t0 = time.perf_counter()
     run(plan)
     check(lib.rt_synchronize(ctx))
@@ -679,6 +682,10 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if not events_in_timed_region and not os.environ.get("BENCH_NO_LAUNCH_TIMING"):
+        grt.set_profiling(ctx, 2)
+        run(plan)
+        check(lib.rt_synchronize(ctx))
     launch_ms = grt.launch_timings(ctx, 0).astype(np.float64)
     shadow_launch_ms = grt.launch_timings(ctx, 1).astype(np.float64)
     grt.set_profiling(ctx, False)
@@ -725,7 +732,7 @@ def main():
                                  "launch_gbps": spread(per_launch_gbps[big]), "rays_per_launch": int(launch_rays[big].mean())},
                 "closest_hit_share_of_bytes": round(float(launch_closest_bytes.sum() / launch_bytes.sum()), 3),
                 "time_share_of_step": round(float(launch_ms.sum() / (elapsed * 1e3)), 3),
-                "note": "achieved = sum of the algorithmic bytes (SURVEY 8d; counted by the counting variant on the same launches) of ALL traversal launches of the timed region / sum of their HIP-event durations; one launch at a time is resident (single stream), so a duration is the kernel's own. steady_state = launches with at least half the rays of the largest. Working set (%.1f MB nodes + %.1f MB triangle positions%s) is L2 / Infinity-Cache resident: algorithmic bytes >> DRAM traffic" % (pt.array("bvh8_nodes").size / 1e6, pt.array("triangles").size // 24 * 48 / 1e6, ", the per-mesh trees and the flattened tree over copies of their triangles; rays only touch the latter" if pt.static_geometry_members else ""),
+                "note": ("" if events_in_timed_region else "N > 1: the launch durations come from an untimed repeat of the timed plan (the timed region itself runs without per-launch events). ") + "achieved = sum of the algorithmic bytes (SURVEY 8d; counted by the counting variant on the same launches) of ALL traversal launches of the timed region / sum of their HIP-event durations; one launch at a time is resident (single stream), so a duration is the kernel's own. steady_state = launches with at least half the rays of the largest. Working set (%.1f MB nodes + %.1f MB triangle positions%s) is L2 / Infinity-Cache resident: algorithmic bytes >> DRAM traffic" % (pt.array("bvh8_nodes").size / 1e6, pt.array("triangles").size // 24 * 48 / 1e6, ", the per-mesh trees and the flattened tree over copies of their triangles; rays only touch the latter" if pt.static_geometry_members else ""),
             })
         else:
             total_ms = float(launch_ms.sum()) if len(launch_ms) else float("nan")

@@ -59,6 +59,21 @@
 #define RT_N_W 16           // dynamic fetch: lost lane-iterations before refilling  (N_w = 16 of 32); swept 0/1 .. 24/64, profiles/r01_trace_fetch_block.txt
 #endif
 
+// Issue priority of a wave by phase of its round (s_setprio), flattened scene's wide engine only. RT_PRIO is five decimal digits, the level (0-3) of: the top of a
+// round until the node's five loads are out | the node test | from there until the triangles' loads are out | the triangle tests | the end of the round (retire / pop).
+// 0: no s_setprio at all. A round is two dependent memory round trips with ~220 and ~120 vector instructions behind them; a wave that is about to ISSUE loads should win
+// the arbitration against waves that grind through a test, so that its latency starts running. Measured (round 5, profiles/r05_traversal_experiments.txt, traversal ms
+// per step, shipped = no hint): 20202 0.958 / 0.977 / 0.959, 0.962 against 0.975 / 0.979 / 0.971, 0.966, 0.969 on three boxes (-0.2 ... -1.7 %); 10101 and 20222 the same;
+// the inverse (02020: the tests first) +1.9 %. Same instructions, same floats: a scheduling hint only.
+#ifndef RT_PRIO
+#define RT_PRIO 20202
+#endif
+#ifndef RT_PRIO_EVERY_ENGINE
+#define RT_PRIO_EVERY_ENGINE 0   // 1: the engine that walks a TLAS takes the hint as well (experiment)
+#endif
+#define RT_SETPRIO(phase) do { if (RT_PRIO && (FLAT || RT_PRIO_EVERY_ENGINE) && !NARROW) __builtin_amdgcn_s_setprio((RT_PRIO / (phase)) % 10); } while (0)
+enum { RT_PHASE_TOP = 10000, RT_PHASE_NODE_TEST = 1000, RT_PHASE_TRI_ADDRESS = 100, RT_PHASE_TRI_TEST = 10, RT_PHASE_END = 1 };
+
 struct Ray3 { f3 origin, direction; };
 
 // Measured in round 5 and not kept (profiles/r05_traversal_experiments.txt): the non-temporal hint on the triangle loads (they would leave the CU's L1 to the
@@ -603,6 +618,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			}
 
 			// ---- node phase: lanes with no triangle work pending advance their traversal by one step
+			RT_SETPRIO(RT_PHASE_TOP);
 			if (triangle_group.y == 0) {
 				if (current_group.y & 0xff000000u) {
 					// take the closest pending child of current_group (pushing the rest) and fetch its node
@@ -624,6 +640,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					const float4 * node = FLAT ? (const float4 *)((const char *)nodes + __umul24(child_node_index, 80u))
 					                    : (!UNIFIED && child_node_index < unsigned(p.tlas_node_count) ? p.tlas_nodes : nodes) + size_t(child_node_index) * 5;
 					float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
+					RT_SETPRIO(RT_PHASE_NODE_TEST);
 					if (COUNT) count_nodes++;
 					unsigned hitmask = NARROW ? group8_or(bvh8_node_intersect_child(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, group_child))
 					                 : (RT_FAST_NODE && UNIFIED && FLAT) ? bvh8_node_intersect_fast(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4)
@@ -636,6 +653,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					triangle_group.y = (hitmask & 0x00ffffffu);
 				}
 			}
+			RT_SETPRIO(RT_PHASE_TRI_ADDRESS);
 
 			// ---- triangle phase: ONE batch per round, then back to the node phase. Lanes with more
 			// triangles than a batch keep them in triangle_group and take part in the next rounds while
@@ -694,6 +712,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 							tri_a[k] = tri[0]; tri_b[k] = tri[1]; tri_c[k] = tri[2].x; // position_0, edge_1, edge_2
 						}
 					}
+					RT_SETPRIO(RT_PHASE_TRI_TEST);
 					#pragma unroll
 					for (int k = 0; k < RT_TRI_BATCH; k++) {
 						if (tri_id[k] != RT_INVALID && !occluded) {
@@ -705,6 +724,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			}
 
 					}
+			RT_SETPRIO(RT_PHASE_END);
 			bool traversal_done = triangle_group.y == 0 && (current_group.y & 0xff000000u) == 0 && stack.size == 0;
 			if (COUNT && ((RT_IS_SHADOW && occluded) || traversal_done)) {
 				unsigned long long * bucket = stats + (MODE == RT_TRACE_MIXED && lane_shadow ? 5 : 0);   // mixed launches: {closest x5, shadow x5}

@@ -106,6 +106,33 @@ static void binned_sah(std::vector<int> & ids, const std::vector<Box> & boxes, i
 	binned_sah(ids, boxes, lo, cut, depth + 1, bins); binned_sah(ids, boxes, cut, hi, depth + 1, bins);
 }
 
+// Hybrid (round 5): top-down binned SAH (object splits, `bins` per axis) only down to pieces of <= K references or `max_depth` levels; a piece's path (0 = left,
+// 1 = right, most significant first) becomes the high word of its references' keys, their Morton code inside the piece's box the low word: the level-by-level 8-wide
+// build over the sorted keys then cuts at the highest differing bit as before -- which is the SAH tree's own cut as long as a run spans several pieces.
+// extents: 0 = the bins span the centroid box (the classic), 1 = they span the node's box (what a device build knows without a pass of its own).
+struct TopLeaf { uint32_t path; int depth; Box box; std::vector<int> ids; };
+static void hybrid_top(std::vector<int> & ids, const std::vector<Box> & boxes, uint32_t path, int depth, int K, int max_depth, int bins, int extents, std::vector<TopLeaf> & out) {
+	Box nb, cb; for (int id : ids) { const Box & b = boxes[id]; nb.grow(b); Box c; for (int d = 0; d < 3; d++) c.lo[d] = c.hi[d] = 0.5f * (b.lo[d] + b.hi[d]); cb.grow(c); }
+	if (int(ids.size()) <= K || depth >= max_depth) { out.push_back({ path, depth, nb, ids }); return; }
+	const Box & eb = extents ? nb : cb;
+	int best_axis = -1, best_plane = 0; float best_cost = 1e38f;
+	for (int axis = 0; axis < 3; axis++) {
+		float extent = eb.hi[axis] - eb.lo[axis]; if (!(extent > 0)) continue;
+		std::vector<Box> bb(bins); std::vector<int> bc(bins, 0);
+		for (int id : ids) { const Box & b = boxes[id]; float c = 0.5f * (b.lo[axis] + b.hi[axis]); int k = std::max(0, std::min(bins - 1, int((c - eb.lo[axis]) / extent * bins))); bb[k].grow(b); bc[k]++; }
+		std::vector<float> la(bins), ra(bins); std::vector<int> ln(bins), rn(bins);
+		{ Box acc; int n = 0; for (int k = 0; k < bins; k++) { acc.grow(bb[k]); n += bc[k]; la[k] = n ? acc.area() : 0; ln[k] = n; } }
+		{ Box acc; int n = 0; for (int k = bins - 1; k >= 0; k--) { acc.grow(bb[k]); n += bc[k]; ra[k] = n ? acc.area() : 0; rn[k] = n; } }
+		for (int k = 0; k + 1 < bins; k++) if (ln[k] > 0 && rn[k + 1] > 0) { float cost = la[k] * ln[k] + ra[k + 1] * rn[k + 1]; if (cost < best_cost) { best_cost = cost; best_axis = axis; best_plane = k; } }
+	}
+	if (best_axis < 0) { out.push_back({ path, depth, nb, ids }); return; }   // every centre in one bin on every axis: the Morton order takes it from here
+	float extent = eb.hi[best_axis] - eb.lo[best_axis];
+	std::vector<int> l, r;
+	for (int id : ids) { const Box & b = boxes[id]; float c = 0.5f * (b.lo[best_axis] + b.hi[best_axis]); int k = std::max(0, std::min(bins - 1, int((c - eb.lo[best_axis]) / extent * bins))); (k <= best_plane ? l : r).push_back(id); }
+	std::vector<int>().swap(ids);
+	hybrid_top(l, boxes, path << 1, depth + 1, K, max_depth, bins, extents, out); hybrid_top(r, boxes, (path << 1) | 1u, depth + 1, K, max_depth, bins, extents, out);
+}
+
 static int build_node(Tree & t, const Build & b, int lo, int hi) {
 	int index = int(t.nodes.size()); t.nodes.emplace_back();
 	int begin[9]; begin[0] = lo; for (int c = 1; c < 9; c++) begin[c] = hi; int count = 1;
@@ -261,6 +288,30 @@ int main(int argc, char ** argv) {
 		#pragma omp parallel for reduction(+:bn, bt)
 		for (size_t i = 0; i < bounce.size(); i++) { float best = 1e30f; int hit = -1; long a = 0, c = 0; trace(t, bounce[i], best, hit, a, c); bn += a; bt += c; }
 		printf("binned SAH, %2d bins, binary tree collapsed 8-wide, %-34s nodes %7zu               | primary %5.2f nodes %5.2f tris | bounce %5.2f nodes %5.2f tris\n", bins, area_first ? "largest area first" : "widest piece first", t.nodes.size(), double(pn) / primary.size(), double(pt) / primary.size(), double(bn) / bounce.size(), double(bt) / bounce.size());
+	}
+	const int morton_bits = bits;
+	for (int extents = 0; extents < 2; extents++) for (int K : { 3, 64, 256, 512, 1024, 2048 }) for (int max_depth : { 24, 32 }) {
+		if (max_depth == 32 && K > 8) continue;
+		std::vector<int> ids(tri_count); for (int i = 0; i < tri_count; i++) ids[i] = i;
+		std::vector<TopLeaf> leaves; hybrid_top(ids, tbox, 0u, 0, K, max_depth, getenv("HYBRID_BINS") ? atoi(getenv("HYBRID_BINS")) : 16, extents, leaves);
+		std::vector<uint64_t> hk(tri_count); int deepest = 0;
+		for (const TopLeaf & leaf : leaves) { deepest = std::max(deepest, leaf.depth);
+			uint64_t high = leaf.depth == 0 ? 0ull : uint64_t(leaf.path) << (32 - leaf.depth);
+			for (int id : leaf.ids) { uint64_t q[3]; for (int d = 0; d < 3; d++) { float c = 0.5f * (tbox[id].lo[d] + tbox[id].hi[d]); double g = double(1u << morton_bits), e = double(leaf.box.hi[d] - leaf.box.lo[d]); q[d] = e > 0 ? uint64_t(std::min(g - 1.0, std::max(0.0, double(c - leaf.box.lo[d]) / e * g))) : 0ull; }
+				hk[id] = (high << 32) | (expand64(q[0]) << 2) | (expand64(q[1]) << 1) | expand64(q[2]); } }
+		std::vector<int> ho(tri_count); for (int i = 0; i < tri_count; i++) ho[i] = i;
+		std::stable_sort(ho.begin(), ho.end(), [&](int a, int b) { return hk[a] < hk[b]; });
+		std::vector<uint64_t> sk(tri_count); std::vector<Box> sb(tri_count); for (int i = 0; i < tri_count; i++) { sk[i] = hk[ho[i]]; sb[i] = tbox[ho[i]]; }
+		Tree t; t.order = ho; Build b { sk, sb, LBVH, true, -1, {}, {} };
+		build_node(t, b, 0, tri_count);
+		long pn = 0, pt = 0, bn = 0, bt = 0;
+		#pragma omp parallel for reduction(+:pn, pt)
+		for (size_t i = 0; i < primary.size(); i++) { float best = 1e30f; int hit = -1; long a = 0, c = 0; trace(t, primary[i], best, hit, a, c); pn += a; pt += c; }
+		#pragma omp parallel for reduction(+:bn, bt)
+		for (size_t i = 0; i < bounce.size(); i++) { float best = 1e30f; int hit = -1; long a = 0, c = 0; trace(t, bounce[i], best, hit, a, c); bn += a; bt += c; }
+		printf("hybrid: binned SAH (16 bins over the %s box) down to <= %4d refs / %2d levels (%6zu pieces, deepest %2d), Morton below  nodes %7zu | primary %5.2f nodes %5.2f tris | bounce %5.2f nodes %5.2f tris\n",
+		       extents ? "node's" : "centroid", K, max_depth, leaves.size(), deepest, t.nodes.size(), double(pn) / primary.size(), double(pt) / primary.size(), double(bn) / bounce.size(), double(bt) / bounce.size());
+		fflush(stdout);
 	}
 	return 0;
 }

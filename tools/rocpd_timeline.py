@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The last <ms> milliseconds of a rocprofv3 kernel trace (rocpd database) as a timeline: start (us from the first listed kernel),
-duration, gap to the previous kernel's end, name. Usage: tools/rocpd_timeline.py <results.db> [ms = 8]"""
+duration, gap to the previous kernel's end, name. Usage: tools/rocpd_timeline.py <results.db> [ms = 8] [anchor [after_ms = 1.5]]
+With an anchor the window ends after_ms behind the last kernel whose name contains it (instead of at the end of the trace)."""
 import sqlite3
 import sys
 
@@ -14,7 +15,11 @@ def main():
     if not rows:
         print("no kernels"); return
     t_last = max(r[2] for r in rows)
-    rows = [r for r in rows if r[1] >= t_last - ms * 1e6]
+    if len(sys.argv) > 3:
+        anchored = [r[2] for r in rows if sys.argv[3] in r[0]]
+        if anchored:
+            t_last = max(anchored) + (float(sys.argv[4]) if len(sys.argv) > 4 else 1.5) * 1e6
+    rows = [r for r in rows if r[1] >= t_last - ms * 1e6 and r[1] <= t_last]
     t0 = rows[0][1]; prev_end = t0
     for name, start, end in rows:
         print("%10.1f us  %9.1f us  gap %7.1f  %s" % ((start - t0) / 1e3, (end - start) / 1e3, (start - prev_end) / 1e3, name.split("(")[0][-60:]))
