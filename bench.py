@@ -93,6 +93,12 @@ def build_scene(grt):
     """BASELINE config #2: Sponza, every odd diffuse material -> roughplastic alpha 0.3."""
     grt.config_reset()
     grt.config_set(merge_static=MERGE_STATIC, expand_block_compressed_textures=EXPAND_TEXTURES)
+    if os.environ.get("BENCH_SLOT_ASSIGNMENT"):   # experiments: how the flattened tree's collapse deals children to octant slots (config static_slot_assignment)
+        grt.config_set(static_slot_assignment=int(os.environ["BENCH_SLOT_ASSIGNMENT"]))
+    if os.environ.get("BENCH_SLOT_LEARNING_RAYS"):
+        grt.config_set(static_slot_learning_rays=int(os.environ["BENCH_SLOT_LEARNING_RAYS"]))
+    if os.environ.get("BENCH_SLOT_LEARNING_VIEWPOINT"):
+        grt.config_set(static_slot_learning_viewpoint=int(os.environ["BENCH_SLOT_LEARNING_VIEWPOINT"]))
     # the reference's own 19 diffuse maps when build() could install them (assets/_cache, see install_reference_sponza_textures),
     # else the quarter-size maps that travel inside the repository, every texel replicated 4x4
     scene = grt.Scene(grt.scene_path("sponza_reference_maps" if grt.reference_sponza_textures_installed() else "sponza"))

@@ -81,6 +81,11 @@ struct BVH8 {
 // flattened scene keeps together at the front of its node array -- every ray walks them, 40 % of all node steps on Sponza touch the top three levels.
 int bvh8_order_breadth_first(BVH8 & bvh, int max_depth);
 
+// Re-seats the children of every node in the octant slots of least cost as `rays` sample rays (seeded) over `triangles` -- the array bvh.indices points into --
+// find it (SlotOrder.cpp); boxes, leaves and triangle order stay. For trees rooted in node 0 in the converter's own (depth-first) order: call it BEFORE
+// bvh8_order_breadth_first. thread_count <= 0: all host threads. viewpoint (3 floats, optional): where the camera stands -- a third of the sample rays then start there.
+void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<struct Triangle> & triangles, int rays, int thread_count = 0, const float * viewpoint = nullptr);
+
 struct Mesh;
 
 // Monotone float -> unsigned key (the reference radix-sorts on it, Core/Sort.h:133-140),
@@ -156,6 +161,7 @@ struct BVH8Converter {
 	const BVH2 & bvh2;
 
 	float primitive_cost = 1.0f;   // SAH cost of a triangle test relative to a node step: 1 in the reference's converter (BVH8Converter.cpp:24-115)
+	int   slot_assignment = 0;     // 0: the reference's greedy assignment of children to octant slots; 1: the assignment of least total cost (experiment, profiles/r05_traversal_experiments.txt)
 	BVH8Converter(BVH8 & bvh8, const BVH2 & bvh2) : bvh8(bvh8), bvh2(bvh2) { }
 	void convert();
 

@@ -70,6 +70,9 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "static_presplit")                     cpu_config.static_presplit = float(value);
 	else if (k == "merge_static")                        cpu_config.merge_static = int(value);
 	else if (k == "static_primitive_cost")               cpu_config.static_primitive_cost = float(value);
+	else if (k == "static_slot_assignment")              cpu_config.static_slot_assignment = int(value);
+	else if (k == "static_slot_learning_rays")           cpu_config.static_slot_learning_rays = int(value);
+	else if (k == "static_slot_learning_viewpoint")      cpu_config.static_slot_learning_viewpoint = int(value);
 	else if (k == "static_mesh_copy_limit_mb")           cpu_config.static_mesh_copy_limit_mb = int(value);
 	else if (k == "static_copy_budget_mb")               cpu_config.static_copy_budget_mb = int(value);
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
@@ -647,7 +650,8 @@ void * grt_build_blas_variant(const float * tris24, int n, int spatial_splits, i
 		else if (spatial_splits) SBVHBuilder(md->bvh2, md->triangles.size()).build(md->triangles);
 		else                SAHBuilder (md->bvh2, md->triangles.size()).build(md->triangles);
 		if (optimize) BVHOptimizer::optimize(md->bvh2);
-		{ BVH8Converter converter(md->bvh8, md->bvh2); if (const char * c = getenv("GRT_PRIMITIVE_COST")) converter.primitive_cost = float(atof(c)); converter.convert(); }
+		{ BVH8Converter converter(md->bvh8, md->bvh2); if (const char * c = getenv("GRT_PRIMITIVE_COST")) converter.primitive_cost = float(atof(c)); if (const char * c = getenv("GRT_SLOT_ASSIGNMENT")) converter.slot_assignment = atoi(c); converter.convert(); }
+		if (const char * c = getenv("GRT_SLOT_LEARNING_RAYS")) bvh8_learn_slot_order(md->bvh8, md->triangles, atoi(c));
 		return md;
 	GRT_CATCH(nullptr)
 }
