@@ -83,8 +83,11 @@ int bvh8_order_breadth_first(BVH8 & bvh, int max_depth);
 
 // Re-seats the children of every node in the octant slots of least cost as `rays` sample rays (seeded) over `triangles` -- the array bvh.indices points into --
 // find it (SlotOrder.cpp); boxes, leaves and triangle order stay. For trees rooted in node 0 in the converter's own (depth-first) order: call it BEFORE
-// bvh8_order_breadth_first. thread_count <= 0: all host threads. viewpoint (3 floats, optional): where the camera stands -- a third of the sample rays then start there.
-void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<struct Triangle> & triangles, int rays, int thread_count = 0, const float * viewpoint = nullptr);
+// bvh8_order_breadth_first. thread_count <= 0: all host threads. view (optional): three quarters of the sample rays are then paths from that camera.
+struct SlotLearningView {   // what the caller is about to look at: the camera as the device gets it (camera_generate_ray: direction = corner + x_axis * px + y_axis * py)
+	Vector3 position, bottom_left_corner, x_axis, y_axis; int width = 0, height = 0;
+};
+void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<struct Triangle> & triangles, int rays, int thread_count = 0, const SlotLearningView * view = nullptr);
 
 struct Mesh;
 

@@ -120,7 +120,18 @@ std::vector<Triangle> Integrator::world_triangles_of(const std::vector<int> & me
 
 // SAH object + spatial splits on all host threads, the reference's 8-wide collapse, breadth-first node order. A pure function of
 // its input and the configuration (it runs on a worker thread when a flattened instance has started to move).
-static void build_flattened_tree(const std::vector<Triangle> & world, BVH8 & wide, int & top_nodes, Vector3 viewpoint) {
+// What the seating of the flattened tree's children is trained on (SlotOrder.cpp): the camera's rays as camera_generate_ray forms them, as the camera stands now.
+SlotLearningView Integrator::slot_learning_view() const {
+	SlotLearningView view;
+	if (!cpu_config.static_slot_learning_viewpoint) return view;   // (width 0: no view)
+	const Camera & c = scene.camera;
+	// (rotated here, as Camera::update does: the first flatten of an integrator runs before its first camera update)
+	view.position = c.position; view.bottom_left_corner = c.rotation * c.bottom_left_corner; view.x_axis = c.rotation * c.x_axis; view.y_axis = c.rotation * c.y_axis;
+	view.width = int(c.screen_width); view.height = int(c.screen_height);
+	return view;
+}
+
+static void build_flattened_tree(const std::vector<Triangle> & world, BVH8 & wide, int & top_nodes, const SlotLearningView & view) {
 	BVH2 binary;
 	if (cpu_config.merge_static == 2) binary = BVH::create_sah_from_triangles(world);   // the per-mesh builder, for comparison
 	else                              StaticBVHBuilder::build(binary, world);           // spatial splits, all host threads
@@ -128,7 +139,7 @@ static void build_flattened_tree(const std::vector<Triangle> & world, BVH8 & wid
 	converter.primitive_cost = cpu_config.static_primitive_cost;
 	converter.slot_assignment = cpu_config.static_slot_assignment;
 	converter.convert();
-	if (cpu_config.static_slot_learning_rays > 0) bvh8_learn_slot_order(wide, world, cpu_config.static_slot_learning_rays, 0, cpu_config.static_slot_learning_viewpoint ? &viewpoint.x : nullptr);
+	if (cpu_config.static_slot_learning_rays > 0) bvh8_learn_slot_order(wide, world, cpu_config.static_slot_learning_rays, 0, &view);
 	top_nodes = std::min(bvh8_order_breadth_first(wide, 2), 64);   // levels 0..2 (at most 1 + 8 + 64 nodes) come first: the part of the tree every ray walks is one contiguous run
 }
 
@@ -173,11 +184,11 @@ void Integrator::start_flatten_worker() {
 	// (the worker reads the reference part of the staged arrays -- the originals of the triangles it copies -- which nothing rewrites
 	// while it runs: init_geometry waits for every worker before it restages that part)
 	const std::vector<DeviceTriangle> * originals = &aggregated_triangles; const std::vector<int> * device_index = &reverse_indices;
-	const Vector3 viewpoint = scene.camera.position;   // (as it stands now: the worker must not read the scene)
-	job->worker = std::thread([job, originals, device_index, viewpoint] {
+	const SlotLearningView view = slot_learning_view();   // (as things stand now: the worker must not read the scene)
+	job->worker = std::thread([job, originals, device_index, view] {
 		auto started = std::chrono::steady_clock::now();
 		try {
-			build_flattened_tree(job->world, job->wide, job->top_nodes, viewpoint);
+			build_flattened_tree(job->world, job->wide, job->top_nodes, view);
 			size_t copies = job->wide.indices.size();
 			job->copy_triangles.resize(copies); job->copy_member.resize(copies); job->copy_original.resize(copies);
 			for (size_t c = 0; c < copies; c++) {
@@ -361,7 +372,7 @@ void Integrator::init_geometry() {
 					reflattens_completed++;
 				} else {
 					auto started = std::chrono::steady_clock::now();
-					build_flattened_tree(world, wide, flat.top_nodes, scene.camera.position);
+					build_flattened_tree(world, wide, flat.top_nodes, slot_learning_view());
 					flat.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
 				}
 				copy_source = wide.indices;

@@ -133,6 +133,7 @@ struct Integrator {
 	void drop_flatten_worker();
 	std::vector<int> flatten_candidates() const;
 	std::vector<Triangle> world_triangles_of(const std::vector<int> & members, std::vector<int> * source_member, std::vector<int> * source_triangle) const;
+	SlotLearningView slot_learning_view() const;   // the camera as it stands: what bvh8_learn_slot_order samples its paths from
 	std::vector<char> instance_has_moved;   // per scene mesh: seen with a changed transform since the scene was loaded -> never flattened again
 	std::vector<int> alias_mesh_ids, alias_triangle_ids;   // per device triangle (-1: not a copy): what rt_upload_triangle_aliases was given
 

@@ -7,8 +7,8 @@
 // ends inside child H of a node walks every other child that is seated in front of H for its octant and whose box it enters -- also
 // those whose box begins BEHIND the hit, which it would have skipped had it been to H first. That is counted here, on the tree itself:
 //   1  sample rays (seeded, a pure function of the input): from area-weighted points on the triangles, cosine-distributed about the
-//      normal (what a bounce is) or towards another such point and no further (what a shadow ray is) -- and, when the caller says where
-//      the camera stands, a third of them from there towards such a point (what a primary ray is);
+//      normal (what a bounce is) or towards another such point and no further (what a shadow ray is) -- and, when the caller hands over
+//      its camera, three quarters of them as the paths it is about to trace: a camera ray through a random pixel and up to three bounces;
 //   2  each is traced for its closest hit; along the path from the root to the leaf that holds the hit, every inner child c that the
 //      ray enters only BEHIND the hit scores one for the pair (c in front of H) in the ray's octant;
 //   3  per node, the children trade slots while that lowers the score summed over the eight octants; the records of its inner children
@@ -66,7 +66,7 @@ struct Learner {
 	std::unique_ptr<std::atomic<unsigned>[]> score;   // [node][octant][c][h]: rays of that octant that ended in child h and enter child c only behind their hit
 	std::vector<float> area_cdf; float scene_size = 1.0f;
 	bool weigh_by_work = true;
-	bool has_viewpoint = false; Vector3 viewpoint = Vector3(0.0f);
+	const SlotLearningView * view = nullptr;
 
 	Learner(const BVH8 & bvh, const std::vector<Triangle> & triangles) : bvh(bvh), triangles(triangles) { }
 
@@ -121,10 +121,10 @@ struct Learner {
 		return hit;
 	}
 
-	void learn_from(const SampleRay & r) {
-		float t_hit;
+	// returns the leaf position of the ray's closest hit (or -1) and its distance
+	int learn_from(const SampleRay & r, float & t_hit) {
 		const int hit = trace(r, t_hit);
-		if (hit < 0) return;
+		if (hit < 0) return hit;
 		unsigned node = 0;
 		for (int depth = 0; depth < 64; depth++) {
 			const BVHNode8 & n = bvh.nodes[node];
@@ -133,7 +133,7 @@ struct Learner {
 				const unsigned child = n.base_index_child + rank++;
 				if (unsigned(hit) >= bvh.nodes[child].base_index_triangle && unsigned(hit) < triangles_end[child]) { holder = s; holder_node = child; }
 			}
-			if (holder < 0) return;   // the hit is in one of this node's own leaves
+			if (holder < 0) return hit;   // the hit is in one of this node's own leaves
 			for (int s = 0; s < 8; s++) if (((n.imask >> s) & 1) && s != holder) {
 				float t_enter;
 				if (enters(r, child_box(n, s), r.tmax, t_enter) && t_enter >= t_hit) {
@@ -145,6 +145,7 @@ struct Learner {
 			}
 			node = holder_node;
 		}
+		return hit;
 	}
 
 	void surface_point(Random & rng, Vector3 & point, Vector3 & normal) const {
@@ -164,14 +165,8 @@ struct Learner {
 		Vector3 from, normal; surface_point(rng, from, normal);
 		if (rng.next() < 0.5f) normal = normal * -1.0f;   // either side of the triangle
 		Vector3 dir; float tmax = INFINITY;
-		const int kind = has_viewpoint ? int(index % 3ull) : int(index & 1ull);
-		if (kind == 2) {      // from where the camera stands towards a point of the surface (what a primary ray is)
-			dir = from - viewpoint;
-			const float distance = Vector3::length(dir);
-			if (!(distance > 1.0e-4f * scene_size)) return false;
-			dir = dir * (1.0f / distance);
-			from = viewpoint; normal = Vector3(0.0f);
-		} else if (kind == 1) {   // towards another point of the surface, and no further
+		const int kind = int(index & 1ull);
+		if (kind == 1) {   // towards another point of the surface, and no further
 			Vector3 to, unused; surface_point(rng, to, unused);
 			dir = to - from;
 			const float distance = Vector3::length(dir);
@@ -179,26 +174,60 @@ struct Learner {
 			dir = dir * (1.0f / distance); tmax = distance * (1.0f - 1.0e-3f);
 			if (Vector3::dot(dir, normal) < 0.0f) normal = normal * -1.0f;
 		} else {              // cosine-distributed about the normal
-			const float r1 = rng.next(), r2 = rng.next(), radius = sqrtf(r1), phi = 6.2831853f * r2;
-			const Vector3 helper = fabsf(normal.x) < 0.9f ? Vector3(1.0f, 0.0f, 0.0f) : Vector3(0.0f, 1.0f, 0.0f);
-			const Vector3 tangent = Vector3::normalize(Vector3::cross(helper, normal)), bitangent = Vector3::cross(normal, tangent);
-			dir = tangent * (radius * cosf(phi)) + bitangent * (radius * sinf(phi)) + normal * sqrtf(std::max(0.0f, 1.0f - r1));
+			dir = cosine_direction(rng, normal);
 		}
-		const Vector3 origin = from + normal * (1.0e-4f * scene_size);
+		set_ray(r, from + normal * (1.0e-4f * scene_size), dir, tmax);
+		return true;
+	}
+	static void set_ray(SampleRay & r, const Vector3 & origin, const Vector3 & dir, float tmax) {
 		r.o[0] = origin.x; r.o[1] = origin.y; r.o[2] = origin.z; r.d[0] = dir.x; r.d[1] = dir.y; r.d[2] = dir.z;
 		for (int d = 0; d < 3; d++) r.inv[d] = 1.0f / r.d[d];
 		r.tmax = tmax;
 		r.octant = (r.d[0] < 0.0f ? 0 : 4) | (r.d[1] < 0.0f ? 0 : 2) | (r.d[2] < 0.0f ? 0 : 1);
-		return true;
+	}
+	static Vector3 cosine_direction(Random & rng, const Vector3 & normal) {
+		const float r1 = rng.next(), r2 = rng.next(), radius = sqrtf(r1), phi = 6.2831853f * r2;
+		const Vector3 helper = fabsf(normal.x) < 0.9f ? Vector3(1.0f, 0.0f, 0.0f) : Vector3(0.0f, 1.0f, 0.0f);
+		const Vector3 tangent = Vector3::normalize(Vector3::cross(helper, normal)), bitangent = Vector3::cross(normal, tangent);
+		return tangent * (radius * cosf(phi)) + bitangent * (radius * sinf(phi)) + normal * sqrtf(std::max(0.0f, 1.0f - r1));
+	}
+
+	// One path as the integrator is about to trace them (Pathtracer.cu:122-139, 557-773 in outline): a camera ray through a random pixel, then up to `bounces`
+	// cosine-distributed bounces; every ray is a sample. (Shadow rays towards the emitting meshes were sampled too and taken out again: scored like closest-hit rays
+	// they made the real ones' walks LONGER, 12.9 -> 13.6 node steps -- an any-hit ray does not care for the nearest occluder; the surface-to-surface segments of
+	// make_ray serve them better. profiles/r05_slot_assignment.txt.) Returns how many rays it traced.
+	int learn_from_path(uint64_t index, int bounces) {
+		Random rng(mix(index * 0x9E3779B1ull + 777ull));
+		SampleRay r;
+		const float px = rng.next() * float(view->width), py = rng.next() * float(view->height);
+		Vector3 dir = Vector3::normalize(view->bottom_left_corner + view->x_axis * px + view->y_axis * py), origin = view->position;
+		if (!std::isfinite(dir.x) || !std::isfinite(dir.y) || !std::isfinite(dir.z) || !std::isfinite(origin.x + origin.y + origin.z)) return 0;   // (a ray of NaNs enters every box)
+		set_ray(r, origin, dir, INFINITY);
+		int traced = 0;
+		for (int bounce = 0; bounce <= bounces; bounce++) {
+			float t_hit; traced++;
+			const int hit = learn_from(r, t_hit);
+			if (hit < 0 || bounce == bounces) break;
+			const Triangle & tri = triangles[size_t(bvh.indices[size_t(hit)])];
+			Vector3 normal = Vector3::cross(tri.position_1 - tri.position_0, tri.position_2 - tri.position_0);
+			const float length = Vector3::length(normal);
+			if (!(length > 0.0f)) break;
+			normal = normal * (1.0f / length);
+			if (Vector3::dot(normal, dir) > 0.0f) normal = normal * -1.0f;
+			const Vector3 point = origin + dir * t_hit + normal * (1.0e-4f * scene_size);
+			origin = point; dir = cosine_direction(rng, normal);
+			set_ray(r, origin, dir, INFINITY);
+		}
+		return traced;
 	}
 };
 
 }   // namespace
 
-void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<Triangle> & triangles, int rays, int thread_count, const float * viewpoint) {
+void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<Triangle> & triangles, int rays, int thread_count, const SlotLearningView * view) {
 	if (bvh.nodes.empty() || triangles.empty() || bvh.indices.empty() || rays <= 0) return;
 	Learner learner(bvh, triangles);
-	if (viewpoint) { learner.has_viewpoint = true; learner.viewpoint = Vector3(viewpoint[0], viewpoint[1], viewpoint[2]); }
+	if (view && view->width > 0 && view->height > 0) learner.view = view;
 	if (const char * c = getenv("GRT_SLOT_LEARNING_UNWEIGHTED")) learner.weigh_by_work = atoi(c) == 0;
 	learner.triangles_end.assign(bvh.nodes.size(), 0u);
 	learner.subtree_end(0);
@@ -219,7 +248,12 @@ void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<Triangle> & triangles, 
 	thread_count = std::min(thread_count, 64);
 	{
 		std::atomic<int> next(0);
-		auto work = [&] { for (int begin; (begin = next.fetch_add(1024)) < rays; ) for (int i = begin; i < std::min(rays, begin + 1024); i++) { SampleRay r; if (learner.make_ray(uint64_t(i), r)) learner.learn_from(r); } };
+		// with a view: three quarters of the rays come as paths from the camera (up to 4 rays each), the rest from the surface itself
+		const int surface_rays = learner.view ? rays / 4 : rays, paths = learner.view ? (rays - surface_rays) / 4 : 0, items = surface_rays + paths;
+		auto work = [&] { for (int begin; (begin = next.fetch_add(512)) < items; ) for (int i = begin; i < std::min(items, begin + 512); i++) {
+			if (i < surface_rays) { SampleRay r; float unused; if (learner.make_ray(uint64_t(i), r)) (void)learner.learn_from(r, unused); }
+			else (void)learner.learn_from_path(uint64_t(i - surface_rays), 3);
+		} };
 		std::vector<std::thread> helpers;
 		for (int t = 1; t < thread_count; t++) helpers.emplace_back(work);
 		work();

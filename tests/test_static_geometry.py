@@ -487,3 +487,57 @@ def test_early_split_clipping_covers_every_triangle_with_the_boxes_of_its_pieces
         tol = 1e-5 * np.abs(corners[t]).max()                                    # the points themselves are rounded
         inside = ((pts[:, None, :] >= mine[None, :, :3] - tol) & (pts[:, None, :] <= mine[None, :, 3:] + tol)).all(axis=2).any(axis=1)
         assert inside.all(), (int(t), int((~inside).sum()))
+
+
+def test_learned_slot_order_reseats_children_and_nothing_else(grt, oracle):
+    """host/SlotOrder.cpp (config static_slot_learning_rays, on by default): the flattened tree's children are dealt to the octant slots by what seeded sample
+    rays say. Only the ORDER of a walk may change: same node count, same multiset of child boxes / leaf contents per tree, identical closest hits and occlusion
+    answers on every compared ray (exact ties in t aside: none among these rays), fewer node steps for the camera's rays, and a tree that is a pure function
+    of scene, configuration and camera (built twice: byte-identical)."""
+    w, h = 192, 108
+    def build(**config):
+        scene, pt = staged(grt, grt.scene_path("sponza"), w, h, 1, **config)
+        view = oracle.SceneView(pt)
+        return scene, pt, view
+    scene_a, pt_a, plain = build(static_slot_learning_rays=0)
+    o, d = rays_for(plain, w, h, 14.0, 20000, 11)
+    hits_a, stats_a = plain.trace(o, d)
+    far = np.full(o.shape[1], 7.0, np.float32)
+    occluded_a = plain.trace_shadow(o, d, far)[0]
+    nodes_a = pt_a.array("bvh8_nodes").reshape(-1, 80).copy(); first_a = 2 * scene_a.mesh_count
+    aliases_a = (pt_a.array("alias_mesh_ids").copy(), pt_a.array("alias_triangle_ids").copy()); triangles_a = pt_a.array("triangles").copy()
+    pt_a.close(); scene_a.close()
+
+    scene_b, pt_b, learned = build(static_slot_learning_rays=300000)
+    hits_b, stats_b = learned.trace(o, d)
+    occluded_b = learned.trace_shadow(o, d, far)[0]
+    nodes_b = pt_b.array("bvh8_nodes").reshape(-1, 80).copy()
+    assert nodes_a.shape == nodes_b.shape and not np.array_equal(nodes_a, nodes_b)
+    assert np.array_equal(triangles_a.view(np.uint32), pt_b.array("triangles").view(np.uint32))      # triangles, their order and what the copies stand for: untouched
+    assert np.array_equal(aliases_a[0], pt_b.array("alias_mesh_ids")) and np.array_equal(aliases_a[1], pt_b.array("alias_triangle_ids"))
+    # per node: the children are the same children in other seats -- compare each node's sorted (meta kind / count, six box bytes) rows, nodes sorted too
+    def child_rows(nodes):
+        rows = []
+        for n in nodes[first_a:]:
+            meta, imask = n[24:32], n[15]
+            kids = []
+            for s in range(8):
+                if meta[s] == 0: continue
+                kind = 255 if (imask >> s) & 1 else int(meta[s] >> 5)                                # inner, or the leaf's unary triangle count
+                kids.append((kind,) + tuple(int(n[32 + 8 * k + s]) for k in range(6)))
+            rows.append((tuple(int(v) for v in n[:15]), tuple(sorted(kids))))
+        return sorted(rows)
+    assert child_rows(nodes_a) == child_rows(nodes_b)
+    ta, tb = unpack_hits(hits_a), unpack_hits(hits_b)
+    assert np.array_equal(hits_a[:, 2], hits_b[:, 2])                                                 # t, to the bit
+    same = (hits_a[:, :2] == hits_b[:, :2]).all(axis=1)
+    assert same.mean() > 0.999, same.mean()                                                           # (instance, triangle): exact ties between coplanar triangles may resolve differently
+    assert np.array_equal(occluded_a, occluded_b)
+    camera = slice(0, w * h)
+    steps_a, steps_b = plain.trace(o[:, camera], d[:, camera])[1].nodes, learned.trace(o[:, camera], d[:, camera])[1].nodes
+    assert steps_b < 0.97 * steps_a, (steps_a, steps_b)                                               # the camera's rays: measurably shorter walks (-10 % at 1080p on the device)
+    pt_b.close(); scene_b.close()
+
+    scene_c, pt_c, _ = build(static_slot_learning_rays=300000)
+    assert np.array_equal(nodes_b, pt_c.array("bvh8_nodes").reshape(-1, 80))
+    pt_c.close(); scene_c.close()
