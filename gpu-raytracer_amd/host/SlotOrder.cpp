@@ -195,7 +195,8 @@ struct Learner {
 	// One path as the integrator is about to trace them (Pathtracer.cu:122-139, 557-773 in outline): a camera ray through a random pixel, then up to `bounces`
 	// cosine-distributed bounces; every ray is a sample. (Shadow rays towards the emitting meshes were sampled too and taken out again: scored like closest-hit rays
 	// they made the real ones' walks LONGER, 12.9 -> 13.6 node steps -- an any-hit ray does not care for the nearest occluder; the surface-to-surface segments of
-	// make_ray serve them better. profiles/r05_slot_assignment.txt.) Returns how many rays it traced.
+	// make_ray serve them better. Scoring segments as what they are -- the child that finds ANY occluder soonest first -- was tried as well: shadow rays 12.9 -> 12.0
+	// node steps, closest-hit rays 13.1 -> 13.3, the launch as long as before; not kept. profiles/r05_slot_assignment.txt.) Returns how many rays it traced.
 	int learn_from_path(uint64_t index, int bounces) {
 		Random rng(mix(index * 0x9E3779B1ull + 777ull));
 		SampleRay r;
