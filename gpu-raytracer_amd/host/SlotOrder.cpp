@@ -63,7 +63,8 @@ struct Learner {
 	const BVH8 & bvh;
 	const std::vector<Triangle> & triangles;
 	std::vector<unsigned> triangles_end;              // per node: one past the last leaf position of its subtree (the first is its base_index_triangle)
-	std::unique_ptr<std::atomic<unsigned>[]> score;   // [node][octant][c][h]: rays of that octant that ended in child h and enter child c only behind their hit
+	std::unique_ptr<std::atomic<unsigned>[]> score;   // [score_row[node]][octant][c][h]: rays of that octant that ended in child h and enter child c only behind their hit
+	std::vector<int> score_row;                       // per node: its row of 512 counters, or -1 (a tree too large to score whole keeps rows for its top levels: memory_limit)
 	std::vector<float> area_cdf; float scene_size = 1.0f;
 	bool weigh_by_work = true;
 	const SlotLearningView * view = nullptr;
@@ -136,11 +137,11 @@ struct Learner {
 			if (holder < 0) return hit;   // the hit is in one of this node's own leaves
 			for (int s = 0; s < 8; s++) if (((n.imask >> s) & 1) && s != holder) {
 				float t_enter;
-				if (enters(r, child_box(n, s), r.tmax, t_enter) && t_enter >= t_hit) {
+				if (score_row[node] >= 0 && enters(r, child_box(n, s), r.tmax, t_enter) && t_enter >= t_hit) {
 					// what the detour costs: the walk of that child's subtree by a ray that has not found its hit yet
 					unsigned work = 2; float unused;
 					if (weigh_by_work) (void)trace(r, unused, n.base_index_child + unsigned(__builtin_popcount(unsigned(n.imask) & ((1u << s) - 1u))), &work);
-					score[((size_t(node) * 8 + size_t(r.octant)) * 8 + size_t(s)) * 8 + size_t(holder)].fetch_add(work, std::memory_order_relaxed);
+					score[((size_t(score_row[node]) * 8 + size_t(r.octant)) * 8 + size_t(s)) * 8 + size_t(holder)].fetch_add(work, std::memory_order_relaxed);
 				}
 			}
 			node = holder_node;
@@ -232,8 +233,24 @@ void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<Triangle> & triangles, 
 	if (const char * c = getenv("GRT_SLOT_LEARNING_UNWEIGHTED")) learner.weigh_by_work = atoi(c) == 0;
 	learner.triangles_end.assign(bvh.nodes.size(), 0u);
 	learner.subtree_end(0);
-	learner.score.reset(new std::atomic<unsigned>[bvh.nodes.size() * 512]);
-	for (size_t i = 0; i < bvh.nodes.size() * 512; i++) learner.score[i].store(0u, std::memory_order_relaxed);
+	// 2 KB of counters per scored node, at most 1 GB of them: a tree of more than half a million nodes is scored down to the depth that fits (the levels every ray walks)
+	{
+		const size_t row_limit = (size_t(1) << 30) / 2048;
+		std::vector<int> depth(bvh.nodes.size(), 0); std::vector<size_t> at_depth(64, 0);
+		std::vector<unsigned> order; order.reserve(bvh.nodes.size()); order.push_back(0u);
+		for (size_t k = 0; k < order.size(); k++) {   // (parents before children)
+			const BVHNode8 & n = bvh.nodes[order[k]];
+			at_depth[size_t(std::min(depth[order[k]], 63))]++;
+			for (int c = 0; c < __builtin_popcount(unsigned(n.imask)); c++) { const unsigned child = n.base_index_child + unsigned(c); if (child < bvh.nodes.size()) { depth[child] = depth[order[k]] + 1; order.push_back(child); } }
+		}
+		int deepest = 0; size_t rows = 0;
+		while (deepest < 64 && rows + at_depth[size_t(deepest)] <= row_limit) rows += at_depth[size_t(deepest++)];
+		learner.score_row.assign(bvh.nodes.size(), -1);
+		int next_row = 0;
+		for (unsigned node : order) if (depth[node] < deepest) learner.score_row[node] = next_row++;
+		learner.score.reset(new std::atomic<unsigned>[size_t(next_row) * 512 + 1]);
+		for (size_t i = 0; i < size_t(next_row) * 512; i++) learner.score[i].store(0u, std::memory_order_relaxed);
+	}
 	learner.area_cdf.resize(triangles.size());
 	Vector3 lo(+INFINITY), hi(-INFINITY); double running = 0.0;
 	for (size_t i = 0; i < triangles.size(); i++) {
@@ -271,8 +288,8 @@ void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<Triangle> & triangles, 
 			for (size_t begin; (begin = next.fetch_add(256)) < bvh.nodes.size(); ) for (size_t node = begin; node < std::min(bvh.nodes.size(), begin + 256); node++) {
 				const BVHNode8 & n = bvh.nodes[node];
 				seated[node] = n;
-				if (__builtin_popcount(unsigned(n.imask)) < 2) continue;
-				const std::atomic<unsigned> * counts = &learner.score[node * 512];
+				if (__builtin_popcount(unsigned(n.imask)) < 2 || learner.score_row[node] < 0) continue;
+				const std::atomic<unsigned> * counts = &learner.score[size_t(learner.score_row[node]) * 512];
 				unsigned table[8][8][8]; unsigned long long total = 0;
 				for (int v = 0; v < 8; v++) for (int c = 0; c < 8; c++) for (int h = 0; h < 8; h++) { table[v][c][h] = counts[(v * 8 + c) * 8 + h].load(std::memory_order_relaxed); total += table[v][c][h]; }
 				if (total < 16) continue;   // nothing to go by: the converter's seating stays
