@@ -783,7 +783,7 @@ def main():
                 "workload": "Sponza (Crytek, 262 687 triangles, 384 instances) 1920x1080, samples 0..3 (4 spp), BVH8/CWBVH, diffuse + roughplastic(odd materials, alpha 0.3), NEE+MIS+RR, 10 bounces, constant white sky, mipmapping on, 19 diffuse textures at the reference's dimensions (1024x1024 + mips, BC1 block-compressed as the reference does by default, decoded once at upload (rt_set_texture_expansion); " + ("the reference's own texture files" if grt.reference_sponza_textures_installed() else "texels replicated 4x4 from the quarter-size maps that travel with the repo") + "), the 5 maps missing upstream are the reference's 1x1 fallback texel",
                 "step": "one sample per pixel for the whole frame; the 4 samples of a frame are one submission (rt_render_samples); the submissions feed one merged wavefront (see burst: declared as a burst they enter it together and every launch carries one bounce of all of them; one by one, every launch carries the rays of all submissions in flight)",
                 "scheduler": scheduler,
-                "acceleration_structure": (("%d of %d instances (all that stand still) flattened into one CWBVH of %d triangle copies" + (", no TLAS: rays start inside the tree (rt_set_static_geometry)" if pt.static_geometry_whole_scene else ", one TLAS leaf beside the other instances") + ", hits reported as the scene's own instances and triangles (rt_upload_triangle_aliases); tree built on the host in %.2f s (SAH object + spatial splits, all threads, then the children of every node seated in the octant slots by what 1 M seeded sample rays -- camera paths and surface rays -- say: config static_slot_learning_rays, host/SlotOrder.cpp; at scene load, not in the timed region); --merge-static 0 runs the reference's layout")
+                "acceleration_structure": (("%d of %d instances (all that stand still) flattened into one CWBVH of %d triangle copies" + (", no TLAS: rays start inside the tree (rt_set_static_geometry)" if pt.static_geometry_whole_scene else ", one TLAS leaf beside the other instances") + ", hits reported as the scene's own instances and triangles (rt_upload_triangle_aliases); tree built on the host in %.2f s (SAH object + spatial splits, all threads, then the children of every node seated in the octant slots by what 1 M seeded sample rays -- a quarter camera paths, half from free-space points, a quarter surface rays -- say: config static_slot_learning_rays, host/SlotOrder.cpp; at scene load, not in the timed region); --merge-static 0 runs the reference's layout")
                                            % (pt.static_geometry_members, scene.mesh_count, int((pt.array("alias_mesh_ids") >= 0).sum()), pt.static_geometry_build_seconds)) if pt.static_geometry_members else "one CWBVH per mesh under a CWBVH TLAS (the reference's layout)",
                 "rays_per_step": round(rays_plan / args.steps), "shadow_rays_per_step": round(shadow_plan / args.steps),
                 "mrays_s_including_shadow": round((rays_plan + shadow_plan) / elapsed / 1e6, 1),

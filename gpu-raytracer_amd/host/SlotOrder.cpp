@@ -7,8 +7,9 @@
 // ends inside child H of a node walks every other child that is seated in front of H for its octant and whose box it enters -- also
 // those whose box begins BEHIND the hit, which it would have skipped had it been to H first. That is counted here, on the tree itself:
 //   1  sample rays (seeded, a pure function of the input): from area-weighted points on the triangles, cosine-distributed about the
-//      normal (what a bounce is) or towards another such point and no further (what a shadow ray is) -- and, when the caller hands over
-//      its camera, three quarters of them as the paths it is about to trace: a camera ray through a random pixel and up to three bounces;
+//      normal (what a bounce is) or towards another such point and no further (what a shadow ray is); half of the budget from points of
+//      the FREE space (somewhere along such a bounce) in uniformly random directions (what a camera standing there would send) -- and, when
+//      the caller hands over its camera, a quarter as the paths it is about to trace: a ray through a random pixel and up to three bounces;
 //   2  each is traced for its closest hit; along the path from the root to the leaf that holds the hit, every inner child c that the
 //      ray enters only BEHIND the hit scores one for the pair (c in front of H) in the ray's octant;
 //   3  per node, the children trade slots while that lowers the score summed over the eight octants; the records of its inner children
@@ -193,6 +194,21 @@ struct Learner {
 		return tangent * (radius * cosf(phi)) + bitangent * (radius * sinf(phi)) + normal * sqrtf(std::max(0.0f, 1.0f - r1));
 	}
 
+	// A ray from a point of the scene's free space in a uniformly random direction: what a camera standing THERE would send. The point: somewhere along a
+	// cosine bounce off the surface, before its hit.
+	void learn_from_free_point(uint64_t index) {
+		Random rng(mix(index * 0xD1342543DE82EF95ull + 4242ull));
+		Vector3 from, normal; surface_point(rng, from, normal);
+		if (rng.next() < 0.5f) normal = normal * -1.0f;
+		SampleRay probe; set_ray(probe, from + normal * (1.0e-4f * scene_size), cosine_direction(rng, normal), INFINITY);
+		float reach; if (trace(probe, reach) < 0) reach = 0.25f * scene_size;
+		const float along = reach * (0.1f + 0.8f * rng.next());
+		const Vector3 eye = Vector3(probe.o[0], probe.o[1], probe.o[2]) + Vector3(probe.d[0], probe.d[1], probe.d[2]) * along;
+		const float z = 1.0f - 2.0f * rng.next(), phi = 6.2831853f * rng.next(), rho = sqrtf(std::max(0.0f, 1.0f - z * z));
+		SampleRay r; set_ray(r, eye, Vector3(rho * cosf(phi), rho * sinf(phi), z), INFINITY);
+		float unused; (void)learn_from(r, unused);
+	}
+
 	// One path as the integrator is about to trace them (Pathtracer.cu:122-139, 557-773 in outline): a camera ray through a random pixel, then up to `bounces`
 	// cosine-distributed bounces; every ray is a sample. (Shadow rays towards the emitting meshes were sampled too and taken out again: scored like closest-hit rays
 	// they made the real ones' walks LONGER, 12.9 -> 13.6 node steps -- an any-hit ray does not care for the nearest occluder; the surface-to-surface segments of
@@ -267,10 +283,15 @@ void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<Triangle> & triangles, 
 	{
 		std::atomic<int> next(0);
 		// with a view: three quarters of the rays come as paths from the camera (up to 4 rays each), the rest from the surface itself
-		const int surface_rays = learner.view ? rays / 4 : rays, paths = learner.view ? (rays - surface_rays) / 4 : 0, items = surface_rays + paths;
+		// the budget: a quarter as paths from the caller's camera (if it has one), half from points of the free space, the rest from the surface itself. Measured
+		// (profiles/r05_slot_assignment.txt, 4.): a quarter of camera paths already seats the tree for that camera as well as three quarters do (1.308 against 1.301 ms
+		// per step), and the free-space rays are what other viewpoints gain from (the reference's nine: 1.286 against 1.291; no camera paths at all: 1.344 / 1.303)
+		const float camera_share = learner.view ? 0.25f : 0.0f, free_share = 0.5f;
+		const int paths = int(float(rays) * camera_share) / 4, free_rays = int(float(rays) * free_share) / 2, surface_rays = std::max(0, rays - paths * 4 - free_rays * 2), items = surface_rays + paths + free_rays;
 		auto work = [&] { for (int begin; (begin = next.fetch_add(512)) < items; ) for (int i = begin; i < std::min(items, begin + 512); i++) {
 			if (i < surface_rays) { SampleRay r; float unused; if (learner.make_ray(uint64_t(i), r)) (void)learner.learn_from(r, unused); }
-			else (void)learner.learn_from_path(uint64_t(i - surface_rays), 3);
+			else if (i < surface_rays + paths) (void)learner.learn_from_path(uint64_t(i - surface_rays), 3);
+			else learner.learn_from_free_point(uint64_t(i - surface_rays - paths));
 		} };
 		std::vector<std::thread> helpers;
 		for (int t = 1; t < thread_count; t++) helpers.emplace_back(work);
