@@ -244,6 +244,7 @@ struct Learner {
 
 void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<Triangle> & triangles, int rays, int thread_count, const SlotLearningView * view) {
 	if (bvh.nodes.empty() || triangles.empty() || bvh.indices.empty() || rays <= 0) return;
+	rays = std::min(rays, 8 << 20);   // (the counters are 32 bits wide: a detour weighs a few hundred at most, the root sees every ray)
 	Learner learner(bvh, triangles);
 	if (view && view->width > 0 && view->height > 0) learner.view = view;
 	if (const char * c = getenv("GRT_SLOT_LEARNING_UNWEIGHTED")) learner.weigh_by_work = atoi(c) == 0;
