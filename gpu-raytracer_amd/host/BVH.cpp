@@ -253,33 +253,35 @@ void BVH8Converter::gather_children(int node_index, int budget, int children[8],
 	else children[child_count++] = node.left + 1;
 }
 
-// Greedy assignment of children to the 8 octant slots: slot s is entered first by rays
-// whose direction signs are s, so a child should sit in the slot whose diagonal points
-// towards it (BVH8Converter.cpp:146-205). Strict '<' => first minimum in (child, slot) order.
+// Assignment of children to the 8 octant slots: slot s is entered first by rays whose direction signs are s, so a child should sit in
+// the slot whose diagonal points towards it.
+//   slot_assignment 0: the reference's rule (BVH8Converter.cpp:146-205) -- every child competes, by where its CENTRE lies, greedily
+//                      (strict '<' => first minimum in (child, slot) order). Per-mesh trees and the TLAS: byte-identical to the reference.
+//   slot_assignment 5: the flattened tree's rule (cpu_config.static_slot_assignment) -- only INNER children compete (a leaf's triangles are
+//                      tested in the node's own round whatever its slot: leaves take what is left), by the CORNER a ray along the slot's
+//                      diagonal enters the child's box at, and by the assignment of least TOTAL cost (children in order over the subsets
+//                      of slots already given away: 8 x 256 steps). Other rules that were measured: profiles/r05_slot_assignment.txt.
 void BVH8Converter::assign_octant_slots(int node_index, int children[8], int child_count) {
 	Vector3 p = bvh2.nodes[node_index].aabb.get_center();
 
 	float cost[8][8] = { };
 	for (int c = 0; c < child_count; c++) {
-		Vector3 offset = bvh2.nodes[children[c]].aabb.get_center() - p;
+		const AABB & b = bvh2.nodes[children[c]].aabb;
+		Vector3 offset = b.get_center() - p;
+		const bool leaf = table[size_t(children[c]) * 7].kind == LEAF;
 		for (int s = 0; s < 8; s++) {
 			Vector3 diagonal((s & 4) ? -1.0f : +1.0f, (s & 2) ? -1.0f : +1.0f, (s & 1) ? -1.0f : +1.0f);
-			cost[c][s] = Vector3::dot(offset, diagonal);
-			if (slot_assignment >= 2) {   // experiments: the corner a ray along the diagonal ENTERS the child's box at (2), leaves it at (3), their mean weighted 3 : 1 (4)
-				const AABB & b = bvh2.nodes[children[c]].aabb;
+			if (slot_assignment == 0) cost[c][s] = Vector3::dot(offset, diagonal);
+			else {
 				Vector3 near_corner((s & 4) ? b.max.x : b.min.x, (s & 2) ? b.max.y : b.min.y, (s & 1) ? b.max.z : b.min.z);
-				Vector3 far_corner ((s & 4) ? b.min.x : b.max.x, (s & 2) ? b.min.y : b.max.y, (s & 1) ? b.min.z : b.max.z);
-				float near_cost = Vector3::dot(near_corner - p, diagonal), far_cost = Vector3::dot(far_corner - p, diagonal);
-				cost[c][s] = slot_assignment == 3 ? far_cost : slot_assignment == 4 ? 0.75f * near_cost + 0.25f * far_cost : near_cost;
-				// 5 and up: only INNER children are visited in slot order (a leaf's triangles are tested in the node's own round whatever its slot): leaves take what is left
-				if (slot_assignment >= 5 && table[size_t(children[c]) * 7].kind == LEAF) cost[c][s] = 0.0f;
+				cost[c][s] = leaf ? 0.0f : Vector3::dot(near_corner - p, diagonal);
 			}
 		}
 	}
 
 	int  slot_of_child[8] = { INVALID, INVALID, INVALID, INVALID, INVALID, INVALID, INVALID, INVALID };
 	bool slot_taken[8] = { };
-	if (slot_assignment >= 1) {   // least total cost: children in order over the subsets of slots already given away (8 x 256 steps)
+	if (slot_assignment != 0) {
 		float best[256]; signed char from[256];
 		for (int m = 0; m < 256; m++) { best[m] = INFINITY; from[m] = -1; }
 		best[0] = 0.0f;
@@ -291,49 +293,6 @@ void BVH8Converter::assign_octant_slots(int node_index, int children[8], int chi
 		int end = -1; float least = INFINITY;
 		for (int m = 0; m < 256; m++) if (__builtin_popcount(unsigned(m)) == child_count && best[m] < least) { least = best[m]; end = m; }
 		for (int c = child_count - 1, m = end; c >= 0 && m > 0; c--) { int s = from[m]; slot_of_child[c] = s; slot_taken[s] = true; m &= ~(1 << s); }
-		if (slot_assignment >= 6 && end >= 0) {
-			// 6 / 7: from there, exchange slots while that lowers how far out of order the eight octants' walks are: a ray whose direction signs are v (bit set: not
-			// negative, the kernel's oct_inv) visits inner children by falling slot ^ v; ideally by rising distance of the corner it enters them at along its diagonal.
-			// What is summed: (entry of the one visited earlier - entry of the one visited later) where positive, over the pairs of inner children and the 8 octants,
-			// weighted 1 (6) or by the product of the two boxes' areas (7: how likely a ray meets both).
-			bool inner[8]; float entry[8][8], area[8];
-			for (int c = 0; c < child_count; c++) {
-				inner[c] = table[size_t(children[c]) * 7].kind != LEAF;
-				const AABB & b = bvh2.nodes[children[c]].aabb;
-				Vector3 d = b.max - b.min; area[c] = 2.0f * (d.x * d.y + d.y * d.z + d.z * d.x);
-				for (int v = 0; v < 8; v++) {
-					Vector3 diagonal((v & 4) ? +1.0f : -1.0f, (v & 2) ? +1.0f : -1.0f, (v & 1) ? +1.0f : -1.0f);
-					Vector3 corner((v & 4) ? b.min.x : b.max.x, (v & 2) ? b.min.y : b.max.y, (v & 1) ? b.min.z : b.max.z);
-					entry[c][v] = Vector3::dot(corner - p, diagonal);
-				}
-			}
-			auto disorder = [&](const int * slot) {
-				double sum = 0.0;
-				for (int v = 0; v < 8; v++) for (int a = 0; a < child_count; a++) if (inner[a]) for (int b = 0; b < child_count; b++) if (inner[b] && a != b && (slot[a] ^ v) > (slot[b] ^ v)) {
-					float excess = entry[a][v] - entry[b][v];
-					if (excess > 0.0f) sum += double(excess) * (slot_assignment == 7 ? double(area[a]) * double(area[b]) : 1.0);
-				}
-				return sum;
-			};
-			double current = disorder(slot_of_child);
-			for (bool improved = true; improved; ) {
-				improved = false;
-				int best_a = -1, best_to = -1; double best = current;
-				for (int a = 0; a < child_count; a++) if (inner[a]) for (int to = 0; to < 8; to++) if (to != slot_of_child[a]) {
-					int trial[8]; for (int c = 0; c < 8; c++) trial[c] = slot_of_child[c];
-					for (int c = 0; c < child_count; c++) if (trial[c] == to) trial[c] = slot_of_child[a];   // whoever sits there trades places
-					trial[a] = to;
-					double v = disorder(trial);
-					if (v < best) { best = v; best_a = a; best_to = to; }
-				}
-				if (best_a >= 0) {
-					for (int c = 0; c < child_count; c++) if (slot_of_child[c] == best_to) slot_of_child[c] = slot_of_child[best_a];
-					slot_of_child[best_a] = best_to; current = best; improved = true;
-				}
-			}
-			for (int s2 = 0; s2 < 8; s2++) slot_taken[s2] = false;
-			for (int c = 0; c < child_count; c++) slot_taken[slot_of_child[c]] = true;
-		}
 	} else
 	while (true) {
 		float best = INFINITY;

@@ -164,7 +164,7 @@ struct BVH8Converter {
 	const BVH2 & bvh2;
 
 	float primitive_cost = 1.0f;   // SAH cost of a triangle test relative to a node step: 1 in the reference's converter (BVH8Converter.cpp:24-115)
-	int   slot_assignment = 0;     // 0: the reference's greedy assignment of children to octant slots; 1: the assignment of least total cost (experiment, profiles/r05_traversal_experiments.txt)
+	int   slot_assignment = 0;     // 0: the reference's greedy assignment of children to octant slots by their centres; otherwise (5): inner children only, by entry corner, least total cost (BVH.cpp: assign_octant_slots)
 	BVH8Converter(BVH8 & bvh8, const BVH2 & bvh2) : bvh8(bvh8), bvh2(bvh2) { }
 	void convert();
 

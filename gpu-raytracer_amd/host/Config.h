@@ -89,9 +89,9 @@ struct CPUConfig {
 	// ... and what a triangle test costs relative to a node step when that tree's binary form is collapsed into 8-wide nodes
 	// (BVH8Converter: 1 in the reference; here a triangle test runs with a quarter of a wave's lanes, a node step with most)
 	float static_primitive_cost = 1.0f;
-	// ... and how that collapse deals a node's children to the eight octant slots (BVH8Converter::slot_assignment): 0 = the reference's greedy rule
-	// (BVH8Converter.cpp:146-205), 5 / 7 = inner children to the slots of least total cost by the corner a ray enters them at, leaves take what is left (7: then
-	// exchanged while that lowers how far out of order the eight octants' walks are). The flattened tree is this renderer's own layout: its slot order is free.
+	// ... and how that collapse deals a node's children to the eight octant slots (BVH8Converter::slot_assignment): 0 = the reference's greedy rule by centres
+	// (BVH8Converter.cpp:146-205), 5 = inner children to the slots of least total cost by the corner a ray enters them at, leaves take what is left.
+	// The flattened tree is this renderer's own layout: its slot order is free.
 	int   static_slot_assignment = 5;
 	// ... and then re-seated by what this many sample rays over the flattened geometry say (bvh8_learn_slot_order, SlotOrder.cpp: a seeded, pure function of the
 	// geometry). 0: off.
