@@ -202,6 +202,8 @@ def host_lib():
         lib.grt_built_array.restype = c_void_p
         lib.grt_built_array.argtypes = [c_void_p, c_char_p, POINTER(c_size_t)]
         lib.grt_built_free.argtypes = [c_void_p]
+        lib.grt_built_learn_slot_order.restype = c_int
+        lib.grt_built_learn_slot_order.argtypes = [c_void_p, c_int, c_int]
         _host = lib
     return _host
 

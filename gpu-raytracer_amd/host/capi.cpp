@@ -639,6 +639,15 @@ void * grt_build_static_bvh(const float * tris24, int n, int threads) {
 		return md;
 	GRT_CATCH(nullptr)
 }
+// The seating learner on a tree built by one of the two calls around it (tests): `rays` sample rays, `threads` host threads (<= 0: all); the tree's bvh8_nodes change in place.
+int grt_built_learn_slot_order(void * handle, int rays, int threads) {
+	GRT_TRY
+		MeshData * md = (MeshData *)handle;
+		if (!md) return -1;
+		bvh8_learn_slot_order(md->bvh8, md->triangles, rays, threads);
+		return 0;
+	GRT_CATCH(-1)
+}
 // Experiments with the builder behind a CWBVH: spatial splits (SBVH: a triangle may sit in several leaves, `bvh8_indices` then
 // repeats it) and / or the insertion optimiser, then the same 8-wide collapse.
 void * grt_build_blas_variant(const float * tris24, int n, int spatial_splits, int optimize) {

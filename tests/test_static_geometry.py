@@ -541,3 +541,54 @@ def test_learned_slot_order_reseats_children_and_nothing_else(grt, oracle):
     scene_c, pt_c, _ = build(static_slot_learning_rays=300000)
     assert np.array_equal(nodes_b, pt_c.array("bvh8_nodes").reshape(-1, 80))
     pt_c.close(); scene_c.close()
+
+
+def _wide_child_rows(wide):
+    """Per 80-byte node: (header without imask, its children as sorted (kind, six box bytes) rows); the list sorted -- what a re-seating may not change."""
+    rows = []
+    for n in wide.reshape(-1, 80):
+        meta, imask = n[24:32], n[15]
+        kids = []
+        for s in range(8):
+            if meta[s] == 0: continue
+            kind = 255 if (imask >> s) & 1 else int(meta[s] >> 5)
+            kids.append((kind,) + tuple(int(n[32 + 8 * k + s]) for k in range(6)))
+        rows.append((tuple(int(v) for v in n[:15]), tuple(sorted(kids))))
+    return sorted(rows)
+
+
+def test_slot_learner_on_soups_slivers_and_degenerate_input_and_any_thread_count(grt):
+    """bvh8_learn_slot_order (host/SlotOrder.cpp) on what a loader can hand it: it must not crash, must only re-seat children (the same children per node, the same
+    node count), and must give the same bytes on 1, 3 and 8 threads (seeded samples, integer scores)."""
+    import ctypes
+    lib = grt.host_lib()
+    rng = np.random.default_rng(8)
+    soup = rng.uniform(-1, 1, (4000, 1, 3)) + rng.normal(size=(4000, 3, 3)) * 0.05
+    broken = soup[:300].copy(); broken[7, 1, 2] = np.nan; broken[11, 0, 0] = np.inf
+    cases = {
+        "soup": soup, "one": soup[:1], "four": soup[:4], "copies": np.repeat(soup[:1], 64, axis=0),
+        "points": np.repeat(rng.uniform(-1, 1, (50, 1, 3)), 3, axis=1),
+        "flat": np.concatenate([rng.uniform(-1, 1, (500, 3, 2)), np.zeros((500, 3, 1))], axis=2),
+        "non-finite": broken,
+    }
+    def learned(triangles, rays, threads):
+        t24 = np.zeros((len(triangles), 24), np.float32); t24[:, :9] = np.asarray(triangles, np.float32).reshape(-1, 9)
+        handle = lib.grt_build_static_bvh(t24.ctypes.data, len(triangles), 0)
+        assert handle, lib.grt_last_error()
+        def wide():
+            size = ctypes.c_size_t(0); p = lib.grt_built_array(handle, b"bvh8_nodes", ctypes.byref(size))
+            return np.frombuffer((ctypes.c_char * size.value).from_address(p), dtype=np.uint8).copy() if size.value else np.zeros(0, np.uint8)
+        before = wide()
+        assert lib.grt_built_learn_slot_order(handle, rays, threads) == 0, lib.grt_last_error()
+        after = wide()
+        lib.grt_built_free(handle)
+        return before, after
+    for name, triangles in cases.items():
+        before, after = learned(triangles, 20000, 0)
+        assert before.shape == after.shape, name
+        assert _wide_child_rows(before) == _wide_child_rows(after), name
+    before, one = learned(soup, 60000, 1)
+    assert not np.array_equal(before, one)                      # (a soup of 4 000 triangles does get re-seated)
+    for threads in (3, 8):
+        assert np.array_equal(one, learned(soup, 60000, threads)[1]), threads
+    assert np.array_equal(learned(soup, 0, 0)[0], learned(soup, 0, 0)[1])     # no rays: nothing moves
