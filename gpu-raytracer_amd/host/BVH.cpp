@@ -212,6 +212,9 @@ int BVH8Converter::fill_cost_table(int node_index) {
 			float c = row_l[k].cost + row_r[6 - k].cost;
 			if (c < cost_distribute) { cost_distribute = c; take_l = char(k); take_r = char(6 - k); }
 		}
+		// (boxes of non-finite vertices make every candidate NaN or +inf and none compares less: the budget is then halved -- any consistent split keeps the
+		// collapse within 8 children; with finite boxes the first candidate always compares less than INFINITY and nothing changes)
+		if (take_l == char(INVALID)) { take_l = char(3); take_r = char(3); }
 		float cost_internal = cost_distribute + node.aabb.surface_area();
 
 		if (cost_leaf < cost_internal) { row[0].kind = LEAF;     row[0].cost = cost_leaf; }
@@ -241,16 +244,18 @@ int BVH8Converter::fill_cost_table(int node_index) {
 
 void BVH8Converter::gather_children(int node_index, int budget, int children[8], int & child_count) {
 	const BVHNode2 & node = bvh2.nodes[node_index];
+	if (child_count >= 8 || budget < 0 || budget > 6) throw std::runtime_error("BVH8 conversion: a node's children do not fit its eight slots (inconsistent cost table)");
 	if (node.is_leaf()) { children[child_count++] = node_index; return; }
 
 	int take_l = table[size_t(node_index) * 7 + budget].take_left;
 	int take_r = table[size_t(node_index) * 7 + budget].take_right;
+	if (take_l < 0 || take_r < 0 || take_l + take_r > 6) throw std::runtime_error("BVH8 conversion: inconsistent cost table");
 
 	if (table[size_t(node.left) * 7 + take_l].kind == DISTRIBUTE) gather_children(node.left, take_l, children, child_count);
-	else children[child_count++] = node.left;
+	else { if (child_count >= 8) throw std::runtime_error("BVH8 conversion: a node's children do not fit its eight slots (inconsistent cost table)"); children[child_count++] = node.left; }
 
 	if (table[size_t(node.left + 1) * 7 + take_r].kind == DISTRIBUTE) gather_children(node.left + 1, take_r, children, child_count);
-	else children[child_count++] = node.left + 1;
+	else { if (child_count >= 8) throw std::runtime_error("BVH8 conversion: a node's children do not fit its eight slots (inconsistent cost table)"); children[child_count++] = node.left + 1; }
 }
 
 // Assignment of children to the 8 octant slots: slot s is entered first by rays whose direction signs are s, so a child should sit in

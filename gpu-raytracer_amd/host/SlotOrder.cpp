@@ -125,6 +125,8 @@ struct Learner {
 
 	// returns the leaf position of the ray's closest hit (or -1) and its distance
 	int learn_from(const SampleRay & r, float & t_hit) {
+		t_hit = r.tmax;
+		if (!std::isfinite(r.o[0] + r.o[1] + r.o[2]) || !std::isfinite(r.d[0] + r.d[1] + r.d[2])) return -1;   // (a ray of NaNs enters every box: non-finite vertices must not cost a walk of the whole tree per sample)
 		const int hit = trace(r, t_hit);
 		if (hit < 0) return hit;
 		unsigned node = 0;
@@ -201,6 +203,7 @@ struct Learner {
 		Vector3 from, normal; surface_point(rng, from, normal);
 		if (rng.next() < 0.5f) normal = normal * -1.0f;
 		SampleRay probe; set_ray(probe, from + normal * (1.0e-4f * scene_size), cosine_direction(rng, normal), INFINITY);
+		if (!std::isfinite(probe.o[0] + probe.o[1] + probe.o[2]) || !std::isfinite(probe.d[0] + probe.d[1] + probe.d[2])) return;
 		float reach; if (trace(probe, reach) < 0) reach = 0.25f * scene_size;
 		const float along = reach * (0.1f + 0.8f * rng.next());
 		const Vector3 eye = Vector3(probe.o[0], probe.o[1], probe.o[2]) + Vector3(probe.d[0], probe.d[1], probe.d[2]) * along;
@@ -272,12 +275,14 @@ void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<Triangle> & triangles, 
 	Vector3 lo(+INFINITY), hi(-INFINITY); double running = 0.0;
 	for (size_t i = 0; i < triangles.size(); i++) {
 		const Triangle & t = triangles[i];
-		running += 0.5 * double(Vector3::length(Vector3::cross(t.position_1 - t.position_0, t.position_2 - t.position_0)));
+		const double area = 0.5 * double(Vector3::length(Vector3::cross(t.position_1 - t.position_0, t.position_2 - t.position_0)));
+		if (std::isfinite(area)) running += area;   // (a triangle with non-finite vertices is never picked)
 		learner.area_cdf[i] = float(running);
-		for (const Vector3 * p : { &t.position_0, &t.position_1, &t.position_2 }) { lo = Vector3::min(lo, *p); hi = Vector3::max(hi, *p); }
+		if (std::isfinite(area)) for (const Vector3 * p : { &t.position_0, &t.position_1, &t.position_2 }) { lo = Vector3::min(lo, *p); hi = Vector3::max(hi, *p); }
 	}
 	if (!(learner.area_cdf.back() > 0.0f)) return;
 	learner.scene_size = Vector3::length(hi - lo);
+	if (!std::isfinite(learner.scene_size) || !(learner.scene_size > 0.0f)) return;
 
 	if (thread_count <= 0) thread_count = int(std::max(1u, std::thread::hardware_concurrency()));
 	thread_count = std::min(thread_count, 64);

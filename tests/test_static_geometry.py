@@ -444,6 +444,13 @@ def test_static_bvh_builder_survives_non_finite_vertices(grt):
         broken = triangles.copy(); broken[5, 1, 2] = poison; broken[100, 0, 0] = poison
         nodes, indices, wide = build_static(grt, broken)
         assert len(indices) >= 2000 and sorted(set(indices.tolist())) == list(range(2000)) and wide.size > 0
+    # ... nor the 8-wide collapse behind it: boxes of non-finite vertices make every candidate of its cost table NaN or +inf; an inconsistent table once sent
+    # gather_children past a node's eight slots (a stack overflow found with one +inf vertex among 20 000 triangles; BVH.cpp: fill_cost_table halves the budget then)
+    big = rng.uniform(-1, 1, (20000, 1, 3)) + rng.normal(size=(20000, 3, 3)) * 0.03
+    for poison in (np.inf, np.nan):
+        broken = big.copy(); broken[5, 0, 0] = poison
+        nodes, indices, wide = build_static(grt, broken)
+        assert sorted(set(indices.tolist())) == list(range(20000)) and wide.size > 0 and wide.size % 80 == 0
 
 
 def test_early_split_clipping_covers_every_triangle_with_the_boxes_of_its_pieces(grt):
@@ -565,11 +572,12 @@ def test_slot_learner_on_soups_slivers_and_degenerate_input_and_any_thread_count
     rng = np.random.default_rng(8)
     soup = rng.uniform(-1, 1, (4000, 1, 3)) + rng.normal(size=(4000, 3, 3)) * 0.05
     broken = soup[:300].copy(); broken[7, 1, 2] = np.nan; broken[11, 0, 0] = np.inf
+    one_bad_vertex = soup.copy(); one_bad_vertex[5, 0, 0] = np.inf   # (every sample ray that touches it is dropped: a ray of NaNs would walk the whole tree)
     cases = {
         "soup": soup, "one": soup[:1], "four": soup[:4], "copies": np.repeat(soup[:1], 64, axis=0),
         "points": np.repeat(rng.uniform(-1, 1, (50, 1, 3)), 3, axis=1),
         "flat": np.concatenate([rng.uniform(-1, 1, (500, 3, 2)), np.zeros((500, 3, 1))], axis=2),
-        "non-finite": broken,
+        "non-finite": broken, "one infinite vertex": one_bad_vertex,
     }
     def learned(triangles, rays, threads):
         t24 = np.zeros((len(triangles), 24), np.float32); t24[:, :9] = np.asarray(triangles, np.float32).reshape(-1, 9)
