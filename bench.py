@@ -99,6 +99,8 @@ def build_scene(grt):
         grt.config_set(static_slot_learning_rays=int(os.environ["BENCH_SLOT_LEARNING_RAYS"]))
     if os.environ.get("BENCH_SLOT_LEARNING_VIEWPOINT"):
         grt.config_set(static_slot_learning_viewpoint=int(os.environ["BENCH_SLOT_LEARNING_VIEWPOINT"]))
+    if os.environ.get("BENCH_SKIP_BEHIND_HIT"):   # A / B: 0 = the reference's walk node for node (config skip_behind_hit, rt_set_skip_behind_hit)
+        grt.config_set(skip_behind_hit=int(os.environ["BENCH_SKIP_BEHIND_HIT"]))
     # the reference's own 19 diffuse maps when build() could install them (assets/_cache, see install_reference_sponza_textures),
     # else the quarter-size maps that travel inside the repository, every texel replicated 4x4
     scene = grt.Scene(grt.scene_path("sponza_reference_maps" if grt.reference_sponza_textures_installed() else "sponza"))

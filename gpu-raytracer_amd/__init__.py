@@ -73,8 +73,8 @@ def device_lib():
         # first) keeps HIP's default of 4 queues and the context says so when it matters.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
         lib = ctypes.CDLL(DEVICE_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-        if hasattr(lib, "rt_abi_version") and lib.rt_abi_version() != 7:
-            raise DeviceLibraryMissing("%s has ABI version %d, this front end was written for 7 -- rebuild (python __graft_entry__.py)" % (DEVICE_LIB_PATH, lib.rt_abi_version()))
+        if hasattr(lib, "rt_abi_version") and lib.rt_abi_version() != 8:
+            raise DeviceLibraryMissing("%s has ABI version %d, this front end was written for 8 -- rebuild (python __graft_entry__.py)" % (DEVICE_LIB_PATH, lib.rt_abi_version()))
         lib.rt_last_error.restype = c_char_p
         lib.rt_last_error.argtypes = [c_void_p]
         lib.rt_version.restype = c_char_p
@@ -157,6 +157,8 @@ def host_lib():
         lib.grt_pathtracer_static_geometry_members.argtypes = [c_void_p]
         lib.grt_pathtracer_static_geometry_whole_scene.restype = c_int
         lib.grt_pathtracer_static_geometry_whole_scene.argtypes = [c_void_p]
+        lib.grt_pathtracer_skip_behind_hit.restype = c_int
+        lib.grt_pathtracer_skip_behind_hit.argtypes = [c_void_p]
         lib.grt_pathtracer_static_geometry_root.restype = c_int
         lib.grt_pathtracer_static_geometry_root.argtypes = [c_void_p]
         lib.grt_pathtracer_static_geometry_top_nodes.restype = c_int
@@ -540,6 +542,11 @@ class Pathtracer:
     def static_geometry_whole_scene(self):
         """Every instance is in the flattened tree: there is no TLAS, rays start inside the tree (rt_set_static_geometry)."""
         return bool(host_lib().grt_pathtracer_static_geometry_whole_scene(self.handle))
+
+    @property
+    def skip_behind_hit(self):
+        """Closest-hit rays drop stacked groups of children behind the hit they hold (config skip_behind_hit AND a one-tree scene: rt_set_skip_behind_hit)."""
+        return bool(host_lib().grt_pathtracer_skip_behind_hit(self.handle))
 
     @property
     def static_geometry_top_levels(self):

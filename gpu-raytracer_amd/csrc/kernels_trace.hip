@@ -106,8 +106,32 @@ RT_DEV f3 transform_direction(const float4 * m, f3 d) {
 
 // 8 slab tests against the quantised child boxes of one node; returns the hit mask
 // (bits 24..31: inner children in octant order, bits 0..23: triangles / TLAS leaves).
+// ---- skip behind the hit (rt_set_skip_behind_hit; the flattened scene's walk) ------------------------------------------------------
+// The reference visits a node's children by falling `slot ^ octant` and keeps the others as ONE stack entry (child base, hit mask):
+// an entry carries no distance, so a closest-hit ray still walks into every stacked child after a hit in front of it has been
+// found -- 12 % of the node visits on Sponza (profiles/r05_traversal_experiments.txt g, h), each a full round that enters no child.
+// Here the node test also keeps the two smallest KEYS of the children it enters: key = entry distance tmin (its low byte replaced
+// by the child's bit index, unique within a node; tmin >= 0, so keys order like the distances as SIGNED integers -- a -0 sorts in
+// front of everything, which is only conservative). The stacked rest of a group is everything but the child visited first (the
+// highest inner bit of the mask), so its bound is the smallest key that is not that child's: `second` if the nearest child IS the
+// first one, else `least`. Cut down to 16 bits (sign, exponent, 7 mantissa bits: rounded towards zero, again conservative) it
+// rides in bits 8..23 of the group's mask word, which the reference leaves empty; at a pop a group whose bound is not in front of
+// the hit held (shadow rays: the maximum distance -- never, their children were tested against it already) is dropped unvisited.
+// Every child of such a group has tmin >= bound >= hit.t: its own test `tmin < min(.., hit.t)` in the parent fails today, the
+// drop merely evaluates it with the hit distance of the pop instead of the push. Leaf children (tested in the node's own round)
+// take part in the minima as well: excluding them costs instructions and changes 11.505 to 11.520 node steps per ray.
+// Counted on the CPU (tests/slot_eval.py, the benchmark's rays): 13.09 -> 11.52 node steps per closest-hit ray (-12 %).
+RT_DEV unsigned skip_bound_bits(unsigned hit_mask, int least, int second) {
+	// (least's bit index == msb(hit_mask), written on the leading-zero count: 31 - x == ~x & 31. An empty mask has no group to bound: any value will do.)
+	int key = unsigned(__builtin_clz(hit_mask)) == (~unsigned(least) & 0x1fu) ? second : least;
+	return (unsigned(key) >> 8) & 0x00ffff00u;
+}
+RT_DEV bool skip_group_is_behind(unsigned group_y, float limit) { return int((group_y << 8) & 0xffff0000u) >= __float_as_int(limit); }
+#define RT_SKIP_NO_KEY 0x7fffffff
+
+template<bool BOUND = false>
 RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_inv4, float max_distance,
-                                    float4 n0, float4 n1, float4 n2, float4 n3, float4 n4) {
+                                    float4 n0, float4 n1, float4 n2, float4 n3, float4 n4, unsigned * bound_bits = nullptr) {
 	f3 p = mk3(n0.x, n0.y, n0.z);
 	unsigned e_imask = __float_as_uint(n0.w);
 
@@ -120,6 +144,7 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 	bool neg_x = ray.direction.x < 0.0f, neg_y = ray.direction.y < 0.0f, neg_z = ray.direction.z < 0.0f;
 
 	unsigned hit_mask = 0;
+	int least = RT_SKIP_NO_KEY, second = RT_SKIP_NO_KEY;
 	#pragma unroll
 	for (int i = 0; i < 2; i++) {
 		unsigned meta4 = __float_as_uint(i == 0 ? n1.z : n1.w);
@@ -153,9 +178,15 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 				unsigned child_bits = extract_byte(child_bits4, j);
 				unsigned bit_index  = extract_byte(bit_index4,  j);
 				hit_mask |= child_bits << bit_index;
+				if (BOUND) {
+					int key = int((__float_as_uint(tmin) & 0xffffff00u) | bit_index);
+					second = max(min(second, key), min(max(second, key), least));   // the median of the three: the second smallest so far
+					least  = min(least, key);
+				}
 			}
 		}
 	}
+	if (BOUND) *bound_bits = skip_bound_bits(hit_mask, least, second);
 	return hit_mask;
 }
 
@@ -179,10 +210,11 @@ RT_DEV unsigned bvh8_node_intersect(const Ray3 & ray, f3 inv_dir, unsigned oct_i
 #ifndef RT_FAST_NODE
 #define RT_FAST_NODE 1
 #endif
+template<bool BOUND = false>
 RT_DEV unsigned bvh8_node_intersect_fast(const Ray3 & ray, f3 inv_dir, unsigned oct_inv4, float max_distance,
-                                         float4 n0, float4 n1, float4 n2, float4 n3, float4 n4) {
+                                         float4 n0, float4 n1, float4 n2, float4 n3, float4 n4, unsigned * bound_bits = nullptr) {
 #if !defined(__gfx950__)
-	return bvh8_node_intersect(ray, inv_dir, oct_inv4, max_distance, n0, n1, n2, n3, n4);   // (host pass and any other target)
+	return bvh8_node_intersect<BOUND>(ray, inv_dir, oct_inv4, max_distance, n0, n1, n2, n3, n4, bound_bits);   // (host pass and any other target)
 #else
 	f3 p = mk3(n0.x, n0.y, n0.z);
 	unsigned e_imask = __float_as_uint(n0.w);
@@ -198,6 +230,7 @@ RT_DEV unsigned bvh8_node_intersect_fast(const Ray3 & ray, f3 inv_dir, unsigned 
 	asm("" : "+v"(neg_x)); asm("" : "+v"(neg_y)); asm("" : "+v"(neg_z));
 
 	unsigned hit_mask = 0;
+	int least = RT_SKIP_NO_KEY, second = RT_SKIP_NO_KEY;   // BOUND: see "skip behind the hit" above
 	// The lanes that run this test, read by an instruction of its own directly in front of the eight places that narrow and restore the mask
 	// (volatile asm statements keep their order; the code between here and the last restore is straight-line: the loops are unrolled).
 	unsigned long long all_lanes;
@@ -238,9 +271,17 @@ RT_DEV unsigned bvh8_node_intersect_fast(const Ray3 & ray, f3 inv_dir, unsigned 
 			if (j == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(contribution) : "v"(bit_index4), "v"(child_bits4));
 			if (j == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(contribution) : "v"(bit_index4), "v"(child_bits4));
 			// (tmin < tmax) ? hit_mask |= contribution : nothing -- as a narrowed execution mask; v_cmpx_lt_f32 is false for unordered operands, as the comparison above
+			if (BOUND) {
+				// key = tmin with its low byte replaced by the child's meta byte (low 5 bits: the bit index) -- ONE v_perm_b32; the two running minima are
+				// updated under the narrowed mask, by the lanes that enter the child
+				unsigned key = __builtin_amdgcn_perm(__float_as_uint(tmin), bit_index4, 0x07060500u + unsigned(j));
+				asm volatile("v_cmpx_lt_f32 %3, %4\n\tv_or_b32 %0, %0, %5\n\tv_med3_i32 %2, %1, %2, %6\n\tv_min_i32 %1, %1, %6\n\ts_mov_b64 exec, %7"
+				             : "+v"(hit_mask), "+v"(least), "+v"(second) : "v"(tmin), "v"(tmax), "v"(contribution), "v"(key), "s"(all_lanes) : "vcc");
+			} else
 			asm volatile("v_cmpx_lt_f32 %1, %2\n\tv_or_b32 %0, %0, %3\n\ts_mov_b64 exec, %4" : "+v"(hit_mask) : "v"(tmin), "v"(tmax), "v"(contribution), "s"(all_lanes) : "vcc");
 		}
 	}
+	if (BOUND) *bound_bits = skip_bound_bits(hit_mask, least, second);
 	return hit_mask;
 #endif
 }
@@ -259,6 +300,12 @@ RT_DEV unsigned group8_or(unsigned v) {
 	v |= unsigned(__builtin_amdgcn_mov_dpp(int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror: lane i <- lane 7 - i
 	return v;
 }
+RT_DEV int group8_min_signed(int v) {
+	v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true));
+	v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true));
+	v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true));
+	return v;
+}
 RT_DEV unsigned group8_min(unsigned v) {
 	v = min(v, unsigned(__builtin_amdgcn_mov_dpp(int(v), 0xB1, 0xf, 0xf, true)));
 	v = min(v, unsigned(__builtin_amdgcn_mov_dpp(int(v), 0x4E, 0xf, 0xf, true)));
@@ -267,8 +314,9 @@ RT_DEV unsigned group8_min(unsigned v) {
 }
 
 // The part of bvh8_node_intersect's hit mask that child slot `child` (0..7) contributes.
+// key (optional): this child's key for the bound of "skip behind the hit", RT_SKIP_NO_KEY when the child is not entered.
 RT_DEV unsigned bvh8_node_intersect_child(const Ray3 & ray, f3 inv_dir, unsigned oct_inv4, float max_distance,
-                                          float4 n0, float4 n1, float4 n2, float4 n3, float4 n4, unsigned child) {
+                                          float4 n0, float4 n1, float4 n2, float4 n3, float4 n4, unsigned child, int * key = nullptr) {
 	f3 p = mk3(n0.x, n0.y, n0.z);
 	unsigned e_imask = __float_as_uint(n0.w);
 
@@ -306,6 +354,7 @@ RT_DEV unsigned bvh8_node_intersect_child(const Ray3 & ray, f3 inv_dir, unsigned
 	float tmin = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, 0.0f));
 	float tmax = fminf(fminf(tx1, ty1), fminf(tz1, max_distance));
 
+	if (key) *key = tmin < tmax ? int((__float_as_uint(tmin) & 0xffffff00u) | extract_byte(bit_index4, j)) : RT_SKIP_NO_KEY;
 	return tmin < tmax ? extract_byte(child_bits4, j) << extract_byte(bit_index4, j) : 0u;
 }
 
@@ -365,7 +414,8 @@ RT_DEV bool triangle_test_loaded(float4 part_0, float4 part_1, float4 part_2, in
 
 // The same test with the ray kind decided per lane (the mixed engine of the merged wavefront); with a compile-time
 // constant `shadow` it folds to triangle_test_loaded<SHADOW>.
-RT_DEV bool triangle_test_kind(bool shadow, float4 part_0, float4 part_1, float4 part_2, int mesh_id, int triangle_id, const Ray3 & ray, float max_distance, HitRecord & hit) {
+// hit.t is the far limit of either kind: the closest hit so far, or a shadow ray's maximum distance.
+RT_DEV bool triangle_test_kind(bool shadow, float4 part_0, float4 part_1, float4 part_2, int mesh_id, int triangle_id, const Ray3 & ray, HitRecord & hit) {
 	f3 p0 = mk3(part_0.x, part_0.y, part_0.z);
 	f3 e1 = mk3(part_0.w, part_1.x, part_1.y);
 	f3 e2 = mk3(part_1.z, part_1.w, part_2.x);
@@ -380,9 +430,8 @@ RT_DEV bool triangle_test_kind(bool shadow, float4 part_0, float4 part_1, float4
 		float v = f * dot_fma(ray.direction, q);
 		if (v >= 0.0f && u + v <= 1.0f) {
 			float t = f * dot_fma(e2, q);
-			if (shadow) {
-				if (t > 0.0f && t < max_distance) return true;
-			} else if (t > 0.0f && t < hit.t) {
+			if (t > 0.0f && t < hit.t) {
+				if (shadow) return true;
 				hit.t = t; hit.u = u; hit.v = v;
 				hit.mesh_id = mesh_id;
 				hit.triangle_id = triangle_id;
@@ -469,7 +518,9 @@ template<int MODE, typename Source> RT_DEV void source_finish(const Source & src
 // base address: no compare / select of two 64-bit bases and no scalar load of the TLAS size in every round.
 // FLAT: the whole scene is one world-space tree rooted in node 0 (rt_set_static_geometry): there is no TLAS to walk, no instance
 // to enter or leave, no object-space ray -- the code for those and the three registers that track them are compiled out.
-template<int MODE, bool COUNT, bool NARROW, bool UNIFIED = false, bool FLAT = false, typename Source>
+// SKIP: "skip behind the hit" (above; rt_set_skip_behind_hit) -- only for scenes that are ONE tree (p.entry_tlas_stack_size == 0): a stack entry
+// is then always a group of inner children of that tree.
+template<int MODE, bool COUNT, bool NARROW, bool UNIFIED = false, bool FLAT = false, bool SKIP = false, typename Source>
 RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr, int ray_count_2 = 0, int * cursor_2 = nullptr) {
 	constexpr bool SHADOW = MODE == RT_TRACE_SHADOW;   // the kind of every ray, unless MODE == RT_TRACE_MIXED: then lane_shadow
 	bool lane_shadow = SHADOW;
@@ -546,7 +597,8 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 	Ray3 ray;
 	f3   inv_dir;
 	unsigned oct_inv4 = 0;
-	float max_distance = 0.0f;
+	// (a shadow ray's maximum distance is kept in hit.t: the node test's far limit and the bound of an accepted triangle are `t < hit.t` for both kinds --
+	// a closest-hit ray lowers it with every hit, a shadow ray ends at its first; one register for the two)
 	HitRecord hit;
 	int  tlas_stack_size = RT_INVALID;
 	int  mesh_id = 0;
@@ -572,11 +624,12 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 			ray_index = fetch_ray();
 			if (ray_index < 0) return;
 
-			source_load<MODE>(src, RT_IS_SHADOW, ray_index, ray, max_distance);
+			float max_distance;
+			source_load<MODE>(src, RT_IS_SHADOW, ray_index, ray, max_distance);   // (closest-hit sources: infinity)
 			inv_dir  = reciprocal(ray.direction);
 			oct_inv4 = ray_get_octant_inv4(ray.direction);
 
-			hit.t = RT_INFINITY; hit.u = 0.0f; hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
+			hit.t = max_distance; hit.u = 0.0f; hit.v = 0.0f; hit.mesh_id = 0; hit.triangle_id = RT_INVALID;
 			// A ray starts at node 0. That is the TLAS root -- or, when the whole scene is one flattened tree (rt_set_static_geometry),
 			// that tree's root, and the ray is INSIDE an instance from the start (row 0, identity: the values mesh_id and
 			// mesh_has_identity_transform hold until an instance is entered, which then never happens): no step on a TLAS root and no
@@ -642,14 +695,22 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					float4 n0 = node[0], n1 = node[1], n2 = node[2], n3 = node[3], n4 = node[4];
 					RT_SETPRIO(RT_PHASE_NODE_TEST);
 					if (COUNT) count_nodes++;
-					unsigned hitmask = NARROW ? group8_or(bvh8_node_intersect_child(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4, group_child))
-					                 : (RT_FAST_NODE && UNIFIED && FLAT) ? bvh8_node_intersect_fast(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4)
-					                 : bvh8_node_intersect(ray, inv_dir, oct_inv4, RT_IS_SHADOW ? max_distance : hit.t, n0, n1, n2, n3, n4);
+					unsigned hitmask, bound_bits = 0;
+					if (NARROW) {
+						int key;
+						hitmask = group8_or(bvh8_node_intersect_child(ray, inv_dir, oct_inv4, hit.t, n0, n1, n2, n3, n4, group_child, SKIP ? &key : nullptr));
+						if (SKIP) {   // the two smallest keys of the group's eight lanes (keys of entered children are distinct: the bit index is part of them)
+							int least = group8_min_signed(key);
+							int second = group8_min_signed(key == least ? RT_SKIP_NO_KEY : key);
+							bound_bits = skip_bound_bits(hitmask, least, second);
+						}
+					} else if (RT_FAST_NODE && UNIFIED && FLAT) hitmask = bvh8_node_intersect_fast<SKIP>(ray, inv_dir, oct_inv4, hit.t, n0, n1, n2, n3, n4, &bound_bits);
+					else hitmask = bvh8_node_intersect<SKIP>(ray, inv_dir, oct_inv4, hit.t, n0, n1, n2, n3, n4, &bound_bits);
 					unsigned imask = extract_byte(__float_as_uint(n0.w), 3);
 
 					current_group .x = __float_as_uint(n1.x);
 					triangle_group.x = __float_as_uint(n1.y);
-					current_group .y = (hitmask & 0xff000000u) | imask;
+					current_group .y = (hitmask & 0xff000000u) | imask | (SKIP ? bound_bits : 0u);
 					triangle_group.y = (hitmask & 0x00ffffffu);
 				}
 			}
@@ -678,7 +739,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 						if (my_bit >= 0) {
 							my_triangle = int(triangle_group.x) + my_bit;
 							const float4 * tri = triangles + size_t(my_triangle) * 3;
-							valid = triangle_test_values(tri[0], tri[1], tri[2].x, ray, t, u, v) && t < (RT_IS_SHADOW ? max_distance : hit.t);
+							valid = triangle_test_values(tri[0], tri[1], tri[2].x, ray, t, u, v) && t < hit.t;
 						}
 						if (RT_IS_SHADOW) {   // (a group's lanes share one ray, so the kind is uniform within the group)
 							if ((__ballot(valid) >> group_base) & 0xffull) occluded = true;
@@ -717,7 +778,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					for (int k = 0; k < RT_TRI_BATCH; k++) {
 						if (tri_id[k] != RT_INVALID && !occluded) {
 							if (COUNT) count_triangles++;
-							if (triangle_test_kind(RT_IS_SHADOW, tri_a[k], tri_b[k], make_float4(tri_c[k], 0.0f, 0.0f, 0.0f), FLAT ? 0 : mesh_id, tri_id[k], ray, max_distance, hit)) occluded = true;
+							if (triangle_test_kind(RT_IS_SHADOW, tri_a[k], tri_b[k], make_float4(tri_c[k], 0.0f, 0.0f, 0.0f), FLAT ? 0 : mesh_id, tri_id[k], ray, hit)) occluded = true;
 						}
 					}
 				}
@@ -725,14 +786,6 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 
 					}
 			RT_SETPRIO(RT_PHASE_END);
-			bool traversal_done = triangle_group.y == 0 && (current_group.y & 0xff000000u) == 0 && stack.size == 0;
-			if (COUNT && ((RT_IS_SHADOW && occluded) || traversal_done)) {
-				unsigned long long * bucket = stats + (MODE == RT_TRACE_MIXED && lane_shadow ? 5 : 0);   // mixed launches: {closest x5, shadow x5}
-				atomicAdd(&bucket[0], (unsigned long long)count_nodes);     atomicAdd(&bucket[1], (unsigned long long)count_triangles);
-				atomicAdd(&bucket[2], (unsigned long long)count_inst_xform); atomicAdd(&bucket[3], (unsigned long long)count_inst_ident);
-				atomicAdd(&bucket[4], 1ull);
-				count_nodes = count_triangles = count_inst_xform = count_inst_ident = 0;
-			}
 			if (RT_IS_SHADOW && occluded) {
 				result_pending = 2;
 				stack.size = 0;
@@ -746,6 +799,12 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					result_pending = 1;
 					current_group.y = 0;
 					running = false;
+				} else if (SKIP) {
+					// Pop until a group in front of the hit turns up (or the stack is empty: the ray is done). Measured against reading the two entries on top
+					// together and sitting out a round when both lie behind (round 6, profiles/r06_skip_behind_hit.txt): the loop is 1.2 % faster -- a lane that
+					// sits out a round loses what the dropped visit would have cost.
+					do { current_group = stack.pop(); } while (skip_group_is_behind(current_group.y, hit.t) && stack.size > 0);
+					if (skip_group_is_behind(current_group.y, hit.t)) { current_group.y = 0; result_pending = 1; running = false; }
 				} else {
 				if (!FLAT && stack.size == tlas_stack_size) {
 					tlas_stack_size = RT_INVALID;
@@ -762,6 +821,13 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 					current_group  = make_uint2(0, 0);
 				}
 				}
+			}
+			if (COUNT && result_pending) {   // (the ray has just retired: running was true at the top of this round)
+				unsigned long long * bucket = stats + (MODE == RT_TRACE_MIXED && lane_shadow ? 5 : 0);   // mixed launches: {closest x5, shadow x5}
+				atomicAdd(&bucket[0], (unsigned long long)count_nodes);     atomicAdd(&bucket[1], (unsigned long long)count_triangles);
+				atomicAdd(&bucket[2], (unsigned long long)count_inst_xform); atomicAdd(&bucket[3], (unsigned long long)count_inst_ident);
+				atomicAdd(&bucket[4], 1ull);
+				count_nodes = count_triangles = count_inst_xform = count_inst_ident = 0;
 			}
 			}
 
@@ -782,9 +848,16 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 
 // One kernel, two instantiations: the ray count is only known on the device.
 // `coherent`: primary rays keep one ray per lane at any count (neighbouring lanes walk the same nodes).
+// (closest-hit rays of a one-tree scene take the skipping walk when the context asks for it -- rt_skip_walk, rt_types.h; uniform over the launch)
 template<bool SHADOW, bool COUNT, typename Source>
 RT_DEV void bvh8_trace_persistent(const RtParams & p, Source & src, int ray_count, int * cursor, unsigned long long * stats = nullptr, bool coherent = false) {
-	if (!COUNT && !coherent && ray_count <= RT_NARROW_MAX_RAYS) bvh8_trace_engine<SHADOW ? RT_TRACE_SHADOW : RT_TRACE_CLOSEST, false, true>(p, src, ray_count, cursor);
+	const bool narrow = !COUNT && !coherent && ray_count <= RT_NARROW_MAX_RAYS;
+	if (!SHADOW && rt_skip_walk(p)) {
+		if (narrow) bvh8_trace_engine<RT_TRACE_CLOSEST, false, true, false, false, true>(p, src, ray_count, cursor);
+		else bvh8_trace_engine<RT_TRACE_CLOSEST, COUNT, false, false, false, true>(p, src, ray_count, cursor, stats);
+		return;
+	}
+	if (narrow) bvh8_trace_engine<SHADOW ? RT_TRACE_SHADOW : RT_TRACE_CLOSEST, false, true>(p, src, ray_count, cursor);
 	else bvh8_trace_engine<SHADOW ? RT_TRACE_SHADOW : RT_TRACE_CLOSEST, COUNT, false>(p, src, ray_count, cursor, stats);
 }
 #define RT_TRACE_ENGINE bvh8_trace_persistent
@@ -1258,7 +1331,7 @@ struct MixedStreamSource {
 	RT_DEV void load(bool is_shadow, int i, Ray3 & ray, float & max_distance) const { if (is_shadow) shadow.load(i, ray, max_distance); else closest.load(i, ray, max_distance); }
 	RT_DEV void finish(bool is_shadow, int i, const HitRecord & hit, bool occluded) const { if (is_shadow) shadow.finish(i, hit, occluded); else closest.finish(i, hit, occluded); }
 };
-template<bool COUNT, bool FLAT = false>
+template<bool COUNT, bool FLAT = false, bool SKIP = false>
 RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	const int q = p.stream_iteration & 1;
 	MixedStreamSource src { { p.trace[q].origin, p.trace[q].direction, p.trace[q].hits },
@@ -1277,12 +1350,12 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	//     where it was a compile-time constant) and a 25 M-ray launch has little to gain from it (0.87 -> 0.83 when mixed).
 	//   profiles/r02_mixed_engine.txt
 	if (!COUNT && closest_count + shadow_count <= RT_NARROW_MAX_RAYS)
-		bvh8_trace_engine<RT_TRACE_MIXED, false, true, true, FLAT>(p, src, closest_count, &p.stream->cursor[q][0], nullptr, shadow_count, &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_MIXED, false, true, true, FLAT, SKIP>(p, src, closest_count, &p.stream->cursor[q][0], nullptr, shadow_count, &p.stream->cursor[q][1]);
 	else if (COUNT || closest_count + shadow_count <= RT_MIXED_MAX_RAYS)
-		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true, FLAT>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true, FLAT, SKIP>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
 	else {
-		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true, FLAT>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
-		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true, FLAT>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true, FLAT, SKIP>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
+		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true, FLAT>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);   // (a shadow ray's limit never moves: nothing to skip)
 	}
 }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8(RtParams p) { trace_stream<false>(p, nullptr); }
@@ -1292,7 +1365,13 @@ __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_
 #define RT_FLAT_WAVES (RT_FAST_NODE ? 6 : 7)
 #endif
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_FLAT_WAVES) kernel_trace_stream_bvh8_flat(RtParams p) { trace_stream<false, true>(p, nullptr); }
-__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_counting(RtParams p, unsigned long long * stats) { trace_stream<true>(p, stats); }
+#ifndef RT_FLAT_SKIP_WAVES
+#define RT_FLAT_SKIP_WAVES RT_FLAT_WAVES
+#endif
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_FLAT_SKIP_WAVES) kernel_trace_stream_bvh8_flat_skip(RtParams p) { trace_stream<false, true, true>(p, nullptr); }
+__global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8_counting(RtParams p, unsigned long long * stats) {
+	if (rt_skip_walk(p)) trace_stream<true, false, true>(p, stats); else trace_stream<true>(p, stats);
+}
 
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_bvh8_explicit(RtParams p, RtVec3SoA origin, RtVec3SoA direction, uint4 * hits, int ray_count, int * retired) {
 	ClosestHitSource src { origin, direction, hits };
@@ -1368,6 +1447,11 @@ void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, hipS
 		return;
 	}
 	if (p.entry_tlas_stack_size == 0 && p.geometry_below_4gib) {   // the whole scene is one world-space tree: the engine without the TLAS / instance code (32-bit offsets; a larger scene walks the general engine from node 0)
+		if (rt_skip_walk(p)) {
+			static int grid_flat_skip = trace_grid_size((const void *)kernel_trace_stream_bvh8_flat_skip);
+			hipLaunchKernelGGL(kernel_trace_stream_bvh8_flat_skip, dim3(grid_flat_skip), dim3(RT_TRACE_BLOCK), 0, stream, p);
+			return;
+		}
 		static int grid_flat = trace_grid_size((const void *)kernel_trace_stream_bvh8_flat);
 		hipLaunchKernelGGL(kernel_trace_stream_bvh8_flat, dim3(grid_flat), dim3(RT_TRACE_BLOCK), 0, stream, p);
 		return;

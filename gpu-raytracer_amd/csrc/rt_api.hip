@@ -438,6 +438,8 @@ int rt_create(int device_ordinal, rt_context ** out_ctx) {
 	memset(&ctx->params, 0, sizeof(ctx->params));
 	ctx->params.entry_tlas_stack_size = RT_INVALID;
 	ctx->params.svgf_tiles = 1;
+	ctx->params.skip_behind_hit = 1;
+	if (const char * e = getenv("GRT_SKIP_BEHIND_HIT")) ctx->params.skip_behind_hit = atoi(e) != 0;   // (A / B runs of one command: bench.py, tools/)
 	memset(&ctx->last_counters, 0, sizeof(ctx->last_counters));
 	RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
 	RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
@@ -576,6 +578,17 @@ int rt_set_static_geometry(rt_context * ctx, int32_t whole_scene) {
 	ctx->params.entry_tlas_stack_size = entry;
 	return RT_OK;
 }
+
+// "Skip behind the hit": see kernels_trace.hip. The wish is stored; the kernels take the walk when the scene is also one tree below 4 GiB (rt_skip_walk).
+int rt_set_skip_behind_hit(rt_context * ctx, int32_t enable) {
+	RT_REQUIRE(ctx, ctx != nullptr, "rt_set_skip_behind_hit: NULL context");
+	if ((ctx->params.skip_behind_hit != 0) == (enable != 0)) return RT_OK;
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));   // (samples in flight were submitted under the other walk; the counters of a statistics pass must belong to one)
+	ctx->params.skip_behind_hit = enable != 0;
+	return RT_OK;
+}
+int rt_get_skip_behind_hit(const rt_context * ctx) { return ctx && rt_skip_walk(ctx->params) ? 1 : 0; }
 
 // ---- BLAS build on the device (kernels_blas.hip) ---------------------------------------------------------------------
 } // extern "C"

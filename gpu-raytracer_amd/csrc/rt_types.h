@@ -123,6 +123,7 @@ struct RtParams {
 	int geometry_below_4gib;          // bvh8_nodes and triangle_positions are both shorter than 4 GiB: the flattened scene's engine addresses them with 32-bit offsets
 	int entry_tlas_stack_size;        // RT_INVALID: rays start at the TLAS root; 0: node 0 is the root of the one world-space tree that holds the
 	                                  // whole scene and rays start inside it, as instance row 0 (rt_set_static_geometry)
+	int skip_behind_hit;              // rt_set_skip_behind_hit's wish (default 1); what the kernels do is rt_skip_walk(p) below
 	int has_triangle_aliases;         // some triangles are copies that report the (instance, triangle) named in the padding of their
 	                                  // position record instead of themselves (rt_upload_triangle_aliases)
 	const int    * mesh_material_ids;
@@ -199,6 +200,11 @@ struct RtParams {
 	float2 * svgf_variance[2];        // (direct.w, indirect.w) of the radiance framebuffers [0] and accumulators [1], kept in step by the filter kernels
 	float4 * svgf_normal_and_depth;   // (normal, depth) of the frame being filtered: decoded once by kernel_svgf_reproject for the variance / a-trous taps
 };
+// "Skip behind the hit" (kernels_trace.hip): closest-hit rays drop stacked groups of children that lie behind the hit they hold. Taken when the context wants it
+// (rt_set_skip_behind_hit) AND the scene is ONE tree the flattened scene's engine walks (rt_set_static_geometry(ctx, 1), arrays below 4 GiB): every CWBVH
+// closest-hit kernel -- the merged wavefront's launch, its counting variant, the per-bounce and the explicit kernels -- decides by this one rule.
+static inline __host__ __device__ bool rt_skip_walk(const RtParams & p) { return p.skip_behind_hit != 0 && p.entry_tlas_stack_size == 0 && p.geometry_below_4gib != 0; }
+
 
 // Scan-order index of local pixel i of this context: its tiles are tile_first, tile_first +
 // tile_stride, ... each tile_pixels long (whole rows), see gpu-raytracer_amd/parallel.py.

@@ -633,6 +633,7 @@ void Integrator::build_tlas() {
 		mesh_transforms[0].cells, mesh_transforms_inv[0].cells, mesh_transforms_prev[0].cells, rows));
 	if (ctx && cpu_config.bvh_type == BVHType::BVH8) {
 		check(rt_set_static_geometry(ctx, whole_scene ? 1 : 0));
+		check(rt_set_skip_behind_hit(ctx, cpu_config.skip_behind_hit ? 1 : 0));
 		// rays start inside the one tree: its top levels (breadth-first: the first nodes from its root) may live in LDS
 	}
 }

@@ -73,6 +73,7 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "static_slot_assignment")              cpu_config.static_slot_assignment = int(value);
 	else if (k == "static_slot_learning_rays")           cpu_config.static_slot_learning_rays = int(value);
 	else if (k == "static_slot_learning_viewpoint")      cpu_config.static_slot_learning_viewpoint = int(value);
+	else if (k == "skip_behind_hit")                     cpu_config.skip_behind_hit = value != 0;
 	else if (k == "static_mesh_copy_limit_mb")           cpu_config.static_mesh_copy_limit_mb = int(value);
 	else if (k == "static_copy_budget_mb")               cpu_config.static_copy_budget_mb = int(value);
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
@@ -88,6 +89,7 @@ double grt_config_get(const char * key) {
 	if (k == "initial_height") return cpu_config.initial_height;
 	if (k == "aov_mask")       return gpu_config.aov_mask;
 	if (k == "enable_svgf")    return gpu_config.enable_svgf;
+	if (k == "skip_behind_hit") return cpu_config.skip_behind_hit;
 	return -1.0;
 }
 
@@ -337,6 +339,13 @@ float  grt_pathtracer_device_blas_build_ms(void * pt) { return as_integrator(pt)
 // Flattened static geometry: instances in it (0: none, or dissolved because one of them moved), and what its tree took to build on the host
 int    grt_pathtracer_static_geometry_members(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active ? int(p->static_geometry.members.size()) : 0; }
 // 1: everything is in the flattened tree, rays start inside it (rt_set_static_geometry); 0: there is a TLAS
+// 1: closest-hit rays take the skipping walk (the rule of rt_skip_walk, csrc/rt_types.h, evaluated on the host's own arrays so that a host-only integrator answers too)
+int    grt_pathtracer_skip_behind_hit(void * pt) {
+	Integrator * p = as_integrator(pt);
+	bool whole_scene = p->static_geometry.active && p->static_geometry.movers.empty();
+	bool below_4gib = p->aggregated_bvh_nodes_8.size() * 80ull < (1ull << 32) && p->aggregated_triangles.size() * 48ull < (1ull << 32);
+	return cpu_config.skip_behind_hit && cpu_config.bvh_type == BVHType::BVH8 && whole_scene && below_4gib ? 1 : 0;
+}
 int    grt_pathtracer_static_geometry_whole_scene(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active && p->static_geometry.movers.empty() ? 1 : 0; }
 // the flattened tree's root node and how many nodes from it (breadth-first order) are its top levels
 int    grt_pathtracer_static_geometry_root(void * pt) { return as_integrator(pt)->static_geometry.root; }

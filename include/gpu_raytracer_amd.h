@@ -146,8 +146,9 @@ const char * rt_version(void);
  *   7  rt_set_node_format (a 96-byte decoded copy of the node array) and rt_set_node_cache (the top of the flattened tree in LDS) REMOVED:
  *      both measured slower than the 80-byte walk on MI355X (profiles/r04_traversal_experiments.txt items 2 and 4) and were off by default;
  *      rt_set_build_boxes added
+ *   8  rt_set_skip_behind_hit, rt_get_skip_behind_hit (additions only)
  * Check `rt_abi_version() == RT_ABI_VERSION` once after loading the library.                                          */
-#define RT_ABI_VERSION 7
+#define RT_ABI_VERSION 8
 int rt_abi_version(void);
 
 /* ---- scene upload ------------------------------------------------------------------- */
@@ -175,6 +176,16 @@ int rt_upload_triangle_aliases(rt_context * ctx, const int32_t * mesh_ids, const
  * (the state after every geometry upload): node 0 is a TLAS root, as in the reference (BVH8.h:161-165), and a flattened tree
  * is one of its leaves. Drains the context when the value changes. CWBVH traversal only.                              */
 int rt_set_static_geometry(rt_context * ctx, int32_t whole_scene);
+/* The walk of closest-hit rays through a one-tree scene (rt_set_static_geometry(ctx, 1)). The reference keeps the children of a node that a ray
+ * enters but does not visit at once as ONE stack entry without a distance (BVH8.h:166-199) and therefore still walks into every one of them after a
+ * hit in front of them has been found; it makes up for that with 32-lane warps and triangle postponing (BVH8.h:200,234-240). enable = 1 (the
+ * default): a stack entry also carries a 16-bit lower bound of the distance at which the ray enters any child left in it (the mask word's unused
+ * bits 8..23) and is dropped at its pop when that bound is not in front of the hit held -- a visit that could enter no child. Closest hits are the
+ * reference walk's (ties in t between coplanar triangles aside: the walk's order decides those, as it does in the reference); the number of nodes a
+ * ray fetches falls (Sponza: 13.1 -> 11.5 per ray). enable = 0: the reference's walk, node for node. Scenes that keep a TLAS always walk the
+ * reference's way. Drains the context when the value changes. rt_get_skip_behind_hit: 1 while the walk is in effect (wish AND one-tree scene).  */
+int rt_set_skip_behind_hit(rt_context * ctx, int32_t enable);
+int rt_get_skip_behind_hit(const rt_context * ctx);
 /* Replaces the per-frame TLAS memcpy into the front of `bvh8_nodes` (Integrator.cpp:404-409). The
  * TLAS, the instance tables (rt_upload_instances) and the light tables (rt_upload_lights) are
  * versioned on the device: the call copies the host data into pinned staging and returns (the

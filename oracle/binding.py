@@ -59,7 +59,7 @@ class OracleScene(Structure):
         ("view_projection", c_float * 16), ("view_projection_prev", c_float * 16),
         ("screen_width", c_int32), ("screen_height", c_int32), ("screen_pitch", c_int32),
         ("alias_mesh_ids", c_void_p), ("alias_triangle_ids", c_void_p),
-        ("static_whole_scene", c_int32),
+        ("static_whole_scene", c_int32), ("skip_behind_hit", c_int32),
     ]
 
 
@@ -520,6 +520,7 @@ class SceneView:
         s.mesh_count = self.keep["mesh_material_ids"].size
         s.alias_mesh_ids = arr("alias_mesh_ids"); s.alias_triangle_ids = arr("alias_triangle_ids")   # flattened static geometry, if any
         s.static_whole_scene = 1 if pt.static_geometry_whole_scene else 0
+        s.skip_behind_hit = 1 if pt.skip_behind_hit else 0   # the walk the device takes (rt_set_skip_behind_hit)
         s.material_types = arr("material_types"); s.materials = arr("materials"); s.material_count = self.keep["material_types"].size
         s.media = arr("media"); s.medium_count = self.keep["media"].size // 8
 

@@ -104,6 +104,9 @@ typedef struct oracle_scene {
 	/* rt_set_static_geometry: node 0 is not a TLAS root but the root of ONE world-space tree that holds the whole scene;
 	 * rays start inside it, as instance row 0. */
 	int32_t static_whole_scene;
+	/* rt_set_skip_behind_hit: closest-hit rays of a one-tree scene drop a stacked group of children whose bound (the least entry
+	 * distance of the children left in it, 16 bits, rounded down) lies at or behind the hit already held. 0: the reference's walk. */
+	int32_t skip_behind_hit;
 } oracle_scene;
 
 /* Per-ray work counters: define the ALGORITHMIC bytes of a trace:

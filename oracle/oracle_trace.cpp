@@ -61,7 +61,7 @@ inline unsigned ray_get_octant_inv4(float3 d) {
 	return (d.x < 0.0f ? 0 : 0x04040404) | (d.y < 0.0f ? 0 : 0x02020202) | (d.z < 0.0f ? 0 : 0x01010101);
 }
 
-struct Counters { uint64_t nodes = 0, triangles = 0, inst_xform = 0, inst_ident = 0; };
+struct Counters { uint64_t nodes = 0, triangles = 0, inst_xform = 0, inst_ident = 0, groups_skipped = 0; };
 
 // Triangle.h:148-174. f = 1/a is an IEEE division (the reference's fast-math reciprocal
 // is not specified); acceptance tests are literal: 0<=u<=1, v>=0, u+v<=1, 0<t<t_best.
@@ -116,7 +116,10 @@ inline bool triangle_intersect_shadow(const oracle_scene & s, int triangle_id, c
 // BVH8.h:29-107. The three "/ direction" of the reference become one IEEE reciprocal per ray
 // (inv_dir) times exact power-of-two scales; min/max use IEEE maxNum/minNum (NaN slabs are
 // ignored) where the reference compares float bit patterns as integers (Util.h:303-341).
-inline unsigned bvh8_node_intersect(const Ray & ray, float3 inv_dir, unsigned oct_inv4, float max_distance, const uint8_t * node) {
+// bound_bits (optional; not in the reference): the 16-bit lower bound of the entry distances of the children the ray enters EXCEPT the one it visits first,
+// in bits 8..23 -- "skip behind the hit", kernels_trace.hip (skip_bound_bits) restated: keys = tmin with the low byte replaced by the child's bit index,
+// compared as signed integers; the two smallest are kept.
+inline unsigned bvh8_node_intersect(const Ray & ray, float3 inv_dir, unsigned oct_inv4, float max_distance, const uint8_t * node, unsigned * bound_bits = nullptr) {
 	uint32_t w[20];
 	memcpy(w, node, 80);
 
@@ -131,6 +134,9 @@ inline unsigned bvh8_node_intersect(const Ray & ray, float3 inv_dir, unsigned oc
 	float3 adjusted_origin = (p - ray.origin) * inv_dir;
 
 	unsigned hit_mask = 0;
+	int32_t least = 0x7fffffff, second = 0x7fffffff;
+	static const int variant = getenv("ORACLE_SKIP_VARIANT") ? atoi(getenv("ORACLE_SKIP_VARIANT")) : 2;
+	int32_t half_min[2] = { 0x7fffffff, 0x7fffffff };
 	for (int i = 0; i < 2; i++) {
 		unsigned meta4 = w[6 + i];
 
@@ -162,8 +168,20 @@ inline unsigned bvh8_node_intersect(const Ray & ray, float3 inv_dir, unsigned oc
 				unsigned child_bits = extract_byte(child_bits4, j);
 				unsigned bit_index  = extract_byte(bit_index4,  j);
 				hit_mask |= child_bits << bit_index;
+				if (bound_bits) {
+					int32_t key = int32_t((float_as_uint(tmin) & 0xffffff00u) | bit_index);   // tmin >= 0: the bit patterns order like the values (a -0 sorts first: conservative)
+					second = key < least ? least : (key < second ? key : second);           // (the median of the three)
+					least  = key < least ? key : least;
+					if (variant == 4 ? bit_index >= 24 : true) half_min[i] = key < half_min[i] ? key : half_min[i];
+				}
 			}
 		}
+	}
+	if (bound_bits) {
+		// the smallest key that is not the key of the child visited first (the highest bit of the mask)
+		int32_t key = (uint32_t(least) & 0x1fu) == (hit_mask ? msb(hit_mask) : 0xffu) ? second : least;
+		*bound_bits = (uint32_t(key) >> 8) & 0x00ffff00u;
+		if (variant >= 3) { int far = (oct_inv4 >> 2) & 1; *bound_bits = (uint32_t(half_min[far]) >> 8) & 0x00ffff00u; }
 	}
 	return hit_mask;
 }
@@ -185,6 +203,8 @@ inline bool bvh8_traverse(const oracle_scene & s, Ray ray, float max_distance, R
 	unsigned oct_inv4 = ray_get_octant_inv4(ray.direction);
 
 	Group current_group = { 0, 0x80000000u };
+	// The walk of the flattened scene's engine (kernels_trace.hip, rt_set_skip_behind_hit): closest-hit rays in a one-tree scene only.
+	const bool skip = !SHADOW && s.skip_behind_hit != 0 && s.static_whole_scene;
 
 	int  tlas_stack_size = RT_INVALID;
 	int  mesh_id = 0;
@@ -213,7 +233,8 @@ inline bool bvh8_traverse(const oracle_scene & s, Ray ray, float max_distance, R
 			c.nodes++;
 
 			float limit = SHADOW ? max_distance : ray_hit.t;
-			unsigned hitmask = bvh8_node_intersect(ray, inv_dir, oct_inv4, limit, node);
+			unsigned bound_bits = 0;
+			unsigned hitmask = bvh8_node_intersect(ray, inv_dir, oct_inv4, limit, node, skip ? &bound_bits : nullptr);
 
 			uint32_t node_w3, node_w4, node_w5;
 			memcpy(&node_w3, node + 12, 4); memcpy(&node_w4, node + 16, 4); memcpy(&node_w5, node + 20, 4);
@@ -222,6 +243,7 @@ inline bool bvh8_traverse(const oracle_scene & s, Ray ray, float max_distance, R
 			current_group .x = node_w4; // child    base offset
 			triangle_group.x = node_w5; // triangle base offset
 			current_group .y = (hitmask & 0xff000000u) | imask;
+			if (skip) current_group.y |= bound_bits;   // (the 16 bits of the mask word that the reference leaves empty)
 			triangle_group.y = (hitmask & 0x00ffffffu);
 		} else {
 			triangle_group = current_group;
@@ -279,6 +301,21 @@ inline bool bvh8_traverse(const oracle_scene & s, Ray ray, float max_distance, R
 				}
 			}
 			current_group = stack[--stack_size];
+			// Skip behind the hit: every child left in the group is entered at or beyond the group's bound; at or beyond the hit
+			// already held none of them can be entered (their test would be tmin < tmax <= hit.t), so the group is dropped unvisited.
+			static const int variant = getenv("ORACLE_SKIP_VARIANT") ? atoi(getenv("ORACLE_SKIP_VARIANT")) : 2;
+			while (skip && variant >= 3) {
+				if (int32_t((current_group.y << 8) & 0xffff0000u) >= int32_t(float_as_uint(ray_hit.t))) current_group.y &= ~0x0f000000u;
+				if (current_group.y & 0xff000000u) break;
+				c.groups_skipped++;
+				if (stack_size == 0) return false;
+				current_group = stack[--stack_size];
+			}
+			while (skip && variant < 3 && int32_t((current_group.y << 8) & 0xffff0000u) >= int32_t(float_as_uint(ray_hit.t))) {
+				c.groups_skipped++;
+				if (stack_size == 0) return false;
+				current_group = stack[--stack_size];
+			}
 		}
 	}
 }

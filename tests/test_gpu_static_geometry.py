@@ -60,6 +60,58 @@ def test_flattened_sponza_on_the_device_finds_what_the_reference_layout_finds(gr
     grt.config_reset()
 
 
+def test_seating_and_the_skipping_walk_change_the_walk_and_not_the_hits(grt, oracle):
+    """The same rays at the benchmark's size through three builds of the flattened Sponza tree on the device: (a) what ships -- children seated by the
+    slot learner, closest-hit rays skipping stack entries behind their hit (rt_set_skip_behind_hit); (b) the same tree walked the reference's way;
+    (c) the tree as the collapse leaves it (no learned seating), the reference's walk. All three name the same distance for every ray, to the bit;
+    the few rays that name another triangle sit on two coplanar triangles at exactly that distance. Then the counting launches: (a) fetches fewer
+    nodes than (b), both exactly what the oracle counts for its restatement of that walk."""
+    w, h = 1920, 1080
+    runs = {}
+    rays = None
+    for name, config in (("ships", {}), ("reference_walk", dict(skip_behind_hit=0)), ("unseated", dict(skip_behind_hit=0, static_slot_learning_rays=0))):
+        scene, pt = make_pathtracer(grt, "sponza", w, h, 0, **config)
+        assert pt.static_geometry_whole_scene and pt.skip_behind_hit == (name == "ships")
+        lib = grt.device_lib(); lib.rt_get_skip_behind_hit.argtypes = [__import__("ctypes").c_void_p]
+        assert lib.rt_get_skip_behind_hit(pt.ctx) == (1 if name == "ships" else 0)
+        view = oracle.SceneView(pt)
+        if rays is None:
+            o, d = rays_for(view, w, h, 14.0, 400000, 33)
+            first, _ = grt.trace_rays(pt.ctx, o, d)
+            so, sd = secondary_rays(view, o, d, first, 3)
+            rays = (o, d, so, sd)
+        o, d, so, sd = rays
+        hits, _ = grt.trace_rays(pt.ctx, o, d)
+        bounce, _ = grt.trace_rays(pt.ctx, so, sd)
+        few, _ = grt.trace_rays(pt.ctx, so[:, :6000], sd[:, :6000])             # a launch small enough for the 8-lanes-per-ray engine
+        assert np.array_equal(few, bounce[:6000])
+        pick = np.random.default_rng(3).choice(so.shape[1], 100000, replace=False)
+        want, oracle_stats = view.trace(so[:, pick], sd[:, pick])
+        assert np.array_equal(bounce[pick], want)                              # the device against the oracle's restatement of the SAME walk: bit for bit
+        runs[name] = (hits, bounce, oracle_stats.nodes / oracle_stats.rays)
+        if name != "unseated":                                                 # the counting launches of one sample, against the oracle's counters
+            frame = oracle.Frame(view)
+            grt.set_trace_statistics(pt.ctx, True); pt.render(); stats = grt.get_trace_statistics(pt.ctx); grt.set_trace_statistics(pt.ctx, False)
+            oc = frame.render_sample(pt.sample_index)
+            assert stats["closest"]["rays"] == oc.trace_stats.rays
+            for key, ref in (("nodes", oc.trace_stats.nodes), ("triangles", oc.trace_stats.triangles)):
+                assert abs(stats["closest"][key] - ref) <= 1e-3 * ref, (name, key)
+            assert abs(stats["shadow"]["nodes"] - oc.shadow_stats.nodes) <= 2e-3 * oc.shadow_stats.nodes
+            runs[name] += (stats["closest"]["nodes"] / stats["closest"]["rays"],)
+        pt.close(); scene.close()
+    for other in ("reference_walk", "unseated"):
+        for which in (0, 1):
+            a, b = runs["ships"][which], runs[other][which]
+            mesh_a, tri_a, t_a, u_a, v_a = unpack_hits(a); mesh_b, tri_b, t_b, u_b, v_b = unpack_hits(b)
+            assert np.array_equal(t_a.view(np.uint32), t_b.view(np.uint32)), other   # ~2.5 M + ~1.5 M rays: the same distance, to the bit
+            tie = tri_a != tri_b
+            assert tie.sum() <= 1e-3 * tie.size, (other, int(tie.sum()))
+            assert np.array_equal(a[~tie], b[~tie])
+    assert runs["ships"][2] < 0.92 * runs["reference_walk"][2] < 0.98 * runs["unseated"][2], [runs[k][2] for k in runs]   # incoherent rays, node steps per ray
+    assert runs["ships"][3] < 0.92 * runs["reference_walk"][3]                                                            # the frame's own rays
+    grt.config_reset()
+
+
 def test_flattened_scene_with_moving_instances_renders_like_the_oracle(grt, oracle, tmp_path):
     """A floor and two emitters flattened (one TLAS leaf), 40 rotated / scaled instances of one mesh beside them in the TLAS
     (an instanced mesh is not copied per instance): frames and queue sizes against the oracle. Then the floor starts to
