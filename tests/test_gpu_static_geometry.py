@@ -93,7 +93,7 @@ def test_seating_and_the_skipping_walk_change_the_walk_and_not_the_hits(grt, ora
             frame = oracle.Frame(view)
             grt.set_trace_statistics(pt.ctx, True); pt.render(); stats = grt.get_trace_statistics(pt.ctx); grt.set_trace_statistics(pt.ctx, False)
             oc = frame.render_sample(pt.sample_index)
-            assert stats["closest"]["rays"] == oc.trace_stats.rays
+            assert abs(stats["closest"]["rays"] - oc.trace_stats.rays) <= 1e-5 * oc.trace_stats.rays   # (a handful of paths per million end elsewhere: sinf / logf differ by ulps between the device library and glibc)
             for key, ref in (("nodes", oc.trace_stats.nodes), ("triangles", oc.trace_stats.triangles)):
                 assert abs(stats["closest"][key] - ref) <= 1e-3 * ref, (name, key)
             assert abs(stats["shadow"]["nodes"] - oc.shadow_stats.nodes) <= 2e-3 * oc.shadow_stats.nodes
