@@ -69,18 +69,28 @@ VALU_PEAK_LANE_INSTR_PER_S = CUS * SIMDS_PER_CU * 32 * CLOCK_HZ
 # fma / mul / add / sub / logic / v_bitop3 / v_mov / right shifts retire a wave in ~2.3 cycles ("fast"), conversions / min / max / compares / selects / left
 # shifts / bit-field instructions in ~4.1 ("slow"), and one of each interleaved take 4.5 cycles per PAIR (they overlap).
 VALU_CYCLES_FAST, VALU_CYCLES_SLOW, VALU_CYCLES_PAIR = 2.3, 4.1, 4.52
-# Static mix of one round of the shipped closest-hit engine (kernel_trace_stream_bvh8_flat, profiles/trace_round_mix.json, tools/isa_loop_mix.py): vector instructions, of which slow
-TRACE_ROUND_VALU, TRACE_ROUND_VALU_SLOW = 381, 159
+# Static mix of one round of the shipped closest-hit engine (kernel_trace_stream_bvh8_flat_skip, profiles/trace_round_mix.json, tools/isa_loop_mix.py): vector instructions, of which slow
+TRACE_ROUND_VALU, TRACE_ROUND_VALU_SLOW = 397, 183
 try:   # tools/isa_loop_mix.py --json profiles/trace_round_mix.json, re-run whenever the traversal kernel changes
     _mix = json.load(open(os.path.join(ROOT, "profiles", "trace_round_mix.json")))
     TRACE_ROUND_VALU, TRACE_ROUND_VALU_SLOW = int(_mix["valu"]), int(_mix["valu_slow"])
 except Exception:
     pass
-# L1 (vector cache, one per CU): 64 B per clock and CU ("Memory hierarchy": `global_load_dwordx4` moves 64 lanes x 16 B in 16 address cycles) = one 64-byte
-# tag look-up per clock: 256 x 2.4e9 look-ups per second, 39.3 TB/s.   L2: 34.5 TB/s aggregate ("L2 (per XCD)").
-L1_PEAK_LOOKUPS_PER_S = CUS * CLOCK_HZ
-L1_PEAK_GBPS = CUS * 64 * CLOCK_HZ / 1e9
-L2_PEAK_GBPS = 34500.0
+# L1 (vector cache, one per CU). The guide gives its capacity and no throughput: the roof is MEASURED (tools/microbench/l1_lookup_rate.hip under rocprofv3 --pmc,
+# profiles/r06_l1_lookup_rate.txt): TCP_TOTAL_CACHE_ACCESSES per clock and CU with every access hitting, by access shape -- a lane's 16-byte piece of its own
+# 80-byte record (the node fetch) 1.672, of its own 48-byte record (the triangle fetch) 1.978, 64 different 128-byte lines 0.989, a coalesced stream 0.913
+# (58.5 B per clock). The traversal launch is priced against the rate of ITS mix of the first two (l1_peak_lookups_per_clock below).
+L1_LOOKUPS_PER_CLOCK = {"node": 1.672, "triangle": 1.978, "lines": 0.989, "coalesced": 0.913}
+L1_STREAM_GBPS = CUS * 64 * L1_LOOKUPS_PER_CLOCK["coalesced"] * CLOCK_HZ / 1e9    # what the L1's data path streams, whole chip: 35.9 TB/s
+L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
+
+
+def l1_peak_lookups_per_clock(node_visits, triangle_tests):
+    """Look-ups per clock and CU the L1 sustains on this launch's mix of node fetches (5 per visit and lane) and triangle fetches (3 per test)."""
+    node, tri = 5.0 * node_visits, 3.0 * triangle_tests
+    if node + tri <= 0:
+        return L1_LOOKUPS_PER_CLOCK["node"]
+    return (node + tri) / (node / L1_LOOKUPS_PER_CLOCK["node"] + tri / L1_LOOKUPS_PER_CLOCK["triangle"])
 L1_TO_L2_REQUEST_BYTES = 64   # TCP_TCC_READ_REQ counts 64-byte requests (a 128-byte line miss is two)
 
 
@@ -173,7 +183,7 @@ def cpu_baseline(grt, pt, scene):
     return out
 
 
-def pmc_section(args, rays_per_step, launch_ms, plan):
+def pmc_section(args, rays_per_step, launch_ms, plan, node_visits=0.0, triangle_tests=0.0):
     """roofline.traffic and the counters the scope table asks for next to the fraction, from rocprofv3 --pmc
     passes over this very command (tools/pmc_pass.py). Everything is per traversal launch of the timed region, like `achieved`."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -241,11 +251,14 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
                                      "note": "what the round's OWN instruction mix could reach: half of its vector instructions are conversions / min / max / compares / selects (4.1 cycles per wave), the other half multiply-adds and logic (2.3), one of each interleaved takes 4.5 per pair. frac_* = (best cycles per instruction / measured) x lane utilisation"}}
             if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
                 lookups = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / seconds
-                l1 = {"bound": "l1 (vector cache: tag look-ups)", "unit": "64-byte look-ups/s", "peak": L1_PEAK_LOOKUPS_PER_S, "achieved": float("%.4g" % lookups), "frac": round(lookups / L1_PEAK_LOOKUPS_PER_S, 4),
-                      "peak_derivation": "MI355X_MICROARCH.md: a global_load_dwordx4 of a wave (64 lanes x 16 B) takes 16 address cycles = 64 B per clock and CU, one look-up per clock: 256 CUs x 2.4 GHz (39.3 TB/s)",
+                per_clock = l1_peak_lookups_per_clock(node_visits, triangle_tests)
+                l1_peak = per_clock * CUS * CLOCK_HZ
+                l1 = {"bound": "l1 (vector cache: tag look-ups)", "unit": "look-ups/s (TCP_TOTAL_CACHE_ACCESSES)", "peak": float("%.4g" % l1_peak), "achieved": float("%.4g" % lookups), "frac": round(lookups / l1_peak, 4),
+                      "lookups_per_clock_and_cu": round(lookups / (CUS * CLOCK_HZ), 4), "peak_lookups_per_clock_and_cu": round(per_clock, 4),
+                      "peak_derivation": "MEASURED, not from the guide (which states the L1's capacity only): tools/microbench/l1_lookup_rate.hip under rocprofv3 --pmc, profiles/r06_l1_lookup_rate.txt -- with every access hitting the unit retires 1.672 look-ups per clock and CU for a lane's 16-byte piece of its own 80-byte record (node fetch), 1.978 for 48-byte records (triangle fetch), 0.989 for 64 different lines, 0.913 for a coalesced stream; the peak here is the rate of THIS launch's mix of node and triangle fetches (5 per node visit, 3 per triangle test, from the counting launches) x 256 CUs x 2.4 GHz",
                       "lookups_per_vector_memory_instruction": round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / max(c.get("SQ_INSTS_VMEM_RD", 0.0) + c.get("SQ_INSTS_VMEM_WR", 0.0), 1.0), 2) if c.get("SQ_INSTS_VMEM_RD") else None}
                 if c.get("TCP_GATE_EN1_sum"):
-                    l1["busy"] = round(c["TCP_GATE_EN1_sum"] / (CUS * seconds * CLOCK_HZ), 4); l1["busy_definition"] = "TCP_GATE_EN1 (cycles the L1 is clocked for work, summed over the 256 CUs) / (256 x launch cycles at 2.4 GHz)"
+                    l1["clocked"] = round(c["TCP_GATE_EN1_sum"] / (CUS * seconds * CLOCK_HZ), 4); l1["clocked_definition"] = "TCP_GATE_EN1 (cycles the L1 is clocked, summed over the 256 CUs) / (256 x launch cycles at 2.4 GHz): the unit has a request in flight -- 0.92-0.99 in every shape of the microbenchmark, whatever its rate; NOT a utilisation (rounds 4-5 read it as one)"
                 if c.get("TA_TA_BUSY_sum"):
                     l1["address_unit_busy"] = round(c["TA_TA_BUSY_sum"] / (CUS * seconds * CLOCK_HZ), 4)
                 binding["l1"] = l1
@@ -260,12 +273,12 @@ def pmc_section(args, rays_per_step, launch_ms, plan):
             fracs = {"valu (lane-instructions)": binding["frac"], "valu issue (wave-instructions)": binding["issue_frac"], "valu, mix-aware": binding["mix_aware"]["frac_classes_serial"]}
             for key in ("l1", "l2", "hbm"):
                 if key in binding:
-                    fracs[key] = binding[key].get("busy", binding[key]["frac"]) if key == "l1" else binding[key]["frac"]
+                    fracs[key] = binding[key]["frac"]
             binding["utilisation_by_unit"] = fracs
             binding["closest_to_its_roof"] = max(fracs, key=fracs.get)
-            binding["note"] = ("The launch is branchy pointer chasing: no unit is saturated, the two closest to their roofs are the CU's L1 (tag look-ups of divergent 16-byte loads: 5 per node step and lane, 3 per triangle) and vector issue. "
+            binding["note"] = ("The launch is branchy pointer chasing: no unit is saturated -- vector issue, what the round's instruction mix allows and the L1's look-up rate (against its MEASURED roof) all sit at 0.4-0.5, L2 and HBM at a tenth. "
                                "valu frac = useful lane-instructions against the guide's peak; it is low because (a) the triangle phase of a round runs with a fifth of the wave's lanes (lane_utilisation), (b) half the instructions are of the 4-cycle class (mix_aware), "
-                               "(c) waves wait for the L1 (counters.wave_cycles_waiting). DESIGN.md 4.1 has the experiments behind this reading")
+                               "(c) a round is two dependent memory round trips (counters.wave_cycles_waiting). DESIGN.md 4.1 has the experiments behind this reading")
             out["binding"] = binding
     if "TCC_HIT_sum" in trace and "TCC_MISS_sum" in trace and (trace["TCC_HIT_sum"][1] + trace["TCC_MISS_sum"][1]) > 0:
         out.setdefault("binding", {})["l2_hit_rate"] = round(trace["TCC_HIT_sum"][1] / (trace["TCC_HIT_sum"][1] + trace["TCC_MISS_sum"][1]), 4)
@@ -373,7 +386,7 @@ def config3_section(grt, scene, device, stream_gbps, frames=64):
             gbps = tap_bytes * px * passes / (per_frame * 1e-3) / 1e9
             kernels.append({"kernel": "kernel_" + name, "launches_per_frame": round(passes, 2), "ms_per_frame": round(per_frame, 4),
                             "tap_bytes_per_pixel": tap_bytes, "unique_bytes_per_pixel": unique_bytes,
-                            "achieved": round(gbps, 1), "unit": "GB/s", "frac": round(gbps / stream_gbps, 4),
+                            "tap_gbps": round(gbps, 1), "unit": "GB/s", "tap_ratio": round(gbps / stream_gbps, 4),
                             "frac_unique": round(unique_bytes * px * passes / (per_frame * 1e-3) / 1e9 / stream_gbps, 4)})
         trace_ms = float(grt.launch_timings(ctx, "trace").sum()) / frames
         grt.set_profiling(ctx, False)
@@ -383,49 +396,71 @@ def config3_section(grt, scene, device, stream_gbps, frames=64):
                 "filter_ms_per_frame": round(filter_ms, 4), "traversal_ms_per_frame": round(trace_ms, 4),
                 "filter_frac_of_stream_unique_bytes": round(unique_total / (filter_ms * 1e-3) / 1e9 / stream_gbps, 4) if filter_ms > 0 else None,
                 "kernels": kernels, "svgf_lds_tiles": svgf_tiles,
-                "note": "tap bytes = every tap the kernel requests (SVGF.h / TAA.h tap loops), unique bytes = each image once; frac against the measured stream-read bandwidth"}
+                "note": "tap bytes = every tap the kernel requests (SVGF.h / TAA.h tap loops; most are served by LDS / L1: tap_ratio = tap bytes over the measured stream-read bandwidth is a re-use figure and exceeds 1), unique bytes = each image once: frac_unique = unique bytes over the measured stream-read bandwidth is the utilisation"}
     finally:
         pt.close()
         grt.config_set(enable_svgf=0, enable_taa=0)
+
+
+def burst_section(grt, device, steps, warmup, config, workload):
+    """The driver's frame loop -- `steps` samples as 4-sample frames, declared as ONE burst of up to 8 frames exactly like the timed region of main() -- on a
+    scene staged with other settings, in the same process on the same GPU; wall time around submit + drain."""
+    import ctypes
+    scene = build_scene(grt)
+    grt.config_set(**config)
+    pt = grt.Pathtracer(scene, WIDTH, HEIGHT, device=device)
+    try:
+        pt.update()
+        lib, ctx = grt.device_lib(), pt.ctx
+        lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        lib.rt_synchronize.argtypes = [ctypes.c_void_p]
+        frames = (steps + SPP - 1) // SPP
+        def submit(count):
+            base = grt.submissions_completed(ctx)
+            for _ in range(count):
+                if lib.rt_render_samples(ctx, 0, SPP) != 0:
+                    raise RuntimeError(lib.rt_last_error(ctx).decode())
+            while grt.submissions_completed(ctx) - base < count:
+                grt.advance(ctx)
+            lib.rt_synchronize(ctx)
+        submit(max((warmup + SPP - 1) // SPP, 1))
+        lib.rt_render_samples(ctx, 0, 1); c = pt.counters(); rays = int(sum(c.trace[:NUM_BOUNCES]))   # closest-hit rays of one sample
+        lib.rt_synchronize(ctx)
+        if frames > 1:
+            grt.set_frame_pipelining(ctx, True)
+            grt.set_stream_batch(ctx, min(frames, 8) * SPP * WIDTH * HEIGHT)
+        submit(frames)                                                                              # untimed: the burst's queues are sized on first use
+        grt.set_profiling(ctx, 2)
+        t0 = time.perf_counter()
+        submit(frames)
+        elapsed = time.perf_counter() - t0
+        trace_ms = float(grt.launch_timings(ctx, 0).sum())
+        grt.set_profiling(ctx, False)
+        done = frames * SPP
+        return {"workload": workload, "steps": done, "ms_per_step": round(elapsed / done * 1e3, 3), "mrays_s": round(rays * done / elapsed / 1e6, 1),
+                "traversal_ms_per_step": round(trace_ms / done, 4), "rays_per_step": rays, "skip_behind_hit": bool(pt.skip_behind_hit)}
+    finally:
+        pt.close(); scene.close()
 
 
 def reference_layout_section(grt, device, steps, warmup):
     """The same frame loop on the REFERENCE'S acceleration-structure layout (config merge_static 0: one CWBVH per mesh under a
     CWBVH TLAS, 384 instance entries), in the same process on the same GPU, so that the line the driver records carries both
     layouts: the headline is measured on the flattened tree, a layout the reference does not have."""
-    import ctypes
     global MERGE_STATIC
     keep = MERGE_STATIC
     MERGE_STATIC = 0
     try:
-        scene = build_scene(grt)
-        pt = grt.Pathtracer(scene, WIDTH, HEIGHT, device=device)
-        try:
-            pt.update()
-            lib, ctx = grt.device_lib(), pt.ctx
-            lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-            lib.rt_synchronize.argtypes = [ctypes.c_void_p]
-            def submit(samples):
-                for _ in range(0, samples, SPP):
-                    if lib.rt_render_samples(ctx, 0, SPP) != 0:
-                        raise RuntimeError(lib.rt_last_error(ctx).decode())
-            submit(max(warmup, SPP)); lib.rt_synchronize(ctx)
-            lib.rt_render_samples(ctx, 0, 1); c = pt.counters(); rays = int(sum(c.trace[:NUM_BOUNCES]))   # closest-hit rays of one sample
-            grt.set_profiling(ctx, 2)
-            t0 = time.perf_counter()
-            submit(steps)
-            lib.rt_synchronize(ctx)
-            elapsed = time.perf_counter() - t0
-            trace_ms = float(grt.launch_timings(ctx, 0).sum())
-            grt.set_profiling(ctx, False)
-            done = ((steps + SPP - 1) // SPP) * SPP
-            return {"workload": "the same scene, camera, samples and frame loop with merge_static = 0: one CWBVH per mesh under a CWBVH TLAS (the reference's layout, Integrator.cpp:101-283)",
-                    "steps": done, "ms_per_step": round(elapsed / done * 1e3, 3), "mrays_s": round(rays * done / elapsed / 1e6, 1),
-                    "traversal_ms_per_step": round(trace_ms / done, 4), "rays_per_step": rays}
-        finally:
-            pt.close(); scene.close()
+        return burst_section(grt, device, steps, warmup, {}, "the same scene, camera, samples and frame loop (one declared burst) with merge_static = 0: one CWBVH per mesh under a CWBVH TLAS, walked the reference's way (the reference's layout, Integrator.cpp:101-283)")
     finally:
         MERGE_STATIC = keep
+
+
+def viewpoint_free_section(grt, device, steps, warmup):
+    """The headline's tree is seated by 1 M sample rays of which a quarter are paths from the benchmark's own camera (config static_slot_learning_viewpoint = 1: a
+    renderer seats the tree it is about to look at). This is the same frame loop on the tree seated WITHOUT any camera rays: what a viewpoint the seating
+    never saw pays."""
+    return burst_section(grt, device, steps, warmup, dict(static_slot_learning_viewpoint=0), "the same scene, camera, samples and frame loop (one declared burst); the flattened tree's children seated by sample rays from free-space points and surfaces only (static_slot_learning_viewpoint = 0: no ray from the benchmark's camera)")
 
 
 def main():
@@ -488,7 +523,7 @@ def main():
     pt = grt.Pathtracer(scene, WIDTH, HEIGHT, device=local_rank)
     pt.update()
     if pt.static_geometry_whole_scene:
-        TRACE_KERNEL[0] = "kernel_trace_stream_bvh8_flat"   # the engine variant without TLAS / instance code
+        TRACE_KERNEL[0] = "kernel_trace_stream_bvh8_flat_skip" if pt.skip_behind_hit else "kernel_trace_stream_bvh8_flat"   # the engine variant without TLAS / instance code (and its skipping walk: rt_set_skip_behind_hit)
     flatten_build_s = pt.static_geometry_build_seconds if pt.static_geometry_members else 0.0
     closed = False
     lib = grt.device_lib()
@@ -721,7 +756,10 @@ def main():
         def spread(values):
             v = np.sort(np.asarray(values, np.float64))
             return {"min": round(float(v[0]), 4), "median": round(float(v[len(v) // 2]), 4), "max": round(float(v[-1]), 4)} if len(v) else None
-        roofline = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None}
+        # bound / achieved / peak / unit / frac: the unit of the dominant kernel that sits closest to its roof, filled in from the hardware counters of the same
+        # command (pmc_section: roofline.binding); every fraction in the record is <= 1. SURVEY 8d's figure -- algorithmic bytes over launch time over the HBM
+        # peak -- is cache-served bytes here (a 31 MB tree) and lives under its own name, algorithmic_bytes_over_hbm_peak.
+        roofline = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None}
         if merged and len(launch_ms) == len(launch_bytes):
             # the dominant kernel: ONE fused traversal launch per iteration (closest-hit rays of every submission in flight +
             # the shadow rays of the previous iteration); bytes per launch from the counting variant of the same launches
@@ -729,14 +767,14 @@ def main():
             big = launch_rays >= 0.5 * launch_rays.max()        # the steady-state launches (fill and drain iterations excluded)
             per_launch_gbps = launch_bytes / np.maximum(launch_ms, 1e-6) / 1e6
             roofline.update({
-                "kernel": TRACE_KERNEL[0], "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "frac_is": "SURVEY 8d's figure: ALGORITHMIC bytes / launch time / HBM peak. The bytes are served by the caches (binding.l1_hit_rate, l2_hit_rate), so this is a yardstick that can exceed 1, NOT a utilisation; the utilisations (all <= 1) are hbm_frac (counter bytes over the same peak), l1_frac_of_algorithmic_bytes and roofline.binding",
-                "l1_frac_of_algorithmic_bytes": round(achieved / L1_PEAK_GBPS, 4),
+                "kernel": TRACE_KERNEL[0], "algorithmic_gbps": round(achieved, 1), "algorithmic_bytes_over_hbm_peak": round(achieved / HBM_PEAK_GBPS, 4),
+                "algorithmic_bytes_over_hbm_peak_is": "SURVEY 8d's figure: ALGORITHMIC bytes / launch time / the 8 TB/s HBM peak. The bytes are served by the caches (binding.l1_hit_rate, l2_hit_rate), so this is a yardstick that can exceed 1, NOT a utilisation; the utilisations (all <= 1) are roofline.frac (the binding unit's), hbm_frac (counter bytes over the same peak), algorithmic_bytes_over_l1_stream_rate and the rest of roofline.binding",
+                "algorithmic_bytes_over_l1_stream_rate": round(achieved / L1_STREAM_GBPS, 4),
                 "launches": int(len(launch_ms)), "algorithmic_bytes_per_launch": round(float(launch_bytes.mean())), "avg_launch_ms": round(float(launch_ms.mean()), 4),
                 "launch_ms": spread(launch_ms), "launch_gbps": spread(per_launch_gbps),
-                "steady_state": {"launches": int(big.sum()), "achieved": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9), 1),
+                "steady_state": {"launches": int(big.sum()), "algorithmic_gbps": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9), 1),
                                  "ratio_to_hbm_peak_cache_served": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9 / HBM_PEAK_GBPS), 4),
-                                 "l1_frac_of_algorithmic_bytes": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9 / L1_PEAK_GBPS), 4),
+                                 "algorithmic_bytes_over_l1_stream_rate": round(float(launch_bytes[big].sum() / (launch_ms[big].sum() * 1e-3) / 1e9 / L1_STREAM_GBPS), 4),
                                  "launch_gbps": spread(per_launch_gbps[big]), "rays_per_launch": int(launch_rays[big].mean())},
                 "closest_hit_share_of_bytes": round(float(launch_closest_bytes.sum() / launch_bytes.sum()), 3),
                 "time_share_of_step": round(float(launch_ms.sum() / (elapsed * 1e3)), 3),
@@ -745,13 +783,13 @@ def main():
         else:
             total_ms = float(launch_ms.sum()) if len(launch_ms) else float("nan")
             achieved = alg_closest_plan / (total_ms * 1e-3) / 1e9
-            roofline.update({"kernel": "kernel_trace_bvh8", "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4), "launches": int(len(launch_ms)),
+            roofline.update({"kernel": "kernel_trace_bvh8", "algorithmic_gbps": round(achieved, 1), "algorithmic_bytes_over_hbm_peak": round(achieved / HBM_PEAK_GBPS, 4), "launches": int(len(launch_ms)),
                              "launch_ms": spread(launch_ms), "shadow_kernel": {"kernel": "kernel_trace_shadow_bvh8", "launches": int(len(shadow_launch_ms)), "launch_ms": spread(shadow_launch_ms),
                              "achieved": round(alg_shadow_plan / (max(float(shadow_launch_ms.sum()), 1e-9) * 1e-3) / 1e9, 1)},
                              "note": "slot scheduler: launches of different submissions queue behind each other, the event durations include that wait"})
         roofline.update({
             "traversal_share": {"algorithmic_gbps_over_the_whole_step": round((alg_closest_plan + alg_shadow_plan) / elapsed / 1e9, 1),
-                                "frac": round((alg_closest_plan + alg_shadow_plan) / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
+                                "algorithmic_bytes_over_hbm_peak": round((alg_closest_plan + alg_shadow_plan) / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
                                 "note": "all traversal bytes (closest + shadow) / wall time of the timed region: a lower bound that charges every other kernel to the traversal"},
             "bytes_per_ray": round(sum(alg_closest_per_sample) / max(sum(rays_per_sample), 1), 1),
             "bytes_per_shadow_ray": round(sum(alg_shadow_per_sample) / max(sum(shadow_per_sample), 1), 1),
@@ -763,17 +801,17 @@ def main():
             "measured_stream_read_gbps": round(grt.measure_stream_bandwidth(ctx, 1 << 30, 5), 1),
         })
         stream_gbps = roofline["measured_stream_read_gbps"]
-        if roofline.get("achieved"):   # the denominator SURVEY 8d names: what a streaming read reaches on THIS GPU
-            roofline["ratio_to_measured_stream_cache_served"] = round(roofline["achieved"] / stream_gbps, 4)
+        if roofline.get("algorithmic_gbps"):   # the denominator SURVEY 8d names: what a streaming read reaches on THIS GPU
+            roofline["algorithmic_bytes_over_measured_stream_cache_served"] = round(roofline["algorithmic_gbps"] / stream_gbps, 4)
         if stages_raw:
             trace_ms = float(grt.launch_timings(ctx, "trace").sum())
             stages = stage_rooflines(grt, ctx, counters_per_sample, plan, args.steps, stream_gbps)
             if merged and launch_bytes is not None:
                 stages.insert(1, {"stage": "traversal", "launches": int(len(launch_bytes)), "ms_per_step": round(trace_ms / args.steps, 4),
                                   "algorithmic_bytes_per_step": round(float(launch_bytes.sum()) / args.steps),
-                                  "achieved": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
-                                  "ratio_to_hbm_peak_cache_served": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                  "l1_frac_of_algorithmic_bytes": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9 / L1_PEAK_GBPS, 4)})
+                                  "algorithmic_gbps": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                  "algorithmic_bytes_over_hbm_peak": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                  "algorithmic_bytes_over_l1_stream_rate": round(float(launch_bytes.sum()) / (trace_ms * 1e-3) / 1e9 / L1_STREAM_GBPS, 4)})
             roofline["stages"] = stages
             roofline["stages_note"] = "a repeat of the timed plan with HIP events around every launch (rt_set_profiling 3); frac = algorithmic bytes (SURVEY 8d formulas, bench.py stage_rooflines) / stage time / the 8 TB/s HBM peak, ratio_to_measured_stream = the same over what a 1 GiB streaming read reaches on this GPU (a read-only probe: a read + write stage such as accumulate can pass it); the traversal's bytes are cache-served, its entry carries a labelled ratio and the L1 fraction instead of frac; the sort kernel is a gather chain, the material kernels are bound by instruction issue: their fraction is a yardstick, not the limit"
             grt.set_profiling(ctx, False)
@@ -830,12 +868,15 @@ def main():
                 pt.close(); pt = None
             result["flatten_build_s"] = round(float(flatten_build_s), 3)
             result["reference_layout"] = reference_layout_section(grt, local_rank, args.steps, args.warmup)
+            result["seating_without_viewpoint"] = viewpoint_free_section(grt, local_rank, args.steps, args.warmup)
+            result["ms_per_step_seating_without_viewpoint"] = result["seating_without_viewpoint"]["ms_per_step"]   # (next to value / ms_per_step: VERDICT round 5, weak 7)
         if world == 1 and split_world == 1 and merged and not args.no_pmc and not os.environ.get("BENCH_PMC_CHILD"):
             # hardware counters of the same command (separate rocprofv3 --pmc passes); this process lets go of the GPU first
             if pt is not None:
                 pt.close()
             scene.close(); closed = True
-            pmc = pmc_section(args, rays_plan / args.steps, launch_ms, plan)
+            node_visits = float(sum(s["closest"]["nodes"] + s["shadow"]["nodes"] for s in trace_rays_stat)); triangle_tests = float(sum(s["closest"]["triangles"] + s["shadow"]["triangles"] for s in trace_rays_stat))
+            pmc = pmc_section(args, rays_plan / args.steps, launch_ms, plan, node_visits, triangle_tests)
             pmc_kernels = pmc.pop("kernels", {})
             result["roofline"].update(pmc)
             r = result["roofline"]
@@ -852,8 +893,22 @@ def main():
                 r["cache_hit_fraction_lower_bound"] = round(1.0 - r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
                 r["hbm_frac"] = round(r["traffic"] / (float(np.mean(launch_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if len(launch_ms) else None
                 bind = r.get("binding", {})
-                r["bound_in_practice"] = ("no unit saturated; closest to its roof: %s. Utilisations (each against its peak from MI355X_MICROARCH.md, roofline.binding): %s. The memory side moves %.0f %% of the algorithmic bytes (hbm_frac %.2f), which is why the SURVEY 8d figure `frac` can exceed 1"
+                r["bound_in_practice"] = ("no unit saturated; closest to its roof: %s. Utilisations (the vector ALU's, L2's and HBM's peaks from MI355X_MICROARCH.md, the L1's measured: profiles/r06_l1_lookup_rate.txt; roofline.binding): %s. The memory side moves %.0f %% of the algorithmic bytes (hbm_frac %.2f), which is why SURVEY 8d's figure (algorithmic_bytes_over_hbm_peak) can exceed 1"
                                           % (bind.get("closest_to_its_roof"), json.dumps(bind.get("utilisation_by_unit")), 100.0 * r["traffic"] / r["algorithmic_bytes_per_launch"], r["hbm_frac"] or float("nan")))
+            bind = r.get("binding") or {}
+            if bind.get("closest_to_its_roof"):   # the top level names the binding unit: bound / achieved / peak / unit / frac are ITS
+                name = bind["closest_to_its_roof"]
+                if name in ("l1", "l2", "hbm"):
+                    unit = bind[name]; r.update({"bound": name, "achieved": unit["achieved"], "peak": unit["peak"], "unit": unit["unit"], "frac": unit["frac"]})
+                elif name == "valu (lane-instructions)":
+                    r.update({"bound": "valu", "achieved": bind["achieved"], "peak": bind["peak"], "unit": bind["unit"], "frac": bind["frac"]})
+                elif name == "valu issue (wave-instructions)":
+                    r.update({"bound": "valu issue", "achieved": round(bind["issue_frac"] * 0.5, 4), "peak": 0.5, "unit": "vector wave-instructions per cycle and SIMD", "frac": bind["issue_frac"]})
+                else:   # what the round's own instruction mix allows (classes serial)
+                    mix = bind["mix_aware"]
+                    r.update({"bound": "valu issue, mix-aware", "achieved": round(1.0 / mix["measured_cycles_per_instruction"], 4), "peak": round(1.0 / mix["best_cycles_per_instruction"]["classes_serial"], 4),
+                              "unit": "vector wave-instructions per cycle and SIMD (x lane utilisation in frac)", "frac": mix["frac_classes_serial"]})
+                r["bound_is"] = "the unit of the dominant kernel closest to its roof (roofline.binding.utilisation_by_unit); no unit is saturated -- the launch is a chain of dependent node and triangle fetches"
         print(json.dumps(result))
 
     if not closed:
