@@ -510,8 +510,16 @@ static int upload_triangle_positions(rt_context * ctx, const void * triangles, s
 	return RT_OK;
 }
 
+// What the flattened scene's engine (kernel_trace_stream_bvh8_flat*) can address: a node's byte offset is v_mul_u32_u24(index, 80) -- a 24-bit multiply, exact for
+// fewer than 2^24 nodes (1.34 GB of them: the 4 GiB of the 32-bit offset is never the limit for nodes) -- and a triangle's a 32-bit index * 48. Beyond either limit
+// the general engine walks the scene (64-bit addresses). (Round 5 checked the 4 GiB only: advisor finding.)
+int rt_geometry_fits_flat_engine(size_t node_count, size_t triangle_count) {
+	return node_count < (size_t(1) << 24) && triangle_count * 48 < (1ull << 32) ? 1 : 0;
+}
+
 int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle_count, const void * bvh8_nodes, size_t node_count) {
 	RT_REQUIRE(ctx, ctx && triangles && bvh8_nodes, "rt_upload_geometry: NULL argument");
+	ctx->build_boxes.clear(); ctx->build_boxes_first = 0;   // (boxes set for a build that never came do not wait for another geometry's)
 	(void)hipSetDevice(ctx->device);
 	int s = upload(ctx, &ctx->triangles, triangles, triangle_count * 96); if (s) return s;
 	s = upload(ctx, &ctx->bvh8_nodes, bvh8_nodes, node_count * 80); if (s) return s;
@@ -520,7 +528,7 @@ int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle
 	ctx->tlas_version_in_nodes = ~0ull;
 	ctx->params.triangles  = (const float4 *)ctx->triangles;
 	ctx->params.bvh8_nodes = (const float4 *)ctx->bvh8_nodes;
-	ctx->params.geometry_below_4gib = node_count * 80 < (1ull << 32) && triangle_count * 48 < (1ull << 32);
+	ctx->params.geometry_below_4gib = rt_geometry_fits_flat_engine(node_count, triangle_count);
 	return RT_OK;
 }
 
@@ -607,6 +615,7 @@ extern "C" {
 
 int rt_set_build_boxes(rt_context * ctx, const float * boxes, size_t first_triangle, size_t count) {
 	RT_REQUIRE(ctx, ctx && (boxes || count == 0), "rt_set_build_boxes: NULL argument");
+	RT_REQUIRE(ctx, first_triangle < (size_t(1) << 30) && count < (size_t(1) << 30), "rt_set_build_boxes: range out of bounds");
 	ctx->build_boxes.assign(boxes, boxes + 6 * count);
 	ctx->build_boxes_first = first_triangle;
 	return RT_OK;
@@ -614,6 +623,10 @@ int rt_set_build_boxes(rt_context * ctx, const float * boxes, size_t first_trian
 
 int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_count, const int32_t * mesh_first_triangle, size_t mesh_count,
                       size_t reserved_tlas_nodes, int32_t * out_root_indices, int32_t * out_triangle_positions, size_t * out_node_count, float * out_build_ms) {
+	// rt_set_build_boxes: boxes that come with some of the triangles -- taken by THIS call whatever becomes of it (an early error exit used to leave them pending
+	// for the next build, of possibly unrelated geometry: advisor finding, round 5); whatever does not fit the input is ignored
+	std::vector<float> given_boxes; size_t given_first = 0;
+	if (ctx) { given_boxes.swap(ctx->build_boxes); given_first = ctx->build_boxes_first; ctx->build_boxes_first = 0; }
 	RT_REQUIRE(ctx, ctx && triangles && mesh_first_triangle && mesh_count >= 1, "rt_build_geometry: NULL argument");
 	RT_REQUIRE(ctx, triangle_count < (size_t(1) << 30) && mesh_count < (size_t(1) << 24), "rt_build_geometry: too many triangles / meshes");
 	RT_REQUIRE(ctx, mesh_first_triangle[0] == 0 && size_t(mesh_first_triangle[mesh_count]) == triangle_count, "rt_build_geometry: mesh_first_triangle must run from 0 to triangle_count");
@@ -653,9 +666,7 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	const size_t o_table = region(split_widest ? 0 : size_t(table_levels) * T * 24);
 	const size_t library_bytes = rt_blas_build_scratch_bytes(T, M + level_capacity);
 	const size_t o_library = region(library_bytes);
-	// rt_set_build_boxes: boxes that come with some of the triangles (taken by THIS build; whatever does not fit the input is ignored)
-	std::vector<float> given_boxes; given_boxes.swap(ctx->build_boxes);
-	const size_t given_first = ctx->build_boxes_first, given_count = given_first + given_boxes.size() / 6 <= T ? given_boxes.size() / 6 : 0;
+	const size_t given_count = given_first + given_boxes.size() / 6 <= T ? given_boxes.size() / 6 : 0;
 	const size_t o_given = region(given_count * 24);
 	if ((s = device_alloc(ctx, &scratch, at))) return give_up(s);
 	char * base = (char *)scratch;
@@ -696,7 +707,7 @@ int rt_build_geometry(rt_context * ctx, const void * triangles, size_t triangle_
 	ctx->triangle_count = T; ctx->bvh8_node_count = size_t(node_count);
 	ctx->tlas_version_in_nodes = ~0ull;
 	ctx->params.triangles = (const float4 *)out_triangles; ctx->params.triangle_positions = (const float4 *)out_positions; ctx->params.bvh8_nodes = (const float4 *)out_nodes;
-	ctx->params.geometry_below_4gib = size_t(node_count) * 80 < (1ull << 32) && size_t(T) * 48 < (1ull << 32);
+	ctx->params.geometry_below_4gib = rt_geometry_fits_flat_engine(size_t(node_count), size_t(T));
 	ctx->params.has_triangle_aliases = 0; ctx->params.entry_tlas_stack_size = RT_INVALID;
 	if (out_root_indices) for (size_t m = 0; m < M; m++) out_root_indices[m] = int32_t(reserved_tlas_nodes + m);
 	if (out_node_count) *out_node_count = size_t(node_count);
@@ -1196,7 +1207,7 @@ int rt_resize(rt_context * ctx, int width, int height) {
 	for (SampleSlot & slot : ctx->slots) slot.aov_samples = 1;
 	ctx->params.frame_pixels = unsigned(ctx->frame_pixels);
 	ctx->params.frame_pixels_magic = unsigned((1ull << 32) / ctx->frame_pixels) + 1u;
-	for (int i = 0; i < 14; i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }
+	for (size_t i = 0; i < sizeof(ctx->svgf_buffers) / sizeof(*ctx->svgf_buffers); i++) { device_free(ctx, ctx->svgf_buffers[i]); ctx->svgf_buffers[i] = nullptr; }   // (all 16: the third TAA image [14] and the young-pixel list [15] used to stay behind, 20 B per pixel per resize)
 	for (SampleSlot & slot : ctx->slots) for (int i = 0; i < 3; i++) { device_free(ctx, slot.gbuffers[i]); slot.gbuffers[i] = nullptr; }
 	ctx->svgf_allocated = false;
 	device_free(ctx, ctx->final_image); ctx->final_image = nullptr;

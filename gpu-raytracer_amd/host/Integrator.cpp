@@ -359,8 +359,13 @@ void Integrator::init_geometry() {
 					for (const Triangle & t : world) { all.expand(t.position_0); all.expand(t.position_1); all.expand(t.position_2); }
 					for (int d = 0; d < 3; d++) longest = std::max(longest, all.max[d] - all.min[d]);
 				}
-				if (longest > 0.0f) StaticBVHBuilder::presplit(world, cpu_config.device_presplit * longest, copy_source, copy_boxes);
-				else {
+				if (longest > 0.0f) {
+					StaticBVHBuilder::presplit(world, cpu_config.device_presplit * longest, copy_source, copy_boxes);
+					// The memory policy was decided on the triangles (flatten_candidates: 176 bytes per copy against static_copy_budget_mb); a cut triangle is up to
+					// 64 copies. Pieces that would take the copies past the budget are not worth it: the references go in uncut (advisor finding, round 5).
+					if (double(copy_source.size()) * 176.0 > double(cpu_config.static_copy_budget_mb) * 1048576.0) { copy_source.clear(); copy_boxes.clear(); longest = 0.0f; }
+				}
+				if (!(longest > 0.0f)) {
 					copy_source.resize(source_member.size());
 					for (size_t c = 0; c < copy_source.size(); c++) copy_source[c] = int(c);
 				}

@@ -144,7 +144,9 @@ struct Learner {
 					// what the detour costs: the walk of that child's subtree by a ray that has not found its hit yet
 					unsigned work = 2; float unused;
 					if (weigh_by_work) (void)trace(r, unused, n.base_index_child + unsigned(__builtin_popcount(unsigned(n.imask) & ((1u << s) - 1u))), &work);
-					score[((size_t(score_row[node]) * 8 + size_t(r.octant)) * 8 + size_t(s)) * 8 + size_t(holder)].fetch_add(work, std::memory_order_relaxed);
+					// (a counter is 32 bits wide and the root's cells see every ray: at most 8 M rays of at most 511 each cannot wrap it -- a detour that costs more than
+					// 255 node steps weighs as one that costs 255: advisor finding, round 5)
+					score[((size_t(score_row[node]) * 8 + size_t(r.octant)) * 8 + size_t(s)) * 8 + size_t(holder)].fetch_add(std::min(work, 511u), std::memory_order_relaxed);
 				}
 			}
 			node = holder_node;
@@ -247,7 +249,7 @@ struct Learner {
 
 void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<Triangle> & triangles, int rays, int thread_count, const SlotLearningView * view) {
 	if (bvh.nodes.empty() || triangles.empty() || bvh.indices.empty() || rays <= 0) return;
-	rays = std::min(rays, 8 << 20);   // (the counters are 32 bits wide: a detour weighs a few hundred at most, the root sees every ray)
+	rays = std::min(rays, 8 << 20);   // (the counters are 32 bits wide, a detour weighs at most 511 (learn_from): 8 M x 511 < 2^32)
 	Learner learner(bvh, triangles);
 	if (view && view->width > 0 && view->height > 0) learner.view = view;
 	if (const char * c = getenv("GRT_SLOT_LEARNING_UNWEIGHTED")) learner.weigh_by_work = atoi(c) == 0;

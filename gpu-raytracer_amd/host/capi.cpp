@@ -343,7 +343,7 @@ int    grt_pathtracer_static_geometry_members(void * pt) { Integrator * p = as_i
 int    grt_pathtracer_skip_behind_hit(void * pt) {
 	Integrator * p = as_integrator(pt);
 	bool whole_scene = p->static_geometry.active && p->static_geometry.movers.empty();
-	bool below_4gib = p->aggregated_bvh_nodes_8.size() * 80ull < (1ull << 32) && p->aggregated_triangles.size() * 48ull < (1ull << 32);
+	bool below_4gib = rt_geometry_fits_flat_engine(p->aggregated_bvh_nodes_8.size(), p->aggregated_triangles.size()) != 0;
 	return cpu_config.skip_behind_hit && cpu_config.bvh_type == BVHType::BVH8 && whole_scene && below_4gib ? 1 : 0;
 }
 int    grt_pathtracer_static_geometry_whole_scene(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active && p->static_geometry.movers.empty() ? 1 : 0; }

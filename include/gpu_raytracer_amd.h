@@ -146,7 +146,7 @@ const char * rt_version(void);
  *   7  rt_set_node_format (a 96-byte decoded copy of the node array) and rt_set_node_cache (the top of the flattened tree in LDS) REMOVED:
  *      both measured slower than the 80-byte walk on MI355X (profiles/r04_traversal_experiments.txt items 2 and 4) and were off by default;
  *      rt_set_build_boxes added
- *   8  rt_set_skip_behind_hit, rt_get_skip_behind_hit (additions only)
+ *   8  rt_set_skip_behind_hit, rt_get_skip_behind_hit, rt_geometry_fits_flat_engine (additions only)
  * Check `rt_abi_version() == RT_ABI_VERSION` once after loading the library.                                          */
 #define RT_ABI_VERSION 8
 int rt_abi_version(void);
@@ -159,6 +159,10 @@ int rt_abi_version(void);
  * (BVH/BVH.h:61-80); slots [0, 2*mesh_count) are reserved for the TLAS.                 */
 int rt_upload_geometry(rt_context * ctx, const void * triangles, size_t triangle_count,
                        const void * bvh8_nodes, size_t node_count);
+/* 1 when a one-tree scene of this size (rt_set_static_geometry(ctx, 1)) is walked by the flattened scene's engine, whose node offsets are a 24-bit multiply and
+ * whose triangle offsets are 32 bits wide: fewer than 2^24 nodes and less than 4 GiB of 48-byte triangle records. Larger scenes are walked by the general
+ * engine (64-bit addresses), the reference's way. A pure function: no context, no device.                                                             */
+int rt_geometry_fits_flat_engine(size_t node_count, size_t triangle_count);
 /* Static geometry flattened into ONE bottom-level tree (no counterpart in the reference, which traverses one BLAS per mesh
  * under the TLAS whether the meshes move or not -- Integrator.cpp:101-283,399-430): the caller adds COPIES of the triangles
  * of its static instances to the triangle array, builds (or lets rt_build_geometry build) one more CWBVH over the copies and

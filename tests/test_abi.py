@@ -53,3 +53,17 @@ def test_host_pathtracer_refuses_to_render_without_device(grt):
         pt.render()
     pt.close()
     scene.close()
+
+
+def test_the_flat_engines_addressing_gate_sits_where_its_multiply_ends(grt):
+    """The flattened scene's engine forms a node's byte offset with a 24-bit multiply (exact below 2^24 nodes) and a triangle's with a 32-bit one (below 4 GiB of
+    48-byte records); rt_geometry_fits_flat_engine is the gate both rt_upload_geometry and rt_build_geometry apply (round 5 checked 4 GiB only: advisor finding)."""
+    lib = grt.device_lib()
+    lib.rt_geometry_fits_flat_engine.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
+    lib.rt_geometry_fits_flat_engine.restype = ctypes.c_int
+    assert lib.rt_geometry_fits_flat_engine(1, 1) == 1
+    assert lib.rt_geometry_fits_flat_engine((1 << 24) - 1, 1) == 1
+    assert lib.rt_geometry_fits_flat_engine(1 << 24, 1) == 0                       # 2^24 * 80 B = 1.34 GB: far below 4 GiB, and past the multiply
+    assert lib.rt_geometry_fits_flat_engine(1000, (1 << 32) // 48) == 1            # 89 478 485 triangles: 4 294 967 280 bytes
+    assert lib.rt_geometry_fits_flat_engine(1000, (1 << 32) // 48 + 1) == 0
+    assert lib.rt_geometry_fits_flat_engine(0, 0) == 1
