@@ -565,7 +565,9 @@ def main():
     # hands the 128 bytes to the others (its only part in the data path), every rank joins with ncclCommInitRank. From then on a
     # completed frame is exchanged by ONE call that packs, all-gathers over RCCL on the context's stream and unpacks.
     exchange = "torch"
-    if world > 1 and args.exchange == "native" and backend == "nccl" and not os.environ.get("BENCH_SHARE_GPU"):
+    # (ranks that share a GPU -- BENCH_SHARE_GPU, a one-GPU test box -- can only take it with a collective library that accepts a device twice: the loopback
+    # stand-in of the test suite, GRT_COLLECTIVE_LIBRARY=tests/support/libloopback_ccl.so; RCCL itself refuses)
+    if world > 1 and args.exchange == "native" and ((backend == "nccl" and not os.environ.get("BENCH_SHARE_GPU")) or os.environ.get("GRT_COLLECTIVE_LIBRARY")):
         lib.rt_comm_unique_id.argtypes = [ctypes.c_void_p]
         lib.rt_comm_init_rank.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         lib.rt_all_gather_framebuffer.argtypes = [ctypes.c_void_p]

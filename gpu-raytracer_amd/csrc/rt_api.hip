@@ -1359,8 +1359,11 @@ RcclApi * rccl_api(std::string & why) {
 	static RcclApi api; static bool tried = false; static std::string failure;
 	if (!tried) {
 		tried = true;
-		for (const char * name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) if ((api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
-		if (!api.handle) failure = std::string("librccl.so not found: ") + dlerror();
+		// GRT_COLLECTIVE_LIBRARY: another library with RCCL's entry points, tried first. tests/support/libloopback_ccl.so uses it to run this very code with two
+		// ranks on a box with one GPU (RCCL refuses a device twice); a deployment could name a site's own RCCL build the same way.
+		if (const char * named = getenv("GRT_COLLECTIVE_LIBRARY")) { if (named[0] && !(api.handle = dlopen(named, RTLD_NOW | RTLD_LOCAL))) failure = std::string("GRT_COLLECTIVE_LIBRARY: ") + dlerror(); }
+		if (!api.handle && failure.empty()) for (const char * name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) if ((api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+		if (!api.handle) { if (failure.empty()) failure = std::string("librccl.so not found: ") + dlerror(); }
 		else {
 			#define RT_BIND(member, symbol) { *(void **)&api.member = dlsym(api.handle, symbol); if (!api.member) failure = std::string("librccl.so lacks ") + symbol; }
 			RT_BIND(get_unique_id, "ncclGetUniqueId") RT_BIND(comm_init_rank, "ncclCommInitRank") RT_BIND(comm_init_all, "ncclCommInitAll") RT_BIND(comm_destroy, "ncclCommDestroy")

@@ -317,7 +317,10 @@ int rt_unpack_pixels(rt_context * ctx, const void * src_device, int tile_pixels,
  * A context renders the tiles rt_set_pixel_tiles(ctx, tile_pixels, rank, world) names; rt_all_gather_framebuffer packs them,
  * all-gathers (ncclAllGather on the context's stream) and scatters the result into every context's final image, asynchronously.
  * Contexts of one process are exchanged by ONE call (grouped: ncclGroupStart / End). rt_all_gather_svgf_inputs moves what the
- * SVGF filter stage reads of a frame instead (DIRECT, INDIRECT, ALBEDO, the g-buffers: 80 B per pixel; see rt_pack_svgf_inputs). */
+ * SVGF filter stage reads of a frame instead (DIRECT, INDIRECT, ALBEDO, the g-buffers: 80 B per pixel; see rt_pack_svgf_inputs).
+ * Environment GRT_COLLECTIVE_LIBRARY names another library with RCCL's entry points (ncclGetUniqueId, ncclCommInitRank, ncclCommInitAll, ncclCommDestroy,
+ * ncclAllGather, ncclGroupStart / End, ncclGetErrorString) to bind instead of librccl.so: a site's own build -- or the loopback stand-in of the test suite
+ * (tests/support/loopback_ccl.cpp), which lets two PROCESSES that share one GPU run this exchange with world = 2 (tests/test_gpu_rccl.py).               */
 int rt_comm_unique_id(void * out_id_128_bytes);
 int rt_comm_init_rank(rt_context * ctx, const void * unique_id_128_bytes, int rank, int world);
 int rt_comm_init_all(rt_context ** contexts, int count);
