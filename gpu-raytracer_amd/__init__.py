@@ -165,6 +165,14 @@ def host_lib():
         lib.grt_pathtracer_static_geometry_top_nodes.argtypes = [c_void_p]
         lib.grt_pathtracer_set_flatten_asynchronously.restype = None
         lib.grt_pathtracer_set_flatten_asynchronously.argtypes = [c_void_p, c_int]
+        lib.grt_pathtracer_set_reseat_asynchronously.restype = None
+        lib.grt_pathtracer_set_reseat_asynchronously.argtypes = [c_void_p, c_int]
+        lib.grt_pathtracer_reseats_completed.restype = c_int
+        lib.grt_pathtracer_reseats_completed.argtypes = [c_void_p]
+        lib.grt_pathtracer_reseat_pending.restype = c_int
+        lib.grt_pathtracer_reseat_pending.argtypes = [c_void_p]
+        lib.grt_pathtracer_last_reseat_seconds.restype = ctypes.c_double
+        lib.grt_pathtracer_last_reseat_seconds.argtypes = [c_void_p]
         lib.grt_pathtracer_reflattens_completed.restype = c_int
         lib.grt_pathtracer_reflattens_completed.argtypes = [c_void_p]
         lib.grt_pathtracer_reflatten_in_progress.restype = c_int
@@ -558,6 +566,23 @@ class Pathtracer:
         """True (default): when a flattened instance starts to move the new tree is built on a worker thread while frames are rendered
         in the reference's layout; False: rebuilt inside update() (a stall of the build time)."""
         host_lib().grt_pathtracer_set_flatten_asynchronously(self.handle, 1 if enable else 0)
+
+    def set_reseat_asynchronously(self, enable):
+        """True (default): the flattened tree is seated again (config static_reseat_distance; device-built trees: for the first time) on a worker thread and its
+        nodes are swapped in between two frames; False: inside update()."""
+        host_lib().grt_pathtracer_set_reseat_asynchronously(self.handle, 1 if enable else 0)
+
+    @property
+    def reseats_completed(self):
+        return int(host_lib().grt_pathtracer_reseats_completed(self.handle))
+
+    @property
+    def reseat_pending(self):
+        return bool(host_lib().grt_pathtracer_reseat_pending(self.handle))
+
+    @property
+    def last_reseat_seconds(self):
+        return float(host_lib().grt_pathtracer_last_reseat_seconds(self.handle))
 
     @property
     def reflattens_completed(self):

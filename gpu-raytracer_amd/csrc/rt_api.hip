@@ -573,6 +573,19 @@ int rt_upload_triangle_aliases(rt_context * ctx, const int32_t * mesh_ids, const
 	return RT_OK;
 }
 
+// Replaces nodes [first_node, first_node + node_count) of the uploaded CWBVH node array in place: a tree whose children have been re-seated beside the frame
+// loop (host/Integrator.cpp: reseat worker). A ray holds stack entries (child base, mask) only INSIDE one traversal launch, so the swap is safe between launches:
+// the context is drained first. Boxes, leaves and triangles must be what they were (the caller's contract: the node count and every index stay).
+int rt_update_nodes(rt_context * ctx, const void * nodes, size_t first_node, size_t node_count) {
+	RT_REQUIRE(ctx, ctx && (nodes || node_count == 0), "rt_update_nodes: NULL argument");
+	RT_REQUIRE(ctx, ctx->bvh8_nodes && first_node <= ctx->bvh8_node_count && node_count <= ctx->bvh8_node_count - first_node, "rt_update_nodes: range outside the uploaded CWBVH node array");
+	if (node_count == 0) return RT_OK;
+	(void)hipSetDevice(ctx->device);
+	RT_HIP(ctx, quiesce(ctx));
+	RT_HIP(ctx, hipMemcpy((char *)ctx->bvh8_nodes + first_node * 80, nodes, node_count * 80, hipMemcpyHostToDevice));
+	return RT_OK;
+}
+
 // Where rays start: 0 = at the TLAS root in node slot 0; 1 = the whole scene is ONE world-space bottom-level tree whose root node
 // the caller has put into node slot 0 (through rt_upload_tlas), rays are inside it from the start, as instance row 0. A change
 // drains the context first: samples in flight were submitted against the old entry.

@@ -96,6 +96,10 @@ struct CPUConfig {
 	// ... and then re-seated by what this many sample rays over the flattened geometry say (bvh8_learn_slot_order, SlotOrder.cpp: a seeded, pure function of the
 	// geometry). 0: off.
 	int   static_slot_learning_rays = 1000000;
+	// The seating is trained for the camera as it stood (static_slot_learning_viewpoint): when the camera has travelled further than this fraction of the flattened
+	// geometry's diagonal from there, the tree is seated again for the new viewpoint BESIDE the frame loop (a worker thread, 0.3 s for Sponza) and its nodes are
+	// swapped in between two frames (rt_update_nodes). 0: never. Trees the DEVICE built (device_blas) get their first seating the same way.
+	float static_reseat_distance = 0.1f;
 	// Closest-hit rays of a one-tree scene drop stacked groups of children that lie behind the hit they already hold (rt_set_skip_behind_hit): same hits,
 	// 12 % fewer node visits on Sponza. false: the reference's walk, node for node.
 	bool  skip_behind_hit = true;

@@ -16,6 +16,8 @@ Integrator::Integrator(Scene & scene, int device_ordinal) : scene(scene) {
 }
 
 Integrator::~Integrator() {
+	if (pending_reseat && pending_reseat->worker.joinable()) pending_reseat->worker.join();
+	for (auto & retired : retired_reseats) if (retired->worker.joinable()) retired->worker.join();
 	if (pending_flatten && pending_flatten->worker.joinable()) pending_flatten->worker.join();
 	for (auto & retired : retired_flattens) if (retired->worker.joinable()) retired->worker.join();
 	if (ctx) rt_destroy(ctx);
@@ -208,6 +210,88 @@ void Integrator::start_flatten_worker() {
 	});
 }
 
+// ---- seating the flattened tree again, beside the frame loop (Integrator.h: PendingReseat) -----------------------------------------------------------
+void Integrator::drop_reseat_worker() {
+	for (size_t i = 0; i < retired_reseats.size();) {
+		if (retired_reseats[i]->ready.load()) { if (retired_reseats[i]->worker.joinable()) retired_reseats[i]->worker.join(); retired_reseats.erase(retired_reseats.begin() + long(i)); } else i++;
+	}
+	if (!pending_reseat) return;
+	if (pending_reseat->ready.load()) { if (pending_reseat->worker.joinable()) pending_reseat->worker.join(); pending_reseat.reset(); }
+	else retired_reseats.push_back(std::move(pending_reseat));
+}
+
+// A copy of the flattened tree as it stands in the staged arrays (host- or device-built: all it takes is the nodes and the triangles of its leaves) goes to a
+// worker that seats its children for the camera as it stands now. The copy is numbered breadth-first from the root; a node's inner children stay one
+// contiguous run in their order, so a record the learner moves within its run has ONE place to go back to.
+void Integrator::start_reseat_worker() {
+	const StaticGeometry & flat = static_geometry;
+	if (!flat.active || cpu_config.bvh_type != BVHType::BVH8 || cpu_config.static_slot_learning_rays <= 0) return;
+	if (size_t(flat.root) >= aggregated_bvh_nodes_8.size()) return;
+	drop_reseat_worker();
+	auto job = std::make_unique<PendingReseat>();
+	job->generation = geometry_generation; job->camera_position = scene.camera.position;
+	job->absolute.push_back(unsigned(flat.root));
+	// (the leaf positions the tree names: the host's builders give it the tail of the triangle array; the device's builder emits the leaves of all trees of a
+	// launch level by level, so the run from its first to its last position also holds other trees' triangles -- never named by this tree, carried along)
+	size_t first_position = aggregated_triangles.size(), end_position = 0;
+	for (size_t k = 0; k < job->absolute.size(); k++) {
+		if (job->absolute[k] >= aggregated_bvh_nodes_8.size()) return;
+		BVHNode8 node = aggregated_bvh_nodes_8[job->absolute[k]];
+		const unsigned children = unsigned(__builtin_popcount(unsigned(node.imask)));
+		const unsigned local_base = unsigned(job->absolute.size());
+		for (unsigned c = 0; c < children; c++) job->absolute.push_back(node.base_index_child + c);
+		if (children) node.base_index_child = local_base;
+		for (int s = 0; s < 8; s++) if (!((node.imask >> s) & 1) && node.meta[s]) {
+			const size_t first = size_t(node.base_index_triangle) + (node.meta[s] & 31u), count = size_t(__builtin_popcount(unsigned(node.meta[s]) >> 5));
+			first_position = std::min(first_position, first); end_position = std::max(end_position, first + count);
+		}
+		job->tree.nodes.push_back(node);
+	}
+	if (first_position >= end_position || end_position > aggregated_triangles.size()) return;
+	job->triangle_base = first_position;
+	for (BVHNode8 & node : job->tree.nodes) node.base_index_triangle -= unsigned(job->triangle_base);   // (modulo 2^32 for a node without leaves, whose base means nothing: install adds it back)
+	const size_t copies = end_position - first_position;
+	job->tree.indices.resize(copies); job->triangles.resize(copies);
+	for (size_t i = 0; i < copies; i++) {
+		const DeviceTriangle & t = aggregated_triangles[job->triangle_base + i];
+		job->tree.indices[i] = int(i);
+		job->triangles[i].position_0 = t.position_0; job->triangles[i].position_1 = t.position_0 + t.position_edge_1; job->triangles[i].position_2 = t.position_0 + t.position_edge_2;
+	}
+	const SlotLearningView view = slot_learning_view();   // (as things stand now: the worker must not read the scene)
+	const int rays = cpu_config.static_slot_learning_rays;
+	PendingReseat * raw = job.get();
+	raw->worker = std::thread([raw, view, rays] {
+		auto started = std::chrono::steady_clock::now();
+		try { bvh8_learn_slot_order(raw->tree, raw->triangles, rays, 0, &view); } catch (...) { raw->failed = true; }
+		raw->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
+		raw->ready.store(true);
+	});
+	pending_reseat = std::move(job);
+}
+
+// The worker is done: its nodes go back to the places they were copied from (children runs and triangle bases in the staged arrays' own numbering again) and
+// to the device (rt_update_nodes: between two frames). False: nothing went in (not ready, failed, or the geometry has been staged again meanwhile).
+bool Integrator::install_reseat() {
+	if (!pending_reseat || !pending_reseat->ready.load()) return false;
+	if (pending_reseat->worker.joinable()) pending_reseat->worker.join();
+	std::unique_ptr<PendingReseat> job = std::move(pending_reseat);
+	const StaticGeometry & flat = static_geometry;
+	if (job->failed || job->generation != geometry_generation || !flat.active || job->absolute.empty() || job->absolute[0] != unsigned(flat.root)) return false;
+	unsigned lowest = ~0u, highest = 0u;
+	for (size_t i = 0; i < job->tree.nodes.size(); i++) {
+		BVHNode8 node = job->tree.nodes[i];
+		if (node.imask) node.base_index_child = job->absolute[node.base_index_child];
+		node.base_index_triangle += unsigned(job->triangle_base);
+		aggregated_bvh_nodes_8[job->absolute[i]] = node;
+		lowest = std::min(lowest, job->absolute[i]); highest = std::max(highest, job->absolute[i]);
+	}
+	// (a host-built tree is one run of nodes; the device's builder interleaves the trees of a launch level by level: the run in between is re-sent as it is)
+	if (ctx) check(rt_update_nodes(ctx, &aggregated_bvh_nodes_8[lowest], lowest, size_t(highest - lowest) + 1));
+	seated_for_position = job->camera_position; seated_for_a_viewpoint = cpu_config.static_slot_learning_viewpoint != 0;
+	reseats_completed++; last_reseat_seconds = job->seconds;
+	return true;
+}
+
 // Concatenates all BLASes into one node array / one triangle array
 // (reference: Integrator::init_geometry, Integrator.cpp:101-283):
 //   * triangles are stored permuted by the BLAS `indices`, as pre-subtracted edges
@@ -306,6 +390,7 @@ void Integrator::init_geometry() {
 	}
 	if (use_bvh8) {
 		staged_index_total = index_total; staged_node_total = node_total;
+		geometry_generation++;   // (a seating in the making was copied from what is being replaced: install_reseat lets it go)
 		if (only_the_flattened_part) aggregated_bvh_nodes_8.resize(node_total);
 		else {
 		aggregated_bvh_nodes_8.assign(node_total, BVHNode8());
@@ -415,6 +500,20 @@ void Integrator::init_geometry() {
 				alias_triangle_ids [index_total + c] = original;
 			}
 			flat.built = flat.active = true;
+			// what the tree's children are seated for: the host's builder has just seated them for the camera as it stands (or as it stood when the worker
+			// started: near enough); the device's collapse knows no seating -- update() sends such a tree to the reseat worker
+			seated_for_position = scene.camera.position;
+			seated_for_a_viewpoint = !build_on_device && cpu_config.static_slot_learning_viewpoint != 0 && cpu_config.static_slot_learning_rays > 0;
+			flattened_tree_needs_seating = build_on_device && cpu_config.static_slot_learning_rays > 0;
+			{   // how far the flattened geometry reaches (finite vertices only): the yardstick of static_reseat_distance
+				Vector3 lo(+INFINITY), hi(-INFINITY);
+				for (size_t c = 0; c < copies; c++) {
+					const DeviceTriangle & t = aggregated_triangles[index_total + c];
+					for (const Vector3 & p : { t.position_0, t.position_0 + t.position_edge_1, t.position_0 + t.position_edge_2 })
+						if (std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z)) { lo = Vector3::min(lo, p); hi = Vector3::max(hi, p); }
+				}
+				flat.diagonal = lo.x <= hi.x ? Vector3::length(hi - lo) : 0.0f;
+			}
 			flat.copy_bytes = copies * (sizeof(DeviceTriangle) + 48 + 8) + (aggregated_bvh_nodes_8.size() - node_total) * sizeof(BVHNode8);
 		}
 		if (build_on_device) {
@@ -696,12 +795,34 @@ void Integrator::update(float delta) {
 	}
 
 	if (pending_flatten && pending_flatten->ready.load()) invalidated_scene = true;   // the tree built beside the frame loop is there: build_tlas installs it
+	if (pending_reseat && pending_reseat->ready.load() && install_reseat()) invalidated_scene = true;   // the tree seated beside the frame loop is there: its root's copy in node 0 follows (build_tlas)
 	if (invalidated_scene) {
 		invalidated_scene = false;
 		build_tlas();
 	}
 
 	scene.camera.update(delta);
+
+	// Seat the flattened tree (again) beside the frame loop: a tree the device built has never been seated; a tree seated for a viewpoint is seated again once
+	// the camera has travelled static_reseat_distance x the geometry's diagonal from there (Integrator.h: PendingReseat)
+	if (static_geometry.active && cpu_config.bvh_type == BVHType::BVH8 && cpu_config.static_slot_learning_rays > 0 && !pending_reseat && !pending_flatten) {
+		bool wanted = flattened_tree_needs_seating;
+		if (!wanted && cpu_config.static_reseat_distance > 0.0f && cpu_config.static_slot_learning_viewpoint && seated_for_a_viewpoint) {
+			const float diagonal = static_geometry.diagonal;
+			wanted = std::isfinite(diagonal) && diagonal > 0.0f && Vector3::length(scene.camera.position - seated_for_position) > cpu_config.static_reseat_distance * diagonal;
+		}
+		if (wanted) {
+			// (the first tree of an integrator is seated inside this update -- nothing has been rendered yet, the scene's load took longer than the 0.3 s --;
+			// later ones, a device rebuild after a member moved or a camera that has travelled, beside the frame loop)
+			const bool inside_this_update = !reseat_asynchronously || (flattened_tree_needs_seating && geometry_generation <= 1);
+			flattened_tree_needs_seating = false;
+			start_reseat_worker();
+			if (inside_this_update && pending_reseat) {
+				if (pending_reseat->worker.joinable()) pending_reseat->worker.join();
+				if (install_reseat()) build_tlas();
+			}
+		}
+	}
 
 	if (scene.camera.moved || invalidated_camera) {
 		const Camera & c = scene.camera;

@@ -104,6 +104,7 @@ struct Integrator {
 		size_t copy_bytes = 0;        // what the copies and the tree's nodes add to the device's geometry
 		int    top_nodes = 0;         // its nodes are in breadth-first order; so many of them (from the root) make up its top levels
 		AABB   aabb;
+		float  diagonal = 0.0f;       // of the box around the copies: what cpu_config.static_reseat_distance is a fraction of
 		double build_seconds = 0.0;   // host SAH + CWBVH conversion (0 when the device built it)
 		int leaves() const { return 1 + int(movers.size()); }   // rows in front of the members' rows
 	} static_geometry;
@@ -133,6 +134,31 @@ struct Integrator {
 	void drop_flatten_worker();
 	std::vector<int> flatten_candidates() const;
 	std::vector<Triangle> world_triangles_of(const std::vector<int> & members, std::vector<int> * source_member, std::vector<int> * source_triangle) const;
+	// Seating again (SlotOrder.cpp) beside the frame loop: a copy of the flattened tree and its triangles goes to a worker, which deals the children of every node
+	// to octant slots for the camera as it stands now; the finished nodes replace the tree's nodes in place (same count, same boxes, same leaves) between two
+	// frames. Started when the camera has travelled (cpu_config.static_reseat_distance) and for a tree the device built (its collapse knows no seating).
+	struct PendingReseat {
+		std::thread worker;
+		std::atomic<bool> ready { false };
+		bool failed = false;
+		BVH8 tree;                               // the flattened tree, root = node 0, indices relative to it
+		std::vector<Triangle> triangles;         // its leaf triangles in leaf order (world space)
+		std::vector<unsigned> absolute;          // node of `tree` -> its place in aggregated_bvh_nodes_8
+		size_t triangle_base = 0;                // leaf position 0 of `tree` in aggregated_triangles
+		unsigned long long generation = 0;       // of the staged geometry it was copied from
+		Vector3 camera_position;                 // what it is seated for
+		double seconds = 0.0;
+	};
+	std::unique_ptr<PendingReseat> pending_reseat;
+	std::vector<std::unique_ptr<PendingReseat>> retired_reseats;
+	unsigned long long geometry_generation = 0;   // every init_geometry is another one
+	Vector3 seated_for_position; bool seated_for_a_viewpoint = false;
+	bool flattened_tree_needs_seating = false;    // a tree the device built: never seated yet
+	int reseats_completed = 0; double last_reseat_seconds = 0.0;
+	bool reseat_asynchronously = true;            // (false: seat inside update(), for tests)
+	void start_reseat_worker();
+	bool install_reseat();                        // true when finished nodes went in
+	void drop_reseat_worker();
 	SlotLearningView slot_learning_view() const;   // the camera as it stands: what bvh8_learn_slot_order samples its paths from
 	std::vector<char> instance_has_moved;   // per scene mesh: seen with a changed transform since the scene was loaded -> never flattened again
 	std::vector<int> alias_mesh_ids, alias_triangle_ids;   // per device triangle (-1: not a copy): what rt_upload_triangle_aliases was given

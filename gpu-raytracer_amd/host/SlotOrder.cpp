@@ -63,7 +63,9 @@ inline bool enters(const SampleRay & r, const ChildBox & b, float limit, float &
 struct Learner {
 	const BVH8 & bvh;
 	const std::vector<Triangle> & triangles;
-	std::vector<unsigned> triangles_end;              // per node: one past the last leaf position of its subtree (the first is its base_index_triangle)
+	// Who holds a leaf position: per node its parent, per leaf position the node whose leaf it is in. (Rounds 5's form -- "a subtree's leaves are one run of
+	// positions" -- holds for the host's depth-first builders only; the device's builder emits leaves level by level, a subtree's positions are scattered.)
+	std::vector<unsigned> parent, leaf_owner;
 	std::unique_ptr<std::atomic<unsigned>[]> score;   // [score_row[node]][octant][c][h]: rays of that octant that ended in child h and enter child c only behind their hit
 	std::vector<int> score_row;                       // per node: its row of 512 counters, or -1 (a tree too large to score whole keeps rows for its top levels: memory_limit)
 	std::vector<float> area_cdf; float scene_size = 1.0f;
@@ -72,13 +74,17 @@ struct Learner {
 
 	Learner(const BVH8 & bvh, const std::vector<Triangle> & triangles) : bvh(bvh), triangles(triangles) { }
 
-	unsigned subtree_end(unsigned node) {
-		const BVHNode8 & n = bvh.nodes[node];
-		unsigned end = n.base_index_triangle;
-		for (int s = 0; s < 8; s++) if (!((n.imask >> s) & 1) && n.meta[s]) end = std::max(end, n.base_index_triangle + unsigned(n.meta[s] & 31u) + unsigned(__builtin_popcount(unsigned(n.meta[s]) >> 5)));
-		int rank = 0;
-		for (int s = 0; s < 8; s++) if ((n.imask >> s) & 1) end = std::max(end, subtree_end(n.base_index_child + unsigned(rank++)));
-		return triangles_end[node] = end;
+	void index_leaves() {
+		parent.assign(bvh.nodes.size(), ~0u); leaf_owner.assign(bvh.indices.size(), ~0u);
+		std::vector<unsigned> order; order.reserve(bvh.nodes.size()); order.push_back(0u);
+		for (size_t k = 0; k < order.size(); k++) {
+			const unsigned node = order[k]; const BVHNode8 & n = bvh.nodes[node];
+			for (int s = 0; s < 8; s++) if (!((n.imask >> s) & 1) && n.meta[s]) {
+				const unsigned first = n.base_index_triangle + unsigned(n.meta[s] & 31u), count = unsigned(__builtin_popcount(unsigned(n.meta[s]) >> 5));
+				for (unsigned t = first; t < first + count && t < leaf_owner.size(); t++) leaf_owner[t] = node;
+			}
+			for (int c = 0; c < __builtin_popcount(unsigned(n.imask)); c++) { const unsigned child = n.base_index_child + unsigned(c); if (child < bvh.nodes.size() && parent[child] == ~0u && child != 0) { parent[child] = node; order.push_back(child); } }
+		}
 	}
 
 	// closest hit below `root`; returns the leaf position (index into bvh.indices) or -1, and what the walk cost (2 per node step, 1 per triangle test)
@@ -128,16 +134,17 @@ struct Learner {
 		t_hit = r.tmax;
 		if (!std::isfinite(r.o[0] + r.o[1] + r.o[2]) || !std::isfinite(r.d[0] + r.d[1] + r.d[2])) return -1;   // (a ray of NaNs enters every box: non-finite vertices must not cost a walk of the whole tree per sample)
 		const int hit = trace(r, t_hit);
-		if (hit < 0) return hit;
-		unsigned node = 0;
-		for (int depth = 0; depth < 64; depth++) {
+		if (hit < 0 || size_t(hit) >= leaf_owner.size() || leaf_owner[size_t(hit)] == ~0u) return hit;
+		// the nodes from the root to the one that holds the hit
+		unsigned path[65]; int length = 0;
+		for (unsigned node = leaf_owner[size_t(hit)]; node != ~0u && length < 65; node = parent[node]) path[length++] = node;
+		if (length == 0 || length >= 65 || path[length - 1] != 0u) return hit;
+		for (int depth = 0; depth + 1 < length; depth++) {
+			const unsigned node = path[length - 1 - depth], holder_node = path[length - 2 - depth];
 			const BVHNode8 & n = bvh.nodes[node];
-			int holder = -1; unsigned holder_node = 0, rank = 0;
-			for (int s = 0; s < 8; s++) if ((n.imask >> s) & 1) {
-				const unsigned child = n.base_index_child + rank++;
-				if (unsigned(hit) >= bvh.nodes[child].base_index_triangle && unsigned(hit) < triangles_end[child]) { holder = s; holder_node = child; }
-			}
-			if (holder < 0) return hit;   // the hit is in one of this node's own leaves
+			int holder = -1; unsigned rank = 0;
+			for (int s = 0; s < 8; s++) if ((n.imask >> s) & 1) { if (n.base_index_child + rank == holder_node) holder = s; rank++; }
+			if (holder < 0) return hit;
 			for (int s = 0; s < 8; s++) if (((n.imask >> s) & 1) && s != holder) {
 				float t_enter;
 				if (score_row[node] >= 0 && enters(r, child_box(n, s), r.tmax, t_enter) && t_enter >= t_hit) {
@@ -149,7 +156,6 @@ struct Learner {
 					score[((size_t(score_row[node]) * 8 + size_t(r.octant)) * 8 + size_t(s)) * 8 + size_t(holder)].fetch_add(std::min(work, 511u), std::memory_order_relaxed);
 				}
 			}
-			node = holder_node;
 		}
 		return hit;
 	}
@@ -253,8 +259,7 @@ void bvh8_learn_slot_order(BVH8 & bvh, const std::vector<Triangle> & triangles, 
 	Learner learner(bvh, triangles);
 	if (view && view->width > 0 && view->height > 0) learner.view = view;
 	if (const char * c = getenv("GRT_SLOT_LEARNING_UNWEIGHTED")) learner.weigh_by_work = atoi(c) == 0;
-	learner.triangles_end.assign(bvh.nodes.size(), 0u);
-	learner.subtree_end(0);
+	learner.index_leaves();
 	// 2 KB of counters per scored node, at most 1 GB of them: a tree of more than half a million nodes is scored down to the depth that fits (the levels every ray walks)
 	{
 		const size_t row_limit = (size_t(1) << 30) / 2048;

@@ -74,6 +74,7 @@ int grt_config_set(const char * key, double value) {
 	else if (k == "static_slot_learning_rays")           cpu_config.static_slot_learning_rays = int(value);
 	else if (k == "static_slot_learning_viewpoint")      cpu_config.static_slot_learning_viewpoint = int(value);
 	else if (k == "skip_behind_hit")                     cpu_config.skip_behind_hit = value != 0;
+	else if (k == "static_reseat_distance")              cpu_config.static_reseat_distance = float(value);
 	else if (k == "static_mesh_copy_limit_mb")           cpu_config.static_mesh_copy_limit_mb = int(value);
 	else if (k == "static_copy_budget_mb")               cpu_config.static_copy_budget_mb = int(value);
 	else if (k == "initial_width")                       cpu_config.initial_width = int(value);
@@ -352,6 +353,11 @@ int    grt_pathtracer_static_geometry_root(void * pt) { return as_integrator(pt)
 int    grt_pathtracer_static_geometry_top_nodes(void * pt) { Integrator * p = as_integrator(pt); return p->static_geometry.active ? p->static_geometry.top_nodes : 0; }
 // re-flattening when a member starts to move: 1 (default) builds the new tree on a worker thread while the frame loop renders in the
 // reference's layout, 0 rebuilds inside update(); how many such background builds have been installed; whether one is in progress
+// the seating of the flattened tree beside the frame loop (Integrator.h: PendingReseat)
+int    grt_pathtracer_reseats_completed(void * pt) { return as_integrator(pt)->reseats_completed; }
+int    grt_pathtracer_reseat_pending(void * pt) { return as_integrator(pt)->pending_reseat ? 1 : 0; }
+double grt_pathtracer_last_reseat_seconds(void * pt) { return as_integrator(pt)->last_reseat_seconds; }
+void   grt_pathtracer_set_reseat_asynchronously(void * pt, int enable) { as_integrator(pt)->reseat_asynchronously = enable != 0; }
 void grt_pathtracer_set_flatten_asynchronously(void * pt, int enable) { as_integrator(pt)->flatten_asynchronously = enable != 0; }
 int  grt_pathtracer_reflattens_completed(void * pt) { return as_integrator(pt)->reflattens_completed; }
 int  grt_pathtracer_reflatten_in_progress(void * pt) { Integrator * p = as_integrator(pt); return p->pending_flatten ? (p->pending_flatten->ready.load() ? 2 : 1) : 0; }

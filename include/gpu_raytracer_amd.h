@@ -146,7 +146,7 @@ const char * rt_version(void);
  *   7  rt_set_node_format (a 96-byte decoded copy of the node array) and rt_set_node_cache (the top of the flattened tree in LDS) REMOVED:
  *      both measured slower than the 80-byte walk on MI355X (profiles/r04_traversal_experiments.txt items 2 and 4) and were off by default;
  *      rt_set_build_boxes added
- *   8  rt_set_skip_behind_hit, rt_get_skip_behind_hit, rt_geometry_fits_flat_engine (additions only)
+ *   8  rt_set_skip_behind_hit, rt_get_skip_behind_hit, rt_geometry_fits_flat_engine, rt_update_nodes (additions only)
  * Check `rt_abi_version() == RT_ABI_VERSION` once after loading the library.                                          */
 #define RT_ABI_VERSION 8
 int rt_abi_version(void);
@@ -180,6 +180,10 @@ int rt_upload_triangle_aliases(rt_context * ctx, const int32_t * mesh_ids, const
  * (the state after every geometry upload): node 0 is a TLAS root, as in the reference (BVH8.h:161-165), and a flattened tree
  * is one of its leaves. Drains the context when the value changes. CWBVH traversal only.                              */
 int rt_set_static_geometry(rt_context * ctx, int32_t whole_scene);
+/* Replaces nodes [first_node, first_node + node_count) of the uploaded CWBVH node array (80 bytes each) in place, between frames: for a tree whose children were
+ * given other octant slots beside the frame loop (the host re-seats the flattened tree when the camera has travelled: Integrator.cpp, reseat worker). The
+ * caller keeps node count, boxes, leaves and every index as they were; the context is drained first (a ray's stack entries are only valid within one launch). */
+int rt_update_nodes(rt_context * ctx, const void * nodes, size_t first_node, size_t node_count);
 /* The walk of closest-hit rays through a one-tree scene (rt_set_static_geometry(ctx, 1)). The reference keeps the children of a node that a ray
  * enters but does not visit at once as ONE stack entry without a distance (BVH8.h:166-199) and therefore still walks into every one of them after a
  * hit in front of them has been found; it makes up for that with 32-lane warps and triangle postponing (BVH8.h:200,234-240). enable = 1 (the

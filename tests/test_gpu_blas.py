@@ -41,7 +41,7 @@ def check_blas(nodes, triangles, root, seen_triangles, is_reference=None):
     def visit(k):
         visited[0] += 1
         lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
-        inner_rank, expected_offset = 0, 0
+        inner_rank, leaf_runs = 0, []
         for s in range(8):
             m = int(meta[k, s])
             if m == 0:
@@ -55,9 +55,8 @@ def check_blas(nodes, triangles, root, seen_triangles, is_reference=None):
                 clo, chi = visit(child)
             else:
                 unary, offset = m >> 5, m & 31
-                assert unary in (1, 3, 7) and offset == expected_offset, (k, s, m, expected_offset)
-                count = {1: 1, 3: 2, 7: 3}[unary]; expected_offset += count
-                assert expected_offset <= 24
+                assert unary in (1, 3, 7), (k, s, m)
+                count = {1: 1, 3: 2, 7: 3}[unary]; leaf_runs.append((offset, count))
                 first = int(words[k, 5]) + offset
                 assert 0 <= first and first + count <= len(triangles)
                 seen_triangles[first:first + count] += 1
@@ -74,6 +73,13 @@ def check_blas(nodes, triangles, root, seen_triangles, is_reference=None):
             slack = 1e-5 * np.maximum(np.abs(clo), np.abs(chi)) + 1e-30
             assert (lo <= clo + slack).all() and (hi >= chi - slack).all(), (k, s, lo, clo, hi, chi)
             lo_all, hi_all = np.minimum(lo_all, clo), np.maximum(hi_all, chi)
+        # the leaves of a node share its 24 triangle bits without gaps or overlaps (the builder deals the offsets in slot order; the learned seating, which gives
+        # a node's children other slots afterwards, keeps every leaf's offset: the runs are checked sorted)
+        expected_offset = 0
+        for offset, count in sorted(leaf_runs):
+            assert offset == expected_offset, (k, leaf_runs)
+            expected_offset += count
+        assert expected_offset <= 24
         return lo_all, hi_all
 
     visit(root)
@@ -99,7 +105,7 @@ def test_device_built_trees_are_valid_and_trace_like_the_host_built_ones(grt, or
     w, h = 320, 180
     results = {}
     for device_blas in (1, 0):
-        scene, pt = make_pathtracer(grt, scene_name, w, h, 0, device_blas=device_blas)
+        scene, pt = make_pathtracer(grt, scene_name, w, h, 0, device_blas=device_blas)   # (the flattened tree of the device build: seated in the first update, like the host's)
         view = oracle.SceneView(pt)
         if device_blas:
             assert pt.device_blas_build_ms > 0.0
@@ -260,4 +266,28 @@ def test_device_build_on_awkward_meshes(grt, oracle, tmp_path):
     hit = b[:, 1] != 0xffffffff
     assert 0.05 < hit.mean() and np.array_equal(hit, a[:, 1] != 0xffffffff)
     assert np.array_equal(a[hit, 2], b[hit, 2])          # t bit for bit (which of 40 identical copies is hit is the tree's choice)
+    grt.config_reset()
+
+
+def test_a_device_built_flattened_tree_is_seated_like_a_host_built_one(grt, oracle):
+    """The device's collapse deals children to octant slots by centre, as the reference's does; the learned seating (host/SlotOrder.cpp) only needs a tree's nodes
+    and the triangles of its leaves: the flattened tree the device built is read back, seated for the camera and its nodes go back in place (rt_update_nodes) --
+    inside the integrator's first update(). Same hits as the unseated tree (t to the bit), fewer node steps; the device walks what the host view shows."""
+    w, h = 640, 360
+    results = {}
+    for name, config in (("seated", dict(device_blas=1)), ("unseated", dict(device_blas=1, static_slot_learning_rays=0))):
+        scene, pt = make_pathtracer(grt, "sponza", w, h, 0, **config)
+        assert pt.static_geometry_whole_scene and pt.device_blas_build_ms > 0.0
+        assert pt.reseats_completed == (1 if name == "seated" else 0) and not pt.reseat_pending
+        view = oracle.SceneView(pt)
+        o, d, _ = view.generate(0, 0, w * h)
+        hits, _ = grt.trace_rays(pt.ctx, o, d)
+        want, stats = view.trace(o, d)
+        assert np.array_equal(hits, want)                          # the device walks the tree the host view shows (the re-seated nodes went to both)
+        results[name] = (hits, stats.nodes / stats.rays)
+        pt.close(); scene.close()
+    a, b = results["seated"][0], results["unseated"][0]
+    assert np.array_equal(a[:, 2], b[:, 2])                        # the same distance for every ray, to the bit
+    assert (a[:, 1] != b[:, 1]).sum() <= 1e-3 * len(a)
+    assert results["seated"][1] < 0.97 * results["unseated"][1], (results["seated"][1], results["unseated"][1])
     grt.config_reset()

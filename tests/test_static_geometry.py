@@ -634,3 +634,60 @@ def test_the_skipping_walk_finds_the_reference_walks_hits_in_fewer_node_steps(gr
     scene, pt = make_pathtracer(grt, "sponza", 96, 54, -1, merge_static=0)
     assert not pt.skip_behind_hit
     pt.close(); scene.close(); grt.config_reset()
+
+
+FAR_VIEWPOINT = ((-129.707321, 17.916590, 43.054050), (0.011467, 0.408287, 0.005129, -0.912762))   # the reference's ninth Sponza point of view (Util/PerfTest.h:30-40): 138 units from where the scene's own camera stands
+
+
+def _node_steps_of_a_sample(oracle, pt):
+    oc = oracle.Frame(oracle.SceneView(pt)).render_sample(0)
+    return oc.trace_stats.nodes / oc.trace_stats.rays, oc.trace_stats.triangles / oc.trace_stats.rays
+
+
+def test_the_flattened_tree_is_seated_again_when_the_camera_has_travelled(grt, oracle):
+    """config static_reseat_distance (0.1 of the flattened geometry's diagonal): the seating of the tree's children is trained on paths from the camera as it
+    stood (static_slot_learning_viewpoint); when the camera has travelled further than that, a worker seats a copy of the tree for the new viewpoint beside the
+    frame loop and the nodes are swapped in between two frames (rt_update_nodes). What the re-seated tree costs the new viewpoint's rays is what a tree BUILT
+    for that viewpoint costs them, and less than the stale seating; boxes, leaves and triangles do not change, so hits cannot."""
+    import time
+    w, h = 320, 180
+    scene, pt = make_pathtracer(grt, "sponza", w, h, -1)
+    assert pt.static_geometry_whole_scene and pt.reseats_completed == 0
+    view = oracle.SceneView(pt); o, d = rays_for(view, w, h, 150.0, 40000, 9)
+    hits_before, _ = view.trace(o, d)
+    nodes_before = pt.array("bvh8_nodes").copy()
+    near = scene.get_camera()
+    scene.set_camera((near[0][0] + 20.0, near[0][1], near[0][2]), tuple(near[1])); pt.update()      # 20 units: not far enough
+    assert pt.reseats_completed == 0 and not pt.reseat_pending
+    scene.set_camera(*FAR_VIEWPOINT); pt.update()
+    assert pt.reseat_pending                                                                        # ... beside the frame loop: this update did not wait
+    deadline = time.time() + 120
+    while pt.reseats_completed == 0:
+        assert time.time() < deadline
+        time.sleep(0.05); pt.update()
+    assert pt.reseats_completed == 1 and not pt.reseat_pending and pt.last_reseat_seconds > 0.0
+    nodes_after = pt.array("bvh8_nodes")
+    assert nodes_after.size == nodes_before.size and (nodes_after != nodes_before).any()
+    root = pt.static_geometry_top_levels[0]
+    assert np.array_equal(pt.array("tlas_nodes").view(np.uint8).reshape(-1, 80)[0], nodes_after.view(np.uint8).reshape(-1, 80)[root])   # node 0, where rays start, is the re-seated root
+    view = oracle.SceneView(pt)
+    hits_after, _ = view.trace(o, d)
+    mesh_a, tri_a, t_a, _, _ = unpack_hits(hits_before); mesh_b, tri_b, t_b, _, _ = unpack_hits(hits_after)
+    assert np.array_equal(t_a.view(np.uint32), t_b.view(np.uint32)) and (tri_a != tri_b).sum() <= 1e-3 * tri_a.size
+    reseated = _node_steps_of_a_sample(oracle, pt)
+    pt.update(); assert pt.reseats_completed == 1                                                   # seated for where the camera stands: nothing more to do
+    pt.close(); scene.close()
+    # a tree built for the far viewpoint from the start
+    grt.config_reset()
+    scene = grt.Scene(grt.scene_path("sponza")); scene.set_camera(*FAR_VIEWPOINT)
+    pt = grt.Pathtracer(scene, w, h, device=-1); pt.update()
+    fresh = _node_steps_of_a_sample(oracle, pt)
+    pt.close(); scene.close()
+    # ... and the seating left as it was (static_reseat_distance 0)
+    scene, pt = make_pathtracer(grt, "sponza", w, h, -1, static_reseat_distance=0)
+    scene.set_camera(*FAR_VIEWPOINT); pt.update(); pt.update()
+    assert pt.reseats_completed == 0 and not pt.reseat_pending
+    stale = _node_steps_of_a_sample(oracle, pt)
+    pt.close(); scene.close(); grt.config_reset()
+    assert abs(reseated[0] - fresh[0]) <= 0.01 * fresh[0], (reseated, fresh)
+    assert reseated[0] < 0.98 * stale[0] and reseated[1] < stale[1], (reseated, stale)

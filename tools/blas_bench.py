@@ -18,9 +18,12 @@ def main():
     lib = grt.device_lib()
     lib.rt_render_samples.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     presplits = [float(v) for v in os.environ.get("DEVICE_PRESPLIT", "0.05").split(",")]   # early split clipping in front of the device build (config device_presplit; 0: off)
-    for device_blas, presplit in [(0, 0.0)] + [(1, v) for v in presplits]:
+    # (device trees twice: as the device's collapse leaves them, and seated by the slot learner in the integrator's first update -- round 6)
+    for device_blas, presplit, seating in [(0, 0.0, 1)] + [(1, v, s) for v in presplits for s in (0, 1)]:
         scene = bench.build_scene(grt)
         grt.config_set(device_blas=device_blas, device_presplit=presplit, merge_static=int(os.environ.get("MERGE_STATIC", "1")))   # (MERGE_STATIC=0: one tree per mesh under the TLAS, the reference's layout)
+        if not seating:
+            grt.config_set(static_slot_learning_rays=0)
         t0 = time.perf_counter()
         pt = grt.Pathtracer(scene, bench.WIDTH, bench.HEIGHT, device=0); pt.update()
         setup_s = time.perf_counter() - t0
@@ -38,8 +41,8 @@ def main():
         grt.set_trace_statistics(ctx, True)
         lib.rt_render_samples(ctx, 0, 1); stats = grt.get_trace_statistics(ctx); c = pt.counters()
         rays = sum(c.trace[:bench.NUM_BOUNCES])
-        print("device_blas=%d presplit=%.3f (%d triangle copies): host BVH build %.1f ms (all meshes, worker threads), device build %.3f ms, %d nodes, integrator set-up %.2f s | %.3f ms per step, %.2f nodes and %.2f triangles per closest-hit ray"
-              % (device_blas, presplit, int((pt.array("alias_mesh_ids") >= 0).sum()), scene.bvh_build_ms, pt.device_blas_build_ms, nodes, setup_s, ms, stats["closest"]["nodes"] / max(rays, 1), stats["closest"]["triangles"] / max(rays, 1)), flush=True)
+        print("device_blas=%d presplit=%.3f seated=%d (%.2f s) (%d triangle copies): host BVH build %.1f ms (all meshes, worker threads), device build %.3f ms, %d nodes, integrator set-up %.2f s | %.3f ms per step, %.2f nodes and %.2f triangles per closest-hit ray"
+              % (device_blas, presplit, seating, pt.last_reseat_seconds, int((pt.array("alias_mesh_ids") >= 0).sum()), scene.bvh_build_ms, pt.device_blas_build_ms, nodes, setup_s, ms, stats["closest"]["nodes"] / max(rays, 1), stats["closest"]["triangles"] / max(rays, 1)), flush=True)
         pt.close(); scene.close()
 
 
