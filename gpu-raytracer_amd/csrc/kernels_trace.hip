@@ -1395,6 +1395,7 @@ static int trace_grid_size(const void * kernel) {
 	int blocks_per_cu = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, RT_TRACE_BLOCK, 0) != hipSuccess || blocks_per_cu <= 0) blocks_per_cu = 2;
 	if (blocks_per_cu > 8) blocks_per_cu = 8;
+	if (const char * e = getenv("GRT_TRACE_BLOCKS_PER_CU")) { int n = atoi(e); if (n >= 1 && n <= 16) blocks_per_cu = n; }   // (experiments: profiles/r06_occupancy.txt)
 	return cus * blocks_per_cu;
 }
 
