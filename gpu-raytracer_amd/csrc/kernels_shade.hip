@@ -141,7 +141,11 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate_stream(RtParam
 // Bookkeeping between the iterations of the merged wavefront, one thread: the generated rays are counted in, the
 // queues this iteration appends to start empty, the cursors of its trace launch are reset, and the host gets the
 // size of the wavefront (it bounds what is in flight with it before admitting the next submission).
-__global__ void kernel_stream_advance(RtStreamControl * control, int iteration, int generated, volatile int * progress) {
+// ... and the statistics rows of the submissions that join with this iteration start at zero (reset_ring_count rows from reset_ring_first, modulo the ring).
+__global__ void __launch_bounds__(256) kernel_stream_advance(RtStreamControl * control, int iteration, int generated, volatile int * progress, int reset_ring_first, int reset_ring_count) {
+	for (int k = int(threadIdx.x); k < reset_ring_count * RT_STAT_KINDS * RT_MAX_BOUNCES; k += int(blockDim.x))
+		(&control->stats[(reset_ring_first + k / (RT_STAT_KINDS * RT_MAX_BOUNCES)) % RT_STREAM_SUBMISSIONS][0][0])[k % (RT_STAT_KINDS * RT_MAX_BOUNCES)] = 0;
+	if (threadIdx.x != 0) return;
 	const int q = iteration & 1;
 	int total = control->trace_count[q] + generated;
 	control->trace_count[q] = total;
@@ -1189,8 +1193,8 @@ void rt_launch_material(const RtParams & p, int material_slot, int bounce, int s
 void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, int slot_base, int queue_offset, hipStream_t stream) {
 	hipLaunchKernelGGL(kernel_generate_stream, dim3(streaming_grid(pixel_count * p.batch_samples)), dim3(RT_SHADE_BLOCK), 0, stream, p, sample_index, pixel_offset, pixel_count, slot_base, queue_offset);
 }
-void rt_launch_stream_advance(RtStreamControl * control, int iteration, int generated, int * progress, hipStream_t stream) {
-	hipLaunchKernelGGL(kernel_stream_advance, dim3(1), dim3(1), 0, stream, control, iteration, generated, (volatile int *)progress);
+void rt_launch_stream_advance(RtStreamControl * control, int iteration, int generated, int * progress, int reset_ring_first, int reset_ring_count, hipStream_t stream) {
+	hipLaunchKernelGGL(kernel_stream_advance, dim3(1), dim3(reset_ring_count > 0 ? 256 : 1), 0, stream, control, iteration, generated, (volatile int *)progress, reset_ring_first, reset_ring_count);
 }
 #ifndef RT_STREAM_SHADE_GRID
 #define RT_STREAM_SHADE_GRID 8192   // workgroups of the grid-stride shade launches of the merged wavefront: 2 048 (two rounds of
