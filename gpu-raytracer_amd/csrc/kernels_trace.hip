@@ -5,7 +5,7 @@
 // octant-ordered traversal of 80-byte compressed 8-wide nodes, TLAS -> BLAS instancing with
 // un-normalised object-space rays, Moeller-Trumbore on pre-subtracted edges -- re-designed
 // for CDNA4:
-//   * persistent 64-lane waves claim rays in blocks of 64..128 with ONE returning atomic per
+//   * persistent 64-lane waves claim rays in blocks of 64..256 with ONE returning atomic per
 //     block and deal them to their lanes as they go idle (ballot + mbcnt prefix rank), instead
 //     of one atomicAdd per lane;
 //   * per round a lane does one node step and then at most one batch of RT_TRI_BATCH triangle
@@ -48,7 +48,14 @@
 #define RT_TRI_BATCH 2           // triangles whose loads are issued together
 #endif
 #ifndef RT_FETCH_BLOCK_MAX
-#define RT_FETCH_BLOCK_MAX 128   // rays claimed per cursor atomic; measured 64..1024, see profiles/r01_trace_fetch_block.txt
+#define RT_FETCH_BLOCK_MAX 256   // most rays claimed per cursor atomic. Rounds 1-5: 128 (launches of 8-16 M rays: profiles/r01_trace_fetch_block.txt, r04 run 13). With a burst's 40-80 M-ray
+                                 // launches the shared cursor is the busiest word of the chip (633 K same-word atomics in a 10 ms launch at ~88 per us): 256 is -5 % traversal on every
+                                 // workload measured in round 6 (profiles/r06_ray_blocks.txt)
+#endif
+// (Guided self-scheduling -- a claim takes (rays left) / (D x waves), large blocks first, small ones at the queue's end -- was built and measured in round 6: worse at every D
+// (0.864 ... 1.016 ms per step against 0.850): what a block size buys is not fewer atomics or a shorter tail but lanes that hold NEIGHBOURS of the queue; profiles/r06_ray_blocks.txt.)
+#ifndef RT_FETCH_BLOCK_DIVISOR
+#define RT_FETCH_BLOCK_DIVISOR 2   // a launch's block size: rays / (this x waves of the grid), between 64 and RT_FETCH_BLOCK_MAX
 #endif
 // Measured and not kept (profiles/r03_variants_at_20_steps.txt, profiles/r04_shadow_rays.txt, profiles/r04_traversal_experiments.txt; the code is gone, the
 // numbers are there): holding the triangle phase back until 8 / 16 lanes want it (+-0), shadow rays taking a node's children far end first (-6.8 % node
@@ -489,7 +496,7 @@ struct TraversalStack {
 // per-wave ray-claim words. File scope, so that the wide and the narrow instantiation of the CWBVH
 // engine inside one kernel share ONE allocation.
 __shared__ uint2 shared_stack[(RT_TRACE_BLOCK / RT_WAVE_SIZE) * RT_LDS_STACK * RT_WAVE_SIZE];
-__shared__ int   shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4]; // per wave: next, end, drained
+__shared__ int   shared_fetch[RT_TRACE_BLOCK / RT_WAVE_SIZE][4]; // per wave: next, end, drained, which queue
 // The fused launch of the merged wavefront: BLAS root (| identity flag) of every instance of a small scene. A ray enters ~8
 // instances on Sponza, and the root index was a dependent global load (TLAS leaf -> root index -> root node) with a full
 // wait behind it in the middle of a round; from LDS it costs a fraction of that latency.
@@ -539,11 +546,11 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 	stack.spill = (GlobalUint2 *)(p.stack_spill + (blockIdx.x * blockDim.x + threadIdx.x));
 	stack.size  = 0;
 
-	// Rays per cursor atomic: up to 128 for big launches, 64 for small ones so that every wave gets work
+	// Rays per cursor atomic: up to RT_FETCH_BLOCK_MAX for big launches, 64 for small ones so that every wave gets work
 	// (narrow mode: 8, one ray per 8-lane group).
 	const int waves_in_grid = int(gridDim.x) * (RT_TRACE_BLOCK / RT_WAVE_SIZE);
 	const int rays_total = ray_count + (MODE == RT_TRACE_MIXED ? ray_count_2 : 0);
-	const int ray_block = NARROW ? 8 : max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (rays_total / (2 * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
+	const int ray_block = NARROW ? 8 : max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (rays_total / (RT_FETCH_BLOCK_DIVISOR * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
 	// Only as many waves as there are blocks take part; the rest of the (machine-sized) persistent
 	// grid leaves without touching the shared cursor.
 	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * unsigned(ray_block) >= unsigned(rays_total)) return;
