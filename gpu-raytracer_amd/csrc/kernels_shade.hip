@@ -116,7 +116,12 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate(RtParams p, in
 // whatever the previous iteration's sort / shade kernels appended (kernel_stream_advance adds the count afterwards).
 // Sample s of the submission renders into sample slot slot_base + s.
 // `queue_offset`: rays generated by earlier submissions of the same iteration (several small submissions can enter together).
-__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate_stream(RtParams p, int sample_index, int pixel_offset, int pixel_count, int slot_base, int queue_offset) {
+// `block_width` / `band_rows` (0: scan lines, the reference's order): the ORDER of a sample's primary rays in the queue. A pixel's ray does not
+// depend on its place in the queue (the random numbers are keyed on the pixel index), but the traversal launch deals
+// consecutive rays to the lanes of one wave and the sort / shade kernels keep neighbours together: the frame is walked in bands of
+// `band_rows` scan lines, a band in blocks of `block_width` columns, a block row by row -- 64 consecutive rays cover an 8 x 8 patch
+// of the screen instead of a 64 x 1 strip. The host asks for it only when the pixel list is made of whole bands (rt_api.hip: stream_generate).
+__global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate_stream(RtParams p, int sample_index, int pixel_offset, int pixel_count, int slot_base, int queue_offset, int block_width, int band_rows) {
 	const int ray_count = pixel_count * p.batch_samples;
 	const RtTraceBuffer & out = p.trace[p.stream_iteration & 1];
 	const int base = p.stream->trace_count[p.stream_iteration & 1] + queue_offset;
@@ -125,6 +130,16 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate_stream(RtParam
 		int index_offset = rt_map_pixel(p, index - sample_in_batch * pixel_count + pixel_offset);
 		int x = index_offset % p.screen_width;
 		int y = index_offset / p.screen_width;
+		if (band_rows > 0) {
+			int band = y / band_rows;
+			int rows = min(band_rows, p.screen_height - band * band_rows);   // the last band may be lower
+			int in_band = index_offset - band * band_rows * p.screen_width;
+			int block = in_band / (block_width * rows);
+			int in_block = in_band - block * block_width * rows;
+			int columns = min(block_width, p.screen_width - block * block_width); // the last block may be narrower
+			x = block * block_width + in_block % columns;
+			y = band * band_rows + in_block / columns;
+		}
 		int pixel_index = x + y * p.screen_pitch;
 		unsigned slot = unsigned(slot_base + sample_in_batch);
 		unsigned virtual_pixel = slot * p.frame_pixels + unsigned(pixel_index);
@@ -1190,8 +1205,8 @@ void rt_launch_material(const RtParams & p, int material_slot, int bounce, int s
 		case 3: hipLaunchKernelGGL(kernel_material_conductor,  grid, block, 0, stream, p, bounce, sample_index); break;
 	}
 }
-void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, int slot_base, int queue_offset, hipStream_t stream) {
-	hipLaunchKernelGGL(kernel_generate_stream, dim3(streaming_grid(pixel_count * p.batch_samples)), dim3(RT_SHADE_BLOCK), 0, stream, p, sample_index, pixel_offset, pixel_count, slot_base, queue_offset);
+void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, int slot_base, int queue_offset, int block_width, int band_rows, hipStream_t stream) {
+	hipLaunchKernelGGL(kernel_generate_stream, dim3(streaming_grid(pixel_count * p.batch_samples)), dim3(RT_SHADE_BLOCK), 0, stream, p, sample_index, pixel_offset, pixel_count, slot_base, queue_offset, block_width, band_rows);
 }
 void rt_launch_stream_advance(RtStreamControl * control, int iteration, int generated, int * progress, int reset_ring_first, int reset_ring_count, hipStream_t stream) {
 	hipLaunchKernelGGL(kernel_stream_advance, dim3(1), dim3(reset_ring_count > 0 ? 256 : 1), 0, stream, control, iteration, generated, (volatile int *)progress, reset_ring_first, reset_ring_count);

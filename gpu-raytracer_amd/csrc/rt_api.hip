@@ -2001,7 +2001,13 @@ static int stream_generate(rt_context * ctx, const StreamSubmission & sub) {
 	RT_HIP(ctx, hipEventRecord(s.ev_begin[sub.ring], st));
 	stage_mark(ctx, STAGE_GENERATE, st);
 	span_mark(ctx, SPAN_GENERATE, st);
-	rt_launch_generate_stream(pg, sub.first_sample, sub.range_offset, sub.range_count, sub.slot_base, int(s.pending_paths), st);
+	// Queue order of the primary rays: 8 x 8 pixel patches along bands of 8 scan lines when the submission's pixel list is made of whole bands
+	// (the whole frame, or tiles of whole bands: rt_map_pixel keeps a band together); scan lines otherwise. GRT_PRIMARY_ORDER=WxH / 0 for A / B runs.
+	static const int order_width = [] { const char * e = getenv("GRT_PRIMARY_ORDER"); return e ? atoi(e) : 8; }();
+	static const int order_rows  = [] { const char * e = getenv("GRT_PRIMARY_ORDER"); const char * x = e ? strchr(e, 'x') : nullptr; return e ? (x ? atoi(x + 1) : atoi(e)) : 8; }();
+	const int frame = pg.screen_width * pg.screen_height;
+	const bool whole_bands = order_width > 0 && order_rows > 0 && (sub.tile_pixels > 0 ? sub.tile_pixels % (order_rows * pg.screen_width) == 0 : (sub.range_offset == 0 && sub.range_count == frame));
+	rt_launch_generate_stream(pg, sub.first_sample, sub.range_offset, sub.range_count, sub.slot_base, int(s.pending_paths), whole_bands ? order_width : 0, whole_bands ? order_rows : 0, st);
 	span_mark(ctx, SPAN_GENERATE, st);
 	s.pending++; s.pending_paths += sub.paths;
 	return RT_OK;

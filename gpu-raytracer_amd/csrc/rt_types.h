@@ -246,7 +246,7 @@ void rt_launch_generate(const RtParams & p, int sample_index, int pixel_offset, 
 void rt_launch_expand_bc1(const uint2 * blocks, uchar4 * texels, size_t block_count, hipStream_t stream);
 void rt_launch_trace(const RtParams & p, int bounce, hipStream_t stream);
 // merged wavefront (the iteration is p.stream_iteration); stats: null, or 10 x u64 as for the counting variants below
-void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, int slot_base, int queue_offset, hipStream_t stream);
+void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_offset, int pixel_count, int slot_base, int queue_offset, int block_width, int band_rows, hipStream_t stream);
 void rt_launch_stream_advance(RtStreamControl * control, int iteration, int generated, int * progress, int reset_ring_first, int reset_ring_count, hipStream_t stream);
 void rt_launch_trace_stream(const RtParams & p, unsigned long long * stats, hipStream_t stream);
 void rt_launch_sort_stream(const RtParams & p, hipStream_t stream);
