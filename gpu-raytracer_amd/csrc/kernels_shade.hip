@@ -160,8 +160,9 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate_stream(RtParam
 __global__ void __launch_bounds__(256) kernel_stream_advance(RtStreamControl * control, int iteration, int generated, volatile int * progress, int reset_ring_first, int reset_ring_count) {
 	for (int k = int(threadIdx.x); k < reset_ring_count * RT_STAT_KINDS * RT_MAX_BOUNCES; k += int(blockDim.x))
 		(&control->stats[(reset_ring_first + k / (RT_STAT_KINDS * RT_MAX_BOUNCES)) % RT_STREAM_SUBMISSIONS][0][0])[k % (RT_STAT_KINDS * RT_MAX_BOUNCES)] = 0;
-	if (threadIdx.x != 0) return;
 	const int q = iteration & 1;
+	for (int k = int(threadIdx.x); k < 2 * RT_ENDGAME_MAX_WAVES; k += int(blockDim.x)) (&control->endgame[q][0][0])[k] = 0;   // the region cursors of this iteration's traversal launch
+	if (threadIdx.x != 0) return;
 	int total = control->trace_count[q] + generated;
 	control->trace_count[q] = total;
 	control->trace_count[q ^ 1] = 0;
@@ -1209,7 +1210,7 @@ void rt_launch_generate_stream(const RtParams & p, int sample_index, int pixel_o
 	hipLaunchKernelGGL(kernel_generate_stream, dim3(streaming_grid(pixel_count * p.batch_samples)), dim3(RT_SHADE_BLOCK), 0, stream, p, sample_index, pixel_offset, pixel_count, slot_base, queue_offset, block_width, band_rows);
 }
 void rt_launch_stream_advance(RtStreamControl * control, int iteration, int generated, int * progress, int reset_ring_first, int reset_ring_count, hipStream_t stream) {
-	hipLaunchKernelGGL(kernel_stream_advance, dim3(1), dim3(reset_ring_count > 0 ? 256 : 1), 0, stream, control, iteration, generated, (volatile int *)progress, reset_ring_first, reset_ring_count);
+	hipLaunchKernelGGL(kernel_stream_advance, dim3(1), dim3(256), 0, stream, control, iteration, generated, (volatile int *)progress, reset_ring_first, reset_ring_count);
 }
 #ifndef RT_STREAM_SHADE_GRID
 #define RT_STREAM_SHADE_GRID 8192   // workgroups of the grid-stride shade launches of the merged wavefront: 2 048 (two rounds of

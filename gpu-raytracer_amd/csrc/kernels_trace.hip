@@ -54,6 +54,12 @@
 #endif
 // (Guided self-scheduling -- a claim takes (rays left) / (D x waves), large blocks first, small ones at the queue's end -- was built and measured in round 6: worse at every D
 // (0.864 ... 1.016 ms per step against 0.850): what a block size buys is not fewer atomics or a shorter tail but lanes that hold NEIGHBOURS of the queue; profiles/r06_ray_blocks.txt.)
+#ifndef RT_ENDGAME
+#define RT_ENDGAME 1   // the merged wavefront's launches deal the end of a queue in per-wave regions (bvh8_trace_engine: `regions`); 0: the shared cursor to the last ray
+#endif
+#ifndef RT_ENDGAME_SCAN_LIMIT
+#define RT_ENDGAME_SCAN_LIMIT 2     // looks (one load per asking lane, spread over the ring of regions) a wave takes, after the region it worked on is finished, before it concludes that there is nothing left to help with
+#endif
 #ifndef RT_FETCH_BLOCK_DIVISOR
 #define RT_FETCH_BLOCK_DIVISOR 2   // a launch's block size: rays / (this x waves of the grid), between 64 and RT_FETCH_BLOCK_MAX
 #endif
@@ -528,7 +534,7 @@ template<int MODE, typename Source> RT_DEV void source_finish(const Source & src
 // SKIP: "skip behind the hit" (above; rt_set_skip_behind_hit) -- only for scenes that are ONE tree (p.entry_tlas_stack_size == 0): a stack entry
 // is then always a group of inner children of that tree.
 template<int MODE, bool COUNT, bool NARROW, bool UNIFIED = false, bool FLAT = false, bool SKIP = false, typename Source>
-RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr, int ray_count_2 = 0, int * cursor_2 = nullptr) {
+RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, int * xcd_counters, unsigned long long * stats = nullptr, int ray_count_2 = 0, int * cursor_2 = nullptr, int * regions = nullptr) {
 	constexpr bool SHADOW = MODE == RT_TRACE_SHADOW;   // the kind of every ray, unless MODE == RT_TRACE_MIXED: then lane_shadow
 	bool lane_shadow = SHADOW;
 	#define RT_IS_SHADOW (MODE == RT_TRACE_MIXED ? lane_shadow : SHADOW)
@@ -550,10 +556,22 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 	// (narrow mode: 8, one ray per 8-lane group).
 	const int waves_in_grid = int(gridDim.x) * (RT_TRACE_BLOCK / RT_WAVE_SIZE);
 	const int rays_total = ray_count + (MODE == RT_TRACE_MIXED ? ray_count_2 : 0);
-	const int ray_block = NARROW ? 8 : max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (rays_total / (RT_FETCH_BLOCK_DIVISOR * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
-	// Only as many waves as there are blocks take part; the rest of the (machine-sized) persistent
+	// The END of a queue (`regions`: the merged wavefront's launches, round 6). With blocks of 256 rays a wave's exit is quantised by whole blocks -- a rank's launch of 5 M rays is 3.3
+	// blocks per wave: the waves left between 0.56 and 1.0 of the launch's duration, 28 % of the wave slots x time stood empty (tools/wave_clock_probe.py, profiles/r06_endgame.txt) --
+	// and smaller blocks from the shared cursor cost what blocks are for: lanes that hold NEIGHBOURS of the queue (profiles/r06_ray_blocks.txt). So the last `region_size` x waves
+	// rays of a queue are not dealt by the shared cursor: wave w owns region w, takes it in pieces of 64 rays with an atomic on the region's own word (no same-word contention,
+	// consecutive claims are neighbours), and a wave that has finished its region helps with the regions behind it, 64 rays at a time, until none is left. A mixed launch deals
+	// its two queues as ONE (closest-hit rays first; the kind of a ray is where its index falls).
+	const bool endgame = !NARROW && regions != nullptr && waves_in_grid <= RT_ENDGAME_MAX_WAVES;
+	const int ray_block = NARROW ? 8 : endgame ? RT_FETCH_BLOCK_MAX : max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (rays_total / (RT_FETCH_BLOCK_DIVISOR * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
+	const int region_size  = max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, ((rays_total + waves_in_grid - 1) / waves_in_grid + RT_WAVE_SIZE - 1) & ~(RT_WAVE_SIZE - 1)));
+	const int region_count = min(waves_in_grid, (rays_total + region_size - 1) / region_size);
+	const int main_limit   = endgame ? max(0, rays_total - region_count * region_size) : 0;   // the shared cursor deals [0, main_limit) in blocks, the regions the rest
+	const int region_stride = max(1, region_count / RT_WAVE_SIZE) | 1;   // a scan's candidates: every region_stride-th region behind the one just finished
+	const unsigned wave_in_grid = blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave;
+	// Only as many waves as there are blocks (regions) take part; the rest of the (machine-sized) persistent
 	// grid leaves without touching the shared cursor.
-	if ((blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + wave) * unsigned(ray_block) >= unsigned(rays_total)) return;
+	if (endgame ? wave_in_grid >= unsigned(region_count) : wave_in_grid * unsigned(ray_block) >= unsigned(rays_total)) return;
 	// volatile: the words are written by one lane and read by OTHER lanes of the same wave with no
 	// barrier in between; without it the compiler forwards a lane's own last view of them.
 	typedef volatile __attribute__((address_space(3))) int LdsFetchWord; // typed: ds_read/ds_write, not FLAT
@@ -564,6 +582,61 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 	// Mixed launches: fetch_state[3] says which queue the wave is claiming from (0: closest hit, 1: shadow); a wave moves on
 	// to the shadow queue when a claim on the first comes back empty, and the lanes served in one round all get that kind.
 	auto fetch_ray = [&]() -> int {
+		while (endgame) {
+			if (fetch_state[2]) return -1;
+			unsigned long long want = __ballot(1);
+			int n_want = __popcll(want);
+			unsigned rank = __builtin_amdgcn_mbcnt_hi(unsigned(want >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(want), 0u));
+			bool elected = rank == 0;
+			int next = fetch_state[0], end = fetch_state[1];
+			if (next >= end) { // the same for every lane of the ballot
+				int region = fetch_state[3];   // 0: this wave still takes blocks from the shared cursor; r + 1: it works on region r
+				if (region == 0) {
+					int base = main_limit;
+					if (main_limit > 0) { if (elected) base = atomicAdd(xcd_counters, ray_block); base = __builtin_amdgcn_readfirstlane(base); }
+					if (base < main_limit) { next = base; end = min(base + ray_block, main_limit); }
+					else region = int(wave_in_grid) + 1;
+				}
+				if (region != 0) {
+					next = 0; end = 0;
+					int scan_from = region, scanned = 0;   // (region index + 1: the first region behind this one)
+					while (true) {
+						int taken = 0;
+						if (elected) taken = atomicAdd(&regions[region - 1], RT_WAVE_SIZE);
+						taken = __builtin_amdgcn_readfirstlane(taken);
+						int first = main_limit + (region - 1) * region_size + taken;
+						if (taken < region_size && first < rays_total) { next = first; end = min(first + RT_WAVE_SIZE, rays_total); break; }
+						// this region is finished: look at the regions behind it, as many at a time as lanes are asking, for one that is not (a look past the L1: the words are other waves' cursors)
+						// (a scan stalls the lanes of this wave that are in the middle of a ray: at most RT_ENDGAME_SCAN_LIMIT of them per refill, each a sample of the whole ring)
+						bool found = false;
+						while (!found && scanned < RT_ENDGAME_SCAN_LIMIT) {
+							int candidate = int((unsigned(scan_from) + (rank + 1u) * unsigned(region_stride)) % unsigned(region_count));
+							int seen = __hip_atomic_load(&regions[candidate], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							bool open = seen < region_size && main_limit + candidate * region_size + seen < rays_total;
+							unsigned long long open_lanes = __ballot(open);
+							if (open_lanes) {
+								int lane_of_first = __ffsll((long long)open_lanes) - 1;
+								region = __builtin_amdgcn_readlane(candidate, lane_of_first) + 1; found = true;
+							} else { scan_from = (scan_from + 1) % region_count; scanned++; }
+						}
+						if (!found) break;   // nothing left that this wave could help with
+					}
+				}
+				if (elected) fetch_state[3] = region;
+			}
+			int give = min(n_want, end - next);
+			if (elected) {
+				fetch_state[0] = next + give;
+				fetch_state[1] = end;
+				if (next >= end) fetch_state[2] = 1;   // drained
+			}
+			if (int(rank) < give) {
+				int index = next + int(rank);
+				if (MODE == RT_TRACE_MIXED) { lane_shadow = index >= ray_count; if (lane_shadow) index -= ray_count; }
+				return index;
+			}
+			// the piece did not cover every lane: the rest goes round again
+		}
 		while (true) {
 			if (fetch_state[2]) return -1;
 			const bool second_queue = MODE == RT_TRACE_MIXED && fetch_state[3] != 0;
@@ -1338,8 +1411,41 @@ struct MixedStreamSource {
 	RT_DEV void load(bool is_shadow, int i, Ray3 & ray, float & max_distance) const { if (is_shadow) shadow.load(i, ray, max_distance); else closest.load(i, ray, max_distance); }
 	RT_DEV void finish(bool is_shadow, int i, const HitRecord & hit, bool occluded) const { if (is_shadow) shadow.finish(i, hit, occluded); else closest.finish(i, hit, occluded); }
 };
+#ifdef RT_WAVE_CLOCK
+// Probe build (tools/build_trace_variant.sh waveclock "-DRT_WAVE_CLOCK=1"; tools/wave_clock_probe.py): every wave of the merged wavefront's traversal launch leaves the
+// constant-rate clock (100 MHz) at which it started, left the closest-hit engine and left the launch -- the drain of a persistent launch, wave by wave.
+#define RT_WAVE_CLOCK_SLOTS 32
+#define RT_WAVE_CLOCK_WAVES 16384
+__device__ unsigned long long grt_wave_clock[RT_WAVE_CLOCK_SLOTS][RT_WAVE_CLOCK_WAVES][3];
+__device__ int grt_wave_clock_meta[RT_WAVE_CLOCK_SLOTS][4];   // iteration, closest-hit rays, shadow rays, waves of the grid
+extern "C" int rt_debug_read_wave_clock(void * clocks, void * meta) {
+	if (hipMemcpyFromSymbol(clocks, HIP_SYMBOL(grt_wave_clock), sizeof(grt_wave_clock)) != hipSuccess) return 1;
+	return hipMemcpyFromSymbol(meta, HIP_SYMBOL(grt_wave_clock_meta), sizeof(grt_wave_clock_meta)) != hipSuccess;
+}
+template<bool COUNT, bool FLAT = false, bool SKIP = false> RT_DEV void trace_stream_probed(const RtParams & p, unsigned long long * stats, unsigned long long * mid);
 template<bool COUNT, bool FLAT = false, bool SKIP = false>
 RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
+	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+	unsigned long long t1 = 0;
+	trace_stream_probed<COUNT, FLAT, SKIP>(p, stats, &t1);
+	const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+	if ((threadIdx.x & 63) == 0) {
+		const int slot = p.stream_iteration % RT_WAVE_CLOCK_SLOTS, wave = blockIdx.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE) + threadIdx.x / RT_WAVE_SIZE;
+		if (wave < RT_WAVE_CLOCK_WAVES) { grt_wave_clock[slot][wave][0] = t0; grt_wave_clock[slot][wave][1] = t1 ? t1 : t2; grt_wave_clock[slot][wave][2] = t2; }
+		if (wave == 0) { const int q = p.stream_iteration & 1; grt_wave_clock_meta[slot][0] = p.stream_iteration; grt_wave_clock_meta[slot][1] = p.stream->trace_count[q]; grt_wave_clock_meta[slot][2] = p.stream->shadow_count[q ^ 1]; grt_wave_clock_meta[slot][3] = gridDim.x * (RT_TRACE_BLOCK / RT_WAVE_SIZE); }
+	}
+}
+#define trace_stream_body trace_stream_probed
+#define RT_WAVE_CLOCK_MID , unsigned long long * mid
+#define RT_WAVE_CLOCK_MARK *mid = __builtin_amdgcn_s_memrealtime();
+#else
+template<bool COUNT, bool FLAT = false, bool SKIP = false> RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats);
+#define trace_stream_body trace_stream
+#define RT_WAVE_CLOCK_MID
+#define RT_WAVE_CLOCK_MARK
+#endif
+template<bool COUNT, bool FLAT, bool SKIP>
+RT_DEV void trace_stream_body(const RtParams & p, unsigned long long * stats RT_WAVE_CLOCK_MID) {
 	const int q = p.stream_iteration & 1;
 	MixedStreamSource src { { p.trace[q].origin, p.trace[q].direction, p.trace[q].hits },
 	                        { p.shadow, p.aovs[RT_AOV_RADIANCE], p.aovs[RT_AOV_RADIANCE_DIRECT], p.aovs[RT_AOV_RADIANCE_INDIRECT] } };
@@ -1359,10 +1465,11 @@ RT_DEV void trace_stream(const RtParams & p, unsigned long long * stats) {
 	if (!COUNT && closest_count + shadow_count <= RT_NARROW_MAX_RAYS)
 		bvh8_trace_engine<RT_TRACE_MIXED, false, true, true, FLAT, SKIP>(p, src, closest_count, &p.stream->cursor[q][0], nullptr, shadow_count, &p.stream->cursor[q][1]);
 	else if (COUNT || closest_count + shadow_count <= RT_MIXED_MAX_RAYS)
-		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true, FLAT, SKIP>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1]);
+		bvh8_trace_engine<RT_TRACE_MIXED, COUNT, false, true, FLAT, SKIP>(p, src, closest_count, &p.stream->cursor[q][0], stats, shadow_count, &p.stream->cursor[q][1], RT_ENDGAME ? &p.stream->endgame[q][0][0] : nullptr);
 	else {
-		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true, FLAT, SKIP>(p, src.closest, closest_count, &p.stream->cursor[q][0]);
-		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true, FLAT>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1]);   // (a shadow ray's limit never moves: nothing to skip)
+		bvh8_trace_engine<RT_TRACE_CLOSEST, false, false, true, FLAT, SKIP>(p, src.closest, closest_count, &p.stream->cursor[q][0], nullptr, 0, nullptr, RT_ENDGAME ? &p.stream->endgame[q][0][0] : nullptr);
+		RT_WAVE_CLOCK_MARK
+		bvh8_trace_engine<RT_TRACE_SHADOW,  false, false, true, FLAT>(p, src.shadow,  shadow_count,  &p.stream->cursor[q][1], nullptr, 0, nullptr, RT_ENDGAME ? &p.stream->endgame[q][1][0] : nullptr);   // (a shadow ray's limit never moves: nothing to skip)
 	}
 }
 __global__ void __launch_bounds__(RT_TRACE_BLOCK, RT_TRACE_LAUNCH_WAVES) kernel_trace_stream_bvh8(RtParams p) { trace_stream<false>(p, nullptr); }

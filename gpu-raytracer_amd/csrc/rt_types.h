@@ -77,6 +77,7 @@ struct RtStreamTable {                 // written by the host per submission (as
 	int submission_birth[RT_STREAM_SUBMISSIONS];
 };
 
+#define RT_ENDGAME_MAX_WAVES 16384     // waves of the persistent traversal grid that can own a region of a queue's end (256 CUs x 16 workgroups x 4)
 struct RtStreamControl {               // queue sizes and ray-claim cursors; [iteration & 1] where two launches overlap in time
 	int trace_count[2];                // rays in trace queue [i & 1]: appended by sort / shade of i - 1 and generate of i
 	int material_count[4];
@@ -84,6 +85,7 @@ struct RtStreamControl {               // queue sizes and ray-claim cursors; [it
 	int cursor[2][2];                  // [i & 1][closest, shadow] cursors of the fused trace launch
 	int pad[4];
 	int stats[RT_STREAM_SUBMISSIONS][RT_STAT_KINDS][RT_MAX_BOUNCES]; // rays per submission, queue kind and bounce
+	int endgame[2][2][RT_ENDGAME_MAX_WAVES];   // [i & 1][closest (or the mixed launch's one queue), shadow][region]: the end of a queue is dealt in regions, one per wave, that other waves help to finish (kernels_trace.hip: fetch_ray)
 };
 
 struct RtTexture {
