@@ -57,6 +57,8 @@
 #ifndef RT_ENDGAME
 #define RT_ENDGAME 1   // the merged wavefront's launches deal the end of a queue in per-wave regions (bvh8_trace_engine: `regions`); 0: the shared cursor to the last ray
 #endif
+// (The WHOLE queue dealt in regions -- a wave owns rays / waves consecutive rays, no shared cursor at all -- was measured in round 6: +3.7 % on the whole frame's launches, -1 % on a
+// rank's: with the shared cursor the 1.5 M rays in flight at one time are ONE stretch of the queue, which the caches like; profiles/r06_endgame.txt.)
 #ifndef RT_ENDGAME_SCAN_LIMIT
 #define RT_ENDGAME_SCAN_LIMIT 2     // looks (one load per asking lane, spread over the ring of regions) a wave takes, after the region it worked on is finished, before it concludes that there is nothing left to help with
 #endif
