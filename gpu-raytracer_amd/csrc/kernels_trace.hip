@@ -59,6 +59,9 @@
 #endif
 // (The WHOLE queue dealt in regions -- a wave owns rays / waves consecutive rays, no shared cursor at all -- was measured in round 6: +3.7 % on the whole frame's launches, -1 % on a
 // rank's: with the shared cursor the 1.5 M rays in flight at one time are ONE stretch of the queue, which the caches like; profiles/r06_endgame.txt.)
+#ifndef RT_ENDGAME_REGION_MAX
+#define RT_ENDGAME_REGION_MAX 256   // rays of a queue's end that a wave owns
+#endif
 #ifndef RT_ENDGAME_SCAN_LIMIT
 #define RT_ENDGAME_SCAN_LIMIT 2     // looks (one load per asking lane, spread over the ring of regions) a wave takes, after the region it worked on is finished, before it concludes that there is nothing left to help with
 #endif
@@ -566,7 +569,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 	// its two queues as ONE (closest-hit rays first; the kind of a ray is where its index falls).
 	const bool endgame = !NARROW && regions != nullptr && waves_in_grid <= RT_ENDGAME_MAX_WAVES;
 	const int ray_block = NARROW ? 8 : endgame ? RT_FETCH_BLOCK_MAX : max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, (rays_total / (RT_FETCH_BLOCK_DIVISOR * waves_in_grid)) & ~(RT_WAVE_SIZE - 1)));
-	const int region_size  = max(RT_WAVE_SIZE, min(RT_FETCH_BLOCK_MAX, ((rays_total + waves_in_grid - 1) / waves_in_grid + RT_WAVE_SIZE - 1) & ~(RT_WAVE_SIZE - 1)));
+	const int region_size  = max(RT_WAVE_SIZE, min(RT_ENDGAME_REGION_MAX, ((rays_total + waves_in_grid - 1) / waves_in_grid + RT_WAVE_SIZE - 1) & ~(RT_WAVE_SIZE - 1)));
 	const int region_count = min(waves_in_grid, (rays_total + region_size - 1) / region_size);
 	const int main_limit   = endgame ? max(0, rays_total - region_count * region_size) : 0;   // the shared cursor deals [0, main_limit) in blocks, the regions the rest
 	const int region_stride = max(1, region_count / RT_WAVE_SIZE) | 1;   // a scan's candidates: every region_stride-th region behind the one just finished
