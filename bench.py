@@ -840,8 +840,6 @@ def main():
             },
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(grt, pt, scene)
         if world == 1 and split_world == 1 and not args.no_povs:
             # the reference's perf harness (Util/PerfTest.h): the same frame loop at its 9 fixed points of view
             povs = []
@@ -851,17 +849,23 @@ def main():
                 run(submissions(2 * SPP)); check(lib.rt_synchronize(ctx))     # untimed: first frames from the new camera
                 grt.set_trace_statistics(ctx, False)
                 pov_plan = submissions(4 * SPP)
+                seating_before = (pt.reseat_pending, pt.reseats_completed)
                 t0 = time.perf_counter()
                 run(pov_plan)
                 check(lib.rt_synchronize(ctx))
                 ms = (time.perf_counter() - t0) / (4 * SPP) * 1e3
                 check(lib.rt_render_samples(ctx, 0, 1)); c = pt.counters()
-                povs.append({"ms_per_step": round(ms, 3), "rays_per_step": int(sum(c.trace[:NUM_BOUNCES])), "mrays_s": round(sum(c.trace[:NUM_BOUNCES]) / ms / 1e3, 1)})
+                povs.append({"ms_per_step": round(ms, 3), "rays_per_step": int(sum(c.trace[:NUM_BOUNCES])), "mrays_s": round(sum(c.trace[:NUM_BOUNCES]) / ms / 1e3, 1),
+                             "seating_in_the_making": bool(seating_before[0]), "seatings_completed": int(seating_before[1])})   # (the tree is seated again beside the frame loop once the camera has travelled: DESIGN.md 4.6)
             scene.set_camera(tuple(camera_before[0]), tuple(camera_before[1])); pt.update()
             ms_all = np.array([p["ms_per_step"] for p in povs]); mr_all = np.array([p["mrays_s"] for p in povs])
             result["povs"] = {"source": "Util/PerfTest.h:30-40 (povs_sponza), 16 steps each", "per_pov": povs,
                               "ms_per_step_avg": round(float(ms_all.mean()), 3), "ms_per_step_stddev": round(float(ms_all.std()), 3),
                               "mrays_s_avg": round(float(mr_all.mean()), 1), "mrays_s_stddev": round(float(mr_all.std()), 1)}
+        # (after the sweep: the oracle's 32 OpenMP threads linger on the host cores for a while, and a frame loop that shares them with the seating worker of the sweep
+        # once showed one point of view at 4.7 ms per step for 1.25: profiles/r06_bench_run27.json)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(grt, pt, scene)
         if world == 1 and split_world == 1 and merged and not args.no_config3 and (not os.environ.get("BENCH_PMC_CHILD") or os.environ.get("BENCH_PMC_CONFIG3")):   # (tools/svgf_counters.py profiles this section)
             pt.close(); pt = None   # (its queues and sample frames go back first)
             result["config3"] = config3_section(grt, scene, local_rank, stream_gbps)

@@ -615,14 +615,15 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 						// (a scan stalls the lanes of this wave that are in the middle of a ray: at most RT_ENDGAME_SCAN_LIMIT of them per refill, each a sample of the whole ring)
 						bool found = false;
 						while (!found && scanned < RT_ENDGAME_SCAN_LIMIT) {
-							int candidate = int((unsigned(scan_from) + (rank + 1u) * unsigned(region_stride)) % unsigned(region_count));
+							int candidate = scan_from + (int(rank) + 1) * region_stride;   // (< 2 x region_count + 64: no division here, its reciprocal would live in two registers through the whole walk)
+							while (candidate >= region_count) candidate -= region_count;
 							int seen = __hip_atomic_load(&regions[candidate], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							bool open = seen < region_size && main_limit + candidate * region_size + seen < rays_total;
 							unsigned long long open_lanes = __ballot(open);
 							if (open_lanes) {
 								int lane_of_first = __ffsll((long long)open_lanes) - 1;
 								region = __builtin_amdgcn_readlane(candidate, lane_of_first) + 1; found = true;
-							} else { scan_from = (scan_from + 1) % region_count; scanned++; }
+							} else { scan_from = scan_from + 1 < region_count ? scan_from + 1 : 0; scanned++; }
 						}
 						if (!found) break;   // nothing left that this wave could help with
 					}
@@ -690,6 +691,16 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 	bool mesh_has_identity_transform = true;
 	unsigned count_nodes = 0, count_triangles = 0, count_inst_xform = 0, count_inst_ident = 0;
 
+	// COUNT: a lane sums the work of its rays and adds the sums to the launch's statistics when it leaves (an atomic per ray and counter was 400 M same-word
+	// atomics for the burst's largest launch: 3.8 s of an untimed pass of bench.py)
+	unsigned long long lane_totals[2][5] = { { 0, 0, 0, 0, 0 }, { 0, 0, 0, 0, 0 } };
+	auto flush_counts = [&]() {
+		#pragma unroll
+		for (int kind = 0; kind < (MODE == RT_TRACE_MIXED ? 2 : 1); kind++) {
+			#pragma unroll
+			for (int k = 0; k < 5; k++) if (lane_totals[kind][k]) atomicAdd(&stats[kind * 5 + k], lane_totals[kind][k]);
+		}
+	};
 	// A finished ray hands over its result at the next refill, together with the other lanes that finished since the last
 	// one: inside the loop the hand-over ran in almost every round for 2-3 of 64 lanes, and its stores sat in front of the
 	// next round's loads (one counter for both on this chip: a wait for a load is a wait for every store before it).
@@ -707,7 +718,7 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 		}
 		if (inactive) {
 			ray_index = fetch_ray();
-			if (ray_index < 0) return;
+			if (ray_index < 0) { if constexpr (COUNT) flush_counts(); return; }
 
 			float max_distance;
 			source_load<MODE>(src, RT_IS_SHADOW, ray_index, ray, max_distance);   // (closest-hit sources: infinity)
@@ -907,11 +918,11 @@ RT_DEV void bvh8_trace_engine(const RtParams & p, Source & src, int ray_count, i
 				}
 				}
 			}
-			if (COUNT && result_pending) {   // (the ray has just retired: running was true at the top of this round)
-				unsigned long long * bucket = stats + (MODE == RT_TRACE_MIXED && lane_shadow ? 5 : 0);   // mixed launches: {closest x5, shadow x5}
-				atomicAdd(&bucket[0], (unsigned long long)count_nodes);     atomicAdd(&bucket[1], (unsigned long long)count_triangles);
-				atomicAdd(&bucket[2], (unsigned long long)count_inst_xform); atomicAdd(&bucket[3], (unsigned long long)count_inst_ident);
-				atomicAdd(&bucket[4], 1ull);
+			if constexpr (COUNT) if (result_pending) {   // (the ray has just retired: running was true at the top of this round) -- into the lane's totals; they leave with the lane (flush_counts)
+				const int kind = MODE == RT_TRACE_MIXED && lane_shadow ? 1 : 0;   // mixed launches: {closest x5, shadow x5}
+				lane_totals[kind][0] += count_nodes;      lane_totals[kind][1] += count_triangles;
+				lane_totals[kind][2] += count_inst_xform; lane_totals[kind][3] += count_inst_ident;
+				lane_totals[kind][4] += 1;
 				count_nodes = count_triangles = count_inst_xform = count_inst_ident = 0;
 			}
 			}

@@ -1,3 +1,6 @@
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include "Integrator.h"
 #include "Exporters.h"
 
@@ -223,7 +226,7 @@ void Integrator::drop_reseat_worker() {
 // A copy of the flattened tree as it stands in the staged arrays (host- or device-built: all it takes is the nodes and the triangles of its leaves) goes to a
 // worker that seats its children for the camera as it stands now. The copy is numbered breadth-first from the root; a node's inner children stay one
 // contiguous run in their order, so a record the learner moves within its run has ONE place to go back to.
-void Integrator::start_reseat_worker() {
+void Integrator::start_reseat_worker(bool beside_frame_loop) {
 	const StaticGeometry & flat = static_geometry;
 	if (!flat.active || cpu_config.bvh_type != BVHType::BVH8 || cpu_config.static_slot_learning_rays <= 0) return;
 	if (size_t(flat.root) >= aggregated_bvh_nodes_8.size()) return;
@@ -260,9 +263,14 @@ void Integrator::start_reseat_worker() {
 	const SlotLearningView view = slot_learning_view();   // (as things stand now: the worker must not read the scene)
 	const int rays = cpu_config.static_slot_learning_rays;
 	PendingReseat * raw = job.get();
-	raw->worker = std::thread([raw, view, rays] {
+	raw->worker = std::thread([raw, view, rays, beside_frame_loop] {
 		auto started = std::chrono::steady_clock::now();
-		try { bvh8_learn_slot_order(raw->tree, raw->triangles, rays, 0, &view); } catch (...) { raw->failed = true; }
+		// Beside the frame loop the learner must not take the processor from the thread that submits frames (one of the reference's nine points of view once ran at
+		// 4.1 ms per step for 1.3 while a seating was in the making: profiles/r06_bench_run26.json): lowest scheduling priority -- on Linux a thread's nice value is its own
+		// and is inherited by the threads it starts, the learner's helpers --, and half of the hardware threads at most.
+		if (beside_frame_loop) setpriority(PRIO_PROCESS, id_t(syscall(SYS_gettid)), 19);
+		const int threads = beside_frame_loop ? int(std::max(1u, std::thread::hardware_concurrency() / 2)) : 0;
+		try { bvh8_learn_slot_order(raw->tree, raw->triangles, rays, threads, &view); } catch (...) { raw->failed = true; }
 		raw->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
 		raw->ready.store(true);
 	});
@@ -816,7 +824,7 @@ void Integrator::update(float delta) {
 			// later ones, a device rebuild after a member moved or a camera that has travelled, beside the frame loop)
 			const bool inside_this_update = !reseat_asynchronously || (flattened_tree_needs_seating && geometry_generation <= 1);
 			flattened_tree_needs_seating = false;
-			start_reseat_worker();
+			start_reseat_worker(!inside_this_update);
 			if (inside_this_update && pending_reseat) {
 				if (pending_reseat->worker.joinable()) pending_reseat->worker.join();
 				if (install_reseat()) build_tlas();

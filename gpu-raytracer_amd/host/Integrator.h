@@ -156,7 +156,7 @@ struct Integrator {
 	bool flattened_tree_needs_seating = false;    // a tree the device built: never seated yet
 	int reseats_completed = 0; double last_reseat_seconds = 0.0;
 	bool reseat_asynchronously = true;            // (false: seat inside update(), for tests)
-	void start_reseat_worker();
+	void start_reseat_worker(bool beside_frame_loop);
 	bool install_reseat();                        // true when finished nodes went in
 	void drop_reseat_worker();
 	SlotLearningView slot_learning_view() const;   // the camera as it stands: what bvh8_learn_slot_order samples its paths from
