@@ -134,11 +134,16 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK) kernel_generate_stream(RtParam
 			int band = y / band_rows;
 			int rows = min(band_rows, p.screen_height - band * band_rows);   // the last band may be lower
 			int in_band = index_offset - band * band_rows * p.screen_width;
-			int block = in_band / (block_width * rows);
-			int in_block = in_band - block * block_width * rows;
-			int columns = min(block_width, p.screen_width - block * block_width); // the last block may be narrower
-			x = block * block_width + in_block % columns;
-			y = band * band_rows + in_block / columns;
+			if (band_rows == 8 && block_width == 8 && rows == 8 && (in_band >> 6) * 8 + 8 <= p.screen_width) {   // a whole 8 x 8 patch (the shipped shape): shifts
+				x = (in_band >> 6) * 8 + (in_band & 7);
+				y = band * 8 + ((in_band >> 3) & 7);
+			} else {
+				int block = in_band / (block_width * rows);
+				int in_block = in_band - block * block_width * rows;
+				int columns = min(block_width, p.screen_width - block * block_width); // the last block may be narrower
+				x = block * block_width + in_block % columns;
+				y = band * band_rows + in_block / columns;
+			}
 		}
 		int pixel_index = x + y * p.screen_pitch;
 		unsigned slot = unsigned(slot_base + sample_in_batch);
