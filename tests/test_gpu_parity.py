@@ -673,6 +673,13 @@ def test_merged_wavefront_equals_the_slot_scheduler(grt):
     def pixel_range(lib, pt):
         assert lib.rt_set_pixel_range(pt.ctx, 640 * 100 + 17, 640 * 120 + 5) == 0
     cases.append(("sponza", 640, 360, [(0, 2), (2, 2), (4, 4)], dict(num_bounces=4), tiles, ()))
+    # ragged in both directions: the merged wavefront walks the frame in 8 x 8 patches along bands of 8 scan lines (kernel_generate_stream) -- 203 = 25 patches + 3 columns,
+    # 157 = 19 bands + 5 lines --, whole and as rank 1 of 3 with 8-row tiles (whose last tile is the clipped band); the slot scheduler walks scan lines
+    def ragged_tiles(lib, pt):
+        lib.rt_set_pixel_tiles.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3
+        assert lib.rt_set_pixel_tiles(pt.ctx, 203 * 8, 1, 3) == 0
+    cases.append(("cornellbox", 203, 157, [(0, 3), (3, 2)], dict(num_bounces=5), None, ()))
+    cases.append(("cornellbox", 203, 157, [(0, 3), (3, 2)], dict(num_bounces=5), ragged_tiles, ()))
     cases.append(("sponza", 640, 360, [(0, 3), (3, 1)], dict(num_bounces=4), pixel_range, ()))
     for scene_name, w, h, plan, config, prepare, aovs in cases:
         merged = _render_plan(grt, scene_name, w, h, "merged", plan, config, prepare, aovs)
