@@ -388,6 +388,14 @@ def config3_section(grt, scene, device, stream_gbps, frames=64):
                             "tap_bytes_per_pixel": tap_bytes, "unique_bytes_per_pixel": unique_bytes,
                             "tap_gbps": round(gbps, 1), "unit": "GB/s", "tap_ratio": round(gbps / stream_gbps, 4),
                             "frac_unique": round(unique_bytes * px * passes / (per_frame * 1e-3) / 1e9 / stream_gbps, 4)})
+        if not any(k["kernel"] == "kernel_svgf_finalize" for k in kernels):
+            # round 6: the last a-trous pass runs tiled and finalizes its pixels itself (svgf_finalize_pixel): it does not write the filtered pair and its variance mirror (40 B) and
+            # moves kernel_svgf_finalize's bytes minus the pair and the (normal, depth) that kernel read back (184 - 48) -- spread over the frame's passes here
+            for k in kernels:
+                if k["kernel"] == "kernel_svgf_atrous" and k["launches_per_frame"] > 0:
+                    unique = k["unique_bytes_per_pixel"] + (184 - 48 - 40) / k["launches_per_frame"]
+                    k["unique_bytes_per_pixel"] = round(unique, 1); k["finalizes_in_its_last_pass"] = True
+                    k["frac_unique"] = round(unique * px * k["launches_per_frame"] / (k["ms_per_frame"] * 1e-3) / 1e9 / stream_gbps, 4)
         trace_ms = float(grt.launch_timings(ctx, "trace").sum()) / frames
         grt.set_profiling(ctx, False)
         unique_total = sum(k["unique_bytes_per_pixel"] * k["launches_per_frame"] for k in kernels) * px

@@ -439,7 +439,32 @@ RT_DEV AtrousNeighbourhood svgf_atrous_neighbourhood(const RtParams & p, int x, 
 	return n;
 }
 
-template<typename TapD, typename TapI, typename TapND>
+// What kernel_svgf_finalize does with a pixel's filtered (direct, indirect) pair (SVGF.h:556-609) -- shared by that kernel and by the LAST a-trous pass when it runs
+// tiled (round 6): the pass then hands its result over in registers instead of writing the pair (and its variance mirror, which nothing reads after the last pass) for a
+// kernel that reads it back: 88 bytes per pixel and a launch less. `normal_and_depth`: the frame's decoded (normal, depth) of the pixel.
+RT_DEV void svgf_finalize_pixel(const RtParams & p, int pixel_index, f4 direct, f4 indirect, float4 normal_and_depth) {
+	if (pixel_index == 0) p.svgf_young_pixels[0] = 0;   // (this frame's variance pass is behind us: the next frame's reproject fills the list again)
+	f4 colour = (direct + indirect) * aov_get(p, RT_AOV_ALBEDO, pixel_index);
+	st4(p.final_image, pixel_index, colour);
+
+	if (p.config.enable_taa) {
+		colour = colour / (1.0f + luminance(colour.x, colour.y, colour.z));
+		colour.x = safe_sqrt(colour.x); colour.y = safe_sqrt(colour.y); colour.z = safe_sqrt(colour.z);
+		st4(p.taa_frame_curr, pixel_index, colour);
+	}
+	float4 moment = p.frame_buffer_moment[pixel_index];
+	if (p.config.num_atrous_iterations <= RT_FEEDBACK_ITERATION) { st4(p.history_direct, pixel_index, direct); st4(p.history_indirect, pixel_index, indirect); }
+	p.history_moment[pixel_index] = moment;
+	p.history_normal_and_depth[pixel_index] = normal_and_depth;   // decoded (normal, depth) of this frame
+
+	p.gbuffer_normal_and_depth[pixel_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	p.gbuffer_mesh_id_and_triangle_id[pixel_index] = make_int2(0, 0);
+	if (!p.config.enable_taa) p.gbuffer_screen_position_prev[pixel_index] = make_float2(0.0f, 0.0f);
+}
+
+// FINAL: the frame's last pass; the result goes to svgf_finalize_pixel instead of the images (a sky pixel, which no pass writes, finalizes what the pair's images hold for it:
+// exactly what kernel_svgf_finalize would have read).
+template<bool FINAL = false, typename TapD, typename TapI, typename TapND>
 RT_DEV void svgf_atrous_pixel(const RtParams & p, int x, int y, int step_size, const AtrousNeighbourhood & near, float4 * __restrict__ d_out, float4 * __restrict__ i_out,
                               float2 * __restrict__ variance_out, TapD tap_d, TapI tap_i, TapND tap_nd) {
 	const int pitch = p.screen_pitch;
@@ -453,7 +478,10 @@ RT_DEV void svgf_atrous_pixel(const RtParams & p, int x, int y, int step_size, c
 	float4 cnd = tap_nd(0, 0);
 	f3 center_normal = mk3(cnd.x, cnd.y, cnd.z);
 	float center_depth = cnd.w;
-	if (center_depth == 0.0f) return; // sky: outputs intentionally not written (SVGF.h:462)
+	if (center_depth == 0.0f) { // sky: outputs intentionally not written (SVGF.h:462)
+		if (FINAL) svgf_finalize_pixel(p, pixel_index, ld4(d_out, pixel_index), ld4(i_out, pixel_index), cnd);
+		return;
+	}
 
 	f2 grad = mk2(near.depth_right - center_depth, near.depth_below - center_depth);
 
@@ -480,10 +508,11 @@ RT_DEV void svgf_atrous_pixel(const RtParams & p, int x, int y, int step_size, c
 	float inv_d = 1.0f / sw_d, inv_i = 1.0f / sw_i;
 	sc_d *= inv_d; sc_i *= inv_i;
 	sc_d.w *= inv_d; sc_i.w *= inv_i;
+	if (step_size == (1 << RT_FEEDBACK_ITERATION)) { st4(p.history_direct, pixel_index, sc_d); st4(p.history_indirect, pixel_index, sc_i); }
+	if (FINAL) { svgf_finalize_pixel(p, pixel_index, sc_d, sc_i, cnd); return; }
 	st4(d_out, pixel_index, sc_d);
 	st4(i_out, pixel_index, sc_i);
 	variance_out[pixel_index] = make_float2(sc_d.w, sc_i.w);
-	if (step_size == (1 << RT_FEEDBACK_ITERATION)) { st4(p.history_direct, pixel_index, sc_d); st4(p.history_indirect, pixel_index, sc_i); }
 }
 
 __global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const float4 * __restrict__ d_in, const float4 * __restrict__ i_in, float4 * __restrict__ d_out, float4 * __restrict__ i_out, const float2 * __restrict__ variance_in, float2 * __restrict__ variance_out, int step_size) {
@@ -513,10 +542,13 @@ __global__ void __launch_bounds__(256) kernel_svgf_atrous(RtParams p, const floa
 // bit-identical to the untiled pass (tests/test_gpu_materials_svgf.py::test_svgf_lds_tiles_do_not_change_a_frame).
 // Tiles are numbered column-fastest within one residue class of rows, XCD k takes the k-th eighth of the sequence (as post_tile_pixel):
 // neighbours in x, which share their STEP halo columns, run back to back on one L2.
+#ifndef RT_SVGF_FUSED_FINALIZE
+#define RT_SVGF_FUSED_FINALIZE 1   // the last tiled a-trous pass finalizes its pixels itself (svgf_finalize_pixel); 0: kernel_svgf_finalize after it, as the reference does
+#endif
 #ifndef RT_ATROUS_ROWS
 #define RT_ATROUS_ROWS 8   // rows of pixels per workgroup (one wave each) of the tiled passes up to step 16
 #endif
-template<int STEP, int TY>
+template<int STEP, int TY, bool FINAL>
 __global__ void __launch_bounds__(64 * TY) kernel_svgf_atrous_tiled(RtParams p, const float4 * __restrict__ d_in, const float4 * __restrict__ i_in, float4 * __restrict__ d_out, float4 * __restrict__ i_out, const float2 * __restrict__ variance_in, float2 * __restrict__ variance_out) {
 	constexpr int W = 64 + 2 * STEP, ROWS = TY + 2, N = W * ROWS, THREADS = 64 * TY;
 	__shared__ float4 tile_d[N], tile_i[N], tile_nd[N];
@@ -550,25 +582,26 @@ __global__ void __launch_bounds__(64 * TY) kernel_svgf_atrous_tiled(RtParams p, 
 
 	if (!has_pixel) return;
 	const int centre = (ty + 1) * W + tx + STEP;
-	svgf_atrous_pixel(p, x, y, STEP, near, d_out, i_out, variance_out,
+	svgf_atrous_pixel<FINAL>(p, x, y, STEP, near, d_out, i_out, variance_out,
 		[&](int i, int j) { return tile_d [centre + i * STEP + j * W]; },
 		[&](int i, int j) { return tile_i [centre + i * STEP + j * W]; },
 		[&](int i, int j) { return tile_nd[centre + i * STEP + j * W]; });
 }
 template<int STEP, int TY>
-static void launch_atrous_tiled(const RtParams & p, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, const float2 * variance_in, float2 * variance_out, hipStream_t stream) {
+static void launch_atrous_tiled(const RtParams & p, bool final_pass, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, const float2 * variance_in, float2 * variance_out, hipStream_t stream) {
 	const unsigned tiles = ((unsigned(p.screen_width) + 63u) / 64u) * unsigned(STEP) * ((unsigned(p.screen_height) + unsigned(TY * STEP) - 1u) / unsigned(TY * STEP));
-	hipLaunchKernelGGL((kernel_svgf_atrous_tiled<STEP, TY>), dim3((tiles + 7) / 8 * 8), dim3(64 * TY), 0, stream, p, d_in, i_in, d_out, i_out, variance_in, variance_out);
+	if (final_pass) hipLaunchKernelGGL((kernel_svgf_atrous_tiled<STEP, TY, true>), dim3((tiles + 7) / 8 * 8), dim3(64 * TY), 0, stream, p, d_in, i_in, d_out, i_out, variance_in, variance_out);
+	else hipLaunchKernelGGL((kernel_svgf_atrous_tiled<STEP, TY, false>), dim3((tiles + 7) / 8 * 8), dim3(64 * TY), 0, stream, p, d_in, i_in, d_out, i_out, variance_in, variance_out);
 }
 // false: no tiled form for this step size (more than six iterations): the caller launches kernel_svgf_atrous
-static bool launch_atrous_tiled_step(const RtParams & p, int step_size, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, const float2 * variance_in, float2 * variance_out, hipStream_t stream) {
+static bool launch_atrous_tiled_step(const RtParams & p, int step_size, bool final_pass, const float4 * d_in, const float4 * i_in, float4 * d_out, float4 * i_out, const float2 * variance_in, float2 * variance_out, hipStream_t stream) {
 	switch (step_size) {   // LDS per workgroup: (64 + 2 STEP) x (TY + 2) x 48 B = 31.7 / 32.6 / 34.6 / 38.4 / 46.1 / 36.9 KB with 8 rows (4 at step 32)
-		case 1:  launch_atrous_tiled<1,  RT_ATROUS_ROWS>(p, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
-		case 2:  launch_atrous_tiled<2,  RT_ATROUS_ROWS>(p, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
-		case 4:  launch_atrous_tiled<4,  RT_ATROUS_ROWS>(p, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
-		case 8:  launch_atrous_tiled<8,  RT_ATROUS_ROWS>(p, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
-		case 16: launch_atrous_tiled<16, RT_ATROUS_ROWS>(p, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
-		case 32: launch_atrous_tiled<32, 4>(p, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
+		case 1:  launch_atrous_tiled<1,  RT_ATROUS_ROWS>(p, final_pass, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
+		case 2:  launch_atrous_tiled<2,  RT_ATROUS_ROWS>(p, final_pass, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
+		case 4:  launch_atrous_tiled<4,  RT_ATROUS_ROWS>(p, final_pass, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
+		case 8:  launch_atrous_tiled<8,  RT_ATROUS_ROWS>(p, final_pass, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
+		case 16: launch_atrous_tiled<16, RT_ATROUS_ROWS>(p, final_pass, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
+		case 32: launch_atrous_tiled<32, 4>(p, final_pass, d_in, i_in, d_out, i_out, variance_in, variance_out, stream); return true;
 	}
 	return false;
 }
@@ -578,25 +611,7 @@ __global__ void __launch_bounds__(256) kernel_svgf_finalize(RtParams p, const fl
 	if (!post_tile_pixel(p, x, y)) return;
 	if (x >= p.screen_width || y >= p.screen_height) return;
 	int pixel_index = x + y * p.screen_pitch;
-
-	if (pixel_index == 0) p.svgf_young_pixels[0] = 0;   // (this frame's variance pass is behind us: the next frame's reproject fills the list again)
-	f4 direct = ld4(colour_direct, pixel_index), indirect = ld4(colour_indirect, pixel_index);
-	f4 colour = (direct + indirect) * aov_get(p, RT_AOV_ALBEDO, pixel_index);
-	st4(p.final_image, pixel_index, colour);
-
-	if (p.config.enable_taa) {
-		colour = colour / (1.0f + luminance(colour.x, colour.y, colour.z));
-		colour.x = safe_sqrt(colour.x); colour.y = safe_sqrt(colour.y); colour.z = safe_sqrt(colour.z);
-		st4(p.taa_frame_curr, pixel_index, colour);
-	}
-	float4 moment = p.frame_buffer_moment[pixel_index];
-	if (p.config.num_atrous_iterations <= RT_FEEDBACK_ITERATION) { st4(p.history_direct, pixel_index, direct); st4(p.history_indirect, pixel_index, indirect); }
-	p.history_moment[pixel_index] = moment;
-	p.history_normal_and_depth[pixel_index] = p.svgf_normal_and_depth[pixel_index];   // decoded (normal, depth) of this frame
-
-	p.gbuffer_normal_and_depth[pixel_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	p.gbuffer_mesh_id_and_triangle_id[pixel_index] = make_int2(0, 0);
-	if (!p.config.enable_taa) p.gbuffer_screen_position_prev[pixel_index] = make_float2(0.0f, 0.0f);
+	svgf_finalize_pixel(p, pixel_index, ld4(colour_direct, pixel_index), ld4(colour_indirect, pixel_index), p.svgf_normal_and_depth[pixel_index]);
 }
 
 RT_DEV f3 clamp3(f3 v, f3 lo, f3 hi) { return mk3(clampf(v.x, lo.x, hi.x), clampf(v.y, lo.y, hi.y), clampf(v.z, lo.z, hi.z)); }
@@ -691,9 +706,11 @@ void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream
 		t = indirect_in; indirect_in = indirect_out; indirect_out = t;
 		float2 * v = variance_in; variance_in = variance_out; variance_out = v;
 	}
+	bool finalized = false;   // the last pass has run tiled and has done kernel_svgf_finalize's work on its way out
 	for (int i = 0; i < p.config.num_atrous_iterations; i++) {
+		const bool last = i == p.config.num_atrous_iterations - 1;
 		auto atrous_pass = [&](int step_size) {
-			if (p.svgf_tiles && launch_atrous_tiled_step(p, step_size, direct_in, indirect_in, direct_out, indirect_out, variance_in, variance_out, stream)) return;
+			if (p.svgf_tiles && launch_atrous_tiled_step(p, step_size, last && RT_SVGF_FUSED_FINALIZE, direct_in, indirect_in, direct_out, indirect_out, variance_in, variance_out, stream)) { finalized = last && RT_SVGF_FUSED_FINALIZE; return; }
 			hipLaunchKernelGGL(kernel_svgf_atrous, grid, block, 0, stream, p, direct_in, indirect_in, direct_out, indirect_out, variance_in, variance_out, step_size);
 		};
 		RT_TIMED(2, atrous_pass(1 << i));
@@ -701,7 +718,7 @@ void rt_launch_svgf_taa(const RtParams & p, int sample_index, hipStream_t stream
 		t = indirect_in; indirect_in = indirect_out; indirect_out = t;
 		float2 * v = variance_in; variance_in = variance_out; variance_out = v;
 	}
-	RT_TIMED(3, hipLaunchKernelGGL(kernel_svgf_finalize, grid, block, 0, stream, p, direct_in, indirect_in));
+	if (!finalized) RT_TIMED(3, hipLaunchKernelGGL(kernel_svgf_finalize, grid, block, 0, stream, p, direct_in, indirect_in));
 
 	if (p.config.enable_taa) {
 		RT_TIMED(4, hipLaunchKernelGGL(kernel_taa, grid, block, 0, stream, p, sample_index));   // (the caller swaps taa_frame_prev / taa_frame_next)
