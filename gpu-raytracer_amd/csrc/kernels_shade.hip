@@ -1123,7 +1123,10 @@ __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_materia
 // ..._texels: no texture on the device holds compressed blocks (RtParams::textures_compressed == 0)
 __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_diffuse_texels(RtParams p, int bounce, int sample_index) { shade_material<BSDFDiffuseT<false>, 0, false>(p, bounce, sample_index); }
 __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_plastic_texels(RtParams p, int bounce, int sample_index) { shade_material<BSDFPlasticT<false>, 1, false>(p, bounce, sample_index); }
-__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_diffuse_stream_texels(RtParams p) { shade_material<BSDFDiffuseT<false>, 0, true>(p, 0, 0); }
+#ifndef RT_SHADE_WAVES_DIFFUSE
+#define RT_SHADE_WAVES_DIFFUSE RT_SHADE_WAVES
+#endif
+__global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES_DIFFUSE) kernel_material_diffuse_stream_texels(RtParams p) { shade_material<BSDFDiffuseT<false>, 0, true>(p, 0, 0); }
 __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_plastic_stream_texels(RtParams p) { shade_material<BSDFPlasticT<false>, 1, true>(p, 0, 0); }
 __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_diffuse_stream(RtParams p)    { shade_material<BSDFDiffuse,    0, true>(p, 0, 0); }
 __global__ void __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_WAVES) kernel_material_plastic_stream(RtParams p)    { shade_material<BSDFPlastic,    1, true>(p, 0, 0); }
