@@ -91,6 +91,7 @@ struct Policy {
 	int tri_hold = 0;           // postponing: run the triangle phase only with >= this many lanes wanting it (or nobody can step)
 	bool pop_in_node_phase = false; // a lane whose round ends with nothing pending pops and may take its node step in the SAME... (unused)
 	int second_min = 0;         // the k-th (k >= 1) test of a batch runs only when at least this many lanes have a k-th triangle; else those triangles wait for the next round
+	bool overlap = false;       // a lane takes its node step while it still holds <= tri_batch pending triangles (they are tested in the same round, after the step); single-tree scenes only
 	bool coop = false;          // cooperative triangle phase: every pending (ray, triangle) pair of the wave gets a lane of its own (hand-over through LDS), all pending triangles of a lane in one round
 	double coop_owner = 43, coop_helper = 58, coop_readback = 8;   // instruction prices: prefix + slot writes (all running lanes), fetch + test + result write per pass of 64 pairs, read-back per triangle trip
 };
@@ -101,7 +102,7 @@ struct Cost { double header = 17 + 2, push = 3, node = 220, leafgroup = 4, inst_
 struct LaneState {
 	bool has_ray = false; int ray_index = -1; bool shadow = false;
 	Ray ray, world; f3 inv; unsigned oct = 0; float max_distance = 0; Hit hit;
-	uint32_t cg_x = 0, cg_y = 0, tg_x = 0, tg_y = 0; int tlas_stack = -1; int mesh = 0; bool ident = true;
+	uint32_t cg_x = 0, cg_y = 0, tg_x = 0, tg_y = 0, ng_x = 0, ng_y = 0; bool stepped = false; int tlas_stack = -1; int mesh = 0; bool ident = true;
 	std::vector<std::pair<uint32_t, uint32_t>> stack;
 	bool running = false;
 };
@@ -155,7 +156,8 @@ static void run_wave(const Scene & s, const std::vector<Ray> & rays, bool shadow
 			if (pol.early_instance) enter_instances();
 			// node phase
 			{ int n = 0, npush = 0, nleaf = 0;
-				for (auto & l : L) if (l.running && l.tg_y == 0) {
+				for (auto & l : L) l.stepped = false;
+				for (auto & l : L) if (l.running && (pol.overlap ? __builtin_popcount(l.tg_y) <= pol.tri_batch : l.tg_y == 0)) {
 					if (l.cg_y & 0xff000000u) { n++;
 						unsigned hits_imask = l.cg_y, off = msb(hits_imask), base = l.cg_x; l.cg_y &= ~(1u << off);
 						if (l.cg_y & 0xff000000u) { l.stack.push_back({ l.cg_x, l.cg_y }); npush++; }
@@ -164,7 +166,8 @@ static void run_wave(const Scene & s, const std::vector<Ray> & rays, bool shadow
 						if (!s.depth.empty()) st.depth_visits[std::min(23, s.depth[size_t(base + rel)])]++;
 						unsigned hm = node_intersect(l.ray, l.inv, l.oct, l.shadow ? l.max_distance : l.hit.t, node);
 						uint32_t w[8]; memcpy(w, node, 32);
-						l.cg_x = w[4]; l.tg_x = w[5]; l.cg_y = (hm & 0xff000000u) | (w[3] >> 24); l.tg_y = hm & 0x00ffffffu; st.nodes++;
+						l.cg_x = w[4]; l.cg_y = (hm & 0xff000000u) | (w[3] >> 24); st.nodes++;
+						if (pol.overlap) { l.ng_x = w[5]; l.ng_y = hm & 0x00ffffffu; l.stepped = true; } else { l.tg_x = w[5]; l.tg_y = hm & 0x00ffffffu; }
 					} else if (!pol.early_instance) { if (l.cg_y) { nleaf++; l.tg_x = l.cg_x; l.tg_y = l.cg_y; l.cg_x = l.cg_y = 0; } }
 				}
 				if (n) { st.node_exec++; st.node_lanes += n; st.instr += c.node; st.useful += c.node * n / 64.0; }
@@ -199,11 +202,12 @@ static void run_wave(const Scene & s, const std::vector<Ray> & rays, bool shadow
 					for (int k = 0; k < pol.tri_batch; k++) if (per_k[k]) { st.tri_exec[k]++; st.tri_lanes[k] += per_k[k]; st.instr += c.tri_test; st.useful += c.tri_test * per_k[k] / 64.0; }
 				}
 			}
+			if (pol.overlap) for (auto & l : L) if (l.stepped) { if (l.running) { l.tg_x = l.ng_x; l.tg_y = l.ng_y; } l.stepped = false; }   // (the pending ones have just been tested: at most tri_batch of them)
 			// end of round: finish / leave instance / pop
 			{ int npop = 0, nreload = 0; int still = 0; for (auto & l : L) if (l.running) still++;
 				st.instr += c.end; st.useful += c.end * still / 64.0;
-				for (auto & l : L) if (l.running && l.tg_y == 0 && (l.cg_y & 0xff000000u) == 0) {
-					if (l.stack.empty()) { l.cg_y = 0; l.running = false; }
+				for (auto & l : L) if (l.running && (pol.overlap ? __builtin_popcount(l.tg_y) <= pol.tri_batch : l.tg_y == 0) && (l.cg_y & 0xff000000u) == 0) {
+					if (l.stack.empty()) { if (l.tg_y == 0) { l.cg_y = 0; l.running = false; } }
 					else { if (int(l.stack.size()) == l.tlas_stack) { l.tlas_stack = -1; if (!l.ident) { nreload++; l.ray = l.world; l.inv = mk3(1.0f / l.ray.d.x, 1.0f / l.ray.d.y, 1.0f / l.ray.d.z); l.oct = octant_inv4(l.ray.d); } }
 						auto e = l.stack.back(); l.stack.pop_back(); npop++; l.cg_x = e.first; l.cg_y = e.second;
 						if (pol.early_instance && (l.cg_y & 0xff000000u) == 0) { l.tg_x = l.cg_x; l.tg_y = l.cg_y; l.cg_x = l.cg_y = 0; st.leafpops++; } }
@@ -297,6 +301,9 @@ int main(int argc, char ** argv) {
 	if (argc > 3) {   // the triangle-phase experiments of round 5 only
 		std::vector<Policy> q;
 		{ Policy p; q.push_back(p); }
+		{ Policy p; p.name = "overlap (step with <= 2 pending)"; p.overlap = true; q.push_back(p); }
+		{ Policy p; p.name = "overlap, batch 3"; p.overlap = true; p.tri_batch = 3; q.push_back(p); }
+		if (argc > 4) { for (auto & p : q) { report("bounce2", p, simulate(s, bounce2, false, p)); report("shadow ", p, simulate(s, shadow, true, p)); report("primary", p, simulate(s, primary, false, p)); } return 0; }
 		for (int m : { 4, 8, 12, 16, 24 }) { Policy p; p.name = "second slot if >= m lanes"; p.second_min = m; q.push_back(p); }
 		for (int m : { 8, 16 }) { Policy p; p.name = "batch 3, slots 2,3 if >= m"; p.tri_batch = 3; p.second_min = m; q.push_back(p); }
 		{ Policy p; p.name = "coop (43/58/8)"; p.coop = true; q.push_back(p); }
