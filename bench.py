@@ -109,6 +109,8 @@ def build_scene(grt):
         grt.config_set(static_slot_learning_rays=int(os.environ["BENCH_SLOT_LEARNING_RAYS"]))
     if os.environ.get("BENCH_SLOT_LEARNING_VIEWPOINT"):
         grt.config_set(static_slot_learning_viewpoint=int(os.environ["BENCH_SLOT_LEARNING_VIEWPOINT"]))
+    if os.environ.get("BENCH_RESEAT_DISTANCE"):   # experiments: 0 = the flattened tree is never seated again when the camera travels (config static_reseat_distance)
+        grt.config_set(static_reseat_distance=float(os.environ["BENCH_RESEAT_DISTANCE"]))
     if os.environ.get("BENCH_SKIP_BEHIND_HIT"):   # A / B: 0 = the reference's walk node for node (config skip_behind_hit, rt_set_skip_behind_hit)
         grt.config_set(skip_behind_hit=int(os.environ["BENCH_SKIP_BEHIND_HIT"]))
     # the reference's own 19 diffuse maps when build() could install them (assets/_cache, see install_reference_sponza_textures),

@@ -1,3 +1,4 @@
+#include <sched.h>
 #include <sys/resource.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -123,6 +124,11 @@ std::vector<Triangle> Integrator::world_triangles_of(const std::vector<int> & me
 	return world;
 }
 
+static int processors_this_process_may_use();
+// What a worker beside the frame loop may use: a quarter of the processors this process can keep busy, eight at most, at the lowest scheduling priority (on Linux a
+// thread's nice value is its own and is inherited by the threads it starts).
+static int background_threads() { setpriority(PRIO_PROCESS, id_t(syscall(SYS_gettid)), 19); return std::max(1, std::min(8, processors_this_process_may_use() / 4)); }
+
 // SAH object + spatial splits on all host threads, the reference's 8-wide collapse, breadth-first node order. A pure function of
 // its input and the configuration (it runs on a worker thread when a flattened instance has started to move).
 // What the seating of the flattened tree's children is trained on (SlotOrder.cpp): the camera's rays as camera_generate_ray forms them, as the camera stands now.
@@ -136,15 +142,16 @@ SlotLearningView Integrator::slot_learning_view() const {
 	return view;
 }
 
-static void build_flattened_tree(const std::vector<Triangle> & world, BVH8 & wide, int & top_nodes, const SlotLearningView & view) {
+// `threads`: 0 = all host threads (a build inside update()); a worker beside the frame loop passes its budget (background_threads)
+static void build_flattened_tree(const std::vector<Triangle> & world, BVH8 & wide, int & top_nodes, const SlotLearningView & view, int threads = 0) {
 	BVH2 binary;
 	if (cpu_config.merge_static == 2) binary = BVH::create_sah_from_triangles(world);   // the per-mesh builder, for comparison
-	else                              StaticBVHBuilder::build(binary, world);           // spatial splits, all host threads
+	else                              StaticBVHBuilder::build(binary, world, threads);  // spatial splits
 	BVH8Converter converter(wide, binary);
 	converter.primitive_cost = cpu_config.static_primitive_cost;
 	converter.slot_assignment = cpu_config.static_slot_assignment;
 	converter.convert();
-	if (cpu_config.static_slot_learning_rays > 0) bvh8_learn_slot_order(wide, world, cpu_config.static_slot_learning_rays, 0, &view);
+	if (cpu_config.static_slot_learning_rays > 0) bvh8_learn_slot_order(wide, world, cpu_config.static_slot_learning_rays, threads, &view);
 	top_nodes = std::min(bvh8_order_breadth_first(wide, 2), 64);   // levels 0..2 (at most 1 + 8 + 64 nodes) come first: the part of the tree every ray walks is one contiguous run
 }
 
@@ -193,7 +200,7 @@ void Integrator::start_flatten_worker() {
 	job->worker = std::thread([job, originals, device_index, view] {
 		auto started = std::chrono::steady_clock::now();
 		try {
-			build_flattened_tree(job->world, job->wide, job->top_nodes, view);
+			build_flattened_tree(job->world, job->wide, job->top_nodes, view, background_threads());
 			size_t copies = job->wide.indices.size();
 			job->copy_triangles.resize(copies); job->copy_member.resize(copies); job->copy_original.resize(copies);
 			for (size_t c = 0; c < copies; c++) {
@@ -226,6 +233,28 @@ void Integrator::drop_reseat_worker() {
 // A copy of the flattened tree as it stands in the staged arrays (host- or device-built: all it takes is the nodes and the triangles of its leaves) goes to a
 // worker that seats its children for the camera as it stands now. The copy is numbered breadth-first from the root; a node's inner children stay one
 // contiguous run in their order, so a record the learner moves within its run has ONE place to go back to.
+// Processors this process can really keep busy: the affinity mask, and a control group's CPU bandwidth limit on top of it (a container that shows 256 logical
+// processors may be allowed 16). The limit matters beside a frame loop: when a group's threads use up its quota of a 100 ms period, EVERY thread of the group is
+// stopped until the next period -- the thread that submits frames included, however low the priority of the threads that spent the quota (round 6: one of the
+// reference's nine points of view at 3.7-5.5 ms per step for 1.25 while the seating worker ran on 64 threads; tools/gpu_jobs/r06_run31.sh).
+static int processors_this_process_may_use() {
+	int count = int(std::max(1u, std::thread::hardware_concurrency()));
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof(set), &set) == 0) count = std::min(count, std::max(1, CPU_COUNT(&set)));
+	auto limit = [&](double quota, double period) { if (quota > 0.0 && period > 0.0) count = std::min(count, std::max(1, int(quota / period + 0.5))); };
+	if (FILE * f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // control groups v2: "<quota | max> <period>"
+		char quota[32] = ""; double period = 0.0;
+		if (fscanf(f, "%31s %lf", quota, &period) == 2 && strcmp(quota, "max") != 0) limit(atof(quota), period);
+		fclose(f);
+	} else {   // v1
+		double quota = -1.0, period = 0.0;
+		if (FILE * q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(q, "%lf", &quota) != 1) quota = -1.0; fclose(q); }
+		if (FILE * q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(q, "%lf", &period) != 1) period = 0.0; fclose(q); }
+		limit(quota, period);
+	}
+	return count;
+}
+
 void Integrator::start_reseat_worker(bool beside_frame_loop) {
 	const StaticGeometry & flat = static_geometry;
 	if (!flat.active || cpu_config.bvh_type != BVHType::BVH8 || cpu_config.static_slot_learning_rays <= 0) return;
@@ -265,11 +294,8 @@ void Integrator::start_reseat_worker(bool beside_frame_loop) {
 	PendingReseat * raw = job.get();
 	raw->worker = std::thread([raw, view, rays, beside_frame_loop] {
 		auto started = std::chrono::steady_clock::now();
-		// Beside the frame loop the learner must not take the processor from the thread that submits frames (one of the reference's nine points of view once ran at
-		// 4.1 ms per step for 1.3 while a seating was in the making: profiles/r06_bench_run26.json): lowest scheduling priority -- on Linux a thread's nice value is its own
-		// and is inherited by the threads it starts, the learner's helpers --, and half of the hardware threads at most.
-		if (beside_frame_loop) setpriority(PRIO_PROCESS, id_t(syscall(SYS_gettid)), 19);
-		const int threads = beside_frame_loop ? int(std::max(1u, std::thread::hardware_concurrency() / 2)) : 0;
+		// (beside the frame loop the learner must not take the processor -- or the control group's quota -- from the thread that submits frames: background_threads)
+		const int threads = beside_frame_loop ? background_threads() : 0;
 		try { bvh8_learn_slot_order(raw->tree, raw->triangles, rays, threads, &view); } catch (...) { raw->failed = true; }
 		raw->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
 		raw->ready.store(true);
