@@ -484,6 +484,7 @@ def main():
     ap.add_argument("--burst", type=int, default=1, help="1 (default): the run's submissions are declared as bursts of up to 8 (rt_set_stream_batch) whose frames share iterations; 0: they follow one another through the wavefront")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage rooflines (a repeat of the timed plan with events around every launch)")
     ap.add_argument("--no-reference-layout", action="store_true", help="skip the pass over the reference's acceleration-structure layout (merge_static 0; N = 1 only)")
+    ap.add_argument("--no-tile-split-bound", action="store_true", help="skip the one-GPU bound of the tile split (child runs of this command with --emulate-world 2 / 4 / 8; N = 1 only)")
     ap.add_argument("--no-povs", action="store_true", help="skip the sweep over the reference's 9 fixed Sponza points of view (N = 1 only)")
     ap.add_argument("--emulate-world", type=int, default=0, help="debug: render only rank 0's tiles of an N-GPU split on one GPU (no collective), to exercise the N > 1 code path")
     ap.add_argument("--merge-static", type=int, default=1, help="1 (default): the 382 instances of Sponza that stand still with the identity transform are flattened into one bottom-level tree (config merge_static); 0: one BLAS per mesh under the TLAS, the reference's layout")
@@ -925,6 +926,28 @@ def main():
                     r.update({"bound": "valu issue, mix-aware", "achieved": round(1.0 / mix["measured_cycles_per_instruction"], 4), "peak": round(1.0 / mix["best_cycles_per_instruction"]["classes_serial"], 4),
                               "unit": "vector wave-instructions per cycle and SIMD (x lane utilisation in frac)", "frac": mix["frac_classes_serial"]})
                 r["bound_is"] = "the unit of the dominant kernel closest to its roof (roofline.binding.utilisation_by_unit); no unit is saturated -- the launch is a chain of dependent node and triangle fetches"
+        if world == 1 and split_world == 1 and merged and not args.no_tile_split_bound and not os.environ.get("BENCH_PMC_CHILD"):
+            # No multi-GPU hardware has run this benchmark in any round (SCALE records: skipped). What ONE GPU can say about the tile split: rank 0's share of an N-way
+            # split rendered alone (--emulate-world N: its tiles, pack + unpack of the exchange, no collective) -- the whole frame's ms per step over the rank's is a BOUND
+            # of the speed-up N ranks can reach on this command (the all-gather itself, 33 MB per frame, comes on top). Child processes of this command, one at a time,
+            # after this process has let go of the GPU.
+            if not closed:
+                if pt is not None:
+                    pt.close(); pt = None
+                scene.close(); closed = True
+            import subprocess
+            bound = {"note": "rank 0's share of an N-way tile split rendered on this one GPU (bench.py --emulate-world N, same steps / warm-up); speedup_bound = this line's ms_per_step / the rank's: an upper bound, the collective is not in it", "ranks": []}
+            for n in (2, 4, 8):
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--emulate-world", str(n), "--burst", str(args.burst),
+                       "--no-cpu-baseline", "--no-povs", "--no-pmc", "--no-config3", "--no-reference-layout", "--no-stages", "--no-tile-split-bound", "--merge-static", str(args.merge_static)]
+                try:
+                    child = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300, env=dict(os.environ, BENCH_PMC_CHILD="1"))
+                    line = [l for l in child.stdout.splitlines() if l.startswith("{")]
+                    ms = json.loads(line[-1])["ms_per_step"]
+                    bound["ranks"].append({"world": n, "rank_ms_per_step": ms, "speedup_bound": round(result["ms_per_step"] / ms, 2)})
+                except Exception as error:   # (a bound that could not be measured is not a reason to lose the line)
+                    bound["ranks"].append({"world": n, "error": str(error)[:200]})
+            result["tile_split_bound"] = bound
         print(json.dumps(result))
 
     if not closed:
