@@ -14,6 +14,17 @@ def main():
     rows = cur.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
     if not rows:
         print("no kernels"); return
+    # memory copies of the same trace (rocprofv3 --memory-copy-trace), where the database has them: listed between the kernels as "copy <direction> <bytes>"
+    for (table,) in cur.execute("select name from sqlite_master where type in ('table', 'view') and name like '%memory_cop%'").fetchall():
+        ccols = [r[1] for r in cur.execute("pragma table_info(%s)" % table)]
+        if "start" in ccols and "end" in ccols:
+            label = [c for c in ("name", "direction", "kind") if c in ccols]
+            size = "size" if "size" in ccols else ("bytes" if "bytes" in ccols else None)
+            query = "select %s, start, end%s from %s" % (label[0] if label else "'copy'", (", " + size) if size else "", table)
+            for r in cur.execute(query).fetchall():
+                rows.append(("copy %s %s" % (r[0], r[3] if size else ""), r[1], r[2]))
+            break
+    rows.sort(key=lambda r: r[1])
     t_last = max(r[2] for r in rows)
     if len(sys.argv) > 3:
         anchored = [r[2] for r in rows if sys.argv[3] in r[0]]
