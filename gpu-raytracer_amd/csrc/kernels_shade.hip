@@ -59,7 +59,9 @@ RT_DEV HitInfo unpack_hit(uint4 h) { // Buffers.h:34-48
 // which random_sample undoes).
 RT_DEV void camera_generate_ray(const RtParams & p, int pixel_index, int sample_index, int x, int y, f3 & origin, f3 & direction, int taa_index) {
 	f2 rand_filter   = random_sample(p, DIM_FILTER,   unsigned(pixel_index), 0, unsigned(sample_index));
-	f2 rand_aperture = random_sample(p, DIM_APERTURE, unsigned(pixel_index), 0, unsigned(sample_index));
+	// (a pinhole camera -- aperture radius 0, uniform over the launch -- multiplies its lens sample by zero: the draw and the disk mapping are skipped, the ray is the same)
+	const bool thin_lens = p.camera.aperture_radius != 0.0f;
+	f2 rand_aperture = thin_lens ? random_sample(p, DIM_APERTURE, unsigned(pixel_index), 0, unsigned(sample_index)) : mk2(0.0f, 0.0f);
 
 	f2 jitter;
 	if (p.config.enable_svgf) {
@@ -85,7 +87,7 @@ RT_DEV void camera_generate_ray(const RtParams & p, int pixel_index, int sample_
 	f3 ya  = mk3(p.camera.y_axis[0], p.camera.y_axis[1], p.camera.y_axis[2]);
 
 	f3 focal_point = p.camera.focal_distance * normalize(blc + x_jittered * xa + y_jittered * ya);
-	f2 lens_point  = p.camera.aperture_radius * sample_disk(rand_aperture.x, rand_aperture.y);
+	f2 lens_point  = thin_lens ? p.camera.aperture_radius * sample_disk(rand_aperture.x, rand_aperture.y) : mk2(0.0f, 0.0f);
 
 	f3 offset = xa * lens_point.x + ya * lens_point.y;
 	direction = normalize(focal_point - offset);
